@@ -1,0 +1,242 @@
+"""Pin the CPU oracle (oracle/arb_oracle.py) against the reference's goldens.
+
+Fixtures under tests/golden/ were produced by tools/gen_golden.py by running the
+reference itself; they also hold the raw payload of the reference's own golden
+HDF5 files and the known answers printed in its unit tests.
+"""
+import numpy as np
+import pytest
+
+import arb_oracle as O
+from conftest import load_golden, load_model
+
+TOL = 1e-11
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.max(np.abs(a - b) / np.maximum(1., np.abs(b))) if a.size else 0.
+    assert err <= tol, err
+
+
+# -- G0 primitives ----------------------------------------------------------
+def test_se3_primitives():
+    g = load_golden("g0_primitives.npz")
+    close(O.hinv(g["H"]), g["H_inv"])
+    close(O.adjoint(g["H"]), g["H_adjoint"])
+    close(O.iadjoint(g["H"]), g["H_iadjoint"])
+    close(O.adjacency(g["tw"]), g["tw_adjacency"])
+    close(O.exp_twist(g["tw"]), g["tw_exp"])
+    for v, H in zip(g["zvec"], g["zaligned"]):
+        close(O.zaligned(v), H)
+
+
+@pytest.mark.parametrize("tid", range(9))
+def test_joint_types(tid):
+    g = load_golden("g0_primitives.npz")
+    q, dq = g["joint%d_q" % tid], g["joint%d_dq" % tid]
+    H, J, dJ = O.joint_kinematics(tid, q, dq)
+    close(H, g["joint%d_pose" % tid])
+    close(J, g["joint%d_jac" % tid])
+    close(dJ, g["joint%d_djac" % tid])
+    close(O.joint_ipose(tid, q, H), g["joint%d_ipose" % tid])
+    T = dq if tid == 0 else (J @ dq[..., None])[..., 0]
+    close(T, g["joint%d_twist" % tid])
+    Ad_nr = O.adjoint(O.joint_ipose(tid, q, H))
+    idad = Ad_nr @ O.adjacency(-(Ad_nr @ T[..., None])[..., 0])
+    close(idad, g["joint%d_idadjoint" % tid])
+
+
+def test_plane_sphere_collision():
+    g = load_golden("g0_primitives.npz")
+    sd, H0, H1 = O._plane_sphere_collision(np.eye(4), g["ps_coeffs"], g["ps_points"], 0.1)
+    close(sd, g["ps_sdist"]); close(H0, g["ps_Hgc0"]); close(H1, g["ps_Hgc1"])
+    # collisions.py:176-191 doctest
+    assert abs(sd[0] - 8.9) < 1e-12
+
+
+# -- G1 simplearm -----------------------------------------------------------
+def test_simplearm_update_dynamic_known_answers():
+    g = load_golden("g1_simplearm.npz")
+    m, _, _ = load_model("simplearm")
+    d = O.update_dynamic(m, g["ud_q"][None], g["ud_dq"][None])
+    close(d["pose"][0], g["ud_pose"]); close(d["jac"][0], g["ud_jac"])
+    close(d["djac"][0], g["ud_djac"]); close(d["twist"][0], g["ud_twist"])
+    close(d["nle"][0], g["ud_nle"])
+    close(d["M"][0], g["ud_M"]); close(d["Bv"][0], g["ud_B"]); close(d["N"][0], g["ud_N"])
+    # literals of tests/test_update_dynamic.py:117-120 and :195-198 (7 places)
+    assert np.abs(d["M"][0] - g["ud_M_known"]).max() < 5e-8
+    assert np.abs(d["N"][0] - g["ud_N_known"]).max() < 5e-8
+
+
+def test_simplearm_pd_doctest():
+    g = load_golden("g1_simplearm.npz")
+    m, q, dq = load_model("simplearm_pd")
+    dyn = O.update_dynamic(m, q[None], dq[None])
+    gf, Z, Y = O.update_controllers(m, dyn, q[None], dq[None], 0.001)
+    close(Z[0], g["pd_impedance"]); close(Y[0], g["pd_admittance"], 1e-10)
+    assert np.abs(Z[0] - g["pd_impedance_known"]).max() < 5e-8      # core.py:754-757
+    assert np.abs(Y[0] - g["pd_admittance_known"]).max() < 5e-8     # core.py:758-761
+
+
+def test_simplearm_trajectory_matches_reference_h5():
+    """Config 1: 99 steps of dt=0.01 under gravity; body poses must equal the
+    payload of the reference's tests/simplearm_flat.h5 / simplearm_notflat.h5."""
+    g = load_golden("g1_simplearm.npz")
+    m, q0, dq0 = load_model("simplearm_g")
+    tl = g["traj_timeline"]
+    assert np.array_equal(tl[:99], g["h5_flat_timeline"])
+    q, dq = q0[None], dq0[None]
+    t = tl[0]
+    poses, jposes = [], []
+    for k, tn in enumerate(tl[1:]):
+        dt = tn - t
+        close(q[0], g["traj_q"][k]); close(dq[0], g["traj_dq"][k], 1e-10)
+        dyn = O.update_dynamic(m, q, dq)
+        poses.append(dyn["pose"][0]); jposes.append(dyn["jpose"][0])
+        q, dq, _ = O.step(m, q, dq, dt)
+        t += dt
+    close(q[0], g["traj_q_final"], 1e-10)
+    poses = np.array(poses)            # (99, 3: Arm Forearm Hand, 4, 4)
+    jposes = np.array(jposes)
+    order = [2, 0, 1]                  # h5 datasets are stored Hand, Arm, Forearm
+    h5 = g["h5_flat_HandArmForearm"]
+    assert np.abs(poses[:, order].transpose(1, 0, 2, 3) - h5).max() < 1e-12
+    h5n = g["h5_notflat_HandArmForearm"]
+    assert np.abs(jposes[:, order].transpose(1, 0, 2, 3) - h5n).max() < 1e-12
+
+
+# -- G2 human36 -------------------------------------------------------------
+def test_human36_mass_known_diagonal():
+    g = load_golden("g2_human36.npz")
+    m, q0, dq0 = load_model("human36_g")
+    assert (m.ndof, m.nb, m.nq) == (42, 17, 52)
+    assert list(m.dof_off) == [0, 6, 9, 10, 12, 15, 16, 18, 21, 23, 26, 28, 30, 32, 35, 37, 39]
+    d = O.update_dynamic(m, q0[None], dq0[None])
+    M = d["M"][0]
+    close(M, g["mass_q0"])
+    for i, v in zip(g["mass_diag_idx"], g["mass_diag_known"]):     # tests/test_human36.rst:93-113
+        assert abs(M[i, i] - v) <= 1e-12 * max(1, abs(v))
+
+
+def test_human36_random_steps():
+    g = load_golden("g2_human36.npz")
+    m, _, _ = load_model("human36_g")
+    for dt in (5e-3, 1e-3):
+        sel = g["dt"] == dt
+        qn, dqn, _, d = O.step(m, g["q"][sel], g["dq"][sel], dt, debug=True)
+        close(qn, g["q_next"][sel], 1e-10); close(dqn, g["dq_next"][sel], 1e-9)
+    q4, dq4 = g["q"][:4], g["dq"][:4]
+    for i in range(4):
+        qn, dqn, _, d = O.step(m, q4[i:i + 1], dq4[i:i + 1], float(g["dt"][i]), debug=True)
+        close(d["M"][0], g["M"][i]); close(d["N"][0], g["N"][i])
+        close(d["Z"][0], g["Z"][i]); close(d["gforce0"][0], g["gforce"][i], 1e-10)
+    q, dq, _ = O.rollout(m, g["roll32_q0"], g["roll32_dq0"], [5e-3] * 32)
+    close(q, g["roll32_q"], 1e-8); close(dq, g["roll32_dq"], 1e-7)
+
+
+# -- G3 contacts -------------------------------------------------------------
+@pytest.mark.parametrize("nc", [8, 4])
+def test_human36_drop_scenario(nc):
+    g = load_golden("g3_contacts.npz")
+    m, _, _ = load_model("human36_c%d" % nc)
+    assert m.nc == nc
+    Q, DQ = g["drop%d_q" % nc], g["drop%d_dq" % nc]
+    # step-by-step from the reference's own states (no error accumulation)
+    qn, dqn, cf, d = O.step(m, Q[:39], DQ[:39], 5e-3, debug=True)
+    close(qn, Q[1:], 1e-9); close(dqn, DQ[1:], 1e-8)
+    assert np.array_equal(d["active"], g["drop%d_active" % nc])
+    close(d["sdist"], g["drop%d_sdist" % nc], 1e-10)
+    close(cf, g["drop%d_force" % nc], 1e-7)
+    # and as a 39-step rollout from the initial state
+    q, dq, _ = O.rollout(m, Q[:1], DQ[:1], [5e-3] * 39)
+    close(q[0], Q[39], 1e-8); close(dq[0], DQ[39], 1e-7)
+    # tests/test_human36_falling.py:44-46: contact points end above the floor
+    assert (g["drop%d_contact_height" % nc] >= 0).all()
+
+
+@pytest.mark.parametrize("nc", [8, 4])
+def test_human36_random_contact_steps(nc):
+    g = load_golden("g3_contacts.npz")
+    m, _, _ = load_model("human36_c%d" % nc)
+    qn, dqn, cf, d = O.step(m, g["rand%d_q" % nc], g["rand%d_dq" % nc], 5e-3, debug=True)
+    close(qn, g["rand%d_q_next" % nc], 1e-9); close(dqn, g["rand%d_dq_next" % nc], 1e-8)
+    close(cf, g["rand%d_force" % nc], 1e-7)
+    assert d["branch_count"][2] > 0         # the sliding branch is exercised
+
+
+@pytest.mark.parametrize("branch,code", [("release", 0), ("static", 1), ("sliding", 2)])
+def test_softfinger_solve_captured(branch, code):
+    g = load_golden("g3_contacts.npz")
+    n = len(g["solve_%s_dt" % branch])
+    assert n > 10
+    for i in range(n):
+        df, newf, br = O._softfinger_solve_one(
+            g["solve_%s_vel" % branch][i], g["solve_%s_adm" % branch][i],
+            g["solve_%s_force" % branch][i].copy(), g["solve_%s_sdist" % branch][i],
+            g["solve_%s_mu" % branch][i], np.ones(3), g["solve_%s_dt" % branch][i])
+        assert br == code
+        close(df, g["solve_%s_dforce" % branch][i], 1e-9)
+        close(newf, g["solve_%s_newforce" % branch][i], 1e-9)
+
+
+# -- G4 snake-64 --------------------------------------------------------------
+def test_snake64():
+    g = load_golden("g4_snake64.npz")
+    m, _, _ = load_model("snake64_g")
+    assert m.ndof == 64
+    dt = float(g["dt"])
+    qn, dqn, _, d = O.step(m, g["q"], g["dq"], dt, debug=True)
+    close(qn, g["q_next"], 1e-9); close(dqn, g["dq_next"], 1e-7)
+    close(d["Z"][0], g["Z0"], 1e-10)
+    q, dq, _ = O.rollout(m, g["q"][:2], g["dq"][:2], [dt] * 10)
+    close(q, g["roll10_q"], 1e-8); close(dq, g["roll10_dq"], 1e-6)
+
+
+# -- G5 energy drift ----------------------------------------------------------
+def test_energy_drift_h5():
+    """tests/test_energy_drift.py: kinetic energy series of the 9-link free snake;
+    reproduces tests/energy_drift.h5 once the frozen-hinge quirk is emulated."""
+    g = load_golden("g5_energy.npz")
+    m, q0, dq0 = load_model("snake9_free_g")
+    q, dq = q0[None].copy(), dq0[None].copy()
+    tl = g["timeline"]
+    t = tl[0]
+    ke = []
+    frozen = g["frozen_bodies"]
+    for tn in tl[1:]:
+        dt = tn - t
+        dyn = O.update_dynamic(m, q, dq)
+        ke.append(0.5 * dq[0] @ dyn["M"][0] @ dq[0])
+        q, dq, _ = O.step(m, q, dq, dt)
+        for b in frozen:
+            q[0, m.q_off[b]] = 0.
+        t += dt
+    ke = np.array(ke)
+    assert np.max(np.abs(ke / g["ke_quirk"] - 1)) < 1e-9
+    assert np.max(np.abs(ke / g["h5_kinetic_energy"] - 1)) < 1e-7   # 7 places, as the reference test
+
+
+# -- G6 constraints ------------------------------------------------------------
+def test_ball_and_socket():
+    g = load_golden("g6_constraints.npz")
+    m, q0, dq0 = load_model("ballsocket")
+    q, dq, cf = q0[None], dq0[None], None
+    for k in range(5):
+        close(q[0], g["bs_q"][k], 1e-10)
+        q, dq, cf = O.step(m, q, dq, 0.001, cf)
+        close(cf[0, 0, :3], g["bs_force"][k], 1e-8)
+        if k == 0:
+            assert np.abs(cf[0, 0, :3] - g["bs_force_known"]).max() < 1e-7   # test_constraints.py:53
+    close(q[0], g["bs_q"][5], 1e-10)
+
+
+@pytest.mark.parametrize("tag", ["max", "min"])
+def test_joint_limits(tag):
+    g = load_golden("g6_constraints.npz")
+    m, q0, dq0 = load_model("jointlimits_%s" % tag)
+    q, dq, _, Q, DQ = O.rollout(m, q0[None], dq0[None], [1e-3] * 99, record=True)
+    close(Q[:, 0], g["jl_%s_q" % tag][:99], 1e-9)
+    close(q[0], g["jl_%s_q" % tag][99], 1e-9)
+    assert abs(q[0, 0]) <= 3.14 / 2                       # tests/test_constraints.py:22-32

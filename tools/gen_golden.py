@@ -1,0 +1,491 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures of tests/golden/ by running the REFERENCE.
+
+Runs only in the build container (needs /root/reference, imported through
+tools/refload.py).  Only numbers are written: flattened models, inputs and the
+reference's outputs.  The oracle (oracle/arb_oracle.py) and the HIP library are
+both checked against these files; nothing here is imported by the product.
+
+Usage:  python tools/gen_golden.py            (rewrites tests/golden/*.npz)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refload  # noqa: E402
+
+arboris = refload.load()
+from arboris.core import World, Body, simulate  # noqa: E402
+from arboris.robots.human36 import add_human36  # noqa: E402
+from arboris.robots.simpleshapes import add_groundplane  # noqa: E402
+from arboris.robots.simplearm import add_simplearm  # noqa: E402
+from arboris.robots.snake import add_snake  # noqa: E402
+from arboris.controllers import WeightController, ProportionalDerivativeController  # noqa: E402
+from arboris.constraints import (get_all_contacts, JointLimits,  # noqa: E402
+                                 BallAndSocketConstraint, SoftFingerContact)
+from arboris.joints import *  # noqa: E402,F401,F403
+import arboris.joints as RJ  # noqa: E402
+import arboris.homogeneousmatrix as Hg  # noqa: E402
+import arboris.twistvector as TW  # noqa: E402
+import arboris.collisions as COL  # noqa: E402
+
+from arboris_python_amd.flatten import flatten_world, JT_FREE  # noqa: E402
+from arboris_python_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+FOUR = ('Right foot toe tip', 'Right foot heel', 'Left foot toe tip', 'Left foot heel')
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %-28s %8.1f KiB" % (name, os.path.getsize(path) / 1024.))
+
+
+def save_model(name, world):
+    m, q, dq = flatten_world(world)
+    d = m.to_npz_dict()
+    d["q0"] = q
+    d["dq0"] = dq
+    save("model_%s.npz" % name, **d)
+    return m
+
+
+# ---- driving the reference at a given flat state ---------------------------
+def set_state(world, m, q, dq):
+    joints = list(world.iterjoints())
+    for b, j in enumerate(joints):
+        qs = slice(int(m.q_off[b]), int(m.q_off[b] + m.jnq[b]))
+        if m.jtype[b] == JT_FREE:
+            j.gpos = q[qs].reshape(4, 4).copy()
+        else:
+            j.gpos[:] = q[qs]
+    world._gvel[:] = dq
+
+
+def get_state(world, m):
+    q = np.concatenate([np.asarray(j.gpos, float).ravel() for j in world.iterjoints()])
+    return q, world._gvel.copy()
+
+
+def ref_step(world, dt):
+    world.update_dynamic()
+    world.update_controllers(dt)
+    world.update_constraints(dt)
+    world.integrate(dt)
+
+
+def human36_ref(contacts=0):
+    w = World()
+    if contacts:
+        add_groundplane(w)
+    add_human36(w)
+    w.register(WeightController())
+    if contacts:
+        for c in get_all_contacts(w, friction_coeff=.6):
+            if contacts == 8 or c._shapes[1].name in FOUR:
+                w.register(c)
+    w.init()
+    return w
+
+
+# ---- G0: primitives --------------------------------------------------------
+def gen_primitives():
+    rng = np.random.default_rng(100)
+    out = {}
+    H = []
+    for _ in range(8):
+        H.append(Hg.transl(*rng.uniform(-2, 2, 3)) @ Hg.rotzyx(*rng.uniform(-3, 3, 3)))
+    H = np.array(H)
+    out["H"] = H
+    out["H_inv"] = np.array([Hg.inv(h) for h in H])
+    out["H_adjoint"] = np.array([Hg.adjoint(h) for h in H])
+    out["H_iadjoint"] = np.array([Hg.iadjoint(h) for h in H])
+    tw = rng.uniform(-3, 3, (8, 6))
+    tw[6, 0:3] *= 1e-4          # below the 1e-3 series switch
+    tw[7, 0:3] = 0.
+    out["tw"] = tw
+    out["tw_adjacency"] = np.array([TW.adjacency(t) for t in tw])
+    out["tw_exp"] = np.array([TW.exp(t) for t in tw])
+    vecs = [(1., 0., 0.), (0., 1., 0.), (0., 0., 1.), (0., -1., 0.)]
+    for _ in range(6):
+        v = rng.normal(size=3)
+        vecs.append(tuple(v / np.linalg.norm(v)))
+    out["zvec"] = np.array(vecs)
+    out["zaligned"] = np.array([Hg.zaligned(np.array(v)) for v in vecs])
+    # every joint type at random (q, dq)
+    classes = ["FreeJoint", "RzRyRxJoint", "RzRyJoint", "RzRxJoint", "RyRxJoint",
+               "RzJoint", "RyJoint", "RxJoint", "TxTyTzJoint"]
+    for tid, cname in enumerate(classes):
+        cls = getattr(RJ, cname)
+        qs, dqs, poses, iposes, jacs, djacs, twists, idads = [], [], [], [], [], [], [], []
+        for _ in range(4):
+            if cname == "FreeJoint":
+                q = Hg.transl(*rng.uniform(-1, 1, 3)) @ Hg.rotzyx(*rng.uniform(-3, 3, 3))
+                dq = rng.uniform(-3, 3, 6)
+                j = cls(gpos=q, gvel=dq)
+            else:
+                k = cls().ndof
+                q = rng.uniform(-2, 2, k)
+                dq = rng.uniform(-3, 3, k)
+                j = cls(gpos=q, gvel=dq)
+            qs.append(np.asarray(q).ravel()); dqs.append(dq)
+            poses.append(j.pose); iposes.append(j.ipose); jacs.append(j.jacobian)
+            djacs.append(j.djacobian); twists.append(j.twist); idads.append(j.idadjoint)
+        out["joint%d_q" % tid] = np.array(qs)
+        out["joint%d_dq" % tid] = np.array(dqs)
+        out["joint%d_pose" % tid] = np.array(poses)
+        out["joint%d_ipose" % tid] = np.array(iposes)
+        out["joint%d_jac" % tid] = np.array(jacs)
+        out["joint%d_djac" % tid] = np.array(djacs)
+        out["joint%d_twist" % tid] = np.array(twists)
+        out["joint%d_idadjoint" % tid] = np.array(idads)
+    # plane/sphere collisions (collisions.py:161-205), incl. the doctest case
+    pts = np.vstack(([2., 4., 3.], rng.uniform(-1, 1, (5, 3))))
+    coeffs = np.array([0., 1., 0., -5.])
+    res = [COL._plane_sphere_collision(np.eye(4), coeffs, p, 0.1) for p in pts]
+    out["ps_points"] = pts
+    out["ps_coeffs"] = coeffs
+    out["ps_sdist"] = np.array([r[0] for r in res])
+    out["ps_Hgc0"] = np.array([r[1] for r in res])
+    out["ps_Hgc1"] = np.array([r[2] for r in res])
+    save("g0_primitives.npz", **out)
+
+
+# ---- G1: simplearm ---------------------------------------------------------
+def read_h5_payload(fname):
+    raw = open(os.path.join(refload.REFERENCE_ROOT, "tests", fname), "rb").read()
+    return np.frombuffer(raw[:len(raw) // 8 * 8], "<f8")
+
+
+def gen_simplearm():
+    out = {}
+    w = World()
+    add_simplearm(w)
+    m = save_model("simplearm", w)
+    # tests/test_update_dynamic.py:10-19 state
+    q = np.array([0.5, 1.0, 2.0 / 3.0])
+    dq = np.array([2.5, -1.0, -0.5])
+    set_state(w, m, q, dq)
+    w.update_dynamic()
+    bodies = list(w.ground.iter_descendant_bodies())
+    out["ud_q"], out["ud_dq"] = q, dq
+    out["ud_pose"] = np.array([b.pose for b in bodies])
+    out["ud_jac"] = np.array([b.jacobian for b in bodies])
+    out["ud_djac"] = np.array([b.djacobian for b in bodies])
+    out["ud_twist"] = np.array([b.twist for b in bodies])
+    out["ud_nle"] = np.array([b.nleffects for b in bodies])
+    out["ud_M"], out["ud_B"], out["ud_N"] = w.mass.copy(), w.viscosity.copy(), w.nleffects.copy()
+    # known answers printed in tests/test_update_dynamic.py:117-120, 195-198
+    out["ud_M_known"] = np.array([[0.55132061, 0.1538999, 0.0080032],
+                                  [0.1538999, 0.09002086, 0.00896043],
+                                  [0.0080032, 0.00896043, 0.00267333]])
+    out["ud_N_known"] = np.array([[0.11838112, -0.15894538, -0.01490104],
+                                  [0.27979997, 0.00247348, -0.00494696],
+                                  [0.03230564, 0.00742044, 0.]])
+    # core.py:744-761 doctest: simplearm + PD(kp=2 on Elbow), dt=1e-3
+    w = World()
+    add_simplearm(w)
+    joints = w.getjoints()
+    w.register(ProportionalDerivativeController(joints[1:2], 2.))
+    w.init()
+    save_model("simplearm_pd", w)
+    w.update_dynamic()
+    w.update_controllers(0.001)
+    out["pd_impedance"], out["pd_admittance"] = w._impedance.copy(), w._admittance.copy()
+    out["pd_impedance_known"] = np.array([[686.98833333, 223.44666667, 20.67333333],
+                                          [223.44666667, 93.44866667, 10.67333333],
+                                          [20.67333333, 10.67333333, 2.67333333]])
+    out["pd_admittance_known"] = np.array([[0.00732382, -0.0203006, 0.0244142],
+                                           [-0.0203006, 0.07594182, -0.14621124],
+                                           [0.0244142, -0.14621124, 0.76901683]])
+    # config 1: gravity swing, timeline arange(0,1,.01) -> 99 steps
+    # (tests/test_visu_collada.py:12-27 produced simplearm_*.h5 this way)
+    w = World()
+    w.register(WeightController())
+    add_simplearm(w, with_shapes=True)
+    w.getjoints()['Shoulder'].gpos[0] = 3.14 / 4
+    m = save_model("simplearm_g", w)
+    timeline = np.arange(0, 1, .01)
+    w._current_time = timeline[0]
+    w.init()
+    bodies = list(w.ground.iter_descendant_bodies())
+    names = [b.name for b in bodies]
+    qs, dqs, poses, jposes = [], [], [], []
+    for t_next in timeline[1:]:
+        dt = t_next - w._current_time
+        w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+        q_, dq_ = get_state(w, m)
+        qs.append(q_); dqs.append(dq_)
+        poses.append(np.array([b.pose for b in bodies]))
+        jposes.append(np.array([b.parentjoint.pose for b in bodies]))
+        w.integrate(dt)
+    q_, dq_ = get_state(w, m)
+    out["traj_timeline"] = timeline
+    out["traj_q"], out["traj_dq"] = np.array(qs), np.array(dqs)
+    out["traj_q_final"], out["traj_dq_final"] = q_, dq_
+    out["traj_pose"] = np.array(poses)          # (99, 3, 4, 4) Arm, Forearm, Hand
+    out["traj_jpose"] = np.array(jposes)
+    out["traj_body_names"] = np.array(names)
+    # raw float64 payload of the reference's golden HDF5 files:
+    for flat in ("flat", "notflat"):
+        a = read_h5_payload("simplearm_%s.h5" % flat)
+        out["h5_%s_timeline" % flat] = a[406:505].copy()
+        out["h5_%s_HandArmForearm" % flat] = a[505:505 + 3 * 99 * 16].reshape(3, 99, 4, 4).copy()
+    save("g1_simplearm.npz", **out)
+
+
+# ---- G2: human36 without contacts -------------------------------------------
+def gen_human36():
+    out = {}
+    w = human36_ref(0)
+    m = save_model("human36_g", w)
+    # tests/test_human36.rst:93-113 known diagonal entries at q = 0
+    w.update_dynamic()
+    out["mass_diag_idx"] = np.array([5, 41, 40, 39, 16, 17, 10, 11])
+    out["mass_diag_known"] = np.array([73.000000000000014, 0.10208399155688053,
+                                       0.020356790291165189, 0.10430013572386694,
+                                       0.0093741757009949949, 0.001397215796713388,
+                                       0.0093741757009949949, 0.001397215796713388])
+    out["mass_q0"] = w.mass.copy()
+    B = 32
+    q, dq = synth.random_states(m, B, seed=0)
+    dts = np.where(np.arange(B) % 2 == 0, 5e-3, 1e-3)
+    qn, dqn, Ms, Ns, Zs, gfs = [], [], [], [], [], []
+    for i in range(B):
+        set_state(w, m, q[i], dq[i])
+        w.update_dynamic(); w.update_controllers(dts[i])
+        if i < 4:
+            Ms.append(w.mass.copy()); Ns.append(w.nleffects.copy())
+            Zs.append(w._impedance.copy()); gfs.append(w._gforce.copy())
+        w.update_constraints(dts[i]); w.integrate(dts[i])
+        a, b = get_state(w, m)
+        qn.append(a); dqn.append(b)
+    out.update(q=q, dq=dq, dt=dts, q_next=np.array(qn), dq_next=np.array(dqn),
+               M=np.array(Ms), N=np.array(Ns), Z=np.array(Zs), gforce=np.array(gfs))
+    # 32-step rollouts of 4 states, dt = 5e-3 (milder velocities: with U(-3,3)
+    # the free-flying humanoid diverges within 32 steps and parity is moot)
+    q, dq = synth.random_states(m, 4, seed=1, vel=0.5)
+    out["roll32_q0"], out["roll32_dq0"] = q, dq
+    rq, rdq = [], []
+    for i in range(4):
+        set_state(w, m, q[i], dq[i])
+        for _ in range(32):
+            ref_step(w, 5e-3)
+        a, b = get_state(w, m)
+        rq.append(a); rdq.append(b)
+    out["roll32_q"], out["roll32_dq"] = np.array(rq), np.array(rdq)
+    save("g2_human36.npz", **out)
+
+
+# ---- G3: human36 with floor contacts ------------------------------------------
+def gen_contacts():
+    out = {}
+    captured = []
+    orig_solve = SoftFingerContact.solve
+
+    def spy(self, vel, admittance, dt):
+        f0 = self._force.copy()
+        df = orig_solve(self, vel, admittance, dt)
+        captured.append((vel.copy(), admittance.copy(), f0, float(self._sdist), float(dt),
+                         float(self._mu), np.array(df).copy(), self._force.copy()))
+        return df
+    SoftFingerContact.solve = spy
+    for nc in (8, 4):
+        w = human36_ref(nc)
+        m = save_model("human36_c%d" % nc, w)
+        # the reference's drop scenario (tests/test_human36_falling.py:10-45)
+        root = w.ground.childrenjoints[0]
+        root.gpos = np.dot(Hg.transl(0, 0.03, 0), root.gpos)
+        dt = 5e-3
+        qs, dqs, act, sd, frc = [], [], [], [], []
+        cons = list(w._constraints)
+        for step in range(39):
+            a, b = get_state(w, m)
+            qs.append(a); dqs.append(b)
+            w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+            act.append([bool(c.is_active()) for c in cons])
+            sd.append([c._sdist for c in cons])
+            frc.append([c._force.copy() for c in cons])
+            w.integrate(dt)
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        out["drop%d_q" % nc] = np.array(qs)        # (40, nq): state before each step + final
+        out["drop%d_dq" % nc] = np.array(dqs)
+        out["drop%d_active" % nc] = np.array(act)
+        out["drop%d_sdist" % nc] = np.array(sd)
+        out["drop%d_force" % nc] = np.array(frc)
+        out["drop%d_contact_height" % nc] = np.array(
+            [(c._frames[1].pose[1, 3]) for c in cons])
+        # random near-ground single steps: config-3 distribution with larger velocities
+        B = 16
+        q, dq = synth.standing_states(m, B, seed=3, drop=0.03, vel=0.5)
+        # give half of them a tangential push so that sliding occurs
+        dq[::2, 3] += 1.0
+        q[:, 7] -= 0.035       # root y (4x4 entry [1,3]) so that feet are at/below the floor
+        qn, dqn, fs = [], [], []
+        for i in range(B):
+            set_state(w, m, q[i], dq[i])
+            ref_step(w, dt)
+            a, b = get_state(w, m)
+            qn.append(a); dqn.append(b)
+            fs.append([c._force.copy() for c in cons])
+        out["rand%d_q" % nc], out["rand%d_dq" % nc] = q, dq
+        out["rand%d_q_next" % nc], out["rand%d_dq_next" % nc] = np.array(qn), np.array(dqn)
+        out["rand%d_force" % nc] = np.array(fs)
+    SoftFingerContact.solve = orig_solve
+    # captured solve() tuples: keep up to 80 per branch
+    rel, sta, sli = [], [], []
+    for t in captured:
+        (vel, adm, f0, sdist, dt, mu, df, f1) = t
+        v0 = vel - adm @ f0
+        if sdist + dt * v0[3] > 0:
+            rel.append(t)
+        elif np.allclose(df, -np.linalg.pinv(adm) @ np.hstack((vel[0:3], vel[3] + sdist / dt))):
+            sta.append(t)
+        else:
+            sli.append(t)
+    print("captured solves: release %d static %d sliding %d" % (len(rel), len(sta), len(sli)))
+    rng = np.random.default_rng(5)
+    for name, lst in (("release", rel), ("static", sta), ("sliding", sli)):
+        if len(lst) > 80:
+            idx = np.sort(rng.choice(len(lst), 80, replace=False))
+            lst = [lst[i] for i in idx]
+        out["solve_%s_vel" % name] = np.array([t[0] for t in lst])
+        out["solve_%s_adm" % name] = np.array([t[1] for t in lst])
+        out["solve_%s_force" % name] = np.array([t[2] for t in lst])
+        out["solve_%s_sdist" % name] = np.array([t[3] for t in lst])
+        out["solve_%s_dt" % name] = np.array([t[4] for t in lst])
+        out["solve_%s_mu" % name] = np.array([t[5] for t in lst])
+        out["solve_%s_dforce" % name] = np.array([t[6] for t in lst])
+        out["solve_%s_newforce" % name] = np.array([t[7] for t in lst])
+    save("g3_contacts.npz", **out)
+
+
+# ---- G4: snake-64 -----------------------------------------------------------
+def gen_snake():
+    out = {}
+    w = World()
+    add_snake(w, 64)
+    w.register(WeightController())
+    w.init()
+    m = save_model("snake64_g", w)
+    B = 8
+    q, dq = synth.random_states(m, B, seed=4, angle=0.5, vel=1.0)
+    dt = 1e-3
+    qn, dqn = [], []
+    for i in range(B):
+        set_state(w, m, q[i], dq[i])
+        ref_step(w, dt)
+        a, b = get_state(w, m)
+        qn.append(a); dqn.append(b)
+    out.update(q=q, dq=dq, dt=np.array(dt), q_next=np.array(qn), dq_next=np.array(dqn))
+    set_state(w, m, q[0], dq[0])
+    w.update_dynamic(); w.update_controllers(dt)
+    out["Z0"] = w._impedance.copy()
+    rq, rdq = [], []
+    for i in range(2):
+        set_state(w, m, q[i], dq[i])
+        for _ in range(10):
+            ref_step(w, dt)
+        a, b = get_state(w, m)
+        rq.append(a); rdq.append(b)
+    out["roll10_q"], out["roll10_dq"] = np.array(rq), np.array(rdq)
+    save("g4_snake64.npz", **out)
+
+
+# ---- G5: energy drift (tests/test_energy_drift.py + energy_drift.h5) -----------
+def gen_energy():
+    out = {}
+    a = read_h5_payload("energy_drift.h5")
+    out["h5_kinetic_energy"] = a[-415:].copy()
+    njoints = 9
+    lengths = [1., .9, .8, .7, .6, .5, .4, .3, .2]
+    masses = [1., .9, .8, .7, .6, .5, .4, .3, .2]
+    gpos = [0., 3.14159 / 4., 0., 0., 0., 0., 0., 0., 0.]
+    gvel = [2.] * njoints
+    w = World()
+    add_snake(w, njoints, lengths=lengths, masses=masses, gpos=gpos, gvel=gvel, is_fixed=False)
+    w.register(WeightController())
+    w.init()
+    m = save_model("snake9_free_g", w)
+    # emulate the integer-gpos truncation of 2010-era NumPy: the
+    # joints built with an int gpos (all hinges but #1) never move.
+    frozen = [b for b in range(m.nb) if m.jtype[b] != JT_FREE and b != 2]
+    timeline = np.arange(0, 2.08, 0.005)
+    ke = []
+    joints = list(w.iterjoints())
+    for t_next in timeline[1:]:
+        dt = t_next - w._current_time
+        w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+        ke.append(0.5 * w._gvel @ w.mass @ w._gvel)
+        w.integrate(dt)
+        for b in frozen:
+            joints[b].gpos[:] = 0.
+    out["ke_quirk"] = np.array(ke)
+    out["frozen_bodies"] = np.array(frozen)
+    out["timeline"] = timeline
+    print("energy drift: max rel err vs h5 payload = %.3e"
+          % np.max(np.abs(out["ke_quirk"] / out["h5_kinetic_energy"] - 1)))
+    save("g5_energy.npz", **out)
+
+
+# ---- G6: BallAndSocket / JointLimits (tests/test_constraints.py) ----------------
+def gen_constraints():
+    out = {}
+    b0 = Body(mass=np.eye(6))
+    w = World()
+    w.add_link(w.ground, FreeJoint(), b0)
+    w.init()
+    w.register(WeightController())
+    c0 = BallAndSocketConstraint(frames=(w.ground, b0))
+    w.register(c0)
+    w.init()
+    m = save_model("ballsocket", w)
+    dt = 0.001
+    fr, qs, dqs = [], [], []
+    for _ in range(5):
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+        fr.append(c0._force.copy())
+        w.integrate(dt)
+    a, b = get_state(w, m)
+    qs.append(a); dqs.append(b)
+    out["bs_force"] = np.array(fr)
+    out["bs_q"], out["bs_dq"] = np.array(qs), np.array(dqs)
+    out["bs_force_known"] = np.array([0., 9.81, 0.])          # tests/test_constraints.py:53
+    # a ball-and-socket pendulum: arm hand pinned to the ground point where it starts
+    for sign, tag in ((1., "max"), (-1., "min")):
+        w = World()
+        add_simplearm(w)
+        w.register(WeightController())
+        sh = w.getjoints()['Shoulder']
+        w.register(JointLimits(sh, -3.14 / 2, 3.14 / 2))
+        sh.gpos[0] = sign * (3.14 / 2 - 0.1)
+        w.init()
+        m = save_model("jointlimits_%s" % tag, w)
+        qs, dqs = [], []
+        for _ in range(99):
+            a, b = get_state(w, m)
+            qs.append(a); dqs.append(b)
+            ref_step(w, 1e-3)
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        out["jl_%s_q" % tag], out["jl_%s_dq" % tag] = np.array(qs), np.array(dqs)
+    save("g6_constraints.npz", **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6"]
+    table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints)
+    for k in which:
+        table[k]()
