@@ -1,0 +1,165 @@
+"""ctypes binding of libarbstep.so (the C ABI declared in include/arbstep.h).
+
+The library is the product: there is no Python/NumPy fallback for the step.
+``load()`` raises ``RuntimeError`` with build instructions when the shared
+object is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarbstep.so")
+
+ARB_ABI_VERSION = 1
+ARB_OK = 0
+ARB_F32, ARB_F64 = 0, 1
+ARB_MAXDOL = 4
+ARB_STEP_SKIP_CONSTRAINTS = 1
+
+_PD = C.POINTER(C.c_double)
+_PI = C.POINTER(C.c_int32)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("nb", C.c_int32), ("ndof", C.c_int32), ("nq", C.c_int32), ("nc", C.c_int32),
+        ("parent", _PI), ("jtype", _PI), ("dof_off", _PI), ("q_off", _PI),
+        ("H_pr", _PD), ("H_cn", _PD), ("mass", _PD), ("visc", _PD),
+        ("weighted", _PI),
+        ("gravity", C.c_double * 3),
+        ("pd_kp", _PD), ("pd_kd", _PD), ("pd_tau0", _PD),
+        ("ctype", _PI), ("c_enabled", _PI), ("c_body", _PI), ("c_body0", _PI), ("c_dof", _PI),
+        ("c_local", _PD), ("c_radius", _PD), ("c_plane_Hinv", _PD), ("c_plane", _PD),
+        ("c_mu", _PD), ("c_prox", _PD), ("c_eps", _PD), ("c_min", _PD), ("c_max", _PD),
+        ("c_bpose0", _PD), ("c_bpose1", _PD),
+    ]
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [("nb", C.c_int32), ("ndof", C.c_int32), ("nq", C.c_int32), ("nc", C.c_int32),
+                ("nmax", C.c_int32), ("ncols", C.c_int32), ("nsets", C.c_int32),
+                ("lds_bytes_f32", C.c_int32), ("lds_bytes_f64", C.c_int32), ("device", C.c_int32)]
+
+
+INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
+                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next"]
+
+
+class InspectOut(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in INSPECT_FIELDS]
+
+
+# every symbol include/arbstep.h declares (tests check they are all exported)
+EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
+            "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_inspect"]
+# host-side self-test hooks (device math compiled for the CPU)
+TEST_HOOKS = ["arb_host_softfinger_solve", "arb_host_eig6", "arb_host_joint_local",
+              "arb_host_exp_twist"]
+
+_lib = None
+
+
+def load():
+    """Load libarbstep.so once; raise RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libarbstep.so is not built (%s missing). Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C arboris_python_amd/csrc`. "
+            "There is no CPU fallback for the step." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.arb_abi_version.restype = C.c_int
+    lib.arb_strerror.restype = C.c_char_p
+    lib.arb_strerror.argtypes = [C.c_int]
+    lib.arb_last_hip_error.restype = C.c_char_p
+    lib.arb_model_create.restype = C.c_int
+    lib.arb_model_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(C.c_void_p)]
+    lib.arb_model_destroy.restype = C.c_int
+    lib.arb_model_destroy.argtypes = [C.c_void_p]
+    lib.arb_model_get_info.restype = C.c_int
+    lib.arb_model_get_info.argtypes = [C.c_void_p, C.POINTER(ModelInfo)]
+    lib.arb_step.restype = C.c_int
+    lib.arb_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_int64, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
+    lib.arb_inspect.restype = C.c_int
+    lib.arb_inspect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_double, C.c_uint32, C.POINTER(InspectOut), C.c_void_p]
+    lib.arb_host_softfinger_solve.restype = C.c_int
+    lib.arb_host_softfinger_solve.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double,
+                                              C.c_double, _PD, _PD]
+    lib.arb_host_eig6.restype = C.c_int
+    lib.arb_host_eig6.argtypes = [_PD, _PD, _PD]
+    lib.arb_host_joint_local.restype = C.c_int
+    lib.arb_host_joint_local.argtypes = [C.c_int, _PD, _PD, _PD]
+    lib.arb_host_exp_twist.restype = C.c_int
+    lib.arb_host_exp_twist.argtypes = [_PD, _PD]
+    if lib.arb_abi_version() != ARB_ABI_VERSION:
+        raise RuntimeError("libarbstep.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class ArbError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != ARB_OK:
+        lib = load()
+        msg = lib.arb_strerror(status).decode()
+        if status == 3:
+            msg += ": " + lib.arb_last_hip_error().decode()
+        raise ArbError("libarbstep: %s (status %d)" % (msg, status))
+
+
+def _dp(a):
+    return a.ctypes.data_as(_PD)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_PI)
+
+
+def make_desc(m):
+    """Fill an ``arb_model_desc`` from a ``flatten.FlatModel``.  Returns
+    ``(desc, keepalive)``; ``keepalive`` owns the host arrays the desc points to."""
+    keep = []
+
+    def f64(x, shape=None):
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+        if shape is not None:
+            a = a.reshape(shape)
+        keep.append(a)
+        return _dp(a)
+
+    def i32(x):
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+        keep.append(a)
+        return _ip(a)
+
+    d = ModelDesc()
+    d.abi_version = ARB_ABI_VERSION
+    d.nb, d.ndof, d.nq, d.nc = int(m.nb), int(m.ndof), int(m.nq), int(m.nc)
+    d.parent, d.jtype = i32(m.parent), i32(m.jtype)
+    d.dof_off, d.q_off = i32(m.dof_off), i32(m.q_off)
+    d.H_pr, d.H_cn = f64(m.H_pr), f64(m.H_cn)
+    d.mass, d.visc = f64(m.mass), f64(m.visc)
+    d.weighted = i32(m.weighted)
+    for i in range(3):
+        d.gravity[i] = float(m.gravity[i])
+    if m.has_pd:
+        d.pd_kp, d.pd_kd, d.pd_tau0 = f64(m.pd_kp), f64(m.pd_kd), f64(m.pd_tau0)
+    if m.nc:
+        d.ctype, d.c_enabled = i32(m.ctype), i32(m.c_enabled)
+        d.c_body, d.c_body0, d.c_dof = i32(m.c_body), i32(m.c_body0), i32(m.c_dof)
+        d.c_local, d.c_radius = f64(m.c_local), f64(m.c_radius)
+        d.c_plane_Hinv, d.c_plane = f64(m.c_plane_Hinv), f64(m.c_plane)
+        d.c_mu, d.c_prox, d.c_eps = f64(m.c_mu), f64(m.c_prox), f64(m.c_eps)
+        d.c_min, d.c_max = f64(m.c_min), f64(m.c_max)
+        d.c_bpose0, d.c_bpose1 = f64(m.c_bpose0), f64(m.c_bpose1)
+    return d, keep

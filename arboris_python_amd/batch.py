@@ -1,0 +1,135 @@
+"""BatchedWorlds: thousands of instances of one flattened world on one MI355X.
+
+Host-side driver of the C ABI (include/arbstep.h).  State lives in PyTorch-ROCm
+tensors owned by the caller (``q`` (B,nq), ``dq`` (B,ndof), optional ``cforce``
+(B,nc,4)); the library only holds the immutable model.  PyTorch is plumbing
+here -- device memory and streams -- the arithmetic is in csrc/arb_kernels.hip.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .flatten import FlatModel, flatten_world
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class BatchedWorlds(object):
+    """One device-resident model + helpers to step/inspect batches of states.
+
+    ``model`` is a ``FlatModel`` or an initialised ``core.World``.
+    """
+
+    def __init__(self, model, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedWorlds needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback for the step")
+        if not isinstance(model, FlatModel):
+            model = flatten_world(model)[0]
+        self.model = model
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self._lib = _capi.load()
+        desc, keep = _capi.make_desc(model)
+        handle = C.c_void_p()
+        _capi.check(self._lib.arb_model_create(C.byref(desc), self.device_index, C.byref(handle)))
+        self._handle = handle
+        del keep
+        info = _capi.ModelInfo()
+        _capi.check(self._lib.arb_model_get_info(self._handle, C.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in _capi.ModelInfo._fields_}
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.arb_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------
+    def _dtype_code(self, t):
+        torch = _torch()
+        if t.dtype == torch.float32:
+            return _capi.ARB_F32
+        if t.dtype == torch.float64:
+            return _capi.ARB_F64
+        raise TypeError("state tensors must be float32 or float64")
+
+    def _check_state(self, q, dq, cforce=None, ext=None):
+        m = self.model
+        B = q.shape[0]
+        for name, t, shape in (("q", q, (B, m.nq)), ("dq", dq, (B, m.ndof)),
+                               ("cforce", cforce, (B, m.nc, _capi.ARB_MAXDOL)),
+                               ("ext_gforce", ext, (B, m.ndof))):
+            if t is None:
+                continue
+            if tuple(t.shape) != shape:
+                raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+            if not t.is_contiguous() or t.device != self.device or t.dtype != q.dtype:
+                raise ValueError("%s must be a contiguous %s tensor on %s" % (name, q.dtype, self.device))
+        return B
+
+    def to_device(self, q, dq, dtype=None):
+        """NumPy (B,nq)/(B,ndof) -> device tensors of ``dtype`` (default float32)."""
+        torch = _torch()
+        dtype = torch.float32 if dtype is None else dtype
+        return (torch.as_tensor(np.ascontiguousarray(q), dtype=dtype, device=self.device).contiguous(),
+                torch.as_tensor(np.ascontiguousarray(dq), dtype=dtype, device=self.device).contiguous())
+
+    def new_cforce(self, B, dtype):
+        torch = _torch()
+        return torch.zeros((B, self.model.nc, _capi.ARB_MAXDOL), dtype=dtype, device=self.device)
+
+    # -- the step --------------------------------------------------------------
+    def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
+             stream=None):
+        """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous)."""
+        torch = _torch()
+        B = self._check_state(q, dq, cforce, ext_gforce)
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
+        _capi.check(self._lib.arb_step(
+            self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
+            None if cforce is None else cforce.data_ptr(),
+            None if ext_gforce is None else ext_gforce.data_ptr(),
+            B, float(dt), int(nsteps), flags, C.c_void_p(st.cuda_stream)))
+
+    def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False):
+        """Evaluate one step without touching ``q``/``dq``; returns a dict of the
+        requested intermediate results (names of ``arb_inspect_out``)."""
+        torch = _torch()
+        m = self.model
+        B = self._check_state(q, dq, cforce, ext_gforce)
+        n, nb, nc, nq = m.ndof, m.nb, m.nc, m.nq
+        shapes = dict(pose=(B, nb, 4, 4), twist=(B, nb, 6), jac=(B, nb, 6, n), djac=(B, nb, 6, n),
+                      M=(B, n, n), B=(B, n, n), N=(B, n, n), Z=(B, n, n), gforce0=(B, n),
+                      vel_free=(B, n), c_sdist=(B, nc), c_active=(B, nc), c_jac=(B, nc, 4, n),
+                      c_force=(B, nc, 4), c_frame=(B, nc, 2, 4, 4), gforce=(B, n),
+                      q_next=(B, nq), dq_next=(B, n))
+        want = list(want)
+        if "gforce" in want and nc and "c_jac" not in want:
+            want.append("c_jac")
+        out = _capi.InspectOut()
+        res = {}
+        for name in want:
+            dt_ = torch.int32 if name == "c_active" else q.dtype
+            t = torch.zeros(shapes[name], dtype=dt_, device=self.device)
+            res[name] = t
+            setattr(out, name, t.data_ptr())
+        st = torch.cuda.current_stream(self.device)
+        flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
+        _capi.check(self._lib.arb_inspect(
+            self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
+            None if cforce is None else cforce.data_ptr(),
+            None if ext_gforce is None else ext_gforce.data_ptr(),
+            B, float(dt), flags, C.byref(out), C.c_void_p(st.cuda_stream)))
+        return res

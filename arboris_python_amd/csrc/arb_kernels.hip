@@ -1,0 +1,1186 @@
+// arb_kernels.hip -- gfx950 (MI355X) kernels of the batched arboris step + C ABI.
+//
+// One WAVEFRONT (64 lanes, one 64-thread workgroup) advances one world through
+//   update_dynamic -> update_controllers -> update_constraints -> integrate
+// (arboris/core.py:1356-1363) for `nsteps` steps, keeping the whole state in
+// LDS/registers; HBM is touched once to load (q, dq) and once to store them.
+//
+// Lane roles change from phase to phase:
+//   A   lane = body        joint-local kinematics, pose/twist down the tree
+//                          (Body.update_dynamic core.py:1158-1315, uniform part)
+//   A'  lane = constraint  collision + contact frames (constraints.py:277-294,
+//                          collisions.py:161-205), activity test
+//   B   lane = dof column  Jacobian / dJacobian columns of the visited body,
+//                          Z = M/dt + B + N accumulated column-per-lane in
+//                          registers (core.py:722-734, 813), rhs = M gvel/dt + gforce
+//   C   lane = column of the augmented system [Z | rhs | J'^T]: Gauss-Jordan in
+//                          registers with v_readlane broadcasts -> Y rhs, Y J'^T
+//                          (replaces numpy.linalg.inv, core.py:818, 925-927)
+//   D   wave-uniform       20 Gauss-Seidel sweeps (core.py:929-935)
+//   E   lane = dof         new gvel, joint integration (core.py:974-980)
+//
+// No CUDA/CPU fallback exists: the library needs a gfx950 device.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+#include "arbstep.h"
+#include "arb_math.h"
+
+#define WAVE 64
+#ifndef ARB_WAVES_PER_EU
+#define ARB_WAVES_PER_EU 2      // 2nd __launch_bounds__ argument: min waves per SIMD (caps VGPRs at 256)
+#endif
+#define GS_SWEEPS 20            // core.py:929-931
+
+// per-body block in LDS (elements)
+#define BD_RCP 0     // R of Ad_cp (9)
+#define BD_PCP 9     // p of Ad_cp (3)
+#define BD_DA 12     // A block of dAd_cp (9)
+#define BD_DB 21     // B block of dAd_cp (9)
+#define BD_PT 30     // M_b T_b (6)
+#define BD_PG 36     // M_b g_b (6)
+#define BD_CM 42     // rx wx - wx rx (9), core.py:1287
+#define BD_W 51      // body angular velocity (3)
+#define BD_RG 54     // R of H_gb (9)
+#define BD_PGB 63    // p of H_gb (3)
+#define BD_TW 66     // body twist (6)
+#define BD_STRIDE 72
+
+// per-constraint block in LDS (elements)
+#define CD_R1 0      // transform body1 -> constraint frame: R (9), p (3)
+#define CD_P1 9
+#define CD_R0 12     // BallAndSocket: transform body0 -> frame0 (9), (3)
+#define CD_P0 21
+#define CD_SDIST 24
+#define CD_ACTIVE 25
+#define CD_POS0 26   // (3) BallAndSocket p_01 / JointLimits pos0
+#define CD_PINV 32   // (16) inverse of the constraint's admittance block
+#define CD_GC0 48    // (3) origin of contact frame 0
+#define CD_GC1 51    // (3) origin of contact frame 1
+#define CD_STRIDE 56
+
+struct Layout {      // offsets in elements of T inside the wave's LDS block
+    int q, dq, qd, bd, sc, jb, slots, cd, rt, am, vv, ff, ff0, work, total;
+};
+
+template <typename T>
+struct DevModel {
+    int nb, n, nq, nc, ndol, ncols, maxdepth, nslots, natt;
+    int has_visc, has_pd, has_warm, has_grav;
+    const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *src, *sslot, *weighted;
+    const int *dof2q, *att_start, *att_c, *att_kind;
+    const unsigned long long *anc;
+    const T *Hpr, *Hcn, *mass, *visc;         // [nb][12], [nb][12], [nb][36], [nb][36]
+    T grav[3];
+    const T *pd_kp, *pd_kd, *pd_tau0;
+    const int *ctype, *cen, *cbody, *cbody0, *cdof;
+    const T *clocal, *cradius, *cHinv, *cplane, *cRz, *cmu, *cprox, *ceps, *cmin, *cmax, *cb0, *cb1;
+};
+
+template <typename T>
+struct DebugOut {
+    T *pose, *twist, *jac, *djac, *Zout, *gforce0, *vel_free, *c_sdist;
+    int *c_active;
+    T *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next;
+};
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float bcast(float x, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+__device__ __forceinline__ double bcast(double x, int lane) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T> __device__ __forceinline__ M3<T> ld_m3(const T *p) {
+    M3<T> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.a[i] = p[i];
+    return r;
+}
+template <typename T> __device__ __forceinline__ V3<T> ld_v3(const T *p) { return v3<T>(p[0], p[1], p[2]); }
+template <typename T> __device__ __forceinline__ void st_m3(T *p, const M3<T> &m) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = m.a[i];
+}
+template <typename T> __device__ __forceinline__ void st_v3(T *p, V3<T> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+// y = M x for a row-major 6x6 M (wave-uniform address -> scalar loads)
+template <typename T>
+__device__ __forceinline__ void mat6_vec(const T *__restrict__ M, const T x[6], T y[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s += M[6 * i + j] * x[j];
+        y[i] = s;
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
+
+// ===========================================================================
+// The step kernel.  MODE 0 = production, 1 = inspect (debug stores, no state
+// write-back).  zmode (inspect only): 0 full Z, 1 M only, 2 B only, 3 N only.
+// ===========================================================================
+template <typename T, int NMAX, int NSETS, int MODE>
+__global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
+    const DevModel<T> m, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
+    T *__restrict__ gcforce, const T *__restrict__ gext, long nworlds, T dt, int nsteps,
+    unsigned flags, const DebugOut<T> dbg, int zmode)
+{
+    const int lane0 = threadIdx.x;
+    int lane = lane0;
+    const long w = blockIdx.x;
+    if (w >= nworlds) return;
+    T *lds = reinterpret_cast<T *>(arb_lds_raw);
+    T *qs = lds + L.q, *dqs = lds + L.dq, *qd = lds + L.qd, *BD = lds + L.bd, *SC = lds + L.sc;
+    T *JB = lds + L.jb, *SL = lds + L.slots, *CD = lds + L.cd, *RT = lds + L.rt;
+    T *AM = lds + L.am, *VV = lds + L.vv, *FF = lds + L.ff, *FF0 = lds + L.ff0, *WORK = lds + L.work;
+    const int n = m.n, nb = m.nb, nq = m.nq, nc = m.nc, ndol = m.ndol;
+    const T inv_dt = T(1) / dt;
+    const bool do_constraints = (nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
+
+    // ---- load state (coalesced, world-major) -----------------------------
+    for (int i = lane; i < nq; i += WAVE) qs[i] = gq[w * nq + i];
+    dqs[lane] = (lane < n) ? gdq[w * n + lane] : T(0);
+    for (int i = lane; i < ndol; i += WAVE) {
+        T f = T(0);
+        if (gcforce != nullptr) f = gcforce[w * ndol + i];
+        FF[i] = f;
+    }
+    const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
+    __syncthreads();
+
+#define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
+    for (int step = 0; step < nsteps; ++step) {
+        // ================= phase A: lane = body ===========================
+        ARB_OPAQUE_LANE();
+        {
+            const int b = lane;
+            const bool on = b < nb;
+            int jt = 0, par = -1, doff = 0, dep = -1, k = 0;
+            M3<T> R_pc, R_cp, R_cn; V3<T> p_pc, p_cp, p_cn, Tnw, Tnv;
+            R_pc = R_cp = R_cn = m3_identity<T>();
+            p_pc = p_cp = p_cn = Tnw = Tnv = v3<T>(T(0), T(0), T(0));
+            if (on) {
+                jt = m.jtype[b]; par = m.parent[b]; doff = m.dof_off[b]; dep = m.depth[b];
+                k = m.jnd[b];
+                JointLocal<T> jl;
+                joint_local<T>(jt, qs + m.q_off[b], dqs + doff, jl);
+                const M3<T> R_pr = ld_m3(m.Hpr + 12 * b);
+                const V3<T> p_pr = ld_v3(m.Hpr + 12 * b + 9);
+                R_cn = ld_m3(m.Hcn + 12 * b);
+                p_cn = ld_v3(m.Hcn + 12 * b + 9);
+                // H_pc = H_pr H_rn inv(H_cn)                       core.py:1298
+                const M3<T> R_nc = transpose(R_cn);
+                const V3<T> p_nc = -mtv(R_cn, p_cn);
+                const M3<T> R_rc = mul(jl.R, R_nc);
+                const V3<T> p_rc = mv(jl.R, p_nc) + jl.p;
+                R_pc = mul(R_pr, R_rc);
+                p_pc = mv(R_pr, p_rc) + p_pr;
+                R_cp = transpose(R_pc);                          // Ad_cp = Ad(inv(H_pc)) :1300
+                p_cp = -mtv(R_pc, p_pc);
+                // Ad_nr, T_rn = -Ad_nr T_nr, dAd_nr = Ad_nr ad(T_rn)   rigidmotion.py:47-73
+                const M3<T> R_nr = transpose(jl.R);
+                const V3<T> p_nr = -mtv(jl.R, jl.p);
+                const V3<T> aw = mv(R_nr, jl.Tw);
+                const V3<T> av = cross(p_nr, aw) + mv(R_nr, jl.Tv);
+                const Blk<T> Ad_nr = blk_adjoint(R_nr, p_nr);
+                const Blk<T> dAd_nr = blk_mul(Ad_nr, blk_adjacency(-aw, -av));
+                // dAd_cp = Ad_cn dAd_nr Ad_rp                        core.py:1304
+                const Blk<T> Ad_cn = blk_adjoint(R_cn, p_cn);
+                const Blk<T> Ad_rp = blk_adjoint(transpose(R_pr), -mtv(R_pr, p_pr));
+                const Blk<T> dAd_cp = blk_mul(Ad_cn, blk_mul(dAd_nr, Ad_rp));
+                T *bd = BD + b * BD_STRIDE;
+                st_m3(bd + BD_RCP, R_cp); st_v3(bd + BD_PCP, p_cp);
+                st_m3(bd + BD_DA, dAd_cp.A); st_m3(bd + BD_DB, dAd_cp.B);
+                // own columns Ad_cn J_nr, Ad_cn dJ_nr               core.py:1310, 1313
+                Tnw = mv(R_cn, jl.Tw);
+                Tnv = cross(p_cn, Tnw) + mv(R_cn, jl.Tv);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (i < k) {
+                        V3<T> cw = v3<T>(T(0), T(0), T(0)), cv = cw, dw = cw;
+                        if (jt == JT_FREE) {
+                            if (i < 3) cw = v3<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
+                            else cv = v3<T>(i == 3 ? T(1) : T(0), i == 4 ? T(1) : T(0), i == 5 ? T(1) : T(0));
+                        } else if (jt == JT_TXTYTZ) {
+                            cv = v3<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
+                        } else if (i < 3) {
+                            cw = jl.jw[i]; dw = jl.djw[i];
+                        }
+                        const V3<T> ow = mv(R_cn, cw);
+                        const V3<T> ov = cross(p_cn, ow) + mv(R_cn, cv);
+                        const V3<T> dow = mv(R_cn, dw);
+                        const V3<T> dov = cross(p_cn, dow);
+                        const int col = doff + i;
+                        SC[0 * WAVE + col] = ow.x; SC[1 * WAVE + col] = ow.y; SC[2 * WAVE + col] = ow.z;
+                        SC[3 * WAVE + col] = ov.x; SC[4 * WAVE + col] = ov.y; SC[5 * WAVE + col] = ov.z;
+                        SC[6 * WAVE + col] = dow.x; SC[7 * WAVE + col] = dow.y; SC[8 * WAVE + col] = dow.z;
+                        SC[9 * WAVE + col] = dov.x; SC[10 * WAVE + col] = dov.y; SC[11 * WAVE + col] = dov.z;
+                    }
+                }
+            }
+            // pose and twist down the tree, one depth level at a time
+            for (int lvl = 0; lvl <= m.maxdepth; ++lvl) {
+                if (on && dep == lvl) {
+                    M3<T> Rg = m3_identity<T>(); V3<T> pg = v3<T>(T(0), T(0), T(0));
+                    V3<T> tw = pg, tv = pg;
+                    if (par >= 0) {
+                        const T *pb = BD + par * BD_STRIDE;
+                        Rg = ld_m3(pb + BD_RG); pg = ld_v3(pb + BD_PGB);
+                        tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
+                    }
+                    const M3<T> Rc = mul(Rg, R_pc);                  // child_pose  core.py:1299
+                    const V3<T> pc = mv(Rg, p_pc) + pg;
+                    const V3<T> cw = mv(R_cp, tw) + Tnw;             // child_twist core.py:1308
+                    const V3<T> cv = cross(p_cp, mv(R_cp, tw)) + mv(R_cp, tv) + Tnv;
+                    T *bd = BD + b * BD_STRIDE;
+                    st_m3(bd + BD_RG, Rc); st_v3(bd + BD_PGB, pc);
+                    st_v3(bd + BD_TW, cw); st_v3(bd + BD_TW + 3, cv);
+                }
+                __syncthreads();
+            }
+            if (on) {
+                T *bd = BD + b * BD_STRIDE;
+                const T *Mb = m.mass + 36 * b;
+                T tw[6], y[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tw[i] = bd[BD_TW + i];
+                mat6_vec<T>(Mb, tw, y);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bd[BD_PT + i] = y[i];
+                // gravity in the body frame: Ad(inv(H_gb)) [0; g up]   controllers.py:56-58
+                T g6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+                if (m.has_grav && m.weighted[b]) {
+                    const M3<T> Rg = ld_m3(bd + BD_RG);
+                    const V3<T> gl = mtv(Rg, v3<T>(m.grav[0], m.grav[1], m.grav[2]));
+                    g6[3] = gl.x; g6[4] = gl.y; g6[5] = gl.z;
+                }
+                mat6_vec<T>(Mb, g6, y);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bd[BD_PG + i] = y[i];
+                // N_b = [[wx, rx wx - wx rx],[0, wx]] M_b              core.py:1276-1288
+                const V3<T> wv = v3<T>(tw[0], tw[1], tw[2]);
+                const M3<T> wx = hat(wv);
+                M3<T> rx = m3_zero<T>();
+                const T mm = Mb[21];
+                if (!(mm <= T(1e-10))) {
+                    const T im = T(1) / mm;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) rx.a[3 * i + j] = Mb[6 * i + 3 + j] * im;
+                }
+                st_m3(bd + BD_CM, sub(mul(rx, wx), mul(wx, rx)));
+                st_v3(bd + BD_W, wv);
+            }
+            // dof-indexed copy of the linear joint positions (PD controller, joint limits)
+            if (lane < n) { const int qi = m.dof2q[lane]; qd[lane] = qi >= 0 ? qs[qi] : T(0); }
+            __syncthreads();
+        }
+        if (MODE == 1 && step == 0) {
+            if (dbg.pose != nullptr && lane < nb) {
+                const T *bd = BD + lane * BD_STRIDE;
+                T *o = dbg.pose + (w * nb + lane) * 16;
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = 0; j < 3; ++j) o[4 * i + j] = bd[BD_RG + 3 * i + j];
+                    o[4 * i + 3] = bd[BD_PGB + i];
+                }
+                o[12] = o[13] = o[14] = T(0); o[15] = T(1);
+            }
+            if (dbg.twist != nullptr && lane < nb)
+                for (int i = 0; i < 6; ++i) dbg.twist[(w * nb + lane) * 6 + i] = BD[lane * BD_STRIDE + BD_TW + i];
+        }
+
+        // ================= phase A': lane = constraint =====================
+        ARB_OPAQUE_LANE();
+        for (int i = lane; i < (1 + ndol) * WAVE; i += WAVE) RT[i] = T(0);
+        if (do_constraints && lane < nc) {
+            const int c = lane;
+            T *cd = CD + c * CD_STRIDE;
+            const int ct = m.ctype[c];
+            bool active = false;
+            T sd = T(0);
+            if (m.cen[c]) {
+                if (ct == ARB_CT_SOFTFINGER_PLANE) {
+                    const T *bd = BD + m.cbody[c] * BD_STRIDE;
+                    const M3<T> Rg = ld_m3(bd + BD_RG); const V3<T> pg = ld_v3(bd + BD_PGB);
+                    const V3<T> p_g1 = mv(Rg, ld_v3(m.clocal + 3 * c)) + pg;
+                    // collisions.py:194-205
+                    const M3<T> Ri = ld_m3(m.cHinv + 12 * c); const V3<T> pi = ld_v3(m.cHinv + 12 * c + 9);
+                    const V3<T> p01 = mv(Ri, p_g1) + pi;
+                    const V3<T> nrm = ld_v3(m.cplane + 4 * c);
+                    const T rad = m.cradius[c];
+                    const T csd = dot(nrm, p01) - m.cplane[4 * c + 3];
+                    sd = csd - rad;
+                    const T sg = sd > T(0) ? T(1) : (sd < T(0) ? T(-1) : T(0));
+                    const V3<T> gc0 = p01 - csd * nrm;
+                    const V3<T> gc1 = p01 - (sg * rad) * nrm;
+                    const M3<T> Rz = ld_m3(m.cRz + 9 * c);
+                    // frame 1 on the body: bpose1 = inv(H_gb) H_gc1       constraints.py:287-288
+                    const M3<T> Rb1 = mulTA(Rg, Rz);
+                    const V3<T> pb1 = mtv(Rg, gc1 - pg);
+                    // twist of frame 1 (core.py:1021-1023) and gap rate (constraints.py:289-291)
+                    const V3<T> bw = ld_v3(bd + BD_TW), bv = ld_v3(bd + BD_TW + 3);
+                    const V3<T> pinv1 = -mtv(Rb1, pb1);
+                    const V3<T> w1 = mtv(Rb1, bw);
+                    const V3<T> v1 = cross(pinv1, w1) + mtv(Rb1, bv);
+                    const V3<T> p0c = mtv(Rz, gc1 - gc0);            // H_c0c1 = [I | p0c]
+                    const T dsd = cross(p0c, w1).z + v1.z;
+                    active = (sd + dsd * dt < m.cprox[c]);
+                    // body -> contact frame 0:  Ad(H_01) Ad(inv(bpose1)) = Ad(inv(H_gc0) H_gb)
+                    st_m3(cd + CD_R1, mulTA(Rz, Rg));
+                    st_v3(cd + CD_P1, mtv(Rz, pg - gc0));
+                    st_v3(cd + CD_GC0, gc0); st_v3(cd + CD_GC1, gc1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
+                } else if (ct == ARB_CT_JOINTLIMITS) {
+                    const T p0 = qd[m.cdof[c]];
+                    cd[CD_POS0] = p0;
+                    active = (p0 - m.cmin[c] < m.cprox[c]) || (m.cmax[c] - p0 < m.cprox[c]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:58-60
+                    sd = p0;
+                } else {                                                // BallAndSocket
+                    const int b0 = m.cbody0[c], b1 = m.cbody[c];
+                    M3<T> Rg0 = m3_identity<T>(), Rg1 = Rg0;
+                    V3<T> pg0 = v3<T>(T(0), T(0), T(0)), pg1 = pg0;
+                    if (b0 >= 0) { Rg0 = ld_m3(BD + b0 * BD_STRIDE + BD_RG); pg0 = ld_v3(BD + b0 * BD_STRIDE + BD_PGB); }
+                    if (b1 >= 0) { Rg1 = ld_m3(BD + b1 * BD_STRIDE + BD_RG); pg1 = ld_v3(BD + b1 * BD_STRIDE + BD_PGB); }
+                    const M3<T> Rf0 = ld_m3(m.cb0 + 12 * c), Rf1 = ld_m3(m.cb1 + 12 * c);
+                    const V3<T> pf0 = ld_v3(m.cb0 + 12 * c + 9), pf1 = ld_v3(m.cb1 + 12 * c + 9);
+                    const M3<T> RP0 = mul(Rg0, Rf0); const V3<T> pP0 = mv(Rg0, pf0) + pg0;
+                    const V3<T> pP1 = mv(Rg1, pf1) + pg1;
+                    st_v3(cd + CD_POS0, mtv(RP0, pP1 - pP0));         // p_01  constraints.py:196-197
+                    // body1 -> frame 0: Ad(inv(P0) H_gb1);  body0 -> frame 0: Ad(inv(bpose0))
+                    st_m3(cd + CD_R1, mulTA(RP0, Rg1)); st_v3(cd + CD_P1, mtv(RP0, pg1 - pP0));
+                    st_m3(cd + CD_R0, transpose(Rf0)); st_v3(cd + CD_P0, -mtv(Rf0, pf0));
+                    active = true;
+                }
+            }
+            cd[CD_SDIST] = sd;
+            cd[CD_ACTIVE] = active ? T(1) : T(0);
+        }
+        __syncthreads();
+        if (lane < ndol) FF0[lane] = FF[lane];
+
+        // ================= phase B: lane = dof column =======================
+        ARB_OPAQUE_LANE();
+        T Z[NMAX];
+        T Z2[NSETS == 2 ? NMAX : 1];
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) Z[i] = T(0);
+        T rhsM = T(0), rhsG = T(0);
+        {
+            T Jw[3] = {T(0), T(0), T(0)}, Jv[3] = {T(0), T(0), T(0)};
+            T dJw[3] = {T(0), T(0), T(0)}, dJv[3] = {T(0), T(0), T(0)};
+            for (int b = 0; b < nb; ++b) {
+                const int src = m.src[b];
+                if (src == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { Jw[i] = Jv[i] = dJw[i] = dJv[i] = T(0); }
+                } else if (src >= 2) {
+                    const T *sl = SL + (src - 2) * 12 * WAVE;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        Jw[i] = sl[i * WAVE + lane]; Jv[i] = sl[(3 + i) * WAVE + lane];
+                        dJw[i] = sl[(6 + i) * WAVE + lane]; dJv[i] = sl[(9 + i) * WAVE + lane];
+                    }
+                }
+                const T *bd = BD + b * BD_STRIDE;
+                const M3<T> R = ld_m3(bd + BD_RCP); const V3<T> p = ld_v3(bd + BD_PCP);
+                const M3<T> dA = ld_m3(bd + BD_DA), dB = ld_m3(bd + BD_DB);
+                const V3<T> jw = v3<T>(Jw[0], Jw[1], Jw[2]), jv = v3<T>(Jv[0], Jv[1], Jv[2]);
+                const V3<T> djw = v3<T>(dJw[0], dJw[1], dJw[2]), djv = v3<T>(dJv[0], dJv[1], dJv[2]);
+                // child_jac = Ad_cp J_pg ; child_djac = dAd_cp J_pg + Ad_cp dJ_pg   core.py:1309-1313
+                V3<T> nw = mv(R, jw);
+                V3<T> nv = mv(R, jv) + cross(p, nw);
+                V3<T> tdw = mv(R, djw);
+                V3<T> ndw = mv(dA, jw) + tdw;
+                V3<T> ndv = mv(dB, jw) + mv(dA, jv) + mv(R, djv) + cross(p, tdw);
+                const int d0 = m.dof_off[b];
+                if (lane >= d0 && lane < d0 + m.jnd[b]) {
+                    nw = nw + v3<T>(SC[0 * WAVE + lane], SC[1 * WAVE + lane], SC[2 * WAVE + lane]);
+                    nv = nv + v3<T>(SC[3 * WAVE + lane], SC[4 * WAVE + lane], SC[5 * WAVE + lane]);
+                    ndw = ndw + v3<T>(SC[6 * WAVE + lane], SC[7 * WAVE + lane], SC[8 * WAVE + lane]);
+                    ndv = ndv + v3<T>(SC[9 * WAVE + lane], SC[10 * WAVE + lane], SC[11 * WAVE + lane]);
+                }
+                Jw[0] = nw.x; Jw[1] = nw.y; Jw[2] = nw.z; Jv[0] = nv.x; Jv[1] = nv.y; Jv[2] = nv.z;
+                dJw[0] = ndw.x; dJw[1] = ndw.y; dJw[2] = ndw.z; dJv[0] = ndv.x; dJv[1] = ndv.y; dJv[2] = ndv.z;
+                const int ss = m.sslot[b];
+                if (ss >= 0) {
+                    T *sl = SL + ss * 12 * WAVE;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        sl[i * WAVE + lane] = Jw[i]; sl[(3 + i) * WAVE + lane] = Jv[i];
+                        sl[(6 + i) * WAVE + lane] = dJw[i]; sl[(9 + i) * WAVE + lane] = dJv[i];
+                    }
+                }
+                if (MODE == 1 && step == 0 && lane < n) {
+                    if (dbg.jac != nullptr)
+                        for (int i = 0; i < 3; ++i) {
+                            dbg.jac[((w * nb + b) * 6 + i) * n + lane] = Jw[i];
+                            dbg.jac[((w * nb + b) * 6 + 3 + i) * n + lane] = Jv[i];
+                        }
+                    if (dbg.djac != nullptr)
+                        for (int i = 0; i < 3; ++i) {
+                            dbg.djac[((w * nb + b) * 6 + i) * n + lane] = dJw[i];
+                            dbg.djac[((w * nb + b) * 6 + 3 + i) * n + lane] = dJv[i];
+                        }
+                }
+                // per-column wrenches: U = M_b J, W = M_b dJ + N_b J, V = B_b J   core.py:726-734
+                const T *Mb = m.mass + 36 * b;
+                T x[6] = {Jw[0], Jw[1], Jw[2], Jv[0], Jv[1], Jv[2]};
+                T dx[6] = {dJw[0], dJw[1], dJw[2], dJv[0], dJv[1], dJv[2]};
+                T U[6], W[6], Q[6];
+                mat6_vec<T>(Mb, x, U);
+                mat6_vec<T>(Mb, dx, W);
+                {
+                    const V3<T> wv = ld_v3(bd + BD_W);
+                    const M3<T> Cm = ld_m3(bd + BD_CM);
+                    const V3<T> ut = v3<T>(U[0], U[1], U[2]), ub = v3<T>(U[3], U[4], U[5]);
+                    const V3<T> top = cross(wv, ut) + mv(Cm, ub);
+                    const V3<T> bot = cross(wv, ub);
+                    W[0] += top.x; W[1] += top.y; W[2] += top.z; W[3] += bot.x; W[4] += bot.y; W[5] += bot.z;
+                }
+                if (MODE == 1 && zmode != 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) Q[i] = (zmode == 1) ? U[i] : ((zmode == 3) ? W[i] : T(0));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) Q[i] = U[i] * inv_dt + W[i];
+                }
+                if (m.has_visc) {
+                    T V[6];
+                    mat6_vec<T>(m.visc + 36 * b, x, V);
+                    if (MODE == 0 || zmode == 0 || zmode == 2) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) Q[i] += V[i];
+                    }
+                }
+                // rhs:  J^T M_b T_b  (= M gvel) and J^T M_b g_b (gravity)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { rhsM += x[i] * bd[BD_PT + i]; rhsG += x[i] * bd[BD_PG + i]; }
+                // constraint rows hanging on this body
+                if (do_constraints) {
+                    for (int a = m.att_start[b]; a < m.att_start[b + 1]; ++a) {
+                        const int c = m.att_c[a], kind = m.att_kind[a];
+                        const T *cd = CD + c * CD_STRIDE;
+                        const T act = cd[CD_ACTIVE];
+                        const M3<T> Rx = ld_m3(cd + (kind == 2 ? CD_R0 : CD_R1));
+                        const V3<T> px = ld_v3(cd + (kind == 2 ? CD_P0 : CD_P1));
+                        const V3<T> cw = mv(Rx, nw);
+                        const V3<T> cv = mv(Rx, nv) + cross(px, cw);
+                        T *row = RT + (1 + 4 * c) * WAVE + lane;
+                        if (kind == 0) {            // SoftFinger rows (w_z, v_x, v_y, v_z)  constraints.py:429-433
+                            row[0] += act * cw.z; row[WAVE] += act * cv.x;
+                            row[2 * WAVE] += act * cv.y; row[3 * WAVE] += act * cv.z;
+                        } else {                    // BallAndSocket linear rows, +frame1 / -frame0  constraints.py:203-207
+                            const T sgn = (kind == 1) ? act : -act;
+                            row[0] += sgn * cv.x; row[WAVE] += sgn * cv.y; row[2 * WAVE] += sgn * cv.z;
+                        }
+                    }
+                }
+                // publish this body's Jacobian columns and accumulate Z[i][k] += J[:,i] . Q[:,k]
+                __syncthreads();
+                JB[8 * lane + 0] = x[0]; JB[8 * lane + 1] = x[1]; JB[8 * lane + 2] = x[2]; JB[8 * lane + 3] = x[3];
+                JB[8 * lane + 4] = x[4]; JB[8 * lane + 5] = x[5];
+                __syncthreads();
+                const unsigned long long mask = m.anc[b];
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) {
+                    if ((mask >> i) & 1ull) {
+                        const T *jb = JB + 8 * i;
+                        Z[i] += jb[0] * Q[0] + jb[1] * Q[1] + jb[2] * Q[2] + jb[3] * Q[3] + jb[4] * Q[4] + jb[5] * Q[5];
+                    }
+                }
+            }
+        }
+        // joint-limit rows are dof selectors                              constraints.py:46-48
+        if (do_constraints) {
+            for (int c = 0; c < nc; ++c)
+                if (m.ctype[c] == ARB_CT_JOINTLIMITS && lane == m.cdof[c])
+                    RT[(1 + 4 * c) * WAVE + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
+        }
+        // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
+        T gf0 = rhsG + ext_k;
+        if (m.has_pd && lane < n) {
+            T acc = m.pd_tau0[lane];
+            for (int i = 0; i < n; ++i) acc -= m.pd_kp[lane * n + i] * qd[i];
+            gf0 += acc;
+            if (MODE == 0 || zmode == 0) {
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i)
+                    if (i < n) Z[i] += dt * m.pd_kp[i * n + lane] + m.pd_kd[i * n + lane];
+            }
+        }
+        T rhs = rhsM * inv_dt + gf0;
+        __syncthreads();
+        if (MODE == 1) {
+            if (dbg.Zout != nullptr && lane < n) {
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) if (i < n) dbg.Zout[(w * n + i) * n + lane] = Z[i];
+            }
+            if (zmode != 0) return;
+            if (dbg.gforce0 != nullptr && lane < n) dbg.gforce0[w * n + lane] = gf0;
+            if (dbg.c_jac != nullptr && lane < n)
+                for (int i = 0; i < ndol; ++i) dbg.c_jac[(w * ndol + i) * n + lane] = do_constraints ? RT[(1 + i) * WAVE + lane] : T(0);
+            if (lane < nc) {
+                const T *cd = CD + lane * CD_STRIDE;
+                if (dbg.c_sdist != nullptr) dbg.c_sdist[w * nc + lane] = do_constraints ? cd[CD_SDIST] : T(0);
+                if (dbg.c_active != nullptr) dbg.c_active[w * nc + lane] = (do_constraints && cd[CD_ACTIVE] != T(0)) ? 1 : 0;
+                if (dbg.c_frame != nullptr && do_constraints && m.ctype[lane] == ARB_CT_SOFTFINGER_PLANE) {
+                    for (int f = 0; f < 2; ++f) {
+                        T *o = dbg.c_frame + ((w * nc + lane) * 2 + f) * 16;
+                        for (int i = 0; i < 3; ++i) {
+                            for (int j = 0; j < 3; ++j) o[4 * i + j] = m.cRz[9 * lane + 3 * i + j];
+                            o[4 * i + 3] = cd[(f ? CD_GC1 : CD_GC0) + i];
+                        }
+                        o[12] = o[13] = o[14] = T(0); o[15] = T(1);
+                    }
+                }
+            }
+        }
+        // warm-started constraint forces enter the right-hand side          core.py:921-924
+        if (do_constraints && m.has_warm && lane < n) {
+            for (int i = 0; i < ndol; ++i) rhs += RT[(1 + i) * WAVE + lane] * FF[i];
+        }
+        // ================= phase C: augmented Gauss-Jordan ===================
+        ARB_OPAQUE_LANE();
+        RT[lane] = (lane < n) ? rhs : T(0);
+        __syncthreads();
+        const int ncols = do_constraints ? m.ncols : n + 1;
+        if (lane >= n) {
+            const int r = lane - n;                 // column r of [rhs | J'^T]
+            const bool have = lane < ncols;
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) Z[i] = (have && i < n) ? RT[r * WAVE + i] : T(0);
+        }
+        if (NSETS == 2) {
+            const int r = WAVE + lane - n;
+            const bool have = (WAVE + lane) < ncols;
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) Z2[i] = (have && i < n) ? RT[r * WAVE + i] : T(0);
+        }
+        for (int j = 0; j < n; ++j) {
+            const T piv = bcast(Z[0], j);
+            const T ip = T(1) / piv;
+            const T t = Z[0] * ip;
+            T t2 = T(0);
+            if (NSETS == 2) t2 = Z2[0] * ip;
+#pragma unroll
+            for (int r = 1; r < NMAX; ++r) {
+                const T f = bcast(Z[r], j);
+                Z[r - 1] = Z[r] - f * t;
+                if (NSETS == 2) Z2[r - 1] = Z2[r] - f * t2;
+            }
+            Z[NMAX - 1] = t;
+            if (NSETS == 2) Z2[NMAX - 1] = t2;
+        }
+        for (int j = n; j < NMAX; ++j) {           // finish the rotation: rows back in place
+            const T t = Z[0];
+            T t2 = T(0);
+            if (NSETS == 2) t2 = Z2[0];
+#pragma unroll
+            for (int r = 1; r < NMAX; ++r) { Z[r - 1] = Z[r]; if (NSETS == 2) Z2[r - 1] = Z2[r]; }
+            Z[NMAX - 1] = t;
+            if (NSETS == 2) Z2[NMAX - 1] = t2;
+        }
+        // lanes >= n (and the second set) now hold Y rhs and Y J'^T columns
+
+        // ================= phase D: constraint space + Gauss-Seidel ==========
+        ARB_OPAQUE_LANE();
+        if (do_constraints) {
+            // [v | Y'] = J' [Y rhs | Y J'^T]                                core.py:925-927
+            for (int idx = 0; idx < ndol; ++idx) {
+                const T *jr = RT + (1 + idx) * WAVE;
+                T acc = T(0), acc2 = T(0);
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) {
+                    const T jv = (i < n) ? jr[i] : T(0);
+                    acc += jv * Z[i];
+                    if (NSETS == 2) acc2 += jv * Z2[i];
+                }
+                if (lane == n) VV[idx] = acc;
+                else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = acc;
+                if (NSETS == 2) {
+                    if (WAVE + lane == n) VV[idx] = acc2;
+                    else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = acc2;
+                }
+            }
+            __syncthreads();
+        }
+        // solution columns -> LDS (row r of RT := column r of [Y rhs | Y J'^T])
+        __syncthreads();
+        if (lane >= n && lane < ncols) {
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(lane - n) * WAVE + i] = Z[i];
+        }
+        if (NSETS == 2 && (WAVE + lane) < ncols) {
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(WAVE + lane - n) * WAVE + i] = Z2[i];
+        }
+        __syncthreads();
+        if (MODE == 1 && dbg.vel_free != nullptr && lane < n) dbg.vel_free[w * n + lane] = RT[lane];
+
+        if (do_constraints) {
+            // inverse of every active constraint's own admittance block (once per step)
+            if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
+                const int c = lane, ct = m.ctype[c];
+                const int nd = (ct == ARB_CT_SOFTFINGER_PLANE) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                T P[16];
+                inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+            }
+            __syncthreads();
+            for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+                for (int c = 0; c < nc; ++c) {
+                    const T *cd = CD + c * CD_STRIDE;
+                    if (cd[CD_ACTIVE] == T(0)) continue;
+                    const int ct = m.ctype[c];
+                    T v[4], f[4], df[4], Y[16], P[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = VV[4 * c + i]; f[i] = FF[4 * c + i]; df[i] = T(0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { Y[4 * i + j] = AM[(4 * c + i) * ndol + 4 * c + j]; P[4 * i + j] = cd[CD_PINV + 4 * i + j]; }
+                    }
+                    __syncthreads();     // everyone has read VV/FF/WORK inputs before they change
+                    if (ct == ARB_CT_SOFTFINGER_PLANE) {
+                        const T eps[3] = {m.ceps[3 * c], m.ceps[3 * c + 1], m.ceps[3 * c + 2]};
+                        // the rare sliding branch runs its 6x6 eigenproblem on an LDS work
+                        // array; all lanes execute it redundantly (wave-uniform data)
+                        softfinger_solve<T>(v, Y, P, f, df, cd[CD_SDIST], dt, m.cmu[c], eps, WORK);
+                    } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            T s = T(0);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) s += P[4 * i + j] * (v[j] + cd[CD_POS0 + j] * inv_dt);
+                            df[i] = -s; f[i] += df[i];
+                        }
+                    } else {                                               // JointLimits.solve constraints.py:73-90
+                        const T pred = cd[CD_POS0] + dt * (v[0] - Y[0] * f[0]);
+                        T nf = T(0);
+                        if (pred <= m.cmin[c]) nf = P[0] * ((m.cmin[c] - pred) * inv_dt);
+                        else if (m.cmax[c] <= pred) nf = P[0] * ((m.cmax[c] - pred) * inv_dt);
+                        df[0] = nf - f[0]; f[0] = nf;
+                    }
+                    // vel += Y'[:, c] dforce                               core.py:935
+                    if (lane < ndol) {
+                        const T *ar = AM + lane * ndol + 4 * c;
+                        VV[lane] += ar[0] * df[0] + ar[1] * df[1] + ar[2] * df[2] + ar[3] * df[3];
+                    }
+                    if (lane < 4) FF[4 * c + lane] = f[lane];
+                    __syncthreads();
+                }
+            }
+        }
+
+        // ================= phase E: new velocity, integrate ==================
+        ARB_OPAQUE_LANE();
+        T vnew = T(0);
+        if (lane < n) {
+            vnew = RT[lane];
+            if (do_constraints)
+                for (int i = 0; i < ndol; ++i) vnew += RT[(1 + i) * WAVE + lane] * (FF[i] - FF0[i]);
+        }
+        if (MODE == 1) {
+            if (dbg.gforce != nullptr && lane < n) {
+                // World._gforce after update_constraints: controllers + sum J_c^T f_c  (core.py:936-937);
+                // J'^T was overwritten by the solution columns, so recompute from dbg.c_jac if present
+                T g = gf0;
+                if (do_constraints && dbg.c_jac != nullptr)
+                    for (int i = 0; i < ndol; ++i) g += dbg.c_jac[(w * ndol + i) * n + lane] * FF[i];
+                dbg.gforce[w * n + lane] = g;
+            }
+            if (dbg.c_force != nullptr)
+                for (int i = lane; i < ndol; i += WAVE) dbg.c_force[w * ndol + i] = FF[i];
+        }
+        __syncthreads();
+        if (lane < n) {
+            dqs[lane] = vnew;
+            const int qi = m.dof2q[lane];
+            if (qi >= 0) qs[qi] += dt * vnew;                               // core.py:238-240
+        }
+        __syncthreads();
+        if (lane < nb && m.jtype[lane] == JT_FREE) {                        // joints.py:54-57
+            T *qp = qs + m.q_off[lane];
+            const T *vp = dqs + m.dof_off[lane];
+            M3<T> R, Re; V3<T> p, pe;
+            R.a[0] = qp[0]; R.a[1] = qp[1]; R.a[2] = qp[2]; p.x = qp[3];
+            R.a[3] = qp[4]; R.a[4] = qp[5]; R.a[5] = qp[6]; p.y = qp[7];
+            R.a[6] = qp[8]; R.a[7] = qp[9]; R.a[8] = qp[10]; p.z = qp[11];
+            exp_twist<T>(dt * v3<T>(vp[0], vp[1], vp[2]), dt * v3<T>(vp[3], vp[4], vp[5]), Re, pe);
+            const M3<T> Rn = mul(R, Re);
+            const V3<T> pn = mv(R, pe) + p;
+            qp[0] = Rn.a[0]; qp[1] = Rn.a[1]; qp[2] = Rn.a[2]; qp[3] = pn.x;
+            qp[4] = Rn.a[3]; qp[5] = Rn.a[4]; qp[6] = Rn.a[5]; qp[7] = pn.y;
+            qp[8] = Rn.a[6]; qp[9] = Rn.a[7]; qp[10] = Rn.a[8]; qp[11] = pn.z;
+            qp[12] = T(0); qp[13] = T(0); qp[14] = T(0); qp[15] = T(1);
+        }
+        __syncthreads();
+    }
+
+    // ---- store state -------------------------------------------------------
+    ARB_OPAQUE_LANE();
+    if (MODE == 0) {
+        for (int i = lane; i < nq; i += WAVE) gq[w * nq + i] = qs[i];
+        if (lane < n) gdq[w * n + lane] = dqs[lane];
+        if (gcforce != nullptr)
+            for (int i = lane; i < ndol; i += WAVE) gcforce[w * ndol + i] = FF[i];
+    } else {
+        if (dbg.q_next != nullptr) for (int i = lane; i < nq; i += WAVE) dbg.q_next[w * nq + i] = qs[i];
+        if (dbg.dq_next != nullptr && lane < n) dbg.dq_next[w * n + lane] = dqs[lane];
+    }
+}
+
+// ===========================================================================
+// Host side: model upload, launch dispatch, C ABI
+// ===========================================================================
+static thread_local std::string g_hip_err;
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);     \
+            return ARB_ERR_HIP;                                                \
+        }                                                                      \
+    } while (0)
+
+struct arb_model {
+    int device;
+    int nb, n, nq, nc, ndol, ncols, nsets, nmax;
+    std::vector<void *> allocs;
+    DevModel<float> df;
+    DevModel<double> dd;
+    Layout lf, ld;
+};
+
+template <typename T>
+static int upload(arb_model *M, const std::vector<T> &h, const T **out) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    M->allocs.push_back(p);
+    if (!h.empty()) HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T *>(p);
+    return ARB_OK;
+}
+
+template <typename T>
+static std::vector<T> conv(const double *src, size_t count) {
+    std::vector<T> v(count);
+    for (size_t i = 0; i < count; ++i) v[i] = static_cast<T>(src ? src[i] : 0.0);
+    return v;
+}
+
+// 4x4 row-major -> 12 scalars (R row-major, p)
+static std::vector<double> h12(const double *H16, int count) {
+    std::vector<double> v(static_cast<size_t>(count) * 12);
+    for (int b = 0; b < count; ++b) {
+        const double *H = H16 + 16 * b;
+        double *o = v.data() + 12 * b;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[3 * i + j] = H[4 * i + j]; o[9 + i] = H[4 * i + 3]; }
+    }
+    return v;
+}
+
+static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int *total_elems) {
+    auto al = [](int x) { return (x + 3) & ~3; };
+    Layout L;
+    int o = 0;
+    L.q = o; o += al(nq);
+    L.dq = o; o += WAVE;
+    L.qd = o; o += WAVE;
+    L.bd = o; o += al(nb * BD_STRIDE);
+    L.sc = o; o += 12 * WAVE;
+    L.jb = o; o += 8 * WAVE;
+    L.slots = o; o += std::max(nslots, 1) * 12 * WAVE;
+    L.cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
+    L.rt = o; o += (1 + ndol) * WAVE;
+    L.am = o; o += al(std::max(ndol * ndol, 4));
+    L.vv = o; o += al(std::max(ndol, 4));
+    L.ff = o; o += al(std::max(ndol, 4));
+    L.ff0 = o; o += al(std::max(ndol, 4));
+    L.work = o; o += 64;
+    L.total = o;
+    *total_elems = o;
+    return L;
+}
+
+// zaligned(normal), arboris/homogeneousmatrix.py:201-232 (constant per contact plane)
+static void zaligned_host(const double z[3], double R[9]) {
+    int idx[3] = {0, 1, 2};
+    double a[3] = {std::fabs(z[0]), std::fabs(z[1]), std::fabs(z[2])};
+    std::stable_sort(idx, idx + 3, [&](int i, int j) { return a[i] < a[j]; });
+    double x[3] = {0, 0, 0};
+    x[idx[0]] = 0; x[idx[1]] = z[idx[2]]; x[idx[2]] = -z[idx[1]];
+    double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    for (int i = 0; i < 3; ++i) x[i] /= nx;
+    double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    for (int i = 0; i < 3; ++i) { R[3 * i] = x[i]; R[3 * i + 1] = y[i]; R[3 * i + 2] = z[i]; }
+}
+
+template <typename T>
+static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<int> &jnd,
+                     const std::vector<int> &depth, const std::vector<int> &src,
+                     const std::vector<int> &sslot, const std::vector<unsigned long long> &anc,
+                     const std::vector<int> &dof2q, const std::vector<int> &att_start,
+                     const std::vector<int> &att_c, const std::vector<int> &att_kind,
+                     int maxdepth, int nslots, DevModel<T> *out) {
+    DevModel<T> m;
+    memset(&m, 0, sizeof(m));
+    const int nb = d->nb, n = d->ndof, nc = d->nc;
+    m.nb = nb; m.n = n; m.nq = d->nq; m.nc = nc; m.ndol = ARB_MAXDOL * nc; m.ncols = n + 1 + m.ndol;
+    m.maxdepth = maxdepth; m.nslots = nslots; m.natt = (int)att_c.size();
+    int rc;
+#define UP_I(field, vec) if ((rc = upload<int>(M, vec, &m.field)) != ARB_OK) return rc
+#define UP_T(field, vec) if ((rc = upload<T>(M, vec, &m.field)) != ARB_OK) return rc
+    UP_I(parent, std::vector<int>(d->parent, d->parent + nb));
+    UP_I(jtype, std::vector<int>(d->jtype, d->jtype + nb));
+    UP_I(dof_off, std::vector<int>(d->dof_off, d->dof_off + nb));
+    UP_I(jnd, jnd);
+    UP_I(q_off, std::vector<int>(d->q_off, d->q_off + nb));
+    UP_I(depth, depth); UP_I(src, src); UP_I(sslot, sslot);
+    UP_I(weighted, std::vector<int>(d->weighted, d->weighted + nb));
+    UP_I(dof2q, dof2q); UP_I(att_start, att_start); UP_I(att_c, att_c); UP_I(att_kind, att_kind);
+    if ((rc = upload<unsigned long long>(M, anc, &m.anc)) != ARB_OK) return rc;
+    UP_T(Hpr, conv<T>(h12(d->H_pr, nb).data(), 12 * nb));
+    UP_T(Hcn, conv<T>(h12(d->H_cn, nb).data(), 12 * nb));
+    UP_T(mass, conv<T>(d->mass, 36 * nb));
+    UP_T(visc, conv<T>(d->visc, 36 * nb));
+    bool hv = false;
+    for (int i = 0; i < 36 * nb; ++i) hv = hv || (d->visc[i] != 0.0);
+    m.has_visc = hv;
+    m.has_grav = 0;
+    for (int i = 0; i < 3; ++i) { m.grav[i] = (T)d->gravity[i]; if (d->gravity[i] != 0.0) m.has_grav = 1; }
+    m.has_pd = (d->pd_kp != nullptr);
+    UP_T(pd_kp, conv<T>(d->pd_kp, m.has_pd ? n * n : 0));
+    UP_T(pd_kd, conv<T>(d->pd_kd, m.has_pd ? n * n : 0));
+    UP_T(pd_tau0, conv<T>(d->pd_tau0, m.has_pd ? n : 0));
+    // constraints
+    std::vector<int> ctype(d->ctype, d->ctype + nc), cen(d->c_enabled, d->c_enabled + nc);
+    UP_I(ctype, ctype); UP_I(cen, cen);
+    UP_I(cbody, std::vector<int>(d->c_body, d->c_body + nc));
+    UP_I(cbody0, std::vector<int>(d->c_body0, d->c_body0 + nc));
+    UP_I(cdof, std::vector<int>(d->c_dof, d->c_dof + nc));
+    UP_T(clocal, conv<T>(d->c_local, 3 * nc));
+    UP_T(cradius, conv<T>(d->c_radius, nc));
+    UP_T(cHinv, conv<T>(h12(d->c_plane_Hinv, nc).data(), 12 * nc));
+    UP_T(cplane, conv<T>(d->c_plane, 4 * nc));
+    std::vector<double> rz(9 * (size_t)nc, 0.0);
+    m.has_warm = 0;
+    for (int c = 0; c < nc; ++c) {
+        if (ctype[c] == ARB_CT_SOFTFINGER_PLANE) zaligned_host(d->c_plane + 4 * c, rz.data() + 9 * c);
+        if (ctype[c] == ARB_CT_BALLSOCKET) m.has_warm = 1;
+    }
+    UP_T(cRz, conv<T>(rz.data(), 9 * nc));
+    UP_T(cmu, conv<T>(d->c_mu, nc));
+    UP_T(cprox, conv<T>(d->c_prox, nc));
+    UP_T(ceps, conv<T>(d->c_eps, 3 * nc));
+    UP_T(cmin, conv<T>(d->c_min, nc));
+    UP_T(cmax, conv<T>(d->c_max, nc));
+    UP_T(cb0, conv<T>(h12(d->c_bpose0, nc).data(), 12 * nc));
+    UP_T(cb1, conv<T>(h12(d->c_bpose1, nc).data(), 12 * nc));
+#undef UP_I
+#undef UP_T
+    *out = m;
+    return ARB_OK;
+}
+
+extern "C" int arb_abi_version(void) { return ARB_ABI_VERSION; }
+
+extern "C" const char *arb_strerror(int status) {
+    switch (status) {
+        case ARB_OK: return "ok";
+        case ARB_ERR_INVALID: return "invalid argument";
+        case ARB_ERR_UNSUPPORTED: return "model not supported by the device step";
+        case ARB_ERR_HIP: return "HIP runtime error";
+        case ARB_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char *arb_last_hip_error(void) { return g_hip_err.c_str(); }
+
+static const int kNmaxChoices[] = {16, 32, 48, 64};
+
+extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model **out) {
+    if (d == nullptr || out == nullptr) return ARB_ERR_INVALID;
+    *out = nullptr;
+    if (d->abi_version != ARB_ABI_VERSION) return ARB_ERR_INVALID;
+    const int nb = d->nb, n = d->ndof, nc = d->nc;
+    if (nb <= 0 || n <= 0 || d->nq <= 0 || nc < 0) return ARB_ERR_INVALID;
+    if (!d->parent || !d->jtype || !d->dof_off || !d->q_off || !d->H_pr || !d->H_cn || !d->mass ||
+        !d->visc || !d->weighted)
+        return ARB_ERR_INVALID;
+    if (nc > 0 && (!d->ctype || !d->c_enabled || !d->c_body || !d->c_body0 || !d->c_dof || !d->c_local ||
+                   !d->c_radius || !d->c_plane_Hinv || !d->c_plane || !d->c_mu || !d->c_prox || !d->c_eps ||
+                   !d->c_min || !d->c_max || !d->c_bpose0 || !d->c_bpose1))
+        return ARB_ERR_INVALID;
+    if (n > WAVE || nb > WAVE || nc > WAVE) return ARB_ERR_UNSUPPORTED;   // one world per wavefront
+    const int ndol = ARB_MAXDOL * nc;
+    const int ncols = n + 1 + ndol;
+    if (ncols > 2 * WAVE || ndol > WAVE) return ARB_ERR_UNSUPPORTED;
+    // ---- tree bookkeeping (counterpart of World.init, core.py:608-635) ----
+    std::vector<int> jnd(nb), depth(nb), src(nb), sslot(nb, -1), lastchild(nb, -1);
+    std::vector<unsigned long long> anc(nb);
+    std::vector<int> dof2q(n, -1);
+    int maxdepth = 0, ndof_chk = 0, nq_chk = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int p = d->parent[b], jt = d->jtype[b];
+        if (p >= b || p < -1 || jt < 0 || jt > ARB_JT_TXTYTZ) return ARB_ERR_INVALID;
+        jnd[b] = joint_ndof(jt);
+        if (d->dof_off[b] != ndof_chk || d->q_off[b] != nq_chk) return ARB_ERR_INVALID;
+        ndof_chk += jnd[b]; nq_chk += joint_nq(jt);
+        depth[b] = (p < 0) ? 0 : depth[p] + 1;
+        maxdepth = std::max(maxdepth, depth[b]);
+        unsigned long long own = 0;
+        for (int i = 0; i < jnd[b]; ++i) own |= 1ull << (d->dof_off[b] + i);
+        anc[b] = own | (p < 0 ? 0ull : anc[p]);
+        if (p >= 0) lastchild[p] = b;
+        if (jt != ARB_JT_FREE)
+            for (int i = 0; i < jnd[b]; ++i) dof2q[d->dof_off[b] + i] = d->q_off[b] + i;
+    }
+    if (ndof_chk != n || nq_chk != d->nq) return ARB_ERR_INVALID;
+    // Jacobian save slots: a body whose columns are needed again after its first
+    // child's subtree keeps them in an LDS slot for the lifetime [b, lastchild[b]]
+    std::vector<int> slot_owner;
+    for (int b = 0; b < nb; ++b) {
+        const int p = d->parent[b];
+        if (p < 0) src[b] = 0;
+        else if (p == b - 1) src[b] = 1;
+        else src[b] = 2 + sslot[p];
+        bool need = false;
+        for (int c2 = b + 2; c2 < nb; ++c2) if (d->parent[c2] == b) need = true;
+        if (need) {
+            int s = -1;
+            for (size_t i = 0; i < slot_owner.size(); ++i)
+                if (lastchild[slot_owner[i]] <= b) { s = (int)i; break; }
+            if (s < 0) { s = (int)slot_owner.size(); slot_owner.push_back(b); } else slot_owner[s] = b;
+            sslot[b] = s;
+        }
+    }
+    for (int b = 0; b < nb; ++b) if (src[b] >= 2 && src[b] - 2 < 0) return ARB_ERR_INVALID;
+    const int nslots = (int)slot_owner.size();
+    // constraint attachments per body
+    std::vector<std::vector<std::pair<int, int>>> per_body(nb);
+    for (int c = 0; c < nc; ++c) {
+        const int ct = d->ctype[c];
+        if (ct == ARB_CT_SOFTFINGER_PLANE) {
+            if (d->c_body[c] < 0 || d->c_body[c] >= nb) return ARB_ERR_INVALID;
+            per_body[d->c_body[c]].push_back({c, 0});
+        } else if (ct == ARB_CT_BALLSOCKET) {
+            if (d->c_body[c] >= nb || d->c_body0[c] >= nb) return ARB_ERR_INVALID;
+            if (d->c_body[c] >= 0) per_body[d->c_body[c]].push_back({c, 1});
+            if (d->c_body0[c] >= 0) per_body[d->c_body0[c]].push_back({c, 2});
+        } else if (ct == ARB_CT_JOINTLIMITS) {
+            if (d->c_dof[c] < 0 || d->c_dof[c] >= n || dof2q[d->c_dof[c]] < 0) return ARB_ERR_INVALID;
+        } else {
+            return ARB_ERR_INVALID;
+        }
+    }
+    std::vector<int> att_start(nb + 1, 0), att_c, att_kind;
+    for (int b = 0; b < nb; ++b) {
+        att_start[b] = (int)att_c.size();
+        for (auto &pr : per_body[b]) { att_c.push_back(pr.first); att_kind.push_back(pr.second); }
+    }
+    att_start[nb] = (int)att_c.size();
+
+    arb_model *M = new (std::nothrow) arb_model();
+    if (!M) return ARB_ERR_NOMEM;
+    M->device = device;
+    M->nb = nb; M->n = n; M->nq = d->nq; M->nc = nc; M->ndol = ndol; M->ncols = ncols;
+    M->nsets = ncols > WAVE ? 2 : 1;
+    M->nmax = 64;
+    for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete M; return ARB_ERR_HIP; }
+    int rc = build_dev<float>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, &M->df);
+    if (rc == ARB_OK)
+        rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, &M->dd);
+    if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
+    int tot;
+    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, &tot);
+    M->ld = M->lf;
+    if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
+    *out = M;
+    return ARB_OK;
+}
+
+extern "C" int arb_model_destroy(arb_model *M) {
+    if (!M) return ARB_ERR_INVALID;
+    (void)hipSetDevice(M->device);
+    for (void *p : M->allocs) (void)hipFree(p);
+    delete M;
+    return ARB_OK;
+}
+
+extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
+    if (!M || !info) return ARB_ERR_INVALID;
+    info->nb = M->nb; info->ndof = M->n; info->nq = M->nq; info->nc = M->nc;
+    info->nmax = M->nmax; info->ncols = M->ncols; info->nsets = M->nsets;
+    info->lds_bytes_f32 = M->lf.total * (int)sizeof(float);
+    info->lds_bytes_f64 = M->ld.total * (int)sizeof(double);
+    info->device = M->device;
+    return ARB_OK;
+}
+
+template <typename T, int NMAX, int NSETS, int MODE>
+static int launch_one(const DevModel<T> &dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw, double dt,
+                      int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, hipStream_t st) {
+    auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
+    const size_t lds = (size_t)L.total * sizeof(T);
+    if (lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, nw, (T)dt, nsteps, flags, dbg, zmode);
+    HIP_TRY(hipGetLastError());
+    return ARB_OK;
+}
+
+template <typename T, int MODE>
+static int launch(arb_model *M, const DevModel<T> &dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw,
+                  double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, hipStream_t st) {
+#ifdef ARB_QUICK
+    // development build: a single instantiation (float, NMAX=48, one column set, production mode)
+    if constexpr (std::is_same<T, float>::value && MODE == 0) {
+        if (M->nmax == 48 && M->nsets == 1)
+            return launch_one<T, 48, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, st);
+    }
+    return ARB_ERR_UNSUPPORTED;
+#else
+#define CASE(NM)                                                                                                     \
+    case NM:                                                                                                         \
+        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, st) \
+                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, st);
+    switch (M->nmax) {
+        CASE(16) CASE(32) CASE(48) CASE(64)
+        default: return ARB_ERR_UNSUPPORTED;
+    }
+#undef CASE
+#endif
+}
+
+extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
+                        int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, void *stream) {
+    if (!M || !q || !dq || nworlds < 0 || nsteps < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
+    if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
+    if (nworlds == 0 || nsteps == 0) return ARB_OK;
+    if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
+    HIP_TRY(hipSetDevice(M->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == ARB_F32) {
+        DebugOut<float> dbg; memset(&dbg, 0, sizeof(dbg));
+        return launch<float, 0>(M, M->df, M->lf, (float *)q, (float *)dq, (float *)cforce, (const float *)ext_gforce,
+                                (long)nworlds, dt, nsteps, flags, dbg, 0, st);
+    }
+    DebugOut<double> dbg; memset(&dbg, 0, sizeof(dbg));
+    return launch<double, 0>(M, M->dd, M->ld, (double *)q, (double *)dq, (double *)cforce, (const double *)ext_gforce,
+                             (long)nworlds, dt, nsteps, flags, dbg, 0, st);
+}
+
+template <typename T>
+static int inspect_t(arb_model *M, const DevModel<T> &dm, const Layout &L, const void *q, const void *dq,
+                     const void *cforce, const void *ext, long nw, double dt, unsigned flags,
+                     const arb_inspect_out *o, hipStream_t st) {
+    DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
+    int rc;
+    // the three world matrices need one pass each (they share the accumulator registers)
+    struct { void *ptr; int zmode; } passes[3] = {{o->M, 1}, {o->B, 2}, {o->N, 3}};
+    for (auto &ps : passes) {
+        if (!ps.ptr) continue;
+        DebugOut<T> d1; memset(&d1, 0, sizeof(d1));
+        d1.Zout = (T *)ps.ptr;
+        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, d1, ps.zmode, st);
+        if (rc != ARB_OK) return rc;
+    }
+    dbg.pose = (T *)o->pose; dbg.twist = (T *)o->twist; dbg.jac = (T *)o->jac; dbg.djac = (T *)o->djac;
+    dbg.Zout = (T *)o->Z; dbg.gforce0 = (T *)o->gforce0; dbg.vel_free = (T *)o->vel_free;
+    dbg.c_sdist = (T *)o->c_sdist; dbg.c_active = (int *)o->c_active; dbg.c_jac = (T *)o->c_jac;
+    dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
+    dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next;
+    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, st);
+}
+
+extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,
+                           const void *ext_gforce, int64_t nworlds, double dt, uint32_t flags,
+                           const arb_inspect_out *out, void *stream) {
+    if (!M || !q || !dq || !out || nworlds < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
+    if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
+    if (out->gforce != nullptr && M->nc > 0 && out->c_jac == nullptr) return ARB_ERR_INVALID;
+    if (nworlds == 0) return ARB_OK;
+    if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
+    HIP_TRY(hipSetDevice(M->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == ARB_F32)
+        return inspect_t<float>(M, M->df, M->lf, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
+    return inspect_t<double>(M, M->dd, M->ld, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
+}
+
+// ---------------------------------------------------------------------------
+// Host-side self-test hooks: the device math of arb_math.h compiled for the host
+// (no GPU needed).  Used by the CPU test-suite to check the hand-written small
+// solvers (4x4 GEPP, 6x6 eigenvalues, SoftFingerContact.solve) against captured
+// reference tuples.
+// ---------------------------------------------------------------------------
+extern "C" int arb_host_softfinger_solve(int dtype, const double *vel, const double *adm, double *force,
+                                         double sdist, double dt, double mu, const double *eps, double *dforce) {
+    if (!vel || !adm || !force || !eps || !dforce) return -1;
+    if (dtype == ARB_F64) {
+        double P[16], work[36], f[4], df[4];
+        inv_block<double>(adm, 4, 4, P);
+        for (int i = 0; i < 4; ++i) f[i] = force[i];
+        int br = softfinger_solve<double>(vel, adm, P, f, df, sdist, dt, mu, eps, work);
+        for (int i = 0; i < 4; ++i) { force[i] = f[i]; dforce[i] = df[i]; }
+        return br;
+    }
+    float v[4], Y[16], P[16], work[36], f[4], df[4], e[3];
+    for (int i = 0; i < 4; ++i) { v[i] = (float)vel[i]; f[i] = (float)force[i]; }
+    for (int i = 0; i < 16; ++i) Y[i] = (float)adm[i];
+    for (int i = 0; i < 3; ++i) e[i] = (float)eps[i];
+    inv_block<float>(Y, 4, 4, P);
+    int br = softfinger_solve<float>(v, Y, P, f, df, (float)sdist, (float)dt, (float)mu, e, work);
+    for (int i = 0; i < 4; ++i) { force[i] = f[i]; dforce[i] = df[i]; }
+    return br;
+}
+
+extern "C" int arb_host_eig6(const double *A, double *wr, double *wi) {
+    double a[36];
+    for (int i = 0; i < 36; ++i) a[i] = A[i];
+    return eig6<double>(a, wr, wi);
+}
+
+extern "C" int arb_host_joint_local(int jt, const double *q, const double *dq, double *out /*[9+3+9+9+6]*/) {
+    JointLocal<double> jl;
+    joint_local<double>(jt, q, dq, jl);
+    for (int i = 0; i < 9; ++i) out[i] = jl.R.a[i];
+    out[9] = jl.p.x; out[10] = jl.p.y; out[11] = jl.p.z;
+    for (int i = 0; i < 3; ++i) { out[12 + 3 * i] = jl.jw[i].x; out[13 + 3 * i] = jl.jw[i].y; out[14 + 3 * i] = jl.jw[i].z; }
+    for (int i = 0; i < 3; ++i) { out[21 + 3 * i] = jl.djw[i].x; out[22 + 3 * i] = jl.djw[i].y; out[23 + 3 * i] = jl.djw[i].z; }
+    out[30] = jl.Tw.x; out[31] = jl.Tw.y; out[32] = jl.Tw.z; out[33] = jl.Tv.x; out[34] = jl.Tv.y; out[35] = jl.Tv.z;
+    return 0;
+}
+
+extern "C" int arb_host_exp_twist(const double *tw, double *H /*16*/) {
+    M3<double> R; V3<double> p;
+    exp_twist<double>(v3<double>(tw[0], tw[1], tw[2]), v3<double>(tw[3], tw[4], tw[5]), R, p);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) H[4 * i + j] = R.a[3 * i + j]; }
+    H[3] = p.x; H[7] = p.y; H[11] = p.z; H[12] = H[13] = H[14] = 0; H[15] = 1;
+    return 0;
+}

@@ -1,0 +1,562 @@
+// arb_math.h -- small fixed-size SE(3) / linear-algebra helpers shared by the
+// gfx950 kernels (arb_kernels.hip) and by the host-side self-test hooks.
+//
+// Everything here is scalar code on registers: in the kernels it runs either
+// once per lane with lane = body / lane = constraint (phase A), or wave-uniform
+// (Gauss-Seidel).  Conventions follow the reference: twists are [w; v],
+// Ad(R,p) = [[R,0],[p^R,R]] (arboris/homogeneousmatrix.py:277-319).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define ARB_HD __host__ __device__ __forceinline__
+#else
+#define ARB_HD inline
+#endif
+
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> struct M3 { T a[9]; };      // row-major
+
+template <typename T> ARB_HD V3<T> v3(T x, T y, T z) { V3<T> r; r.x = x; r.y = y; r.z = z; return r; }
+template <typename T> ARB_HD V3<T> operator+(V3<T> a, V3<T> b) { return v3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> ARB_HD V3<T> operator-(V3<T> a, V3<T> b) { return v3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename T> ARB_HD V3<T> operator-(V3<T> a) { return v3<T>(-a.x, -a.y, -a.z); }
+template <typename T> ARB_HD V3<T> operator*(T s, V3<T> a) { return v3<T>(s * a.x, s * a.y, s * a.z); }
+template <typename T> ARB_HD T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> ARB_HD V3<T> cross(V3<T> a, V3<T> b) {
+    return v3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename T> ARB_HD M3<T> m3_identity() {
+    M3<T> r; for (int i = 0; i < 9; ++i) r.a[i] = T(0); r.a[0] = r.a[4] = r.a[8] = T(1); return r;
+}
+template <typename T> ARB_HD M3<T> m3_zero() { M3<T> r; for (int i = 0; i < 9; ++i) r.a[i] = T(0); return r; }
+template <typename T> ARB_HD M3<T> mul(const M3<T> &A, const M3<T> &B) {          // A B
+    M3<T> r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.a[3 * i + j] = A.a[3 * i] * B.a[j] + A.a[3 * i + 1] * B.a[3 + j] + A.a[3 * i + 2] * B.a[6 + j];
+    return r;
+}
+template <typename T> ARB_HD M3<T> mulTA(const M3<T> &A, const M3<T> &B) {        // A^T B
+    M3<T> r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.a[3 * i + j] = A.a[i] * B.a[j] + A.a[3 + i] * B.a[3 + j] + A.a[6 + i] * B.a[6 + j];
+    return r;
+}
+template <typename T> ARB_HD M3<T> mulBT(const M3<T> &A, const M3<T> &B) {        // A B^T
+    M3<T> r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.a[3 * i + j] = A.a[3 * i] * B.a[3 * j] + A.a[3 * i + 1] * B.a[3 * j + 1] + A.a[3 * i + 2] * B.a[3 * j + 2];
+    return r;
+}
+template <typename T> ARB_HD M3<T> transpose(const M3<T> &A) {
+    M3<T> r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.a[3 * i + j] = A.a[3 * j + i];
+    return r;
+}
+template <typename T> ARB_HD M3<T> add(const M3<T> &A, const M3<T> &B) {
+    M3<T> r; for (int i = 0; i < 9; ++i) r.a[i] = A.a[i] + B.a[i]; return r;
+}
+template <typename T> ARB_HD M3<T> sub(const M3<T> &A, const M3<T> &B) {
+    M3<T> r; for (int i = 0; i < 9; ++i) r.a[i] = A.a[i] - B.a[i]; return r;
+}
+template <typename T> ARB_HD V3<T> mv(const M3<T> &A, V3<T> v) {                  // A v
+    return v3<T>(A.a[0] * v.x + A.a[1] * v.y + A.a[2] * v.z,
+                 A.a[3] * v.x + A.a[4] * v.y + A.a[5] * v.z,
+                 A.a[6] * v.x + A.a[7] * v.y + A.a[8] * v.z);
+}
+template <typename T> ARB_HD V3<T> mtv(const M3<T> &A, V3<T> v) {                 // A^T v
+    return v3<T>(A.a[0] * v.x + A.a[3] * v.y + A.a[6] * v.z,
+                 A.a[1] * v.x + A.a[4] * v.y + A.a[7] * v.z,
+                 A.a[2] * v.x + A.a[5] * v.y + A.a[8] * v.z);
+}
+template <typename T> ARB_HD M3<T> hat(V3<T> p) {                                  // p^
+    M3<T> r;
+    r.a[0] = T(0); r.a[1] = -p.z; r.a[2] = p.y;
+    r.a[3] = p.z; r.a[4] = T(0); r.a[5] = -p.x;
+    r.a[6] = -p.y; r.a[7] = p.x; r.a[8] = T(0);
+    return r;
+}
+template <typename T> ARB_HD M3<T> hatmul(V3<T> p, const M3<T> &R) {              // p^ R
+    M3<T> r;
+    for (int j = 0; j < 3; ++j) {
+        V3<T> c = cross(p, v3<T>(R.a[j], R.a[3 + j], R.a[6 + j]));
+        r.a[j] = c.x; r.a[3 + j] = c.y; r.a[6 + j] = c.z;
+    }
+    return r;
+}
+
+// A 6x6 matrix of the closed family [[A,0],[B,A]] (adjoints, ad-matrices and
+// their products all have this shape).
+template <typename T> struct Blk { M3<T> A, B; };
+template <typename T> ARB_HD Blk<T> blk_adjoint(const M3<T> &R, V3<T> p) {         // Ad(R,p)
+    Blk<T> r; r.A = R; r.B = hatmul(p, R); return r;
+}
+template <typename T> ARB_HD Blk<T> blk_adjacency(V3<T> w, V3<T> v) {              // ad([w;v]) twistvector.py:27-33
+    Blk<T> r; r.A = hat(w); r.B = hat(v); return r;
+}
+template <typename T> ARB_HD Blk<T> blk_mul(const Blk<T> &X, const Blk<T> &Y) {
+    Blk<T> r; r.A = mul(X.A, Y.A); r.B = add(mul(X.B, Y.A), mul(X.A, Y.B)); return r;
+}
+
+// ---------------------------------------------------------------------------
+// Joint-local kinematics, arboris/joints.py + homogeneousmatrix.py:11-199.
+// Rotational joints only have angular Jacobian columns (jw, djw); TxTyTz has
+// unit linear columns; the FreeJoint Jacobian is the identity.
+// ---------------------------------------------------------------------------
+enum { JT_FREE = 0, JT_RZRYRX, JT_RZRY, JT_RZRX, JT_RYRX, JT_RZ, JT_RY, JT_RX, JT_TXTYTZ };
+
+ARB_HD int joint_ndof(int jt) {
+    switch (jt) {
+        case JT_FREE: return 6;
+        case JT_RZRYRX: case JT_TXTYTZ: return 3;
+        case JT_RZRY: case JT_RZRX: case JT_RYRX: return 2;
+        default: return 1;
+    }
+}
+ARB_HD int joint_nq(int jt) { return jt == JT_FREE ? 16 : joint_ndof(jt); }
+
+ARB_HD float arb_abs(float x) { return x < 0.f ? -x : x; }
+ARB_HD double arb_abs(double x) { return x < 0. ? -x : x; }
+ARB_HD float arb_sqrt(float x) { return sqrtf(x); }
+ARB_HD double arb_sqrt(double x) { return sqrt(x); }
+ARB_HD void arb_sincos(float a, float *s, float *c) { *s = sinf(a); *c = cosf(a); }
+ARB_HD void arb_sincos(double a, double *s, double *c) { *s = sin(a); *c = cos(a); }
+
+template <typename T> struct JointLocal {
+    M3<T> R;          // rotation of H_rn
+    V3<T> p;          // translation of H_rn
+    V3<T> jw[3];      // angular part of Jacobian columns (rotational joints)
+    V3<T> djw[3];     // angular part of dJacobian columns
+    V3<T> Tw, Tv;     // T_nr = J_nr * gvel   (core.py:197-201; gvel itself for FreeJoint)
+};
+
+// q, dq point at the joint's own slice of the state.
+template <typename T, typename QP>
+ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
+    const T Z = T(0), O = T(1);
+    o.R = m3_identity<T>();
+    o.p = v3<T>(Z, Z, Z);
+    for (int i = 0; i < 3; ++i) { o.jw[i] = v3<T>(Z, Z, Z); o.djw[i] = v3<T>(Z, Z, Z); }
+    o.Tw = v3<T>(Z, Z, Z); o.Tv = v3<T>(Z, Z, Z);
+    switch (jt) {
+    case JT_FREE: {                                   // joints.py:10-57
+        o.R.a[0] = q[0]; o.R.a[1] = q[1]; o.R.a[2] = q[2]; o.p.x = q[3];
+        o.R.a[3] = q[4]; o.R.a[4] = q[5]; o.R.a[5] = q[6]; o.p.y = q[7];
+        o.R.a[6] = q[8]; o.R.a[7] = q[9]; o.R.a[8] = q[10]; o.p.z = q[11];
+        o.Tw = v3<T>(dq[0], dq[1], dq[2]);
+        o.Tv = v3<T>(dq[3], dq[4], dq[5]);
+    } break;
+    case JT_RZRYRX: {                                 // joints.py:59-104, rotzyx :34-59
+        T sz, cz, sy, cy, sx, cx;
+        arb_sincos(q[0], &sz, &cz); arb_sincos(q[1], &sy, &cy); arb_sincos(q[2], &sx, &cx);
+        o.R.a[0] = cz * cy; o.R.a[1] = cz * sy * sx - sz * cx; o.R.a[2] = cz * sy * cx + sz * sx;
+        o.R.a[3] = sz * cy; o.R.a[4] = sz * sy * sx + cz * cx; o.R.a[5] = sz * sy * cx - cz * sx;
+        o.R.a[6] = -sy;     o.R.a[7] = cy * sx;                o.R.a[8] = cy * cx;
+        o.jw[0] = v3<T>(-sy, sx * cy, cx * cy);
+        o.jw[1] = v3<T>(Z, cx, -sx);
+        o.jw[2] = v3<T>(O, Z, Z);
+        T dy = dq[1], dx = dq[2];
+        o.djw[0] = v3<T>(-dy * cy, dx * cx * cy - dy * sx * sy, -dx * sx * cy - dy * cx * sy);
+        o.djw[1] = v3<T>(Z, -dx * sx, -dx * cx);
+        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1] + dq[2] * o.jw[2];
+    } break;
+    case JT_RZRY: {                                   // joints.py:107-146, rotzy :60-80
+        T sz, cz, sy, cy;
+        arb_sincos(q[0], &sz, &cz); arb_sincos(q[1], &sy, &cy);
+        o.R.a[0] = cz * cy; o.R.a[1] = -sz; o.R.a[2] = cz * sy;
+        o.R.a[3] = sz * cy; o.R.a[4] = cz;  o.R.a[5] = sz * sy;
+        o.R.a[6] = -sy;     o.R.a[7] = Z;   o.R.a[8] = cy;
+        o.jw[0] = v3<T>(-sy, Z, cy);
+        o.jw[1] = v3<T>(Z, O, Z);
+        T dy = dq[1];
+        o.djw[0] = v3<T>(-dy * cy, Z, -dy * sy);
+        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1];
+    } break;
+    case JT_RZRX: {                                   // joints.py:149-185, rotzx :82-102
+        T sz, cz, sx, cx;
+        arb_sincos(q[0], &sz, &cz); arb_sincos(q[1], &sx, &cx);
+        o.R.a[0] = cz; o.R.a[1] = -sz * cx; o.R.a[2] = sz * sx;
+        o.R.a[3] = sz; o.R.a[4] = cz * cx;  o.R.a[5] = -cz * sx;
+        o.R.a[6] = Z;  o.R.a[7] = sx;       o.R.a[8] = cx;
+        o.jw[0] = v3<T>(Z, sx, cx);
+        o.jw[1] = v3<T>(O, Z, Z);
+        T dx = dq[1];
+        o.djw[0] = v3<T>(Z, dx * cx, -dx * sx);
+        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1];
+    } break;
+    case JT_RYRX: {                                   // joints.py:188-224, rotyx :104-124
+        T sy, cy, sx, cx;
+        arb_sincos(q[0], &sy, &cy); arb_sincos(q[1], &sx, &cx);
+        o.R.a[0] = cy;  o.R.a[1] = sy * sx; o.R.a[2] = sy * cx;
+        o.R.a[3] = Z;   o.R.a[4] = cx;      o.R.a[5] = -sx;
+        o.R.a[6] = -sy; o.R.a[7] = cy * sx; o.R.a[8] = cy * cx;
+        o.jw[0] = v3<T>(Z, cx, -sx);
+        o.jw[1] = v3<T>(O, Z, Z);
+        T dx = dq[1];
+        o.djw[0] = v3<T>(Z, -dx * sx, -dx * cx);
+        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1];
+    } break;
+    case JT_RZ: {                                     // joints.py:227-303
+        T s, c; arb_sincos(q[0], &s, &c);
+        o.R.a[0] = c; o.R.a[1] = -s; o.R.a[3] = s; o.R.a[4] = c;
+        o.jw[0] = v3<T>(Z, Z, O);
+        o.Tw = dq[0] * o.jw[0];
+    } break;
+    case JT_RY: {                                     // joints.py:305-326
+        T s, c; arb_sincos(q[0], &s, &c);
+        o.R.a[0] = c; o.R.a[2] = s; o.R.a[6] = -s; o.R.a[8] = c;
+        o.jw[0] = v3<T>(Z, O, Z);
+        o.Tw = dq[0] * o.jw[0];
+    } break;
+    case JT_RX: {                                     // joints.py:328-349
+        T s, c; arb_sincos(q[0], &s, &c);
+        o.R.a[4] = c; o.R.a[5] = -s; o.R.a[7] = s; o.R.a[8] = c;
+        o.jw[0] = v3<T>(O, Z, Z);
+        o.Tw = dq[0] * o.jw[0];
+    } break;
+    case JT_TXTYTZ: {                                 // joints.py:352-384
+        o.p = v3<T>(q[0], q[1], q[2]);
+        o.Tv = v3<T>(dq[0], dq[1], dq[2]);
+    } break;
+    default: break;
+    }
+}
+
+// SE(3) exponential, arboris/twistvector.py:35-70 (series below |w| = 1e-3).
+template <typename T>
+ARB_HD void exp_twist(V3<T> w, V3<T> v, M3<T> &R, V3<T> &p) {
+    T t = arb_sqrt(dot(w, w));
+    T cc, sc, dsc;
+    if (t >= T(0.001)) {
+        T s, c; arb_sincos(t, &s, &c);
+        cc = (T(1) - c) / (t * t);
+        sc = s / t;
+        dsc = (t - s) / (t * t * t);
+    } else {
+        cc = T(0.5);
+        sc = T(1) - t * t / T(6);
+        dsc = T(1) / T(6);
+    }
+    M3<T> wx = hat(w);
+    M3<T> wx2 = mul(wx, wx);
+    R = m3_identity<T>();
+    for (int i = 0; i < 9; ++i) R.a[i] += sc * wx.a[i] + cc * wx2.a[i];
+    // p = (sc I + cc w^ + dsc w w^T) v
+    V3<T> wv = cross(w, v);
+    T wdv = dot(w, v);
+    p = sc * v + cc * wv + (dsc * wdv) * w;
+}
+
+// ---------------------------------------------------------------------------
+// Small dense solvers (wave-uniform use in the Gauss-Seidel stage)
+// ---------------------------------------------------------------------------
+// Gaussian elimination with partial pivoting on a 4x4 system with NR right-hand
+// sides, fully unrolled (static indices only, so everything stays in registers).
+// Stands in for numpy.linalg.solve (constraints.py:834) and, for the
+// non-singular blocks met in practice, numpy.linalg.pinv (constraints.py:795).
+template <typename T, int NR>
+ARB_HD void gepp4(T A[4][4], T B[4][NR]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // pick the pivot row among c..3 and bubble it to row c
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            bool sw = arb_abs(A[r][c]) > arb_abs(A[c][c]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { T a = A[c][j], b = A[r][j]; A[c][j] = sw ? b : a; A[r][j] = sw ? a : b; }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) { T a = B[c][j], b = B[r][j]; B[c][j] = sw ? b : a; B[r][j] = sw ? a : b; }
+        }
+        T ip = T(1) / A[c][c];
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            T f = A[r][c] * ip;
+#pragma unroll
+            for (int j = c + 1; j < 4; ++j) A[r][j] -= f * A[c][j];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) B[r][j] -= f * B[c][j];
+        }
+    }
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+        T ip = T(1) / A[c][c];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            T s = B[c][j];
+#pragma unroll
+            for (int k = c + 1; k < 4; ++k) s -= A[c][k] * B[k][j];
+            B[c][j] = s * ip;
+        }
+    }
+}
+
+// Inverse of a ND x ND block (ND <= 4) embedded in a 4x4 identity.
+template <typename T>
+ARB_HD void inv_block(const T *Y, int ld, int nd, T P[16]) {
+    T A[4][4], B[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            A[i][j] = (i < nd && j < nd) ? Y[i * ld + j] : (i == j ? T(1) : T(0));
+            B[i][j] = (i == j) ? T(1) : T(0);
+        }
+    gepp4<T, 4>(A, B);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[4 * i + j] = B[i][j];
+}
+
+// Eigenvalues of a real 6x6 matrix: scaling balance + elimination to Hessenberg
+// form + Francis double-shift QR (the classic EISPACK balanc/elmhes/hqr
+// sequence; LAPACK's dgeev, which numpy.linalg.eigvals calls at
+// constraints.py:825, is the same family of algorithm).  `a` is a row-major 6x6
+// work array addressed dynamically (it lives in LDS in the kernel).  Returns the
+// number of eigenvalues found (6 unless the iteration failed to converge).
+template <typename T, typename AP>
+ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
+    const int n = 6;
+#define E_(i, j) a[(i) * 6 + (j)]
+    // --- balance (powers of 2 only, exact) ---
+    {
+        const T RADIX = T(2), sqrdx = T(4);
+        bool last = false;
+        int guard = 0;
+        while (!last && guard++ < 64) {
+            last = true;
+            for (int i = 0; i < n; ++i) {
+                T r = T(0), c = T(0);
+                for (int j = 0; j < n; ++j)
+                    if (j != i) { c += arb_abs(E_(j, i)); r += arb_abs(E_(i, j)); }
+                if (c != T(0) && r != T(0)) {
+                    T g = r / RADIX, f = T(1), s = c + r;
+                    while (c < g) { f *= RADIX; c *= sqrdx; }
+                    g = r * RADIX;
+                    while (c > g) { f /= RADIX; c /= sqrdx; }
+                    if ((c + r) / f < T(0.95) * s) {
+                        last = false;
+                        g = T(1) / f;
+                        for (int j = 0; j < n; ++j) E_(i, j) *= g;
+                        for (int j = 0; j < n; ++j) E_(j, i) *= f;
+                    }
+                }
+            }
+        }
+    }
+    // --- reduction to upper Hessenberg form by stabilised elimination ---
+    for (int m = 1; m < n - 1; ++m) {
+        T x = T(0);
+        int i = m;
+        for (int j = m; j < n; ++j)
+            if (arb_abs(E_(j, m - 1)) > arb_abs(x)) { x = E_(j, m - 1); i = j; }
+        if (i != m) {
+            for (int j = m - 1; j < n; ++j) { T t = E_(i, j); E_(i, j) = E_(m, j); E_(m, j) = t; }
+            for (int j = 0; j < n; ++j) { T t = E_(j, i); E_(j, i) = E_(j, m); E_(j, m) = t; }
+        }
+        if (x != T(0)) {
+            for (i = m + 1; i < n; ++i) {
+                T y = E_(i, m - 1);
+                if (y != T(0)) {
+                    y /= x;
+                    E_(i, m - 1) = y;
+                    for (int j = m; j < n; ++j) E_(i, j) -= y * E_(m, j);
+                    for (int j = 0; j < n; ++j) E_(j, m) += y * E_(j, i);
+                }
+            }
+        }
+    }
+    for (int i = 2; i < n; ++i)
+        for (int j = 0; j < i - 1; ++j) E_(i, j) = T(0);
+    // --- shifted QR on the Hessenberg matrix ---
+    T anorm = T(0);
+    for (int i = 0; i < n; ++i)
+        for (int j = (i > 0 ? i - 1 : 0); j < n; ++j) anorm += arb_abs(E_(i, j));
+    int nn = n - 1, found = 0;
+    T t = T(0);
+    T p = T(0), q = T(0), r = T(0);
+    while (nn >= 0) {
+        int its = 0, l;
+        do {
+            for (l = nn; l >= 1; --l) {
+                T s = arb_abs(E_(l - 1, l - 1)) + arb_abs(E_(l, l));
+                if (s == T(0)) s = anorm;
+                if ((T)(arb_abs(E_(l, l - 1)) + s) == s) { E_(l, l - 1) = T(0); break; }
+            }
+            T x = E_(nn, nn);
+            if (l == nn) {                              // one real root
+                wr[nn] = x + t; wi[nn] = T(0); --nn; ++found;
+            } else {
+                T y = E_(nn - 1, nn - 1);
+                T w = E_(nn, nn - 1) * E_(nn - 1, nn);
+                if (l == nn - 1) {                      // a 2x2 block: two roots
+                    p = T(0.5) * (y - x);
+                    q = p * p + w;
+                    T z = arb_sqrt(arb_abs(q));
+                    x += t;
+                    if (q >= T(0)) {
+                        z = p + (p >= T(0) ? arb_abs(z) : -arb_abs(z));
+                        wr[nn - 1] = wr[nn] = x + z;
+                        if (z != T(0)) wr[nn] = x - w / z;
+                        wi[nn - 1] = wi[nn] = T(0);
+                    } else {
+                        wr[nn - 1] = wr[nn] = x + p;
+                        wi[nn] = z; wi[nn - 1] = -z;
+                    }
+                    nn -= 2; found += 2;
+                } else {
+                    if (its >= 60) return found;        // no convergence
+                    if (its == 10 || its == 20) {       // exceptional shift
+                        t += x;
+                        for (int i = 0; i <= nn; ++i) E_(i, i) -= x;
+                        T s = arb_abs(E_(nn, nn - 1)) + arb_abs(E_(nn - 1, nn - 2));
+                        y = x = T(0.75) * s;
+                        w = T(-0.4375) * s * s;
+                    }
+                    ++its;
+                    int m;
+                    T z;
+                    for (m = nn - 2; m >= l; --m) {
+                        z = E_(m, m);
+                        r = x - z;
+                        T s = y - z;
+                        p = (r * s - w) / E_(m + 1, m) + E_(m, m + 1);
+                        q = E_(m + 1, m + 1) - z - r - s;
+                        r = E_(m + 2, m + 1);
+                        s = arb_abs(p) + arb_abs(q) + arb_abs(r);
+                        p /= s; q /= s; r /= s;
+                        if (m == l) break;
+                        T u = arb_abs(E_(m, m - 1)) * (arb_abs(q) + arb_abs(r));
+                        T v = arb_abs(p) * (arb_abs(E_(m - 1, m - 1)) + arb_abs(z) + arb_abs(E_(m + 1, m + 1)));
+                        if ((T)(u + v) == v) break;
+                    }
+                    for (int i = m + 2; i <= nn; ++i) {
+                        E_(i, i - 2) = T(0);
+                        if (i != m + 2) E_(i, i - 3) = T(0);
+                    }
+                    for (int k = m; k <= nn - 1; ++k) {
+                        if (k != m) {
+                            p = E_(k, k - 1);
+                            q = E_(k + 1, k - 1);
+                            r = T(0);
+                            if (k != nn - 1) r = E_(k + 2, k - 1);
+                            x = arb_abs(p) + arb_abs(q) + arb_abs(r);
+                            if (x != T(0)) { p /= x; q /= x; r /= x; }
+                        }
+                        T s = arb_sqrt(p * p + q * q + r * r);
+                        if (p < T(0)) s = -s;
+                        if (s != T(0)) {
+                            if (k == m) {
+                                if (l != m) E_(k, k - 1) = -E_(k, k - 1);
+                            } else {
+                                E_(k, k - 1) = -s * x;
+                            }
+                            p += s;
+                            x = p / s; y = q / s; z = r / s;
+                            q /= p; r /= p;
+                            for (int j = k; j <= nn; ++j) {
+                                p = E_(k, j) + q * E_(k + 1, j);
+                                if (k != nn - 1) { p += r * E_(k + 2, j); E_(k + 2, j) -= p * z; }
+                                E_(k + 1, j) -= p * y;
+                                E_(k, j) -= p * x;
+                            }
+                            int mmin = nn < k + 3 ? nn : k + 3;
+                            for (int i = l; i <= mmin; ++i) {
+                                p = x * E_(i, k) + y * E_(i, k + 1);
+                                if (k != nn - 1) { p += z * E_(i, k + 2); E_(i, k + 2) -= p * r; }
+                                E_(i, k + 1) -= p * q;
+                                E_(i, k) -= p;
+                            }
+                        }
+                    }
+                }
+            }
+        } while (l < nn - 1);
+    }
+#undef E_
+    return found;
+}
+
+// ---------------------------------------------------------------------------
+// SoftFingerContact.solve, arboris/constraints.py:780-836, including the
+// reference's scalar arithmetic in the sliding branch (its dot() of 1-D arrays).
+//   v[4], Y[16] (row-major block of the constraint admittance), f[4] current
+//   force, P[16] = inverse of Y (computed once per step), work = 36-element
+//   scratch for the eigenvalue problem.
+// Writes the new force into f and returns the force increment in df.
+// Returns the branch taken: 0 release, 1 static, 2 sliding.
+// ---------------------------------------------------------------------------
+template <typename T, typename AP>
+ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], T df[4],
+                            T sdist, T dt, T mu, const T eps[3], AP work) {
+    T v0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v0[i] = v[i] - (Y[4 * i] * f[0] + Y[4 * i + 1] * f[1] + Y[4 * i + 2] * f[2] + Y[4 * i + 3] * f[3]);
+    if (sdist + dt * v0[3] > T(0)) {                    // constraints.py:781-785
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { df[i] = -f[i]; f[i] = T(0); }
+        return 0;
+    }
+    T tgt[4] = {v[0], v[1], v[2], v[3] + sdist / dt};   // constraints.py:795-797
+    T fn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        df[i] = -(P[4 * i] * tgt[0] + P[4 * i + 1] * tgt[1] + P[4 * i + 2] * tgt[2] + P[4 * i + 3] * tgt[3]);
+        fn[i] = f[i] + df[i];
+    }
+    T lhs = (fn[0] / eps[0]) * (fn[0] / eps[0]) + (fn[1] / eps[1]) * (fn[1] / eps[1])
+          + (fn[2] / eps[2]) * (fn[2] / eps[2]);
+    T rhs = (fn[3] * mu) * (fn[3] * mu);
+    if (lhs <= rhs) {                                   // constraints.py:799-802
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = fn[i];
+        return 1;
+    }
+    // sliding, constraints.py:803-836
+    T alpha[4] = {v0[0], v0[1], v0[2], v0[3] + sdist / dt};
+    T Yc[3] = {Y[3], Y[7], Y[11]};
+    T yn = Y[15];
+    T beta[3], b[3];
+    T a = mu / yn * alpha[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { beta[i] = alpha[i] - alpha[3] / yn * Yc[i]; b[i] = mu / yn * Yc[i]; }
+    T e2[3] = {eps[0] * eps[0], eps[1] * eps[1], eps[2] * eps[2]};
+    T ycyc = Yc[0] * Yc[0] + Yc[1] * Yc[1] + Yc[2] * Yc[2];     // dot(Y_c, Y_c.T): a scalar
+    T bb = beta[0] * b[0] + beta[1] * b[1] + beta[2] * b[2];     // dot(beta, b.T)
+    T b2 = beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2];
+    T bsq = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            T yhat = Y[4 * i + j] - ycyc / yn;                   // scalar subtracted from every entry
+            work[(3 + i) * 6 + (3 + j)] = e2[i] * yhat;
+            work[i * 6 + j] = e2[i] * (yhat + T(2) / a * bb);
+            work[i * 6 + (3 + j)] = (i == j) ? -(e2[i] * (b2 / (a * a))) : T(0);
+            work[(3 + i) * 6 + j] = (i == j) ? (e2[i] * bsq - T(1)) : T(0);
+        }
+    T wr[6], wi[6];
+    int nf = eig6<T>(work, wr, wi);
+    bool any = false;
+    T smin = T(0);
+    for (int i = 0; i < 6; ++i) {
+        bool ok = (i >= 6 - nf) && (wi[i] == T(0)) && (wr[i] <= T(0));
+        if (ok) { smin = any ? (wr[i] < smin ? wr[i] : smin) : wr[i]; any = true; }
+    }
+    T s = any ? (smin > T(-1e10) ? smin : T(-1e10)) : T(-1e10);   // constraints.py:827-830
+    T A[4][4], Bv[4][1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[i][j] = Y[4 * i + j];
+        Bv[i][0] = -alpha[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) A[i][i] -= s / e2[i];              // s * diag(eps**-2)
+    gepp4<T, 1>(A, Bv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { df[i] = Bv[i][0] - f[i]; f[i] = Bv[i][0]; }
+    return 2;
+}

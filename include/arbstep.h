@@ -1,0 +1,195 @@
+/*
+ * arbstep.h -- C ABI of libarbstep.so, the MI355X (gfx950) batched rigid-body step.
+ *
+ * The reference (sbarthelemy/arboris-python) is pure Python: it has no FFI, no
+ * operator registry and no native boundary.  Its "plugin API" is the set of
+ * World/Body/Joint/Constraint/Controller classes of arboris/core.py, and its hot
+ * path is the loop body of core.simulate (arboris/core.py:1356-1363):
+ *
+ *     world.update_dynamic()        core.py:682-734  (+ Body.update_dynamic :1158-1315)
+ *     world.update_controllers(dt)  core.py:811-818  (+ controllers.py:43-60, 141-158)
+ *     world.update_constraints(dt)  core.py:910-937  (+ constraints.py, collisions.py)
+ *     world.integrate(dt)           core.py:974-980  (+ joints.py:54-57, core.py:238-240)
+ *
+ * This header is therefore the boundary a maintainer would bind from a re-authored
+ * `World` (see INTEGRATION.md for the ctypes stub): the world tree is flattened
+ * once (arb_model_desc, the counterpart of World.init core.py:608-635) and the
+ * four calls above become one arb_step() over a batch of independent worlds.
+ *
+ * Conventions
+ *   - plain C, every entry point returns an int status (ARB_OK == 0) and never
+ *     throws; arb_strerror() describes a status.
+ *   - the caller owns all state buffers and passes DEVICE pointers (e.g. from
+ *     torch.Tensor.data_ptr()); the library keeps only the immutable model.
+ *   - calls are asynchronous with respect to `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream); there is no hidden synchronisation.
+ *   - one model handle per device; calls on different handles are re-entrant.
+ *   - twists/wrenches are ordered [angular; linear]; matrices are row-major.
+ *
+ * State layout (world-major): q[nworlds][nq], dq[nworlds][ndof].  q is the
+ * concatenation, in depth-first joint order, of each joint's gpos; a FreeJoint
+ * stores its 4x4 pose (16 scalars, joints.py:26-31).  dq is World._gvel.
+ */
+#ifndef ARBSTEP_H
+#define ARBSTEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARB_ABI_VERSION 1
+
+/* status codes */
+enum {
+    ARB_OK = 0,
+    ARB_ERR_INVALID = 1,      /* bad argument (null pointer, negative size, bad enum) */
+    ARB_ERR_UNSUPPORTED = 2,  /* model outside what the kernels handle (ndof > 64 ...) */
+    ARB_ERR_HIP = 3,          /* a HIP runtime call failed (see arb_last_hip_error) */
+    ARB_ERR_NOMEM = 4
+};
+
+/* scalar type of the state buffers and of the arithmetic */
+enum { ARB_F32 = 0, ARB_F64 = 1 };
+
+/* joint types, arboris/joints.py (ids shared with arboris_python_amd/flatten.py) */
+enum {
+    ARB_JT_FREE = 0,     /* joints.py:10-57   */
+    ARB_JT_RZRYRX = 1,   /* joints.py:59-104  */
+    ARB_JT_RZRY = 2,     /* joints.py:107-146 */
+    ARB_JT_RZRX = 3,     /* joints.py:149-185 */
+    ARB_JT_RYRX = 4,     /* joints.py:188-224 */
+    ARB_JT_RZ = 5,       /* joints.py:227-303 */
+    ARB_JT_RY = 6,       /* joints.py:305-326 */
+    ARB_JT_RX = 7,       /* joints.py:328-349 */
+    ARB_JT_TXTYTZ = 8    /* joints.py:352-384 */
+};
+
+/* constraint types, arboris/constraints.py */
+enum {
+    ARB_CT_SOFTFINGER_PLANE = 0, /* SoftFingerContact :300-836 on (Plane on ground, Point|Sphere on body),
+                                    collisions.py:161-205 */
+    ARB_CT_JOINTLIMITS = 1,      /* JointLimits :15-90 */
+    ARB_CT_BALLSOCKET = 2        /* BallAndSocketConstraint :92-237 */
+};
+
+#define ARB_MAXDOL 4   /* rows reserved per constraint in cforce / contact outputs */
+
+/* arb_step flags */
+#define ARB_STEP_SKIP_CONSTRAINTS 1u  /* integrate with controller forces only */
+
+/*
+ * Flattened world (host pointers, copied by arb_model_create).  Bodies are the
+ * moving bodies in depth-first order (DOF numbering of core.py:611-615); body b
+ * is attached to parent[b] (-1 = ground) through one joint.
+ */
+typedef struct arb_model_desc {
+    int32_t abi_version;      /* ARB_ABI_VERSION */
+    int32_t nb, ndof, nq, nc;
+    const int32_t *parent;    /* [nb] */
+    const int32_t *jtype;     /* [nb] ARB_JT_* */
+    const int32_t *dof_off;   /* [nb] first dof of the joint */
+    const int32_t *q_off;     /* [nb] first position scalar of the joint */
+    const double *H_pr;       /* [nb][16] joint.frames[0].bpose (core.py:1295-1296) */
+    const double *H_cn;       /* [nb][16] joint.frames[1].bpose */
+    const double *mass;       /* [nb][36] Body.mass */
+    const double *visc;       /* [nb][36] Body.viscosity */
+    const int32_t *weighted;  /* [nb] body is acted on by the WeightController (controllers.py:37) */
+    double gravity[3];        /* sum over WeightControllers of gravity*up (controllers.py:40-41) */
+    /* merged ProportionalDerivativeControllers (controllers.py:141-158), or NULL:
+       gforce += pd_tau0 - pd_kp q ;  Z += dt*pd_kp + pd_kd   (dof-indexed, row-major) */
+    const double *pd_kp;      /* [ndof][ndof] */
+    const double *pd_kd;      /* [ndof][ndof] */
+    const double *pd_tau0;    /* [ndof] */
+    /* constraints in registration order (core.py:913, 933) */
+    const int32_t *ctype;     /* [nc] ARB_CT_* */
+    const int32_t *c_enabled; /* [nc] Constraint.is_enabled() */
+    const int32_t *c_body;    /* [nc] body of frame 1 (contact point / socket ball), -1 = ground */
+    const int32_t *c_body0;   /* [nc] BallAndSocket: body of frame 0, -1 = ground */
+    const int32_t *c_dof;     /* [nc] JointLimits: constrained dof */
+    const double *c_local;    /* [nc][3] contact point in its body frame */
+    const double *c_radius;   /* [nc] sphere radius (0 for a Point) */
+    const double *c_plane_Hinv; /* [nc][16] inverse pose of the plane frame */
+    const double *c_plane;    /* [nc][4] plane coefficients (unit normal, d) */
+    const double *c_mu;       /* [nc] friction coefficient */
+    const double *c_prox;     /* [nc] proximity (contacts, joint limits) */
+    const double *c_eps;      /* [nc][3] SoftFingerContact._eps */
+    const double *c_min;      /* [nc] JointLimits */
+    const double *c_max;      /* [nc] JointLimits */
+    const double *c_bpose0;   /* [nc][16] BallAndSocket frame 0 bpose */
+    const double *c_bpose1;   /* [nc][16] BallAndSocket frame 1 bpose */
+} arb_model_desc;
+
+typedef struct arb_model arb_model;   /* opaque, device-resident immutable model */
+
+typedef struct arb_model_info {
+    int32_t nb, ndof, nq, nc;
+    int32_t nmax;             /* register-tile height the kernels were instantiated for */
+    int32_t ncols;            /* ndof + 1 + ARB_MAXDOL*nc columns of the augmented system */
+    int32_t nsets;            /* 1 or 2 register column sets */
+    int32_t lds_bytes_f32;    /* dynamic LDS per world (= per wavefront) */
+    int32_t lds_bytes_f64;
+    int32_t device;
+} arb_model_info;
+
+/*
+ * Optional per-stage outputs of arb_inspect (device pointers, any may be NULL).
+ * They expose what the reference leaves on its objects after each of the four
+ * calls, for parity tests and for the single-world object API.
+ */
+typedef struct arb_inspect_out {
+    void *pose;      /* [nw][nb][16]       Body.pose                         core.py:1272 */
+    void *twist;     /* [nw][nb][6]        Body.twist                        core.py:1275 */
+    void *jac;       /* [nw][nb][6][ndof]  Body.jacobian                     core.py:1273 */
+    void *djac;      /* [nw][nb][6][ndof]  Body.djacobian                    core.py:1274 */
+    void *M;         /* [nw][ndof][ndof]   World.mass                        core.py:726-728 */
+    void *B;         /* [nw][ndof][ndof]   World.viscosity                   core.py:729-731 */
+    void *N;         /* [nw][ndof][ndof]   World.nleffects                   core.py:732-734 */
+    void *Z;         /* [nw][ndof][ndof]   World._impedance                  core.py:813-817 */
+    void *gforce0;   /* [nw][ndof]         controllers' gforce               core.py:812-816 */
+    void *vel_free;  /* [nw][ndof]         Y (M gvel/dt + gforce0): new gvel without constraints */
+    void *c_sdist;   /* [nw][nc]           PointContact._sdist / |p_01| ...  constraints.py:293 */
+    void *c_active;  /* [nw][nc] int32     Constraint.is_active()            core.py:916 */
+    void *c_jac;     /* [nw][nc][4][ndof]  Constraint.jacobian (0 if inactive) core.py:923 */
+    void *c_force;   /* [nw][nc][4]        Constraint._force after the 20 sweeps  core.py:929-935 */
+    void *c_frame;   /* [nw][nc][2][16]    contact frame poses H_gc0, H_gc1  constraints.py:284-288 */
+    void *gforce;    /* [nw][ndof]         World._gforce incl. constraints   core.py:936-937 */
+    void *q_next;    /* [nw][nq]           state after integrate             core.py:974-980 */
+    void *dq_next;   /* [nw][ndof] */
+} arb_inspect_out;
+
+int arb_abi_version(void);
+const char *arb_strerror(int status);
+const char *arb_last_hip_error(void);
+
+/* Build the device-resident model on HIP device `device`. Replaces World.init
+ * (core.py:608-635) + the per-step reads of the object graph. */
+int arb_model_create(const arb_model_desc *desc, int device, arb_model **out);
+int arb_model_destroy(arb_model *m);
+int arb_model_get_info(const arb_model *m, arb_model_info *info);
+
+/*
+ * Advance `nworlds` independent worlds by `nsteps` steps of `dt`, in place.
+ * Replaces nsteps iterations of core.py:1358-1363 (without observers).
+ *   q, dq    device, dtype-typed, [nworlds][nq] / [nworlds][ndof], updated in place
+ *   cforce   device [nworlds][nc][ARB_MAXDOL] or NULL: constraint forces; read as the
+ *            warm start of BallAndSocket constraints and written back after the
+ *            last step (contact / joint-limit forces of that step)
+ *   ext_gforce  device [nworlds][ndof] or NULL: extra generalized force with zero
+ *            impedance, constant over the call (a user torque Controller)
+ */
+int arb_step(arb_model *m, int dtype, void *q, void *dq, void *cforce,
+             const void *ext_gforce, int64_t nworlds, double dt, int32_t nsteps,
+             uint32_t flags, void *stream);
+
+/* Evaluate one step WITHOUT modifying q/dq and write the requested intermediate
+ * results.  Same arithmetic as arb_step (same kernels, debug stores enabled). */
+int arb_inspect(arb_model *m, int dtype, const void *q, const void *dq,
+                const void *cforce, const void *ext_gforce, int64_t nworlds, double dt,
+                uint32_t flags, const arb_inspect_out *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARBSTEP_H */

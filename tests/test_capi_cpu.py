@@ -1,0 +1,152 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/arbstep.h declares, validates its arguments, and its device math
+(compiled for the host through the self-test hooks) reproduces the reference's
+captured SoftFingerContact.solve tuples.  No GPU compute is launched here.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, load_model
+from arboris_python_amd import _capi
+
+needs_lib = pytest.mark.skipif(not os.path.exists(_capi.LIB_PATH),
+                               reason="libarbstep.so not built (run __graft_entry__.build())")
+
+
+@needs_lib
+def test_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "arbstep.h")).read()
+    declared = set(re.findall(r"\b(arb_[a-z_0-9]+)\s*\(", header))
+    declared -= {"arb_model_desc", "arb_inspect_out", "arb_model_info"}
+    assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
+    lib = C.CDLL(_capi.LIB_PATH)
+    for name in _capi.EXPORTED + _capi.TEST_HOOKS:
+        assert hasattr(lib, name), name
+    assert _capi.load().arb_abi_version() == _capi.ARB_ABI_VERSION
+    assert _capi.load().arb_strerror(0) == b"ok"
+
+
+@needs_lib
+def test_argument_validation_without_gpu():
+    lib = _capi.load()
+    h = C.c_void_p()
+    assert lib.arb_model_create(None, 0, C.byref(h)) == 1          # ARB_ERR_INVALID
+    m, _, _ = load_model("human36_c4")
+    desc, keep = _capi.make_desc(m)
+    desc.abi_version = 99
+    assert lib.arb_model_create(C.byref(desc), 0, C.byref(h)) == 1
+    assert lib.arb_step(None, 0, None, None, None, None, 1, 1e-3, 1, 0, None) == 1
+    assert lib.arb_model_destroy(None) == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libarbstep.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _capi.load()
+
+
+def test_world_step_without_gpu_raises():
+    """The object API never falls back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from arboris_python_amd.core import simplearm
+    w = simplearm()
+    with pytest.raises(RuntimeError):
+        w.update_dynamic()
+
+
+@needs_lib
+@pytest.mark.parametrize("branch,code", [("release", 0), ("static", 1), ("sliding", 2)])
+def test_device_softfinger_solve_on_host(branch, code):
+    """arb_math.h::softfinger_solve (float64, host build) vs the reference's
+    captured solve() tuples, incl. the sliding branch's 6x6 eigenvalues."""
+    lib = _capi.load()
+    g = load_golden("g3_contacts.npz")
+    n = len(g["solve_%s_dt" % branch])
+    worst = 0.
+    for i in range(n):
+        vel = np.ascontiguousarray(g["solve_%s_vel" % branch][i])
+        adm = np.ascontiguousarray(g["solve_%s_adm" % branch][i])
+        f = np.ascontiguousarray(g["solve_%s_force" % branch][i].copy())
+        df = np.zeros(4)
+        eps = np.ones(3)
+        br = lib.arb_host_softfinger_solve(_capi.ARB_F64, _capi._dp(vel), _capi._dp(adm), _capi._dp(f),
+                                           float(g["solve_%s_sdist" % branch][i]),
+                                           float(g["solve_%s_dt" % branch][i]),
+                                           float(g["solve_%s_mu" % branch][i]), _capi._dp(eps), _capi._dp(df))
+        assert br == code
+        ref = g["solve_%s_dforce" % branch][i]
+        worst = max(worst, np.abs(df - ref).max() / max(1., np.abs(ref).max()))
+    assert worst < 1e-8, worst
+
+
+@needs_lib
+def test_device_softfinger_solve_float32_on_host():
+    lib = _capi.load()
+    g = load_golden("g3_contacts.npz")
+    worst = 0.
+    for branch, code in (("static", 1), ("sliding", 2)):
+        for i in range(len(g["solve_%s_dt" % branch])):
+            vel = np.ascontiguousarray(g["solve_%s_vel" % branch][i])
+            adm = np.ascontiguousarray(g["solve_%s_adm" % branch][i])
+            f = np.ascontiguousarray(g["solve_%s_force" % branch][i].copy())
+            df = np.zeros(4)
+            eps = np.ones(3)
+            br = lib.arb_host_softfinger_solve(_capi.ARB_F32, _capi._dp(vel), _capi._dp(adm), _capi._dp(f),
+                                               float(g["solve_%s_sdist" % branch][i]),
+                                               float(g["solve_%s_dt" % branch][i]),
+                                               float(g["solve_%s_mu" % branch][i]), _capi._dp(eps), _capi._dp(df))
+            ref = g["solve_%s_dforce" % branch][i]
+            if br == code:          # a float32 borderline case may legitimately flip branch
+                worst = max(worst, np.abs(df - ref).max() / max(1., np.abs(ref).max()))
+    assert worst < 5e-3, worst
+
+
+@needs_lib
+def test_device_eig6_on_host():
+    lib = _capi.load()
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        A = rng.normal(size=(6, 6))
+        wr, wi = np.zeros(6), np.zeros(6)
+        assert lib.arb_host_eig6(_capi._dp(np.ascontiguousarray(A)), _capi._dp(wr), _capi._dp(wi)) == 6
+        ref = np.linalg.eigvals(A)
+        got = wr + 1j * wi
+        for lam in ref:
+            assert np.min(np.abs(got - lam)) < 1e-9 * max(1, abs(lam))
+
+
+@needs_lib
+@pytest.mark.parametrize("tid", range(9))
+def test_device_joint_local_on_host(tid):
+    lib = _capi.load()
+    g = load_golden("g0_primitives.npz")
+    for q, dq, pose, jac, djac, tw in zip(g["joint%d_q" % tid], g["joint%d_dq" % tid],
+                                          g["joint%d_pose" % tid], g["joint%d_jac" % tid],
+                                          g["joint%d_djac" % tid], g["joint%d_twist" % tid]):
+        out = np.zeros(36)
+        lib.arb_host_joint_local(tid, _capi._dp(np.ascontiguousarray(q)),
+                                 _capi._dp(np.ascontiguousarray(dq)), _capi._dp(out))
+        assert np.abs(out[0:9].reshape(3, 3) - pose[0:3, 0:3]).max() < 1e-14
+        assert np.abs(out[9:12] - pose[0:3, 3]).max() < 1e-14
+        assert np.abs(out[30:36] - tw).max() < 1e-13
+        if tid not in (0, 8):
+            k = jac.shape[1]
+            assert np.abs(out[12:21].reshape(3, 3)[:k].T - jac[0:3]).max() < 1e-14
+            assert np.abs(out[21:30].reshape(3, 3)[:k].T - djac[0:3]).max() < 1e-14
+
+
+@needs_lib
+def test_device_exp_twist_on_host():
+    lib = _capi.load()
+    g = load_golden("g0_primitives.npz")
+    for tw, H in zip(g["tw"], g["tw_exp"]):
+        out = np.zeros(16)
+        lib.arb_host_exp_twist(_capi._dp(np.ascontiguousarray(tw)), _capi._dp(out))
+        assert np.abs(out.reshape(4, 4) - H).max() < 1e-12
