@@ -44,14 +44,15 @@
 #define BD_PCP 9     // p of Ad_cp (3)
 #define BD_DA 12     // A block of dAd_cp (9)
 #define BD_DB 21     // B block of dAd_cp (9)
-#define BD_PT 30     // M_b T_b (6)
+#define BD_PT 30     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form
 #define BD_PG 36     // M_b g_b (6)
 #define BD_CM 42     // rx wx - wx rx (9), core.py:1287
 #define BD_W 51      // body angular velocity (3)
 #define BD_RG 54     // R of H_gb (9)
 #define BD_PGB 63    // p of H_gb (3)
 #define BD_TW 66     // body twist (6)
-#define BD_STRIDE 72
+#define BD_AB 72     // bias acceleration dJ_b * gvel (6)
+#define BD_STRIDE 80
 
 // per-constraint block in LDS (elements)
 #define CD_R1 0      // transform body1 -> constraint frame: R (9), p (3)
@@ -67,7 +68,7 @@
 #define CD_STRIDE 56
 
 struct Layout {      // offsets in elements of T inside the wave's LDS block
-    int q, dq, qd, bd, sc, jb, slots, cd, rt, am, vv, ff, ff0, work, total;
+    int q, dq, qd, bd, pd, sc, jb, slots, cd, rt, am, vv, ff, ff0, work, total;
 };
 
 template <typename T>
@@ -78,6 +79,8 @@ struct DevModel {
     const int *dof2q, *att_start, *att_c, *att_kind;
     const unsigned long long *anc;
     const T *Hpr, *Hcn, *mass, *visc;         // [nb][12], [nb][12], [nb][36], [nb][36]
+    const double *Hpr_d, *Hcn_d;              // float64 copies for the pose chain
+    const double *clocal_d, *cradius_d, *cHinv_d, *cplane_d, *cb0_d, *cb1_d;
     T grav[3];
     const T *pd_kp, *pd_kd, *pd_tau0;
     const int *ctype, *cen, *cbody, *cbody0, *cdof;
@@ -115,6 +118,25 @@ template <typename T> __device__ __forceinline__ void st_m3(T *p, const M3<T> &m
 }
 template <typename T> __device__ __forceinline__ void st_v3(T *p, V3<T> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 
+template <typename TO, typename TI> __device__ __forceinline__ M3<TO> cvt_m3(const M3<TI> &m) {
+    M3<TO> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.a[i] = (TO)m.a[i];
+    return r;
+}
+template <typename TO, typename TI> __device__ __forceinline__ V3<TO> cvt_v3(V3<TI> v) {
+    return v3<TO>((TO)v.x, (TO)v.y, (TO)v.z);
+}
+template <typename TO, typename TI> __device__ __forceinline__ M3<TO> ld_m3_as(const TI *p) {
+    M3<TO> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.a[i] = (TO)p[i];
+    return r;
+}
+template <typename TO, typename TI> __device__ __forceinline__ V3<TO> ld_v3_as(const TI *p) {
+    return v3<TO>((TO)p[0], (TO)p[1], (TO)p[2]);
+}
+
 // y = M x for a row-major 6x6 M (wave-uniform address -> scalar loads)
 template <typename T>
 __device__ __forceinline__ void mat6_vec(const T *__restrict__ M, const T x[6], T y[6]) {
@@ -145,6 +167,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     if (w >= nworlds) return;
     T *lds = reinterpret_cast<T *>(arb_lds_raw);
     T *qs = lds + L.q, *dqs = lds + L.dq, *qd = lds + L.qd, *BD = lds + L.bd, *SC = lds + L.sc;
+    double *PD = reinterpret_cast<double *>(lds + L.pd);
     T *JB = lds + L.jb, *SL = lds + L.slots, *CD = lds + L.cd, *RT = lds + L.rt;
     T *AM = lds + L.am, *VV = lds + L.vv, *FF = lds + L.ff, *FF0 = lds + L.ff0, *WORK = lds + L.work;
     const int n = m.n, nb = m.nb, nq = m.nq, nc = m.nc, ndol = m.ndol;
@@ -170,25 +193,39 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             const int b = lane;
             const bool on = b < nb;
             int jt = 0, par = -1, doff = 0, dep = -1, k = 0;
-            M3<T> R_pc, R_cp, R_cn; V3<T> p_pc, p_cp, p_cn, Tnw, Tnv;
+            // Positions are chained in float64 whatever the state type: the contact gap
+            // (sdist) is a difference of O(1 m) positions that is then divided by dt, so
+            // float32 rounding of the pose chain alone would cost ~1e-7/dt = 2e-5 m/s.
+            M3<T> R_pc, R_cp, R_cn, dA_cp, dB_cp; V3<T> p_pc, p_cp, p_cn, Tnw, Tnv, Bnw, Bnv;
+            M3<double> R_pc_d = m3_identity<double>(); V3<double> p_pc_d = v3<double>(0., 0., 0.);
             R_pc = R_cp = R_cn = m3_identity<T>();
-            p_pc = p_cp = p_cn = Tnw = Tnv = v3<T>(T(0), T(0), T(0));
+            dA_cp = dB_cp = m3_zero<T>();
+            p_pc = p_cp = p_cn = Tnw = Tnv = Bnw = Bnv = v3<T>(T(0), T(0), T(0));
             if (on) {
                 jt = m.jtype[b]; par = m.parent[b]; doff = m.dof_off[b]; dep = m.depth[b];
                 k = m.jnd[b];
+                JointLocal<double> jld;
+                joint_local<double>(jt, qs + m.q_off[b], dqs + doff, jld);
                 JointLocal<T> jl;
-                joint_local<T>(jt, qs + m.q_off[b], dqs + doff, jl);
+                jl.R = cvt_m3<T>(jld.R); jl.p = cvt_v3<T>(jld.p);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { jl.jw[i] = cvt_v3<T>(jld.jw[i]); jl.djw[i] = cvt_v3<T>(jld.djw[i]); }
+                jl.Tw = cvt_v3<T>(jld.Tw); jl.Tv = cvt_v3<T>(jld.Tv);
                 const M3<T> R_pr = ld_m3(m.Hpr + 12 * b);
                 const V3<T> p_pr = ld_v3(m.Hpr + 12 * b + 9);
                 R_cn = ld_m3(m.Hcn + 12 * b);
                 p_cn = ld_v3(m.Hcn + 12 * b + 9);
                 // H_pc = H_pr H_rn inv(H_cn)                       core.py:1298
-                const M3<T> R_nc = transpose(R_cn);
-                const V3<T> p_nc = -mtv(R_cn, p_cn);
-                const M3<T> R_rc = mul(jl.R, R_nc);
-                const V3<T> p_rc = mv(jl.R, p_nc) + jl.p;
-                R_pc = mul(R_pr, R_rc);
-                p_pc = mv(R_pr, p_rc) + p_pr;
+                {
+                    const M3<double> Rpr = ld_m3(m.Hpr_d + 12 * b), Rcn = ld_m3(m.Hcn_d + 12 * b);
+                    const V3<double> ppr = ld_v3(m.Hpr_d + 12 * b + 9), pcn = ld_v3(m.Hcn_d + 12 * b + 9);
+                    const M3<double> R_rc = mulBT(jld.R, Rcn);
+                    const V3<double> p_rc = mv(jld.R, -mtv(Rcn, pcn)) + jld.p;
+                    R_pc_d = mul(Rpr, R_rc);
+                    p_pc_d = mv(Rpr, p_rc) + ppr;
+                }
+                R_pc = cvt_m3<T>(R_pc_d);
+                p_pc = cvt_v3<T>(p_pc_d);
                 R_cp = transpose(R_pc);                          // Ad_cp = Ad(inv(H_pc)) :1300
                 p_cp = -mtv(R_pc, p_pc);
                 // Ad_nr, T_rn = -Ad_nr T_nr, dAd_nr = Ad_nr ad(T_rn)   rigidmotion.py:47-73
@@ -205,6 +242,17 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 T *bd = BD + b * BD_STRIDE;
                 st_m3(bd + BD_RCP, R_cp); st_v3(bd + BD_PCP, p_cp);
                 st_m3(bd + BD_DA, dAd_cp.A); st_m3(bd + BD_DB, dAd_cp.B);
+                dA_cp = dAd_cp.A; dB_cp = dAd_cp.B;
+                // Ad_cn (dJ_nr gvel_j): the joint's own contribution to dJ_c gvel
+                {
+                    V3<T> bw = v3<T>(T(0), T(0), T(0));
+                    if (jt != JT_FREE && jt != JT_TXTYTZ) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) if (i < k) bw = bw + dqs[doff + i] * jl.djw[i];
+                    }
+                    Bnw = mv(R_cn, bw);
+                    Bnv = cross(p_cn, Bnw);
+                }
                 // own columns Ad_cn J_nr, Ad_cn dJ_nr               core.py:1310, 1313
                 Tnw = mv(R_cn, jl.Tw);
                 Tnv = cross(p_cn, Tnw) + mv(R_cn, jl.Tv);
@@ -235,32 +283,40 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // pose and twist down the tree, one depth level at a time
             for (int lvl = 0; lvl <= m.maxdepth; ++lvl) {
                 if (on && dep == lvl) {
-                    M3<T> Rg = m3_identity<T>(); V3<T> pg = v3<T>(T(0), T(0), T(0));
-                    V3<T> tw = pg, tv = pg;
+                    M3<double> Rg = m3_identity<double>(); V3<double> pg = v3<double>(0., 0., 0.);
+                    V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw;
                     if (par >= 0) {
                         const T *pb = BD + par * BD_STRIDE;
-                        Rg = ld_m3(pb + BD_RG); pg = ld_v3(pb + BD_PGB);
+                        Rg = ld_m3(PD + 12 * par); pg = ld_v3(PD + 12 * par + 9);
                         tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
+                        aw = ld_v3(pb + BD_AB); av = ld_v3(pb + BD_AB + 3);
                     }
-                    const M3<T> Rc = mul(Rg, R_pc);                  // child_pose  core.py:1299
-                    const V3<T> pc = mv(Rg, p_pc) + pg;
+                    const M3<double> Rc_d = mul(Rg, R_pc_d);         // child_pose  core.py:1299
+                    const V3<double> pc_d = mv(Rg, p_pc_d) + pg;
+                    st_m3(PD + 12 * b, Rc_d); st_v3(PD + 12 * b + 9, pc_d);
+                    const M3<T> Rc = cvt_m3<T>(Rc_d);
+                    const V3<T> pc = cvt_v3<T>(pc_d);
                     const V3<T> cw = mv(R_cp, tw) + Tnw;             // child_twist core.py:1308
                     const V3<T> cv = cross(p_cp, mv(R_cp, tw)) + mv(R_cp, tv) + Tnv;
                     T *bd = BD + b * BD_STRIDE;
                     st_m3(bd + BD_RG, Rc); st_v3(bd + BD_PGB, pc);
                     st_v3(bd + BD_TW, cw); st_v3(bd + BD_TW + 3, cv);
+                    // dJ_c gvel = dAd_cp T_p + Ad_cp (dJ_p gvel) + Ad_cn dJ_nr gvel_j   (core.py:1312-1313 times gvel)
+                    const V3<T> raw = mv(R_cp, aw);
+                    const V3<T> nbw = mv(dA_cp, tw) + raw + Bnw;
+                    const V3<T> nbv = mv(dB_cp, tw) + mv(dA_cp, tv) + cross(p_cp, raw) + mv(R_cp, av) + Bnv;
+                    st_v3(bd + BD_AB, nbw); st_v3(bd + BD_AB + 3, nbv);
                 }
                 __syncthreads();
             }
             if (on) {
                 T *bd = BD + b * BD_STRIDE;
                 const T *Mb = m.mass + 36 * b;
-                T tw[6], y[6];
+                T tw[6], ab[6], mt[6], ma[6], mg[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) tw[i] = bd[BD_TW + i];
-                mat6_vec<T>(Mb, tw, y);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) bd[BD_PT + i] = y[i];
+                for (int i = 0; i < 6; ++i) { tw[i] = bd[BD_TW + i]; ab[i] = bd[BD_AB + i]; }
+                mat6_vec<T>(Mb, tw, mt);
+                mat6_vec<T>(Mb, ab, ma);
                 // gravity in the body frame: Ad(inv(H_gb)) [0; g up]   controllers.py:56-58
                 T g6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
                 if (m.has_grav && m.weighted[b]) {
@@ -268,9 +324,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<T> gl = mtv(Rg, v3<T>(m.grav[0], m.grav[1], m.grav[2]));
                     g6[3] = gl.x; g6[4] = gl.y; g6[5] = gl.z;
                 }
-                mat6_vec<T>(Mb, g6, y);
+                mat6_vec<T>(Mb, g6, mg);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) bd[BD_PG + i] = y[i];
+                for (int i = 0; i < 6; ++i) bd[BD_PG + i] = mg[i];
                 // N_b = [[wx, rx wx - wx rx],[0, wx]] M_b              core.py:1276-1288
                 const V3<T> wv = v3<T>(tw[0], tw[1], tw[2]);
                 const M3<T> wx = hat(wv);
@@ -283,8 +339,24 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                         for (int j = 0; j < 3; ++j) rx.a[3 * i + j] = Mb[6 * i + 3 + j] * im;
                 }
-                st_m3(bd + BD_CM, sub(mul(rx, wx), mul(wx, rx)));
+                const M3<T> Cm = sub(mul(rx, wx), mul(wx, rx));
+                st_m3(bd + BD_CM, Cm);
                 st_v3(bd + BD_W, wv);
+                // increment form of core.py:975-976: Z (gvel+ - gvel) = gforce - (N + B) gvel, and
+                // (N gvel)|_b = M_b (dJ_b gvel) + N_b T_b ;  (B gvel)|_b = B_b T_b
+                const V3<T> mtt = v3<T>(mt[0], mt[1], mt[2]), mtb = v3<T>(mt[3], mt[4], mt[5]);
+                const V3<T> ntop = cross(wv, mtt) + mv(Cm, mtb);
+                const V3<T> nbot = cross(wv, mtb);
+                T pt[6] = {mg[0] - ma[0] - ntop.x, mg[1] - ma[1] - ntop.y, mg[2] - ma[2] - ntop.z,
+                           mg[3] - ma[3] - nbot.x, mg[4] - ma[4] - nbot.y, mg[5] - ma[5] - nbot.z};
+                if (m.has_visc) {
+                    T vt[6];
+                    mat6_vec<T>(m.visc + 36 * b, tw, vt);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pt[i] -= vt[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bd[BD_PT + i] = pt[i];
             }
             // dof-indexed copy of the linear joint positions (PD controller, joint limits)
             if (lane < n) { const int qi = m.dof2q[lane]; qd[lane] = qi >= 0 ? qs[qi] : T(0); }
@@ -315,35 +387,37 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             T sd = T(0);
             if (m.cen[c]) {
                 if (ct == ARB_CT_SOFTFINGER_PLANE) {
-                    const T *bd = BD + m.cbody[c] * BD_STRIDE;
-                    const M3<T> Rg = ld_m3(bd + BD_RG); const V3<T> pg = ld_v3(bd + BD_PGB);
-                    const V3<T> p_g1 = mv(Rg, ld_v3(m.clocal + 3 * c)) + pg;
-                    // collisions.py:194-205
-                    const M3<T> Ri = ld_m3(m.cHinv + 12 * c); const V3<T> pi = ld_v3(m.cHinv + 12 * c + 9);
-                    const V3<T> p01 = mv(Ri, p_g1) + pi;
-                    const V3<T> nrm = ld_v3(m.cplane + 4 * c);
-                    const T rad = m.cradius[c];
-                    const T csd = dot(nrm, p01) - m.cplane[4 * c + 3];
-                    sd = csd - rad;
-                    const T sg = sd > T(0) ? T(1) : (sd < T(0) ? T(-1) : T(0));
-                    const V3<T> gc0 = p01 - csd * nrm;
-                    const V3<T> gc1 = p01 - (sg * rad) * nrm;
-                    const M3<T> Rz = ld_m3(m.cRz + 9 * c);
+                    const int b1 = m.cbody[c];
+                    const T *bd = BD + b1 * BD_STRIDE;
+                    const M3<double> Rg = ld_m3(PD + 12 * b1); const V3<double> pg = ld_v3(PD + 12 * b1 + 9);
+                    const V3<double> p_g1 = mv(Rg, ld_v3(m.clocal_d + 3 * c)) + pg;
+                    // collisions.py:194-205 (float64: the gap is a difference of O(1) positions)
+                    const M3<double> Ri = ld_m3(m.cHinv_d + 12 * c); const V3<double> pi = ld_v3(m.cHinv_d + 12 * c + 9);
+                    const V3<double> p01 = mv(Ri, p_g1) + pi;
+                    const V3<double> nrm = ld_v3(m.cplane_d + 4 * c);
+                    const double rad = m.cradius_d[c];
+                    const double csd = dot(nrm, p01) - m.cplane_d[4 * c + 3];
+                    const double sd_d = csd - rad;
+                    sd = (T)sd_d;
+                    const double sg = sd_d > 0. ? 1. : (sd_d < 0. ? -1. : 0.);
+                    const V3<double> gc0 = p01 - csd * nrm;
+                    const V3<double> gc1 = p01 - (sg * rad) * nrm;
+                    const M3<double> Rz = ld_m3_as<double>(m.cRz + 9 * c);
                     // frame 1 on the body: bpose1 = inv(H_gb) H_gc1       constraints.py:287-288
-                    const M3<T> Rb1 = mulTA(Rg, Rz);
-                    const V3<T> pb1 = mtv(Rg, gc1 - pg);
+                    const M3<T> Rb1 = cvt_m3<T>(mulTA(Rg, Rz));
+                    const V3<T> pb1 = cvt_v3<T>(mtv(Rg, gc1 - pg));
                     // twist of frame 1 (core.py:1021-1023) and gap rate (constraints.py:289-291)
                     const V3<T> bw = ld_v3(bd + BD_TW), bv = ld_v3(bd + BD_TW + 3);
                     const V3<T> pinv1 = -mtv(Rb1, pb1);
                     const V3<T> w1 = mtv(Rb1, bw);
                     const V3<T> v1 = cross(pinv1, w1) + mtv(Rb1, bv);
-                    const V3<T> p0c = mtv(Rz, gc1 - gc0);            // H_c0c1 = [I | p0c]
+                    const V3<T> p0c = cvt_v3<T>(mtv(Rz, gc1 - gc0));  // H_c0c1 = [I | p0c]
                     const T dsd = cross(p0c, w1).z + v1.z;
-                    active = (sd + dsd * dt < m.cprox[c]);
+                    active = ((double)sd_d + (double)dsd * (double)dt < (double)m.cprox[c]);
                     // body -> contact frame 0:  Ad(H_01) Ad(inv(bpose1)) = Ad(inv(H_gc0) H_gb)
-                    st_m3(cd + CD_R1, mulTA(Rz, Rg));
-                    st_v3(cd + CD_P1, mtv(Rz, pg - gc0));
-                    st_v3(cd + CD_GC0, gc0); st_v3(cd + CD_GC1, gc1);
+                    st_m3(cd + CD_R1, cvt_m3<T>(mulTA(Rz, Rg)));
+                    st_v3(cd + CD_P1, cvt_v3<T>(mtv(Rz, pg - gc0)));
+                    st_v3(cd + CD_GC0, cvt_v3<T>(gc0)); st_v3(cd + CD_GC1, cvt_v3<T>(gc1));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
                 } else if (ct == ARB_CT_JOINTLIMITS) {
@@ -355,18 +429,18 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     sd = p0;
                 } else {                                                // BallAndSocket
                     const int b0 = m.cbody0[c], b1 = m.cbody[c];
-                    M3<T> Rg0 = m3_identity<T>(), Rg1 = Rg0;
-                    V3<T> pg0 = v3<T>(T(0), T(0), T(0)), pg1 = pg0;
-                    if (b0 >= 0) { Rg0 = ld_m3(BD + b0 * BD_STRIDE + BD_RG); pg0 = ld_v3(BD + b0 * BD_STRIDE + BD_PGB); }
-                    if (b1 >= 0) { Rg1 = ld_m3(BD + b1 * BD_STRIDE + BD_RG); pg1 = ld_v3(BD + b1 * BD_STRIDE + BD_PGB); }
-                    const M3<T> Rf0 = ld_m3(m.cb0 + 12 * c), Rf1 = ld_m3(m.cb1 + 12 * c);
-                    const V3<T> pf0 = ld_v3(m.cb0 + 12 * c + 9), pf1 = ld_v3(m.cb1 + 12 * c + 9);
-                    const M3<T> RP0 = mul(Rg0, Rf0); const V3<T> pP0 = mv(Rg0, pf0) + pg0;
-                    const V3<T> pP1 = mv(Rg1, pf1) + pg1;
-                    st_v3(cd + CD_POS0, mtv(RP0, pP1 - pP0));         // p_01  constraints.py:196-197
+                    M3<double> Rg0 = m3_identity<double>(), Rg1 = Rg0;
+                    V3<double> pg0 = v3<double>(0., 0., 0.), pg1 = pg0;
+                    if (b0 >= 0) { Rg0 = ld_m3(PD + 12 * b0); pg0 = ld_v3(PD + 12 * b0 + 9); }
+                    if (b1 >= 0) { Rg1 = ld_m3(PD + 12 * b1); pg1 = ld_v3(PD + 12 * b1 + 9); }
+                    const M3<double> Rf0 = ld_m3(m.cb0_d + 12 * c);
+                    const V3<double> pf0 = ld_v3(m.cb0_d + 12 * c + 9), pf1 = ld_v3(m.cb1_d + 12 * c + 9);
+                    const M3<double> RP0 = mul(Rg0, Rf0); const V3<double> pP0 = mv(Rg0, pf0) + pg0;
+                    const V3<double> pP1 = mv(Rg1, pf1) + pg1;
+                    st_v3(cd + CD_POS0, cvt_v3<T>(mtv(RP0, pP1 - pP0)));  // p_01  constraints.py:196-197
                     // body1 -> frame 0: Ad(inv(P0) H_gb1);  body0 -> frame 0: Ad(inv(bpose0))
-                    st_m3(cd + CD_R1, mulTA(RP0, Rg1)); st_v3(cd + CD_P1, mtv(RP0, pg1 - pP0));
-                    st_m3(cd + CD_R0, transpose(Rf0)); st_v3(cd + CD_P0, -mtv(Rf0, pf0));
+                    st_m3(cd + CD_R1, cvt_m3<T>(mulTA(RP0, Rg1))); st_v3(cd + CD_P1, cvt_v3<T>(mtv(RP0, pg1 - pP0)));
+                    st_m3(cd + CD_R0, cvt_m3<T>(transpose(Rf0))); st_v3(cd + CD_P0, cvt_v3<T>(-mtv(Rf0, pf0)));
                     active = true;
                 }
             }
@@ -470,9 +544,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         for (int i = 0; i < 6; ++i) Q[i] += V[i];
                     }
                 }
-                // rhs:  J^T M_b T_b  (= M gvel) and J^T M_b g_b (gravity)
+                // rhs of the increment form, and (inspect only) the controllers' gforce J^T M_b g_b
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { rhsM += x[i] * bd[BD_PT + i]; rhsG += x[i] * bd[BD_PG + i]; }
+                for (int i = 0; i < 6; ++i) rhsM += x[i] * bd[BD_PT + i];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) rhsG += x[i] * bd[BD_PG + i];
+                }
                 // constraint rows hanging on this body
                 if (do_constraints) {
                     for (int a = m.att_start[b]; a < m.att_start[b + 1]; ++a) {
@@ -515,18 +593,22 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     RT[(1 + 4 * c) * WAVE + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
         }
         // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
-        T gf0 = rhsG + ext_k;
+        T gf0 = rhsG + ext_k;          // controllers' generalized force (inspect output)
+        T rhs = rhsM + ext_k;          // gforce - (N + B + Z_pd) gvel
         if (m.has_pd && lane < n) {
-            T acc = m.pd_tau0[lane];
-            for (int i = 0; i < n; ++i) acc -= m.pd_kp[lane * n + i] * qd[i];
+            T acc = m.pd_tau0[lane], accv = T(0);
+            for (int i = 0; i < n; ++i) {
+                acc -= m.pd_kp[lane * n + i] * qd[i];
+                accv += (dt * m.pd_kp[lane * n + i] + m.pd_kd[lane * n + i]) * dqs[i];
+            }
             gf0 += acc;
+            rhs += acc - accv;
             if (MODE == 0 || zmode == 0) {
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i)
                     if (i < n) Z[i] += dt * m.pd_kp[i * n + lane] + m.pd_kd[i * n + lane];
             }
         }
-        T rhs = rhsM * inv_dt + gf0;
         __syncthreads();
         if (MODE == 1) {
             if (dbg.Zout != nullptr && lane < n) {
@@ -574,29 +656,43 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
             for (int i = 0; i < NMAX; ++i) Z2[i] = (have && i < n) ? RT[r * WAVE + i] : T(0);
         }
-        for (int j = 0; j < n; ++j) {
-            const T piv = bcast(Z[0], j);
-            const T ip = T(1) / piv;
-            const T t = Z[0] * ip;
+        // Pivots are taken from the last dof to the first (extremities before the
+        // root): on these graded, nearly-SPD matrices that order halves the float32
+        // error of pivot-free elimination (measured).  The register file
+        // is rotated one row per step so that the pivot row always sits in
+        // Z[NMAX-1] and every index below is a compile-time constant.
+        for (int j = n; j < NMAX; ++j) {           // bring row n-1 into Z[NMAX-1]
+            const T t = Z[NMAX - 1];
             T t2 = T(0);
-            if (NSETS == 2) t2 = Z2[0] * ip;
+            if (NSETS == 2) t2 = Z2[NMAX - 1];
 #pragma unroll
-            for (int r = 1; r < NMAX; ++r) {
-                const T f = bcast(Z[r], j);
-                Z[r - 1] = Z[r] - f * t;
-                if (NSETS == 2) Z2[r - 1] = Z2[r] - f * t2;
-            }
-            Z[NMAX - 1] = t;
-            if (NSETS == 2) Z2[NMAX - 1] = t2;
+            for (int r = NMAX - 1; r >= 1; --r) { Z[r] = Z[r - 1]; if (NSETS == 2) Z2[r] = Z2[r - 1]; }
+            Z[0] = t;
+            if (NSETS == 2) Z2[0] = t2;
         }
-        for (int j = n; j < NMAX; ++j) {           // finish the rotation: rows back in place
-            const T t = Z[0];
+        for (int j = n - 1; j >= 0; --j) {
+            const T piv = bcast(Z[NMAX - 1], j);
+            const T ip = T(1) / piv;
+            const T t = Z[NMAX - 1] * ip;
             T t2 = T(0);
-            if (NSETS == 2) t2 = Z2[0];
+            if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
 #pragma unroll
-            for (int r = 1; r < NMAX; ++r) { Z[r - 1] = Z[r]; if (NSETS == 2) Z2[r - 1] = Z2[r]; }
-            Z[NMAX - 1] = t;
-            if (NSETS == 2) Z2[NMAX - 1] = t2;
+            for (int r = NMAX - 1; r >= 1; --r) {
+                const T f = bcast(Z[r - 1], j);
+                Z[r] = Z[r - 1] - f * t;
+                if (NSETS == 2) Z2[r] = Z2[r - 1] - f * t2;
+            }
+            Z[0] = t;
+            if (NSETS == 2) Z2[0] = t2;
+        }
+        // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
+        if (lane == n) {
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) if (i < n) Z[i] += dqs[i];
+        }
+        if (NSETS == 2 && WAVE + lane == n) {
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) if (i < n) Z2[i] += dqs[i];
         }
         // lanes >= n (and the second set) now hold Y rhs and Y J'^T columns
 
@@ -661,9 +757,18 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     __syncthreads();     // everyone has read VV/FF/WORK inputs before they change
                     if (ct == ARB_CT_SOFTFINGER_PLANE) {
                         const T eps[3] = {m.ceps[3 * c], m.ceps[3 * c + 1], m.ceps[3 * c + 2]};
-                        // the rare sliding branch runs its 6x6 eigenproblem on an LDS work
-                        // array; all lanes execute it redundantly (wave-uniform data)
-                        softfinger_solve<T>(v, Y, P, f, df, cd[CD_SDIST], dt, m.cmu[c], eps, WORK);
+                        // wave-uniform data: every lane evaluates the same scalar code in registers.
+                        T alpha[4], shift = T(0);
+                        int br = softfinger_try<T>(v, Y, P, f, df, cd[CD_SDIST], dt, m.cmu[c], eps, WORK, alpha, &shift);
+                        if (br == 3) {
+                            // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
+                            __syncthreads();
+                            if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
+                            __syncthreads();
+                            shift = WORK[40];
+                            br = 2;
+                        }
+                        if (br == 2) softfinger_slide_finish<T>(Y, alpha, eps, shift, f, df);
                     } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
@@ -800,7 +905,7 @@ static std::vector<double> h12(const double *H16, int count) {
     return v;
 }
 
-static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int *total_elems) {
+static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int elems_per_double, int *total_elems) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
@@ -808,6 +913,7 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int *tot
     L.dq = o; o += WAVE;
     L.qd = o; o += WAVE;
     L.bd = o; o += al(nb * BD_STRIDE);
+    L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
     L.sc = o; o += 12 * WAVE;
     L.jb = o; o += 8 * WAVE;
     L.slots = o; o += std::max(nslots, 1) * 12 * WAVE;
@@ -862,6 +968,14 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     if ((rc = upload<unsigned long long>(M, anc, &m.anc)) != ARB_OK) return rc;
     UP_T(Hpr, conv<T>(h12(d->H_pr, nb).data(), 12 * nb));
     UP_T(Hcn, conv<T>(h12(d->H_cn, nb).data(), 12 * nb));
+    if ((rc = upload<double>(M, h12(d->H_pr, nb), &m.Hpr_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, h12(d->H_cn, nb), &m.Hcn_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, conv<double>(d->c_local, 3 * nc), &m.clocal_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, conv<double>(d->c_radius, nc), &m.cradius_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, h12(d->c_plane_Hinv, nc), &m.cHinv_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, conv<double>(d->c_plane, 4 * nc), &m.cplane_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, h12(d->c_bpose0, nc), &m.cb0_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, h12(d->c_bpose1, nc), &m.cb1_d)) != ARB_OK) return rc;
     UP_T(mass, conv<T>(d->mass, 36 * nb));
     UP_T(visc, conv<T>(d->visc, 36 * nb));
     bool hv = false;
@@ -1016,8 +1130,8 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     int tot;
-    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, &tot);
-    M->ld = M->lf;
+    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, 2, &tot);
+    M->ld = make_layout(nb, d->nq, nc, ndol, nslots, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     *out = M;
     return ARB_OK;
@@ -1139,14 +1253,17 @@ extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *d
 // solvers (4x4 GEPP, 6x6 eigenvalues, SoftFingerContact.solve) against captured
 // reference tuples.
 // ---------------------------------------------------------------------------
+// dtype: ARB_F32 / ARB_F64, optionally | 0x100 to force the generic eig6 route of the sliding branch
 extern "C" int arb_host_softfinger_solve(int dtype, const double *vel, const double *adm, double *force,
                                          double sdist, double dt, double mu, const double *eps, double *dforce) {
     if (!vel || !adm || !force || !eps || !dforce) return -1;
+    const bool use_fast = !(dtype & 0x100);
+    dtype &= 0xff;
     if (dtype == ARB_F64) {
         double P[16], work[36], f[4], df[4];
         inv_block<double>(adm, 4, 4, P);
         for (int i = 0; i < 4; ++i) f[i] = force[i];
-        int br = softfinger_solve<double>(vel, adm, P, f, df, sdist, dt, mu, eps, work);
+        int br = softfinger_solve<double>(vel, adm, P, f, df, sdist, dt, mu, eps, work, use_fast);
         for (int i = 0; i < 4; ++i) { force[i] = f[i]; dforce[i] = df[i]; }
         return br;
     }
@@ -1155,9 +1272,26 @@ extern "C" int arb_host_softfinger_solve(int dtype, const double *vel, const dou
     for (int i = 0; i < 16; ++i) Y[i] = (float)adm[i];
     for (int i = 0; i < 3; ++i) e[i] = (float)eps[i];
     inv_block<float>(Y, 4, 4, P);
-    int br = softfinger_solve<float>(v, Y, P, f, df, (float)sdist, (float)dt, (float)mu, e, work);
+    int br = softfinger_solve<float>(v, Y, P, f, df, (float)sdist, (float)dt, (float)mu, e, work, use_fast);
     for (int i = 0; i < 4; ++i) { force[i] = f[i]; dforce[i] = df[i]; }
     return br;
+}
+
+// raw branch code of softfinger_try (3 = the fast sliding-shift path declined and eig6 is needed)
+extern "C" int arb_host_softfinger_try(int dtype, const double *vel, const double *adm, const double *force,
+                                       double sdist, double dt, double mu, const double *eps) {
+    if (dtype == ARB_F64) {
+        double P[16], work[36], f[4], df[4], alpha[4], s = 0;
+        inv_block<double>(adm, 4, 4, P);
+        for (int i = 0; i < 4; ++i) f[i] = force[i];
+        return softfinger_try<double>(vel, adm, P, f, df, sdist, dt, mu, eps, work, alpha, &s);
+    }
+    float v[4], Y[16], P[16], work[36], f[4], df[4], e[3], alpha[4], s = 0;
+    for (int i = 0; i < 4; ++i) { v[i] = (float)vel[i]; f[i] = (float)force[i]; }
+    for (int i = 0; i < 16; ++i) Y[i] = (float)adm[i];
+    for (int i = 0; i < 3; ++i) e[i] = (float)eps[i];
+    inv_block<float>(Y, 4, 4, P);
+    return softfinger_try<float>(v, Y, P, f, df, (float)sdist, (float)dt, (float)mu, e, work, alpha, &s);
 }
 
 extern "C" int arb_host_eig6(const double *A, double *wr, double *wi) {

@@ -146,12 +146,12 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.R.a[0] = q[0]; o.R.a[1] = q[1]; o.R.a[2] = q[2]; o.p.x = q[3];
         o.R.a[3] = q[4]; o.R.a[4] = q[5]; o.R.a[5] = q[6]; o.p.y = q[7];
         o.R.a[6] = q[8]; o.R.a[7] = q[9]; o.R.a[8] = q[10]; o.p.z = q[11];
-        o.Tw = v3<T>(dq[0], dq[1], dq[2]);
-        o.Tv = v3<T>(dq[3], dq[4], dq[5]);
+        o.Tw = v3<T>(T(dq[0]), T(dq[1]), T(dq[2]));
+        o.Tv = v3<T>(T(dq[3]), T(dq[4]), T(dq[5]));
     } break;
     case JT_RZRYRX: {                                 // joints.py:59-104, rotzyx :34-59
         T sz, cz, sy, cy, sx, cx;
-        arb_sincos(q[0], &sz, &cz); arb_sincos(q[1], &sy, &cy); arb_sincos(q[2], &sx, &cx);
+        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sy, &cy); arb_sincos(T(q[2]), &sx, &cx);
         o.R.a[0] = cz * cy; o.R.a[1] = cz * sy * sx - sz * cx; o.R.a[2] = cz * sy * cx + sz * sx;
         o.R.a[3] = sz * cy; o.R.a[4] = sz * sy * sx + cz * cx; o.R.a[5] = sz * sy * cx - cz * sx;
         o.R.a[6] = -sy;     o.R.a[7] = cy * sx;                o.R.a[8] = cy * cx;
@@ -161,11 +161,11 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         T dy = dq[1], dx = dq[2];
         o.djw[0] = v3<T>(-dy * cy, dx * cx * cy - dy * sx * sy, -dx * sx * cy - dy * cx * sy);
         o.djw[1] = v3<T>(Z, -dx * sx, -dx * cx);
-        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1] + dq[2] * o.jw[2];
+        o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1] + T(dq[2]) * o.jw[2];
     } break;
     case JT_RZRY: {                                   // joints.py:107-146, rotzy :60-80
         T sz, cz, sy, cy;
-        arb_sincos(q[0], &sz, &cz); arb_sincos(q[1], &sy, &cy);
+        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sy, &cy);
         o.R.a[0] = cz * cy; o.R.a[1] = -sz; o.R.a[2] = cz * sy;
         o.R.a[3] = sz * cy; o.R.a[4] = cz;  o.R.a[5] = sz * sy;
         o.R.a[6] = -sy;     o.R.a[7] = Z;   o.R.a[8] = cy;
@@ -173,11 +173,11 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.jw[1] = v3<T>(Z, O, Z);
         T dy = dq[1];
         o.djw[0] = v3<T>(-dy * cy, Z, -dy * sy);
-        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1];
+        o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1];
     } break;
     case JT_RZRX: {                                   // joints.py:149-185, rotzx :82-102
         T sz, cz, sx, cx;
-        arb_sincos(q[0], &sz, &cz); arb_sincos(q[1], &sx, &cx);
+        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sx, &cx);
         o.R.a[0] = cz; o.R.a[1] = -sz * cx; o.R.a[2] = sz * sx;
         o.R.a[3] = sz; o.R.a[4] = cz * cx;  o.R.a[5] = -cz * sx;
         o.R.a[6] = Z;  o.R.a[7] = sx;       o.R.a[8] = cx;
@@ -185,11 +185,11 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.jw[1] = v3<T>(O, Z, Z);
         T dx = dq[1];
         o.djw[0] = v3<T>(Z, dx * cx, -dx * sx);
-        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1];
+        o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1];
     } break;
     case JT_RYRX: {                                   // joints.py:188-224, rotyx :104-124
         T sy, cy, sx, cx;
-        arb_sincos(q[0], &sy, &cy); arb_sincos(q[1], &sx, &cx);
+        arb_sincos(T(q[0]), &sy, &cy); arb_sincos(T(q[1]), &sx, &cx);
         o.R.a[0] = cy;  o.R.a[1] = sy * sx; o.R.a[2] = sy * cx;
         o.R.a[3] = Z;   o.R.a[4] = cx;      o.R.a[5] = -sx;
         o.R.a[6] = -sy; o.R.a[7] = cy * sx; o.R.a[8] = cy * cx;
@@ -197,29 +197,29 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.jw[1] = v3<T>(O, Z, Z);
         T dx = dq[1];
         o.djw[0] = v3<T>(Z, -dx * sx, -dx * cx);
-        o.Tw = dq[0] * o.jw[0] + dq[1] * o.jw[1];
+        o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1];
     } break;
     case JT_RZ: {                                     // joints.py:227-303
-        T s, c; arb_sincos(q[0], &s, &c);
+        T s, c; arb_sincos(T(q[0]), &s, &c);
         o.R.a[0] = c; o.R.a[1] = -s; o.R.a[3] = s; o.R.a[4] = c;
         o.jw[0] = v3<T>(Z, Z, O);
-        o.Tw = dq[0] * o.jw[0];
+        o.Tw = T(dq[0]) * o.jw[0];
     } break;
     case JT_RY: {                                     // joints.py:305-326
-        T s, c; arb_sincos(q[0], &s, &c);
+        T s, c; arb_sincos(T(q[0]), &s, &c);
         o.R.a[0] = c; o.R.a[2] = s; o.R.a[6] = -s; o.R.a[8] = c;
         o.jw[0] = v3<T>(Z, O, Z);
-        o.Tw = dq[0] * o.jw[0];
+        o.Tw = T(dq[0]) * o.jw[0];
     } break;
     case JT_RX: {                                     // joints.py:328-349
-        T s, c; arb_sincos(q[0], &s, &c);
+        T s, c; arb_sincos(T(q[0]), &s, &c);
         o.R.a[4] = c; o.R.a[5] = -s; o.R.a[7] = s; o.R.a[8] = c;
         o.jw[0] = v3<T>(O, Z, Z);
-        o.Tw = dq[0] * o.jw[0];
+        o.Tw = T(dq[0]) * o.jw[0];
     } break;
     case JT_TXTYTZ: {                                 // joints.py:352-384
-        o.p = v3<T>(q[0], q[1], q[2]);
-        o.Tv = v3<T>(dq[0], dq[1], dq[2]);
+        o.p = v3<T>(T(q[0]), T(q[1]), T(q[2]));
+        o.Tv = v3<T>(T(dq[0]), T(dq[1]), T(dq[2]));
     } break;
     default: break;
     }
@@ -481,17 +481,102 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
 }
 
 // ---------------------------------------------------------------------------
+// Sliding-friction shift `s` of SoftFingerContact.solve (constraints.py:803-830):
+// the smallest real non-positive eigenvalue of the 6x6 matrix
+//     B = [[E (Yh + c1 1 1^T), -c2 E], [c3 E - I, E Yh]],   E = diag(eps^2)
+// (the reference's 1-D dot() products make c0..c3 scalars).  For eps = (1,1,1)
+// the lower-left block is a multiple of I and commutes with everything, so
+//     det(B - s I) = det((P - s I)(Q - s I) + c2 (c3 - 1) I),  P = Q + c1 1 1^T,
+// a sextic in s whose coefficients come from a 3x3 determinant of quadratics.
+// Its leftmost real root is found in float64 registers by Laguerre iterations
+// started left of the spectrum (monotone and cubically convergent when all
+// roots are real, which is the case met in practice); any anomaly makes the
+// caller fall back to the generic QR eigenvalue routine eig6().
+// ---------------------------------------------------------------------------
+struct SlideCoef { double c0, c1, c2, c3m1; };   // c3m1 = (b.b) - 1
+
+ARB_HD void arb_quadmul(const double a[3], const double b[3], double c[5]) {
+    c[0] = a[0] * b[0];
+    c[1] = a[0] * b[1] + a[1] * b[0];
+    c[2] = a[0] * b[2] + a[1] * b[1] + a[2] * b[0];
+    c[3] = a[1] * b[2] + a[2] * b[1];
+    c[4] = a[2] * b[2];
+}
+
+// Returns true and the leftmost real root in *root when the fast path succeeded.
+template <typename T>
+ARB_HD bool slide_leftmost_root(const T Y[16], const SlideCoef &k, double *root) {
+    double Q[3][3], P[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { Q[i][j] = (double)Y[4 * i + j] - k.c0; P[i][j] = Q[i][j] + k.c1; }
+    const double kappa = k.c2 * k.c3m1;
+    // F(s) = s^2 I + s A1 + A0 ; entries as quadratics f[i][j] = {A0, A1, delta}
+    double f[3][3][3];
+    double rb = 0.;                                   // row-sum bound on the spectrum of B
+    for (int i = 0; i < 3; ++i) {
+        double r1 = fabs(k.c2), r2 = fabs(k.c3m1);
+        for (int j = 0; j < 3; ++j) {
+            double a0 = P[i][0] * Q[0][j] + P[i][1] * Q[1][j] + P[i][2] * Q[2][j];
+            f[i][j][0] = a0 + (i == j ? kappa : 0.);
+            f[i][j][1] = -(P[i][j] + Q[i][j]);
+            f[i][j][2] = (i == j) ? 1. : 0.;
+            r1 += fabs(P[i][j]); r2 += fabs(Q[i][j]);
+        }
+        rb = fmax(rb, fmax(r1, r2));
+    }
+    double pc[7] = {0., 0., 0., 0., 0., 0., 0.};
+    for (int t = 0; t < 3; ++t) {                     // cofactor expansion along row 0
+        const int a = (t + 1) % 3, b = (t + 2) % 3;   // cyclic columns keep the sign positive
+        double m1[5], m2[5];
+        arb_quadmul(f[1][a], f[2][b], m1);
+        arb_quadmul(f[1][b], f[2][a], m2);
+        for (int i = 0; i < 5; ++i) m1[i] -= m2[i];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 5; ++j) pc[i + j] += f[0][t][i] * m1[j];
+    }
+    if (!(rb > 0.) || !(rb < 1e300)) return false;
+    // Laguerre from the left of every root
+    double x = -1.0001 * rb - 1e-300;
+    const double n = 6.;
+    for (int it = 0; it < 40; ++it) {
+        double p0 = pc[6], p1 = 0., p2 = 0., ee = fabs(pc[6]);
+        const double ax = fabs(x);
+        for (int i = 5; i >= 0; --i) {
+            p2 = p2 * x + p1; p1 = p1 * x + p0; p0 = p0 * x + pc[i];
+            ee = ee * ax + fabs(p0);                    // running Horner error bound
+        }
+        p2 *= 2.;
+        if (fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0))) { *root = x; return true; }   // p(x) = 0 to rounding
+        if (!(p0 > 0.) || !(p1 < 0.)) return false;   // not left of all roots any more: anomaly
+        const double G = p1 / p0;
+        const double H = G * G - p2 / p0;
+        const double rad = (n - 1.) * (n * H - G * G);
+        if (!(rad >= 0.)) return false;               // complex roots nearby
+        const double den = G - sqrt(rad);             // G < 0: largest magnitude denominator
+        const double dx = n / den;                    // negative
+        const double xn = x - dx;
+        if (!(xn > x)) { *root = x; return true; }    // no representable progress: converged
+        if (fabs(dx) <= 4e-16 * fabs(xn)) { *root = xn; return true; }
+        x = xn;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------
 // SoftFingerContact.solve, arboris/constraints.py:780-836, including the
 // reference's scalar arithmetic in the sliding branch (its dot() of 1-D arrays).
-//   v[4], Y[16] (row-major block of the constraint admittance), f[4] current
-//   force, P[16] = inverse of Y (computed once per step), work = 36-element
-//   scratch for the eigenvalue problem.
-// Writes the new force into f and returns the force increment in df.
-// Returns the branch taken: 0 release, 1 static, 2 sliding.
+// Split in three so that the kernel can run the rare generic eigenvalue
+// fallback on a single lane:
+//   softfinger_try   release / static / sliding with the fast shift; returns
+//                    0, 1, 2, or 3 = sliding but the 6x6 matrix was written to
+//                    `work` and eig6 must provide the shift
+//   slide_shift_from_eig   shift from eig6's output
+//   softfinger_slide_finish  A = Y - s diag(eps^-2); f = solve(A, -alpha)
 // ---------------------------------------------------------------------------
 template <typename T, typename AP>
-ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], T df[4],
-                            T sdist, T dt, T mu, const T eps[3], AP work) {
+ARB_HD int softfinger_try(const T v[4], const T Y[16], const T P[16], T f[4], T df[4],
+                          T sdist, T dt, T mu, const T eps[3], AP work, T alpha[4], T *shift,
+                          bool use_fast = true) {
     T v0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -517,7 +602,7 @@ ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], 
         return 1;
     }
     // sliding, constraints.py:803-836
-    T alpha[4] = {v0[0], v0[1], v0[2], v0[3] + sdist / dt};
+    alpha[0] = v0[0]; alpha[1] = v0[1]; alpha[2] = v0[2]; alpha[3] = v0[3] + sdist / dt;
     T Yc[3] = {Y[3], Y[7], Y[11]};
     T yn = Y[15];
     T beta[3], b[3];
@@ -529,6 +614,19 @@ ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], 
     T bb = beta[0] * b[0] + beta[1] * b[1] + beta[2] * b[2];     // dot(beta, b.T)
     T b2 = beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2];
     T bsq = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+    if (use_fast && eps[0] == T(1) && eps[1] == T(1) && eps[2] == T(1)) {
+        SlideCoef k;
+        k.c0 = (double)ycyc / (double)yn;
+        k.c1 = 2. / (double)a * (double)bb;
+        k.c2 = (double)b2 / ((double)a * (double)a);
+        k.c3m1 = (double)bsq - 1.;
+        double root;
+        if (slide_leftmost_root<T>(Y, k, &root)) {
+            // leftmost real eigenvalue; admissible when <= 0, else no admissible one (constraints.py:826-830)
+            *shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
+            return 2;
+        }
+    }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             T yhat = Y[4 * i + j] - ycyc / yn;                   // scalar subtracted from every entry
@@ -537,6 +635,11 @@ ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], 
             work[i * 6 + (3 + j)] = (i == j) ? -(e2[i] * (b2 / (a * a))) : T(0);
             work[(3 + i) * 6 + j] = (i == j) ? (e2[i] * bsq - T(1)) : T(0);
         }
+    return 3;
+}
+
+template <typename T, typename AP>
+ARB_HD T slide_shift_from_eig(AP work) {
     T wr[6], wi[6];
     int nf = eig6<T>(work, wr, wi);
     bool any = false;
@@ -545,7 +648,11 @@ ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], 
         bool ok = (i >= 6 - nf) && (wi[i] == T(0)) && (wr[i] <= T(0));
         if (ok) { smin = any ? (wr[i] < smin ? wr[i] : smin) : wr[i]; any = true; }
     }
-    T s = any ? (smin > T(-1e10) ? smin : T(-1e10)) : T(-1e10);   // constraints.py:827-830
+    return any ? (smin > T(-1e10) ? smin : T(-1e10)) : T(-1e10);   // constraints.py:827-830
+}
+
+template <typename T>
+ARB_HD void softfinger_slide_finish(const T Y[16], const T alpha[4], const T eps[3], T s, T f[4], T df[4]) {
     T A[4][4], Bv[4][1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -554,9 +661,19 @@ ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], 
         Bv[i][0] = -alpha[i];
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) A[i][i] -= s / e2[i];              // s * diag(eps**-2)
+    for (int i = 0; i < 3; ++i) A[i][i] -= s / (eps[i] * eps[i]);  // s * diag(eps**-2)
     gepp4<T, 1>(A, Bv);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { df[i] = Bv[i][0] - f[i]; f[i] = Bv[i][0]; }
-    return 2;
+}
+
+// Sequential composition (host tests; `use_fast` = false forces the eig6 route).
+template <typename T, typename AP>
+ARB_HD int softfinger_solve(const T v[4], const T Y[16], const T P[16], T f[4], T df[4],
+                            T sdist, T dt, T mu, const T eps[3], AP work, bool use_fast = true) {
+    T alpha[4], s = T(0);
+    int br = softfinger_try<T>(v, Y, P, f, df, sdist, dt, mu, eps, work, alpha, &s, use_fast);
+    if (br == 3) { s = slide_shift_from_eig<T>(work); br = 2; }
+    if (br == 2) softfinger_slide_finish<T>(Y, alpha, eps, s, f, df);
+    return br;
 }

@@ -62,10 +62,12 @@ def test_world_step_without_gpu_raises():
 
 
 @needs_lib
+@pytest.mark.parametrize("route", [0, 0x100])
 @pytest.mark.parametrize("branch,code", [("release", 0), ("static", 1), ("sliding", 2)])
-def test_device_softfinger_solve_on_host(branch, code):
+def test_device_softfinger_solve_on_host(branch, code, route):
     """arb_math.h::softfinger_solve (float64, host build) vs the reference's
-    captured solve() tuples, incl. the sliding branch's 6x6 eigenvalues."""
+    captured solve() tuples.  route 0 = sextic + Laguerre fast path for the sliding
+    shift, 0x100 = generic 6x6 QR eigenvalues (the fallback)."""
     lib = _capi.load()
     g = load_golden("g3_contacts.npz")
     n = len(g["solve_%s_dt" % branch])
@@ -76,7 +78,7 @@ def test_device_softfinger_solve_on_host(branch, code):
         f = np.ascontiguousarray(g["solve_%s_force" % branch][i].copy())
         df = np.zeros(4)
         eps = np.ones(3)
-        br = lib.arb_host_softfinger_solve(_capi.ARB_F64, _capi._dp(vel), _capi._dp(adm), _capi._dp(f),
+        br = lib.arb_host_softfinger_solve(_capi.ARB_F64 | route, _capi._dp(vel), _capi._dp(adm), _capi._dp(f),
                                            float(g["solve_%s_sdist" % branch][i]),
                                            float(g["solve_%s_dt" % branch][i]),
                                            float(g["solve_%s_mu" % branch][i]), _capi._dp(eps), _capi._dp(df))
@@ -84,6 +86,24 @@ def test_device_softfinger_solve_on_host(branch, code):
         ref = g["solve_%s_dforce" % branch][i]
         worst = max(worst, np.abs(df - ref).max() / max(1., np.abs(ref).max()))
     assert worst < 1e-8, worst
+
+
+@needs_lib
+@pytest.mark.parametrize("dtype", [_capi.ARB_F64, _capi.ARB_F32])
+def test_sliding_shift_fast_path_is_taken(dtype):
+    """The register-only sextic/Laguerre route must handle every captured sliding
+    case (code 2); code 3 would mean the slow generic eig6 fallback."""
+    lib = _capi.load()
+    g = load_golden("g3_contacts.npz")
+    eps = np.ones(3)
+    for i in range(len(g["solve_sliding_dt"])):
+        br = lib.arb_host_softfinger_try(
+            dtype, _capi._dp(np.ascontiguousarray(g["solve_sliding_vel"][i])),
+            _capi._dp(np.ascontiguousarray(g["solve_sliding_adm"][i])),
+            _capi._dp(np.ascontiguousarray(g["solve_sliding_force"][i])),
+            float(g["solve_sliding_sdist"][i]), float(g["solve_sliding_dt"][i]),
+            float(g["solve_sliding_mu"][i]), _capi._dp(eps))
+        assert br == 2
 
 
 @needs_lib
