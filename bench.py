@@ -155,14 +155,13 @@ def main():
     # final state gather over RCCL/xGMI (outside the timed region, reported separately)
     gather_ms = None
     if dist is not None:
-        state = torch.cat([qf, dqf], dim=1).contiguous()
-        out = [torch.empty_like(state) for _ in range(world)] if rank == 0 else None
+        from arboris_python_amd.dist import gather_state
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        outl = [torch.empty_like(state) for _ in range(world)]
-        dist.all_gather(outl, state)
+        q_all, dq_all = gather_state(qf, dqf, world * B, dist)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        assert q_all.shape[0] == world * B
 
     if rank != 0:
         if dist is not None:
