@@ -45,7 +45,7 @@ class ModelInfo(C.Structure):
 
 
 INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
-                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next"]
+                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "stamps"]
 
 
 class InspectOut(C.Structure):

@@ -114,14 +114,14 @@ class BatchedWorlds(object):
                       M=(B, n, n), B=(B, n, n), N=(B, n, n), Z=(B, n, n), gforce0=(B, n),
                       vel_free=(B, n), c_sdist=(B, nc), c_active=(B, nc), c_jac=(B, nc, 4, n),
                       c_force=(B, nc, 4), c_frame=(B, nc, 2, 4, 4), gforce=(B, n),
-                      q_next=(B, nq), dq_next=(B, n))
+                      q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 4), stamps=(B, 8))
         want = list(want)
         if "gforce" in want and nc and "c_jac" not in want:
             want.append("c_jac")
         out = _capi.InspectOut()
         res = {}
         for name in want:
-            dt_ = torch.int32 if name == "c_active" else q.dtype
+            dt_ = torch.int32 if name in ("c_active", "gs_stats") else (torch.int64 if name == "stamps" else q.dtype)
             t = torch.zeros(shapes[name], dtype=dt_, device=self.device)
             res[name] = t
             setattr(out, name, t.data_ptr())

@@ -73,7 +73,7 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
 
 template <typename T>
 struct DevModel {
-    int nb, n, nq, nc, ndol, ncols, maxdepth, nslots, natt;
+    int nb, n, nq, nc, ndol, ncols, maxdepth, nslots, natt, slot_elems;
     int has_visc, has_pd, has_warm, has_grav;
     const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *src, *sslot, *weighted;
     const int *dof2q, *att_start, *att_c, *att_kind;
@@ -92,6 +92,8 @@ struct DebugOut {
     T *pose, *twist, *jac, *djac, *Zout, *gforce0, *vel_free, *c_sdist;
     int *c_active;
     T *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next;
+    long long *stamps;  // [nw][8] s_memtime at the phase boundaries (diagnostic)
+    int *gs_stats;      // [nw][4]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts
 };
 
 // ---------------------------------------------------------------------------
@@ -151,6 +153,16 @@ __device__ __forceinline__ void mat6_vec(const T *__restrict__ M, const T x[6], 
 
 extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 
+// One workgroup = one wavefront.  LDS instructions of a single wave execute in issue
+// order, so a value written by one lane is visible to any lane's later ds_read without
+// a hardware barrier; what must be prevented is the COMPILER moving LDS accesses across
+// the hand-off points.  A workgroup-scope fence does that (it lowers to s_waitcnt
+// lgkmcnt(0) only, it does not drain outstanding global/scalar loads like
+// __syncthreads() does).
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+                         __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
 // ===========================================================================
 // The step kernel.  MODE 0 = production, 1 = inspect (debug stores, no state
 // write-back).  zmode (inspect only): 0 full Z, 1 M only, 2 B only, 3 N only.
@@ -171,6 +183,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     T *JB = lds + L.jb, *SL = lds + L.slots, *CD = lds + L.cd, *RT = lds + L.rt;
     T *AM = lds + L.am, *VV = lds + L.vv, *FF = lds + L.ff, *FF0 = lds + L.ff0, *WORK = lds + L.work;
     const int n = m.n, nb = m.nb, nq = m.nq, nc = m.nc, ndol = m.ndol;
+    constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
     const T inv_dt = T(1) / dt;
     const bool do_constraints = (nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
 
@@ -183,12 +196,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         FF[i] = f;
     }
     const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
-    __syncthreads();
+    WAVE_SYNC();
 
+#define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
     for (int step = 0; step < nsteps; ++step) {
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
+        ARB_STAMP(0);
         {
             const int b = lane;
             const bool on = b < nb;
@@ -273,10 +288,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         const V3<T> dow = mv(R_cn, dw);
                         const V3<T> dov = cross(p_cn, dow);
                         const int col = doff + i;
-                        SC[0 * WAVE + col] = ow.x; SC[1 * WAVE + col] = ow.y; SC[2 * WAVE + col] = ow.z;
-                        SC[3 * WAVE + col] = ov.x; SC[4 * WAVE + col] = ov.y; SC[5 * WAVE + col] = ov.z;
-                        SC[6 * WAVE + col] = dow.x; SC[7 * WAVE + col] = dow.y; SC[8 * WAVE + col] = dow.z;
-                        SC[9 * WAVE + col] = dov.x; SC[10 * WAVE + col] = dov.y; SC[11 * WAVE + col] = dov.z;
+                        SC[0 * RS + col] = ow.x; SC[1 * RS + col] = ow.y; SC[2 * RS + col] = ow.z;
+                        SC[3 * RS + col] = ov.x; SC[4 * RS + col] = ov.y; SC[5 * RS + col] = ov.z;
+                        SC[6 * RS + col] = dow.x; SC[7 * RS + col] = dow.y; SC[8 * RS + col] = dow.z;
+                        SC[9 * RS + col] = dov.x; SC[10 * RS + col] = dov.y; SC[11 * RS + col] = dov.z;
                     }
                 }
             }
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<T> nbv = mv(dB_cp, tw) + mv(dA_cp, tv) + cross(p_cp, raw) + mv(R_cp, av) + Bnv;
                     st_v3(bd + BD_AB, nbw); st_v3(bd + BD_AB + 3, nbv);
                 }
-                __syncthreads();
+                WAVE_SYNC();
             }
             if (on) {
                 T *bd = BD + b * BD_STRIDE;
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             }
             // dof-indexed copy of the linear joint positions (PD controller, joint limits)
             if (lane < n) { const int qi = m.dof2q[lane]; qd[lane] = qi >= 0 ? qs[qi] : T(0); }
-            __syncthreads();
+            WAVE_SYNC();
         }
         if (MODE == 1 && step == 0) {
             if (dbg.pose != nullptr && lane < nb) {
@@ -378,7 +393,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 
         // ================= phase A': lane = constraint =====================
         ARB_OPAQUE_LANE();
-        for (int i = lane; i < (1 + ndol) * WAVE; i += WAVE) RT[i] = T(0);
+        ARB_STAMP(1);
+        for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0);
         if (do_constraints && lane < nc) {
             const int c = lane;
             T *cd = CD + c * CD_STRIDE;
@@ -447,11 +463,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             cd[CD_SDIST] = sd;
             cd[CD_ACTIVE] = active ? T(1) : T(0);
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < ndol) FF0[lane] = FF[lane];
 
         // ================= phase B: lane = dof column =======================
         ARB_OPAQUE_LANE();
+        ARB_STAMP(2);
         T Z[NMAX];
         T Z2[NSETS == 2 ? NMAX : 1];
 #pragma unroll
@@ -466,11 +483,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { Jw[i] = Jv[i] = dJw[i] = dJv[i] = T(0); }
                 } else if (src >= 2) {
-                    const T *sl = SL + (src - 2) * 12 * WAVE;
+                    // parent's columns were parked in an LDS slot; only its ancestor dofs are non-zero
+                    const unsigned long long pm = m.anc[m.parent[b]];
+                    const bool mine = (pm >> lane) & 1ull;
+                    const T *sl = SL + (src - 2) * m.slot_elems + 12 * __popcll(pm & ((1ull << lane) - 1ull));
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        Jw[i] = sl[i * WAVE + lane]; Jv[i] = sl[(3 + i) * WAVE + lane];
-                        dJw[i] = sl[(6 + i) * WAVE + lane]; dJv[i] = sl[(9 + i) * WAVE + lane];
+                        Jw[i] = mine ? sl[i] : T(0); Jv[i] = mine ? sl[3 + i] : T(0);
+                        dJw[i] = mine ? sl[6 + i] : T(0); dJv[i] = mine ? sl[9 + i] : T(0);
                     }
                 }
                 const T *bd = BD + b * BD_STRIDE;
@@ -486,20 +506,20 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 V3<T> ndv = mv(dB, jw) + mv(dA, jv) + mv(R, djv) + cross(p, tdw);
                 const int d0 = m.dof_off[b];
                 if (lane >= d0 && lane < d0 + m.jnd[b]) {
-                    nw = nw + v3<T>(SC[0 * WAVE + lane], SC[1 * WAVE + lane], SC[2 * WAVE + lane]);
-                    nv = nv + v3<T>(SC[3 * WAVE + lane], SC[4 * WAVE + lane], SC[5 * WAVE + lane]);
-                    ndw = ndw + v3<T>(SC[6 * WAVE + lane], SC[7 * WAVE + lane], SC[8 * WAVE + lane]);
-                    ndv = ndv + v3<T>(SC[9 * WAVE + lane], SC[10 * WAVE + lane], SC[11 * WAVE + lane]);
+                    nw = nw + v3<T>(SC[0 * RS + lane], SC[1 * RS + lane], SC[2 * RS + lane]);
+                    nv = nv + v3<T>(SC[3 * RS + lane], SC[4 * RS + lane], SC[5 * RS + lane]);
+                    ndw = ndw + v3<T>(SC[6 * RS + lane], SC[7 * RS + lane], SC[8 * RS + lane]);
+                    ndv = ndv + v3<T>(SC[9 * RS + lane], SC[10 * RS + lane], SC[11 * RS + lane]);
                 }
                 Jw[0] = nw.x; Jw[1] = nw.y; Jw[2] = nw.z; Jv[0] = nv.x; Jv[1] = nv.y; Jv[2] = nv.z;
                 dJw[0] = ndw.x; dJw[1] = ndw.y; dJw[2] = ndw.z; dJv[0] = ndv.x; dJv[1] = ndv.y; dJv[2] = ndv.z;
                 const int ss = m.sslot[b];
                 if (ss >= 0) {
-                    T *sl = SL + ss * 12 * WAVE;
+                    const unsigned long long bm = m.anc[b];
+                    if ((bm >> lane) & 1ull) {
+                        T *sl = SL + ss * m.slot_elems + 12 * __popcll(bm & ((1ull << lane) - 1ull));
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        sl[i * WAVE + lane] = Jw[i]; sl[(3 + i) * WAVE + lane] = Jv[i];
-                        sl[(6 + i) * WAVE + lane] = dJw[i]; sl[(9 + i) * WAVE + lane] = dJv[i];
+                        for (int i = 0; i < 3; ++i) { sl[i] = Jw[i]; sl[3 + i] = Jv[i]; sl[6 + i] = dJw[i]; sl[9 + i] = dJv[i]; }
                     }
                 }
                 if (MODE == 1 && step == 0 && lane < n) {
@@ -561,21 +581,24 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         const V3<T> px = ld_v3(cd + (kind == 2 ? CD_P0 : CD_P1));
                         const V3<T> cw = mv(Rx, nw);
                         const V3<T> cv = mv(Rx, nv) + cross(px, cw);
-                        T *row = RT + (1 + 4 * c) * WAVE + lane;
+                        T *row = RT + (1 + 4 * c) * RS + (lane < RS ? lane : 0);
+                        if (lane >= RS) continue;
                         if (kind == 0) {            // SoftFinger rows (w_z, v_x, v_y, v_z)  constraints.py:429-433
-                            row[0] += act * cw.z; row[WAVE] += act * cv.x;
-                            row[2 * WAVE] += act * cv.y; row[3 * WAVE] += act * cv.z;
+                            row[0] += act * cw.z; row[RS] += act * cv.x;
+                            row[2 * RS] += act * cv.y; row[3 * RS] += act * cv.z;
                         } else {                    // BallAndSocket linear rows, +frame1 / -frame0  constraints.py:203-207
                             const T sgn = (kind == 1) ? act : -act;
-                            row[0] += sgn * cv.x; row[WAVE] += sgn * cv.y; row[2 * WAVE] += sgn * cv.z;
+                            row[0] += sgn * cv.x; row[RS] += sgn * cv.y; row[2 * RS] += sgn * cv.z;
                         }
                     }
                 }
                 // publish this body's Jacobian columns and accumulate Z[i][k] += J[:,i] . Q[:,k]
-                __syncthreads();
-                JB[8 * lane + 0] = x[0]; JB[8 * lane + 1] = x[1]; JB[8 * lane + 2] = x[2]; JB[8 * lane + 3] = x[3];
-                JB[8 * lane + 4] = x[4]; JB[8 * lane + 5] = x[5];
-                __syncthreads();
+                WAVE_SYNC();
+                if (lane < RS) {
+                    JB[8 * lane + 0] = x[0]; JB[8 * lane + 1] = x[1]; JB[8 * lane + 2] = x[2]; JB[8 * lane + 3] = x[3];
+                    JB[8 * lane + 4] = x[4]; JB[8 * lane + 5] = x[5];
+                }
+                WAVE_SYNC();
                 const unsigned long long mask = m.anc[b];
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i) {
@@ -590,7 +613,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         if (do_constraints) {
             for (int c = 0; c < nc; ++c)
                 if (m.ctype[c] == ARB_CT_JOINTLIMITS && lane == m.cdof[c])
-                    RT[(1 + 4 * c) * WAVE + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
+                    RT[(1 + 4 * c) * RS + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
         }
         // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
         T gf0 = rhsG + ext_k;          // controllers' generalized force (inspect output)
@@ -609,7 +632,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     if (i < n) Z[i] += dt * m.pd_kp[i * n + lane] + m.pd_kd[i * n + lane];
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (MODE == 1) {
             if (dbg.Zout != nullptr && lane < n) {
 #pragma unroll
@@ -618,7 +641,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             if (zmode != 0) return;
             if (dbg.gforce0 != nullptr && lane < n) dbg.gforce0[w * n + lane] = gf0;
             if (dbg.c_jac != nullptr && lane < n)
-                for (int i = 0; i < ndol; ++i) dbg.c_jac[(w * ndol + i) * n + lane] = do_constraints ? RT[(1 + i) * WAVE + lane] : T(0);
+                for (int i = 0; i < ndol; ++i) dbg.c_jac[(w * ndol + i) * n + lane] = do_constraints ? RT[(1 + i) * RS + lane] : T(0);
             if (lane < nc) {
                 const T *cd = CD + lane * CD_STRIDE;
                 if (dbg.c_sdist != nullptr) dbg.c_sdist[w * nc + lane] = do_constraints ? cd[CD_SDIST] : T(0);
@@ -637,24 +660,25 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         }
         // warm-started constraint forces enter the right-hand side          core.py:921-924
         if (do_constraints && m.has_warm && lane < n) {
-            for (int i = 0; i < ndol; ++i) rhs += RT[(1 + i) * WAVE + lane] * FF[i];
+            for (int i = 0; i < ndol; ++i) rhs += RT[(1 + i) * RS + lane] * FF[i];
         }
         // ================= phase C: augmented Gauss-Jordan ===================
         ARB_OPAQUE_LANE();
-        RT[lane] = (lane < n) ? rhs : T(0);
-        __syncthreads();
+        ARB_STAMP(3);
+        if (lane < RS) RT[lane] = (lane < n) ? rhs : T(0);
+        WAVE_SYNC();
         const int ncols = do_constraints ? m.ncols : n + 1;
         if (lane >= n) {
             const int r = lane - n;                 // column r of [rhs | J'^T]
             const bool have = lane < ncols;
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) Z[i] = (have && i < n) ? RT[r * WAVE + i] : T(0);
+            for (int i = 0; i < NMAX; ++i) Z[i] = (have && i < n) ? RT[r * RS + i] : T(0);
         }
         if (NSETS == 2) {
             const int r = WAVE + lane - n;
             const bool have = (WAVE + lane) < ncols;
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) Z2[i] = (have && i < n) ? RT[r * WAVE + i] : T(0);
+            for (int i = 0; i < NMAX; ++i) Z2[i] = (have && i < n) ? RT[r * RS + i] : T(0);
         }
         // Pivots are taken from the last dof to the first (extremities before the
         // root): on these graded, nearly-SPD matrices that order halves the float32
@@ -698,16 +722,20 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 
         // ================= phase D: constraint space + Gauss-Seidel ==========
         ARB_OPAQUE_LANE();
+        ARB_STAMP(4);
         if (do_constraints) {
             // [v | Y'] = J' [Y rhs | Y J'^T]                                core.py:925-927
+            typedef T V4 __attribute__((ext_vector_type(4)));
             for (int idx = 0; idx < ndol; ++idx) {
-                const T *jr = RT + (1 + idx) * WAVE;
+                // row idx of J' (zero beyond ndof), read as 16/32-byte LDS vectors (wave-uniform address)
+                const V4 *jr4 = reinterpret_cast<const V4 *>(RT + (1 + idx) * RS);
                 T acc = T(0), acc2 = T(0);
 #pragma unroll
-                for (int i = 0; i < NMAX; ++i) {
-                    const T jv = (i < n) ? jr[i] : T(0);
-                    acc += jv * Z[i];
-                    if (NSETS == 2) acc2 += jv * Z2[i];
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    const V4 jv = jr4[i4];
+                    acc += jv.x * Z[4 * i4] + jv.y * Z[4 * i4 + 1] + jv.z * Z[4 * i4 + 2] + jv.w * Z[4 * i4 + 3];
+                    if (NSETS == 2)
+                        acc2 += jv.x * Z2[4 * i4] + jv.y * Z2[4 * i4 + 1] + jv.z * Z2[4 * i4 + 2] + jv.w * Z2[4 * i4 + 3];
                 }
                 if (lane == n) VV[idx] = acc;
                 else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = acc;
@@ -716,19 +744,19 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = acc2;
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
         // solution columns -> LDS (row r of RT := column r of [Y rhs | Y J'^T])
-        __syncthreads();
+        WAVE_SYNC();
         if (lane >= n && lane < ncols) {
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(lane - n) * WAVE + i] = Z[i];
+            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(lane - n) * RS + i] = Z[i];
         }
         if (NSETS == 2 && (WAVE + lane) < ncols) {
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(WAVE + lane - n) * WAVE + i] = Z2[i];
+            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(WAVE + lane - n) * RS + i] = Z2[i];
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (MODE == 1 && dbg.vel_free != nullptr && lane < n) dbg.vel_free[w * n + lane] = RT[lane];
 
         if (do_constraints) {
@@ -741,67 +769,146 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                 for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
             }
-            __syncthreads();
-            for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
-                for (int c = 0; c < nc; ++c) {
-                    const T *cd = CD + c * CD_STRIDE;
-                    if (cd[CD_ACTIVE] == T(0)) continue;
-                    const int ct = m.ctype[c];
-                    T v[4], f[4], df[4], Y[16], P[16];
+            WAVE_SYNC();
+            ARB_STAMP(5);
+            // ---- Gauss-Seidel, core.py:929-935, register resident ----------------------
+            // lane = row of the stacked constraint system: it keeps its velocity, its force,
+            // its row of the constraint's own admittance block Y_cc and of inv(Y_cc).  Lane c
+            // also keeps the scalars of constraint c.  Everything a solve needs from other
+            // lanes comes through v_readlane broadcasts (wave-uniform values), so the 20 x nc
+            // sequential solves touch LDS only to read their column block of Y' (read-only).
+            T vr = T(0), fr = T(0), Yrow[4], Prow[4];
+            T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
+            T k_min = T(0), k_max = T(0);
+            int k_ct = 0;
+            bool k_act = false;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[i] = VV[4 * c + i]; f[i] = FF[4 * c + i]; df[i] = T(0);
+            for (int i = 0; i < 4; ++i) { Yrow[i] = T(0); Prow[i] = T(0); }
+            if (lane < ndol) {
+                const int cc = lane >> 2, rr = lane & 3;
+                vr = VV[lane]; fr = FF[lane];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { Y[4 * i + j] = AM[(4 * c + i) * ndol + 4 * c + j]; P[4 * i + j] = cd[CD_PINV + 4 * i + j]; }
-                    }
-                    __syncthreads();     // everyone has read VV/FF/WORK inputs before they change
-                    if (ct == ARB_CT_SOFTFINGER_PLANE) {
-                        const T eps[3] = {m.ceps[3 * c], m.ceps[3 * c + 1], m.ceps[3 * c + 2]};
-                        // wave-uniform data: every lane evaluates the same scalar code in registers.
-                        T alpha[4], shift = T(0);
-                        int br = softfinger_try<T>(v, Y, P, f, df, cd[CD_SDIST], dt, m.cmu[c], eps, WORK, alpha, &shift);
-                        if (br == 3) {
-                            // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
-                            __syncthreads();
-                            if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
-                            __syncthreads();
-                            shift = WORK[40];
-                            br = 2;
-                        }
-                        if (br == 2) softfinger_slide_finish<T>(Y, alpha, eps, shift, f, df);
-                    } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            T s = T(0);
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) s += P[4 * i + j] * (v[j] + cd[CD_POS0 + j] * inv_dt);
-                            df[i] = -s; f[i] += df[i];
-                        }
-                    } else {                                               // JointLimits.solve constraints.py:73-90
-                        const T pred = cd[CD_POS0] + dt * (v[0] - Y[0] * f[0]);
-                        T nf = T(0);
-                        if (pred <= m.cmin[c]) nf = P[0] * ((m.cmin[c] - pred) * inv_dt);
-                        else if (m.cmax[c] <= pred) nf = P[0] * ((m.cmax[c] - pred) * inv_dt);
-                        df[0] = nf - f[0]; f[0] = nf;
-                    }
-                    // vel += Y'[:, c] dforce                               core.py:935
-                    if (lane < ndol) {
-                        const T *ar = AM + lane * ndol + 4 * c;
-                        VV[lane] += ar[0] * df[0] + ar[1] * df[1] + ar[2] * df[2] + ar[3] * df[3];
-                    }
-                    if (lane < 4) FF[4 * c + lane] = f[lane];
-                    __syncthreads();
+                for (int i = 0; i < 4; ++i) {
+                    Yrow[i] = AM[lane * ndol + 4 * cc + i];
+                    Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
                 }
             }
+            if (lane < nc) {
+                const T *cd = CD + lane * CD_STRIDE;
+                k_act = cd[CD_ACTIVE] != T(0);
+                k_sd = cd[CD_SDIST]; k_p0 = cd[CD_POS0]; k_p1 = cd[CD_POS0 + 1]; k_p2 = cd[CD_POS0 + 2];
+                k_ct = m.ctype[lane]; k_mu = m.cmu[lane];
+                k_e0 = m.ceps[3 * lane]; k_e1 = m.ceps[3 * lane + 1]; k_e2 = m.ceps[3 * lane + 2];
+                k_min = m.cmin[lane]; k_max = m.cmax[lane];
+            }
+            const unsigned long long actmask = __ballot(k_act);
+            int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0;
+            for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+                for (int c = 0; c < nc; ++c) {
+                    if (!((actmask >> c) & 1ull)) continue;
+                    const int base = 4 * c;
+                    // column block Y'[:, 4c..4c+3] of this lane's row (issued early, used last)
+                    T a4[4] = {T(0), T(0), T(0), T(0)};
+                    if (lane < ndol) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a4[i] = AM[lane * ndol + base + i];
+                    }
+                    const int ct = __builtin_amdgcn_readlane(k_ct, c);
+                    T vc[4], fc[4], df[4], fnew[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { vc[i] = bcast(vr, base + i); fc[i] = bcast(fr, base + i); }
+                    // own-row products (meaningful on lanes base..base+3)
+                    const T v0r = vr - (Yrow[0] * fc[0] + Yrow[1] * fc[1] + Yrow[2] * fc[2] + Yrow[3] * fc[3]);
+                    if (ct == ARB_CT_SOFTFINGER_PLANE) {                   // constraints.py:780-836
+                        const T sd = bcast(k_sd, c), mu = bcast(k_mu, c);
+                        const T v0n = bcast(v0r, base + 3);
+                        if (sd + dt * v0n > T(0)) {                        // release
+                            if (MODE == 1) ++st_rel;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { df[i] = -fc[i]; fnew[i] = T(0); }
+                        } else {
+                            const T sdt = sd / dt;
+                            const T dfr = -(Prow[0] * vc[0] + Prow[1] * vc[1] + Prow[2] * vc[2] + Prow[3] * (vc[3] + sdt));
+                            const T fnr = fr + dfr;
+                            T fn[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fn[i] = bcast(fnr, base + i);
+                            const T eps[3] = {bcast(k_e0, c), bcast(k_e1, c), bcast(k_e2, c)};
+                            const T lhs = (fn[0] / eps[0]) * (fn[0] / eps[0]) + (fn[1] / eps[1]) * (fn[1] / eps[1])
+                                        + (fn[2] / eps[2]) * (fn[2] / eps[2]);
+                            const T rhs = (fn[3] * mu) * (fn[3] * mu);
+                            if (lhs <= rhs) {                              // static friction
+                                if (MODE == 1) ++st_sta;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { fnew[i] = fn[i]; df[i] = fn[i] - fc[i]; }
+                                // df must be exactly -pinv(Y)(...) as in the reference: recover it from the rows
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) df[i] = bcast(dfr, base + i);
+                            } else {                                       // sliding friction
+                                T Y[16], alpha[4], shift = T(0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    alpha[r] = bcast(v0r, base + r);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) Y[4 * r + i] = bcast(Yrow[i], base + r);
+                                }
+                                alpha[3] += sdt;
+                                if (MODE == 1) ++st_fast;
+                                if (!softfinger_sliding_shift<T>(Y, alpha, mu, eps, WORK, &shift)) {
+                                    if (MODE == 1) { ++st_slow; --st_fast; }
+                                    // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
+                                    WAVE_SYNC();
+                                    if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
+                                    WAVE_SYNC();
+                                    shift = WORK[40];
+                                    WAVE_SYNC();
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) fnew[i] = fc[i];
+                                softfinger_slide_finish<T>(Y, alpha, eps, shift, fnew, df);
+                            }
+                        }
+                    } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
+                        const T p0 = bcast(k_p0, c), p1 = bcast(k_p1, c), p2 = bcast(k_p2, c);
+                        const T dfr = -(Prow[0] * (vc[0] + p0 * inv_dt) + Prow[1] * (vc[1] + p1 * inv_dt)
+                                        + Prow[2] * (vc[2] + p2 * inv_dt));
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { df[i] = bcast(dfr, base + i); fnew[i] = fc[i] + df[i]; }
+                        df[3] = T(0); fnew[3] = fc[3];
+                    } else {                                               // JointLimits.solve constraints.py:73-90
+                        const T pos0 = bcast(k_p0, c), lo = bcast(k_min, c), hi = bcast(k_max, c);
+                        const T p00 = bcast(Prow[0], base);
+                        const T pred = pos0 + dt * bcast(v0r, base);
+                        T nf = T(0);
+                        if (pred <= lo) nf = p00 * ((lo - pred) * inv_dt);
+                        else if (hi <= pred) nf = p00 * ((hi - pred) * inv_dt);
+                        df[0] = nf - fc[0]; fnew[0] = nf;
+#pragma unroll
+                        for (int i = 1; i < 4; ++i) { df[i] = T(0); fnew[i] = fc[i]; }
+                    }
+                    // vel += Y'[:, c] dforce                               core.py:935
+                    vr += a4[0] * df[0] + a4[1] * df[1] + a4[2] * df[2] + a4[3] * df[3];
+                    const int rr = lane - base;
+                    fr = (rr == 0) ? fnew[0] : (rr == 1) ? fnew[1] : (rr == 2) ? fnew[2] : (rr == 3) ? fnew[3] : fr;
+                }
+            }
+            if (MODE == 1 && dbg.gs_stats != nullptr && lane == 0) {
+                int *o = dbg.gs_stats + w * 4;
+                o[0] = st_rel; o[1] = st_sta; o[2] = st_fast; o[3] = st_slow;
+            }
+            WAVE_SYNC();
+            if (lane < ndol) { FF[lane] = fr; VV[lane] = vr; }
+            WAVE_SYNC();
         }
 
         // ================= phase E: new velocity, integrate ==================
         ARB_OPAQUE_LANE();
+        ARB_STAMP(6);
         T vnew = T(0);
         if (lane < n) {
             vnew = RT[lane];
             if (do_constraints)
-                for (int i = 0; i < ndol; ++i) vnew += RT[(1 + i) * WAVE + lane] * (FF[i] - FF0[i]);
+                for (int i = 0; i < ndol; ++i) vnew += RT[(1 + i) * RS + lane] * (FF[i] - FF0[i]);
         }
         if (MODE == 1) {
             if (dbg.gforce != nullptr && lane < n) {
@@ -815,13 +922,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             if (dbg.c_force != nullptr)
                 for (int i = lane; i < ndol; i += WAVE) dbg.c_force[w * ndol + i] = FF[i];
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < n) {
             dqs[lane] = vnew;
             const int qi = m.dof2q[lane];
             if (qi >= 0) qs[qi] += dt * vnew;                               // core.py:238-240
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < nb && m.jtype[lane] == JT_FREE) {                        // joints.py:54-57
             T *qp = qs + m.q_off[lane];
             const T *vp = dqs + m.dof_off[lane];
@@ -837,11 +944,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             qp[8] = Rn.a[6]; qp[9] = Rn.a[7]; qp[10] = Rn.a[8]; qp[11] = pn.z;
             qp[12] = T(0); qp[13] = T(0); qp[14] = T(0); qp[15] = T(1);
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
 
     // ---- store state -------------------------------------------------------
     ARB_OPAQUE_LANE();
+    ARB_STAMP(7);
     if (MODE == 0) {
         for (int i = lane; i < nq; i += WAVE) gq[w * nq + i] = qs[i];
         if (lane < n) gdq[w * n + lane] = dqs[lane];
@@ -905,7 +1013,7 @@ static std::vector<double> h12(const double *H16, int count) {
     return v;
 }
 
-static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int elems_per_double, int *total_elems) {
+static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot_elems, int rs, int elems_per_double, int *total_elems) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
@@ -914,11 +1022,11 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int elem
     L.qd = o; o += WAVE;
     L.bd = o; o += al(nb * BD_STRIDE);
     L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
-    L.sc = o; o += 12 * WAVE;
-    L.jb = o; o += 8 * WAVE;
-    L.slots = o; o += std::max(nslots, 1) * 12 * WAVE;
+    L.sc = o; o += 12 * rs;
+    L.jb = o; o += 8 * rs;
+    L.slots = o; o += al(std::max(nslots, 1) * std::max(slot_elems, 12));
     L.cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
-    L.rt = o; o += (1 + ndol) * WAVE;
+    L.rt = o; o += (1 + ndol) * rs;
     L.am = o; o += al(std::max(ndol * ndol, 4));
     L.vv = o; o += al(std::max(ndol, 4));
     L.ff = o; o += al(std::max(ndol, 4));
@@ -948,12 +1056,12 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
                      const std::vector<int> &sslot, const std::vector<unsigned long long> &anc,
                      const std::vector<int> &dof2q, const std::vector<int> &att_start,
                      const std::vector<int> &att_c, const std::vector<int> &att_kind,
-                     int maxdepth, int nslots, DevModel<T> *out) {
+                     int maxdepth, int nslots, int slot_elems, DevModel<T> *out) {
     DevModel<T> m;
     memset(&m, 0, sizeof(m));
     const int nb = d->nb, n = d->ndof, nc = d->nc;
     m.nb = nb; m.n = n; m.nq = d->nq; m.nc = nc; m.ndol = ARB_MAXDOL * nc; m.ncols = n + 1 + m.ndol;
-    m.maxdepth = maxdepth; m.nslots = nslots; m.natt = (int)att_c.size();
+    m.maxdepth = maxdepth; m.nslots = nslots; m.natt = (int)att_c.size(); m.slot_elems = slot_elems;
     int rc;
 #define UP_I(field, vec) if ((rc = upload<int>(M, vec, &m.field)) != ARB_OK) return rc
 #define UP_T(field, vec) if ((rc = upload<T>(M, vec, &m.field)) != ARB_OK) return rc
@@ -1092,6 +1200,9 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     }
     for (int b = 0; b < nb; ++b) if (src[b] >= 2 && src[b] - 2 < 0) return ARB_ERR_INVALID;
     const int nslots = (int)slot_owner.size();
+    int slot_elems = 12;
+    for (int b = 0; b < nb; ++b)
+        if (sslot[b] >= 0) slot_elems = std::max(slot_elems, 12 * (int)__builtin_popcountll(anc[b]));
     // constraint attachments per body
     std::vector<std::vector<std::pair<int, int>>> per_body(nb);
     for (int c = 0; c < nc; ++c) {
@@ -1125,13 +1236,13 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete M; return ARB_ERR_HIP; }
-    int rc = build_dev<float>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, &M->df);
+    int rc = build_dev<float>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, &M->df);
     if (rc == ARB_OK)
-        rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, &M->dd);
+        rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     int tot;
-    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, 2, &tot);
-    M->ld = make_layout(nb, d->nq, nc, ndol, nslots, 1, &tot);
+    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 2, &tot);
+    M->ld = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     *out = M;
     return ARB_OK;
@@ -1228,7 +1339,7 @@ static int inspect_t(arb_model *M, const DevModel<T> &dm, const Layout &L, const
     dbg.Zout = (T *)o->Z; dbg.gforce0 = (T *)o->gforce0; dbg.vel_free = (T *)o->vel_free;
     dbg.c_sdist = (T *)o->c_sdist; dbg.c_active = (int *)o->c_active; dbg.c_jac = (T *)o->c_jac;
     dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
-    dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next;
+    dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.stamps = (long long *)o->stamps;
     return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, st);
 }
 

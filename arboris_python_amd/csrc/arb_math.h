@@ -495,6 +495,21 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
 // ---------------------------------------------------------------------------
 struct SlideCoef { double c0, c1, c2, c3m1; };   // c3m1 = (b.b) - 1
 
+ARB_HD double arb_fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    return 1. / x;
+#endif
+}
+ARB_HD double arb_fast_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x > 0. ? x * __builtin_amdgcn_rsq(x) : 0.;
+#else
+    return sqrt(x);
+#endif
+}
+
 ARB_HD void arb_quadmul(const double a[3], const double b[3], double c[5]) {
     c[0] = a[0] * b[0];
     c[1] = a[0] * b[1] + a[1] * b[0];
@@ -512,9 +527,12 @@ ARB_HD bool slide_leftmost_root(const T Y[16], const SlideCoef &k, double *root)
     const double kappa = k.c2 * k.c3m1;
     // F(s) = s^2 I + s A1 + A0 ; entries as quadratics f[i][j] = {A0, A1, delta}
     double f[3][3][3];
-    double rb = 0.;                                   // row-sum bound on the spectrum of B
+    // Spectrum bound: (P - s)(Q - s) + kappa I is non-singular as soon as
+    // (|s| - |P|)(|s| - |Q|) > |kappa|, hence every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
+    // (infinity norms).
+    double rb = 0.;
     for (int i = 0; i < 3; ++i) {
-        double r1 = fabs(k.c2), r2 = fabs(k.c3m1);
+        double r1 = 0., r2 = 0.;
         for (int j = 0; j < 3; ++j) {
             double a0 = P[i][0] * Q[0][j] + P[i][1] * Q[1][j] + P[i][2] * Q[2][j];
             f[i][j][0] = a0 + (i == j ? kappa : 0.);
@@ -534,6 +552,7 @@ ARB_HD bool slide_leftmost_root(const T Y[16], const SlideCoef &k, double *root)
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 5; ++j) pc[i + j] += f[0][t][i] * m1[j];
     }
+    rb += sqrt(fabs(kappa));
     if (!(rb > 0.) || !(rb < 1e300)) return false;
     // Laguerre from the left of every root
     double x = -1.0001 * rb - 1e-300;
@@ -548,17 +567,63 @@ ARB_HD bool slide_leftmost_root(const T Y[16], const SlideCoef &k, double *root)
         p2 *= 2.;
         if (fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0))) { *root = x; return true; }   // p(x) = 0 to rounding
         if (!(p0 > 0.) || !(p1 < 0.)) return false;   // not left of all roots any more: anomaly
-        const double G = p1 / p0;
-        const double H = G * G - p2 / p0;
-        const double rad = (n - 1.) * (n * H - G * G);
+        // Laguerre step  dx = n p / (p' - sqrt((n-1)((n-1) p'^2 - n p p'')))  (p' < 0 here).
+        // Only the step uses approximate sqrt / reciprocal (hardware v_rsq_f64 / v_rcp_f64,
+        // ~1e-8 relative): the accuracy of the root is set by the float64 Horner values and
+        // the stopping test above, not by the step.
+        const double rad = (n - 1.) * ((n - 1.) * p1 * p1 - n * p0 * p2);
         if (!(rad >= 0.)) return false;               // complex roots nearby
-        const double den = G - sqrt(rad);             // G < 0: largest magnitude denominator
-        const double dx = n / den;                    // negative
+        const double den = p1 - arb_fast_sqrt(rad);   // both terms negative: no cancellation
+        // shortened by 2^-20 so that the ~1e-8 error of the approximate sqrt/rcp can never
+        // carry the iterate past the root (the exact Laguerre step from the left never does)
+        const double dx = (n * (1. - 9.5367431640625e-07)) * p0 * arb_fast_rcp(den); // negative
         const double xn = x - dx;
         if (!(xn > x)) { *root = x; return true; }    // no representable progress: converged
         if (fabs(dx) <= 4e-16 * fabs(xn)) { *root = xn; return true; }
         x = xn;
     }
+    return false;
+}
+
+// Sliding branch, constraints.py:803-830: coefficients of B from (Y, alpha) and the
+// shift s.  Returns true with *shift set when the register-only fast path
+// succeeded; otherwise writes the 6x6 matrix B to `work` and returns false (the
+// caller then runs eig6 on it).
+template <typename T, typename AP>
+ARB_HD bool softfinger_sliding_shift(const T Y[16], const T alpha[4], T mu, const T eps[3], AP work,
+                                     T *shift, bool use_fast = true) {
+    T Yc[3] = {Y[3], Y[7], Y[11]};
+    T yn = Y[15];
+    T beta[3], b[3];
+    T a = mu / yn * alpha[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { beta[i] = alpha[i] - alpha[3] / yn * Yc[i]; b[i] = mu / yn * Yc[i]; }
+    T e2[3] = {eps[0] * eps[0], eps[1] * eps[1], eps[2] * eps[2]};
+    T ycyc = Yc[0] * Yc[0] + Yc[1] * Yc[1] + Yc[2] * Yc[2];     // dot(Y_c, Y_c.T): a scalar
+    T bb = beta[0] * b[0] + beta[1] * b[1] + beta[2] * b[2];     // dot(beta, b.T)
+    T b2 = beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2];
+    T bsq = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+    if (use_fast && eps[0] == T(1) && eps[1] == T(1) && eps[2] == T(1)) {
+        SlideCoef k;
+        k.c0 = (double)ycyc / (double)yn;
+        k.c1 = 2. / (double)a * (double)bb;
+        k.c2 = (double)b2 / ((double)a * (double)a);
+        k.c3m1 = (double)bsq - 1.;
+        double root;
+        if (slide_leftmost_root<T>(Y, k, &root)) {
+            // leftmost real eigenvalue; admissible when <= 0, else no admissible one (constraints.py:826-830)
+            *shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
+            return true;
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            T yhat = Y[4 * i + j] - ycyc / yn;                   // scalar subtracted from every entry
+            work[(3 + i) * 6 + (3 + j)] = e2[i] * yhat;
+            work[i * 6 + j] = e2[i] * (yhat + T(2) / a * bb);
+            work[i * 6 + (3 + j)] = (i == j) ? -(e2[i] * (b2 / (a * a))) : T(0);
+            work[(3 + i) * 6 + j] = (i == j) ? (e2[i] * bsq - T(1)) : T(0);
+        }
     return false;
 }
 
@@ -603,39 +668,7 @@ ARB_HD int softfinger_try(const T v[4], const T Y[16], const T P[16], T f[4], T 
     }
     // sliding, constraints.py:803-836
     alpha[0] = v0[0]; alpha[1] = v0[1]; alpha[2] = v0[2]; alpha[3] = v0[3] + sdist / dt;
-    T Yc[3] = {Y[3], Y[7], Y[11]};
-    T yn = Y[15];
-    T beta[3], b[3];
-    T a = mu / yn * alpha[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { beta[i] = alpha[i] - alpha[3] / yn * Yc[i]; b[i] = mu / yn * Yc[i]; }
-    T e2[3] = {eps[0] * eps[0], eps[1] * eps[1], eps[2] * eps[2]};
-    T ycyc = Yc[0] * Yc[0] + Yc[1] * Yc[1] + Yc[2] * Yc[2];     // dot(Y_c, Y_c.T): a scalar
-    T bb = beta[0] * b[0] + beta[1] * b[1] + beta[2] * b[2];     // dot(beta, b.T)
-    T b2 = beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2];
-    T bsq = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
-    if (use_fast && eps[0] == T(1) && eps[1] == T(1) && eps[2] == T(1)) {
-        SlideCoef k;
-        k.c0 = (double)ycyc / (double)yn;
-        k.c1 = 2. / (double)a * (double)bb;
-        k.c2 = (double)b2 / ((double)a * (double)a);
-        k.c3m1 = (double)bsq - 1.;
-        double root;
-        if (slide_leftmost_root<T>(Y, k, &root)) {
-            // leftmost real eigenvalue; admissible when <= 0, else no admissible one (constraints.py:826-830)
-            *shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
-            return 2;
-        }
-    }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            T yhat = Y[4 * i + j] - ycyc / yn;                   // scalar subtracted from every entry
-            work[(3 + i) * 6 + (3 + j)] = e2[i] * yhat;
-            work[i * 6 + j] = e2[i] * (yhat + T(2) / a * bb);
-            work[i * 6 + (3 + j)] = (i == j) ? -(e2[i] * (b2 / (a * a))) : T(0);
-            work[(3 + i) * 6 + j] = (i == j) ? (e2[i] * bsq - T(1)) : T(0);
-        }
-    return 3;
+    return softfinger_sliding_shift<T>(Y, alpha, mu, eps, work, shift, use_fast) ? 2 : 3;
 }
 
 template <typename T, typename AP>
