@@ -169,10 +169,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 // ===========================================================================
 template <typename T, int NMAX, int NSETS, int MODE>
 __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
-    const DevModel<T> m, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
+    const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
     T *__restrict__ gcforce, const T *__restrict__ gext, long nworlds, T dt, int nsteps,
     unsigned flags, const DebugOut<T> dbg, int zmode)
 {
+    const DevModel<T> *mp = mp_in;     // device-resident model, fields fetched with scalar loads
     const int lane0 = threadIdx.x;
     int lane = lane0;
     const long w = blockIdx.x;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     double *PD = reinterpret_cast<double *>(lds + L.pd);
     T *JB = lds + L.jb, *SL = lds + L.slots, *CD = lds + L.cd, *RT = lds + L.rt;
     T *AM = lds + L.am, *VV = lds + L.vv, *FF = lds + L.ff, *FF0 = lds + L.ff0, *WORK = lds + L.work;
-    const int n = m.n, nb = m.nb, nq = m.nq, nc = m.nc, ndol = m.ndol;
+    const int n = mp->n, nb = mp->nb, nq = mp->nq, nc = mp->nc, ndol = mp->ndol;
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
     const T inv_dt = T(1) / dt;
     const bool do_constraints = (nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     WAVE_SYNC();
 
 #define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
-#define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); } while (0)
+#define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); } while (0)
     for (int step = 0; step < nsteps; ++step) {
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
@@ -217,23 +218,23 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             dA_cp = dB_cp = m3_zero<T>();
             p_pc = p_cp = p_cn = Tnw = Tnv = Bnw = Bnv = v3<T>(T(0), T(0), T(0));
             if (on) {
-                jt = m.jtype[b]; par = m.parent[b]; doff = m.dof_off[b]; dep = m.depth[b];
-                k = m.jnd[b];
+                jt = mp->jtype[b]; par = mp->parent[b]; doff = mp->dof_off[b]; dep = mp->depth[b];
+                k = mp->jnd[b];
                 JointLocal<double> jld;
-                joint_local<double>(jt, qs + m.q_off[b], dqs + doff, jld);
+                joint_local<double>(jt, qs + mp->q_off[b], dqs + doff, jld);
                 JointLocal<T> jl;
                 jl.R = cvt_m3<T>(jld.R); jl.p = cvt_v3<T>(jld.p);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { jl.jw[i] = cvt_v3<T>(jld.jw[i]); jl.djw[i] = cvt_v3<T>(jld.djw[i]); }
                 jl.Tw = cvt_v3<T>(jld.Tw); jl.Tv = cvt_v3<T>(jld.Tv);
-                const M3<T> R_pr = ld_m3(m.Hpr + 12 * b);
-                const V3<T> p_pr = ld_v3(m.Hpr + 12 * b + 9);
-                R_cn = ld_m3(m.Hcn + 12 * b);
-                p_cn = ld_v3(m.Hcn + 12 * b + 9);
+                const M3<T> R_pr = ld_m3(mp->Hpr + 12 * b);
+                const V3<T> p_pr = ld_v3(mp->Hpr + 12 * b + 9);
+                R_cn = ld_m3(mp->Hcn + 12 * b);
+                p_cn = ld_v3(mp->Hcn + 12 * b + 9);
                 // H_pc = H_pr H_rn inv(H_cn)                       core.py:1298
                 {
-                    const M3<double> Rpr = ld_m3(m.Hpr_d + 12 * b), Rcn = ld_m3(m.Hcn_d + 12 * b);
-                    const V3<double> ppr = ld_v3(m.Hpr_d + 12 * b + 9), pcn = ld_v3(m.Hcn_d + 12 * b + 9);
+                    const M3<double> Rpr = ld_m3(mp->Hpr_d + 12 * b), Rcn = ld_m3(mp->Hcn_d + 12 * b);
+                    const V3<double> ppr = ld_v3(mp->Hpr_d + 12 * b + 9), pcn = ld_v3(mp->Hcn_d + 12 * b + 9);
                     const M3<double> R_rc = mulBT(jld.R, Rcn);
                     const V3<double> p_rc = mv(jld.R, -mtv(Rcn, pcn)) + jld.p;
                     R_pc_d = mul(Rpr, R_rc);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
             }
             // pose and twist down the tree, one depth level at a time
-            for (int lvl = 0; lvl <= m.maxdepth; ++lvl) {
+            for (int lvl = 0; lvl <= mp->maxdepth; ++lvl) {
                 if (on && dep == lvl) {
                     M3<double> Rg = m3_identity<double>(); V3<double> pg = v3<double>(0., 0., 0.);
                     V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             }
             if (on) {
                 T *bd = BD + b * BD_STRIDE;
-                const T *Mb = m.mass + 36 * b;
+                const T *Mb = mp->mass + 36 * b;
                 T tw[6], ab[6], mt[6], ma[6], mg[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { tw[i] = bd[BD_TW + i]; ab[i] = bd[BD_AB + i]; }
@@ -334,9 +335,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 mat6_vec<T>(Mb, ab, ma);
                 // gravity in the body frame: Ad(inv(H_gb)) [0; g up]   controllers.py:56-58
                 T g6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-                if (m.has_grav && m.weighted[b]) {
+                if (mp->has_grav && mp->weighted[b]) {
                     const M3<T> Rg = ld_m3(bd + BD_RG);
-                    const V3<T> gl = mtv(Rg, v3<T>(m.grav[0], m.grav[1], m.grav[2]));
+                    const V3<T> gl = mtv(Rg, v3<T>(mp->grav[0], mp->grav[1], mp->grav[2]));
                     g6[3] = gl.x; g6[4] = gl.y; g6[5] = gl.z;
                 }
                 mat6_vec<T>(Mb, g6, mg);
@@ -364,9 +365,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const V3<T> nbot = cross(wv, mtb);
                 T pt[6] = {mg[0] - ma[0] - ntop.x, mg[1] - ma[1] - ntop.y, mg[2] - ma[2] - ntop.z,
                            mg[3] - ma[3] - nbot.x, mg[4] - ma[4] - nbot.y, mg[5] - ma[5] - nbot.z};
-                if (m.has_visc) {
+                if (mp->has_visc) {
                     T vt[6];
-                    mat6_vec<T>(m.visc + 36 * b, tw, vt);
+                    mat6_vec<T>(mp->visc + 36 * b, tw, vt);
 #pragma unroll
                     for (int i = 0; i < 6; ++i) pt[i] -= vt[i];
                 }
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 for (int i = 0; i < 6; ++i) bd[BD_PT + i] = pt[i];
             }
             // dof-indexed copy of the linear joint positions (PD controller, joint limits)
-            if (lane < n) { const int qi = m.dof2q[lane]; qd[lane] = qi >= 0 ? qs[qi] : T(0); }
+            if (lane < n) { const int qi = mp->dof2q[lane]; qd[lane] = qi >= 0 ? qs[qi] : T(0); }
             WAVE_SYNC();
         }
         if (MODE == 1 && step == 0) {
@@ -398,27 +399,27 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         if (do_constraints && lane < nc) {
             const int c = lane;
             T *cd = CD + c * CD_STRIDE;
-            const int ct = m.ctype[c];
+            const int ct = mp->ctype[c];
             bool active = false;
             T sd = T(0);
-            if (m.cen[c]) {
+            if (mp->cen[c]) {
                 if (ct == ARB_CT_SOFTFINGER_PLANE) {
-                    const int b1 = m.cbody[c];
+                    const int b1 = mp->cbody[c];
                     const T *bd = BD + b1 * BD_STRIDE;
                     const M3<double> Rg = ld_m3(PD + 12 * b1); const V3<double> pg = ld_v3(PD + 12 * b1 + 9);
-                    const V3<double> p_g1 = mv(Rg, ld_v3(m.clocal_d + 3 * c)) + pg;
+                    const V3<double> p_g1 = mv(Rg, ld_v3(mp->clocal_d + 3 * c)) + pg;
                     // collisions.py:194-205 (float64: the gap is a difference of O(1) positions)
-                    const M3<double> Ri = ld_m3(m.cHinv_d + 12 * c); const V3<double> pi = ld_v3(m.cHinv_d + 12 * c + 9);
+                    const M3<double> Ri = ld_m3(mp->cHinv_d + 12 * c); const V3<double> pi = ld_v3(mp->cHinv_d + 12 * c + 9);
                     const V3<double> p01 = mv(Ri, p_g1) + pi;
-                    const V3<double> nrm = ld_v3(m.cplane_d + 4 * c);
-                    const double rad = m.cradius_d[c];
-                    const double csd = dot(nrm, p01) - m.cplane_d[4 * c + 3];
+                    const V3<double> nrm = ld_v3(mp->cplane_d + 4 * c);
+                    const double rad = mp->cradius_d[c];
+                    const double csd = dot(nrm, p01) - mp->cplane_d[4 * c + 3];
                     const double sd_d = csd - rad;
                     sd = (T)sd_d;
                     const double sg = sd_d > 0. ? 1. : (sd_d < 0. ? -1. : 0.);
                     const V3<double> gc0 = p01 - csd * nrm;
                     const V3<double> gc1 = p01 - (sg * rad) * nrm;
-                    const M3<double> Rz = ld_m3_as<double>(m.cRz + 9 * c);
+                    const M3<double> Rz = ld_m3_as<double>(mp->cRz + 9 * c);
                     // frame 1 on the body: bpose1 = inv(H_gb) H_gc1       constraints.py:287-288
                     const M3<T> Rb1 = cvt_m3<T>(mulTA(Rg, Rz));
                     const V3<T> pb1 = cvt_v3<T>(mtv(Rg, gc1 - pg));
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<T> v1 = cross(pinv1, w1) + mtv(Rb1, bv);
                     const V3<T> p0c = cvt_v3<T>(mtv(Rz, gc1 - gc0));  // H_c0c1 = [I | p0c]
                     const T dsd = cross(p0c, w1).z + v1.z;
-                    active = ((double)sd_d + (double)dsd * (double)dt < (double)m.cprox[c]);
+                    active = ((double)sd_d + (double)dsd * (double)dt < (double)mp->cprox[c]);
                     // body -> contact frame 0:  Ad(H_01) Ad(inv(bpose1)) = Ad(inv(H_gc0) H_gb)
                     st_m3(cd + CD_R1, cvt_m3<T>(mulTA(Rz, Rg)));
                     st_v3(cd + CD_P1, cvt_v3<T>(mtv(Rz, pg - gc0)));
@@ -437,20 +438,20 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
                 } else if (ct == ARB_CT_JOINTLIMITS) {
-                    const T p0 = qd[m.cdof[c]];
+                    const T p0 = qd[mp->cdof[c]];
                     cd[CD_POS0] = p0;
-                    active = (p0 - m.cmin[c] < m.cprox[c]) || (m.cmax[c] - p0 < m.cprox[c]);
+                    active = (p0 - mp->cmin[c] < mp->cprox[c]) || (mp->cmax[c] - p0 < mp->cprox[c]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:58-60
                     sd = p0;
                 } else {                                                // BallAndSocket
-                    const int b0 = m.cbody0[c], b1 = m.cbody[c];
+                    const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
                     M3<double> Rg0 = m3_identity<double>(), Rg1 = Rg0;
                     V3<double> pg0 = v3<double>(0., 0., 0.), pg1 = pg0;
                     if (b0 >= 0) { Rg0 = ld_m3(PD + 12 * b0); pg0 = ld_v3(PD + 12 * b0 + 9); }
                     if (b1 >= 0) { Rg1 = ld_m3(PD + 12 * b1); pg1 = ld_v3(PD + 12 * b1 + 9); }
-                    const M3<double> Rf0 = ld_m3(m.cb0_d + 12 * c);
-                    const V3<double> pf0 = ld_v3(m.cb0_d + 12 * c + 9), pf1 = ld_v3(m.cb1_d + 12 * c + 9);
+                    const M3<double> Rf0 = ld_m3(mp->cb0_d + 12 * c);
+                    const V3<double> pf0 = ld_v3(mp->cb0_d + 12 * c + 9), pf1 = ld_v3(mp->cb1_d + 12 * c + 9);
                     const M3<double> RP0 = mul(Rg0, Rf0); const V3<double> pP0 = mv(Rg0, pf0) + pg0;
                     const V3<double> pP1 = mv(Rg1, pf1) + pg1;
                     st_v3(cd + CD_POS0, cvt_v3<T>(mtv(RP0, pP1 - pP0)));  // p_01  constraints.py:196-197
@@ -478,15 +479,15 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             T Jw[3] = {T(0), T(0), T(0)}, Jv[3] = {T(0), T(0), T(0)};
             T dJw[3] = {T(0), T(0), T(0)}, dJv[3] = {T(0), T(0), T(0)};
             for (int b = 0; b < nb; ++b) {
-                const int src = m.src[b];
+                const int src = mp->src[b];
                 if (src == 0) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { Jw[i] = Jv[i] = dJw[i] = dJv[i] = T(0); }
                 } else if (src >= 2) {
                     // parent's columns were parked in an LDS slot; only its ancestor dofs are non-zero
-                    const unsigned long long pm = m.anc[m.parent[b]];
+                    const unsigned long long pm = mp->anc[mp->parent[b]];
                     const bool mine = (pm >> lane) & 1ull;
-                    const T *sl = SL + (src - 2) * m.slot_elems + 12 * __popcll(pm & ((1ull << lane) - 1ull));
+                    const T *sl = SL + (src - 2) * mp->slot_elems + 12 * __popcll(pm & ((1ull << lane) - 1ull));
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         Jw[i] = mine ? sl[i] : T(0); Jv[i] = mine ? sl[3 + i] : T(0);
@@ -504,8 +505,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 V3<T> tdw = mv(R, djw);
                 V3<T> ndw = mv(dA, jw) + tdw;
                 V3<T> ndv = mv(dB, jw) + mv(dA, jv) + mv(R, djv) + cross(p, tdw);
-                const int d0 = m.dof_off[b];
-                if (lane >= d0 && lane < d0 + m.jnd[b]) {
+                const int d0 = mp->dof_off[b];
+                if (lane >= d0 && lane < d0 + mp->jnd[b]) {
                     nw = nw + v3<T>(SC[0 * RS + lane], SC[1 * RS + lane], SC[2 * RS + lane]);
                     nv = nv + v3<T>(SC[3 * RS + lane], SC[4 * RS + lane], SC[5 * RS + lane]);
                     ndw = ndw + v3<T>(SC[6 * RS + lane], SC[7 * RS + lane], SC[8 * RS + lane]);
@@ -513,11 +514,11 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
                 Jw[0] = nw.x; Jw[1] = nw.y; Jw[2] = nw.z; Jv[0] = nv.x; Jv[1] = nv.y; Jv[2] = nv.z;
                 dJw[0] = ndw.x; dJw[1] = ndw.y; dJw[2] = ndw.z; dJv[0] = ndv.x; dJv[1] = ndv.y; dJv[2] = ndv.z;
-                const int ss = m.sslot[b];
+                const int ss = mp->sslot[b];
                 if (ss >= 0) {
-                    const unsigned long long bm = m.anc[b];
+                    const unsigned long long bm = mp->anc[b];
                     if ((bm >> lane) & 1ull) {
-                        T *sl = SL + ss * m.slot_elems + 12 * __popcll(bm & ((1ull << lane) - 1ull));
+                        T *sl = SL + ss * mp->slot_elems + 12 * __popcll(bm & ((1ull << lane) - 1ull));
 #pragma unroll
                         for (int i = 0; i < 3; ++i) { sl[i] = Jw[i]; sl[3 + i] = Jv[i]; sl[6 + i] = dJw[i]; sl[9 + i] = dJv[i]; }
                     }
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         }
                 }
                 // per-column wrenches: U = M_b J, W = M_b dJ + N_b J, V = B_b J   core.py:726-734
-                const T *Mb = m.mass + 36 * b;
+                const T *Mb = mp->mass + 36 * b;
                 T x[6] = {Jw[0], Jw[1], Jw[2], Jv[0], Jv[1], Jv[2]};
                 T dx[6] = {dJw[0], dJw[1], dJw[2], dJv[0], dJv[1], dJv[2]};
                 T U[6], W[6], Q[6];
@@ -556,9 +557,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                     for (int i = 0; i < 6; ++i) Q[i] = U[i] * inv_dt + W[i];
                 }
-                if (m.has_visc) {
+                if (mp->has_visc) {
                     T V[6];
-                    mat6_vec<T>(m.visc + 36 * b, x, V);
+                    mat6_vec<T>(mp->visc + 36 * b, x, V);
                     if (MODE == 0 || zmode == 0 || zmode == 2) {
 #pragma unroll
                         for (int i = 0; i < 6; ++i) Q[i] += V[i];
@@ -573,8 +574,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
                 // constraint rows hanging on this body
                 if (do_constraints) {
-                    for (int a = m.att_start[b]; a < m.att_start[b + 1]; ++a) {
-                        const int c = m.att_c[a], kind = m.att_kind[a];
+                    for (int a = mp->att_start[b]; a < mp->att_start[b + 1]; ++a) {
+                        const int c = mp->att_c[a], kind = mp->att_kind[a];
                         const T *cd = CD + c * CD_STRIDE;
                         const T act = cd[CD_ACTIVE];
                         const M3<T> Rx = ld_m3(cd + (kind == 2 ? CD_R0 : CD_R1));
@@ -596,15 +597,23 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 WAVE_SYNC();
                 if (lane < RS) {
                     JB[8 * lane + 0] = x[0]; JB[8 * lane + 1] = x[1]; JB[8 * lane + 2] = x[2]; JB[8 * lane + 3] = x[3];
-                    JB[8 * lane + 4] = x[4]; JB[8 * lane + 5] = x[5];
+                    JB[8 * lane + 4] = x[4]; JB[8 * lane + 5] = x[5]; JB[8 * lane + 6] = T(0); JB[8 * lane + 7] = T(0);
                 }
                 WAVE_SYNC();
-                const unsigned long long mask = m.anc[b];
+                // Columns of non-ancestor dofs are exactly zero, so rows can be taken in groups of
+                // eight without per-row tests: one wave-uniform test per group, then 16 back-to-back
+                // vector LDS reads (wave-uniform addresses) and 48 FMAs.
+                const unsigned long long mask = mp->anc[b];
+                typedef T V4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int i = 0; i < NMAX; ++i) {
-                    if ((mask >> i) & 1ull) {
-                        const T *jb = JB + 8 * i;
-                        Z[i] += jb[0] * Q[0] + jb[1] * Q[1] + jb[2] * Q[2] + jb[3] * Q[3] + jb[4] * Q[4] + jb[5] * Q[5];
+                for (int g = 0; g < NMAX / 8; ++g) {
+                    if ((mask >> (8 * g)) & 0xffull) {
+#pragma unroll
+                        for (int i = 8 * g; i < 8 * g + 8; ++i) {
+                            const V4 ja = *reinterpret_cast<const V4 *>(JB + 8 * i);
+                            const V4 jc = *reinterpret_cast<const V4 *>(JB + 8 * i + 4);
+                            Z[i] += ja.x * Q[0] + ja.y * Q[1] + ja.z * Q[2] + ja.w * Q[3] + jc.x * Q[4] + jc.y * Q[5];
+                        }
                     }
                 }
             }
@@ -612,24 +621,24 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         // joint-limit rows are dof selectors                              constraints.py:46-48
         if (do_constraints) {
             for (int c = 0; c < nc; ++c)
-                if (m.ctype[c] == ARB_CT_JOINTLIMITS && lane == m.cdof[c])
+                if (mp->ctype[c] == ARB_CT_JOINTLIMITS && lane == mp->cdof[c])
                     RT[(1 + 4 * c) * RS + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
         }
         // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
         T gf0 = rhsG + ext_k;          // controllers' generalized force (inspect output)
         T rhs = rhsM + ext_k;          // gforce - (N + B + Z_pd) gvel
-        if (m.has_pd && lane < n) {
-            T acc = m.pd_tau0[lane], accv = T(0);
+        if (mp->has_pd && lane < n) {
+            T acc = mp->pd_tau0[lane], accv = T(0);
             for (int i = 0; i < n; ++i) {
-                acc -= m.pd_kp[lane * n + i] * qd[i];
-                accv += (dt * m.pd_kp[lane * n + i] + m.pd_kd[lane * n + i]) * dqs[i];
+                acc -= mp->pd_kp[lane * n + i] * qd[i];
+                accv += (dt * mp->pd_kp[lane * n + i] + mp->pd_kd[lane * n + i]) * dqs[i];
             }
             gf0 += acc;
             rhs += acc - accv;
             if (MODE == 0 || zmode == 0) {
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i)
-                    if (i < n) Z[i] += dt * m.pd_kp[i * n + lane] + m.pd_kd[i * n + lane];
+                    if (i < n) Z[i] += dt * mp->pd_kp[i * n + lane] + mp->pd_kd[i * n + lane];
             }
         }
         WAVE_SYNC();
@@ -646,11 +655,11 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const T *cd = CD + lane * CD_STRIDE;
                 if (dbg.c_sdist != nullptr) dbg.c_sdist[w * nc + lane] = do_constraints ? cd[CD_SDIST] : T(0);
                 if (dbg.c_active != nullptr) dbg.c_active[w * nc + lane] = (do_constraints && cd[CD_ACTIVE] != T(0)) ? 1 : 0;
-                if (dbg.c_frame != nullptr && do_constraints && m.ctype[lane] == ARB_CT_SOFTFINGER_PLANE) {
+                if (dbg.c_frame != nullptr && do_constraints && mp->ctype[lane] == ARB_CT_SOFTFINGER_PLANE) {
                     for (int f = 0; f < 2; ++f) {
                         T *o = dbg.c_frame + ((w * nc + lane) * 2 + f) * 16;
                         for (int i = 0; i < 3; ++i) {
-                            for (int j = 0; j < 3; ++j) o[4 * i + j] = m.cRz[9 * lane + 3 * i + j];
+                            for (int j = 0; j < 3; ++j) o[4 * i + j] = mp->cRz[9 * lane + 3 * i + j];
                             o[4 * i + 3] = cd[(f ? CD_GC1 : CD_GC0) + i];
                         }
                         o[12] = o[13] = o[14] = T(0); o[15] = T(1);
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             }
         }
         // warm-started constraint forces enter the right-hand side          core.py:921-924
-        if (do_constraints && m.has_warm && lane < n) {
+        if (do_constraints && mp->has_warm && lane < n) {
             for (int i = 0; i < ndol; ++i) rhs += RT[(1 + i) * RS + lane] * FF[i];
         }
         // ================= phase C: augmented Gauss-Jordan ===================
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         ARB_STAMP(3);
         if (lane < RS) RT[lane] = (lane < n) ? rhs : T(0);
         WAVE_SYNC();
-        const int ncols = do_constraints ? m.ncols : n + 1;
+        const int ncols = do_constraints ? mp->ncols : n + 1;
         if (lane >= n) {
             const int r = lane - n;                 // column r of [rhs | J'^T]
             const bool have = lane < ncols;
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         if (do_constraints) {
             // inverse of every active constraint's own admittance block (once per step)
             if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
-                const int c = lane, ct = m.ctype[c];
+                const int c = lane, ct = mp->ctype[c];
                 const int nd = (ct == ARB_CT_SOFTFINGER_PLANE) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 T P[16];
                 inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
@@ -797,9 +806,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const T *cd = CD + lane * CD_STRIDE;
                 k_act = cd[CD_ACTIVE] != T(0);
                 k_sd = cd[CD_SDIST]; k_p0 = cd[CD_POS0]; k_p1 = cd[CD_POS0 + 1]; k_p2 = cd[CD_POS0 + 2];
-                k_ct = m.ctype[lane]; k_mu = m.cmu[lane];
-                k_e0 = m.ceps[3 * lane]; k_e1 = m.ceps[3 * lane + 1]; k_e2 = m.ceps[3 * lane + 2];
-                k_min = m.cmin[lane]; k_max = m.cmax[lane];
+                k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
+                k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
+                k_min = mp->cmin[lane]; k_max = mp->cmax[lane];
             }
             const unsigned long long actmask = __ballot(k_act);
             int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0;
@@ -925,13 +934,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         WAVE_SYNC();
         if (lane < n) {
             dqs[lane] = vnew;
-            const int qi = m.dof2q[lane];
+            const int qi = mp->dof2q[lane];
             if (qi >= 0) qs[qi] += dt * vnew;                               // core.py:238-240
         }
         WAVE_SYNC();
-        if (lane < nb && m.jtype[lane] == JT_FREE) {                        // joints.py:54-57
-            T *qp = qs + m.q_off[lane];
-            const T *vp = dqs + m.dof_off[lane];
+        if (lane < nb && mp->jtype[lane] == JT_FREE) {                        // joints.py:54-57
+            T *qp = qs + mp->q_off[lane];
+            const T *vp = dqs + mp->dof_off[lane];
             M3<T> R, Re; V3<T> p, pe;
             R.a[0] = qp[0]; R.a[1] = qp[1]; R.a[2] = qp[2]; p.x = qp[3];
             R.a[3] = qp[4]; R.a[4] = qp[5]; R.a[5] = qp[6]; p.y = qp[7];
@@ -981,6 +990,8 @@ struct arb_model {
     std::vector<void *> allocs;
     DevModel<float> df;
     DevModel<double> dd;
+    DevModel<float> *df_dev;
+    DevModel<double> *dd_dev;
     Layout lf, ld;
 };
 
@@ -1240,6 +1251,13 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     if (rc == ARB_OK)
         rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
+    {
+        const DevModel<float> *pf = nullptr; const DevModel<double> *pd = nullptr;
+        rc = upload<DevModel<float>>(M, std::vector<DevModel<float>>(1, M->df), &pf);
+        if (rc == ARB_OK) rc = upload<DevModel<double>>(M, std::vector<DevModel<double>>(1, M->dd), &pd);
+        if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
+        M->df_dev = const_cast<DevModel<float> *>(pf); M->dd_dev = const_cast<DevModel<double> *>(pd);
+    }
     int tot;
     M->lf = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 2, &tot);
     M->ld = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 1, &tot);
@@ -1267,7 +1285,7 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 }
 
 template <typename T, int NMAX, int NSETS, int MODE>
-static int launch_one(const DevModel<T> &dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw, double dt,
+static int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw, double dt,
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, hipStream_t st) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
     const size_t lds = (size_t)L.total * sizeof(T);
@@ -1280,7 +1298,7 @@ static int launch_one(const DevModel<T> &dm, const Layout &L, T *q, T *dq, T *cf
 }
 
 template <typename T, int MODE>
-static int launch(arb_model *M, const DevModel<T> &dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw,
+static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw,
                   double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, hipStream_t st) {
 #ifdef ARB_QUICK
     // development build: a single instantiation (float, NMAX=48, one column set, production mode)
@@ -1312,16 +1330,16 @@ extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32) {
         DebugOut<float> dbg; memset(&dbg, 0, sizeof(dbg));
-        return launch<float, 0>(M, M->df, M->lf, (float *)q, (float *)dq, (float *)cforce, (const float *)ext_gforce,
+        return launch<float, 0>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce, (const float *)ext_gforce,
                                 (long)nworlds, dt, nsteps, flags, dbg, 0, st);
     }
     DebugOut<double> dbg; memset(&dbg, 0, sizeof(dbg));
-    return launch<double, 0>(M, M->dd, M->ld, (double *)q, (double *)dq, (double *)cforce, (const double *)ext_gforce,
+    return launch<double, 0>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce, (const double *)ext_gforce,
                              (long)nworlds, dt, nsteps, flags, dbg, 0, st);
 }
 
 template <typename T>
-static int inspect_t(arb_model *M, const DevModel<T> &dm, const Layout &L, const void *q, const void *dq,
+static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const void *q, const void *dq,
                      const void *cforce, const void *ext, long nw, double dt, unsigned flags,
                      const arb_inspect_out *o, hipStream_t st) {
     DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
@@ -1354,8 +1372,8 @@ extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *d
     HIP_TRY(hipSetDevice(M->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32)
-        return inspect_t<float>(M, M->df, M->lf, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
-    return inspect_t<double>(M, M->dd, M->ld, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
+        return inspect_t<float>(M, M->df_dev, M->lf, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
+    return inspect_t<double>(M, M->dd_dev, M->ld, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
 }
 
 // ---------------------------------------------------------------------------

@@ -123,7 +123,33 @@ ARB_HD double arb_abs(double x) { return x < 0. ? -x : x; }
 ARB_HD float arb_sqrt(float x) { return sqrtf(x); }
 ARB_HD double arb_sqrt(double x) { return sqrt(x); }
 ARB_HD void arb_sincos(float a, float *s, float *c) { *s = sinf(a); *c = cosf(a); }
-ARB_HD void arb_sincos(double a, double *s, double *c) { *s = sin(a); *c = cos(a); }
+// float64 sin/cos for joint angles.  On the device this is a branch-free Cody-Waite
+// reduction by pi/2 (two constants, exact to ~1e-17 * |a| for |a| < 1e5 rad) followed by
+// the classic minimax kernels on [-pi/4, pi/4] (fdlibm __kernel_sin/__kernel_cos
+// coefficients): ~45 flops instead of the library routine's large-argument machinery,
+// which cost a third of phase A and most of the kernel's SGPR spills.
+ARB_HD void arb_sincos(double a, double *s, double *c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double k = rint(a * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, a);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04
+                    + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
+                    + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double sr = fma(r * z, ps, r);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double ss = (q & 1) ? cr : sr;
+    const double cc = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+#else
+    *s = sin(a); *c = cos(a);
+#endif
+}
 
 template <typename T> struct JointLocal {
     M3<T> R;          // rotation of H_rn
