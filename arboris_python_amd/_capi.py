@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libarbstep.so")
 
-ARB_ABI_VERSION = 1
+ARB_ABI_VERSION = 2
 ARB_OK = 0
 ARB_F32, ARB_F64 = 0, 1
 ARB_MAXDOL = 4
@@ -30,6 +30,7 @@ class ModelDesc(C.Structure):
         ("H_pr", _PD), ("H_cn", _PD), ("mass", _PD), ("visc", _PD),
         ("weighted", _PI),
         ("gravity", C.c_double * 3),
+        ("up", C.c_double * 3),
         ("pd_kp", _PD), ("pd_kd", _PD), ("pd_tau0", _PD),
         ("ctype", _PI), ("c_enabled", _PI), ("c_body", _PI), ("c_body0", _PI), ("c_dof", _PI),
         ("c_local", _PD), ("c_radius", _PD), ("c_plane_Hinv", _PD), ("c_plane", _PD),
@@ -45,7 +46,11 @@ class ModelInfo(C.Structure):
 
 
 INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
-                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "stamps"]
+                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps"]
+
+
+class RolloutLog(C.Structure):
+    _fields_ = [("q_log", C.c_void_p), ("dq_log", C.c_void_p), ("energy_log", C.c_void_p)]
 
 
 class InspectOut(C.Structure):
@@ -54,7 +59,7 @@ class InspectOut(C.Structure):
 
 # every symbol include/arbstep.h declares (tests check they are all exported)
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
-            "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_inspect"]
+            "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_rollout", "arb_inspect"]
 # host-side self-test hooks (device math compiled for the CPU)
 TEST_HOOKS = ["arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_eig6", "arb_host_joint_local",
               "arb_host_exp_twist"]
@@ -86,6 +91,9 @@ def load():
     lib.arb_step.restype = C.c_int
     lib.arb_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int64, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
+    lib.arb_rollout.restype = C.c_int
+    lib.arb_rollout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_double, C.c_int32, C.c_uint32, C.POINTER(RolloutLog), C.c_void_p]
     lib.arb_inspect.restype = C.c_int
     lib.arb_inspect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_double, C.c_uint32, C.POINTER(InspectOut), C.c_void_p]
@@ -154,6 +162,7 @@ def make_desc(m):
     d.weighted = i32(m.weighted)
     for i in range(3):
         d.gravity[i] = float(m.gravity[i])
+        d.up[i] = float(m.up[i])
     if m.has_pd:
         d.pd_kp, d.pd_kd, d.pd_tau0 = f64(m.pd_kp), f64(m.pd_kd), f64(m.pd_tau0)
     if m.nc:

@@ -103,6 +103,32 @@ class BatchedWorlds(object):
             None if ext_gforce is None else ext_gforce.data_ptr(),
             B, float(dt), int(nsteps), flags, C.c_void_p(st.cuda_stream)))
 
+    def rollout(self, q, dq, dt, nsteps, cforce=None, ext_gforce=None, log_state=True, log_energy=True,
+                skip_constraints=False, stream=None):
+        """Advance ``nsteps`` steps in ONE launch and return the per-step logs an Observer
+        would have recorded (state and energies at the beginning of every step):
+        ``{"q": (nsteps,B,nq), "dq": (nsteps,B,ndof), "energy": (nsteps,B,2)}``."""
+        torch = _torch()
+        B = self._check_state(q, dq, cforce, ext_gforce)
+        m = self.model
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
+        out = {}
+        log = _capi.RolloutLog()
+        if log_state:
+            out["q"] = torch.empty((nsteps, B, m.nq), dtype=q.dtype, device=self.device)
+            out["dq"] = torch.empty((nsteps, B, m.ndof), dtype=q.dtype, device=self.device)
+            log.q_log, log.dq_log = out["q"].data_ptr(), out["dq"].data_ptr()
+        if log_energy:
+            out["energy"] = torch.empty((nsteps, B, 2), dtype=q.dtype, device=self.device)
+            log.energy_log = out["energy"].data_ptr()
+        _capi.check(self._lib.arb_rollout(
+            self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
+            None if cforce is None else cforce.data_ptr(),
+            None if ext_gforce is None else ext_gforce.data_ptr(),
+            B, float(dt), int(nsteps), flags, C.byref(log), C.c_void_p(st.cuda_stream)))
+        return out
+
     def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False):
         """Evaluate one step without touching ``q``/``dq``; returns a dict of the
         requested intermediate results (names of ``arb_inspect_out``)."""
@@ -114,7 +140,7 @@ class BatchedWorlds(object):
                       M=(B, n, n), B=(B, n, n), N=(B, n, n), Z=(B, n, n), gforce0=(B, n),
                       vel_free=(B, n), c_sdist=(B, nc), c_active=(B, nc), c_jac=(B, nc, 4, n),
                       c_force=(B, nc, 4), c_frame=(B, nc, 2, 4, 4), gforce=(B, n),
-                      q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 4), stamps=(B, 8))
+                      q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 4), stamps=(B, 8), energy=(B, 2))
         want = list(want)
         if "gforce" in want and nc and "c_jac" not in want:
             want.append("c_jac")

@@ -81,10 +81,18 @@ struct DevModel {
     const T *Hpr, *Hcn, *mass, *visc;         // [nb][12], [nb][12], [nb][36], [nb][36]
     const double *Hpr_d, *Hcn_d;              // float64 copies for the pose chain
     const double *clocal_d, *cradius_d, *cHinv_d, *cplane_d, *cb0_d, *cb1_d;
+    const double *com_d;                      // [nb][4] centre of mass in the body frame, mass (EnergyMonitor)
+    double up[3];
     T grav[3];
     const T *pd_kp, *pd_kd, *pd_tau0;
     const int *ctype, *cen, *cbody, *cbody0, *cdof;
     const T *clocal, *cradius, *cHinv, *cplane, *cRz, *cmu, *cprox, *ceps, *cmin, *cmax, *cb0, *cb1;
+};
+
+// Optional per-step logs of arb_rollout (state and energies as observers see them: before the step)
+template <typename T>
+struct LogOut {
+    T *q, *dq, *energy;   // [nsteps][nw][nq], [nsteps][nw][ndof], [nsteps][nw][2]
 };
 
 template <typename T>
@@ -92,6 +100,7 @@ struct DebugOut {
     T *pose, *twist, *jac, *djac, *Zout, *gforce0, *vel_free, *c_sdist;
     int *c_active;
     T *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next;
+    T *energy;          // [nw][2] kinetic, potential energy (EnergyMonitor, observers.py:40-51)
     long long *stamps;  // [nw][8] s_memtime at the phase boundaries (diagnostic)
     int *gs_stats;      // [nw][4]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts
 };
@@ -171,7 +180,7 @@ template <typename T, int NMAX, int NSETS, int MODE>
 __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
     T *__restrict__ gcforce, const T *__restrict__ gext, long nworlds, T dt, int nsteps,
-    unsigned flags, const DebugOut<T> dbg, int zmode)
+    unsigned flags, const DebugOut<T> dbg, int zmode, const LogOut<T> logo)
 {
     const DevModel<T> *mp = mp_in;     // device-resident model, fields fetched with scalar loads
     const int lane0 = threadIdx.x;
@@ -205,6 +214,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
+        if (MODE == 0) {            // trajectory log: what an Observer sees at time t (core.py:1361-1362)
+            if (logo.q != nullptr) for (int i = lane; i < nq; i += WAVE) logo.q[((long)step * nworlds + w) * nq + i] = qs[i];
+            if (logo.dq != nullptr && lane < n) logo.dq[((long)step * nworlds + w) * n + lane] = dqs[lane];
+        }
         {
             const int b = lane;
             const bool on = b < nb;
@@ -390,6 +403,32 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             }
             if (dbg.twist != nullptr && lane < nb)
                 for (int i = 0; i < 6; ++i) dbg.twist[(w * nb + lane) * 6 + i] = BD[lane * BD_STRIDE + BD_TW + i];
+        }
+
+        // ---- energies (EnergyMonitor.update, observers.py:40-51): KE = 1/2 sum_b T_b . M_b T_b
+        //      (= 1/2 gvel^T M gvel), PE = 9.81 sum_b m_b up . (H_gb c_b); lane = body, wave reduction
+        if ((MODE == 0 && logo.energy != nullptr) || (MODE == 1 && dbg.energy != nullptr && step == 0)) {
+            double ke = 0., pe = 0.;
+            if (lane < nb) {
+                const T *bd = BD + lane * BD_STRIDE;
+                const T *Mb = mp->mass + 36 * lane;
+                T tw[6], mt[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) tw[i] = bd[BD_TW + i];
+                mat6_vec<T>(Mb, tw, mt);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ke += 0.5 * (double)tw[i] * (double)mt[i];
+                const double *cm = mp->com_d + 4 * lane;
+                const M3<double> Rg = ld_m3(PD + 12 * lane); const V3<double> pg = ld_v3(PD + 12 * lane + 9);
+                const V3<double> cg = mv(Rg, v3<double>(cm[0], cm[1], cm[2])) + pg;
+                pe = 9.81 * cm[3] * (mp->up[0] * cg.x + mp->up[1] * cg.y + mp->up[2] * cg.z);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { ke += __shfl_xor(ke, off); pe += __shfl_xor(pe, off); }
+            if (lane == 0) {
+                T *o = (MODE == 0) ? logo.energy + ((long)step * nworlds + w) * 2 : dbg.energy + w * 2;
+                o[0] = (T)ke; o[1] = (T)pe;
+            }
         }
 
         // ================= phase A': lane = constraint =====================
@@ -1095,6 +1134,21 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     if ((rc = upload<double>(M, conv<double>(d->c_plane, 4 * nc), &m.cplane_d)) != ARB_OK) return rc;
     if ((rc = upload<double>(M, h12(d->c_bpose0, nc), &m.cb0_d)) != ARB_OK) return rc;
     if ((rc = upload<double>(M, h12(d->c_bpose1, nc), &m.cb1_d)) != ARB_OK) return rc;
+    {
+        // centre of mass of every body as massmatrix.principalframe places it (massmatrix.py:96-99),
+        // and its mass; massless bodies contribute nothing
+        std::vector<double> com(4 * (size_t)nb, 0.0);
+        for (int b = 0; b < nb; ++b) {
+            const double *Mb = d->mass + 36 * b;
+            const double mass_b = Mb[35];
+            if (mass_b > 0.0) {
+                com[4 * b + 0] = Mb[6 * 2 + 4] / mass_b; com[4 * b + 1] = Mb[6 * 0 + 5] / mass_b;
+                com[4 * b + 2] = Mb[6 * 1 + 3] / mass_b; com[4 * b + 3] = Mb[21];
+            }
+        }
+        if ((rc = upload<double>(M, com, &m.com_d)) != ARB_OK) return rc;
+        for (int i = 0; i < 3; ++i) m.up[i] = d->up[i];
+    }
     UP_T(mass, conv<T>(d->mass, 36 * nb));
     UP_T(visc, conv<T>(d->visc, 36 * nb));
     bool hv = false;
@@ -1286,32 +1340,32 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 
 template <typename T, int NMAX, int NSETS, int MODE>
 static int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw, double dt,
-                      int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, hipStream_t st) {
+                      int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo, hipStream_t st) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
     const size_t lds = (size_t)L.total * sizeof(T);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, nw, (T)dt, nsteps, flags, dbg, zmode);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, nw, (T)dt, nsteps, flags, dbg, zmode, logo);
     HIP_TRY(hipGetLastError());
     return ARB_OK;
 }
 
 template <typename T, int MODE>
 static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw,
-                  double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, hipStream_t st) {
+                  double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo, hipStream_t st) {
 #ifdef ARB_QUICK
     // development build: a single instantiation (float, NMAX=48, one column set, production mode)
     if constexpr (std::is_same<T, float>::value && MODE == 0) {
         if (M->nmax == 48 && M->nsets == 1)
-            return launch_one<T, 48, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, st);
+            return launch_one<T, 48, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, st);
     }
     return ARB_ERR_UNSUPPORTED;
 #else
 #define CASE(NM)                                                                                                     \
     case NM:                                                                                                         \
-        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, st) \
-                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, st);
+        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, st) \
+                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, st);
     switch (M->nmax) {
         CASE(16) CASE(32) CASE(48) CASE(64)
         default: return ARB_ERR_UNSUPPORTED;
@@ -1320,22 +1374,40 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #endif
 }
 
-extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
-                        int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, void *stream) {
-    if (!M || !q || !dq || nworlds < 0 || nsteps < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
+static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
+                     int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, const arb_rollout_log *log,
+                     void *stream) {
+    if (!M || nworlds < 0 || nsteps < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
     if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
-    if (nworlds == 0 || nsteps == 0) return ARB_OK;
+    if (nworlds == 0 || nsteps == 0) return ARB_OK;     // empty batch: nothing to do (pointers may be null)
+    if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     HIP_TRY(hipSetDevice(M->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32) {
         DebugOut<float> dbg; memset(&dbg, 0, sizeof(dbg));
+        LogOut<float> lo; memset(&lo, 0, sizeof(lo));
+        if (log) { lo.q = (float *)log->q_log; lo.dq = (float *)log->dq_log; lo.energy = (float *)log->energy_log; }
         return launch<float, 0>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce, (const float *)ext_gforce,
-                                (long)nworlds, dt, nsteps, flags, dbg, 0, st);
+                                (long)nworlds, dt, nsteps, flags, dbg, 0, lo, st);
     }
     DebugOut<double> dbg; memset(&dbg, 0, sizeof(dbg));
+    LogOut<double> lo; memset(&lo, 0, sizeof(lo));
+    if (log) { lo.q = (double *)log->q_log; lo.dq = (double *)log->dq_log; lo.energy = (double *)log->energy_log; }
     return launch<double, 0>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce, (const double *)ext_gforce,
-                             (long)nworlds, dt, nsteps, flags, dbg, 0, st);
+                             (long)nworlds, dt, nsteps, flags, dbg, 0, lo, st);
+}
+
+extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
+                        int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, void *stream) {
+    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nworlds, dt, nsteps, flags, nullptr, stream);
+}
+
+extern "C" int arb_rollout(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
+                           int64_t nworlds, double dt, int32_t nsteps, uint32_t flags,
+                           const arb_rollout_log *log, void *stream) {
+    if (!log) return ARB_ERR_INVALID;
+    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nworlds, dt, nsteps, flags, log, stream);
 }
 
 template <typename T>
@@ -1350,24 +1422,27 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
         if (!ps.ptr) continue;
         DebugOut<T> d1; memset(&d1, 0, sizeof(d1));
         d1.Zout = (T *)ps.ptr;
-        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, d1, ps.zmode, st);
+        LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
+        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, d1, ps.zmode, nolog, st);
         if (rc != ARB_OK) return rc;
     }
     dbg.pose = (T *)o->pose; dbg.twist = (T *)o->twist; dbg.jac = (T *)o->jac; dbg.djac = (T *)o->djac;
     dbg.Zout = (T *)o->Z; dbg.gforce0 = (T *)o->gforce0; dbg.vel_free = (T *)o->vel_free;
     dbg.c_sdist = (T *)o->c_sdist; dbg.c_active = (int *)o->c_active; dbg.c_jac = (T *)o->c_jac;
     dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
-    dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.stamps = (long long *)o->stamps;
-    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, st);
+    dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.stamps = (long long *)o->stamps; dbg.energy = (T *)o->energy;
+    LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
+    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, nolog, st);
 }
 
 extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,
                            const void *ext_gforce, int64_t nworlds, double dt, uint32_t flags,
                            const arb_inspect_out *out, void *stream) {
-    if (!M || !q || !dq || !out || nworlds < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
+    if (!M || !out || nworlds < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
     if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
     if (out->gforce != nullptr && M->nc > 0 && out->c_jac == nullptr) return ARB_ERR_INVALID;
     if (nworlds == 0) return ARB_OK;
+    if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     HIP_TRY(hipSetDevice(M->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -80,6 +80,7 @@ class FlatModel(object):
         self.visc = np.zeros((0, 6, 6))
         self.weighted = np.zeros(0, np.int32)   # bodies the WeightController acts on
         self.gravity = np.zeros(3)              # sum over WeightControllers of g*up
+        self.up = np.array((0., 1., 0.))        # World.up
         # proportional-derivative controllers, merged, dof-indexed
         self.has_pd = False
         self.pd_kp = None
@@ -198,6 +199,7 @@ def flatten_world(world, positions=True):
     visit(world.ground, -1)
 
     m.nb, m.ndof, m.nq = len(bodies), ndof, nq
+    m.up = np.array(world.up, dtype=float)
     m.parent = np.array(parent, np.int32)
     m.jtype = np.array(jtype, np.int32)
     m.dof_off = np.array(dof_off, np.int32)

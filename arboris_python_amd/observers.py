@@ -1,0 +1,214 @@
+"""Observers: energy, timing and trajectory logging (host side + batched device logs).
+
+Counterpart of arboris/observers.py (EnergyMonitor :14-67, PerfMonitor :70-130,
+Hdf5Logger :133-289).  Two levels:
+
+* ``EnergyMonitor`` / ``PerfMonitor`` / ``TrajectoryLogger`` are ``core.Observer``
+  subclasses for the single-world ``simulate()`` loop; they read what the device
+  left on the world objects.
+* ``batched_trajectory`` turns the per-step device logs of
+  ``BatchedWorlds.rollout`` (``arb_rollout``: state and energies written by the
+  step kernel itself, one launch for the whole horizon) into the same dataset
+  layout as ``Hdf5Logger``: ``timeline (nsteps,)``, ``gpositions/<joint>``,
+  ``gvelocities/<joint>``, ``transforms/<name> (nsteps,4,4)``.
+
+h5py is not a dependency: ``save()`` writes ``.npz`` with the dataset paths as
+keys, or HDF5 when h5py happens to be importable and the file name ends in .h5.
+"""
+import time
+
+import numpy as np
+
+from .core import Observer
+from .flatten import flatten_world, JT_FREE
+
+
+def _com_and_mass(mass):
+    """Centre of mass as massmatrix.principalframe places it (massmatrix.py:96-99)."""
+    m = mass[5, 5]
+    if not m > 0.:
+        return np.zeros(3), 0.
+    rx = mass[0:3, 3:6] / m
+    return np.array([rx[2, 1], rx[0, 2], rx[1, 0]]), float(mass[3, 3])
+
+
+class EnergyMonitor(Observer):
+    """Kinetic, potential and mechanical energy at each step (observers.py:14-67).
+    Massless bodies are skipped (the reference's ``principalframe`` asserts on them)."""
+
+    def init(self, world, timeline):
+        self._world = world
+        self.time = []
+        self.kinetic_energy = []
+        self.potential_energy = []
+        self.mechanichal_energy = []
+        self._bodies = list(world.ground.iter_descendant_bodies())
+        self._com = [_com_and_mass(np.asarray(b.mass, float)) for b in self._bodies]
+
+    def update(self, dt):
+        w = self._world
+        self.time.append(w.current_time)
+        gvel = w.gvel
+        Ec = float(np.dot(gvel, np.dot(w.mass, gvel)) / 2.)
+        Ep = 0.
+        for body, (c, m) in zip(self._bodies, self._com):
+            if m == 0.:
+                continue
+            h = np.dot(np.dot(body.pose, np.hstack((c, 1.)))[0:3], w.up)
+            Ep += m * h
+        Ep *= 9.81
+        self.kinetic_energy.append(Ec)
+        self.potential_energy.append(Ep)
+        self.mechanichal_energy.append(Ec + Ep)
+
+    def finish(self):
+        pass
+
+
+class PerfMonitor(Observer):
+    """Wall-clock time between successive updates (observers.py:70-130)."""
+
+    def __init__(self, log=False):
+        self._log = log
+        self._last = None
+        self._durations = []
+
+    def init(self, world, timeline):
+        self._world = world
+        self._last = time.perf_counter()
+
+    def update(self, dt):
+        now = time.perf_counter()
+        self._durations.append(now - self._last)
+        self._last = now
+
+    def finish(self):
+        pass
+
+    def get_summary(self):
+        d = np.array(self._durations)
+        if len(d) == 0:
+            return "no step recorded"
+        return ("total computation time (s): {0}\nmin computation time (s): {1}\n"
+                "mean computation time (s): {2}\nmax computation time (s): {3}"
+                .format(d.sum(), d.min(), d.mean(), d.max()))
+
+
+def _save_datasets(filename, data):
+    if filename.endswith((".h5", ".hdf5")):
+        try:
+            import h5py
+        except ImportError:
+            raise RuntimeError("h5py is not installed; use a .npz file name")
+        with h5py.File(filename, "w") as f:
+            for k, v in data.items():
+                f[k] = v
+    else:
+        np.savez_compressed(filename, **data)
+
+
+class TrajectoryLogger(Observer):
+    """Records the datasets of ``Hdf5Logger`` (observers.py:133-289) in memory.
+
+    ``flat=True``: one transform per body (``Body.pose``); ``flat=False``: one per
+    joint (``Joint.pose``) named after the joint's second frame.
+    """
+
+    def __init__(self, save_state=False, save_transforms=True, flat=False):
+        self._save_state = save_state
+        self._save_transforms = save_transforms
+        self._flat = flat
+        self.data = {}
+
+    def init(self, world, timeline):
+        self._world = world
+        self._nb_steps = len(timeline) - 1
+        self._step = 0
+        self.data = {"timeline": np.zeros(self._nb_steps)}
+        self._joints = list(world.iterjoints())
+        if self._save_state:
+            for j in self._joints:
+                shape = (4, 4) if np.ndim(j.gpos) == 2 else (j.ndof,)
+                self.data["gpositions/%s" % j.name] = np.zeros((self._nb_steps,) + shape)
+                self.data["gvelocities/%s" % j.name] = np.zeros((self._nb_steps, j.ndof))
+        if self._save_transforms:
+            if self._flat:
+                self._transforms = {b.name: b for b in world.iterbodies() if b.name is not None}
+            else:
+                self._transforms = {j.frames[1].name: j for j in self._joints if j.frames[1].name is not None}
+            for name in self._transforms:
+                self.data["transforms/%s" % name] = np.zeros((self._nb_steps, 4, 4))
+
+    def update(self, dt):
+        k = self._step
+        self.data["timeline"][k] = self._world.current_time
+        if self._save_state:
+            for j in self._joints:
+                self.data["gpositions/%s" % j.name][k] = j.gpos
+                self.data["gvelocities/%s" % j.name][k] = j.gvel
+        if self._save_transforms:
+            for name, obj in self._transforms.items():
+                self.data["transforms/%s" % name][k] = obj.pose
+        self._step += 1
+
+    def finish(self):
+        pass
+
+    def save(self, filename):
+        _save_datasets(filename, self.data)
+
+
+def batched_trajectory(bw, world, log, dt, t0=0., world_index=0, flat=True, save_state=True):
+    """Hdf5Logger-layout datasets of ONE world of a batched rollout.
+
+    ``bw``: the ``BatchedWorlds`` that produced ``log = bw.rollout(...)``;
+    ``world``: the ``core.World`` the model was flattened from (names only).
+    Body poses are evaluated on the device from the logged states in one
+    ``arb_inspect`` call over the whole horizon.
+    """
+    import torch
+    m = bw.model
+    q = log["q"][:, world_index].contiguous()            # (nsteps, nq)
+    dq = log["dq"][:, world_index].contiguous()
+    nsteps = q.shape[0]
+    data = {"timeline": t0 + dt * np.arange(nsteps)}
+    joints = list(world.iterjoints())
+    qh, dqh = q.cpu().numpy(), dq.cpu().numpy()
+    if save_state:
+        for b, j in enumerate(joints):
+            qs = slice(int(m.q_off[b]), int(m.q_off[b] + m.jnq[b]))
+            ds = slice(int(m.dof_off[b]), int(m.dof_off[b] + m.jnd[b]))
+            gp = qh[:, qs].reshape(nsteps, 4, 4) if m.jtype[b] == JT_FREE else qh[:, qs]
+            data["gpositions/%s" % j.name] = gp.astype(np.float64)
+            data["gvelocities/%s" % j.name] = dqh[:, ds].astype(np.float64)
+    if flat:
+        poses = bw.inspect(q, dq, float(dt), ["pose"], skip_constraints=True)["pose"].cpu().numpy()
+        data["transforms/%s" % world.ground.name] = np.tile(np.eye(4), (nsteps, 1, 1))
+        for b, body in enumerate(world.ground.iter_descendant_bodies()):
+            if body.name is not None:
+                data["transforms/%s" % body.name] = poses[:, b].astype(np.float64)
+    else:
+        # Joint.pose is the joint-local transform: evaluated from the logged positions with the
+        # host joint classes (this is bookkeeping for viewers, not part of the step)
+        from . import joints as J
+        cls = {0: J.FreeJoint, 1: J.RzRyRxJoint, 2: J.RzRyJoint, 3: J.RzRxJoint, 4: J.RyRxJoint,
+               5: J.RzJoint, 6: J.RyJoint, 7: J.RxJoint, 8: J.TxTyTzJoint}
+        for b, j in enumerate(joints):
+            name = j.frames[1].name
+            if name is None:
+                continue
+            qs = slice(int(m.q_off[b]), int(m.q_off[b] + m.jnq[b]))
+            out = np.zeros((nsteps, 4, 4))
+            for k in range(nsteps):
+                out[k] = cls[int(m.jtype[b])](gpos=qh[k, qs].astype(np.float64)).pose
+            data["transforms/%s" % name] = out
+    if "energy" in log:
+        e = log["energy"][:, world_index].cpu().numpy().astype(np.float64)
+        data["energy/kinetic"] = e[:, 0]
+        data["energy/potential"] = e[:, 1]
+    return data
+
+
+def save_trajectory(filename, data):
+    """Write the datasets of ``batched_trajectory`` / ``TrajectoryLogger.data``."""
+    _save_datasets(filename, data)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ARB_ABI_VERSION 1
+#define ARB_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -97,6 +97,7 @@ typedef struct arb_model_desc {
     const double *visc;       /* [nb][36] Body.viscosity */
     const int32_t *weighted;  /* [nb] body is acted on by the WeightController (controllers.py:37) */
     double gravity[3];        /* sum over WeightControllers of gravity*up (controllers.py:40-41) */
+    double up[3];             /* World.up (core.py:351), used by the energy monitor */
     /* merged ProportionalDerivativeControllers (controllers.py:141-158), or NULL:
        gforce += pd_tau0 - pd_kp q ;  Z += dt*pd_kp + pd_kd   (dof-indexed, row-major) */
     const double *pd_kp;      /* [ndof][ndof] */
@@ -159,6 +160,7 @@ typedef struct arb_inspect_out {
     void *dq_next;   /* [nw][ndof] */
     void *gs_stats;  /* [nw][4] int32  Gauss-Seidel solve counts of the step: SoftFingerContact release,
                         static, sliding via the fast shift, sliding via the eig6 fallback (diagnostic) */
+    void *energy;    /* [nw][2]            kinetic and potential energy, EnergyMonitor.update observers.py:40-51 */
     void *stamps;    /* [nw][8] int64  shader clock at the phase boundaries A, A', B, C, D, GS, E, end (diagnostic) */
 } arb_inspect_out;
 
@@ -185,6 +187,24 @@ int arb_model_get_info(const arb_model *m, arb_model_info *info);
 int arb_step(arb_model *m, int dtype, void *q, void *dq, void *cforce,
              const void *ext_gforce, int64_t nworlds, double dt, int32_t nsteps,
              uint32_t flags, void *stream);
+
+/*
+ * Per-step logs of a rollout (device pointers, any may be NULL): the state and the
+ * energies an Observer would see at each step (core.py:1361-1362: after
+ * update_constraints, before integrate, i.e. the state at time t).
+ * Counterpart of observers.Hdf5Logger(save_state=True) (observers.py:222-229, 264-267)
+ * and observers.EnergyMonitor (observers.py:40-51), batched.
+ */
+typedef struct arb_rollout_log {
+    void *q_log;       /* [nsteps][nworlds][nq]    */
+    void *dq_log;      /* [nsteps][nworlds][ndof]  */
+    void *energy_log;  /* [nsteps][nworlds][2]     kinetic, potential */
+} arb_rollout_log;
+
+/* arb_step + per-step logs. */
+int arb_rollout(arb_model *m, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
+                int64_t nworlds, double dt, int32_t nsteps, uint32_t flags,
+                const arb_rollout_log *log, void *stream);
 
 /* Evaluate one step WITHOUT modifying q/dq and write the requested intermediate
  * results.  Same arithmetic as arb_step (same kernels, debug stores enabled). */

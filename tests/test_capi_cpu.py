@@ -40,6 +40,7 @@ def test_argument_validation_without_gpu():
     desc.abi_version = 99
     assert lib.arb_model_create(C.byref(desc), 0, C.byref(h)) == 1
     assert lib.arb_step(None, 0, None, None, None, None, 1, 1e-3, 1, 0, None) == 1
+    assert lib.arb_step(None, 0, None, None, None, None, 0, 1e-3, 1, 0, None) == 1     # still needs a model
     assert lib.arb_model_destroy(None) == 1
 
 

@@ -1,0 +1,144 @@
+"""Edge cases of the batched device path: empty / tiny / ragged batches, multi-step
+launches vs repeated single steps, flags, optional buffers, argument checking."""
+import numpy as np
+import pytest
+
+import arb_oracle as O
+from conftest import load_model
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from arboris_python_amd.batch import BatchedWorlds  # noqa: E402
+from arboris_python_amd import synth, scenes  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def h4():
+    m, _, _ = load_model("human36_c4")
+    bw = BatchedWorlds(m)
+    yield bw, m
+    bw.close()
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(1., float(np.max(np.abs(b)))))
+
+
+@pytest.mark.parametrize("B", [0, 1, 3, 65, 257])
+def test_batch_sizes(h4, B):
+    bw, m = h4
+    q, dq = synth.standing_states(m, max(B, 1), seed=3, drop=0.01, vel=0.2)
+    q, dq = q[:B], dq[:B]
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    cf = bw.new_cforce(B, torch.float64)
+    bw.step(tq, tdq, 5e-3, 1, cforce=cf)
+    torch.cuda.synchronize()
+    if B:
+        oq, odq, ocf = O.step(m, q, dq, 5e-3)
+        assert rel(tq.cpu().numpy(), oq) < 1e-9 and rel(tdq.cpu().numpy(), odq) < 1e-8
+        assert rel(cf.cpu().numpy(), ocf) < 1e-6
+
+
+def test_multistep_launch_equals_repeated_single_steps(h4):
+    bw, m = h4
+    q, dq = synth.standing_states(m, 32, seed=4, drop=0.02, vel=0.2)
+    for dtype in (torch.float32, torch.float64):
+        a_q, a_dq = bw.to_device(q, dq, dtype)
+        b_q, b_dq = bw.to_device(q, dq, dtype)
+        ca, cb = bw.new_cforce(32, dtype), bw.new_cforce(32, dtype)
+        bw.step(a_q, a_dq, 5e-3, 12, cforce=ca)
+        for _ in range(12):
+            bw.step(b_q, b_dq, 5e-3, 1, cforce=cb)
+        torch.cuda.synchronize()
+        assert torch.equal(a_q, b_q) and torch.equal(a_dq, b_dq) and torch.equal(ca, cb)
+    bw.step(a_q, a_dq, 5e-3, 0, cforce=ca)            # nsteps = 0 is a no-op
+    torch.cuda.synchronize()
+    assert torch.equal(a_q, b_q)
+
+
+def test_cforce_is_optional_and_skip_constraints(h4):
+    bw, m = h4
+    q, dq = synth.standing_states(m, 16, seed=5, drop=0.0, vel=0.1)
+    a_q, a_dq = bw.to_device(q, dq, torch.float64)
+    b_q, b_dq = bw.to_device(q, dq, torch.float64)
+    bw.step(a_q, a_dq, 5e-3, 1)                         # no cforce buffer
+    bw.step(b_q, b_dq, 5e-3, 1, cforce=bw.new_cforce(16, torch.float64))
+    torch.cuda.synchronize()
+    assert torch.equal(a_q, b_q) and torch.equal(a_dq, b_dq)
+    # skipping the constraints = the contact-free model
+    mg, _, _ = load_model("human36_g")
+    c_q, c_dq = bw.to_device(q, dq, torch.float64)
+    bw.step(c_q, c_dq, 5e-3, 1, skip_constraints=True)
+    torch.cuda.synchronize()
+    oq, odq, _ = O.step(mg, q, dq, 5e-3)
+    assert rel(c_dq.cpu().numpy(), odq) < 1e-9
+    assert not torch.equal(c_dq, a_dq)                  # the feet were on the floor: contacts matter
+
+
+def test_external_generalized_force(h4):
+    bw, m = h4
+    rng = np.random.default_rng(0)
+    q, dq = synth.standing_states(m, 8, seed=6, drop=0.05, vel=0.1)
+    ext = rng.normal(size=(8, m.ndof))
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    text = torch.as_tensor(ext, dtype=torch.float64, device=bw.device).contiguous()
+    bw.step(tq, tdq, 5e-3, 1, ext_gforce=text)
+    torch.cuda.synchronize()
+    oq, odq, _ = O.step(m, q, dq, 5e-3, ext_gforce=ext)
+    assert rel(tdq.cpu().numpy(), odq) < 1e-9
+
+
+def test_disabled_constraint():
+    w = scenes.human36_world(4)
+    w._constraints[1].disable()
+    from arboris_python_amd.flatten import flatten_world
+    m, _, _ = flatten_world(w)
+    assert list(m.c_enabled) == [1, 0, 1, 1]
+    bw = BatchedWorlds(m)
+    q, dq = synth.standing_states(m, 8, seed=7, drop=0.0, vel=0.2)
+    q[:, 7] -= 0.002
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    cf = bw.new_cforce(8, torch.float64)
+    bw.step(tq, tdq, 5e-3, 1, cforce=cf)
+    torch.cuda.synchronize()
+    oq, odq, ocf = O.step(m, q, dq, 5e-3)
+    assert rel(tdq.cpu().numpy(), odq) < 1e-8
+    assert float(cf[:, 1].abs().max()) == 0.
+    bw.close()
+
+
+def test_argument_checking(h4):
+    bw, m = h4
+    q, dq = synth.standing_states(m, 4, seed=8)
+    tq, tdq = bw.to_device(q, dq, torch.float32)
+    with pytest.raises(ValueError):
+        bw.step(tq[:, :10].contiguous(), tdq, 5e-3)
+    with pytest.raises(ValueError):
+        bw.step(tq, tdq.double(), 5e-3)
+    with pytest.raises(ValueError):
+        bw.step(tq.cpu(), tdq, 5e-3)
+    with pytest.raises(TypeError):
+        bw.step(tq.half(), tdq.half(), 5e-3)
+    from arboris_python_amd._capi import ArbError
+    with pytest.raises(ArbError):
+        bw.step(tq, tdq, -1.0)
+
+
+def test_small_models_use_other_register_tiles():
+    """simplearm (NMAX=16 tile) and a 20-link chain (NMAX=32), float32 + float64."""
+    for name, mdl, kw in (("arm", scenes.flat(scenes.simplearm_world()), dict(seed=1, angle=1.0, vel=1.0)),
+                          ("snake20", scenes.flat(scenes.snake_world(20)), dict(seed=2, angle=0.5, vel=1.0))):
+        bw = BatchedWorlds(mdl)
+        assert bw.info["nmax"] in (16, 32)
+        q, dq = synth.random_states(mdl, 16, **kw)
+        oq, odq, _ = O.step(mdl, q, dq, 1e-3)
+        # the chain's Z is ill-conditioned: the reference's explicit inverse limits the
+        # float64 agreement to ~1e-8 ("snake-64")
+        for dtype, tol in ((torch.float64, 1e-9 if name == "arm" else 1e-7),
+                           (torch.float32, 2e-5 if name == "arm" else 1e-2)):
+            tq, tdq = bw.to_device(q, dq, dtype)
+            bw.step(tq, tdq, 1e-3, 1)
+            torch.cuda.synchronize()
+            assert rel(tdq.cpu().numpy(), odq) < tol, (name, dtype)
+        bw.close()
