@@ -61,7 +61,7 @@ class InspectOut(C.Structure):
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
             "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_rollout", "arb_inspect"]
 # host-side self-test hooks (device math compiled for the CPU)
-TEST_HOOKS = ["arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_eig6", "arb_host_joint_local",
+TEST_HOOKS = ["arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_joint_local",
               "arb_host_exp_twist"]
 
 _lib = None
@@ -102,6 +102,8 @@ def load():
                                               C.c_double, _PD, _PD]
     lib.arb_host_softfinger_try.restype = C.c_int
     lib.arb_host_softfinger_try.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, _PD]
+    lib.arb_host_slide_root.restype = C.c_int
+    lib.arb_host_slide_root.argtypes = [_PD, C.c_double, C.c_double, C.c_double, _PD]
     lib.arb_host_eig6.restype = C.c_int
     lib.arb_host_eig6.argtypes = [_PD, _PD, _PD]
     lib.arb_host_joint_local.restype = C.c_int

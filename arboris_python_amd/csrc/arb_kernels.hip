@@ -828,6 +828,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             T vr = T(0), fr = T(0), Yrow[4], Prow[4];
             T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
             T k_min = T(0), k_max = T(0);
+            double k_tr = 0., k_m2 = 0., k_det = 0., k_sQ = 0., k_sA = 0., k_nq = 0., k_warm = NAN;
             int k_ct = 0;
             bool k_act = false;
 #pragma unroll
@@ -848,6 +849,16 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
                 k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
                 k_min = mp->cmin[lane]; k_max = mp->cmax[lane];
+                if (k_act && k_ct == ARB_CT_SOFTFINGER_PLANE) {
+                    // admittance-only part of the sliding-branch polynomial, once per step
+                    T Yc4[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * lane + i) * ndol + 4 * lane + j];
+                    const SlidePre sp = slide_precompute<T>(Yc4);
+                    k_tr = sp.tr; k_m2 = sp.m2; k_det = sp.det; k_sQ = sp.sQ; k_sA = sp.sA; k_nq = sp.nq;
+                }
             }
             const unsigned long long actmask = __ballot(k_act);
             int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0;
@@ -902,7 +913,11 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                                 }
                                 alpha[3] += sdt;
                                 if (MODE == 1) ++st_fast;
-                                if (!softfinger_sliding_shift<T>(Y, alpha, mu, eps, WORK, &shift)) {
+                                SlidePre sp;
+                                sp.tr = bcast(k_tr, c); sp.m2 = bcast(k_m2, c); sp.det = bcast(k_det, c);
+                                sp.sQ = bcast(k_sQ, c); sp.sA = bcast(k_sA, c); sp.nq = bcast(k_nq, c);
+                                double warm = bcast(k_warm, c);
+                                if (!softfinger_sliding_shift<T>(Y, alpha, mu, eps, WORK, &shift, true, &sp, &warm)) {
                                     if (MODE == 1) { ++st_slow; --st_fast; }
                                     // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
                                     WAVE_SYNC();
@@ -910,7 +925,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                                     WAVE_SYNC();
                                     shift = WORK[40];
                                     WAVE_SYNC();
+                                    warm = NAN;
                                 }
+                                if (lane == c) k_warm = warm;       // next sweep restarts next to this root
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) fnew[i] = fc[i];
                                 softfinger_slide_finish<T>(Y, alpha, eps, shift, fnew, df);
@@ -1496,6 +1513,13 @@ extern "C" int arb_host_softfinger_try(int dtype, const double *vel, const doubl
     for (int i = 0; i < 3; ++i) e[i] = (float)eps[i];
     inv_block<float>(Y, 4, 4, P);
     return softfinger_try<float>(v, Y, P, f, df, (float)sdist, (float)dt, (float)mu, e, work, alpha, &s);
+}
+
+// leftmost real root of the sliding-branch sextic for the admittance block Y (4x4, row-major);
+// returns 1 on success.  `warm` may be NaN.
+extern "C" int arb_host_slide_root(const double *Y, double c1, double kappa, double warm, double *root) {
+    const SlidePre k = slide_precompute<double>(Y);
+    return slide_leftmost_root(k, c1, kappa, warm, root) ? 1 : 0;
 }
 
 extern "C" int arb_host_eig6(const double *A, double *wr, double *wi) {

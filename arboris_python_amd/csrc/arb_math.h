@@ -519,7 +519,6 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
 // roots are real, which is the case met in practice); any anomaly makes the
 // caller fall back to the generic QR eigenvalue routine eig6().
 // ---------------------------------------------------------------------------
-struct SlideCoef { double c0, c1, c2, c3m1; };   // c3m1 = (b.b) - 1
 
 ARB_HD double arb_fast_rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -536,52 +535,82 @@ ARB_HD double arb_fast_sqrt(double x) {
 #endif
 }
 
-ARB_HD void arb_quadmul(const double a[3], const double b[3], double c[5]) {
-    c[0] = a[0] * b[0];
-    c[1] = a[0] * b[1] + a[1] * b[0];
-    c[2] = a[0] * b[2] + a[1] * b[1] + a[2] * b[0];
-    c[3] = a[1] * b[2] + a[2] * b[1];
-    c[4] = a[2] * b[2];
+// Pieces of det(B - sI) that depend only on the constraint's admittance block (constant over
+// the 20 sweeps of a step): with Q = Y_t - c0 11^T,
+//   chi(z) = det(zI - Q) = z^3 - tr z^2 + m2 z - det,   rho(z) = 1^T adj(Q - zI) 1 = 3 z^2 - (3 tr - sQ) z + sA
+// and, for kappa = c2 (c3 - 1) = -d2,
+//   det(B - sI) = E_chi^2 - d2 O_chi^2 - c1 (E_rho E_chi - d2 O_rho O_chi)
+// where E/O are the parts of chi(s +- d), rho(s +- d) even/odd in d (all real whatever the
+// sign of d2):  E_chi = chi(s) + d2 (3s - tr),  O_chi = chi'(s) + d2,  E_rho = rho(s) + 3 d2,
+// O_rho = rho'(s).  (Matrix determinant lemma on (Q - s + c1 11^T)(Q - s) + kappa I.)
+struct SlidePre { double tr, m2, det, sQ, sA, nq; };
+
+template <typename T>
+ARB_HD SlidePre slide_precompute(const T Y[16]) {
+    const T ycyc = Y[3] * Y[3] + Y[7] * Y[7] + Y[11] * Y[11];        // dot(Y_c, Y_c.T): a scalar (constraints.py:813)
+    const double c0 = (double)ycyc / (double)Y[15];
+    double Q[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Q[i][j] = (double)Y[4 * i + j] - c0;
+    SlidePre k;
+    k.tr = Q[0][0] + Q[1][1] + Q[2][2];
+    // adjugate (transposed cofactors); only its trace and the sum of its entries are needed
+    const double A00 = Q[1][1] * Q[2][2] - Q[1][2] * Q[2][1], A01 = Q[0][2] * Q[2][1] - Q[0][1] * Q[2][2],
+                 A02 = Q[0][1] * Q[1][2] - Q[0][2] * Q[1][1], A10 = Q[1][2] * Q[2][0] - Q[1][0] * Q[2][2],
+                 A11 = Q[0][0] * Q[2][2] - Q[0][2] * Q[2][0], A12 = Q[0][2] * Q[1][0] - Q[0][0] * Q[1][2],
+                 A20 = Q[1][0] * Q[2][1] - Q[1][1] * Q[2][0], A21 = Q[0][1] * Q[2][0] - Q[0][0] * Q[2][1],
+                 A22 = Q[0][0] * Q[1][1] - Q[0][1] * Q[1][0];
+    k.m2 = A00 + A11 + A22;
+    k.det = Q[0][0] * A00 + Q[0][1] * A10 + Q[0][2] * A20;
+    k.sQ = 0.; k.nq = 0.;
+    for (int i = 0; i < 3; ++i) {
+        double r = 0.;
+        for (int j = 0; j < 3; ++j) { k.sQ += Q[i][j]; r += fabs(Q[i][j]); }
+        k.nq = fmax(k.nq, r);
+    }
+    k.sA = A00 + A01 + A02 + A10 + A11 + A12 + A20 + A21 + A22;
+    return k;
 }
 
-// Returns true and the leftmost real root in *root when the fast path succeeded.
-template <typename T>
-ARB_HD bool slide_leftmost_root(const T Y[16], const SlideCoef &k, double *root) {
-    double Q[3][3], P[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) { Q[i][j] = (double)Y[4 * i + j] - k.c0; P[i][j] = Q[i][j] + k.c1; }
-    const double kappa = k.c2 * k.c3m1;
-    // F(s) = s^2 I + s A1 + A0 ; entries as quadratics f[i][j] = {A0, A1, delta}
-    double f[3][3][3];
-    // Spectrum bound: (P - s)(Q - s) + kappa I is non-singular as soon as
-    // (|s| - |P|)(|s| - |Q|) > |kappa|, hence every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
-    // (infinity norms).
-    double rb = 0.;
-    for (int i = 0; i < 3; ++i) {
-        double r1 = 0., r2 = 0.;
-        for (int j = 0; j < 3; ++j) {
-            double a0 = P[i][0] * Q[0][j] + P[i][1] * Q[1][j] + P[i][2] * Q[2][j];
-            f[i][j][0] = a0 + (i == j ? kappa : 0.);
-            f[i][j][1] = -(P[i][j] + Q[i][j]);
-            f[i][j][2] = (i == j) ? 1. : 0.;
-            r1 += fabs(P[i][j]); r2 += fabs(Q[i][j]);
-        }
-        rb = fmax(rb, fmax(r1, r2));
-    }
-    double pc[7] = {0., 0., 0., 0., 0., 0., 0.};
-    for (int t = 0; t < 3; ++t) {                     // cofactor expansion along row 0
-        const int a = (t + 1) % 3, b = (t + 2) % 3;   // cyclic columns keep the sign positive
-        double m1[5], m2[5];
-        arb_quadmul(f[1][a], f[2][b], m1);
-        arb_quadmul(f[1][b], f[2][a], m2);
-        for (int i = 0; i < 5; ++i) m1[i] -= m2[i];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 5; ++j) pc[i + j] += f[0][t][i] * m1[j];
-    }
-    rb += sqrt(fabs(kappa));
+// Leftmost real root of det(B - sI).  `warm` (NaN = none) is the root found for the same
+// constraint in the previous sweep: the iteration restarts just left of it when a
+// Budan-Fourier certificate (all Taylor coefficients at the start point alternate in sign,
+// hence no real root to its left) holds, otherwise from the spectrum bound.
+// Returns true and the root when the register-only path succeeded.
+ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, double warm, double *root) {
+    const double d2 = -kappa;
+    const double l1 = -(3. * k.tr - k.sQ);
+    const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
+    const double o[3] = {k.m2 + d2, -2. * k.tr, 3.};                          // O_chi
+    const double er[3] = {k.sA + 3. * d2, l1, 3.};                            // E_rho
+    const double orr[2] = {l1, 6.};                                           // O_rho
+    double pc[7];
+    // E_chi^2 - d2 O_chi^2
+    pc[0] = e[0] * e[0] - d2 * (o[0] * o[0]);
+    pc[1] = 2. * e[0] * e[1] - d2 * (2. * o[0] * o[1]);
+    pc[2] = 2. * e[0] * e[2] + e[1] * e[1] - d2 * (2. * o[0] * o[2] + o[1] * o[1]);
+    pc[3] = 2. * (e[0] * e[3] + e[1] * e[2]) - d2 * (2. * o[1] * o[2]);
+    pc[4] = 2. * e[1] * e[3] + e[2] * e[2] - d2 * (o[2] * o[2]);
+    pc[5] = 2. * e[2] * e[3];
+    pc[6] = 1.;
+    // - c1 (E_rho E_chi - d2 O_rho O_chi)
+    pc[0] -= c1 * (er[0] * e[0] - d2 * (orr[0] * o[0]));
+    pc[1] -= c1 * (er[0] * e[1] + er[1] * e[0] - d2 * (orr[0] * o[1] + orr[1] * o[0]));
+    pc[2] -= c1 * (er[0] * e[2] + er[1] * e[1] + er[2] * e[0] - d2 * (orr[0] * o[2] + orr[1] * o[1]));
+    pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
+    pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
+    pc[5] -= c1 * (er[2] * e[3]);
+    // |P| <= |Q| + 3 |c1| (infinity norms); every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
+    const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
     if (!(rb > 0.) || !(rb < 1e300)) return false;
-    // Laguerre from the left of every root
     double x = -1.0001 * rb - 1e-300;
+    if (warm == warm && warm > x) {
+        const double x0 = warm - 1e-3 * fabs(warm) - 1e-300;
+        double t[7];
+        for (int i = 0; i < 7; ++i) t[i] = pc[i];
+        for (int j = 0; j < 6; ++j)                 // Taylor shift: t[i] = p^(i)(x0) / i!
+            for (int i = 5; i >= j; --i) t[i] += x0 * t[i + 1];
+        if (t[0] > 0. && t[1] < 0. && t[2] > 0. && t[3] < 0. && t[4] > 0. && t[5] < 0.) x = x0;
+    }
     const double n = 6.;
     for (int it = 0; it < 40; ++it) {
         double p0 = pc[6], p1 = 0., p2 = 0., ee = fabs(pc[6]);
@@ -617,7 +646,8 @@ ARB_HD bool slide_leftmost_root(const T Y[16], const SlideCoef &k, double *root)
 // caller then runs eig6 on it).
 template <typename T, typename AP>
 ARB_HD bool softfinger_sliding_shift(const T Y[16], const T alpha[4], T mu, const T eps[3], AP work,
-                                     T *shift, bool use_fast = true) {
+                                     T *shift, bool use_fast = true, const SlidePre *pre = nullptr,
+                                     double *warm = nullptr) {
     T Yc[3] = {Y[3], Y[7], Y[11]};
     T yn = Y[15];
     T beta[3], b[3];
@@ -630,13 +660,13 @@ ARB_HD bool softfinger_sliding_shift(const T Y[16], const T alpha[4], T mu, cons
     T b2 = beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2];
     T bsq = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
     if (use_fast && eps[0] == T(1) && eps[1] == T(1) && eps[2] == T(1)) {
-        SlideCoef k;
-        k.c0 = (double)ycyc / (double)yn;
-        k.c1 = 2. / (double)a * (double)bb;
-        k.c2 = (double)b2 / ((double)a * (double)a);
-        k.c3m1 = (double)bsq - 1.;
+        const SlidePre kk = pre ? *pre : slide_precompute<T>(Y);
+        const double ia = 1. / (double)a;
+        const double c1 = 2. * ia * (double)bb;
+        const double kappa = ((double)b2 * ia * ia) * ((double)bsq - 1.);
         double root;
-        if (slide_leftmost_root<T>(Y, k, &root)) {
+        if (slide_leftmost_root(kk, c1, kappa, warm ? *warm : NAN, &root)) {
+            if (warm) *warm = root;
             // leftmost real eigenvalue; admissible when <= 0, else no admissible one (constraints.py:826-830)
             *shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
             return true;

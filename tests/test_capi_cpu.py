@@ -108,6 +108,38 @@ def test_sliding_shift_fast_path_is_taken(dtype):
 
 
 @needs_lib
+def test_sliding_root_formula_and_warm_start():
+    """The structured sextic (per-step precompute + per-sweep scalars) has the eigenvalues
+    of the reference's 6x6 matrix, and a warm start left or right of the root, certified or
+    not, never changes the answer."""
+    lib = _capi.load()
+    g = load_golden("g3_contacts.npz")
+    for i in range(0, len(g["solve_sliding_dt"]), 3):
+        vel, adm, f = g["solve_sliding_vel"][i], g["solve_sliding_adm"][i], g["solve_sliding_force"][i]
+        sd, dt, mu = g["solve_sliding_sdist"][i], g["solve_sliding_dt"][i], g["solve_sliding_mu"][i]
+        alpha = vel - adm @ f
+        alpha[3] += sd / dt
+        Yc, yn = adm[0:3, 3], adm[3, 3]
+        beta = alpha[0:3] - alpha[3] / yn * Yc
+        a = mu / yn * alpha[3]
+        b = mu / yn * Yc
+        c0, c1 = Yc @ Yc / yn, 2 / a * (beta @ b)
+        c2, c3m1 = (beta @ beta) / a ** 2, b @ b - 1
+        B = np.zeros((6, 6))
+        B[3:, 3:] = adm[0:3, 0:3] - c0
+        B[:3, :3] = adm[0:3, 0:3] - c0 + c1
+        B[:3, 3:] = -np.eye(3) * c2
+        B[3:, :3] = np.eye(3) * c3m1
+        ev = np.linalg.eigvals(B)
+        ref = np.min(ev.real[np.abs(ev.imag) < 1e-12])
+        Y = np.ascontiguousarray(adm)
+        for warm in (float("nan"), ref, ref * 1.5, ref * 0.5, 0.3, -50.0):
+            root = np.zeros(1)
+            assert lib.arb_host_slide_root(_capi._dp(Y), float(c1), float(c2 * c3m1), float(warm), _capi._dp(root)) == 1
+            assert abs(root[0] - ref) < 1e-9 * max(1e-3, abs(ref)), (i, warm, root[0], ref)
+
+
+@needs_lib
 def test_device_softfinger_solve_float32_on_host():
     lib = _capi.load()
     g = load_golden("g3_contacts.npz")
