@@ -17,6 +17,8 @@ ARB_OK = 0
 ARB_F32, ARB_F64 = 0, 1
 ARB_MAXDOL = 4
 ARB_STEP_SKIP_CONSTRAINTS = 1
+ARB_STEP_FUSED = 2
+ARB_STEP_SPLIT = 4
 
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)

@@ -91,12 +91,16 @@ class BatchedWorlds(object):
 
     # -- the step --------------------------------------------------------------
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
-             stream=None):
+             stream=None, fused=False, split=False):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous)."""
         torch = _torch()
         B = self._check_state(q, dq, cforce, ext_gforce)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
+        if fused:
+            flags |= _capi.ARB_STEP_FUSED
+        if split:
+            flags |= _capi.ARB_STEP_SPLIT
         _capi.check(self._lib.arb_step(
             self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
             None if cforce is None else cforce.data_ptr(),
@@ -104,7 +108,7 @@ class BatchedWorlds(object):
             B, float(dt), int(nsteps), flags, C.c_void_p(st.cuda_stream)))
 
     def rollout(self, q, dq, dt, nsteps, cforce=None, ext_gforce=None, log_state=True, log_energy=True,
-                skip_constraints=False, stream=None):
+                skip_constraints=False, stream=None, fused=False, split=False):
         """Advance ``nsteps`` steps in ONE launch and return the per-step logs an Observer
         would have recorded (state and energies at the beginning of every step):
         ``{"q": (nsteps,B,nq), "dq": (nsteps,B,ndof), "energy": (nsteps,B,2)}``."""
@@ -113,6 +117,10 @@ class BatchedWorlds(object):
         m = self.model
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
+        if fused:
+            flags |= _capi.ARB_STEP_FUSED
+        if split:
+            flags |= _capi.ARB_STEP_SPLIT
         out = {}
         log = _capi.RolloutLog()
         if log_state:

@@ -89,6 +89,21 @@ struct DevModel {
     const T *clocal, *cradius, *cHinv, *cplane, *cRz, *cmu, *cprox, *ceps, *cmin, *cmax, *cb0, *cb1;
 };
 
+// Split execution (contact models, large batches): the step kernel stops after the
+// constraint-space system is built and writes it here; arb_gs_kernel then runs the
+// Gauss-Seidel sweeps with one LANE per world, and the next step kernel launch starts
+// by applying the resulting forces (core.py:975-979).  World-major blocks.
+template <typename T>
+struct SplitIO {
+    int mode;          // 0 fused; bit 0: apply the pending update first; bit 1: produce a system and stop
+    T *A;              // [nw][ndol][ndol]   Y' = J' Y J'^T
+    T *v;              // [nw][ndol]         J' Y (M gvel/dt + gforce)
+    T *f;              // [nw][ndol]         constraint forces (in: warm start, out: after the sweeps)
+    T *f0;             // [nw][ndol]         forces already contained in v (warm start)
+    T *c;              // [nw][nc][8]        active, sdist, pos0[3]
+    T *sol;            // [nw][1+ndol][ndof] columns of [Y rhs | Y J'^T]
+};
+
 // Optional per-step logs of arb_rollout (state and energies as observers see them: before the step)
 template <typename T>
 struct LogOut {
@@ -180,7 +195,7 @@ template <typename T, int NMAX, int NSETS, int MODE>
 __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
     T *__restrict__ gcforce, const T *__restrict__ gext, long nworlds, T dt, int nsteps,
-    unsigned flags, const DebugOut<T> dbg, int zmode, const LogOut<T> logo)
+    unsigned flags, const DebugOut<T> dbg, int zmode, const LogOut<T> logo, const SplitIO<T> sio)
 {
     const DevModel<T> *mp = mp_in;     // device-resident model, fields fetched with scalar loads
     const int lane0 = threadIdx.x;
@@ -210,6 +225,51 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 
 #define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); } while (0)
+
+    // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
+    // columns in RT, then every joint integrates its position.
+    auto integrate_from_rt = [&](bool with_forces) {
+        T vnew = T(0);
+        if (lane < n) {
+            vnew = RT[lane];
+            if (with_forces)
+                for (int i = 0; i < ndol; ++i) vnew += RT[(1 + i) * RS + lane] * (FF[i] - FF0[i]);
+        }
+        WAVE_SYNC();
+        if (lane < n) {
+            dqs[lane] = vnew;
+            const int qi = mp->dof2q[lane];
+            if (qi >= 0) qs[qi] += dt * vnew;                               // core.py:238-240
+        }
+        WAVE_SYNC();
+        if (lane < nb && mp->jtype[lane] == JT_FREE) {                        // joints.py:54-57
+            T *qp = qs + mp->q_off[lane];
+            const T *vp = dqs + mp->dof_off[lane];
+            M3<T> R, Re; V3<T> p, pe;
+            R.a[0] = qp[0]; R.a[1] = qp[1]; R.a[2] = qp[2]; p.x = qp[3];
+            R.a[3] = qp[4]; R.a[4] = qp[5]; R.a[5] = qp[6]; p.y = qp[7];
+            R.a[6] = qp[8]; R.a[7] = qp[9]; R.a[8] = qp[10]; p.z = qp[11];
+            exp_twist<T>(dt * v3<T>(vp[0], vp[1], vp[2]), dt * v3<T>(vp[3], vp[4], vp[5]), Re, pe);
+            const M3<T> Rn = mul(R, Re);
+            const V3<T> pn = mv(R, pe) + p;
+            qp[0] = Rn.a[0]; qp[1] = Rn.a[1]; qp[2] = Rn.a[2]; qp[3] = pn.x;
+            qp[4] = Rn.a[3]; qp[5] = Rn.a[4]; qp[6] = Rn.a[5]; qp[7] = pn.y;
+            qp[8] = Rn.a[6]; qp[9] = Rn.a[7]; qp[10] = Rn.a[8]; qp[11] = pn.z;
+            qp[12] = T(0); qp[13] = T(0); qp[14] = T(0); qp[15] = T(1);
+        }
+        WAVE_SYNC();
+    };
+
+    if (MODE == 0 && (sio.mode & 1)) {
+        // split execution: finish the previous step with the forces arb_gs_kernel left in sio.f
+        const int ncol_s = 1 + ndol;
+        for (int i = lane; i < ncol_s * n; i += WAVE) RT[(i / n) * RS + (i % n)] = sio.sol[(long)w * ncol_s * n + i];
+        for (int i = lane; i < ndol; i += WAVE) { FF[i] = sio.f[w * ndol + i]; FF0[i] = sio.f0[w * ndol + i]; }
+        WAVE_SYNC();
+        integrate_from_rt(true);
+    }
+    if (MODE == 0 && sio.mode != 0 && !(sio.mode & 2)) nsteps = 0;      // apply only
+
     for (int step = 0; step < nsteps; ++step) {
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
@@ -807,6 +867,23 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         WAVE_SYNC();
         if (MODE == 1 && dbg.vel_free != nullptr && lane < n) dbg.vel_free[w * n + lane] = RT[lane];
 
+        if (MODE == 0 && (sio.mode & 2)) {
+            // split execution: hand the constraint-space system to arb_gs_kernel and stop here;
+            // the next launch applies the forces (integrate_from_rt above)
+            const int ncol_s = 1 + ndol;
+            for (int i = lane; i < ncol_s * n; i += WAVE) sio.sol[(long)w * ncol_s * n + i] = RT[(i / n) * RS + (i % n)];
+            for (int i = lane; i < ndol * ndol; i += WAVE) sio.A[(long)w * ndol * ndol + i] = AM[i];
+            for (int i = lane; i < ndol; i += WAVE) {
+                sio.v[w * ndol + i] = VV[i]; sio.f[w * ndol + i] = FF[i]; sio.f0[w * ndol + i] = FF0[i];
+            }
+            if (lane < nc) {
+                const T *cd = CD + lane * CD_STRIDE;
+                T *o = sio.c + ((long)w * nc + lane) * 8;
+                o[0] = cd[CD_ACTIVE]; o[1] = cd[CD_SDIST]; o[2] = cd[CD_POS0]; o[3] = cd[CD_POS0 + 1]; o[4] = cd[CD_POS0 + 2];
+            }
+            break;
+        }
+
         if (do_constraints) {
             // inverse of every active constraint's own admittance block (once per step)
             if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
@@ -969,12 +1046,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         // ================= phase E: new velocity, integrate ==================
         ARB_OPAQUE_LANE();
         ARB_STAMP(6);
-        T vnew = T(0);
-        if (lane < n) {
-            vnew = RT[lane];
-            if (do_constraints)
-                for (int i = 0; i < ndol; ++i) vnew += RT[(1 + i) * RS + lane] * (FF[i] - FF0[i]);
-        }
         if (MODE == 1) {
             if (dbg.gforce != nullptr && lane < n) {
                 // World._gforce after update_constraints: controllers + sum J_c^T f_c  (core.py:936-937);
@@ -987,29 +1058,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             if (dbg.c_force != nullptr)
                 for (int i = lane; i < ndol; i += WAVE) dbg.c_force[w * ndol + i] = FF[i];
         }
-        WAVE_SYNC();
-        if (lane < n) {
-            dqs[lane] = vnew;
-            const int qi = mp->dof2q[lane];
-            if (qi >= 0) qs[qi] += dt * vnew;                               // core.py:238-240
-        }
-        WAVE_SYNC();
-        if (lane < nb && mp->jtype[lane] == JT_FREE) {                        // joints.py:54-57
-            T *qp = qs + mp->q_off[lane];
-            const T *vp = dqs + mp->dof_off[lane];
-            M3<T> R, Re; V3<T> p, pe;
-            R.a[0] = qp[0]; R.a[1] = qp[1]; R.a[2] = qp[2]; p.x = qp[3];
-            R.a[3] = qp[4]; R.a[4] = qp[5]; R.a[5] = qp[6]; p.y = qp[7];
-            R.a[6] = qp[8]; R.a[7] = qp[9]; R.a[8] = qp[10]; p.z = qp[11];
-            exp_twist<T>(dt * v3<T>(vp[0], vp[1], vp[2]), dt * v3<T>(vp[3], vp[4], vp[5]), Re, pe);
-            const M3<T> Rn = mul(R, Re);
-            const V3<T> pn = mv(R, pe) + p;
-            qp[0] = Rn.a[0]; qp[1] = Rn.a[1]; qp[2] = Rn.a[2]; qp[3] = pn.x;
-            qp[4] = Rn.a[3]; qp[5] = Rn.a[4]; qp[6] = Rn.a[5]; qp[7] = pn.y;
-            qp[8] = Rn.a[6]; qp[9] = Rn.a[7]; qp[10] = Rn.a[8]; qp[11] = pn.z;
-            qp[12] = T(0); qp[13] = T(0); qp[14] = T(0); qp[15] = T(1);
-        }
-        WAVE_SYNC();
+        integrate_from_rt(do_constraints);
     }
 
     // ---- store state -------------------------------------------------------
@@ -1018,11 +1067,118 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     if (MODE == 0) {
         for (int i = lane; i < nq; i += WAVE) gq[w * nq + i] = qs[i];
         if (lane < n) gdq[w * n + lane] = dqs[lane];
-        if (gcforce != nullptr)
+        if (gcforce != nullptr && !(sio.mode & 2))
             for (int i = lane; i < ndol; i += WAVE) gcforce[w * ndol + i] = FF[i];
     } else {
         if (dbg.q_next != nullptr) for (int i = lane; i < nq; i += WAVE) dbg.q_next[w * nq + i] = qs[i];
         if (dbg.dq_next != nullptr && lane < n) dbg.dq_next[w * n + lane] = dqs[lane];
+    }
+}
+
+// ===========================================================================
+// Gauss-Seidel with one LANE per world (split execution).  Same per-constraint
+// algebra as the fused kernel (arb_math.h), 20 sweeps in registration order
+// (core.py:929-935).  The constraint-space matrix of the block's worlds is staged
+// in LDS (row padded by one element: lane-private rows on distinct banks).
+// ===========================================================================
+template <typename T, int NC, int WPB>
+__global__ __launch_bounds__(WAVE) void arb_gs_kernel(
+    const DevModel<T> *__restrict__ mp, const T *__restrict__ wsA, const T *__restrict__ wsv,
+    T *__restrict__ wsf, const T *__restrict__ wsc, long nworlds, T dt)
+{
+    constexpr int ND = 4 * NC;
+    T *lds = reinterpret_cast<T *>(arb_lds_raw);
+    const int nc = mp->nc, ndol = mp->ndol;
+    const int nA = ndol * ndol, sA = nA + 1, sP = 16 * nc + 1, sW = 41;
+    T *Ash = lds, *Psh = Ash + WPB * sA, *Wsh = Psh + WPB * sP;
+    const int lane = threadIdx.x;
+    const long w0 = (long)blockIdx.x * WPB;
+    const long w = w0 + lane;
+    const bool on = lane < WPB && w < nworlds;
+    const long nblk = (nworlds - w0) < WPB ? (nworlds - w0) : WPB;
+    for (long i = lane; i < nblk * nA; i += WAVE) Ash[(i / nA) * sA + (i % nA)] = wsA[w0 * nA + i];
+    __syncthreads();
+    const T inv_dt = T(1) / dt;
+    T v[ND], f[ND];
+    T c_sd[NC], c_p0[NC], c_p1[NC], c_p2[NC];
+    double c_warm[NC];
+    bool c_act[NC];
+    const T *Arow = Ash + lane * sA;
+    T *Prow = Psh + lane * sP;
+    T *work = Wsh + lane * sW;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { v[i] = T(0); f[i] = T(0); }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { c_act[c] = false; c_sd[c] = c_p0[c] = c_p1[c] = c_p2[c] = T(0); c_warm[c] = NAN; }
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) if (i < ndol) { v[i] = wsv[w * ndol + i]; f[i] = wsf[w * ndol + i]; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c < nc) {
+                const T *cs = wsc + (w * nc + c) * 8;
+                c_act[c] = cs[0] != T(0);
+                c_sd[c] = cs[1]; c_p0[c] = cs[2]; c_p1[c] = cs[3]; c_p2[c] = cs[4];
+                if (c_act[c]) {
+                    const int ct = mp->ctype[c];
+                    const int nd = (ct == ARB_CT_SOFTFINGER_PLANE) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                    T P[16];
+                    inv_block<T>(Arow + (4 * c) * ndol + 4 * c, ndol, nd, P);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Prow[16 * c + i] = P[i];
+                }
+            }
+        }
+    }
+    for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c >= nc) continue;
+            const int ct = mp->ctype[c];                       // same model for every world: uniform
+            if (!(on && c_act[c])) continue;
+            T Y[16], P[16], v4[4], f4[4], df[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v4[i] = v[4 * c + i]; f4[i] = f[4 * c + i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { Y[4 * i + j] = Arow[(4 * c + i) * ndol + 4 * c + j]; P[4 * i + j] = Prow[16 * c + 4 * i + j]; }
+            }
+            if (ct == ARB_CT_SOFTFINGER_PLANE) {                   // constraints.py:780-836
+                const T eps[3] = {mp->ceps[3 * c], mp->ceps[3 * c + 1], mp->ceps[3 * c + 2]};
+                T alpha[4], shift = T(0);
+                int br = softfinger_try<T>(v4, Y, P, f4, df, c_sd[c], dt, mp->cmu[c], eps, work, alpha, &shift,
+                                           true, nullptr, &c_warm[c]);
+                if (br == 3) { shift = slide_shift_from_eig<T>(work); c_warm[c] = NAN; br = 2; }
+                if (br == 2) softfinger_slide_finish<T>(Y, alpha, eps, shift, f4, df);
+            } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
+                const T tg[3] = {v4[0] + c_p0[c] * inv_dt, v4[1] + c_p1[c] * inv_dt, v4[2] + c_p2[c] * inv_dt};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    df[i] = -(P[4 * i] * tg[0] + P[4 * i + 1] * tg[1] + P[4 * i + 2] * tg[2]);
+                    f4[i] += df[i];
+                }
+            } else {                                               // JointLimits.solve constraints.py:73-90
+                const T pred = c_p0[c] + dt * (v4[0] - Y[0] * f4[0]);
+                const T lo = mp->cmin[c], hi = mp->cmax[c];
+                T nf = T(0);
+                if (pred <= lo) nf = P[0] * ((lo - pred) * inv_dt);
+                else if (hi <= pred) nf = P[0] * ((hi - pred) * inv_dt);
+                df[0] = nf - f4[0]; f4[0] = nf;
+            }
+            // vel += Y'[:, c] dforce                               core.py:935
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+                if (i < ndol) {
+                    const T *ar = Arow + i * ndol + 4 * c;
+                    v[i] += ar[0] * df[0] + ar[1] * df[1] + ar[2] * df[2] + ar[3] * df[3];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[4 * c + i] = f4[i];
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) if (i < ndol) wsf[w * ndol + i] = f[i];
     }
 }
 
@@ -1048,6 +1204,8 @@ struct arb_model {
     DevModel<double> dd;
     DevModel<float> *df_dev;
     DevModel<double> *dd_dev;
+    void *ws = nullptr;            // split-execution workspace (grow-only)
+    size_t ws_bytes = 0;
     Layout lf, ld;
 };
 
@@ -1341,6 +1499,7 @@ extern "C" int arb_model_destroy(arb_model *M) {
     if (!M) return ARB_ERR_INVALID;
     (void)hipSetDevice(M->device);
     for (void *p : M->allocs) (void)hipFree(p);
+    if (M->ws) (void)hipFree(M->ws);
     delete M;
     return ARB_OK;
 }
@@ -1357,38 +1516,127 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 
 template <typename T, int NMAX, int NSETS, int MODE>
 static int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw, double dt,
-                      int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo, hipStream_t st) {
+                      int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
+                      const SplitIO<T> &sio, hipStream_t st) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
     const size_t lds = (size_t)L.total * sizeof(T);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, nw, (T)dt, nsteps, flags, dbg, zmode, logo);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio);
     HIP_TRY(hipGetLastError());
     return ARB_OK;
 }
 
 template <typename T, int MODE>
 static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw,
-                  double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo, hipStream_t st) {
+                  double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
+                  const SplitIO<T> &sio, hipStream_t st) {
 #ifdef ARB_QUICK
     // development build: a single instantiation (float, NMAX=48, one column set, production mode)
     if constexpr (std::is_same<T, float>::value && MODE == 0) {
         if (M->nmax == 48 && M->nsets == 1)
-            return launch_one<T, 48, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, st);
+            return launch_one<T, 48, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
     }
     return ARB_ERR_UNSUPPORTED;
 #else
 #define CASE(NM)                                                                                                     \
     case NM:                                                                                                         \
-        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, st) \
-                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, st);
+        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st) \
+                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
     switch (M->nmax) {
         CASE(16) CASE(32) CASE(48) CASE(64)
         default: return ARB_ERR_UNSUPPORTED;
     }
 #undef CASE
 #endif
+}
+
+// Gauss-Seidel kernel launch (lane = world).  Picks the constraint-count tile NC and the
+// number of worlds per 64-thread block that fits the 160 KB LDS.
+template <typename T, int NC>
+static int launch_gs_nc(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, hipStream_t st) {
+    const int ndol = 4 * nc;
+    const size_t per_world = ((size_t)ndol * ndol + 1 + 16 * nc + 1 + 41) * sizeof(T);
+    int wpb = 64;
+    while (wpb > 16 && per_world * wpb > 160 * 1024) wpb >>= 1;
+    if (per_world * wpb > 160 * 1024) return ARB_ERR_UNSUPPORTED;
+    const size_t lds = per_world * wpb;
+    const unsigned grid = (unsigned)((nw + wpb - 1) / wpb);
+#define GS_LAUNCH(W)                                                                                              \
+    do {                                                                                                          \
+        auto kern = arb_gs_kernel<T, NC, W>;                                                                      \
+        if (lds > 64 * 1024)                                                                                      \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt);     \
+    } while (0)
+    if (wpb == 64) GS_LAUNCH(64); else if (wpb == 32) GS_LAUNCH(32); else GS_LAUNCH(16);
+#undef GS_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return ARB_OK;
+}
+
+template <typename T>
+static int launch_gs(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, hipStream_t st) {
+#ifdef ARB_QUICK
+    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, st);
+    return ARB_ERR_UNSUPPORTED;
+#else
+    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, st);
+    if (nc <= 8) return launch_gs_nc<T, 8>(dm, nc, sio, nw, dt, st);
+    if (nc <= 16) return launch_gs_nc<T, 16>(dm, nc, sio, nw, dt, st);
+    return ARB_ERR_UNSUPPORTED;
+#endif
+}
+
+// Measured on MI355X (tools/split_vs_fused.py, human36): with 4 contacts the split execution
+// overtakes the fused kernel from ~8k worlds per launch (1.3x at 16k-64k); with 8 contacts it never
+// does.  Below that the lane-per-world kernel is a latency chain on too few wavefronts.
+#define ARB_SPLIT_MIN_WORLDS 16384
+#define ARB_SPLIT_MAX_NC 4
+
+template <typename T>
+static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext,
+                      long nw, double dt, int nsteps, unsigned flags, const arb_rollout_log *log, hipStream_t st) {
+    DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
+    LogOut<T> lo; memset(&lo, 0, sizeof(lo));
+    if (log) { lo.q = (T *)log->q_log; lo.dq = (T *)log->dq_log; lo.energy = (T *)log->energy_log; }
+    SplitIO<T> sio; memset(&sio, 0, sizeof(sio));
+    const int nc = M->nc, ndol = M->ndol, n = M->n;
+    const bool can_split = nc > 0 && nc <= 16 && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
+    const bool split = can_split && ((flags & ARB_STEP_SPLIT) || (nw >= ARB_SPLIT_MIN_WORLDS && nc <= ARB_SPLIT_MAX_NC));
+    if (!split)
+        return launch<T, 0>(M, dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, 0, lo, sio, st);
+    // ---- split execution: step kernel (dynamics + system) / Gauss-Seidel kernel (lane = world) ----
+    const size_t per_world = (size_t)ndol * ndol + 3 * (size_t)ndol + 8 * (size_t)nc + (size_t)(1 + ndol) * n;
+    const size_t need = per_world * (size_t)nw * sizeof(T);
+    if (need > M->ws_bytes) {
+        if (M->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(M->ws)); M->ws = nullptr; M->ws_bytes = 0; }
+        HIP_TRY(hipMalloc(&M->ws, need));
+        M->ws_bytes = need;
+    }
+    T *p = (T *)M->ws;
+    sio.A = p; p += (size_t)nw * ndol * ndol;
+    sio.v = p; p += (size_t)nw * ndol;
+    sio.f = p; p += (size_t)nw * ndol;
+    sio.f0 = p; p += (size_t)nw * ndol;
+    sio.c = p; p += (size_t)nw * nc * 8;
+    sio.sol = p;
+    for (int k = 0; k < nsteps; ++k) {
+        LogOut<T> lk = lo;
+        if (lk.q) lk.q += (size_t)k * nw * M->nq;
+        if (lk.dq) lk.dq += (size_t)k * nw * n;
+        if (lk.energy) lk.energy += (size_t)k * nw * 2;
+        sio.mode = 2 | (k > 0 ? 1 : 0);
+        int rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, nw, dt, 1, flags, dbg, 0, lk, sio, st);
+        if (rc != ARB_OK) return rc;
+        rc = launch_gs<T>(dm, nc, sio, nw, dt, st);
+        if (rc != ARB_OK) return rc;
+    }
+    sio.mode = 1;                                      // apply the last step's forces, write cforce
+    LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
+    return launch<T, 0>(M, dm, L, q, dq, cf, ext, nw, dt, 1, flags, dbg, 0, nolog, sio, st);
 }
 
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
@@ -1401,18 +1649,11 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     HIP_TRY(hipSetDevice(M->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == ARB_F32) {
-        DebugOut<float> dbg; memset(&dbg, 0, sizeof(dbg));
-        LogOut<float> lo; memset(&lo, 0, sizeof(lo));
-        if (log) { lo.q = (float *)log->q_log; lo.dq = (float *)log->dq_log; lo.energy = (float *)log->energy_log; }
-        return launch<float, 0>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce, (const float *)ext_gforce,
-                                (long)nworlds, dt, nsteps, flags, dbg, 0, lo, st);
-    }
-    DebugOut<double> dbg; memset(&dbg, 0, sizeof(dbg));
-    LogOut<double> lo; memset(&lo, 0, sizeof(lo));
-    if (log) { lo.q = (double *)log->q_log; lo.dq = (double *)log->dq_log; lo.energy = (double *)log->energy_log; }
-    return launch<double, 0>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce, (const double *)ext_gforce,
-                             (long)nworlds, dt, nsteps, flags, dbg, 0, lo, st);
+    if (dtype == ARB_F32)
+        return step_typed<float>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce,
+                                 (const float *)ext_gforce, (long)nworlds, dt, nsteps, flags, log, st);
+    return step_typed<double>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce,
+                              (const double *)ext_gforce, (long)nworlds, dt, nsteps, flags, log, st);
 }
 
 extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
@@ -1440,7 +1681,8 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
         DebugOut<T> d1; memset(&d1, 0, sizeof(d1));
         d1.Zout = (T *)ps.ptr;
         LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
-        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, d1, ps.zmode, nolog, st);
+        SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
+        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, d1, ps.zmode, nolog, nosplit, st);
         if (rc != ARB_OK) return rc;
     }
     dbg.pose = (T *)o->pose; dbg.twist = (T *)o->twist; dbg.jac = (T *)o->jac; dbg.djac = (T *)o->djac;
@@ -1449,7 +1691,8 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
     dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
     dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.stamps = (long long *)o->stamps; dbg.energy = (T *)o->energy;
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
-    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, nolog, st);
+    SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
+    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, nolog, nosplit, st);
 }
 
 extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,

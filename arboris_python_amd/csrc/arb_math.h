@@ -347,6 +347,13 @@ template <typename T, typename AP>
 ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
     const int n = 6;
 #define E_(i, j) a[(i) * 6 + (j)]
+    // Non-finite input (e.g. the reference's 2/a with a == 0, where numpy.linalg.eigvals
+    // raises LinAlgError) has no eigenvalues to offer: report none instead of iterating on
+    // infinities.  Every data-dependent loop below is also capped.
+    for (int i = 0; i < 36; ++i) {
+        const T x = a[i];
+        if (!(x - x == T(0))) return 0;
+    }
     // --- balance (powers of 2 only, exact) ---
     {
         const T RADIX = T(2), sqrdx = T(4);
@@ -360,9 +367,9 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
                     if (j != i) { c += arb_abs(E_(j, i)); r += arb_abs(E_(i, j)); }
                 if (c != T(0) && r != T(0)) {
                     T g = r / RADIX, f = T(1), s = c + r;
-                    while (c < g) { f *= RADIX; c *= sqrdx; }
+                    for (int cap = 0; c < g && cap < 1100; ++cap) { f *= RADIX; c *= sqrdx; }
                     g = r * RADIX;
-                    while (c > g) { f /= RADIX; c /= sqrdx; }
+                    for (int cap = 0; c > g && cap < 1100; ++cap) { f /= RADIX; c /= sqrdx; }
                     if ((c + r) / f < T(0.95) * s) {
                         last = false;
                         g = T(1) / f;
@@ -404,9 +411,11 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
     int nn = n - 1, found = 0;
     T t = T(0);
     T p = T(0), q = T(0), r = T(0);
+    int total_its = 0;
     while (nn >= 0) {
         int its = 0, l;
         do {
+            if (++total_its > 600) return found;        // hard cap on the whole iteration
             for (l = nn; l >= 1; --l) {
                 T s = arb_abs(E_(l - 1, l - 1)) + arb_abs(E_(l, l));
                 if (s == T(0)) s = anorm;
@@ -697,7 +706,7 @@ ARB_HD bool softfinger_sliding_shift(const T Y[16], const T alpha[4], T mu, cons
 template <typename T, typename AP>
 ARB_HD int softfinger_try(const T v[4], const T Y[16], const T P[16], T f[4], T df[4],
                           T sdist, T dt, T mu, const T eps[3], AP work, T alpha[4], T *shift,
-                          bool use_fast = true) {
+                          bool use_fast = true, const SlidePre *pre = nullptr, double *warm = nullptr) {
     T v0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -724,7 +733,7 @@ ARB_HD int softfinger_try(const T v[4], const T Y[16], const T P[16], T f[4], T 
     }
     // sliding, constraints.py:803-836
     alpha[0] = v0[0]; alpha[1] = v0[1]; alpha[2] = v0[2]; alpha[3] = v0[3] + sdist / dt;
-    return softfinger_sliding_shift<T>(Y, alpha, mu, eps, work, shift, use_fast) ? 2 : 3;
+    return softfinger_sliding_shift<T>(Y, alpha, mu, eps, work, shift, use_fast, pre, warm) ? 2 : 3;
 }
 
 template <typename T, typename AP>

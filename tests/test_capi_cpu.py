@@ -176,6 +176,26 @@ def test_device_eig6_on_host():
 
 
 @needs_lib
+def test_degenerate_sliding_inputs_terminate():
+    """alpha[3] == 0 makes the reference divide by zero (numpy.linalg.eigvals then raises
+    LinAlgError); the device math must neither hang nor crash: non-finite matrices have no
+    eigenvalues and the sliding branch falls back to s = -1e10."""
+    lib = _capi.load()
+    for bad in (np.inf, -np.inf, np.nan):
+        A = np.eye(6); A[2, 3] = bad
+        wr, wi = np.zeros(6), np.zeros(6)
+        assert lib.arb_host_eig6(_capi._dp(np.ascontiguousarray(A)), _capi._dp(wr), _capi._dp(wi)) == 0
+    adm = np.diag([5., 4e-3, 4e-3, 3e-3]); adm[0:3, 3] = adm[3, 0:3] = 1e-4
+    for dtype in (_capi.ARB_F64, _capi.ARB_F32, _capi.ARB_F64 | 0x100):
+        f = np.zeros(4); df = np.zeros(4)
+        # vel[3] + sdist/dt == 0 with zero force: alpha[3] == 0 exactly; tangential velocity forces sliding
+        vel = np.array([0., 1., 0., 1.0])
+        br = lib.arb_host_softfinger_solve(dtype, _capi._dp(vel), _capi._dp(np.ascontiguousarray(adm)), _capi._dp(f),
+                                           -5e-3, 5e-3, 0.6, _capi._dp(np.ones(3)), _capi._dp(df))
+        assert br in (1, 2)
+
+
+@needs_lib
 @pytest.mark.parametrize("tid", range(9))
 def test_device_joint_local_on_host(tid):
     lib = _capi.load()

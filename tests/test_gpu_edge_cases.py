@@ -142,3 +142,62 @@ def test_small_models_use_other_register_tiles():
             torch.cuda.synchronize()
             assert rel(tdq.cpu().numpy(), odq) < tol, (name, dtype)
         bw.close()
+
+
+# ---------------------------------------------------------------------------
+# split execution (default for >= 16384 worlds with <= 4 constraints, forced here): the
+# Gauss-Seidel sweeps run in a second kernel with one lane per world; it must agree with
+# the fused kernel.
+@pytest.mark.parametrize("name,nsteps", [("human36_c4", 6), ("human36_c8", 3)])
+def test_split_execution_equals_fused(name, nsteps):
+    m, _, _ = load_model(name)
+    bw = BatchedWorlds(m)
+    B = 768
+    q, dq = synth.standing_states(m, B, seed=11, drop=0.01, vel=0.3)
+    q[:, 7] -= 0.004                      # feet slightly into the floor: static + sliding contacts
+    dq[::3, 3] += 0.8
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
+        a_q, a_dq = bw.to_device(q, dq, dtype)
+        b_q, b_dq = bw.to_device(q, dq, dtype)
+        ca, cb = bw.new_cforce(B, dtype), bw.new_cforce(B, dtype)
+        la = bw.rollout(a_q, a_dq, 5e-3, nsteps, cforce=ca, split=True)
+        lb = bw.rollout(b_q, b_dq, 5e-3, nsteps, cforce=cb, fused=True)
+        torch.cuda.synchronize()
+        assert rel(a_q.cpu().numpy(), b_q.cpu().numpy()) < tol
+        assert rel(a_dq.cpu().numpy(), b_dq.cpu().numpy()) < tol * 10
+        assert rel(ca.cpu().numpy(), cb.cpu().numpy()) < tol * 100
+        for k in ("q", "dq", "energy"):
+            assert rel(la[k].cpu().numpy(), lb[k].cpu().numpy()) < tol * 10
+        assert float(ca.abs().max()) > 10.                                  # contacts really engaged
+    # and against the oracle for one step
+    oq, odq, ocf = O.step(m, q[:64], dq[:64], 5e-3)
+    s_q, s_dq = bw.to_device(q, dq, torch.float64)
+    cs = bw.new_cforce(B, torch.float64)
+    bw.step(s_q, s_dq, 5e-3, 1, cforce=cs, split=True)
+    torch.cuda.synchronize()
+    assert rel(s_dq.cpu().numpy()[:64], odq) < 1e-8
+    assert rel(cs.cpu().numpy()[:64], ocf) < 1e-6
+    bw.close()
+
+
+def test_split_execution_other_constraint_types():
+    """BallAndSocket (warm-started forces) and JointLimits through the lane-per-world kernel."""
+    for name, dt, nsteps in (("ballsocket", 1e-3, 5), ("jointlimits_max", 1e-3, 60)):
+        m, q0, dq0 = load_model(name)
+        bw = BatchedWorlds(m)
+        B = 512
+        rng = np.random.default_rng(3)
+        q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1))
+        dq += 0.05 * rng.normal(size=dq.shape)
+        a_q, a_dq = bw.to_device(q, dq, torch.float64)
+        b_q, b_dq = bw.to_device(q, dq, torch.float64)
+        ca, cb = bw.new_cforce(B, torch.float64), bw.new_cforce(B, torch.float64)
+        bw.step(a_q, a_dq, dt, nsteps, cforce=ca, split=True)
+        bw.step(b_q, b_dq, dt, nsteps, cforce=cb, fused=True)
+        torch.cuda.synchronize()
+        assert rel(a_q.cpu().numpy(), b_q.cpu().numpy()) < 1e-11
+        assert rel(a_dq.cpu().numpy(), b_dq.cpu().numpy()) < 1e-10
+        assert rel(ca.cpu().numpy(), cb.cpu().numpy()) < 1e-9
+        oq, odq, ocf = O.rollout(m, q[:8], dq[:8], [dt] * nsteps)
+        assert rel(a_q.cpu().numpy()[:8], oq) < 1e-8
+        bw.close()

@@ -299,5 +299,11 @@ def test_batch_oracle_random_4096(bw_cache):
                         dq[sub].astype(np.float32).astype(np.float64), 5e-3)
     assert rel(gq[sub], oq) < F32_TOL
     assert rel(gdq[sub], odq) < F32_TOL
-    gq2, gdq2, _ = gpu_step(bw, q[sub], dq[sub], 5e-3, torch.float32)
-    assert np.array_equal(gq2, gq[sub]) and np.array_equal(gdq2, gdq[sub])
+    # batch-size independence, bitwise
+    tq, tdq = bw.to_device(q, dq, torch.float32)
+    bw.step(tq, tdq, 5e-3, 1, cforce=bw.new_cforce(4096, torch.float32), fused=True)
+    tq2, tdq2 = bw.to_device(q[sub], dq[sub], torch.float32)
+    bw.step(tq2, tdq2, 5e-3, 1, cforce=bw.new_cforce(len(sub), torch.float32), fused=True)
+    torch.cuda.synchronize()
+    assert torch.equal(tq[sub], tq2) and torch.equal(tdq[sub], tdq2)
+    assert rel(tq.cpu().numpy(), gq) < 1e-6 and rel(tdq.cpu().numpy(), gdq) < 1e-5
