@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include <string>
 #include <algorithm>
@@ -39,20 +40,21 @@
 #endif
 #define GS_SWEEPS 20            // core.py:929-931
 
-// per-body block in LDS (elements)
+// per-body block in LDS (elements).  The fields phase B reads are first, 16-byte aligned, so
+// that it can fetch them with 13 vector LDS loads.
 #define BD_RCP 0     // R of Ad_cp (9)
 #define BD_PCP 9     // p of Ad_cp (3)
 #define BD_DA 12     // A block of dAd_cp (9)
-#define BD_DB 21     // B block of dAd_cp (9)
-#define BD_PT 30     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form
-#define BD_PG 36     // M_b g_b (6)
-#define BD_CM 42     // rx wx - wx rx (9), core.py:1287
-#define BD_W 51      // body angular velocity (3)
-#define BD_RG 54     // R of H_gb (9)
-#define BD_PGB 63    // p of H_gb (3)
-#define BD_TW 66     // body twist (6)
-#define BD_AB 72     // bias acceleration dJ_b * gvel (6)
-#define BD_STRIDE 80
+#define BD_DB 21     // B block of dAd_cp (9) (+2 pad)
+#define BD_CM 32     // rx wx - wx rx (9), core.py:1287
+#define BD_W 41      // body angular velocity (3)
+#define BD_PT 44     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form (+2 pad)
+#define BD_PG 52     // M_b g_b (6)
+#define BD_RG 58     // R of H_gb (9)
+#define BD_PGB 67    // p of H_gb (3)
+#define BD_TW 70     // body twist (6)
+#define BD_AB 76     // bias acceleration dJ_b * gvel (6)
+#define BD_STRIDE 84
 
 // per-constraint block in LDS (elements)
 #define CD_R1 0      // transform body1 -> constraint frame: R (9), p (3)
@@ -78,6 +80,8 @@ struct DevModel {
     const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *src, *sslot, *weighted;
     const int *dof2q, *att_start, *att_c, *att_kind;
     const unsigned long long *anc;
+    const int *bi;   // [nb][16] packed per-body ints for the phase-B loop: src, dof_off, jnd, sslot, att_start,
+                     // att_end, anc lo/hi, parent's anc lo/hi (one scalar load per body instead of eight)
     const T *Hpr, *Hcn, *mass, *visc;         // [nb][12], [nb][12], [nb][36], [nb][36]
     const double *Hpr_d, *Hcn_d;              // float64 copies for the pose chain
     const double *clocal_d, *cradius_d, *cHinv_d, *cplane_d, *cb0_d, *cb1_d;
@@ -117,6 +121,7 @@ struct DebugOut {
     T *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next;
     T *energy;          // [nw][2] kinetic, potential energy (EnergyMonitor, observers.py:40-51)
     long long *stamps;  // [nw][8] s_memtime at the phase boundaries (diagnostic)
+    int ablate;         // diagnostic: bit mask of phase-B pieces to skip (timing experiments only, env ARB_ABLATE)
     int *gs_stats;      // [nw][4]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts
 };
 
@@ -177,15 +182,15 @@ __device__ __forceinline__ void mat6_vec(const T *__restrict__ M, const T x[6], 
 
 extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 
-// One workgroup = one wavefront.  LDS instructions of a single wave execute in issue
-// order, so a value written by one lane is visible to any lane's later ds_read without
-// a hardware barrier; what must be prevented is the COMPILER moving LDS accesses across
-// the hand-off points.  A workgroup-scope fence does that (it lowers to s_waitcnt
-// lgkmcnt(0) only, it does not drain outstanding global/scalar loads like
-// __syncthreads() does).
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-                         __builtin_amdgcn_wave_barrier(); \
-                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+// One workgroup = one wavefront.  The DS (LDS) instructions of a wave are executed in issue
+// order, so a value written by one lane is seen by any lane's later ds_read without a
+// hardware barrier and without waiting for the write to retire.  The only thing to prevent is
+// the COMPILER moving LDS accesses across the hand-off points: an empty asm with a memory
+// clobber plus the wave_barrier scheduling fence does that and emits no instruction (a
+// workgroup-scope fence would add s_waitcnt lgkmcnt(0) = a full drain of LDS and scalar loads
+// at every hand-off; __syncthreads() additionally drains global loads and executes s_barrier).
+#define WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); \
+                         asm volatile("" ::: "memory"); } while (0)
 
 // ===========================================================================
 // The step kernel.  MODE 0 = production, 1 = inspect (debug stores, no state
@@ -578,13 +583,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             T Jw[3] = {T(0), T(0), T(0)}, Jv[3] = {T(0), T(0), T(0)};
             T dJw[3] = {T(0), T(0), T(0)}, dJv[3] = {T(0), T(0), T(0)};
             for (int b = 0; b < nb; ++b) {
-                const int src = mp->src[b];
+                const int *brow = mp->bi + 16 * b;
+                const int src = brow[0];
                 if (src == 0) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) { Jw[i] = Jv[i] = dJw[i] = dJv[i] = T(0); }
                 } else if (src >= 2) {
                     // parent's columns were parked in an LDS slot; only its ancestor dofs are non-zero
-                    const unsigned long long pm = mp->anc[mp->parent[b]];
+                    const unsigned long long pm = (unsigned long long)(unsigned)brow[8] | ((unsigned long long)(unsigned)brow[9] << 32);
                     const bool mine = (pm >> lane) & 1ull;
                     const T *sl = SL + (src - 2) * mp->slot_elems + 12 * __popcll(pm & ((1ull << lane) - 1ull));
 #pragma unroll
@@ -594,8 +600,18 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     }
                 }
                 const T *bd = BD + b * BD_STRIDE;
-                const M3<T> R = ld_m3(bd + BD_RCP); const V3<T> p = ld_v3(bd + BD_PCP);
-                const M3<T> dA = ld_m3(bd + BD_DA), dB = ld_m3(bd + BD_DB);
+                typedef T BV4 __attribute__((ext_vector_type(4)));
+                T bf[52];
+                {
+                    const BV4 *b4 = reinterpret_cast<const BV4 *>(bd);     // wave-uniform address: broadcast reads
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) {
+                        const BV4 t4 = b4[i];
+                        bf[4 * i] = t4.x; bf[4 * i + 1] = t4.y; bf[4 * i + 2] = t4.z; bf[4 * i + 3] = t4.w;
+                    }
+                }
+                const M3<T> R = ld_m3(bf + BD_RCP); const V3<T> p = ld_v3(bf + BD_PCP);
+                const M3<T> dA = ld_m3(bf + BD_DA), dB = ld_m3(bf + BD_DB);
                 const V3<T> jw = v3<T>(Jw[0], Jw[1], Jw[2]), jv = v3<T>(Jv[0], Jv[1], Jv[2]);
                 const V3<T> djw = v3<T>(dJw[0], dJw[1], dJw[2]), djv = v3<T>(dJv[0], dJv[1], dJv[2]);
                 // child_jac = Ad_cp J_pg ; child_djac = dAd_cp J_pg + Ad_cp dJ_pg   core.py:1309-1313
@@ -604,8 +620,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 V3<T> tdw = mv(R, djw);
                 V3<T> ndw = mv(dA, jw) + tdw;
                 V3<T> ndv = mv(dB, jw) + mv(dA, jv) + mv(R, djv) + cross(p, tdw);
-                const int d0 = mp->dof_off[b];
-                if (lane >= d0 && lane < d0 + mp->jnd[b]) {
+                const int d0 = brow[1];
+                if (lane >= d0 && lane < d0 + brow[2] && !((MODE == 1 ? dbg.ablate : 0) & 4)) {
                     nw = nw + v3<T>(SC[0 * RS + lane], SC[1 * RS + lane], SC[2 * RS + lane]);
                     nv = nv + v3<T>(SC[3 * RS + lane], SC[4 * RS + lane], SC[5 * RS + lane]);
                     ndw = ndw + v3<T>(SC[6 * RS + lane], SC[7 * RS + lane], SC[8 * RS + lane]);
@@ -613,9 +629,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
                 Jw[0] = nw.x; Jw[1] = nw.y; Jw[2] = nw.z; Jv[0] = nv.x; Jv[1] = nv.y; Jv[2] = nv.z;
                 dJw[0] = ndw.x; dJw[1] = ndw.y; dJw[2] = ndw.z; dJv[0] = ndv.x; dJv[1] = ndv.y; dJv[2] = ndv.z;
-                const int ss = mp->sslot[b];
+                const unsigned long long bmask = (unsigned long long)(unsigned)brow[6] | ((unsigned long long)(unsigned)brow[7] << 32);
+                const int ss = brow[3];
                 if (ss >= 0) {
-                    const unsigned long long bm = mp->anc[b];
+                    const unsigned long long bm = bmask;
                     if ((bm >> lane) & 1ull) {
                         T *sl = SL + ss * mp->slot_elems + 12 * __popcll(bm & ((1ull << lane) - 1ull));
 #pragma unroll
@@ -634,16 +651,20 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                             dbg.djac[((w * nb + b) * 6 + 3 + i) * n + lane] = dJv[i];
                         }
                 }
+                const int abl = (MODE == 1) ? dbg.ablate : 0;
                 // per-column wrenches: U = M_b J, W = M_b dJ + N_b J, V = B_b J   core.py:726-734
                 const T *Mb = mp->mass + 36 * b;
                 T x[6] = {Jw[0], Jw[1], Jw[2], Jv[0], Jv[1], Jv[2]};
                 T dx[6] = {dJw[0], dJw[1], dJw[2], dJv[0], dJv[1], dJv[2]};
                 T U[6], W[6], Q[6];
-                mat6_vec<T>(Mb, x, U);
-                mat6_vec<T>(Mb, dx, W);
+                if (!(abl & 2)) { mat6_vec<T>(Mb, x, U); mat6_vec<T>(Mb, dx, W); }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { U[i] = x[i]; W[i] = dx[i]; }
+                }
                 {
-                    const V3<T> wv = ld_v3(bd + BD_W);
-                    const M3<T> Cm = ld_m3(bd + BD_CM);
+                    const V3<T> wv = ld_v3(bf + BD_W);
+                    const M3<T> Cm = ld_m3(bf + BD_CM);
                     const V3<T> ut = v3<T>(U[0], U[1], U[2]), ub = v3<T>(U[3], U[4], U[5]);
                     const V3<T> top = cross(wv, ut) + mv(Cm, ub);
                     const V3<T> bot = cross(wv, ub);
@@ -666,14 +687,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
                 // rhs of the increment form, and (inspect only) the controllers' gforce J^T M_b g_b
 #pragma unroll
-                for (int i = 0; i < 6; ++i) rhsM += x[i] * bd[BD_PT + i];
+                for (int i = 0; i < 6; ++i) rhsM += x[i] * bf[BD_PT + i];
                 if (MODE == 1) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) rhsG += x[i] * bd[BD_PG + i];
                 }
                 // constraint rows hanging on this body
                 if (do_constraints) {
-                    for (int a = mp->att_start[b]; a < mp->att_start[b + 1]; ++a) {
+                    for (int a = brow[4]; a < brow[5]; ++a) {
                         const int c = mp->att_c[a], kind = mp->att_kind[a];
                         const T *cd = CD + c * CD_STRIDE;
                         const T act = cd[CD_ACTIVE];
@@ -702,13 +723,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 // Columns of non-ancestor dofs are exactly zero, so rows can be taken in groups of
                 // eight without per-row tests: one wave-uniform test per group, then 16 back-to-back
                 // vector LDS reads (wave-uniform addresses) and 48 FMAs.
-                const unsigned long long mask = mp->anc[b];
+                const unsigned long long mask = bmask;
                 typedef T V4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int g = 0; g < NMAX / 8; ++g) {
-                    if ((mask >> (8 * g)) & 0xffull) {
+                for (int g = 0; g < (NMAX + 7) / 8; ++g) {
+                    if (((mask >> (8 * g)) & 0xffull) && !(abl & 1)) {
 #pragma unroll
-                        for (int i = 8 * g; i < 8 * g + 8; ++i) {
+                        for (int i = 8 * g; i < (8 * g + 8 < NMAX ? 8 * g + 8 : NMAX); ++i) {
                             const V4 ja = *reinterpret_cast<const V4 *>(JB + 8 * i);
                             const V4 jc = *reinterpret_cast<const V4 *>(JB + 8 * i + 4);
                             Z[i] += ja.x * Q[0] + ja.y * Q[1] + ja.z * Q[2] + ja.w * Q[3] + jc.x * Q[4] + jc.y * Q[5];
@@ -1299,6 +1320,18 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     UP_I(weighted, std::vector<int>(d->weighted, d->weighted + nb));
     UP_I(dof2q, dof2q); UP_I(att_start, att_start); UP_I(att_c, att_c); UP_I(att_kind, att_kind);
     if ((rc = upload<unsigned long long>(M, anc, &m.anc)) != ARB_OK) return rc;
+    {
+        std::vector<int> bi(16 * (size_t)nb, 0);
+        for (int b = 0; b < nb; ++b) {
+            int *r = bi.data() + 16 * b;
+            const unsigned long long am = anc[b], pm = d->parent[b] >= 0 ? anc[d->parent[b]] : 0ull;
+            r[0] = src[b]; r[1] = d->dof_off[b]; r[2] = jnd[b]; r[3] = sslot[b];
+            r[4] = att_start[b]; r[5] = att_start[b + 1];
+            r[6] = (int)(unsigned)(am & 0xffffffffull); r[7] = (int)(unsigned)(am >> 32);
+            r[8] = (int)(unsigned)(pm & 0xffffffffull); r[9] = (int)(unsigned)(pm >> 32);
+        }
+        UP_I(bi, bi);
+    }
     UP_T(Hpr, conv<T>(h12(d->H_pr, nb).data(), 12 * nb));
     UP_T(Hcn, conv<T>(h12(d->H_cn, nb).data(), 12 * nb));
     if ((rc = upload<double>(M, h12(d->H_pr, nb), &m.Hpr_d)) != ARB_OK) return rc;
@@ -1380,7 +1413,7 @@ extern "C" const char *arb_strerror(int status) {
 
 extern "C" const char *arb_last_hip_error(void) { return g_hip_err.c_str(); }
 
-static const int kNmaxChoices[] = {16, 32, 48, 64};
+static const int kNmaxChoices[] = {16, 32, 44, 48, 64};    // 44: human36 (42 dofs) wastes 2 rows instead of 6
 
 extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model **out) {
     if (d == nullptr || out == nullptr) return ARB_ERR_INVALID;
@@ -1535,8 +1568,8 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #ifdef ARB_QUICK
     // development build: a single instantiation (float, NMAX=48, one column set, production mode)
     if constexpr (std::is_same<T, float>::value && MODE == 0) {
-        if (M->nmax == 48 && M->nsets == 1)
-            return launch_one<T, 48, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
+        if (M->nmax == 44 && M->nsets == 1)
+            return launch_one<T, 44, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
     }
     return ARB_ERR_UNSUPPORTED;
 #else
@@ -1545,7 +1578,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st) \
                                : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
     switch (M->nmax) {
-        CASE(16) CASE(32) CASE(48) CASE(64)
+        CASE(16) CASE(32) CASE(44) CASE(48) CASE(64)
         default: return ARB_ERR_UNSUPPORTED;
     }
 #undef CASE
@@ -1690,6 +1723,7 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
     dbg.c_sdist = (T *)o->c_sdist; dbg.c_active = (int *)o->c_active; dbg.c_jac = (T *)o->c_jac;
     dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
     dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.stamps = (long long *)o->stamps; dbg.energy = (T *)o->energy;
+    { const char *ab = getenv("ARB_ABLATE"); dbg.ablate = ab ? atoi(ab) : 0; }
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
     SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
     return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, nolog, nosplit, st);
