@@ -194,6 +194,17 @@ def main():
                                      "frac": flop_dense * B / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
         "state_finite": finite,
     }
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh,
+    # profiles/): only valid for the workload those passes were taken on
+    prof = os.path.join(ROOT, "profiles", "r01_final_summary.json")
+    if os.path.exists(prof) and args.contacts == 4 and B == 4096 and args.dtype == "f32":
+        try:
+            pm = json.load(open(prof))["pmc_per_launch"]
+            res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
+            res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
+                                               "(profiles/r01_final_summary.json); 4 B/lane accesses, reported uncorrected")
+        except Exception:
+            pass
     if gather_ms is not None:
         res["final_state_allgather_ms"] = gather_ms
     if n_gpus == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,11 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/${1:-pmc2}
+C=${2:-0}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --contacts $C"
+timeout 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/a -- $B > $OUT/a.log 2>&1
+timeout 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC --output-format csv -d $OUT/b -- $B > $OUT/b.log 2>&1
+timeout 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN --output-format csv -d $OUT/c -- $B > $OUT/c.log 2>&1
+tail -1 $OUT/a.log | cut -c1-200; tail -1 $OUT/c.log | cut -c1-200
