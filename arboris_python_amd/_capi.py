@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libarbstep.so")
 
-ARB_ABI_VERSION = 2
+ARB_ABI_VERSION = 3
 ARB_OK = 0
 ARB_F32, ARB_F64 = 0, 1
 ARB_MAXDOL = 4
@@ -34,8 +34,8 @@ class ModelDesc(C.Structure):
         ("gravity", C.c_double * 3),
         ("up", C.c_double * 3),
         ("pd_kp", _PD), ("pd_kd", _PD), ("pd_tau0", _PD),
-        ("ctype", _PI), ("c_enabled", _PI), ("c_body", _PI), ("c_body0", _PI), ("c_dof", _PI),
-        ("c_local", _PD), ("c_radius", _PD), ("c_plane_Hinv", _PD), ("c_plane", _PD),
+        ("ctype", _PI), ("c_enabled", _PI), ("c_body", _PI), ("c_body0", _PI), ("c_geom", _PI), ("c_dof", _PI),
+        ("c_local", _PD), ("c_radius", _PD), ("c_radius0", _PD), ("c_half", _PD), ("c_plane", _PD),
         ("c_mu", _PD), ("c_prox", _PD), ("c_eps", _PD), ("c_min", _PD), ("c_max", _PD),
         ("c_bpose0", _PD), ("c_bpose1", _PD),
     ]
@@ -64,7 +64,7 @@ EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_
             "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_rollout", "arb_inspect"]
 # host-side self-test hooks (device math compiled for the CPU)
 TEST_HOOKS = ["arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_joint_local",
-              "arb_host_exp_twist"]
+              "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
 
 _lib = None
 
@@ -112,6 +112,10 @@ def load():
     lib.arb_host_joint_local.argtypes = [C.c_int, _PD, _PD, _PD]
     lib.arb_host_exp_twist.restype = C.c_int
     lib.arb_host_exp_twist.argtypes = [_PD, _PD]
+    lib.arb_host_zaligned.restype = None
+    lib.arb_host_zaligned.argtypes = [_PD, _PD]
+    lib.arb_host_narrow_phase.restype = C.c_double
+    lib.arb_host_narrow_phase.argtypes = [C.c_int, _PD, _PD, C.c_double, C.c_double, _PD, _PD, _PD, _PD, _PD]
     if lib.arb_abi_version() != ARB_ABI_VERSION:
         raise RuntimeError("libarbstep.so ABI version mismatch")
     _lib = lib
@@ -172,8 +176,9 @@ def make_desc(m):
     if m.nc:
         d.ctype, d.c_enabled = i32(m.ctype), i32(m.c_enabled)
         d.c_body, d.c_body0, d.c_dof = i32(m.c_body), i32(m.c_body0), i32(m.c_dof)
+        d.c_geom = i32(m.c_geom)
         d.c_local, d.c_radius = f64(m.c_local), f64(m.c_radius)
-        d.c_plane_Hinv, d.c_plane = f64(m.c_plane_Hinv), f64(m.c_plane)
+        d.c_radius0, d.c_half, d.c_plane = f64(m.c_radius0), f64(m.c_half), f64(m.c_plane)
         d.c_mu, d.c_prox, d.c_eps = f64(m.c_mu), f64(m.c_prox), f64(m.c_eps)
         d.c_min, d.c_max = f64(m.c_min), f64(m.c_max)
         d.c_bpose0, d.c_bpose1 = f64(m.c_bpose0), f64(m.c_bpose1)

@@ -16,10 +16,10 @@ import numpy as np
 
 from . import _capi
 from .batch import BatchedWorlds
-from .flatten import (flatten_world, JT_FREE, CT_SOFTFINGER_PLANE, CT_JOINTLIMITS,
+from .flatten import (flatten_world, JT_FREE, CT_SOFTFINGER, CT_JOINTLIMITS,
                       CT_BALLSOCKET)
 
-_NDOL = {CT_SOFTFINGER_PLANE: 4, CT_JOINTLIMITS: 1, CT_BALLSOCKET: 3}
+_NDOL = {CT_SOFTFINGER: 4, CT_JOINTLIMITS: 1, CT_BALLSOCKET: 3}
 
 
 def _same_model(a, b):
@@ -129,13 +129,13 @@ class SingleWorldEngine(object):
             nd = _NDOL[ct]
             if not m.c_enabled[c]:
                 continue
-            if ct == CT_SOFTFINGER_PLANE:
+            if ct == CT_SOFTFINGER:
                 con._force = r["c_force"][c, :nd].copy()
                 con._sdist = float(r["c_sdist"][c])
                 con._is_active = bool(r["c_active"][c])
-                pose1 = r["pose"][int(m.c_body[c])]
-                con._frames[0].bpose = r["c_frame"][c, 0]          # plane is on the ground body
-                con._frames[1].bpose = _hinv(pose1) @ r["c_frame"][c, 1]
+                for k, b in enumerate((int(m.c_body0[c]), int(m.c_body[c]))):      # constraints.py:287-288
+                    Hgc = r["c_frame"][c, k]
+                    con._frames[k].bpose = Hgc.copy() if b < 0 else _hinv(r["pose"][b]) @ Hgc
             elif ct == CT_JOINTLIMITS:
                 con._force = r["c_force"][c, :nd].copy()
                 con._pos0 = con._joint.gpos

@@ -84,13 +84,13 @@ struct DevModel {
                      // att_end, anc lo/hi, parent's anc lo/hi (one scalar load per body instead of eight)
     const T *Hpr, *Hcn, *mass, *visc;         // [nb][12], [nb][12], [nb][36], [nb][36]
     const double *Hpr_d, *Hcn_d;              // float64 copies for the pose chain
-    const double *clocal_d, *cradius_d, *cHinv_d, *cplane_d, *cb0_d, *cb1_d;
+    const double *clocal_d, *cradius_d, *cradius0_d, *chalf_d, *cplane_d, *cRz_d, *cb0_d, *cb1_d;
     const double *com_d;                      // [nb][4] centre of mass in the body frame, mass (EnergyMonitor)
     double up[3];
     T grav[3];
     const T *pd_kp, *pd_kd, *pd_tau0;
-    const int *ctype, *cen, *cbody, *cbody0, *cdof;
-    const T *clocal, *cradius, *cHinv, *cplane, *cRz, *cmu, *cprox, *ceps, *cmin, *cmax, *cb0, *cb1;
+    const int *ctype, *cen, *cbody, *cbody0, *cdof, *cgeom;
+    const T *cmu, *cprox, *ceps, *cmin, *cmax, *cb0, *cb1;
 };
 
 // Split execution (contact models, large batches): the step kernel stops after the
@@ -507,37 +507,43 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             bool active = false;
             T sd = T(0);
             if (mp->cen[c]) {
-                if (ct == ARB_CT_SOFTFINGER_PLANE) {
-                    const int b1 = mp->cbody[c];
-                    const T *bd = BD + b1 * BD_STRIDE;
-                    const M3<double> Rg = ld_m3(PD + 12 * b1); const V3<double> pg = ld_v3(PD + 12 * b1 + 9);
-                    const V3<double> p_g1 = mv(Rg, ld_v3(mp->clocal_d + 3 * c)) + pg;
-                    // collisions.py:194-205 (float64: the gap is a difference of O(1) positions)
-                    const M3<double> Ri = ld_m3(mp->cHinv_d + 12 * c); const V3<double> pi = ld_v3(mp->cHinv_d + 12 * c + 9);
-                    const V3<double> p01 = mv(Ri, p_g1) + pi;
-                    const V3<double> nrm = ld_v3(mp->cplane_d + 4 * c);
+                if (ct == ARB_CT_SOFTFINGER) {
+                    // Narrow phase in float64: the gap is a difference of O(1) positions.
+                    const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
+                    M3<double> Rg0 = m3_identity<double>(), Rg1 = Rg0;
+                    V3<double> pg0 = v3<double>(0., 0., 0.), pg1 = pg0;
+                    V3<T> bw0 = v3<T>(T(0), T(0), T(0)), bv0 = bw0, bw1 = bw0, bv1 = bw0;
+                    if (b0 >= 0) {
+                        Rg0 = ld_m3(PD + 12 * b0); pg0 = ld_v3(PD + 12 * b0 + 9);
+                        bw0 = ld_v3(BD + b0 * BD_STRIDE + BD_TW); bv0 = ld_v3(BD + b0 * BD_STRIDE + BD_TW + 3);
+                    }
+                    if (b1 >= 0) {
+                        Rg1 = ld_m3(PD + 12 * b1); pg1 = ld_v3(PD + 12 * b1 + 9);
+                        bw1 = ld_v3(BD + b1 * BD_STRIDE + BD_TW); bv1 = ld_v3(BD + b1 * BD_STRIDE + BD_TW + 3);
+                    }
+                    // pose of shape 0's frame and centre of shape 1 (a Sphere or a Point)
+                    const M3<double> Rs0 = mul(Rg0, ld_m3(mp->cb0_d + 12 * c));
+                    const V3<double> ps0 = mv(Rg0, ld_v3(mp->cb0_d + 12 * c + 9)) + pg0;
+                    const V3<double> p_g1 = mv(Rg1, ld_v3(mp->clocal_d + 3 * c)) + pg1;
                     const double rad = mp->cradius_d[c];
-                    const double csd = dot(nrm, p01) - mp->cplane_d[4 * c + 3];
-                    const double sd_d = csd - rad;
+                    const int geom = mp->cgeom[c];
+                    V3<double> gc0, gc1;
+                    M3<double> Rc;
+                    const double sd_d = narrow_phase(geom, Rs0, ps0, p_g1, rad, mp->cradius0_d[c], ld_v3(mp->chalf_d + 3 * c),
+                                                     ld_v3(mp->cplane_d + 4 * c), mp->cplane_d[4 * c + 3],
+                                                     ld_m3(mp->cRz_d + 9 * c), gc0, gc1, Rc);
                     sd = (T)sd_d;
-                    const double sg = sd_d > 0. ? 1. : (sd_d < 0. ? -1. : 0.);
-                    const V3<double> gc0 = p01 - csd * nrm;
-                    const V3<double> gc1 = p01 - (sg * rad) * nrm;
-                    const M3<double> Rz = ld_m3_as<double>(mp->cRz + 9 * c);
-                    // frame 1 on the body: bpose1 = inv(H_gb) H_gc1       constraints.py:287-288
-                    const M3<T> Rb1 = cvt_m3<T>(mulTA(Rg, Rz));
-                    const V3<T> pb1 = cvt_v3<T>(mtv(Rg, gc1 - pg));
-                    // twist of frame 1 (core.py:1021-1023) and gap rate (constraints.py:289-291)
-                    const V3<T> bw = ld_v3(bd + BD_TW), bv = ld_v3(bd + BD_TW + 3);
-                    const V3<T> pinv1 = -mtv(Rb1, pb1);
-                    const V3<T> w1 = mtv(Rb1, bw);
-                    const V3<T> v1 = cross(pinv1, w1) + mtv(Rb1, bv);
-                    const V3<T> p0c = cvt_v3<T>(mtv(Rz, gc1 - gc0));  // H_c0c1 = [I | p0c]
-                    const T dsd = cross(p0c, w1).z + v1.z;
+                    // body k -> contact frame 0: Ad(inv(H_gc0) H_gbk).  With pose0 = H_gc0 this is both
+                    // Ad(H_01) Ad(inv(bpose1)) and Ad(inv(bpose0)) of constraints.py:429-433.
+                    const M3<T> R1 = cvt_m3<T>(mulTA(Rc, Rg1)), R0 = cvt_m3<T>(mulTA(Rc, Rg0));
+                    const V3<T> P1 = cvt_v3<T>(mtv(Rc, pg1 - gc0)), P0 = cvt_v3<T>(mtv(Rc, pg0 - gc0));
+                    // gap rate: z velocity of body 1 minus that of body 0 at frame 0   constraints.py:289-291
+                    const T vz1 = (mv(R1, bv1) + cross(P1, mv(R1, bw1))).z;
+                    const T vz0 = (mv(R0, bv0) + cross(P0, mv(R0, bw0))).z;
+                    const T dsd = vz1 - vz0;
                     active = ((double)sd_d + (double)dsd * (double)dt < (double)mp->cprox[c]);
-                    // body -> contact frame 0:  Ad(H_01) Ad(inv(bpose1)) = Ad(inv(H_gc0) H_gb)
-                    st_m3(cd + CD_R1, cvt_m3<T>(mulTA(Rz, Rg)));
-                    st_v3(cd + CD_P1, cvt_v3<T>(mtv(Rz, pg - gc0)));
+                    st_m3(cd + CD_R1, R1); st_v3(cd + CD_P1, P1);
+                    st_m3(cd + CD_R0, R0); st_v3(cd + CD_P0, P0);
                     st_v3(cd + CD_GC0, cvt_v3<T>(gc0)); st_v3(cd + CD_GC1, cvt_v3<T>(gc1));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
@@ -698,15 +704,16 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         const int c = mp->att_c[a], kind = mp->att_kind[a];
                         const T *cd = CD + c * CD_STRIDE;
                         const T act = cd[CD_ACTIVE];
-                        const M3<T> Rx = ld_m3(cd + (kind == 2 ? CD_R0 : CD_R1));
-                        const V3<T> px = ld_v3(cd + (kind == 2 ? CD_P0 : CD_P1));
+                        const M3<T> Rx = ld_m3(cd + (kind >= 2 ? CD_R0 : CD_R1));
+                        const V3<T> px = ld_v3(cd + (kind >= 2 ? CD_P0 : CD_P1));
                         const V3<T> cw = mv(Rx, nw);
                         const V3<T> cv = mv(Rx, nv) + cross(px, cw);
                         T *row = RT + (1 + 4 * c) * RS + (lane < RS ? lane : 0);
                         if (lane >= RS) continue;
-                        if (kind == 0) {            // SoftFinger rows (w_z, v_x, v_y, v_z)  constraints.py:429-433
-                            row[0] += act * cw.z; row[RS] += act * cv.x;
-                            row[2 * RS] += act * cv.y; row[3 * RS] += act * cv.z;
+                        if (kind == 0 || kind == 3) {   // SoftFinger rows (w_z, v_x, v_y, v_z), +body1 / -body0
+                            const T sgn = (kind == 0) ? act : -act;                     // constraints.py:429-433
+                            row[0] += sgn * cw.z; row[RS] += sgn * cv.x;
+                            row[2 * RS] += sgn * cv.y; row[3 * RS] += sgn * cv.z;
                         } else {                    // BallAndSocket linear rows, +frame1 / -frame0  constraints.py:203-207
                             const T sgn = (kind == 1) ? act : -act;
                             row[0] += sgn * cv.x; row[RS] += sgn * cv.y; row[2 * RS] += sgn * cv.z;
@@ -775,11 +782,18 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const T *cd = CD + lane * CD_STRIDE;
                 if (dbg.c_sdist != nullptr) dbg.c_sdist[w * nc + lane] = do_constraints ? cd[CD_SDIST] : T(0);
                 if (dbg.c_active != nullptr) dbg.c_active[w * nc + lane] = (do_constraints && cd[CD_ACTIVE] != T(0)) ? 1 : 0;
-                if (dbg.c_frame != nullptr && do_constraints && mp->ctype[lane] == ARB_CT_SOFTFINGER_PLANE) {
+                if (dbg.c_frame != nullptr && do_constraints && mp->ctype[lane] == ARB_CT_SOFTFINGER) {
                     for (int f = 0; f < 2; ++f) {
                         T *o = dbg.c_frame + ((w * nc + lane) * 2 + f) * 16;
+                        // rotation of both frames: Rc = R_g1 R1^T (R1 = Rc^T R_g1; ground: R1 = Rc^T)
+                        const int b1 = mp->cbody[lane];
                         for (int i = 0; i < 3; ++i) {
-                            for (int j = 0; j < 3; ++j) o[4 * i + j] = mp->cRz[9 * lane + 3 * i + j];
+                            for (int j = 0; j < 3; ++j) {
+                                double acc = 0.;
+                                for (int k = 0; k < 3; ++k)
+                                    acc += (b1 >= 0 ? PD[12 * b1 + 3 * i + k] : (i == k ? 1. : 0.)) * (double)cd[CD_R1 + 3 * j + k];
+                                o[4 * i + j] = (T)acc;
+                            }
                             o[4 * i + 3] = cd[(f ? CD_GC1 : CD_GC0) + i];
                         }
                         o[12] = o[13] = o[14] = T(0); o[15] = T(1);
@@ -909,7 +923,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // inverse of every active constraint's own admittance block (once per step)
             if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
                 const int c = lane, ct = mp->ctype[c];
-                const int nd = (ct == ARB_CT_SOFTFINGER_PLANE) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 T P[16];
                 inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
 #pragma unroll
@@ -947,7 +961,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
                 k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
                 k_min = mp->cmin[lane]; k_max = mp->cmax[lane];
-                if (k_act && k_ct == ARB_CT_SOFTFINGER_PLANE) {
+                if (k_act && k_ct == ARB_CT_SOFTFINGER) {
                     // admittance-only part of the sliding-branch polynomial, once per step
                     T Yc4[16];
 #pragma unroll
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     for (int i = 0; i < 4; ++i) { vc[i] = bcast(vr, base + i); fc[i] = bcast(fr, base + i); }
                     // own-row products (meaningful on lanes base..base+3)
                     const T v0r = vr - (Yrow[0] * fc[0] + Yrow[1] * fc[1] + Yrow[2] * fc[2] + Yrow[3] * fc[3]);
-                    if (ct == ARB_CT_SOFTFINGER_PLANE) {                   // constraints.py:780-836
+                    if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
                         const T sd = bcast(k_sd, c), mu = bcast(k_mu, c);
                         const T v0n = bcast(v0r, base + 3);
                         if (sd + dt * v0n > T(0)) {                        // release
@@ -1142,7 +1156,7 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
                 c_sd[c] = cs[1]; c_p0[c] = cs[2]; c_p1[c] = cs[3]; c_p2[c] = cs[4];
                 if (c_act[c]) {
                     const int ct = mp->ctype[c];
-                    const int nd = (ct == ARB_CT_SOFTFINGER_PLANE) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                    const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                     T P[16];
                     inv_block<T>(Arow + (4 * c) * ndol + 4 * c, ndol, nd, P);
 #pragma unroll
@@ -1164,7 +1178,7 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { Y[4 * i + j] = Arow[(4 * c + i) * ndol + 4 * c + j]; P[4 * i + j] = Prow[16 * c + 4 * i + j]; }
             }
-            if (ct == ARB_CT_SOFTFINGER_PLANE) {                   // constraints.py:780-836
+            if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
                 const T eps[3] = {mp->ceps[3 * c], mp->ceps[3 * c + 1], mp->ceps[3 * c + 2]};
                 T alpha[4], shift = T(0);
                 int br = softfinger_try<T>(v4, Y, P, f4, df, c_sd[c], dt, mp->cmu[c], eps, work, alpha, &shift,
@@ -1283,7 +1297,7 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot
     return L;
 }
 
-// zaligned(normal), arboris/homogeneousmatrix.py:201-232 (constant per contact plane)
+// zaligned(normal), arboris/homogeneousmatrix.py:201-232 (constant for a contact plane)
 static void zaligned_host(const double z[3], double R[9]) {
     int idx[3] = {0, 1, 2};
     double a[3] = {std::fabs(z[0]), std::fabs(z[1]), std::fabs(z[2])};
@@ -1338,7 +1352,8 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     if ((rc = upload<double>(M, h12(d->H_cn, nb), &m.Hcn_d)) != ARB_OK) return rc;
     if ((rc = upload<double>(M, conv<double>(d->c_local, 3 * nc), &m.clocal_d)) != ARB_OK) return rc;
     if ((rc = upload<double>(M, conv<double>(d->c_radius, nc), &m.cradius_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, h12(d->c_plane_Hinv, nc), &m.cHinv_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, conv<double>(d->c_radius0, nc), &m.cradius0_d)) != ARB_OK) return rc;
+    if ((rc = upload<double>(M, conv<double>(d->c_half, 3 * nc), &m.chalf_d)) != ARB_OK) return rc;
     if ((rc = upload<double>(M, conv<double>(d->c_plane, 4 * nc), &m.cplane_d)) != ARB_OK) return rc;
     if ((rc = upload<double>(M, h12(d->c_bpose0, nc), &m.cb0_d)) != ARB_OK) return rc;
     if ((rc = upload<double>(M, h12(d->c_bpose1, nc), &m.cb1_d)) != ARB_OK) return rc;
@@ -1374,17 +1389,15 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     UP_I(cbody, std::vector<int>(d->c_body, d->c_body + nc));
     UP_I(cbody0, std::vector<int>(d->c_body0, d->c_body0 + nc));
     UP_I(cdof, std::vector<int>(d->c_dof, d->c_dof + nc));
-    UP_T(clocal, conv<T>(d->c_local, 3 * nc));
-    UP_T(cradius, conv<T>(d->c_radius, nc));
-    UP_T(cHinv, conv<T>(h12(d->c_plane_Hinv, nc).data(), 12 * nc));
-    UP_T(cplane, conv<T>(d->c_plane, 4 * nc));
+    UP_I(cgeom, std::vector<int>(d->c_geom, d->c_geom + nc));
     std::vector<double> rz(9 * (size_t)nc, 0.0);
     m.has_warm = 0;
     for (int c = 0; c < nc; ++c) {
-        if (ctype[c] == ARB_CT_SOFTFINGER_PLANE) zaligned_host(d->c_plane + 4 * c, rz.data() + 9 * c);
+        if (ctype[c] == ARB_CT_SOFTFINGER && d->c_geom[c] == ARB_CG_PLANE_SPHERE)
+            zaligned_host(d->c_plane + 4 * c, rz.data() + 9 * c);
         if (ctype[c] == ARB_CT_BALLSOCKET) m.has_warm = 1;
     }
-    UP_T(cRz, conv<T>(rz.data(), 9 * nc));
+    if ((rc = upload<double>(M, rz, &m.cRz_d)) != ARB_OK) return rc;
     UP_T(cmu, conv<T>(d->c_mu, nc));
     UP_T(cprox, conv<T>(d->c_prox, nc));
     UP_T(ceps, conv<T>(d->c_eps, 3 * nc));
@@ -1396,6 +1409,29 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
 #undef UP_T
     *out = m;
     return ARB_OK;
+}
+
+// test hooks: host builds of the device narrow phase (same source as the kernel)
+extern "C" void arb_host_zaligned(const double z[3], double R[9]) {
+    const M3<double> m = zaligned_rot(v3<double>(z[0], z[1], z[2]));
+    for (int i = 0; i < 9; ++i) R[i] = m.a[i];
+}
+
+extern "C" double arb_host_narrow_phase(int geom, const double H_s0[16], const double p_g1[3], double rad,
+                                        double r0, const double half[3], const double plane[4],
+                                        double gc0[3], double gc1[3], double Rc[9]) {
+    M3<double> Rs0, Rz, R;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rs0.a[3 * i + j] = H_s0[4 * i + j];
+    double rz[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (geom == ARB_CG_PLANE_SPHERE) zaligned_host(plane, rz);
+    for (int i = 0; i < 9; ++i) Rz.a[i] = rz[i];
+    V3<double> a, b;
+    const double sd = narrow_phase(geom, Rs0, v3<double>(H_s0[3], H_s0[7], H_s0[11]), v3<double>(p_g1[0], p_g1[1], p_g1[2]),
+                                   rad, r0, v3<double>(half[0], half[1], half[2]),
+                                   v3<double>(plane[0], plane[1], plane[2]), plane[3], Rz, a, b, R);
+    gc0[0] = a.x; gc0[1] = a.y; gc0[2] = a.z; gc1[0] = b.x; gc1[1] = b.y; gc1[2] = b.z;
+    for (int i = 0; i < 9; ++i) Rc[i] = R.a[i];
+    return sd;
 }
 
 extern "C" int arb_abi_version(void) { return ARB_ABI_VERSION; }
@@ -1425,7 +1461,7 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         !d->visc || !d->weighted)
         return ARB_ERR_INVALID;
     if (nc > 0 && (!d->ctype || !d->c_enabled || !d->c_body || !d->c_body0 || !d->c_dof || !d->c_local ||
-                   !d->c_radius || !d->c_plane_Hinv || !d->c_plane || !d->c_mu || !d->c_prox || !d->c_eps ||
+                   !d->c_radius || !d->c_geom || !d->c_radius0 || !d->c_half || !d->c_plane || !d->c_mu || !d->c_prox || !d->c_eps ||
                    !d->c_min || !d->c_max || !d->c_bpose0 || !d->c_bpose1))
         return ARB_ERR_INVALID;
     if (n > WAVE || nb > WAVE || nc > WAVE) return ARB_ERR_UNSUPPORTED;   // one world per wavefront
@@ -1480,9 +1516,11 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     std::vector<std::vector<std::pair<int, int>>> per_body(nb);
     for (int c = 0; c < nc; ++c) {
         const int ct = d->ctype[c];
-        if (ct == ARB_CT_SOFTFINGER_PLANE) {
-            if (d->c_body[c] < 0 || d->c_body[c] >= nb) return ARB_ERR_INVALID;
-            per_body[d->c_body[c]].push_back({c, 0});
+        if (ct == ARB_CT_SOFTFINGER) {
+            if (d->c_body[c] >= nb || d->c_body0[c] >= nb) return ARB_ERR_INVALID;
+            if (d->c_geom[c] < ARB_CG_PLANE_SPHERE || d->c_geom[c] > ARB_CG_BOX_SPHERE) return ARB_ERR_INVALID;
+            if (d->c_body[c] >= 0) per_body[d->c_body[c]].push_back({c, 0});
+            if (d->c_body0[c] >= 0) per_body[d->c_body0[c]].push_back({c, 3});
         } else if (ct == ARB_CT_BALLSOCKET) {
             if (d->c_body[c] >= nb || d->c_body0[c] >= nb) return ARB_ERR_INVALID;
             if (d->c_body[c] >= 0) per_body[d->c_body[c]].push_back({c, 1});

@@ -72,6 +72,87 @@ template <typename T> ARB_HD V3<T> mtv(const M3<T> &A, V3<T> v) {               
                  A.a[1] * v.x + A.a[4] * v.y + A.a[7] * v.z,
                  A.a[2] * v.x + A.a[5] * v.y + A.a[8] * v.z);
 }
+// zaligned(vec), arboris/homogeneousmatrix.py:201-232: rotation whose third column is z and whose
+// first column zeroes the smallest |z_i| (stable argsort, as numpy's for three elements).
+ARB_HD M3<double> zaligned_rot(V3<double> z) {
+    const double a0 = fabs(z.x), a1 = fabs(z.y), a2 = fabs(z.z);
+    int i1, i2;                                   // middle and largest component
+    if (a0 <= a1) {
+        if (a1 <= a2) { i1 = 1; i2 = 2; } else if (a0 <= a2) { i1 = 2; i2 = 1; } else { i1 = 0; i2 = 1; }
+    } else {
+        if (a0 <= a2) { i1 = 0; i2 = 2; } else if (a1 <= a2) { i1 = 2; i2 = 0; } else { i1 = 1; i2 = 0; }
+    }
+    const double z1 = i1 == 0 ? z.x : (i1 == 1 ? z.y : z.z);
+    const double z2 = i2 == 0 ? z.x : (i2 == 1 ? z.y : z.z);
+    V3<double> x;                                 // x[i0] = 0, x[i1] = z[i2], x[i2] = -z[i1]
+    x.x = i1 == 0 ? z2 : (i2 == 0 ? -z1 : 0.);
+    x.y = i1 == 1 ? z2 : (i2 == 1 ? -z1 : 0.);
+    x.z = i1 == 2 ? z2 : (i2 == 2 ? -z1 : 0.);
+    x = (1. / sqrt(dot(x, x))) * x;
+    const V3<double> y = cross(z, x);
+    M3<double> R;
+    R.a[0] = x.x; R.a[1] = y.x; R.a[2] = z.x;
+    R.a[3] = x.y; R.a[4] = y.y; R.a[5] = z.y;
+    R.a[6] = x.z; R.a[7] = y.z; R.a[8] = z.z;
+    return R;
+}
+
+// Narrow phase of a SoftFingerContact, arboris/collisions.py:67-299, in float64.  (Rs0, ps0): pose of
+// shape 0's frame; p_g1: centre of shape 1 (Sphere/Point of radius `rad`).  Outputs the signed
+// distance, the origins of the two contact frames and their common rotation.
+ARB_HD double narrow_phase(int geom, const M3<double> &Rs0, V3<double> ps0, V3<double> p_g1, double rad,
+                           double r0, V3<double> he, V3<double> pn, double pd, const M3<double> &Rz,
+                           V3<double> &gc0, V3<double> &gc1, M3<double> &Rc) {
+    double sd;
+    if (geom == 0) {                                        // plane / sphere      collisions.py:194-205
+        // (the reference leaves both contact frames in the PLANE's coordinates)
+        const V3<double> p01 = mtv(Rs0, p_g1 - ps0);
+        const double csd = dot(pn, p01) - pd;
+        sd = csd - rad;
+        const double sg = sd > 0. ? 1. : (sd < 0. ? -1. : 0.);
+        gc0 = p01 - csd * pn;
+        gc1 = p01 - (sg * rad) * pn;
+        Rc = Rz;
+    } else if (geom == 1) {                                 // sphere / sphere     collisions.py:149-159
+        const V3<double> vec = p_g1 - ps0;
+        const double len = sqrt(dot(vec, vec));
+        sd = len - r0 - rad;
+        const V3<double> z = v3<double>(vec.x / len, vec.y / len, vec.z / len);
+        Rc = zaligned_rot(z);
+        gc0 = ps0 + r0 * z;
+        gc1 = gc0 + sd * z;
+    } else {                                                // box / sphere        collisions.py:268-299
+        const V3<double> p01 = mtv(Rs0, p_g1 - ps0);
+        V3<double> f0, nrm;
+        if (fabs(p01.x) <= he.x && fabs(p01.y) <= he.y && fabs(p01.z) <= he.z) {
+            // centre inside the box: nearest face = first minimum of [he - p, he + p]; the normal
+            // stays in box coordinates, as in the reference
+            const double g[6] = {he.x - p01.x, he.y - p01.y, he.z - p01.z, he.x + p01.x, he.y + p01.y, he.z + p01.z};
+            int im = 0;
+            double gm = g[0];
+            for (int i = 1; i < 6; ++i) if (g[i] < gm) { gm = g[i]; im = i; }
+            f0 = p01;
+            nrm = v3<double>(0., 0., 0.);
+            if (im == 0) { f0.x = he.x; nrm.x = 1.; } else if (im == 1) { f0.y = he.y; nrm.y = 1.; }
+            else if (im == 2) { f0.z = he.z; nrm.z = 1.; } else if (im == 3) { f0.x = -he.x; nrm.x = -1.; }
+            else if (im == 4) { f0.y = -he.y; nrm.y = -1.; } else { f0.z = -he.z; nrm.z = -1.; }
+            gc0 = mv(Rs0, f0) + ps0;
+            const V3<double> dv = gc0 - p_g1;
+            sd = -sqrt(dot(dv, dv)) - rad;
+        } else {
+            f0 = v3<double>(fmax(fmin(he.x, p01.x), -he.x), fmax(fmin(he.y, p01.y), -he.y), fmax(fmin(he.z, p01.z), -he.z));
+            gc0 = mv(Rs0, f0) + ps0;
+            const V3<double> vec = p_g1 - gc0;
+            const double len = sqrt(dot(vec, vec));
+            nrm = v3<double>(vec.x / len, vec.y / len, vec.z / len);
+            sd = len - rad;
+        }
+        Rc = zaligned_rot(nrm);
+        gc1 = p_g1 - rad * nrm;
+    }
+    return sd;
+}
+
 template <typename T> ARB_HD M3<T> hat(V3<T> p) {                                  // p^
     M3<T> r;
     r.a[0] = T(0); r.a[1] = -p.z; r.a[2] = p.y;

@@ -33,7 +33,10 @@ JOINT_TYPES = {
 }
 
 # constraint type ids (enum arb_constraint_type)
-CT_SOFTFINGER_PLANE, CT_JOINTLIMITS, CT_BALLSOCKET = range(3)
+CT_SOFTFINGER, CT_JOINTLIMITS, CT_BALLSOCKET = range(3)
+CT_SOFTFINGER_PLANE = CT_SOFTFINGER      # historical name
+# narrow-phase geometry of a SoftFingerContact (collisions.py): shape 0 / shape 1
+CG_PLANE_SPHERE, CG_SPHERE_SPHERE, CG_BOX_SPHERE = range(3)
 
 
 class UnsupportedModelError(NotImplementedError):
@@ -90,11 +93,14 @@ class FlatModel(object):
         # constraints, registration order
         self.ctype = np.zeros(0, np.int32)
         self.c_names = []
-        # SoftFingerContact on (Plane-on-ground, Point/Sphere-on-body)
+        # SoftFingerContact: shape 0 (Plane | Sphere | Box) on body0 at bpose0, shape 1
+        # (Sphere | Point) on body at c_local; bodies are -1 for the ground
+        self.c_geom = np.zeros(0, np.int32)
         self.c_body = np.zeros(0, np.int32)
         self.c_local = np.zeros((0, 3))
         self.c_radius = np.zeros(0)
-        self.c_plane_Hinv = np.zeros((0, 4, 4))
+        self.c_radius0 = np.zeros(0)
+        self.c_half = np.zeros((0, 3))
         self.c_plane = np.zeros((0, 4))
         self.c_mu = np.zeros(0)
         self.c_prox = np.zeros(0)
@@ -278,7 +284,7 @@ def flatten_world(world, positions=True):
         m.pd_mask = pdmask
 
     # ---- constraints -----------------------------------------------------
-    ctype, c_body, c_local, c_radius, c_plane_Hinv, c_plane = [], [], [], [], [], []
+    ctype, c_geom, c_body, c_local, c_radius, c_radius0, c_half, c_plane = [], [], [], [], [], [], [], []
     c_mu, c_prox, c_eps, c_enabled = [], [], [], []
     c_dof, c_min, c_max = [], [], []
     c_body0, c_bpose0, c_bpose1 = [], [], []
@@ -288,36 +294,43 @@ def flatten_world(world, positions=True):
         m.c_names.append(getattr(c, "name", None))
         c_enabled.append(1 if c.is_enabled() else 0)
 
+    def _defaults(skip=()):
+        for lst, val in ((c_geom, 0), (c_body, -1), (c_local, np.zeros(3)), (c_radius, 0.), (c_radius0, 0.),
+                         (c_half, np.zeros(3)), (c_plane, np.zeros(4)), (c_mu, 0.), (c_prox, 0.),
+                         (c_eps, np.ones(3)), (c_dof, -1), (c_min, 0.), (c_max, 0.), (c_body0, -1),
+                         (c_bpose0, I4), (c_bpose1, I4)):
+            if not any(lst is x for x in skip):
+                lst.append(val)
+
     for c in getattr(world, "_constraints", []):
         tname = type(c).__name__
         if tname == "SoftFingerContact":
             s0, s1 = c._shapes
             n0, n1 = type(s0).__name__, type(s1).__name__
-            if not (n0 == "Plane" and n1 in ("Point", "Sphere")):
+            geom = {"Plane": CG_PLANE_SPHERE, "Sphere": CG_SPHERE_SPHERE, "Box": CG_BOX_SPHERE}.get(n0)
+            if geom is None or n1 not in ("Point", "Sphere"):
                 raise UnsupportedModelError(
-                    "SoftFingerContact between %s and %s is not lowered yet "
-                    "(only Plane-Point / Plane-Sphere)" % (n0, n1))
-            if index_of.get(id(s0.frame.body), None) != -1:
-                raise UnsupportedModelError(
-                    "contact plane must be attached to the ground body")
+                    "SoftFingerContact between %s and %s cannot be lowered (shape 0 must be a Plane, "
+                    "Sphere or Box, shape 1 a Sphere or Point)" % (n0, n1))
+            b0 = index_of.get(id(s0.frame.body), None)
             b1 = index_of.get(id(s1.frame.body), None)
-            if b1 is None or b1 < 0:
-                raise UnsupportedModelError("contact point must be on a moving body")
-            Hg0 = _bpose(s0.frame)
-            Hinv = np.eye(4)
-            Hinv[0:3, 0:3] = Hg0[0:3, 0:3].T
-            Hinv[0:3, 3] = -Hg0[0:3, 0:3].T @ Hg0[0:3, 3]
-            ctype.append(CT_SOFTFINGER_PLANE)
+            if b0 is None or b1 is None:
+                raise UnsupportedModelError("contact shape on a body that is not in the world tree")
+            ctype.append(CT_SOFTFINGER)
+            c_geom.append(geom)
+            c_body0.append(b0)
+            c_bpose0.append(_bpose(s0.frame))
             c_body.append(b1)
             c_local.append(_bpose(s1.frame)[0:3, 3])
             c_radius.append(float(getattr(s1, "radius", 0.)))
-            c_plane_Hinv.append(Hinv)
-            c_plane.append(np.array(s0.coeffs, float))
+            c_radius0.append(float(s0.radius) if geom == CG_SPHERE_SPHERE else 0.)
+            c_half.append(np.array(s0.half_extents, float) if geom == CG_BOX_SPHERE else np.zeros(3))
+            c_plane.append(np.array(s0.coeffs, float) if geom == CG_PLANE_SPHERE else np.zeros(4))
             c_mu.append(float(c._mu))
             c_prox.append(float(c._proximity))
             c_eps.append(np.array(c._eps, float))
-            c_dof.append(-1); c_min.append(0.); c_max.append(0.)
-            c_body0.append(-1); c_bpose0.append(I4); c_bpose1.append(I4)
+            _defaults(skip=(c_geom, c_body0, c_bpose0, c_body, c_local, c_radius, c_radius0, c_half, c_plane,
+                            c_mu, c_prox, c_eps))
             _pad_common(c)
         elif tname == "JointLimits":
             j = c._joint
@@ -330,10 +343,7 @@ def flatten_world(world, positions=True):
             c_min.append(float(np.asarray(c._min).ravel()[0]))
             c_max.append(float(np.asarray(c._max).ravel()[0]))
             c_prox.append(float(np.asarray(c._proximity).ravel()[0]))
-            c_body.append(-1); c_local.append(np.zeros(3)); c_radius.append(0.)
-            c_plane_Hinv.append(I4); c_plane.append(np.zeros(4))
-            c_mu.append(0.); c_eps.append(np.ones(3))
-            c_body0.append(-1); c_bpose0.append(I4); c_bpose1.append(I4)
+            _defaults(skip=(c_dof, c_min, c_max, c_prox))
             _pad_common(c)
         elif tname == "BallAndSocketConstraint":
             f0, f1 = c._frames
@@ -342,10 +352,7 @@ def flatten_world(world, positions=True):
             c_body.append(index_of[id(f1.body)])
             c_bpose0.append(_bpose(f0))
             c_bpose1.append(_bpose(f1))
-            c_local.append(np.zeros(3)); c_radius.append(0.)
-            c_plane_Hinv.append(I4); c_plane.append(np.zeros(4))
-            c_mu.append(0.); c_prox.append(0.); c_eps.append(np.ones(3))
-            c_dof.append(-1); c_min.append(0.); c_max.append(0.)
+            _defaults(skip=(c_body0, c_body, c_bpose0, c_bpose1))
             _pad_common(c)
         else:
             raise UnsupportedModelError(
@@ -353,10 +360,12 @@ def flatten_world(world, positions=True):
                 % (getattr(c, "name", None), tname))
     nc = len(ctype)
     m.ctype = np.array(ctype, np.int32)
+    m.c_geom = np.array(c_geom, np.int32)
     m.c_body = np.array(c_body, np.int32)
     m.c_local = np.array(c_local, float).reshape(nc, 3)
     m.c_radius = np.array(c_radius, float)
-    m.c_plane_Hinv = np.array(c_plane_Hinv, float).reshape(nc, 4, 4)
+    m.c_radius0 = np.array(c_radius0, float)
+    m.c_half = np.array(c_half, float).reshape(nc, 3)
     m.c_plane = np.array(c_plane, float).reshape(nc, 4)
     m.c_mu = np.array(c_mu, float)
     m.c_prox = np.array(c_prox, float)

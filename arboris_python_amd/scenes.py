@@ -58,3 +58,82 @@ def human36_world(contacts=0, gravity=True, friction_coeff=0.6):
 def flat(world):
     """FlatModel of an initialised world."""
     return flatten_world(world)[0]
+
+
+class _NS(object):
+    pass
+
+
+def _own_namespace():
+    from . import core, shapes, joints, massmatrix, homogeneousmatrix
+    from .robots.simpleshapes import add_sphere
+    W = _NS()
+    W.World, W.Body, W.SubFrame, W.Hg = core.World, core.Body, core.SubFrame, homogeneousmatrix
+    W.Box, W.Sphere, W.Point = shapes.Box, shapes.Sphere, shapes.Point
+    W.add_sphere, W.add_groundplane = add_sphere, add_groundplane
+    W.WeightController, W.get_all_contacts, W.FreeJoint = WeightController, get_all_contacts, joints.FreeJoint
+    W.massmatrix = massmatrix
+    return W
+
+
+def shape_scenes(W=None):
+    """Four small scenes, one per remaining narrow-phase pair (collisions.py:27-64), built from
+    the class namespace `W`: this package by default, the reference's classes when
+    tools/gen_golden.py records tests/golden/g7_shapes.npz."""
+    if W is None:
+        W = _own_namespace()
+    out = {}
+    # (1) ball rolling on the ground plane: Plane / Sphere with a non-zero radius
+    w = W.World()
+    W.add_groundplane(w)
+    W.add_sphere(w, radius=0.3, mass=2., name="ball")
+    j = w.ground.childrenjoints[0]
+    j.gpos = W.Hg.transl(0., 0.31, 0.)
+    j.gvel = np.array([0., 0., -2., 1., 0., 0.2])
+    w.register(W.WeightController())
+    for c in W.get_all_contacts(w, friction_coeff=0.5):
+        w.register(c)
+    w.init()
+    out["plane_ball"] = w
+    # (2) ball dropped on the edge region of a box fixed to the ground: Box / Sphere
+    w = W.World()
+    f = W.SubFrame(w.ground, W.Hg.transl(0., 0.2, 0.), "box frame")
+    w.register(W.Box(f, (0.5, 0.2, 0.5), "box"))
+    W.add_sphere(w, radius=0.1, mass=1., name="ball")
+    j = w.ground.childrenjoints[0]
+    j.gpos = W.Hg.transl(0.47, 0.51, 0.1)
+    j.gvel = np.array([0.3, 0., 0., 0.4, -0.5, 0.])
+    w.register(W.WeightController())
+    for c in W.get_all_contacts(w, friction_coeff=0.4):
+        w.register(c)
+    w.init()
+    out["box_ball"] = w
+    # (3) two free balls colliding, no gravity: Sphere / Sphere, both bodies moving
+    w = W.World()
+    W.add_sphere(w, radius=0.2, mass=1., name="a")
+    W.add_sphere(w, radius=0.3, mass=3., name="b")
+    ja, jb = w.ground.childrenjoints
+    ja.gpos = W.Hg.transl(0., 0., 0.)
+    ja.gvel = np.array([0., 0.5, 0., 2., 0., 0.])
+    jb.gpos = W.Hg.transl(0.56, 0.12, 0.03)
+    jb.gvel = np.array([0., 0., 0., 0., 0., 0.])
+    for c in W.get_all_contacts(w, friction_coeff=0.3):
+        w.register(c)
+    w.init()
+    out["ball_ball"] = w
+    # (4) a body carrying a Point dropped on a big sphere fixed to the ground: Sphere / Point
+    w = W.World()
+    w.register(W.Sphere(w.ground, 0.5, "dome"))
+    body = W.Body(name="probe", mass=W.massmatrix.box((0.1, 0.1, 0.1), 1.5))
+    w.add_link(w.ground, W.FreeJoint(), body)
+    tip = W.SubFrame(body, W.Hg.transl(0., -0.1, 0.), "tip")
+    w.register(W.Point(tip, "tip point"))
+    j = w.ground.childrenjoints[0]
+    j.gpos = W.Hg.transl(0.1, 0.615, -0.05)
+    j.gvel = np.array([0., 0., 0., 0., -0.3, 0.])
+    w.register(W.WeightController())
+    for c in W.get_all_contacts(w, friction_coeff=0.6):
+        w.register(c)
+    w.init()
+    out["dome_point"] = w
+    return out

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ARB_ABI_VERSION 2
+#define ARB_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -68,10 +68,17 @@ enum {
 
 /* constraint types, arboris/constraints.py */
 enum {
-    ARB_CT_SOFTFINGER_PLANE = 0, /* SoftFingerContact :300-836 on (Plane on ground, Point|Sphere on body),
-                                    collisions.py:161-205 */
+    ARB_CT_SOFTFINGER = 0,       /* SoftFingerContact :300-836; the shape pair is c_geom */
     ARB_CT_JOINTLIMITS = 1,      /* JointLimits :15-90 */
     ARB_CT_BALLSOCKET = 2        /* BallAndSocketConstraint :92-237 */
+};
+
+/* narrow-phase pair of a SoftFingerContact: (shape 0, shape 1), arboris/collisions.py:27-64.
+   Shape 1 is always a Sphere or a Point (radius 0). */
+enum {
+    ARB_CG_PLANE_SPHERE = 0,     /* plane_sphere_collision / plane_point_collision :161-205 */
+    ARB_CG_SPHERE_SPHERE = 1,    /* sphere_sphere_collision / sphere_point_collision :67-159 */
+    ARB_CG_BOX_SPHERE = 2        /* box_sphere_collision :207-299 (box / point uses radius 0) */
 };
 
 #define ARB_MAXDOL 4   /* rows reserved per constraint in cforce / contact outputs */
@@ -111,18 +118,20 @@ typedef struct arb_model_desc {
     const int32_t *ctype;     /* [nc] ARB_CT_* */
     const int32_t *c_enabled; /* [nc] Constraint.is_enabled() */
     const int32_t *c_body;    /* [nc] body of frame 1 (contact point / socket ball), -1 = ground */
-    const int32_t *c_body0;   /* [nc] BallAndSocket: body of frame 0, -1 = ground */
+    const int32_t *c_body0;   /* [nc] body of frame 0 (contact shape 0 / socket), -1 = ground */
+    const int32_t *c_geom;    /* [nc] SoftFingerContact: ARB_CG_* */
     const int32_t *c_dof;     /* [nc] JointLimits: constrained dof */
     const double *c_local;    /* [nc][3] contact point in its body frame */
     const double *c_radius;   /* [nc] sphere radius (0 for a Point) */
-    const double *c_plane_Hinv; /* [nc][16] inverse pose of the plane frame */
-    const double *c_plane;    /* [nc][4] plane coefficients (unit normal, d) */
+    const double *c_radius0;  /* [nc] ARB_CG_SPHERE_SPHERE: radius of shape 0 */
+    const double *c_half;     /* [nc][3] ARB_CG_BOX_SPHERE: half extents of shape 0 */
+    const double *c_plane;    /* [nc][4] ARB_CG_PLANE_SPHERE: plane coefficients (unit normal, d) */
     const double *c_mu;       /* [nc] friction coefficient */
     const double *c_prox;     /* [nc] proximity (contacts, joint limits) */
     const double *c_eps;      /* [nc][3] SoftFingerContact._eps */
     const double *c_min;      /* [nc] JointLimits */
     const double *c_max;      /* [nc] JointLimits */
-    const double *c_bpose0;   /* [nc][16] BallAndSocket frame 0 bpose */
+    const double *c_bpose0;   /* [nc][16] bpose of frame 0: socket frame / frame of contact shape 0 in c_body0 */
     const double *c_bpose1;   /* [nc][16] BallAndSocket frame 1 bpose */
 } arb_model_desc;
 

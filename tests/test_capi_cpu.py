@@ -12,6 +12,7 @@ import pytest
 
 from conftest import ROOT, load_golden, load_model
 from arboris_python_amd import _capi
+import arb_oracle as O
 
 needs_lib = pytest.mark.skipif(not os.path.exists(_capi.LIB_PATH),
                                reason="libarbstep.so not built (run __graft_entry__.build())")
@@ -223,3 +224,55 @@ def test_device_exp_twist_on_host():
         out = np.zeros(16)
         lib.arb_host_exp_twist(_capi._dp(np.ascontiguousarray(tw)), _capi._dp(out))
         assert np.abs(out.reshape(4, 4) - H).max() < 1e-12
+
+
+@needs_lib
+def test_device_zaligned_on_host():
+    """homogeneousmatrix.py:201-232 incl. the argsort tie-breaking for axis-aligned normals."""
+    lib = _capi.load()
+    rng = np.random.default_rng(3)
+    vecs = [v / np.linalg.norm(v) for v in rng.normal(size=(200, 3))]
+    for a in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1],
+              [1, 1, 0], [0, 1, 1], [1, 0, 1], [1, 1, 1], [-1, 1, -1], [1, -1, 0]):
+        a = np.array(a, float)
+        vecs.append(a / np.linalg.norm(a))
+    for v in vecs:
+        out = np.zeros(9)
+        lib.arb_host_zaligned(_capi._dp(np.ascontiguousarray(v)), _capi._dp(out))
+        assert np.abs(out.reshape(3, 3) - O.zaligned(v)[0:3, 0:3]).max() < 1e-15, v
+
+
+@needs_lib
+@pytest.mark.parametrize("geom", [0, 1, 2])
+def test_device_narrow_phase_on_host(geom):
+    """The kernel's narrow phase (compiled for the host) against the oracle's collisions.py restatement."""
+    lib = _capi.load()
+    rng = np.random.default_rng(10 + geom)
+    half = np.array([0.5, 0.2, 0.8])
+    plane = np.array([0., 0.6, 0.8, 0.1])
+    n_inside = 0
+    for k in range(300):
+        H = np.eye(4)
+        tw = rng.normal(size=6) * 0.7
+        Hx = np.zeros(16)
+        lib.arb_host_exp_twist(_capi._dp(tw), _capi._dp(Hx))
+        H = Hx.reshape(4, 4)
+        scale = 0.3 if (geom == 2 and k % 2) else 1.0         # half of the box cases start inside
+        p = H[0:3, 0:3] @ (rng.uniform(-1, 1, 3) * scale * (half if geom == 2 and k % 2 else 1.)) + H[0:3, 3]
+        rad, r0 = (0., 0.3) if k % 3 == 0 else (0.15, 0.25)
+        gc0, gc1, Rc = np.zeros(3), np.zeros(3), np.zeros(9)
+        sd = lib.arb_host_narrow_phase(geom, _capi._dp(np.ascontiguousarray(H.ravel())), _capi._dp(p), rad, r0,
+                                       _capi._dp(half), _capi._dp(plane), _capi._dp(gc0), _capi._dp(gc1), _capi._dp(Rc))
+        if geom == 0:
+            esd, H0, H1 = O._plane_sphere_collision(H[None], plane, p[None], rad)
+        elif geom == 1:
+            esd, H0, H1 = O._sphere_sphere_collision(H[None, 0:3, 3], r0, p[None], rad)
+        else:
+            esd, H0, H1 = O._box_sphere_collision(H[None], half, p[None], rad)
+            n_inside += esd[0] < -rad
+        assert abs(sd - esd[0]) < 1e-13
+        assert np.abs(gc0 - H0[0, 0:3, 3]).max() < 1e-13 and np.abs(gc1 - H1[0, 0:3, 3]).max() < 1e-13
+        assert np.abs(Rc.reshape(3, 3) - H0[0, 0:3, 0:3]).max() < 1e-12
+        assert np.abs(Rc.reshape(3, 3) - H1[0, 0:3, 0:3]).max() < 1e-12
+    if geom == 2:
+        assert n_inside > 50

@@ -205,6 +205,46 @@ def test_human36_random_contact_steps(bw_cache, nc, dtype, tol):
     assert rel(dq, rdq) < tol
 
 
+@pytest.mark.parametrize("name", ["plane_ball", "box_ball", "ball_ball", "dome_point"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, F32_TOL)])
+def test_shape_pair_contacts(bw_cache, name, dtype, tol):
+    """Plane/Sphere (r>0), Box/Sphere, Sphere/Sphere (both bodies moving) and Sphere/Point
+    contacts (collisions.py:67-299), each step from the reference's own state."""
+    g = load_golden("g7_shapes.npz")
+    bw, m, _, _ = bw_cache("shapes_" + name)
+    Q, DQ = g[name + "_q"], g[name + "_dq"]
+    q, dq, cf = gpu_step(bw, Q[:40], DQ[:40], 5e-3, dtype)
+    rq, rdq = ref_step(m, Q[:40], DQ[:40], 5e-3, dtype, Q[1:], DQ[1:])
+    assert rel(q, rq) < tol
+    assert rel(dq, rdq) < tol
+    tq, tdq = bw.to_device(Q[:40], DQ[:40], dtype)
+    r = bw.inspect(tq, tdq, 5e-3, ["c_active", "c_sdist", "c_force", "c_frame"])
+    act = r["c_active"].cpu().numpy().astype(bool)
+    if dtype == torch.float64:
+        assert np.array_equal(act, g[name + "_active"])
+        assert np.abs(r["c_sdist"].cpu().numpy() - g[name + "_sdist"]).max() < 1e-10
+        assert rel(r["c_force"].cpu().numpy(), g[name + "_force"]) < 1e-7
+        # contact frames against the oracle's (H_gc0, H_gc1)
+        _, _, _, d = O.step(m, Q[:40], DQ[:40], 5e-3, debug=True)
+        fr = r["c_frame"].cpu().numpy()
+        assert np.abs(fr[:, :, 0] - d["frames0"]).max() < 1e-10
+        assert np.abs(fr[:, :, 1] - d["frames1"]).max() < 1e-10
+    else:
+        # a gap within float32 rounding of the proximity threshold may flip; none does in these runs
+        assert (act != g[name + "_active"]).sum() <= 1
+        assert np.abs(r["c_sdist"].cpu().numpy() - g[name + "_sdist"]).max() < 5e-7
+
+
+@pytest.mark.parametrize("name", ["plane_ball", "box_ball", "ball_ball", "dome_point"])
+def test_shape_pair_rollout_f64(bw_cache, name):
+    g = load_golden("g7_shapes.npz")
+    bw, m, _, _ = bw_cache("shapes_" + name)
+    Q, DQ = g[name + "_q"], g[name + "_dq"]
+    q, dq, _ = gpu_step(bw, Q[:1], DQ[:1], 5e-3, torch.float64, nsteps=40)
+    assert rel(q[0], Q[40]) < 1e-7
+    assert rel(dq[0], DQ[40]) < 1e-6
+
+
 def test_snake64_f64(bw_cache):
     """Config 4 model, float64 kernels.  cond(Z) ~ 3e8 here, and the reference forms
     the explicit inverse (core.py:818): its own dq+ is only accurate to ~3e-6 against

@@ -36,6 +36,16 @@ def test_own_robots_flatten_like_the_reference(name, builder):
     _same(ref, m)
 
 
+@pytest.mark.parametrize("name", ["plane_ball", "box_ball", "ball_ball", "dome_point"])
+def test_shape_pair_scenes_flatten_like_the_reference(name):
+    """Sphere/Sphere, Box/Sphere, Sphere/Point and Plane/Sphere contacts found by
+    get_all_contacts (constraints.py:839-874) lower to the same arrays as the reference's."""
+    ref, q0, dq0 = load_model("shapes_" + name)
+    m, q, dq = flatten_world(scenes.shape_scenes()[name])
+    _same(ref, m)
+    assert np.abs(q - q0).max() < 1e-15 and np.abs(dq - dq0).max() < 1e-15
+
+
 def _arm_g():
     from arboris_python_amd.robots.simplearm import add_simplearm
     w = core.World()

@@ -50,7 +50,8 @@ def test_joint_types(tid):
 
 def test_plane_sphere_collision():
     g = load_golden("g0_primitives.npz")
-    sd, H0, H1 = O._plane_sphere_collision(np.eye(4), g["ps_coeffs"], g["ps_points"], 0.1)
+    B = len(g["ps_points"])
+    sd, H0, H1 = O._plane_sphere_collision(np.broadcast_to(np.eye(4), (B, 4, 4)), g["ps_coeffs"], g["ps_points"], 0.1)
     close(sd, g["ps_sdist"]); close(H0, g["ps_Hgc0"]); close(H1, g["ps_Hgc1"])
     # collisions.py:176-191 doctest
     assert abs(sd[0] - 8.9) < 1e-12
@@ -240,3 +241,36 @@ def test_joint_limits(tag):
     close(Q[:, 0], g["jl_%s_q" % tag][:99], 1e-9)
     close(q[0], g["jl_%s_q" % tag][99], 1e-9)
     assert abs(q[0, 0]) <= 3.14 / 2                       # tests/test_constraints.py:22-32
+
+
+# -- G7 other narrow-phase pairs -------------------------------------------------
+def test_collision_doctests_sphere_box():
+    """collisions.py:120-148 and :222-267 doctest values."""
+    sd, H0, H1 = O._sphere_sphere_collision(np.zeros((1, 3)), 1.1, np.array([[2., 2., 1.]]), 1.2)
+    assert abs(sd[0] - 0.7) < 1e-12
+    assert np.abs(H0[0, 0:3, 3] - [0.73333333, 0.73333333, 0.36666667]).max() < 1e-8
+    assert np.abs(H1[0, 0:3, 3] - [1.2, 1.2, 0.6]).max() < 1e-12
+    assert np.abs(H0[0, 0:3, 0] - [0.70710678, -0.70710678, 0.]).max() < 1e-8
+    eye = np.eye(4)[None]
+    half = np.array([0.5, 1., 1.5])
+    sd, H0, H1 = O._box_sphere_collision(eye, half, np.array([[0., 3., 1.]]), 0.1)
+    assert abs(sd[0] - 1.9) < 1e-12 and np.abs(H1[0, 0:3, 3] - [0., 2.9, 1.]).max() < 1e-12
+    sd, H0, H1 = O._box_sphere_collision(eye, half, np.array([[0.55, 0., 0.]]), 0.1)
+    assert abs(sd[0] + 0.05) < 1e-12 and np.abs(H1[0, 0:3, 3] - [0.45, 0., 0.]).max() < 1e-12
+    sd, H0, H1 = O._box_sphere_collision(eye, half, np.array([[0.45, 0., 0.]]), 0.1)
+    assert abs(sd[0] + 0.15) < 1e-12 and np.abs(H1[0, 0:3, 3] - [0.35, 0., 0.]).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["plane_ball", "box_ball", "ball_ball", "dome_point"])
+def test_shape_pair_scenarios(name):
+    g = load_golden("g7_shapes.npz")
+    m, _, _ = load_model("shapes_" + name)
+    Q, DQ = g[name + "_q"], g[name + "_dq"]
+    qn, dqn, cf, d = O.step(m, Q[:40], DQ[:40], 5e-3, debug=True)
+    close(qn, Q[1:], 1e-9); close(dqn, DQ[1:], 1e-8)
+    assert np.array_equal(d["active"], g[name + "_active"])
+    close(d["sdist"], g[name + "_sdist"], 1e-10)
+    close(cf, g[name + "_force"], 1e-7)
+    assert g[name + "_active"].any()                      # the contact really engages
+    q, dq, _ = O.rollout(m, Q[:1], DQ[:1], [5e-3] * 40)
+    close(q[0], Q[40], 1e-7)

@@ -482,10 +482,53 @@ def gen_constraints():
     save("g6_constraints.npz", **out)
 
 
+# ---- G7: other narrow-phase pairs (collisions.py:113-159, 207-299) ----
+from arboris_python_amd.scenes import shape_scenes   # scene definitions shared with the tests
+
+
+class _RefNS(object):
+    pass
+
+
+def gen_shapes():
+    from arboris.core import SubFrame
+    from arboris.shapes import Box, Sphere, Point
+    from arboris.robots.simpleshapes import add_sphere
+    import arboris.massmatrix as massmatrix
+    W = _RefNS()
+    W.World, W.Body, W.SubFrame, W.Hg = World, Body, SubFrame, Hg
+    W.Box, W.Sphere, W.Point = Box, Sphere, Point
+    W.add_sphere, W.add_groundplane = add_sphere, add_groundplane
+    W.WeightController, W.get_all_contacts, W.FreeJoint = WeightController, get_all_contacts, FreeJoint
+    W.massmatrix = massmatrix
+    out = {}
+    dt = 5e-3
+    for name, w in shape_scenes(W).items():
+        m = save_model("shapes_" + name, w)
+        cons = list(w._constraints)
+        assert len(cons) >= 1, name
+        qs, dqs, act, sd, frc = [], [], [], [], []
+        for step in range(40):
+            a, b = get_state(w, m)
+            qs.append(a); dqs.append(b)
+            w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+            act.append([bool(c.is_active()) for c in cons])
+            sd.append([c._sdist for c in cons])
+            frc.append([c._force.copy() for c in cons])
+            w.integrate(dt)
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        out[name + "_q"], out[name + "_dq"] = np.array(qs), np.array(dqs)
+        out[name + "_active"], out[name + "_sdist"] = np.array(act), np.array(sd)
+        out[name + "_force"] = np.array(frc)
+        print("  %-12s contacts %d, active steps %d, max |f| %.2f" % (name, len(cons), int(np.array(act).any(1).sum()), np.abs(np.array(frc)).max()))
+    save("g7_shapes.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes)
     for k in which:
         table[k]()
