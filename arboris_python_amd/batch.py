@@ -148,7 +148,7 @@ class BatchedWorlds(object):
                       M=(B, n, n), B=(B, n, n), N=(B, n, n), Z=(B, n, n), gforce0=(B, n),
                       vel_free=(B, n), c_sdist=(B, nc), c_active=(B, nc), c_jac=(B, nc, 4, n),
                       c_force=(B, nc, 4), c_frame=(B, nc, 2, 4, 4), gforce=(B, n),
-                      q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 4), stamps=(B, 8), energy=(B, 2))
+                      q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 5), stamps=(B, 8), energy=(B, 2))
         want = list(want)
         if "gforce" in want and nc and "c_jac" not in want:
             want.append("c_jac")

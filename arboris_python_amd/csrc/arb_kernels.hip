@@ -73,6 +73,10 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
     int q, dq, qd, bd, pd, sc, jb, slots, cd, rt, am, vv, ff, ff0, work, total;
 };
 
+// exact (bit pattern) equality, also true for identical NaNs
+__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_int(a) == __float_as_int(b); }
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
 template <typename T>
 struct DevModel {
     int nb, n, nq, nc, ndol, ncols, maxdepth, nslots, natt, slot_elems;
@@ -940,6 +944,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             T vr = T(0), fr = T(0), Yrow[4], Prow[4];
             T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
             T k_min = T(0), k_max = T(0);
+            T k_sdt = T(0), k_iyn = T(0), k_muyn = T(0), k_yc0 = T(0), k_yc1 = T(0), k_yc2 = T(0), k_bsq = T(0);
+            bool k_eps1 = false;
             double k_tr = 0., k_m2 = 0., k_det = 0., k_sQ = 0., k_sA = 0., k_nq = 0., k_warm = NAN;
             int k_ct = 0;
             bool k_act = false;
@@ -970,11 +976,21 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * lane + i) * ndol + 4 * lane + j];
                     const SlidePre sp = slide_precompute<T>(Yc4);
                     k_tr = sp.tr; k_m2 = sp.m2; k_det = sp.det; k_sQ = sp.sQ; k_sA = sp.sA; k_nq = sp.nq;
+                    // other per-step constants of SoftFingerContact.solve (constraints.py:795, 808-812)
+                    k_sdt = k_sd / dt;
+                    k_iyn = T(1) / Yc4[15]; k_muyn = k_mu / Yc4[15];
+                    k_yc0 = Yc4[3]; k_yc1 = Yc4[7]; k_yc2 = Yc4[11];
+                    const T bq0 = k_muyn * k_yc0, bq1 = k_muyn * k_yc1, bq2 = k_muyn * k_yc2;
+                    k_bsq = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
+                    k_eps1 = (k_e0 == T(1)) && (k_e1 == T(1)) && (k_e2 == T(1));
                 }
             }
             const unsigned long long actmask = __ballot(k_act);
-            int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0;
+            const unsigned long long eps1mask = __ballot(k_eps1);
+            int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
+            T vr_prev = vr, fr_prev = fr;
             for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+                if (MODE == 1) ++st_sweeps;
                 for (int c = 0; c < nc; ++c) {
                     if (!((actmask >> c) & 1ull)) continue;
                     const int base = 4 * c;
@@ -998,40 +1014,68 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { df[i] = -fc[i]; fnew[i] = T(0); }
                         } else {
-                            const T sdt = sd / dt;
+                            const T sdt = bcast(k_sdt, c);
+                            const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
                             const T dfr = -(Prow[0] * vc[0] + Prow[1] * vc[1] + Prow[2] * vc[2] + Prow[3] * (vc[3] + sdt));
                             const T fnr = fr + dfr;
                             T fn[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) fn[i] = bcast(fnr, base + i);
-                            const T eps[3] = {bcast(k_e0, c), bcast(k_e1, c), bcast(k_e2, c)};
-                            const T lhs = (fn[0] / eps[0]) * (fn[0] / eps[0]) + (fn[1] / eps[1]) * (fn[1] / eps[1])
-                                        + (fn[2] / eps[2]) * (fn[2] / eps[2]);
+                            T eps[3] = {T(1), T(1), T(1)};
+                            T lhs;
+                            if (eps1) {
+                                lhs = fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2];
+                            } else {
+                                eps[0] = bcast(k_e0, c); eps[1] = bcast(k_e1, c); eps[2] = bcast(k_e2, c);
+                                lhs = (fn[0] / eps[0]) * (fn[0] / eps[0]) + (fn[1] / eps[1]) * (fn[1] / eps[1])
+                                    + (fn[2] / eps[2]) * (fn[2] / eps[2]);
+                            }
                             const T rhs = (fn[3] * mu) * (fn[3] * mu);
                             if (lhs <= rhs) {                              // static friction
                                 if (MODE == 1) ++st_sta;
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) { fnew[i] = fn[i]; df[i] = fn[i] - fc[i]; }
+                                for (int i = 0; i < 4; ++i) fnew[i] = fn[i];
                                 // df must be exactly -pinv(Y)(...) as in the reference: recover it from the rows
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) df[i] = bcast(dfr, base + i);
                             } else {                                       // sliding friction
-                                T Y[16], alpha[4], shift = T(0);
+                                T alpha[4], shift = T(0);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    alpha[r] = bcast(v0r, base + r);
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) Y[4 * r + i] = bcast(Yrow[i], base + r);
-                                }
+                                for (int r = 0; r < 4; ++r) alpha[r] = bcast(v0r, base + r);
                                 alpha[3] += sdt;
+                                // the constraint's own 4x4 admittance block (wave-uniform LDS reads)
+                                T Y[16];
+                                {
+                                    typedef T Y4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const Y4 y4 = *reinterpret_cast<const Y4 *>(AM + (base + r) * ndol + base);
+                                        Y[4 * r] = y4.x; Y[4 * r + 1] = y4.y; Y[4 * r + 2] = y4.z; Y[4 * r + 3] = y4.w;
+                                    }
+                                }
                                 if (MODE == 1) ++st_fast;
-                                SlidePre sp;
-                                sp.tr = bcast(k_tr, c); sp.m2 = bcast(k_m2, c); sp.det = bcast(k_det, c);
-                                sp.sQ = bcast(k_sQ, c); sp.sA = bcast(k_sA, c); sp.nq = bcast(k_nq, c);
                                 double warm = bcast(k_warm, c);
-                                if (!softfinger_sliding_shift<T>(Y, alpha, mu, eps, WORK, &shift, true, &sp, &warm)) {
+                                bool have = false;
+                                if (eps1) {
+                                    SlidePre sp;
+                                    sp.tr = bcast(k_tr, c); sp.m2 = bcast(k_m2, c); sp.det = bcast(k_det, c);
+                                    sp.sQ = bcast(k_sQ, c); sp.sA = bcast(k_sA, c); sp.nq = bcast(k_nq, c);
+                                    const T yc[3] = {bcast(k_yc0, c), bcast(k_yc1, c), bcast(k_yc2, c)};
+                                    const T muyn = bcast(k_muyn, c);
+                                    const T bq[3] = {muyn * yc[0], muyn * yc[1], muyn * yc[2]};
+                                    double c1, kappa, root;
+                                    slide_c1_kappa<T>(alpha, yc, bcast(k_iyn, c), muyn, bq, bcast(k_bsq, c), &c1, &kappa);
+                                    if (slide_leftmost_root(sp, c1, kappa, warm, &root, slide_step_tol<T>())) {
+                                        warm = root;
+                                        // leftmost real eigenvalue; admissible when <= 0 (constraints.py:826-830)
+                                        shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
+                                        have = true;
+                                    }
+                                }
+                                if (!have) {
                                     if (MODE == 1) { ++st_slow; --st_fast; }
                                     // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
+                                    softfinger_sliding_shift<T>(Y, alpha, mu, eps, WORK, &shift, false);
                                     WAVE_SYNC();
                                     if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
                                     WAVE_SYNC();
@@ -1042,7 +1086,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                                 if (lane == c) k_warm = warm;       // next sweep restarts next to this root
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) fnew[i] = fc[i];
-                                softfinger_slide_finish<T>(Y, alpha, eps, shift, fnew, df);
+                                T sie2[3] = {shift, shift, shift};
+                                if (!eps1) {
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i) sie2[i] = shift / (eps[i] * eps[i]);
+                                }
+                                softfinger_slide_finish_scaled<T>(Y, alpha, sie2, fnew, df);
                             }
                         }
                     } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
@@ -1068,10 +1117,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const int rr = lane - base;
                     fr = (rr == 0) ? fnew[0] : (rr == 1) ? fnew[1] : (rr == 2) ? fnew[2] : (rr == 3) ? fnew[3] : fr;
                 }
+                // A sweep that leaves every velocity and force bit-for-bit unchanged is a fixed point
+                // of the iteration: the remaining sweeps of core.py:929-935 would repeat it exactly.
+                if (__all(same_bits(vr, vr_prev) && same_bits(fr, fr_prev)) && !(MODE == 1 && (dbg.ablate & 8))) break;
+                vr_prev = vr; fr_prev = fr;
             }
             if (MODE == 1 && dbg.gs_stats != nullptr && lane == 0) {
-                int *o = dbg.gs_stats + w * 4;
-                o[0] = st_rel; o[1] = st_sta; o[2] = st_fast; o[3] = st_slow;
+                int *o = dbg.gs_stats + w * 5;
+                o[0] = st_rel; o[1] = st_sta; o[2] = st_fast; o[3] = st_slow; o[4] = st_sweeps;
             }
             WAVE_SYNC();
             if (lane < ndol) { FF[lane] = fr; VV[lane] = vr; }
@@ -1166,6 +1219,7 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
         }
     }
     for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+        bool moved = false;          // any velocity or force of this lane's world changed in this sweep
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (c >= nc) continue;
@@ -1205,11 +1259,15 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
             for (int i = 0; i < ND; ++i)
                 if (i < ndol) {
                     const T *ar = Arow + i * ndol + 4 * c;
-                    v[i] += ar[0] * df[0] + ar[1] * df[1] + ar[2] * df[2] + ar[3] * df[3];
+                    const T vn = v[i] + (ar[0] * df[0] + ar[1] * df[1] + ar[2] * df[2] + ar[3] * df[3]);
+                    moved = moved || !same_bits(vn, v[i]);
+                    v[i] = vn;
                 }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[4 * c + i] = f4[i];
+            for (int i = 0; i < 4; ++i) { moved = moved || !same_bits(f4[i], f[4 * c + i]); f[4 * c + i] = f4[i]; }
         }
+        // fixed point reached by every world of the wave: the remaining sweeps would repeat it exactly
+        if (!__any(moved)) break;
     }
     if (on) {
 #pragma unroll

@@ -357,6 +357,26 @@ ARB_HD void exp_twist(V3<T> w, V3<T> v, M3<T> &R, V3<T> &p) {
     p = sc * v + cc * wv + (dsc * wdv) * w;
 }
 
+// Reciprocal to ~1 ulp without the IEEE division sequence (v_rcp + Newton steps on the
+// device; a pivot of 0 still gives inf/NaN like a division).
+ARB_HD float arb_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(r, fmaf(-x, r, 1.f), r);
+#else
+    return 1.f / x;
+#endif
+}
+ARB_HD double arb_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.), r);
+    return fma(r, fma(-x, r, 1.), r);
+#else
+    return 1. / x;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // Small dense solvers (wave-uniform use in the Gauss-Seidel stage)
 // ---------------------------------------------------------------------------
@@ -377,7 +397,8 @@ ARB_HD void gepp4(T A[4][4], T B[4][NR]) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) { T a = B[c][j], b = B[r][j]; B[c][j] = sw ? b : a; B[r][j] = sw ? a : b; }
         }
-        T ip = T(1) / A[c][c];
+        const T ip = arb_rcp(A[c][c]);
+        A[c][c] = ip;                                  // the diagonal now holds the pivots' reciprocals
 #pragma unroll
         for (int r = c + 1; r < 4; ++r) {
             T f = A[r][c] * ip;
@@ -389,7 +410,7 @@ ARB_HD void gepp4(T A[4][4], T B[4][NR]) {
     }
 #pragma unroll
     for (int c = 3; c >= 0; --c) {
-        T ip = T(1) / A[c][c];
+        const T ip = A[c][c];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             T s = B[c][j];
@@ -666,7 +687,10 @@ ARB_HD SlidePre slide_precompute(const T Y[16]) {
 // Budan-Fourier certificate (all Taylor coefficients at the start point alternate in sign,
 // hence no real root to its left) holds, otherwise from the spectrum bound.
 // Returns true and the root when the register-only path succeeded.
-ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, double warm, double *root) {
+// `step_tol`: a Laguerre step shorter than step_tol |x| ends the iteration (the steps shrink at
+// least geometrically from the left, so the remaining distance is below the last step).
+ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, double warm, double *root,
+                                double step_tol = 4e-16) {
     const double d2 = -kappa;
     const double l1 = -(3. * k.tr - k.sQ);
     const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
@@ -724,11 +748,29 @@ ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, doub
         const double dx = (n * (1. - 9.5367431640625e-07)) * p0 * arb_fast_rcp(den); // negative
         const double xn = x - dx;
         if (!(xn > x)) { *root = x; return true; }    // no representable progress: converged
-        if (fabs(dx) <= 4e-16 * fabs(xn)) { *root = xn; return true; }
+        if (fabs(dx) <= step_tol * fabs(xn)) { *root = xn; return true; }
         x = xn;
     }
     return false;
 }
+
+// The two sweep-dependent scalars of det(B - sI) from the constants of the constraint's own
+// admittance block: yc = Y_c, iyn = 1/y_n, muyn = mu/y_n, b = muyn Y_c, bsq = b.b   (constraints.py:808-812)
+template <typename T>
+ARB_HD void slide_c1_kappa(const T alpha[4], const T yc[3], T iyn, T muyn, const T b[3], T bsq,
+                           double *c1, double *kappa) {
+    const T t = alpha[3] * iyn;
+    const T beta[3] = {alpha[0] - t * yc[0], alpha[1] - t * yc[1], alpha[2] - t * yc[2]};
+    const T a = muyn * alpha[3];
+    const T bb = beta[0] * b[0] + beta[1] * b[1] + beta[2] * b[2];
+    const T b2 = beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2];
+    const double ia = arb_rcp((double)a);
+    *c1 = 2. * ia * (double)bb;
+    *kappa = ((double)b2 * ia * ia) * ((double)bsq - 1.);
+}
+
+// Laguerre step tolerance per state precision (see slide_leftmost_root)
+template <typename T> ARB_HD double slide_step_tol() { return sizeof(T) == 4 ? 1e-7 : 1e-12; }
 
 // Sliding branch, constraints.py:803-830: coefficients of B from (Y, alpha) and the
 // shift s.  Returns true with *shift set when the register-only fast path
@@ -755,7 +797,7 @@ ARB_HD bool softfinger_sliding_shift(const T Y[16], const T alpha[4], T mu, cons
         const double c1 = 2. * ia * (double)bb;
         const double kappa = ((double)b2 * ia * ia) * ((double)bsq - 1.);
         double root;
-        if (slide_leftmost_root(kk, c1, kappa, warm ? *warm : NAN, &root)) {
+        if (slide_leftmost_root(kk, c1, kappa, warm ? *warm : NAN, &root, slide_step_tol<T>())) {
             if (warm) *warm = root;
             // leftmost real eigenvalue; admissible when <= 0, else no admissible one (constraints.py:826-830)
             *shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
@@ -830,8 +872,9 @@ ARB_HD T slide_shift_from_eig(AP work) {
     return any ? (smin > T(-1e10) ? smin : T(-1e10)) : T(-1e10);   // constraints.py:827-830
 }
 
+// `sie2` = s * eps**-2 (three values)
 template <typename T>
-ARB_HD void softfinger_slide_finish(const T Y[16], const T alpha[4], const T eps[3], T s, T f[4], T df[4]) {
+ARB_HD void softfinger_slide_finish_scaled(const T Y[16], const T alpha[4], const T sie2[3], T f[4], T df[4]) {
     T A[4][4], Bv[4][1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -840,10 +883,16 @@ ARB_HD void softfinger_slide_finish(const T Y[16], const T alpha[4], const T eps
         Bv[i][0] = -alpha[i];
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) A[i][i] -= s / (eps[i] * eps[i]);  // s * diag(eps**-2)
+    for (int i = 0; i < 3; ++i) A[i][i] -= sie2[i];                // s * diag(eps**-2)
     gepp4<T, 1>(A, Bv);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { df[i] = Bv[i][0] - f[i]; f[i] = Bv[i][0]; }
+}
+
+template <typename T>
+ARB_HD void softfinger_slide_finish(const T Y[16], const T alpha[4], const T eps[3], T s, T f[4], T df[4]) {
+    const T sie2[3] = {s / (eps[0] * eps[0]), s / (eps[1] * eps[1]), s / (eps[2] * eps[2])};
+    softfinger_slide_finish_scaled<T>(Y, alpha, sie2, f, df);
 }
 
 // Sequential composition (host tests; `use_fast` = false forces the eig6 route).

@@ -171,8 +171,9 @@ typedef struct arb_inspect_out {
     void *gforce;    /* [nw][ndof]         World._gforce incl. constraints   core.py:936-937 */
     void *q_next;    /* [nw][nq]           state after integrate             core.py:974-980 */
     void *dq_next;   /* [nw][ndof] */
-    void *gs_stats;  /* [nw][4] int32  Gauss-Seidel solve counts of the step: SoftFingerContact release,
-                        static, sliding via the fast shift, sliding via the eig6 fallback (diagnostic) */
+    void *gs_stats;  /* [nw][5] int32  Gauss-Seidel solve counts of the step: SoftFingerContact release,
+                        static, sliding via the fast shift, sliding via the eig6 fallback, and the number
+                        of sweeps executed before the iteration reached a bit-exact fixed point (diagnostic) */
     void *energy;    /* [nw][2]            kinetic and potential energy, EnergyMonitor.update observers.py:40-51 */
     void *stamps;    /* [nw][8] int64  shader clock at the phase boundaries A, A', B, C, D, GS, E, end (diagnostic) */
 } arb_inspect_out;
