@@ -713,17 +713,20 @@ ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, doub
     pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
     pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
     pc[5] -= c1 * (er[2] * e[3]);
-    // |P| <= |Q| + 3 |c1| (infinity norms); every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
-    const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
-    if (!(rb > 0.) || !(rb < 1e300)) return false;
-    double x = -1.0001 * rb - 1e-300;
-    if (warm == warm && warm > x) {
+    double x = NAN;
+    if (warm == warm) {
         const double x0 = warm - 1e-3 * fabs(warm) - 1e-300;
         double t[7];
         for (int i = 0; i < 7; ++i) t[i] = pc[i];
         for (int j = 0; j < 6; ++j)                 // Taylor shift: t[i] = p^(i)(x0) / i!
             for (int i = 5; i >= j; --i) t[i] += x0 * t[i + 1];
         if (t[0] > 0. && t[1] < 0. && t[2] > 0. && t[3] < 0. && t[4] > 0. && t[5] < 0.) x = x0;
+    }
+    if (!(x == x)) {
+        // |P| <= |Q| + 3 |c1| (infinity norms); every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
+        const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
+        if (!(rb > 0.) || !(rb < 1e300)) return false;
+        x = -1.0001 * rb - 1e-300;
     }
     const double n = 6.;
     for (int it = 0; it < 40; ++it) {
@@ -749,6 +752,13 @@ ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, doub
         const double xn = x - dx;
         if (!(xn > x)) { *root = x; return true; }    // no representable progress: converged
         if (fabs(dx) <= step_tol * fabs(xn)) { *root = xn; return true; }
+        if (fabs(dx) <= 1e-2 * fabs(xn)) {
+            // Short step: accept xn when the Newton estimate of what is left, p(xn) / |p'(x)|, is
+            // below the tolerance (|p'| decreases towards the root, hence the factor 1/4).
+            double q0 = pc[6];
+            for (int i = 5; i >= 0; --i) q0 = q0 * xn + pc[i];
+            if (fabs(q0) <= 0.25 * step_tol * fabs(xn) * (-p1)) { *root = xn; return true; }
+        }
         x = xn;
     }
     return false;
