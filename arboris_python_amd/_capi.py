@@ -55,13 +55,20 @@ class RolloutLog(C.Structure):
     _fields_ = [("q_log", C.c_void_p), ("dq_log", C.c_void_p), ("energy_log", C.c_void_p)]
 
 
+class StepArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("dq", C.c_void_p), ("cforce", C.c_void_p), ("ext_gforce", C.c_void_p),
+                ("pd_qdes", C.c_void_p), ("pd_dqdes", C.c_void_p), ("pd_kp", C.c_void_p), ("pd_kd", C.c_void_p),
+                ("nworlds", C.c_int64), ("dt", C.c_double), ("nsteps", C.c_int32), ("flags", C.c_uint32),
+                ("log", C.POINTER(RolloutLog))]
+
+
 class InspectOut(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in INSPECT_FIELDS]
 
 
 # every symbol include/arbstep.h declares (tests check they are all exported)
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
-            "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_rollout", "arb_inspect"]
+            "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_step_ex", "arb_rollout", "arb_inspect"]
 # host-side self-test hooks (device math compiled for the CPU)
 TEST_HOOKS = ["arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_joint_local",
               "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
@@ -93,6 +100,8 @@ def load():
     lib.arb_step.restype = C.c_int
     lib.arb_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int64, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]
+    lib.arb_step_ex.restype = C.c_int
+    lib.arb_step_ex.argtypes = [C.c_void_p, C.c_int, C.POINTER(StepArgs), C.c_void_p]
     lib.arb_rollout.restype = C.c_int
     lib.arb_rollout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_double, C.c_int32, C.c_uint32, C.POINTER(RolloutLog), C.c_void_p]

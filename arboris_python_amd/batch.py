@@ -91,8 +91,13 @@ class BatchedWorlds(object):
 
     # -- the step --------------------------------------------------------------
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
-             stream=None, fused=False, split=False):
-        """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous)."""
+             stream=None, fused=False, split=False, pd_targets=None, pd_gains=None):
+        """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).
+
+        ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller).
+        ``pd_targets=(qdes, dqdes)`` (B,ndof) each: one ProportionalDerivativeController target
+        per world (controllers.py:63-158), with the model's gains, or with the per-world DIAGONAL
+        gains ``pd_gains=(kp, kd)`` (B,ndof) each."""
         torch = _torch()
         B = self._check_state(q, dq, cforce, ext_gforce)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
@@ -101,11 +106,27 @@ class BatchedWorlds(object):
             flags |= _capi.ARB_STEP_FUSED
         if split:
             flags |= _capi.ARB_STEP_SPLIT
-        _capi.check(self._lib.arb_step(
-            self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
-            None if cforce is None else cforce.data_ptr(),
-            None if ext_gforce is None else ext_gforce.data_ptr(),
-            B, float(dt), int(nsteps), flags, C.c_void_p(st.cuda_stream)))
+        if pd_targets is None and pd_gains is None:
+            _capi.check(self._lib.arb_step(
+                self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
+                None if cforce is None else cforce.data_ptr(),
+                None if ext_gforce is None else ext_gforce.data_ptr(),
+                B, float(dt), int(nsteps), flags, C.c_void_p(st.cuda_stream)))
+            return
+        a = _capi.StepArgs()
+        a.q, a.dq = q.data_ptr(), dq.data_ptr()
+        a.cforce = None if cforce is None else cforce.data_ptr()
+        a.ext_gforce = None if ext_gforce is None else ext_gforce.data_ptr()
+        for names, pair in ((("pd_qdes", "pd_dqdes"), pd_targets), (("pd_kp", "pd_kd"), pd_gains)):
+            if pair is None:
+                continue
+            for name, t in zip(names, pair):
+                if tuple(t.shape) != (B, self.model.ndof) or not t.is_contiguous() or t.dtype != q.dtype \
+                        or t.device != self.device:
+                    raise ValueError("%s must be a contiguous (B, ndof) %s tensor on %s" % (name, q.dtype, self.device))
+                setattr(a, name, t.data_ptr())
+        a.nworlds, a.dt, a.nsteps, a.flags = B, float(dt), int(nsteps), flags
+        _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
 
     def rollout(self, q, dq, dt, nsteps, cforce=None, ext_gforce=None, log_state=True, log_energy=True,
                 skip_constraints=False, stream=None, fused=False, split=False):

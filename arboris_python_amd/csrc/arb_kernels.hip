@@ -112,6 +112,11 @@ struct SplitIO {
     T *sol;            // [nw][1+ndol][ndof] columns of [Y rhs | Y J'^T]
 };
 
+// Optional per-world PD inputs of arb_step_ex (all [nworlds][ndof], null = absent): desired
+// positions/velocities, and diagonal gains that replace the model's gain matrices.
+template <typename T>
+struct PerWorldPD { const T *qdes, *dqdes, *kp, *kd; };
+
 // Optional per-step logs of arb_rollout (state and energies as observers see them: before the step)
 template <typename T>
 struct LogOut {
@@ -203,7 +208,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 template <typename T, int NMAX, int NSETS, int MODE>
 __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
-    T *__restrict__ gcforce, const T *__restrict__ gext, long nworlds, T dt, int nsteps,
+    T *__restrict__ gcforce, const T *__restrict__ gext, const PerWorldPD<T> pwd, long nworlds, T dt, int nsteps,
     unsigned flags, const DebugOut<T> dbg, int zmode, const LogOut<T> logo, const SplitIO<T> sio)
 {
     const DevModel<T> *mp = mp_in;     // device-resident model, fields fetched with scalar loads
@@ -758,11 +763,27 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
         T gf0 = rhsG + ext_k;          // controllers' generalized force (inspect output)
         T rhs = rhsM + ext_k;          // gforce - (N + B + Z_pd) gvel
-        if (mp->has_pd && lane < n) {
-            T acc = mp->pd_tau0[lane], accv = T(0);
+        if (pwd.kp != nullptr) {
+            // per-world diagonal gains and targets (arb_step_ex): tau0 = kp (qdes - q) + kd dqdes, Z += dt kp + kd
+            if (lane < n) {
+                const T kp = pwd.kp[w * n + lane], kd = pwd.kd[w * n + lane];
+                const T acc = kp * (pwd.qdes[w * n + lane] - qd[lane]) + kd * pwd.dqdes[w * n + lane];
+                const T zd = dt * kp + kd;
+                gf0 += acc;
+                rhs += acc - zd * dqs[lane];
+                if (MODE == 0 || zmode == 0) {
+#pragma unroll
+                    for (int i = 0; i < NMAX; ++i) Z[i] += (i == lane) ? zd : T(0);
+                }
+            }
+        } else if (mp->has_pd && lane < n) {
+            // model gains (controllers.py:141-158); per-world targets replace the model's tau0 when given
+            T acc = (pwd.qdes != nullptr) ? T(0) : mp->pd_tau0[lane], accv = T(0);
             for (int i = 0; i < n; ++i) {
-                acc -= mp->pd_kp[lane * n + i] * qd[i];
-                accv += (dt * mp->pd_kp[lane * n + i] + mp->pd_kd[lane * n + i]) * dqs[i];
+                const T kp = mp->pd_kp[lane * n + i], kd = mp->pd_kd[lane * n + i];
+                if (pwd.qdes != nullptr) acc += kp * (pwd.qdes[w * n + i] - qd[i]) + kd * pwd.dqdes[w * n + i];
+                else acc -= kp * qd[i];
+                accv += (dt * kp + kd) * dqs[i];
             }
             gf0 += acc;
             rhs += acc - accv;
@@ -1644,7 +1665,7 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 }
 
 template <typename T, int NMAX, int NSETS, int MODE>
-static int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw, double dt,
+static int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw, double dt,
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
                       const SplitIO<T> &sio, hipStream_t st) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
@@ -1652,27 +1673,27 @@ static int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio);
     HIP_TRY(hipGetLastError());
     return ARB_OK;
 }
 
 template <typename T, int MODE>
-static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, long nw,
+static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw,
                   double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
                   const SplitIO<T> &sio, hipStream_t st) {
 #ifdef ARB_QUICK
     // development build: a single instantiation (float, NMAX=48, one column set, production mode)
     if constexpr (std::is_same<T, float>::value && MODE == 0) {
         if (M->nmax == 44 && M->nsets == 1)
-            return launch_one<T, 44, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
+            return launch_one<T, 44, 1, MODE>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
     }
     return ARB_ERR_UNSUPPORTED;
 #else
 #define CASE(NM)                                                                                                     \
     case NM:                                                                                                         \
-        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st) \
-                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
+        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st) \
+                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
     switch (M->nmax) {
         CASE(16) CASE(32) CASE(44) CASE(48) CASE(64)
         default: return ARB_ERR_UNSUPPORTED;
@@ -1727,7 +1748,7 @@ static int launch_gs(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long 
 
 template <typename T>
 static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext,
-                      long nw, double dt, int nsteps, unsigned flags, const arb_rollout_log *log, hipStream_t st) {
+                      const PerWorldPD<T> &pwd, long nw, double dt, int nsteps, unsigned flags, const arb_rollout_log *log, hipStream_t st) {
     DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
     LogOut<T> lo; memset(&lo, 0, sizeof(lo));
     if (log) { lo.q = (T *)log->q_log; lo.dq = (T *)log->dq_log; lo.energy = (T *)log->energy_log; }
@@ -1736,7 +1757,7 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
     const bool can_split = nc > 0 && nc <= 16 && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
     const bool split = can_split && ((flags & ARB_STEP_SPLIT) || (nw >= ARB_SPLIT_MIN_WORLDS && nc <= ARB_SPLIT_MAX_NC));
     if (!split)
-        return launch<T, 0>(M, dm, L, q, dq, cf, ext, nw, dt, nsteps, flags, dbg, 0, lo, sio, st);
+        return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, st);
     // ---- split execution: step kernel (dynamics + system) / Gauss-Seidel kernel (lane = world) ----
     const size_t per_world = (size_t)ndol * ndol + 3 * (size_t)ndol + 8 * (size_t)nc + (size_t)(1 + ndol) * n;
     const size_t need = per_world * (size_t)nw * sizeof(T);
@@ -1758,49 +1779,67 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
         if (lk.dq) lk.dq += (size_t)k * nw * n;
         if (lk.energy) lk.energy += (size_t)k * nw * 2;
         sio.mode = 2 | (k > 0 ? 1 : 0);
-        int rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, nw, dt, 1, flags, dbg, 0, lk, sio, st);
+        int rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, st);
         if (rc != ARB_OK) return rc;
         rc = launch_gs<T>(dm, nc, sio, nw, dt, st);
         if (rc != ARB_OK) return rc;
     }
     sio.mode = 1;                                      // apply the last step's forces, write cforce
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
-    return launch<T, 0>(M, dm, L, q, dq, cf, ext, nw, dt, 1, flags, dbg, 0, nolog, sio, st);
+    return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, sio, st);
 }
 
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
+                     const void *pd_qdes, const void *pd_dqdes, const void *pd_kp, const void *pd_kd,
                      int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, const arb_rollout_log *log,
                      void *stream) {
     if (!M || nworlds < 0 || nsteps < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
     if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
+    // per-world PD inputs: targets come in pairs; diagonal gains come in pairs and need targets;
+    // targets without gains use the model's gain matrices, so the model must hold a PD controller
+    if ((pd_qdes == nullptr) != (pd_dqdes == nullptr) || (pd_kp == nullptr) != (pd_kd == nullptr)) return ARB_ERR_INVALID;
+    if (pd_kp != nullptr && pd_qdes == nullptr) return ARB_ERR_INVALID;
+    if (pd_qdes != nullptr && pd_kp == nullptr && !M->df.has_pd) return ARB_ERR_INVALID;
     if (nworlds == 0 || nsteps == 0) return ARB_OK;     // empty batch: nothing to do (pointers may be null)
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     HIP_TRY(hipSetDevice(M->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == ARB_F32)
+    if (dtype == ARB_F32) {
+        const PerWorldPD<float> pwd = {(const float *)pd_qdes, (const float *)pd_dqdes, (const float *)pd_kp, (const float *)pd_kd};
         return step_typed<float>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce,
-                                 (const float *)ext_gforce, (long)nworlds, dt, nsteps, flags, log, st);
+                                 (const float *)ext_gforce, pwd, (long)nworlds, dt, nsteps, flags, log, st);
+    }
+    const PerWorldPD<double> pwd = {(const double *)pd_qdes, (const double *)pd_dqdes, (const double *)pd_kp, (const double *)pd_kd};
     return step_typed<double>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce,
-                              (const double *)ext_gforce, (long)nworlds, dt, nsteps, flags, log, st);
+                              (const double *)ext_gforce, pwd, (long)nworlds, dt, nsteps, flags, log, st);
 }
 
 extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                         int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, void *stream) {
-    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nworlds, dt, nsteps, flags, nullptr, stream);
+    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nullptr, nullptr, nullptr, nullptr, nworlds, dt, nsteps,
+                     flags, nullptr, stream);
+}
+
+extern "C" int arb_step_ex(arb_model *M, int dtype, const arb_step_args *a, void *stream) {
+    if (!a) return ARB_ERR_INVALID;
+    return step_impl(M, dtype, a->q, a->dq, a->cforce, a->ext_gforce, a->pd_qdes, a->pd_dqdes, a->pd_kp, a->pd_kd,
+                     a->nworlds, a->dt, a->nsteps, a->flags, a->log, stream);
 }
 
 extern "C" int arb_rollout(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                            int64_t nworlds, double dt, int32_t nsteps, uint32_t flags,
                            const arb_rollout_log *log, void *stream) {
     if (!log) return ARB_ERR_INVALID;
-    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nworlds, dt, nsteps, flags, log, stream);
+    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nullptr, nullptr, nullptr, nullptr, nworlds, dt, nsteps,
+                     flags, log, stream);
 }
 
 template <typename T>
 static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const void *q, const void *dq,
                      const void *cforce, const void *ext, long nw, double dt, unsigned flags,
                      const arb_inspect_out *o, hipStream_t st) {
+    PerWorldPD<T> pwd; memset(&pwd, 0, sizeof(pwd));
     DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
     int rc;
     // the three world matrices need one pass each (they share the accumulator registers)
@@ -1811,7 +1850,7 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
         d1.Zout = (T *)ps.ptr;
         LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
         SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
-        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, d1, ps.zmode, nolog, nosplit, st);
+        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, d1, ps.zmode, nolog, nosplit, st);
         if (rc != ARB_OK) return rc;
     }
     dbg.pose = (T *)o->pose; dbg.twist = (T *)o->twist; dbg.jac = (T *)o->jac; dbg.djac = (T *)o->djac;
@@ -1822,7 +1861,7 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
     { const char *ab = getenv("ARB_ABLATE"); dbg.ablate = ab ? atoi(ab) : 0; }
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
     SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
-    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, nw, dt, 1, flags, dbg, 0, nolog, nosplit, st);
+    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, nosplit, st);
 }
 
 extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,

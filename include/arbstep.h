@@ -220,6 +220,33 @@ int arb_rollout(arb_model *m, int dtype, void *q, void *dq, void *cforce, const 
                 int64_t nworlds, double dt, int32_t nsteps, uint32_t flags,
                 const arb_rollout_log *log, void *stream);
 
+/*
+ * The general form of arb_step / arb_rollout, with the per-world controller inputs that
+ * stand for one ProportionalDerivativeController PER WORLD (controllers.py:63-158):
+ *     gforce += Kp (qdes_w - q) + Kd dqdes_w ,   Z += dt Kp + Kd        (controllers.py:141-158)
+ *   pd_qdes, pd_dqdes  device [nworlds][ndof] or both NULL: desired positions and velocities,
+ *            dof-indexed (entries of dofs no gain touches are ignored).  Without pd_kp/pd_kd the
+ *            gains are the model's merged Kp, Kd (arb_model_desc.pd_kp/pd_kd, required then) and
+ *            these targets replace the model's pd_tau0.
+ *   pd_kp, pd_kd  device [nworlds][ndof] or both NULL: per-world DIAGONAL gains; they replace the
+ *            model's gain matrices altogether and need pd_qdes/pd_dqdes.
+ *   log      NULL (arb_step) or the per-step logs (arb_rollout)
+ * Other fields as in arb_step.  ext_gforce is the hook for user torques (MPC inputs).
+ */
+typedef struct arb_step_args {
+    void *q, *dq, *cforce;
+    const void *ext_gforce;
+    const void *pd_qdes, *pd_dqdes;
+    const void *pd_kp, *pd_kd;
+    int64_t nworlds;
+    double dt;
+    int32_t nsteps;
+    uint32_t flags;
+    const arb_rollout_log *log;
+} arb_step_args;
+
+int arb_step_ex(arb_model *m, int dtype, const arb_step_args *args, void *stream);
+
 /* Evaluate one step WITHOUT modifying q/dq and write the requested intermediate
  * results.  Same arithmetic as arb_step (same kernels, debug stores enabled). */
 int arb_inspect(arb_model *m, int dtype, const void *q, const void *dq,

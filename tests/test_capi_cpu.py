@@ -42,6 +42,10 @@ def test_argument_validation_without_gpu():
     assert lib.arb_model_create(C.byref(desc), 0, C.byref(h)) == 1
     assert lib.arb_step(None, 0, None, None, None, None, 1, 1e-3, 1, 0, None) == 1
     assert lib.arb_step(None, 0, None, None, None, None, 0, 1e-3, 1, 0, None) == 1     # still needs a model
+    assert lib.arb_step_ex(None, 0, None, None) == 1
+    a = _capi.StepArgs()
+    a.nworlds, a.dt, a.nsteps = 1, 1e-3, 1
+    assert lib.arb_step_ex(None, 0, C.byref(a), None) == 1
     assert lib.arb_model_destroy(None) == 1
 
 

@@ -274,3 +274,36 @@ def test_shape_pair_scenarios(name):
     assert g[name + "_active"].any()                      # the contact really engages
     q, dq, _ = O.rollout(m, Q[:1], DQ[:1], [5e-3] * 40)
     close(q[0], Q[40], 1e-7)
+
+
+# -- G8 one PD controller per world ---------------------------------------------
+def test_pd_per_world_targets_and_gains():
+    """controllers.py:63-158 with a different controller in every world: each golden world is a
+    separate run of the reference with its own targets (and gains)."""
+    g = load_golden("g8_pd_per_world.npz")
+    m, _, _ = load_model("simplearm_pdw")
+    Q, DQ = g["arm_t_q"], g["arm_t_dq"]                       # (step, world, .)
+    q, dq = Q[0], DQ[0]
+    pd = dict(qdes=g["arm_t_qdes"], dqdes=g["arm_t_dqdes"])
+    for k in range(30):
+        q, dq, _ = O.step(m, q, dq, 5e-3, pd=pd)
+        close(q, Q[k + 1], 1e-9); close(dq, DQ[k + 1], 1e-9)
+    # world 0's targets are the model's own: without per-world input the oracle reproduces world 0
+    q0, dq0, _ = O.step(m, Q[0, :1], DQ[0, :1], 5e-3)
+    close(q0, Q[1, :1], 1e-12)
+    Q, DQ = g["arm_g_q"], g["arm_g_dq"]
+    q, dq = Q[0], DQ[0]
+    pd = dict(qdes=g["arm_g_qdes"], dqdes=g["arm_g_dqdes"], kp=g["arm_g_kp"], kd=g["arm_g_kd"])
+    for k in range(30):
+        q, dq, _ = O.step(m, q, dq, 5e-3, pd=pd)
+        close(q, Q[k + 1], 1e-9); close(dq, DQ[k + 1], 1e-9)
+
+
+def test_pd_per_world_human36_posture_servo():
+    g = load_golden("g8_pd_per_world.npz")
+    m, _, _ = load_model("human36_c4_pdw")
+    Q, DQ = g["h36_q"], g["h36_dq"]
+    pd = dict(qdes=g["h36_qdes"], dqdes=np.zeros_like(g["h36_qdes"]), kp=g["h36_kp"], kd=g["h36_kd"])
+    for k in range(12):
+        q, dq, _ = O.step(m, Q[k], DQ[k], 5e-3, pd=pd)
+        close(q, Q[k + 1], 1e-8); close(dq, DQ[k + 1], 1e-7)

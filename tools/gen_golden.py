@@ -525,10 +525,98 @@ def gen_shapes():
     save("g7_shapes.npz", **out)
 
 
+# ---- G8: one ProportionalDerivativeController per world (controllers.py:63-158) ----
+def gen_pd_per_world():
+    """Each 'world' is a separate run of the reference with its own PD targets (and gains)."""
+    from arboris.robots.simplearm import add_simplearm
+    out = {}
+    rng = np.random.RandomState(8)
+    dt, nsteps = 5e-3, 30
+
+    def arm(kp, kd, qdes, dqdes):
+        w = World()
+        add_simplearm(w)
+        w.register(WeightController())
+        js = [w.getjoints()[n] for n in ('Shoulder', 'Elbow', 'Wrist')]
+        w.register(ProportionalDerivativeController(js, kp, kd, qdes, dqdes))
+        w.init()
+        js[0].gpos[0] = 0.4; js[1].gpos[0] = -0.3; js[2].gpos[0] = 0.2
+        return w
+
+    def run(w, m):
+        qs, dqs = [], []
+        for k in range(nsteps):
+            a, b = get_state(w, m)
+            qs.append(a); dqs.append(b)
+            ref_step(w, dt)
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        return np.array(qs), np.array(dqs)
+
+    # (a) shared full gain matrices, per-world targets
+    A = rng.uniform(-1, 1, (3, 3)); KP = 30. * (A @ A.T + 3 * np.eye(3)) / 3.
+    A = rng.uniform(-1, 1, (3, 3)); KD = 2. * (A @ A.T + 3 * np.eye(3)) / 3.
+    W = 6
+    qdes, dqdes = rng.uniform(-1, 1, (W, 3)), rng.uniform(-0.5, 0.5, (W, 3))
+    Q, DQ = [], []
+    for i in range(W):
+        w = arm(KP, KD, qdes[i], dqdes[i])
+        if i == 0:
+            m = save_model("simplearm_pdw", w)
+        a, b = run(w, m)
+        Q.append(a); DQ.append(b)
+    out["arm_t_q"], out["arm_t_dq"] = np.array(Q).transpose(1, 0, 2), np.array(DQ).transpose(1, 0, 2)   # (step, world, .)
+    out["arm_t_qdes"], out["arm_t_dqdes"] = qdes, dqdes
+    # (b) per-world diagonal gains and targets
+    kp, kd = rng.uniform(5, 60, (W, 3)), rng.uniform(0.2, 4, (W, 3))
+    qdes, dqdes = rng.uniform(-1, 1, (W, 3)), rng.uniform(-0.5, 0.5, (W, 3))
+    Q, DQ = [], []
+    for i in range(W):
+        a, b = run(arm(np.diag(kp[i]), np.diag(kd[i]), qdes[i], dqdes[i]), m)
+        Q.append(a); DQ.append(b)
+    out["arm_g_q"], out["arm_g_dq"] = np.array(Q).transpose(1, 0, 2), np.array(DQ).transpose(1, 0, 2)
+    out["arm_g_kp"], out["arm_g_kd"], out["arm_g_qdes"], out["arm_g_dqdes"] = kp, kd, qdes, dqdes
+    # (c) human36 standing on 4 contacts, posture servo on every hinge, per-world posture targets
+    W = 3
+    n_h = None
+    Q, DQ, QD, KPs, KDs = [], [], [], [], []
+    for i in range(W):
+        w = human36_ref(contacts=4)
+        joints = [j for j in w.iterjoints() if not isinstance(j, FreeJoint)]
+        dofs = np.concatenate([np.arange(j.dof.start, j.dof.stop) for j in joints])
+        nd = len(dofs)
+        tq = rng.uniform(-0.3, 0.3, nd)
+        kpv, kdv = rng.uniform(100, 300, nd), rng.uniform(5, 20, nd)
+        # the reference's PD.update stacks joint.gpos arrays (controllers.py:147-153), which needs
+        # joints of equal ndof: one controller per joint size
+        for size in sorted(set(j.ndof for j in joints)):
+            grp = [j for j in joints if j.ndof == size]
+            sel = np.concatenate([np.flatnonzero(dofs == d) for j in grp for d in range(j.dof.start, j.dof.stop)])
+            w.register(ProportionalDerivativeController(grp, np.diag(kpv[sel]), np.diag(kdv[sel]), tq[sel],
+                                                        np.zeros(len(sel))))
+        w.init()
+        if i == 0:
+            mh = save_model("human36_c4_pdw", w)
+        a, b = [], []
+        for k in range(12):
+            x, y = get_state(w, mh)
+            a.append(x); b.append(y)
+            ref_step(w, dt)
+        x, y = get_state(w, mh)
+        a.append(x); b.append(y)
+        Q.append(np.array(a)); DQ.append(np.array(b))
+        full = np.zeros(mh.ndof); fullp = np.zeros(mh.ndof); fulld = np.zeros(mh.ndof)
+        full[dofs] = tq; fullp[dofs] = kpv; fulld[dofs] = kdv
+        QD.append(full); KPs.append(fullp); KDs.append(fulld)
+    out["h36_q"], out["h36_dq"] = np.array(Q).transpose(1, 0, 2), np.array(DQ).transpose(1, 0, 2)
+    out["h36_qdes"], out["h36_kp"], out["h36_kd"] = np.array(QD), np.array(KPs), np.array(KDs)
+    save("g8_pd_per_world.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world)
     for k in which:
         table[k]()
