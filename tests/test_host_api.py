@@ -223,3 +223,24 @@ def test_host_softfinger_solve_matches_captures():
             df = c.solve(g["solve_%s_vel" % branch][i].copy(), g["solve_%s_adm" % branch][i].copy(),
                          float(g["solve_%s_dt" % branch][i]))
             assert np.allclose(df, g["solve_%s_dforce" % branch][i], rtol=1e-9, atol=1e-9)
+
+
+def test_world_parse_order_and_scene_export(tmp_path):
+    """World.parse (core.py:562-606) visits the world in the reference's order -- the order the
+    Collada/OSG drawers rely on -- and the scene-graph exporter built on it round-trips to JSON."""
+    import json
+    from arboris_python_amd.exporters import ParseRecorder, export_scene
+    from conftest import load_golden
+    g = load_golden("g9_parse_order.npz")
+    for name, w in (("human36_c8", scenes.human36_world(8)), ("shapes_box_ball", scenes.shape_scenes()["box_ball"])):
+        rec = ParseRecorder()
+        w.parse(rec)
+        assert list(g[name]) == rec.calls, name
+    w = scenes.human36_world(4)
+    scene = export_scene(w, str(tmp_path / "scene.json"))
+    back = json.load(open(str(tmp_path / "scene.json")))
+    assert back["root"]["name"] == w.ground.name and len(back["constraints"]) == 4
+
+    def count(node):
+        return 1 + sum(count(l["child"]) for l in node["links"]) + sum(count(f) - 1 for f in node["frames"])
+    assert count(scene["root"]) == 1 + len(w.getbodies()) - 1

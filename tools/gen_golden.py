@@ -490,7 +490,7 @@ class _RefNS(object):
     pass
 
 
-def gen_shapes():
+def _ref_namespace():
     from arboris.core import SubFrame
     from arboris.shapes import Box, Sphere, Point
     from arboris.robots.simpleshapes import add_sphere
@@ -501,6 +501,11 @@ def gen_shapes():
     W.add_sphere, W.add_groundplane = add_sphere, add_groundplane
     W.WeightController, W.get_all_contacts, W.FreeJoint = WeightController, get_all_contacts, FreeJoint
     W.massmatrix = massmatrix
+    return W
+
+
+def gen_shapes():
+    W = _ref_namespace()
     out = {}
     dt = 5e-3
     for name, w in shape_scenes(W).items():
@@ -613,10 +618,22 @@ def gen_pd_per_world():
     save("g8_pd_per_world.npz", **out)
 
 
+# ---- G9: World.parse traversal order (core.py:562-606) ----
+def gen_parse_order():
+    from arboris_python_amd.exporters import ParseRecorder
+    out = {}
+    for name, w in (("human36_c8", human36_ref(contacts=8)), ("shapes_box_ball", shape_scenes(_ref_namespace())["box_ball"])):
+        rec = ParseRecorder()
+        w.parse(rec)
+        out[name] = np.array(rec.calls)
+        print("  %-16s %d hook calls" % (name, len(rec.calls)))
+    save("g9_parse_order.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order)
     for k in which:
         table[k]()

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_gpu.sh (gpurun_out/<dir>) into
+profiles/<tag>_summary.json + profiles/<tag>_kernel_stats.csv.
+
+usage: summarize_profile.py gpurun_out/<dir> <tag>
+"""
+import csv, glob, json, os, shutil, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {}
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(stats[0])))
+    out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+                           for r in rows[:4]]
+trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+if trace:
+    d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace[0]))
+         if "arb_step_kernel" in r["Kernel_Name"]]
+    d.sort()
+    ms = [(b - a) / 1e6 for a, b in d]
+    out["arb_step_kernel"] = dict(dispatches=len(ms), mean_ms_all=sum(ms) / len(ms),
+                                  mean_ms_timed_region_last80=sum(ms[-80:]) / len(ms[-80:]),
+                                  per_step_ms_first_cycle=[round(x, 3) for x in ms[:40]])
+pmc = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if "arb_step_kernel" not in r["Kernel_Name"]:
+            continue
+        a = acc.setdefault(r["Counter_Name"], [0.0, set()])
+        a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
+    for name, (tot, ids) in acc.items():
+        pmc[name] = dict(mean_per_launch=tot / len(ids), launches=len(ids))
+out["pmc_per_launch"] = pmc
+out["notes"] = ("bench.py human36 + 4 contacts, 4096 worlds, f32; kernel-trace pass: --steps 80 --warmup 10; "
+                "each --pmc group in its own pass (--steps 20 --warmup 2). FETCH_SIZE / WRITE_SIZE are in KiB "
+                "(rocprofv3 units), summed over the device's XCDs per dispatch.")
+json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "kernel_stats"}, indent=1)[:1500])
