@@ -235,13 +235,16 @@ def main():
     }
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh,
     # profiles/): only valid for the workload those passes were taken on
-    prof = os.path.join(ROOT, "profiles", "r01_final_summary.json")
+    import glob
+    profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))   # newest round last by name
+    profs = [f for f in profs if "baseline" not in f]
+    prof = profs[-1] if profs else ""
     if os.path.exists(prof) and args.contacts == 4 and B == 4096 and args.dtype == "f32":
         try:
             pm = json.load(open(prof))["pmc_per_launch"]
             res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
             res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
-                                               "(profiles/r01_final_summary.json); 4 B/lane accesses, reported uncorrected")
+                                               "(profiles/%s); 4 B/lane accesses, reported uncorrected" % os.path.basename(prof))
         except Exception:
             pass
     if gather_ms is not None:
