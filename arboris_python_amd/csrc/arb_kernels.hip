@@ -44,6 +44,7 @@
 // that it can fetch them with 13 vector LDS loads.
 #define BD_RCP 0     // R of Ad_cp (9)
 #define BD_PCP 9     // p of Ad_cp (3)
+#define BD_OM 12     // composite build: accumulated pseudo twist Om_b (6), see phase B  [overlays BD_DA]
 #define BD_DA 12     // A block of dAd_cp (9)
 #define BD_DB 21     // B block of dAd_cp (9) (+2 pad)
 #define BD_CM 32     // rx wx - wx rx (9), core.py:1287
@@ -55,6 +56,13 @@
 #define BD_TW 70     // body twist (6)
 #define BD_AB 76     // bias acceleration dJ_b * gvel (6)
 #define BD_STRIDE 84
+// Composite assembly of Z (phase B): per-body accumulators travelling up the tree, in float64:
+// A (36) | M upper triangle (21) | wrench of the increment rhs (6) | gravity wrench (6, inspect only)
+#ifndef ARB_COMPOSITE
+#define ARB_COMPOSITE 1
+#endif
+#define STG_STRIDE 70     // float64 slots per body in the level staging area (>= 69, even)
+#define XPR_STRIDE 18     // float64 per dof: X (6) | P = A^T X (6) | R = M X (6)
 
 // per-constraint block in LDS (elements)
 #define CD_R1 0      // transform body1 -> constraint frame: R (9), p (3)
@@ -83,6 +91,11 @@ struct DevModel {
     int has_visc, has_pd, has_warm, has_grav;
     const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *src, *sslot, *weighted;
     const int *dof2q, *att_start, *att_c, *att_kind;
+    // composite phase B: rank of a body among the bodies of its depth, bodies per depth, children lists,
+    // body of every dof, and per dof the dofs of ancestor-or-own / strictly descendant bodies
+    const int *lvlrank, *lvlwidth, *child_start, *child_list, *dofbody;
+    const unsigned long long *upmask, *descmask;
+    int stage_cap;
     const unsigned long long *anc;
     const int *bi;   // [nb][16] packed per-body ints for the phase-B loop: src, dof_off, jnd, sslot, att_start,
                      // att_end, anc lo/hi, parent's anc lo/hi (one scalar load per body instead of eight)
@@ -300,6 +313,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // (sdist) is a difference of O(1 m) positions that is then divided by dt, so
             // float32 rounding of the pose chain alone would cost ~1e-7/dt = 2e-5 m/s.
             M3<T> R_pc, R_cp, R_cn, dA_cp, dB_cp; V3<T> p_pc, p_cp, p_cn, Tnw, Tnv, Bnw, Bnv;
+            V3<T> Wcw = v3<T>(T(0), T(0), T(0)), Wcv = Wcw;      // W_c with dAd_cp = ad(W_c) Ad_cp (composite build)
             M3<double> R_pc_d = m3_identity<double>(); V3<double> p_pc_d = v3<double>(0., 0., 0.);
             R_pc = R_cp = R_cn = m3_identity<T>();
             dA_cp = dB_cp = m3_zero<T>();
@@ -344,7 +358,17 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const Blk<T> dAd_cp = blk_mul(Ad_cn, blk_mul(dAd_nr, Ad_rp));
                 T *bd = BD + b * BD_STRIDE;
                 st_m3(bd + BD_RCP, R_cp); st_v3(bd + BD_PCP, p_cp);
+#if !ARB_COMPOSITE
                 st_m3(bd + BD_DA, dAd_cp.A); st_m3(bd + BD_DB, dAd_cp.B);
+#else
+                {
+                    // dAd_cp = Ad_cn Ad_nr ad(T_rn) Ad_rp = ad(W_c) Ad_cp with W_c = Ad_cn Ad_nr T_rn, T_rn = -(aw, av)
+                    const V3<T> nw = -mv(R_nr, aw);
+                    const V3<T> nv = cross(p_nr, nw) - mv(R_nr, av);
+                    Wcw = mv(R_cn, nw);
+                    Wcv = cross(p_cn, Wcw) + mv(R_cn, nv);
+                }
+#endif
                 dA_cp = dAd_cp.A; dB_cp = dAd_cp.B;
                 // Ad_cn (dJ_nr gvel_j): the joint's own contribution to dJ_c gvel
                 {
@@ -387,12 +411,15 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             for (int lvl = 0; lvl <= mp->maxdepth; ++lvl) {
                 if (on && dep == lvl) {
                     M3<double> Rg = m3_identity<double>(); V3<double> pg = v3<double>(0., 0., 0.);
-                    V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw;
+                    V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw, ow = tw, ov = tw;
                     if (par >= 0) {
                         const T *pb = BD + par * BD_STRIDE;
                         Rg = ld_m3(PD + 12 * par); pg = ld_v3(PD + 12 * par + 9);
                         tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
                         aw = ld_v3(pb + BD_AB); av = ld_v3(pb + BD_AB + 3);
+#if ARB_COMPOSITE
+                        ow = ld_v3(pb + BD_OM); ov = ld_v3(pb + BD_OM + 3);
+#endif
                     }
                     const M3<double> Rc_d = mul(Rg, R_pc_d);         // child_pose  core.py:1299
                     const V3<double> pc_d = mv(Rg, p_pc_d) + pg;
@@ -409,6 +436,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<T> nbw = mv(dA_cp, tw) + raw + Bnw;
                     const V3<T> nbv = mv(dB_cp, tw) + mv(dA_cp, tv) + cross(p_cp, raw) + mv(R_cp, av) + Bnv;
                     st_v3(bd + BD_AB, nbw); st_v3(bd + BD_AB + 3, nbv);
+#if ARB_COMPOSITE
+                    // accumulated pseudo twist: Om_c = Ad_cp Om_p + W_c  (dJ_b = Ad(b<-g) (dX' + ad(Om_b^g) X), phase B)
+                    const V3<T> rw = mv(R_cp, ow);
+                    st_v3(bd + BD_OM, rw + Wcw);
+                    st_v3(bd + BD_OM + 3, cross(p_cp, rw) + mv(R_cp, ov) + Wcv);
+#endif
                 }
                 WAVE_SYNC();
             }
@@ -551,8 +584,15 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const T vz0 = (mv(R0, bv0) + cross(P0, mv(R0, bw0))).z;
                     const T dsd = vz1 - vz0;
                     active = ((double)sd_d + (double)dsd * (double)dt < (double)mp->cprox[c]);
+#if ARB_COMPOSITE
+                    {   // phase B works on world-axes columns about the root body's origin: store world -> contact frame 0
+                        const V3<double> p0w = ld_v3(PD + 9);
+                        st_m3(cd + CD_R1, cvt_m3<T>(transpose(Rc))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(Rc, gc0 - p0w)));
+                    }
+#else
                     st_m3(cd + CD_R1, R1); st_v3(cd + CD_P1, P1);
                     st_m3(cd + CD_R0, R0); st_v3(cd + CD_P0, P0);
+#endif
                     st_v3(cd + CD_GC0, cvt_v3<T>(gc0)); st_v3(cd + CD_GC1, cvt_v3<T>(gc1));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
@@ -575,8 +615,15 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<double> pP1 = mv(Rg1, pf1) + pg1;
                     st_v3(cd + CD_POS0, cvt_v3<T>(mtv(RP0, pP1 - pP0)));  // p_01  constraints.py:196-197
                     // body1 -> frame 0: Ad(inv(P0) H_gb1);  body0 -> frame 0: Ad(inv(bpose0))
+#if ARB_COMPOSITE
+                    {
+                        const V3<double> p0w = ld_v3(PD + 9);
+                        st_m3(cd + CD_R1, cvt_m3<T>(transpose(RP0))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(RP0, pP0 - p0w)));
+                    }
+#else
                     st_m3(cd + CD_R1, cvt_m3<T>(mulTA(RP0, Rg1))); st_v3(cd + CD_P1, cvt_v3<T>(mtv(RP0, pg1 - pP0)));
                     st_m3(cd + CD_R0, cvt_m3<T>(transpose(Rf0))); st_v3(cd + CD_P0, cvt_v3<T>(-mtv(Rf0, pf0)));
+#endif
                     active = true;
                 }
             }
@@ -594,6 +641,304 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) Z[i] = T(0);
         T rhsM = T(0), rhsG = T(0);
+#if ARB_COMPOSITE
+        // ---- composite assembly ---------------------------------------------------------------------
+        // With X_k = Ad(g<-body(k)) S_k the column of dof k in WORLD axes (about the root body's
+        // origin; the same vector for every body below the joint), the reference's sums over bodies
+        // (core.py:722-734) become sums over subtrees of per-body 6x6 matrices:
+        //     Z[i][k] = X_i . (Ac_a X_k + Mc_a dX'_k),   a = the deeper of body(i), body(k)
+        //     A_b  = Mg/dt - ad(T*_b)^T Mg + Mg ad(Om_b) + Bg,  Mg = Ad^T M_b Ad,  T*_b = [w; c x w]
+        //     dX'_k = Ad(g<-b)(dS_k - ad(Om_b) S_k),  Ac_a = sum of A_b over the subtree of a (Mc_a likewise)
+        // where Om_b is the accumulated pseudo twist of phase A (the reference's dAd_cp is ad(W_c) Ad_cp
+        // with W_c != minus the relative twist for multi-dof joints, so Om_b != -V_b; tools/composite_proto.py
+        // checks these identities against the oracle).  All of it in float64: the world-frame matrices of
+        // distal bodies are small differences of large numbers.
+        {
+            constexpr int NACC = (MODE == 1) ? 69 : 63;
+            double Acc[NACC];
+            T om_b[6];
+            double *STG = reinterpret_cast<double *>(BD);
+            const V3<double> p0w = ld_v3(PD + 9);
+            const bool useM = (MODE == 0) || zmode == 0 || zmode == 1;     // mass term of Z
+            const bool useN = (MODE == 0) || zmode == 0 || zmode == 3;     // N (incl. the M dJ part)
+            const bool useB = (MODE == 0) || zmode == 0 || zmode == 2;     // viscosity
+            const double cM = (MODE == 1 && zmode == 1) ? 1. : (double)inv_dt;
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) Acc[i] = 0.;
+            T twb[6], ptb[6], pgb[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { om_b[i] = T(0); twb[i] = T(0); ptb[i] = T(0); pgb[i] = T(0); }
+            if (lane < nb) {
+                const T *bd = BD + lane * BD_STRIDE;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { twb[i] = bd[BD_TW + i]; om_b[i] = bd[BD_OM + i]; ptb[i] = bd[BD_PT + i]; pgb[i] = bd[BD_PG + i]; }
+            }
+            WAVE_SYNC();                       // the per-body blocks are dead from here: the region becomes STG
+            // ---- lane = body: world-frame matrices of the body -----------------------------------
+            if (lane < nb) {
+                const int b = lane;
+                const M3<double> R = ld_m3(PD + 12 * b);
+                const V3<double> p = ld_v3(PD + 12 * b + 9) - p0w;
+                const T *Mb = mp->mass + 36 * b;
+                auto blk = [](const T *m6, int r0, int c0) {
+                    M3<double> o;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) o.a[3 * i + j] = (double)m6[6 * (r0 + i) + c0 + j];
+                    return o;
+                };
+                auto rot = [&](const M3<double> &Xm) { return mul(R, mulBT(Xm, R)); };       // R X R^T
+                auto rowcross = [](const M3<double> &Xm, V3<double> v) {                      // X v^
+                    M3<double> o;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const V3<double> c = cross(v3<double>(Xm.a[3 * i], Xm.a[3 * i + 1], Xm.a[3 * i + 2]), v);
+                        o.a[3 * i] = c.x; o.a[3 * i + 1] = c.y; o.a[3 * i + 2] = c.z;
+                    }
+                    return o;
+                };
+                double G[36];                  // Mg = Ad(b<-g)^T M_b Ad(b<-g), symmetric
+                {
+                    const M3<double> M11 = rot(blk(Mb, 0, 0)), M12 = rot(blk(Mb, 0, 3)), M22 = rot(blk(Mb, 3, 3));
+                    const M3<double> G12 = add(M12, hatmul(p, M22));
+                    const M3<double> G21 = transpose(G12);
+                    const M3<double> G11 = add(sub(M11, rowcross(M12, p)), hatmul(p, G21));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            G[6 * i + j] = G11.a[3 * i + j]; G[6 * i + 3 + j] = G12.a[3 * i + j];
+                            G[6 * (3 + i) + j] = G21.a[3 * i + j]; G[6 * (3 + i) + 3 + j] = M22.a[3 * i + j];
+                        }
+                }
+                // T* = [w; c x w] (c = centre of mass, core.py:1276-1288) and Om, both in world axes
+                const V3<double> wb = v3<double>((double)twb[0], (double)twb[1], (double)twb[2]);
+                const double mm = (double)Mb[21];
+                V3<double> cm = v3<double>(0., 0., 0.);
+                if (!(mm <= 1e-10)) cm = (1. / mm) * v3<double>((double)Mb[6 * 2 + 4], (double)Mb[6 * 0 + 5], (double)Mb[6 * 1 + 3]);
+                const V3<double> Tw = mv(R, wb);
+                const V3<double> Tv = mv(R, cross(cm, wb)) + cross(p, Tw);
+                const V3<double> ow = mv(R, v3<double>((double)om_b[0], (double)om_b[1], (double)om_b[2]));
+                const V3<double> ov = mv(R, v3<double>((double)om_b[3], (double)om_b[4], (double)om_b[5])) + cross(p, ow);
+#pragma unroll
+                for (int i = 0; i < 36; ++i) Acc[i] = useM ? cM * G[i] : 0.;
+                if (useN) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {                        // -ad(T*)^T Mg, column by column
+                        const V3<double> gt = v3<double>(G[j], G[6 + j], G[12 + j]), gb = v3<double>(G[18 + j], G[24 + j], G[30 + j]);
+                        const V3<double> t = cross(Tw, gt) + cross(Tv, gb), u = cross(Tw, gb);
+                        Acc[j] += t.x; Acc[6 + j] += t.y; Acc[12 + j] += t.z;
+                        Acc[18 + j] += u.x; Acc[24 + j] += u.y; Acc[30 + j] += u.z;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {                        // Mg ad(Om), row by row
+                        const V3<double> gl = v3<double>(G[6 * r], G[6 * r + 1], G[6 * r + 2]), gr = v3<double>(G[6 * r + 3], G[6 * r + 4], G[6 * r + 5]);
+                        const V3<double> t = cross(gl, ow) + cross(gr, ov), u = cross(gr, ow);
+                        Acc[6 * r] += t.x; Acc[6 * r + 1] += t.y; Acc[6 * r + 2] += t.z;
+                        Acc[6 * r + 3] += u.x; Acc[6 * r + 4] += u.y; Acc[6 * r + 5] += u.z;
+                    }
+                }
+                if (mp->has_visc && useB) {                              // Bg = Ad^T B_b Ad (general 6x6)
+                    const T *Vb = mp->visc + 36 * b;
+                    const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
+                    const M3<double> H12 = add(B12, hatmul(p, B22));
+                    const M3<double> H21 = sub(B21, rowcross(B22, p));
+                    const M3<double> H11 = add(sub(B11, rowcross(B12, p)), hatmul(p, H21));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            Acc[6 * i + j] += H11.a[3 * i + j]; Acc[6 * i + 3 + j] += H12.a[3 * i + j];
+                            Acc[6 * (3 + i) + j] += H21.a[3 * i + j]; Acc[6 * (3 + i) + 3 + j] += B22.a[3 * i + j];
+                        }
+                }
+                {
+                    int t = 36;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int c2 = r; c2 < 6; ++c2) Acc[t++] = useN ? G[6 * r + c2] : 0.;
+                }
+                // wrenches to world axes: Ad(b<-g)^T f = (R tau + p x R f, R f)
+                {
+                    const V3<double> f = mv(R, v3<double>((double)ptb[3], (double)ptb[4], (double)ptb[5]));
+                    const V3<double> tq = mv(R, v3<double>((double)ptb[0], (double)ptb[1], (double)ptb[2])) + cross(p, f);
+                    Acc[57] = tq.x; Acc[58] = tq.y; Acc[59] = tq.z; Acc[60] = f.x; Acc[61] = f.y; Acc[62] = f.z;
+                }
+                if (MODE == 1) {
+                    const V3<double> f = mv(R, v3<double>((double)pgb[3], (double)pgb[4], (double)pgb[5]));
+                    const V3<double> tq = mv(R, v3<double>((double)pgb[0], (double)pgb[1], (double)pgb[2])) + cross(p, f);
+                    Acc[NACC - 6] = tq.x; Acc[NACC - 5] = tq.y; Acc[NACC - 4] = tq.z; Acc[NACC - 3] = f.x; Acc[NACC - 2] = f.y; Acc[NACC - 1] = f.z;
+                }
+            }
+            // ---- subtree sums, deepest level first; children hand their sums over through STG ------
+            {
+                typedef double D2 __attribute__((ext_vector_type(2)));
+                const int mydep = (lane < nb) ? mp->depth[lane] : -1;
+                const int myrank = (lane < nb) ? mp->lvlrank[lane] : 0;
+                const int cs = (lane < nb) ? mp->child_start[lane] : 0;
+                const int cn = (lane < nb) ? mp->child_start[lane + 1] - cs : 0;
+                const int cap = mp->stage_cap;
+                for (int lvl = mp->maxdepth; lvl >= 1; --lvl) {
+                    const int width = mp->lvlwidth[lvl];
+                    for (int s0 = 0; s0 < width; s0 += cap) {
+                        if (mydep == lvl && myrank >= s0 && myrank < s0 + cap) {
+                            D2 *o = reinterpret_cast<D2 *>(STG + (myrank - s0) * STG_STRIDE);
+#pragma unroll
+                            for (int i = 0; i < NACC / 2; ++i) { D2 v; v.x = Acc[2 * i]; v.y = Acc[2 * i + 1]; o[i] = v; }
+                            if (NACC & 1) STG[(myrank - s0) * STG_STRIDE + NACC - 1] = Acc[NACC - 1];
+                        }
+                        WAVE_SYNC();
+                        if (mydep == lvl - 1) {
+                            for (int j = 0; j < cn; ++j) {
+                                const int r = mp->lvlrank[mp->child_list[cs + j]];
+                                if (r < s0 || r >= s0 + cap) continue;
+                                const D2 *in = reinterpret_cast<const D2 *>(STG + (r - s0) * STG_STRIDE);
+#pragma unroll
+                                for (int i = 0; i < NACC / 2; ++i) { const D2 v = in[i]; Acc[2 * i] += v.x; Acc[2 * i + 1] += v.y; }
+                                if (NACC & 1) Acc[NACC - 1] += STG[(r - s0) * STG_STRIDE + NACC - 1];
+                            }
+                        }
+                        WAVE_SYNC();
+                    }
+                }
+            }
+            // ---- lane = dof k: fetch the composites of body(k), own column, the three products -----
+            const int bsrc = (lane < n) ? mp->dofbody[lane] : 0;
+            double Xk[6], dXk[6], Gk[6];
+            {
+                // in place: from here on Acc holds the composites of body(k), not of body(lane)
+#pragma unroll
+                for (int i = 0; i < NACC; ++i) Acc[i] = __shfl(Acc[i], bsrc);
+                double (&Cc)[NACC] = Acc;
+                T omk[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) omk[i] = __shfl(om_b[i], bsrc);
+                const M3<double> R = ld_m3(PD + 12 * bsrc);
+                const V3<double> p = ld_v3(PD + 12 * bsrc + 9) - p0w;
+                const int kc = lane < RS ? lane : 0;
+                const V3<double> sw = v3<double>((double)SC[0 * RS + kc], (double)SC[1 * RS + kc], (double)SC[2 * RS + kc]);
+                const V3<double> sv = v3<double>((double)SC[3 * RS + kc], (double)SC[4 * RS + kc], (double)SC[5 * RS + kc]);
+                const V3<double> dsw = v3<double>((double)SC[6 * RS + kc], (double)SC[7 * RS + kc], (double)SC[8 * RS + kc]);
+                const V3<double> dsv = v3<double>((double)SC[9 * RS + kc], (double)SC[10 * RS + kc], (double)SC[11 * RS + kc]);
+                const V3<double> okw = v3<double>((double)omk[0], (double)omk[1], (double)omk[2]);
+                const V3<double> okv = v3<double>((double)omk[3], (double)omk[4], (double)omk[5]);
+                const V3<double> xw = mv(R, sw);
+                const V3<double> xv = mv(R, sv) + cross(p, xw);
+                const V3<double> aw2 = dsw - cross(okw, sw);                          // dS - ad(Om) S
+                const V3<double> av2 = dsv - cross(okv, sw) - cross(okw, sv);
+                const V3<double> dw = mv(R, aw2);
+                const V3<double> dv = mv(R, av2) + cross(p, dw);
+                Xk[0] = xw.x; Xk[1] = xw.y; Xk[2] = xw.z; Xk[3] = xv.x; Xk[4] = xv.y; Xk[5] = xv.z;
+                dXk[0] = dw.x; dXk[1] = dw.y; dXk[2] = dw.z; dXk[3] = dv.x; dXk[4] = dv.y; dXk[5] = dv.z;
+                if (lane >= n) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { Xk[i] = 0.; dXk[i] = 0.; }
+                }
+                double Ms[36];                 // symmetric composite inertia, unpacked
+                {
+                    int t = 36;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int c2 = r; c2 < 6; ++c2) { Ms[6 * r + c2] = Cc[t]; Ms[6 * c2 + r] = Cc[t]; ++t; }
+                }
+                double Pk[6], Rk[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double g = 0., pp = 0., rr = 0., md = 0.;
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; ++c2) {
+                        g += Cc[6 * r + c2] * Xk[c2];           // A X
+                        pp += Cc[6 * c2 + r] * Xk[c2];          // A^T X
+                        rr += Ms[6 * r + c2] * Xk[c2];          // M X
+                        md += Ms[6 * r + c2] * dXk[c2];         // M dX'
+                    }
+                    Gk[r] = g + md; Pk[r] = pp; Rk[r] = rr;
+                }
+                double rm = 0., rg = 0.;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { rm += Xk[i] * Cc[57 + i]; if (MODE == 1) rg += Xk[i] * Cc[NACC - 6 + i]; }
+                rhsM = (lane < n) ? (T)rm : T(0);
+                rhsG = (MODE == 1 && lane < n) ? (T)rg : T(0);
+                WAVE_SYNC();                   // every lane is done with the staging area: it becomes XPR
+                if (lane < n) {
+                    double *o = STG + XPR_STRIDE * lane;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { o[i] = Xk[i]; o[6 + i] = Pk[i]; o[12 + i] = Rk[i]; }
+                }
+                WAVE_SYNC();
+            }
+            // ---- lane = column k: rows of Z ----------------------------------------------------------
+            {
+                typedef double D2 __attribute__((ext_vector_type(2)));
+                const unsigned long long up = (lane < n) ? mp->upmask[lane] : 0ull;
+                const unsigned long long dn = (lane < n) ? mp->descmask[lane] : 0ull;
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) {
+                    if (i < n) {
+                        const D2 *xi = reinterpret_cast<const D2 *>(STG + XPR_STRIDE * i);   // wave-uniform: broadcast reads
+                        double tu = 0., td = 0.;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const D2 a = xi[j], pq = xi[3 + j], rq = xi[6 + j];
+                            tu += a.x * Gk[2 * j] + a.y * Gk[2 * j + 1];
+                            td += pq.x * Xk[2 * j] + pq.y * Xk[2 * j + 1] + rq.x * dXk[2 * j] + rq.y * dXk[2 * j + 1];
+                        }
+                        Z[i] = (T)(((up >> i) & 1ull) ? tu : (((dn >> i) & 1ull) ? td : 0.));
+                    } else {
+                        Z[i] = T(0);
+                    }
+                }
+            }
+            // ---- constraint rows: s_k [Ad(c0<-g) X_k] with s_k = [k above body 1] - [k above body 0] --
+            if (do_constraints) {
+                for (int c = 0; c < nc; ++c) {
+                    const int ct = mp->ctype[c];
+                    if (ct == ARB_CT_JOINTLIMITS) continue;
+                    const T *cd = CD + c * CD_STRIDE;
+                    const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
+                    const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
+                    const double s = (double)cd[CD_ACTIVE] * ((double)((a1 >> lane) & 1ull) - (double)((a0 >> lane) & 1ull));
+                    const M3<double> Rx = ld_m3_as<double>(cd + CD_R1);
+                    const V3<double> px = cvt_v3<double>(ld_v3(cd + CD_P1));
+                    const V3<double> cw = mv(Rx, v3<double>(Xk[0], Xk[1], Xk[2]));
+                    const V3<double> cv = mv(Rx, v3<double>(Xk[3], Xk[4], Xk[5])) + cross(px, cw);
+                    if (lane < n) {
+                        T *row = RT + (1 + 4 * c) * RS + lane;
+                        if (ct == ARB_CT_SOFTFINGER) {          // rows (w_z, v_x, v_y, v_z)        constraints.py:429-433
+                            row[0] = (T)(s * cw.z); row[RS] = (T)(s * cv.x); row[2 * RS] = (T)(s * cv.y); row[3 * RS] = (T)(s * cv.z);
+                        } else {                                // BallAndSocket linear rows         constraints.py:203-207
+                            row[0] = (T)(s * cv.x); row[RS] = (T)(s * cv.y); row[2 * RS] = (T)(s * cv.z);
+                        }
+                    }
+                }
+            }
+            // ---- inspect: body Jacobians J_b = Ad(b<-g) X, dJ_b = Ad(b<-g) dX' + ad(Om_b) J_b -----------
+            if (MODE == 1 && step == 0 && (dbg.jac != nullptr || dbg.djac != nullptr)) {
+                for (int b = 0; b < nb; ++b) {
+                    const M3<double> R = ld_m3(PD + 12 * b);
+                    const V3<double> p = ld_v3(PD + 12 * b + 9) - p0w;
+                    const V3<double> obw = v3<double>((double)bcast(om_b[0], b), (double)bcast(om_b[1], b), (double)bcast(om_b[2], b));
+                    const V3<double> obv = v3<double>((double)bcast(om_b[3], b), (double)bcast(om_b[4], b), (double)bcast(om_b[5], b));
+                    const bool mine = (lane < n) && ((mp->anc[b] >> lane) & 1ull);
+                    const V3<double> xw = v3<double>(Xk[0], Xk[1], Xk[2]), xv = v3<double>(Xk[3], Xk[4], Xk[5]);
+                    const V3<double> dw = v3<double>(dXk[0], dXk[1], dXk[2]), dv = v3<double>(dXk[3], dXk[4], dXk[5]);
+                    const V3<double> jw = mtv(R, xw), jv = mtv(R, xv - cross(p, xw));
+                    const V3<double> ew = mtv(R, dw) + cross(obw, jw);
+                    const V3<double> ev = mtv(R, dv - cross(p, dw)) + cross(obv, jw) + cross(obw, jv);
+                    if (lane < n) {
+                        const double j6[6] = {jw.x, jw.y, jw.z, jv.x, jv.y, jv.z}, e6[6] = {ew.x, ew.y, ew.z, ev.x, ev.y, ev.z};
+                        for (int i = 0; i < 6; ++i) {
+                            if (dbg.jac != nullptr) dbg.jac[((w * nb + b) * 6 + i) * n + lane] = mine ? (T)j6[i] : T(0);
+                            if (dbg.djac != nullptr) dbg.djac[((w * nb + b) * 6 + i) * n + lane] = mine ? (T)e6[i] : T(0);
+                        }
+                    }
+                }
+            }
+        }
+#else
         {
             T Jw[3] = {T(0), T(0), T(0)}, Jv[3] = {T(0), T(0), T(0)};
             T dJw[3] = {T(0), T(0), T(0)}, dJv[3] = {T(0), T(0), T(0)};
@@ -754,6 +1099,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
             }
         }
+#endif
         // joint-limit rows are dof selectors                              constraints.py:46-48
         if (do_constraints) {
             for (int c = 0; c < nc; ++c)
@@ -815,8 +1161,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         for (int i = 0; i < 3; ++i) {
                             for (int j = 0; j < 3; ++j) {
                                 double acc = 0.;
+#if ARB_COMPOSITE
+                                acc = (double)cd[CD_R1 + 3 * j + i];          // CD_R1 holds Rc^T
+#else
                                 for (int k = 0; k < 3; ++k)
                                     acc += (b1 >= 0 ? PD[12 * b1 + 3 * i + k] : (i == k ? 1. : 0.)) * (double)cd[CD_R1 + 3 * j + k];
+#endif
                                 o[4 * i + j] = (T)acc;
                             }
                             o[4 * i + 3] = cd[(f ? CD_GC1 : CD_GC0) + i];
@@ -1352,17 +1702,37 @@ static std::vector<double> h12(const double *H16, int count) {
     return v;
 }
 
-static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot_elems, int rs, int elems_per_double, int *total_elems) {
+// Size (in elements of T) of the per-body block region.  In the composite build the region is
+// reused, once phase A' is over, as float64 scratch: the level staging area of the tree
+// accumulation (stage_cap bodies x STG_STRIDE) and then the per-dof X | P | R vectors.
+static int bd_region_elems(int nb, int rs, int elems_per_double, int maxwidth, int *stage_cap) {
+    auto al = [](int x) { return (x + 3) & ~3; };
+    int sz = al(nb * BD_STRIDE);
+#if ARB_COMPOSITE
+    sz = std::max(sz, al(XPR_STRIDE * rs * elems_per_double));
+    sz = std::max(sz, al(STG_STRIDE * elems_per_double));
+    *stage_cap = std::max(1, std::min(maxwidth, sz / (STG_STRIDE * elems_per_double)));
+#else
+    *stage_cap = 1;
+#endif
+    return sz;
+}
+
+static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot_elems, int rs, int elems_per_double, int maxwidth, int *total_elems) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
+    int cap;
     L.q = o; o += al(nq);
     L.dq = o; o += WAVE;
     L.qd = o; o += WAVE;
-    L.bd = o; o += al(nb * BD_STRIDE);
+    L.bd = o; o += bd_region_elems(nb, rs, elems_per_double, maxwidth, &cap);
+#if ARB_COMPOSITE
+    nslots = 0; slot_elems = 4;          // no Jacobian propagation: no parking slots
+#endif
     L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
     L.sc = o; o += 12 * rs;
-    L.jb = o; o += 8 * rs;
+    L.jb = o; o += ARB_COMPOSITE ? 4 : 8 * rs;
     L.slots = o; o += al(std::max(nslots, 1) * std::max(slot_elems, 12));
     L.cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
     L.rt = o; o += (1 + ndol) * rs;
@@ -1375,6 +1745,12 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot
     *total_elems = o;
     return L;
 }
+
+struct TreeTables {
+    std::vector<int> lvlrank, lvlwidth, child_start, child_list, dofbody;
+    std::vector<unsigned long long> upmask, descmask;
+    int maxwidth;
+};
 
 // zaligned(normal), arboris/homogeneousmatrix.py:201-232 (constant for a contact plane)
 static void zaligned_host(const double z[3], double R[9]) {
@@ -1395,7 +1771,7 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
                      const std::vector<int> &sslot, const std::vector<unsigned long long> &anc,
                      const std::vector<int> &dof2q, const std::vector<int> &att_start,
                      const std::vector<int> &att_c, const std::vector<int> &att_kind,
-                     int maxdepth, int nslots, int slot_elems, DevModel<T> *out) {
+                     int maxdepth, int nslots, int slot_elems, const TreeTables &tt, DevModel<T> *out) {
     DevModel<T> m;
     memset(&m, 0, sizeof(m));
     const int nb = d->nb, n = d->ndof, nc = d->nc;
@@ -1412,6 +1788,15 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     UP_I(depth, depth); UP_I(src, src); UP_I(sslot, sslot);
     UP_I(weighted, std::vector<int>(d->weighted, d->weighted + nb));
     UP_I(dof2q, dof2q); UP_I(att_start, att_start); UP_I(att_c, att_c); UP_I(att_kind, att_kind);
+    UP_I(lvlrank, tt.lvlrank); UP_I(lvlwidth, tt.lvlwidth); UP_I(child_start, tt.child_start);
+    UP_I(child_list, tt.child_list); UP_I(dofbody, tt.dofbody);
+    if ((rc = upload<unsigned long long>(M, tt.upmask, &m.upmask)) != ARB_OK) return rc;
+    if ((rc = upload<unsigned long long>(M, tt.descmask, &m.descmask)) != ARB_OK) return rc;
+    {
+        int cap;
+        (void)bd_region_elems(nb, M->nmax, sizeof(T) == 4 ? 2 : 1, tt.maxwidth, &cap);
+        m.stage_cap = cap;
+    }
     if ((rc = upload<unsigned long long>(M, anc, &m.anc)) != ARB_OK) return rc;
     {
         std::vector<int> bi(16 * (size_t)nb, 0);
@@ -1568,6 +1953,40 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
             for (int i = 0; i < jnd[b]; ++i) dof2q[d->dof_off[b] + i] = d->q_off[b] + i;
     }
     if (ndof_chk != n || nq_chk != d->nq) return ARB_ERR_INVALID;
+    // composite phase B tables
+    TreeTables tt;
+    tt.lvlrank.assign(nb, 0); tt.lvlwidth.assign(maxdepth + 1, 0); tt.child_start.assign(nb + 1, 0);
+    tt.dofbody.assign(n, 0); tt.upmask.assign(n, 0ull); tt.descmask.assign(n, 0ull);
+    for (int b = 0; b < nb; ++b) tt.lvlrank[b] = tt.lvlwidth[depth[b]]++;
+    for (int b = 0; b < nb; ++b) {
+        tt.child_start[b] = (int)tt.child_list.size();
+        for (int c2 = b + 1; c2 < nb; ++c2) if (d->parent[c2] == b) tt.child_list.push_back(c2);
+    }
+    tt.child_start[nb] = (int)tt.child_list.size();
+    tt.maxwidth = *std::max_element(tt.lvlwidth.begin(), tt.lvlwidth.end());
+    for (int b = 0; b < nb; ++b)
+        for (int i = 0; i < jnd[b]; ++i) { tt.dofbody[d->dof_off[b] + i] = b; tt.upmask[d->dof_off[b] + i] = anc[b]; }
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < n; ++i)
+            if (((anc[tt.dofbody[i]] >> k) & 1ull) && tt.dofbody[i] != tt.dofbody[k]) tt.descmask[k] |= 1ull << i;
+    const int maxwidth = tt.maxwidth;
+#if ARB_COMPOSITE
+    // The composite assembly writes N_b as -ad([w; c x w])^T M_b, which needs rigid-body mass matrices
+    // [[I, m c^],[m c^T, m 1]] (everything arboris/massmatrix.py builds); anything else is refused.
+    for (int b = 0; b < nb; ++b) {
+        const double *Mb = d->mass + 36 * b;
+        double sc = 0.;
+        for (int i = 0; i < 36; ++i) sc = std::max(sc, std::fabs(Mb[i]));
+        const double tol = 1e-9 * std::max(sc, 1e-300);
+        bool ok = true;
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) ok = ok && std::fabs(Mb[6 * i + j] - Mb[6 * j + i]) <= tol;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            ok = ok && std::fabs(Mb[6 * (3 + i) + 3 + j] - (i == j ? Mb[21] : 0.)) <= tol;       // m 1
+            ok = ok && std::fabs(Mb[6 * i + 3 + j] + Mb[6 * j + 3 + i]) <= tol;                  // m c^ skew
+        }
+        if (!ok) return ARB_ERR_UNSUPPORTED;
+    }
+#endif
     // Jacobian save slots: a body whose columns are needed again after its first
     // child's subtree keeps them in an LDS slot for the lifetime [b, lastchild[b]]
     std::vector<int> slot_owner;
@@ -1626,9 +2045,9 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete M; return ARB_ERR_HIP; }
-    int rc = build_dev<float>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, &M->df);
+    int rc = build_dev<float>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, tt, &M->df);
     if (rc == ARB_OK)
-        rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, &M->dd);
+        rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, tt, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     {
         const DevModel<float> *pf = nullptr; const DevModel<double> *pd = nullptr;
@@ -1638,8 +2057,8 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         M->df_dev = const_cast<DevModel<float> *>(pf); M->dd_dev = const_cast<DevModel<double> *>(pd);
     }
     int tot;
-    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 2, &tot);
-    M->ld = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 1, &tot);
+    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 2, maxwidth, &tot);
+    M->ld = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 1, maxwidth, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     *out = M;
     return ARB_OK;
