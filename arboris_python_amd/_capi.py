@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libarbstep.so")
+if os.environ.get("ARBSTEP_LIB"):                 # development: load a differently built library
+    LIB_PATH = os.environ["ARBSTEP_LIB"]
 
 ARB_ABI_VERSION = 3
 ARB_OK = 0

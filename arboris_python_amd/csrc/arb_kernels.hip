@@ -42,9 +42,21 @@
 
 // per-body block in LDS (elements).  The fields phase B reads are first, 16-byte aligned, so
 // that it can fetch them with 13 vector LDS loads.
+#ifndef ARB_COMPOSITE
+#define ARB_COMPOSITE 1   // phase B: composite (subtree-sum) assembly; 0 = body-by-body accumulation of the first rounds
+#endif
 #define BD_RCP 0     // R of Ad_cp (9)
 #define BD_PCP 9     // p of Ad_cp (3)
-#define BD_OM 12     // composite build: accumulated pseudo twist Om_b (6), see phase B  [overlays BD_DA]
+#if ARB_COMPOSITE
+#define BD_OM 12     // W_c, then the accumulated pseudo twist Om_b (6), see phase B
+#define BD_PT 18     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form
+#define BD_PG 24     // M_b g_b (6)
+#define BD_RG 30     // R of H_gb (9)
+#define BD_PGB 39    // p of H_gb (3)
+#define BD_TW 42     // body twist (6)
+#define BD_AB 48     // bias acceleration dJ_b * gvel (6)
+#define BD_STRIDE 54
+#else
 #define BD_DA 12     // A block of dAd_cp (9)
 #define BD_DB 21     // B block of dAd_cp (9) (+2 pad)
 #define BD_CM 32     // rx wx - wx rx (9), core.py:1287
@@ -56,11 +68,9 @@
 #define BD_TW 70     // body twist (6)
 #define BD_AB 76     // bias acceleration dJ_b * gvel (6)
 #define BD_STRIDE 84
+#endif
 // Composite assembly of Z (phase B): per-body accumulators travelling up the tree, in float64:
 // A (36) | M upper triangle (21) | wrench of the increment rhs (6) | gravity wrench (6, inspect only)
-#ifndef ARB_COMPOSITE
-#define ARB_COMPOSITE 1
-#endif
 #define STG_STRIDE 70     // float64 slots per body in the level staging area (>= 69, even)
 #define XPR_STRIDE 18     // float64 per dof: X (6) | P = A^T X (6) | R = M X (6)
 
@@ -93,7 +103,7 @@ struct DevModel {
     const int *dof2q, *att_start, *att_c, *att_kind;
     // composite phase B: rank of a body among the bodies of its depth, bodies per depth, children lists,
     // body of every dof, and per dof the dofs of ancestor-or-own / strictly descendant bodies
-    const int *lvlrank, *lvlwidth, *child_start, *child_list, *dofbody;
+    const int *lvlrank, *lvlwidth, *lvlmaxch, *child_start, *child_list, *dofbody;
     const unsigned long long *upmask, *descmask;
     int stage_cap;
     const unsigned long long *anc;
@@ -250,7 +260,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
     WAVE_SYNC();
 
+#ifdef ARB_BSTAMPS   /* development: slots 3..7 = sub-phases of phase B (levels, dof products, rows of Z, constraint rows, end) */
+#define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0 && (k) <= 2) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
+#define ARB_BSTAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
+#else
 #define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
+#define ARB_BSTAMP(k) do { } while (0)
+#endif
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); } while (0)
 
     // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
@@ -313,7 +329,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // (sdist) is a difference of O(1 m) positions that is then divided by dt, so
             // float32 rounding of the pose chain alone would cost ~1e-7/dt = 2e-5 m/s.
             M3<T> R_pc, R_cp, R_cn, dA_cp, dB_cp; V3<T> p_pc, p_cp, p_cn, Tnw, Tnv, Bnw, Bnv;
-            V3<T> Wcw = v3<T>(T(0), T(0), T(0)), Wcv = Wcw;      // W_c with dAd_cp = ad(W_c) Ad_cp (composite build)
             M3<double> R_pc_d = m3_identity<double>(); V3<double> p_pc_d = v3<double>(0., 0., 0.);
             R_pc = R_cp = R_cn = m3_identity<T>();
             dA_cp = dB_cp = m3_zero<T>();
@@ -363,10 +378,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #else
                 {
                     // dAd_cp = Ad_cn Ad_nr ad(T_rn) Ad_rp = ad(W_c) Ad_cp with W_c = Ad_cn Ad_nr T_rn, T_rn = -(aw, av)
+                    // (parked in the body block right away: phase A is the register-pressure peak of the kernel)
                     const V3<T> nw = -mv(R_nr, aw);
                     const V3<T> nv = cross(p_nr, nw) - mv(R_nr, av);
-                    Wcw = mv(R_cn, nw);
-                    Wcv = cross(p_cn, Wcw) + mv(R_cn, nv);
+                    const V3<T> Wcw = mv(R_cn, nw);
+                    st_v3(bd + BD_OM, Wcw);
+                    st_v3(bd + BD_OM + 3, cross(p_cn, Wcw) + mv(R_cn, nv));
                 }
 #endif
                 dA_cp = dAd_cp.A; dB_cp = dAd_cp.B;
@@ -411,15 +428,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             for (int lvl = 0; lvl <= mp->maxdepth; ++lvl) {
                 if (on && dep == lvl) {
                     M3<double> Rg = m3_identity<double>(); V3<double> pg = v3<double>(0., 0., 0.);
-                    V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw, ow = tw, ov = tw;
+                    V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw;
                     if (par >= 0) {
                         const T *pb = BD + par * BD_STRIDE;
                         Rg = ld_m3(PD + 12 * par); pg = ld_v3(PD + 12 * par + 9);
                         tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
                         aw = ld_v3(pb + BD_AB); av = ld_v3(pb + BD_AB + 3);
-#if ARB_COMPOSITE
-                        ow = ld_v3(pb + BD_OM); ov = ld_v3(pb + BD_OM + 3);
-#endif
                     }
                     const M3<double> Rc_d = mul(Rg, R_pc_d);         // child_pose  core.py:1299
                     const V3<double> pc_d = mv(Rg, p_pc_d) + pg;
@@ -436,12 +450,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<T> nbw = mv(dA_cp, tw) + raw + Bnw;
                     const V3<T> nbv = mv(dB_cp, tw) + mv(dA_cp, tv) + cross(p_cp, raw) + mv(R_cp, av) + Bnv;
                     st_v3(bd + BD_AB, nbw); st_v3(bd + BD_AB + 3, nbv);
-#if ARB_COMPOSITE
-                    // accumulated pseudo twist: Om_c = Ad_cp Om_p + W_c  (dJ_b = Ad(b<-g) (dX' + ad(Om_b^g) X), phase B)
-                    const V3<T> rw = mv(R_cp, ow);
-                    st_v3(bd + BD_OM, rw + Wcw);
-                    st_v3(bd + BD_OM + 3, cross(p_cp, rw) + mv(R_cp, ov) + Wcv);
-#endif
                 }
                 WAVE_SYNC();
             }
@@ -476,8 +484,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         for (int j = 0; j < 3; ++j) rx.a[3 * i + j] = Mb[6 * i + 3 + j] * im;
                 }
                 const M3<T> Cm = sub(mul(rx, wx), mul(wx, rx));
+#if !ARB_COMPOSITE
                 st_m3(bd + BD_CM, Cm);
                 st_v3(bd + BD_W, wv);
+#endif
                 // increment form of core.py:975-976: Z (gvel+ - gvel) = gforce - (N + B) gvel, and
                 // (N gvel)|_b = M_b (dJ_b gvel) + N_b T_b ;  (B gvel)|_b = B_b T_b
                 const V3<T> mtt = v3<T>(mt[0], mt[1], mt[2]), mtb = v3<T>(mt[3], mt[4], mt[5]);
@@ -665,6 +675,24 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             const double cM = (MODE == 1 && zmode == 1) ? 1. : (double)inv_dt;
 #pragma unroll
             for (int i = 0; i < NACC; ++i) Acc[i] = 0.;
+            // accumulated pseudo twist down the tree: Om_c = Ad_cp Om_p + W_c (phase A left W_c in BD_OM; done here,
+            // one depth level per iteration, because phase A is the register-pressure peak of the kernel)
+            {
+                const int mydep = (lane < nb) ? mp->depth[lane] : -1;
+                const int par = (lane < nb) ? mp->parent[lane] : -1;
+                for (int lvl = 1; lvl <= mp->maxdepth; ++lvl) {
+                    if (mydep == lvl) {
+                        T *bd = BD + lane * BD_STRIDE;
+                        const T *pb = BD + par * BD_STRIDE;
+                        const M3<T> R_cp = ld_m3(bd + BD_RCP);
+                        const V3<T> p_cp = ld_v3(bd + BD_PCP);
+                        const V3<T> rw = mv(R_cp, ld_v3(pb + BD_OM));
+                        st_v3(bd + BD_OM + 3, cross(p_cp, rw) + mv(R_cp, ld_v3(pb + BD_OM + 3)) + ld_v3(bd + BD_OM + 3));
+                        st_v3(bd + BD_OM, rw + ld_v3(bd + BD_OM));
+                    }
+                    WAVE_SYNC();
+                }
+            }
             T twb[6], ptb[6], pgb[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) { om_b[i] = T(0); twb[i] = T(0); ptb[i] = T(0); pgb[i] = T(0); }
@@ -673,7 +701,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { twb[i] = bd[BD_TW + i]; om_b[i] = bd[BD_OM + i]; ptb[i] = bd[BD_PT + i]; pgb[i] = bd[BD_PG + i]; }
             }
-            WAVE_SYNC();                       // the per-body blocks are dead from here: the region becomes STG
             // ---- lane = body: world-frame matrices of the body -----------------------------------
             if (lane < nb) {
                 const int b = lane;
@@ -772,7 +799,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     Acc[NACC - 6] = tq.x; Acc[NACC - 5] = tq.y; Acc[NACC - 4] = tq.z; Acc[NACC - 3] = f.x; Acc[NACC - 2] = f.y; Acc[NACC - 1] = f.z;
                 }
             }
+            WAVE_SYNC();                       // the per-body blocks are dead from here: the region becomes STG
             // ---- subtree sums, deepest level first; children hand their sums over through STG ------
+            ARB_BSTAMP(3);
             {
                 typedef double D2 __attribute__((ext_vector_type(2)));
                 const int mydep = (lane < nb) ? mp->depth[lane] : -1;
@@ -780,8 +809,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const int cs = (lane < nb) ? mp->child_start[lane] : 0;
                 const int cn = (lane < nb) ? mp->child_start[lane + 1] - cs : 0;
                 const int cap = mp->stage_cap;
+                // ranks of the first children in registers: no dependent global loads inside the level loop
+                constexpr int NCR = 4;
+                int crk[NCR];
+#pragma unroll
+                for (int j = 0; j < NCR; ++j) crk[j] = (j < cn) ? mp->lvlrank[mp->child_list[cs + j]] : -1;
                 for (int lvl = mp->maxdepth; lvl >= 1; --lvl) {
                     const int width = mp->lvlwidth[lvl];
+                    const int maxch = mp->lvlmaxch[lvl - 1];           // wave-uniform bound of the child slots at this level
                     for (int s0 = 0; s0 < width; s0 += cap) {
                         if (mydep == lvl && myrank >= s0 && myrank < s0 + cap) {
                             D2 *o = reinterpret_cast<D2 *>(STG + (myrank - s0) * STG_STRIDE);
@@ -791,7 +826,17 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         }
                         WAVE_SYNC();
                         if (mydep == lvl - 1) {
-                            for (int j = 0; j < cn; ++j) {
+#pragma unroll
+                            for (int j = 0; j < NCR; ++j) {
+                                if (j >= maxch) break;
+                                const int r = crk[j];
+                                if (r < s0 || r >= s0 + cap) continue;
+                                const D2 *in = reinterpret_cast<const D2 *>(STG + (r - s0) * STG_STRIDE);
+#pragma unroll
+                                for (int i = 0; i < NACC / 2; ++i) { const D2 v = in[i]; Acc[2 * i] += v.x; Acc[2 * i + 1] += v.y; }
+                                if (NACC & 1) Acc[NACC - 1] += STG[(r - s0) * STG_STRIDE + NACC - 1];
+                            }
+                            for (int j = NCR; j < cn; ++j) {          // bodies with many children (rare)
                                 const int r = mp->lvlrank[mp->child_list[cs + j]];
                                 if (r < s0 || r >= s0 + cap) continue;
                                 const D2 *in = reinterpret_cast<const D2 *>(STG + (r - s0) * STG_STRIDE);
@@ -805,6 +850,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
             }
             // ---- lane = dof k: fetch the composites of body(k), own column, the three products -----
+            ARB_BSTAMP(4);
             const int bsrc = (lane < n) ? mp->dofbody[lane] : 0;
             double Xk[6], dXk[6], Gk[6];
             {
@@ -871,10 +917,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 WAVE_SYNC();
             }
             // ---- lane = column k: rows of Z ----------------------------------------------------------
+            ARB_BSTAMP(5);
             {
                 typedef double D2 __attribute__((ext_vector_type(2)));
-                const unsigned long long up = (lane < n) ? mp->upmask[lane] : 0ull;
-                const unsigned long long dn = (lane < n) ? mp->descmask[lane] : 0ull;
+                // DFS numbering: rows related to column k are ancestors' (or own) dofs up to the last own dof
+                // e_k, descendants' dofs after it
+                const unsigned long long rel = (lane < n) ? (mp->upmask[lane] | mp->descmask[lane]) : 0ull;
+                const unsigned rel_lo = (unsigned)rel, rel_hi = (unsigned)(rel >> 32);
+                const int e_k = (lane < n) ? (mp->dof_off[bsrc] + mp->jnd[bsrc] - 1) : -1;
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i) {
                     if (i < n) {
@@ -886,13 +936,15 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                             tu += a.x * Gk[2 * j] + a.y * Gk[2 * j + 1];
                             td += pq.x * Xk[2 * j] + pq.y * Xk[2 * j + 1] + rq.x * dXk[2 * j] + rq.y * dXk[2 * j + 1];
                         }
-                        Z[i] = (T)(((up >> i) & 1ull) ? tu : (((dn >> i) & 1ull) ? td : 0.));
+                        const T val = (T)((i <= e_k) ? tu : td);
+                        Z[i] = (((i < 32 ? rel_lo : rel_hi) >> (i & 31)) & 1u) ? val : T(0);
                     } else {
                         Z[i] = T(0);
                     }
                 }
             }
             // ---- constraint rows: s_k [Ad(c0<-g) X_k] with s_k = [k above body 1] - [k above body 0] --
+            ARB_BSTAMP(6);
             if (do_constraints) {
                 for (int c = 0; c < nc; ++c) {
                     const int ct = mp->ctype[c];
@@ -1182,6 +1234,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         }
         // ================= phase C: augmented Gauss-Jordan ===================
         ARB_OPAQUE_LANE();
+        ARB_BSTAMP(7);
         ARB_STAMP(3);
         if (lane < RS) RT[lane] = (lane < n) ? rhs : T(0);
         WAVE_SYNC();
@@ -1747,7 +1800,7 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot
 }
 
 struct TreeTables {
-    std::vector<int> lvlrank, lvlwidth, child_start, child_list, dofbody;
+    std::vector<int> lvlrank, lvlwidth, lvlmaxch, child_start, child_list, dofbody;
     std::vector<unsigned long long> upmask, descmask;
     int maxwidth;
 };
@@ -1788,7 +1841,7 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     UP_I(depth, depth); UP_I(src, src); UP_I(sslot, sslot);
     UP_I(weighted, std::vector<int>(d->weighted, d->weighted + nb));
     UP_I(dof2q, dof2q); UP_I(att_start, att_start); UP_I(att_c, att_c); UP_I(att_kind, att_kind);
-    UP_I(lvlrank, tt.lvlrank); UP_I(lvlwidth, tt.lvlwidth); UP_I(child_start, tt.child_start);
+    UP_I(lvlrank, tt.lvlrank); UP_I(lvlwidth, tt.lvlwidth); UP_I(lvlmaxch, tt.lvlmaxch); UP_I(child_start, tt.child_start);
     UP_I(child_list, tt.child_list); UP_I(dofbody, tt.dofbody);
     if ((rc = upload<unsigned long long>(M, tt.upmask, &m.upmask)) != ARB_OK) return rc;
     if ((rc = upload<unsigned long long>(M, tt.descmask, &m.descmask)) != ARB_OK) return rc;
@@ -1963,6 +2016,9 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         for (int c2 = b + 1; c2 < nb; ++c2) if (d->parent[c2] == b) tt.child_list.push_back(c2);
     }
     tt.child_start[nb] = (int)tt.child_list.size();
+    tt.lvlmaxch.assign(maxdepth + 1, 0);          // most children any body has at this level (children sit one level down)
+    for (int b = 0; b < nb; ++b)
+        tt.lvlmaxch[depth[b]] = std::max(tt.lvlmaxch[depth[b]], tt.child_start[b + 1] - tt.child_start[b]);
     tt.maxwidth = *std::max_element(tt.lvlwidth.begin(), tt.lvlwidth.end());
     for (int b = 0; b < nb; ++b)
         for (int i = 0; i < jnd[b]; ++i) { tt.dofbody[d->dof_off[b] + i] = b; tt.upmask[d->dof_off[b] + i] = anc[b]; }

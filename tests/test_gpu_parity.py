@@ -321,6 +321,21 @@ def test_step_ex_argument_validation(bw_cache):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, F64_TOL), (torch.float32, F32_TOL)])
+def test_body_viscosity(bw_cache, dtype, tol):
+    """Non-symmetric body viscosity matrices (core.py:729-731): world B matrix and one step."""
+    g = load_golden("g10_viscosity.npz")
+    bw, m, _, _ = bw_cache("human36_visc")
+    q, dq, _ = gpu_step(bw, g["q"], g["dq"], 5e-3, dtype)
+    rq, rdq = ref_step(m, g["q"], g["dq"], 5e-3, dtype, g["q_next"], g["dq_next"])
+    assert rel(q, rq) < tol
+    assert rel(dq, rdq) < tol
+    if dtype == torch.float64:
+        tq, tdq = bw.to_device(g["q"], g["dq"], dtype)
+        r = bw.inspect(tq, tdq, 5e-3, ["B"])
+        assert rel(r["B"].cpu().numpy(), g["B"]) < 1e-11
+
+
 def test_snake64_f64(bw_cache):
     """Config 4 model, float64 kernels.  cond(Z) ~ 3e8 here, and the reference forms
     the explicit inverse (core.py:818): its own dq+ is only accurate to ~3e-6 against

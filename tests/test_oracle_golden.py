@@ -307,3 +307,14 @@ def test_pd_per_world_human36_posture_servo():
     for k in range(12):
         q, dq, _ = O.step(m, Q[k], DQ[k], 5e-3, pd=pd)
         close(q, Q[k + 1], 1e-8); close(dq, DQ[k + 1], 1e-7)
+
+
+# -- G10 body viscosity ------------------------------------------------------------
+def test_body_viscosity():
+    """core.py:729-731: B = sum J_b^T B_b J_b with general (non-symmetric) body viscosity matrices."""
+    g = load_golden("g10_viscosity.npz")
+    m, _, _ = load_model("human36_visc")
+    dyn = O.update_dynamic(m, g["q"], g["dq"])
+    close(dyn["Bv"], g["B"], 1e-12)
+    qn, dqn, _ = O.step(m, g["q"], g["dq"], 5e-3)
+    close(qn, g["q_next"], 1e-9); close(dqn, g["dq_next"], 1e-9)

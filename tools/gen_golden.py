@@ -630,10 +630,36 @@ def gen_parse_order():
     save("g9_parse_order.npz", **out)
 
 
+# ---- G10: body viscosity (core.py:729-731, 813) ----
+def gen_viscosity():
+    """human36 with a (non-symmetric) viscosity matrix on every body: world B matrix and 6 steps."""
+    rng = np.random.RandomState(10)
+    w = human36_ref(contacts=0)
+    for b in w.iterbodies():
+        if b is w.ground:
+            continue
+        A = rng.uniform(-1, 1, (6, 6))
+        b.viscosity = 0.05 * (A @ A.T) + 0.02 * rng.uniform(-1, 1, (6, 6))
+    w.init()
+    m = save_model("human36_visc", w)
+    q, dq = synth.random_states(m, 4, seed=21, vel=1.0)
+    out = dict(q=q, dq=dq)
+    Bs, qn, dqn = [], [], []
+    for i in range(4):
+        set_state(w, m, q[i], dq[i])
+        w.update_dynamic()
+        Bs.append(w.viscosity.copy())
+        w.update_controllers(5e-3); w.update_constraints(5e-3); w.integrate(5e-3)
+        a, b2 = get_state(w, m)
+        qn.append(a); dqn.append(b2)
+    out["B"], out["q_next"], out["dq_next"] = np.array(Bs), np.array(qn), np.array(dqn)
+    save("g10_viscosity.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity)
     for k in which:
         table[k]()
