@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--dt", type=float, default=5e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--steps-per-launch", type=int, default=RESET_EVERY,
+                    help="steps advanced by one arb_step call (state stays on chip in between); "
+                         "%d = one falling episode per launch, 1 = one launch per step" % RESET_EVERY)
     ap.add_argument("--extra", action="store_true", help="also time the other BASELINE configs")
     return ap.parse_args()
 
@@ -118,35 +121,39 @@ def cpu_baseline(model, q, dq, dt, budget_s):
     return out
 
 
-def time_config(bw, q0, dq0, dt, steps, warmup, torch, dist=None, use_cf=True):
-    """Run warmup + K timed steps; returns (wall seconds, mean kernel ms from HIP events)."""
+def time_config(bw, q0, dq0, dt, steps, warmup, torch, dist=None, use_cf=True, spl=1):
+    """Time exactly `steps` steps (after `warmup` untimed ones).  The workload is the reference's
+    falling scenario: every RESET_EVERY steps the worlds restart from the initial states.  One
+    arb_step call advances min(spl, steps left in the episode) steps.  Returns wall seconds, the
+    mean duration of a launch (ms, events on the launch stream), the mean steps per launch,
+    finiteness of the final state and the final state."""
     dev = bw.device
     q, dq = q0.clone(), dq0.clone()
     cf = bw.new_cforce(q.shape[0], q.dtype) if (bw.model.nc and use_cf) else None
-    k = 0
 
-    def one():
-        nonlocal k
+    def chunks(total):
+        k = 0
+        while k < total:
+            c = min(spl, RESET_EVERY - k % RESET_EVERY, total - k)
+            yield k, c
+            k += c
+    for k, c in chunks(warmup):
         if k % RESET_EVERY == 0:
             q.copy_(q0); dq.copy_(dq0)
-        bw.step(q, dq, dt, 1, cforce=cf)
-        k += 1
-    for _ in range(warmup):
-        one()
-    k = 0
+        bw.step(q, dq, dt, c, cforce=cf)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    plan = list(chunks(steps))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plan]
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i, (k, c) in enumerate(plan):
         if k % RESET_EVERY == 0:
             q.copy_(q0); dq.copy_(dq0)
         ev[i][0].record()               # on torch's current stream = the stream arb_step launches on
-        bw.step(q, dq, dt, 1, cforce=cf)
+        bw.step(q, dq, dt, c, cforce=cf)
         ev[i][1].record()
-        k += 1
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -154,7 +161,7 @@ def time_config(bw, q0, dq0, dt, steps, warmup, torch, dist=None, use_cf=True):
     wall = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     finite = bool(torch.isfinite(q).all() and torch.isfinite(dq).all())
-    return wall, kern_ms, finite, (q, dq)
+    return wall, kern_ms, steps / float(len(plan)), finite, (q, dq)
 
 
 def main():
@@ -185,7 +192,8 @@ def main():
         q, dq = synth.random_states(model, B, seed=1000 + rank)
     q0, dq0 = bw.to_device(q, dq, dtype)
 
-    wall, kern_ms, finite, (qf, dqf) = time_config(bw, q0, dq0, args.dt, args.steps, args.warmup, torch, dist)
+    spl = max(1, args.steps_per_launch)
+    wall, kern_ms, spl_avg, finite, (qf, dqf) = time_config(bw, q0, dq0, args.dt, args.steps, args.warmup, torch, dist, spl=spl)
     t = torch.tensor([wall], dtype=torch.float64, device=bw.device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,6 +218,7 @@ def main():
     elem = 4 if args.dtype == "f32" else 8
     bytes_per_world_step = 2 * (model.nq + model.ndof) * elem           # state in + state out
     value = n_gpus * B * args.steps / wall
+    # one launch reads and writes the state once, whatever the number of steps it advances on chip
     achieved_gbs = bytes_per_world_step * B / (kern_ms * 1e-3) / 1e9
     flop_dense = {0: 1.66e6, 4: 1.9e6, 8: 2.13e6}[args.contacts]          # dense-as-written count, SURVEY 6
     res = {
@@ -218,19 +227,22 @@ def main():
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "human36 (42 dof) + %d floor SoftFingerContact, batch %d worlds/GPU, dt=%g, "
-                               "standing-drop states reset every %d steps (BASELINE config #3)"
-                               % (args.contacts, B, args.dt, RESET_EVERY),
-                   "worlds_per_gpu": B, "global_batch": n_gpus * B, "parallelism": "dp%d" % n_gpus},
+                               "standing-drop states reset every %d steps (BASELINE config #3), "
+                               "%g steps per arb_step launch"
+                               % (args.contacts, B, args.dt, RESET_EVERY, spl_avg),
+                   "worlds_per_gpu": B, "global_batch": n_gpus * B, "parallelism": "dp%d" % n_gpus,
+                   "steps_per_launch": spl_avg},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "arb_step_kernel", "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_world_step": bytes_per_world_step,
+                     "algorithmic_bytes_per_launch": bytes_per_world_step * B,
+                     "algorithmic_bytes_per_world_step": bytes_per_world_step / spl_avg,
                      "note": "compulsory traffic is state in+out only; the path is VALU/latency bound, "
                              "see fp32_vector",
                      "fp32_vector": {"dense_equiv_flop_per_world_step": flop_dense,
-                                     "achieved_tflops": flop_dense * B / (kern_ms * 1e-3) / 1e12,
+                                     "achieved_tflops": flop_dense * B * spl_avg / (kern_ms * 1e-3) / 1e12,
                                      "peak_tflops": FP32_PEAK_TFLOPS,
-                                     "frac": flop_dense * B / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
+                                     "frac": flop_dense * B * spl_avg / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
         "state_finite": finite,
     }
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh,
@@ -239,7 +251,7 @@ def main():
     profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))   # newest round last by name
     profs = [f for f in profs if "baseline" not in f]
     prof = profs[-1] if profs else ""
-    if os.path.exists(prof) and args.contacts == 4 and B == 4096 and args.dtype == "f32":
+    if os.path.exists(prof) and args.contacts == 4 and B == 4096 and args.dtype == "f32" and spl == RESET_EVERY:
         try:
             pm = json.load(open(prof))["pmc_per_launch"]
             res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
@@ -249,23 +261,16 @@ def main():
             pass
     if gather_ms is not None:
         res["final_state_allgather_ms"] = gather_ms
+    if n_gpus == 1 and spl != 1:
+        # the same workload with one launch per step (how rounds up to r01b were measured)
+        w1, k1, _, _, _ = time_config(bw, q0, dq0, args.dt, 2 * RESET_EVERY, RESET_EVERY // 2, torch, None, spl=1)
+        res["per_step_launch"] = {"value": B * 2 * RESET_EVERY / w1, "unit": "world-steps/s", "kernel_ms": k1,
+                                  "steps": 2 * RESET_EVERY}
     if n_gpus == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(model, q, dq, args.dt, args.cpu_seconds)
         res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     if args.extra and n_gpus == 1:
         extra = {}
-        # in-kernel multi-step residency: 40 steps per launch
-        qq, dd = q0.clone(), dq0.clone()
-        cf = bw.new_cforce(B, dtype) if model.nc else None
-        bw.step(qq, dd, args.dt, RESET_EVERY, cforce=cf)
-        torch.cuda.synchronize()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            qq.copy_(q0); dd.copy_(dq0)
-            bw.step(qq, dd, args.dt, RESET_EVERY, cforce=cf)
-        torch.cuda.synchronize()
-        extra["resident_%dsteps_per_launch_world_steps_per_s" % RESET_EVERY] = B * RESET_EVERY * reps / (time.perf_counter() - t0)
         for name, mdl, gen, kw, bsz, dtt, dty in (
                 ("config2_human36_nocontact_b1024_f32", scenes.flat(scenes.human36_world(0)), synth.random_states,
                  dict(seed=0), 1024, 5e-3, torch.float32),
@@ -276,8 +281,11 @@ def main():
             b2 = BatchedWorlds(mdl, local_rank)
             qa, da = gen(mdl, bsz, **kw)
             ta, tb = b2.to_device(qa, da, dty)
-            wl, km, fin, _ = time_config(b2, ta, tb, dtt, 50, 5, torch)
-            extra[name] = {"world_steps_per_s": bsz * 50 / wl, "kernel_ms": km, "finite": fin}
+            wl, km, _, fin, _ = time_config(b2, ta, tb, dtt, 80, 10, torch, spl=1)
+            wr, kr, _, _, _ = time_config(b2, ta, tb, dtt, 80, 10, torch, spl=RESET_EVERY)
+            # (from the launch durations: these short runs are dominated by host-side setup otherwise)
+            extra[name] = {"world_steps_per_s": bsz * RESET_EVERY / (kr * 1e-3), "launch_ms_%d_steps" % RESET_EVERY: kr,
+                           "per_step_launch_world_steps_per_s": bsz / (km * 1e-3), "per_step_launch_ms": km, "finite": fin}
             b2.close()
         res["extra"] = extra
     print(json.dumps(res))

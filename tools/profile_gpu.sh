@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 80 --warmup 10 --no-cpu-baseline"
-BENCH_S="python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 200 --warmup 40 --no-cpu-baseline"   # 1 + 5 launches of 40 steps (+ the per-step-launch leg)
+BENCH_S="python3 $R/bench.py --steps 40 --warmup 40 --no-cpu-baseline"  # 2 launches of 40 steps (+ the per-step-launch leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH_S > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH_S > $OUT/pmc_write.log 2>&1

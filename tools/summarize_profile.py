@@ -21,22 +21,30 @@ if trace:
          if "arb_step_kernel" in r["Kernel_Name"]]
     d.sort()
     ms = [(b - a) / 1e6 for a, b in d]
-    out["arb_step_kernel"] = dict(dispatches=len(ms), mean_ms_all=sum(ms) / len(ms),
-                                  mean_ms_timed_region_last80=sum(ms[-80:]) / len(ms[-80:]),
-                                  per_step_ms_first_cycle=[round(x, 3) for x in ms[:40]])
+    # bench.py launches whole 40-step episodes first, then (per_step_launch leg) one launch per step
+    epi = [x for x in ms if x > 5.0]
+    one = [x for x in ms if x <= 5.0]
+    out["arb_step_kernel"] = dict(dispatches=len(ms),
+                                  episode_launches=len(epi), mean_ms_episode_launch=(sum(epi) / len(epi)) if epi else None,
+                                  timed_episode_launches_ms=[round(x, 3) for x in epi[1:]],
+                                  single_step_launches=len(one), mean_ms_single_step_launch=(sum(one) / len(one)) if one else None,
+                                  single_step_ms_first_cycle=[round(x, 3) for x in one[:40]])
 pmc = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     acc = {}
-    for r in csv.DictReader(open(f)):
-        if "arb_step_kernel" not in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f)) if "arb_step_kernel" in r["Kernel_Name"]]
+    # keep the episode launches only (the first two dispatches of bench.py --steps 40 --warmup 40)
+    first = sorted(set(int(r["Dispatch_Id"]) for r in rows))[:2]
+    for r in rows:
+        if int(r["Dispatch_Id"]) not in first:
             continue
         a = acc.setdefault(r["Counter_Name"], [0.0, set()])
         a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
     for name, (tot, ids) in acc.items():
         pmc[name] = dict(mean_per_launch=tot / len(ids), launches=len(ids))
 out["pmc_per_launch"] = pmc
-out["notes"] = ("bench.py human36 + 4 contacts, 4096 worlds, f32; kernel-trace pass: --steps 80 --warmup 10; "
-                "each --pmc group in its own pass (--steps 20 --warmup 2). FETCH_SIZE / WRITE_SIZE are in KiB "
-                "(rocprofv3 units), summed over the device's XCDs per dispatch.")
+out["notes"] = ("bench.py human36 + 4 contacts, 4096 worlds, f32, one 40-step episode per launch; kernel-trace pass: "
+                "--steps 200 --warmup 40; each --pmc group in its own pass (--steps 40 --warmup 40), counters of the two "
+                "episode launches. FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 units), summed over the XCDs per dispatch.")
 json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "kernel_stats"}, indent=1)[:1500])
