@@ -376,15 +376,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #if !ARB_COMPOSITE
                 st_m3(bd + BD_DA, dAd_cp.A); st_m3(bd + BD_DB, dAd_cp.B);
 #else
-                {
-                    // dAd_cp = Ad_cn Ad_nr ad(T_rn) Ad_rp = ad(W_c) Ad_cp with W_c = Ad_cn Ad_nr T_rn, T_rn = -(aw, av)
-                    // (parked in the body block right away: phase A is the register-pressure peak of the kernel)
-                    const V3<T> nw = -mv(R_nr, aw);
-                    const V3<T> nv = cross(p_nr, nw) - mv(R_nr, av);
-                    const V3<T> Wcw = mv(R_cn, nw);
-                    st_v3(bd + BD_OM, Wcw);
-                    st_v3(bd + BD_OM + 3, cross(p_cn, Wcw) + mv(R_cn, nv));
-                }
+                // T_rn = -(aw, av) is all phase B needs from here (dAd_cp = ad(W_c) Ad_cp, W_c = Ad_cp Ad_pr T_rn)
+                st_v3(bd + BD_OM, -aw); st_v3(bd + BD_OM + 3, -av);
 #endif
                 dA_cp = dAd_cp.A; dB_cp = dAd_cp.B;
                 // Ad_cn (dJ_nr gvel_j): the joint's own contribution to dJ_c gvel
@@ -680,6 +673,18 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             {
                 const int mydep = (lane < nb) ? mp->depth[lane] : -1;
                 const int par = (lane < nb) ? mp->parent[lane] : -1;
+                if (lane < nb) {
+                    // W_c = Ad_cn Ad_nr T_rn = Ad_cp Ad_pr T_rn   (H_cn H_nr = H_cp H_pr)
+                    T *bd = BD + lane * BD_STRIDE;
+                    const M3<T> R_pr = ld_m3(mp->Hpr + 12 * lane), R_cp = ld_m3(bd + BD_RCP);
+                    const V3<T> p_pr = ld_v3(mp->Hpr + 12 * lane + 9), p_cp = ld_v3(bd + BD_PCP);
+                    const V3<T> uw = mv(R_pr, ld_v3(bd + BD_OM));
+                    const V3<T> uv = cross(p_pr, uw) + mv(R_pr, ld_v3(bd + BD_OM + 3));
+                    const V3<T> ww = mv(R_cp, uw);
+                    st_v3(bd + BD_OM, ww);
+                    st_v3(bd + BD_OM + 3, cross(p_cp, ww) + mv(R_cp, uv));
+                }
+                WAVE_SYNC();
                 for (int lvl = 1; lvl <= mp->maxdepth; ++lvl) {
                     if (mydep == lvl) {
                         T *bd = BD + lane * BD_STRIDE;
@@ -725,6 +730,32 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     }
                     return o;
                 };
+                // (first, while nothing else is live: this rarely taken block needs ~70 registers of its own)
+                if (mp->has_visc && useB) {                              // Bg = Ad^T B_b Ad (general 6x6)
+                    const T *Vb = mp->visc + 36 * b;
+                    const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
+                    const M3<double> H12 = add(B12, hatmul(p, B22));
+                    const M3<double> H21 = sub(B21, rowcross(B22, p));
+                    const M3<double> H11 = add(sub(B11, rowcross(B12, p)), hatmul(p, H21));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            Acc[6 * i + j] += H11.a[3 * i + j]; Acc[6 * i + 3 + j] += H12.a[3 * i + j];
+                            Acc[6 * (3 + i) + j] += H21.a[3 * i + j]; Acc[6 * (3 + i) + 3 + j] += B22.a[3 * i + j];
+                        }
+                }
+                // (before the 3x3 blocks, so that R and p die with them) wrenches to world axes: Ad(b<-g)^T f = (R tau + p x R f, R f)
+                {
+                    const V3<double> f = mv(R, v3<double>((double)ptb[3], (double)ptb[4], (double)ptb[5]));
+                    const V3<double> tq = mv(R, v3<double>((double)ptb[0], (double)ptb[1], (double)ptb[2])) + cross(p, f);
+                    Acc[57] = tq.x; Acc[58] = tq.y; Acc[59] = tq.z; Acc[60] = f.x; Acc[61] = f.y; Acc[62] = f.z;
+                }
+                if (MODE == 1) {
+                    const V3<double> f = mv(R, v3<double>((double)pgb[3], (double)pgb[4], (double)pgb[5]));
+                    const V3<double> tq = mv(R, v3<double>((double)pgb[0], (double)pgb[1], (double)pgb[2])) + cross(p, f);
+                    Acc[NACC - 6] = tq.x; Acc[NACC - 5] = tq.y; Acc[NACC - 4] = tq.z; Acc[NACC - 3] = f.x; Acc[NACC - 2] = f.y; Acc[NACC - 1] = f.z;
+                }
                 double G[36];                  // Mg = Ad(b<-g)^T M_b Ad(b<-g), symmetric
                 {
                     const M3<double> M11 = rot(blk(Mb, 0, 0)), M12 = rot(blk(Mb, 0, 3)), M22 = rot(blk(Mb, 3, 3));
@@ -749,7 +780,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const V3<double> ow = mv(R, v3<double>((double)om_b[0], (double)om_b[1], (double)om_b[2]));
                 const V3<double> ov = mv(R, v3<double>((double)om_b[3], (double)om_b[4], (double)om_b[5])) + cross(p, ow);
 #pragma unroll
-                for (int i = 0; i < 36; ++i) Acc[i] = useM ? cM * G[i] : 0.;
+                for (int i = 0; i < 36; ++i) Acc[i] += useM ? cM * G[i] : 0.;
                 if (useN) {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {                        // -ad(T*)^T Mg, column by column
@@ -766,37 +797,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         Acc[6 * r + 3] += u.x; Acc[6 * r + 4] += u.y; Acc[6 * r + 5] += u.z;
                     }
                 }
-                if (mp->has_visc && useB) {                              // Bg = Ad^T B_b Ad (general 6x6)
-                    const T *Vb = mp->visc + 36 * b;
-                    const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
-                    const M3<double> H12 = add(B12, hatmul(p, B22));
-                    const M3<double> H21 = sub(B21, rowcross(B22, p));
-                    const M3<double> H11 = add(sub(B11, rowcross(B12, p)), hatmul(p, H21));
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            Acc[6 * i + j] += H11.a[3 * i + j]; Acc[6 * i + 3 + j] += H12.a[3 * i + j];
-                            Acc[6 * (3 + i) + j] += H21.a[3 * i + j]; Acc[6 * (3 + i) + 3 + j] += B22.a[3 * i + j];
-                        }
-                }
                 {
                     int t = 36;
 #pragma unroll
                     for (int r = 0; r < 6; ++r)
 #pragma unroll
                         for (int c2 = r; c2 < 6; ++c2) Acc[t++] = useN ? G[6 * r + c2] : 0.;
-                }
-                // wrenches to world axes: Ad(b<-g)^T f = (R tau + p x R f, R f)
-                {
-                    const V3<double> f = mv(R, v3<double>((double)ptb[3], (double)ptb[4], (double)ptb[5]));
-                    const V3<double> tq = mv(R, v3<double>((double)ptb[0], (double)ptb[1], (double)ptb[2])) + cross(p, f);
-                    Acc[57] = tq.x; Acc[58] = tq.y; Acc[59] = tq.z; Acc[60] = f.x; Acc[61] = f.y; Acc[62] = f.z;
-                }
-                if (MODE == 1) {
-                    const V3<double> f = mv(R, v3<double>((double)pgb[3], (double)pgb[4], (double)pgb[5]));
-                    const V3<double> tq = mv(R, v3<double>((double)pgb[0], (double)pgb[1], (double)pgb[2])) + cross(p, f);
-                    Acc[NACC - 6] = tq.x; Acc[NACC - 5] = tq.y; Acc[NACC - 4] = tq.z; Acc[NACC - 3] = f.x; Acc[NACC - 2] = f.y; Acc[NACC - 1] = f.z;
                 }
             }
             WAVE_SYNC();                       // the per-body blocks are dead from here: the region becomes STG

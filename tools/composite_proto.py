@@ -39,8 +39,8 @@ for w in range(q.shape[0]):
         H_rn, J_nr, dJ_nr = O.joint_kinematics(jt, q[w:w + 1, qs], dq[w:w + 1, ds])
         T_nr = dq[w, ds].copy() if jt == O.JT_FREE else (J_nr[0] @ dq[w, ds])
         Ad_nr = O.adjoint(O.joint_ipose(jt, q[w:w + 1, qs], H_rn))[0]
-        W = O.adjoint(m.H_cn[b]) @ (Ad_nr @ (-(Ad_nr @ T_nr)))
         H_pc = m.H_pr[b] @ (H_rn[0] @ O.hinv(m.H_cn[b]))
+        W = O.iadjoint(H_pc) @ (O.adjoint(m.H_pr[b]) @ (-(Ad_nr @ T_nr)))      # = Ad_cn Ad_nr T_rn
         Om[b] = W + (0 if p < 0 else O.iadjoint(H_pc) @ Om[p])
         tw = dyn["twist"][w, b]
         ab = dyn["djac"][w, b] @ dq[w]
