@@ -43,6 +43,15 @@
 // per-body block in LDS (elements).  The fields phase B reads are first, 16-byte aligned, so
 // that it can fetch them with 13 vector LDS loads.
 #ifndef ARB_COMPOSITE
+#ifndef ARB_PIVOT_COLUMN_LDS
+#define ARB_PIVOT_COLUMN_LDS 0   // phase C: pivot-column multipliers through LDS broadcast reads instead of v_readlane (measured: no gain, the DS pipe becomes the limit)
+#endif
+#ifndef ARB_SCAN_SUMS
+#define ARB_SCAN_SUMS 1          // phase B subtree sums from a DPP prefix scan over the body lanes (needs DFS preorder numbering); 0: level by level through LDS
+#endif
+#ifndef ARB_GS_PRIO
+#define ARB_GS_PRIO 2          // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
+#endif
 #define ARB_COMPOSITE 1   // phase B: composite (subtree-sum) assembly; 0 = body-by-body accumulation of the first rounds
 #endif
 #define BD_RCP 0     // R of Ad_cp (9)
@@ -106,6 +115,8 @@ struct DevModel {
     const int *lvlrank, *lvlwidth, *lvlmaxch, *child_start, *child_list, *dofbody;
     const unsigned long long *upmask, *descmask;
     int stage_cap;
+    int dfs_contig;            // bodies are numbered in DFS preorder: the subtree of b is b .. b + subsize[b] - 1
+    const int *subsize;        // [nb] bodies in the subtree of b (b included)
     const unsigned long long *anc;
     const int *bi;   // [nb][16] packed per-body ints for the phase-B loop: src, dof_off, jnd, sslot, att_start,
                      // att_end, anc lo/hi, parent's anc lo/hi (one scalar load per body instead of eight)
@@ -166,6 +177,16 @@ __device__ __forceinline__ double bcast(double x, int lane) {
     lo = __builtin_amdgcn_readlane(lo, lane);
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
+}
+
+// x moved across lanes by a DPP control (row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143);
+// lanes without a source, or in rows outside ROW_MASK, get 0.0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 template <typename T> __device__ __forceinline__ M3<T> ld_m3(const T *p) {
@@ -808,6 +829,31 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             WAVE_SYNC();                       // the per-body blocks are dead from here: the region becomes STG
             // ---- subtree sums, deepest level first; children hand their sums over through STG ------
             ARB_BSTAMP(3);
+#if ARB_SCAN_SUMS
+            const int bsrc = (lane < n) ? mp->dofbody[lane] : 0;
+            {
+                // Bodies in DFS preorder: subtree(a) = lanes a .. a + subsize[a] - 1, so a subtree sum is a
+                // difference of inclusive prefix sums over the lanes, P[a + subsize[a] - 1] - P[a - 1].  The scan
+                // runs on DPP row shifts in the vector ALU (log2 steps, no LDS traffic); float64 keeps the
+                // difference exact to ~1e-13 of the whole-tree sum.  Element by element, and straight on to the
+                // dof lanes (lane k takes the composite of body(k)), so that only one element is in flight.
+                const bool two_rows = nb > 16, four_rows = nb > 32;
+                const int hi = (lane < nb) ? lane + mp->subsize[lane] - 1 : lane;
+#pragma unroll
+                for (int i = 0; i < NACC; ++i) {
+                    double x = Acc[i];
+                    x += dpp_f64<0x111, 0xF>(x);            // row_shr:1
+                    x += dpp_f64<0x112, 0xF>(x);            // row_shr:2
+                    x += dpp_f64<0x114, 0xF>(x);            // row_shr:4
+                    x += dpp_f64<0x118, 0xF>(x);            // row_shr:8
+                    if (two_rows) x += dpp_f64<0x142, 0xA>(x);      // row_bcast:15 into rows 1 and 3
+                    if (four_rows) x += dpp_f64<0x143, 0xC>(x);     // row_bcast:31 into rows 2 and 3
+                    const double sub = __shfl(x, hi) - dpp_f64<0x138, 0xF>(x);      // wave_shr:1 (0.0 into lane 0)
+                    Acc[i] = __shfl(sub, bsrc);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // four chains in flight (eight: slower, measured)
+                }
+            }
+#else
             {
                 typedef double D2 __attribute__((ext_vector_type(2)));
                 const int mydep = (lane < nb) ? mp->depth[lane] : -1;
@@ -855,14 +901,19 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     }
                 }
             }
+#endif
             // ---- lane = dof k: fetch the composites of body(k), own column, the three products -----
             ARB_BSTAMP(4);
+#if !ARB_SCAN_SUMS
             const int bsrc = (lane < n) ? mp->dofbody[lane] : 0;
+#endif
             double Xk[6], dXk[6], Gk[6];
             {
-                // in place: from here on Acc holds the composites of body(k), not of body(lane)
+                // from here on Acc holds the composites of body(k), not of body(lane)
+#if !ARB_SCAN_SUMS
 #pragma unroll
                 for (int i = 0; i < NACC; ++i) Acc[i] = __shfl(Acc[i], bsrc);
+#endif
                 double (&Cc)[NACC] = Acc;
                 T omk[6];
 #pragma unroll
@@ -1271,21 +1322,70 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             Z[0] = t;
             if (NSETS == 2) Z2[0] = t2;
         }
+#if ARB_PIVOT_COLUMN_LDS
+        // The multipliers of a pivot step are the entries of column j, i.e. lane j's registers.  Lane j
+        // writes them to LDS and every lane reads them back as broadcast vector loads: the wave's vector
+        // ALU then issues one fma per row instead of a v_readlane + wait states + fma (the kernel is
+        // VALU-issue bound; the DS pipe has room).
+        {
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            V4 *W4 = reinterpret_cast<V4 *>(WORK);          // 64 elements >= NMAX; the Gauss-Seidel stage uses it later
+            for (int j = n - 1; j >= 0; --j) {
+                if (lane == j) {
+#pragma unroll
+                    for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                        V4 z4; z4.x = Z[4 * i4]; z4.y = Z[4 * i4 + 1]; z4.z = Z[4 * i4 + 2]; z4.w = Z[4 * i4 + 3];
+                        W4[i4] = z4;
+                    }
+                }
+                WAVE_SYNC();
+                T F[NMAX];
+#pragma unroll
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    const V4 f4 = W4[i4];
+                    F[4 * i4] = f4.x; F[4 * i4 + 1] = f4.y; F[4 * i4 + 2] = f4.z; F[4 * i4 + 3] = f4.w;
+                }
+                WAVE_SYNC();
+                const T ip = arb_rcp(F[NMAX - 1]);
+                const T t = Z[NMAX - 1] * ip;
+                T t2 = T(0);
+                if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
+#pragma unroll
+                for (int r = NMAX - 1; r >= 1; --r) {
+                    Z[r] = Z[r - 1] - F[r - 1] * t;
+                    if (NSETS == 2) Z2[r] = Z2[r - 1] - F[r - 1] * t2;
+                }
+                Z[0] = t;
+                if (NSETS == 2) Z2[0] = t2;
+            }
+        }
+#else
         for (int j = n - 1; j >= 0; --j) {
             const T piv = bcast(Z[NMAX - 1], j);
-            const T ip = T(1) / piv;
+            const T ip = arb_rcp(piv);
             const T t = Z[NMAX - 1] * ip;
             T t2 = T(0);
             if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
+            // multipliers in groups of 8 broadcasts: the v_readlane -> SGPR -> v_fma wait states of one row are
+            // filled by the broadcasts of the next rows instead of s_nop
+            constexpr int GB = 8;
 #pragma unroll
-            for (int r = NMAX - 1; r >= 1; --r) {
-                const T f = bcast(Z[r - 1], j);
-                Z[r] = Z[r - 1] - f * t;
-                if (NSETS == 2) Z2[r] = Z2[r - 1] - f * t2;
+            for (int r0 = NMAX - 1; r0 >= 1; r0 -= GB) {
+                T f[GB];
+#pragma unroll
+                for (int k = 0; k < GB; ++k) if (r0 - k >= 1) f[k] = bcast(Z[r0 - k - 1], j);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < GB; ++k) if (r0 - k >= 1) {
+                    const int r = r0 - k;
+                    Z[r] = Z[r - 1] - f[k] * t;
+                    if (NSETS == 2) Z2[r] = Z2[r - 1] - f[k] * t2;
+                }
             }
             Z[0] = t;
             if (NSETS == 2) Z2[0] = t2;
         }
+#endif
         // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
         if (lane == n) {
 #pragma unroll
@@ -1419,6 +1519,11 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             const unsigned long long eps1mask = __ballot(k_eps1);
             int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
             T vr_prev = vr, fr_prev = fr;
+#if ARB_GS_PRIO
+            // the sweeps are one long dependent chain: let this wave issue ahead of the SIMD's other wave,
+            // whose bulk phases have independent instructions to fill the gaps
+            __builtin_amdgcn_s_setprio(ARB_GS_PRIO);
+#endif
             for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
                 if (MODE == 1) ++st_sweeps;
                 for (int c = 0; c < nc; ++c) {
@@ -1552,6 +1657,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 if (__all(same_bits(vr, vr_prev) && same_bits(fr, fr_prev)) && !(MODE == 1 && (dbg.ablate & 8))) break;
                 vr_prev = vr; fr_prev = fr;
             }
+#if ARB_GS_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (MODE == 1 && dbg.gs_stats != nullptr && lane == 0) {
                 int *o = dbg.gs_stats + w * 5;
                 o[0] = st_rel; o[1] = st_sta; o[2] = st_fast; o[3] = st_slow; o[4] = st_sweeps;
@@ -1708,7 +1816,11 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
 // ===========================================================================
 // Host side: model upload, launch dispatch, C ABI
 // ===========================================================================
-static thread_local std::string g_hip_err;
+#ifdef ARB_PART
+extern thread_local std::string g_hip_err;
+#else
+thread_local std::string g_hip_err;
+#endif
 
 #define HIP_TRY(expr)                                                          \
     do {                                                                       \
@@ -1718,6 +1830,49 @@ static thread_local std::string g_hip_err;
             return ARB_ERR_HIP;                                                \
         }                                                                      \
     } while (0)
+
+// ---------------------------------------------------------------------------
+// One launcher per (T, NMAX, NSETS, MODE).  The library is built from several translation units
+// of this same file (csrc/Makefile): -DARB_PART_NMAX=<tile> -DARB_PART_T=<float|double> compiles the
+// kernels of one register tile and precision only (explicit instantiations below) and none of the
+// host code; the main unit declares them extern and holds the C ABI.
+// ---------------------------------------------------------------------------
+template <typename T, int NMAX, int NSETS, int MODE>
+int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw, double dt,
+                      int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
+                      const SplitIO<T> &sio, hipStream_t st) {
+    auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
+    const size_t lds = (size_t)L.total * sizeof(T);
+    if (lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio);
+    HIP_TRY(hipGetLastError());
+    return ARB_OK;
+}
+
+#if defined(ARB_PART_NMAX) && !defined(ARB_PART)
+#error "define ARB_PART together with ARB_PART_NMAX / ARB_PART_T"
+#endif
+#define ARB_LAUNCH_ONE_ARGS(T)                                                                                             \
+    const DevModel<T> *, const Layout &, T *, T *, T *, const T *, const PerWorldPD<T> &, long, double, int, unsigned,   \
+    const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, hipStream_t
+#ifdef ARB_PART
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#else
+#if defined(ARB_SPLIT_BUILD)
+#define ARB_EXTERN_TILE(T, NM)                                                        \
+    extern template int launch_one<T, NM, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));              \
+    extern template int launch_one<T, NM, 2, 0>(ARB_LAUNCH_ONE_ARGS(T));              \
+    extern template int launch_one<T, NM, 1, 1>(ARB_LAUNCH_ONE_ARGS(T));              \
+    extern template int launch_one<T, NM, 2, 1>(ARB_LAUNCH_ONE_ARGS(T));
+ARB_EXTERN_TILE(float, 16) ARB_EXTERN_TILE(float, 32) ARB_EXTERN_TILE(float, 44) ARB_EXTERN_TILE(float, 48) ARB_EXTERN_TILE(float, 64)
+ARB_EXTERN_TILE(double, 16) ARB_EXTERN_TILE(double, 32) ARB_EXTERN_TILE(double, 44) ARB_EXTERN_TILE(double, 48) ARB_EXTERN_TILE(double, 64)
+#undef ARB_EXTERN_TILE
+#endif
 
 struct arb_model {
     int device;
@@ -1806,7 +1961,8 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot
 }
 
 struct TreeTables {
-    std::vector<int> lvlrank, lvlwidth, lvlmaxch, child_start, child_list, dofbody;
+    std::vector<int> lvlrank, lvlwidth, lvlmaxch, child_start, child_list, dofbody, subsize;
+    int dfs_contig;
     std::vector<unsigned long long> upmask, descmask;
     int maxwidth;
 };
@@ -1848,7 +2004,8 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     UP_I(weighted, std::vector<int>(d->weighted, d->weighted + nb));
     UP_I(dof2q, dof2q); UP_I(att_start, att_start); UP_I(att_c, att_c); UP_I(att_kind, att_kind);
     UP_I(lvlrank, tt.lvlrank); UP_I(lvlwidth, tt.lvlwidth); UP_I(lvlmaxch, tt.lvlmaxch); UP_I(child_start, tt.child_start);
-    UP_I(child_list, tt.child_list); UP_I(dofbody, tt.dofbody);
+    UP_I(child_list, tt.child_list); UP_I(dofbody, tt.dofbody); UP_I(subsize, tt.subsize);
+    m.dfs_contig = tt.dfs_contig;
     if ((rc = upload<unsigned long long>(M, tt.upmask, &m.upmask)) != ARB_OK) return rc;
     if ((rc = upload<unsigned long long>(M, tt.descmask, &m.descmask)) != ARB_OK) return rc;
     {
@@ -2031,6 +2188,20 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     for (int k = 0; k < n; ++k)
         for (int i = 0; i < n; ++i)
             if (((anc[tt.dofbody[i]] >> k) & 1ull) && tt.dofbody[i] != tt.dofbody[k]) tt.descmask[k] |= 1ull << i;
+    // subtree sizes; DFS preorder numbering (what World.init produces, core.py:611-615) makes every subtree a
+    // contiguous range of bodies, which lets phase B form the subtree sums from a prefix scan over the lanes
+    tt.subsize.assign(nb, 1);
+    for (int b = nb - 1; b > 0; --b) if (d->parent[b] >= 0) tt.subsize[d->parent[b]] += tt.subsize[b];   // -1: child of the ground
+    tt.dfs_contig = 1;
+    for (int b = 0; b < nb && tt.dfs_contig; ++b)
+        for (int c2 = b + 1; c2 < b + tt.subsize[b]; ++c2) {
+            int a = c2;
+            while (a > b) a = d->parent[a];                 // (a root's parent is -1)
+            if (a != b) { tt.dfs_contig = 0; break; }
+        }
+#if ARB_SCAN_SUMS
+    if (!tt.dfs_contig) return ARB_ERR_UNSUPPORTED;     // bodies must come in DFS preorder (include/arbstep.h)
+#endif
     const int maxwidth = tt.maxwidth;
 #if ARB_COMPOSITE
     // The composite assembly writes N_b as -ad([w; c x w])^T M_b, which needs rigid-body mass matrices
@@ -2145,27 +2316,17 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
     return ARB_OK;
 }
 
-template <typename T, int NMAX, int NSETS, int MODE>
-static int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw, double dt,
-                      int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
-                      const SplitIO<T> &sio, hipStream_t st) {
-    auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
-    const size_t lds = (size_t)L.total * sizeof(T);
-    if (lds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio);
-    HIP_TRY(hipGetLastError());
-    return ARB_OK;
-}
-
 template <typename T, int MODE>
 static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw,
                   double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
                   const SplitIO<T> &sio, hipStream_t st) {
 #ifdef ARB_QUICK
     // development build: a single instantiation (float, NMAX=48, one column set, production mode)
+#ifdef ARB_QUICK_INSPECT
+    if constexpr (std::is_same<T, float>::value) {
+#else
     if constexpr (std::is_same<T, float>::value && MODE == 0) {
+#endif
         if (M->nmax == 44 && M->nsets == 1)
             return launch_one<T, 44, 1, MODE>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
     }
@@ -2439,3 +2600,5 @@ extern "C" int arb_host_exp_twist(const double *tw, double *H /*16*/) {
     H[3] = p.x; H[7] = p.y; H[11] = p.z; H[12] = H[13] = H[14] = 0; H[15] = 1;
     return 0;
 }
+
+#endif  // !ARB_PART
