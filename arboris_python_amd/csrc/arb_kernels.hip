@@ -39,24 +39,14 @@
 #define ARB_WAVES_PER_EU 2      // 2nd __launch_bounds__ argument: min waves per SIMD (caps VGPRs at 256)
 #endif
 #define GS_SWEEPS 20            // core.py:929-931
+#ifndef ARB_GS_PRIO
+#define ARB_GS_PRIO 2           // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
+#endif
 
 // per-body block in LDS (elements).  The fields phase B reads are first, 16-byte aligned, so
 // that it can fetch them with 13 vector LDS loads.
-#ifndef ARB_COMPOSITE
-#ifndef ARB_PIVOT_COLUMN_LDS
-#define ARB_PIVOT_COLUMN_LDS 0   // phase C: pivot-column multipliers through LDS broadcast reads instead of v_readlane (measured: no gain, the DS pipe becomes the limit)
-#endif
-#ifndef ARB_SCAN_SUMS
-#define ARB_SCAN_SUMS 1          // phase B subtree sums from a DPP prefix scan over the body lanes (needs DFS preorder numbering); 0: level by level through LDS
-#endif
-#ifndef ARB_GS_PRIO
-#define ARB_GS_PRIO 2          // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
-#endif
-#define ARB_COMPOSITE 1   // phase B: composite (subtree-sum) assembly; 0 = body-by-body accumulation of the first rounds
-#endif
 #define BD_RCP 0     // R of Ad_cp (9)
 #define BD_PCP 9     // p of Ad_cp (3)
-#if ARB_COMPOSITE
 #define BD_OM 12     // W_c, then the accumulated pseudo twist Om_b (6), see phase B
 #define BD_PT 18     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form
 #define BD_PG 24     // M_b g_b (6)
@@ -65,22 +55,8 @@
 #define BD_TW 42     // body twist (6)
 #define BD_AB 48     // bias acceleration dJ_b * gvel (6)
 #define BD_STRIDE 54
-#else
-#define BD_DA 12     // A block of dAd_cp (9)
-#define BD_DB 21     // B block of dAd_cp (9) (+2 pad)
-#define BD_CM 32     // rx wx - wx rx (9), core.py:1287
-#define BD_W 41      // body angular velocity (3)
-#define BD_PT 44     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form (+2 pad)
-#define BD_PG 52     // M_b g_b (6)
-#define BD_RG 58     // R of H_gb (9)
-#define BD_PGB 67    // p of H_gb (3)
-#define BD_TW 70     // body twist (6)
-#define BD_AB 76     // bias acceleration dJ_b * gvel (6)
-#define BD_STRIDE 84
-#endif
 // Composite assembly of Z (phase B): per-body accumulators travelling up the tree, in float64:
 // A (36) | M upper triangle (21) | wrench of the increment rhs (6) | gravity wrench (6, inspect only)
-#define STG_STRIDE 70     // float64 slots per body in the level staging area (>= 69, even)
 #define XPR_STRIDE 18     // float64 per dof: X (6) | P = A^T X (6) | R = M X (6)
 
 // per-constraint block in LDS (elements)
@@ -97,7 +73,7 @@
 #define CD_STRIDE 56
 
 struct Layout {      // offsets in elements of T inside the wave's LDS block
-    int q, dq, qd, bd, pd, sc, jb, slots, cd, rt, am, vv, ff, ff0, work, total;
+    int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, total;
 };
 
 // exact (bit pattern) equality, also true for identical NaNs
@@ -106,20 +82,15 @@ __device__ __forceinline__ bool same_bits(double a, double b) { return __double_
 
 template <typename T>
 struct DevModel {
-    int nb, n, nq, nc, ndol, ncols, maxdepth, nslots, natt, slot_elems;
+    int nb, n, nq, nc, ndol, ncols, maxdepth;
     int has_visc, has_pd, has_warm, has_grav;
-    const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *src, *sslot, *weighted;
-    const int *dof2q, *att_start, *att_c, *att_kind;
-    // composite phase B: rank of a body among the bodies of its depth, bodies per depth, children lists,
-    // body of every dof, and per dof the dofs of ancestor-or-own / strictly descendant bodies
-    const int *lvlrank, *lvlwidth, *lvlmaxch, *child_start, *child_list, *dofbody;
+    const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *weighted;
+    const int *dof2q;
+    // composite phase B: body of every dof, bodies in the subtree of a body (DFS preorder: the subtree of b
+    // is b .. b + subsize[b] - 1), and per dof the dofs of ancestor-or-own / strictly descendant bodies
+    const int *dofbody, *subsize;
     const unsigned long long *upmask, *descmask;
-    int stage_cap;
-    int dfs_contig;            // bodies are numbered in DFS preorder: the subtree of b is b .. b + subsize[b] - 1
-    const int *subsize;        // [nb] bodies in the subtree of b (b included)
-    const unsigned long long *anc;
-    const int *bi;   // [nb][16] packed per-body ints for the phase-B loop: src, dof_off, jnd, sslot, att_start,
-                     // att_end, anc lo/hi, parent's anc lo/hi (one scalar load per body instead of eight)
+    const unsigned long long *anc;            // [nb] dofs of the body's joint and of its ancestors'
     const T *Hpr, *Hcn, *mass, *visc;         // [nb][12], [nb][12], [nb][36], [nb][36]
     const double *Hpr_d, *Hcn_d;              // float64 copies for the pose chain
     const double *clocal_d, *cradius_d, *cradius0_d, *chalf_d, *cplane_d, *cRz_d, *cb0_d, *cb1_d;
@@ -263,7 +234,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     T *lds = reinterpret_cast<T *>(arb_lds_raw);
     T *qs = lds + L.q, *dqs = lds + L.dq, *qd = lds + L.qd, *BD = lds + L.bd, *SC = lds + L.sc;
     double *PD = reinterpret_cast<double *>(lds + L.pd);
-    T *JB = lds + L.jb, *SL = lds + L.slots, *CD = lds + L.cd, *RT = lds + L.rt;
+    T *CD = lds + L.cd, *RT = lds + L.rt;
     T *AM = lds + L.am, *VV = lds + L.vv, *FF = lds + L.ff, *FF0 = lds + L.ff0, *WORK = lds + L.work;
     const int n = mp->n, nb = mp->nb, nq = mp->nq, nc = mp->nc, ndol = mp->ndol;
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
@@ -281,12 +252,19 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
     WAVE_SYNC();
 
-#ifdef ARB_BSTAMPS   /* development: slots 3..7 = sub-phases of phase B (levels, dof products, rows of Z, constraint rows, end) */
+#ifdef ARB_CSTAMPS   /* development: slots 4..7 = inside phase C (columns loaded, pivot loop done, gvel added = start of D, end of D) */
+#define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0 && (k) <= 3) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
+#define ARB_BSTAMP(k) do { } while (0)
+#define ARB_CSTAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
+#elif defined(ARB_BSTAMPS)   /* development: slots 3..7 = sub-phases of phase B (levels, dof products, rows of Z, constraint rows, end) */
 #define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0 && (k) <= 2) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
 #define ARB_BSTAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
 #else
 #define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
 #define ARB_BSTAMP(k) do { } while (0)
+#endif
+#ifndef ARB_CSTAMP
+#define ARB_CSTAMP(k) do { } while (0)
 #endif
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); } while (0)
 
@@ -394,12 +372,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const Blk<T> dAd_cp = blk_mul(Ad_cn, blk_mul(dAd_nr, Ad_rp));
                 T *bd = BD + b * BD_STRIDE;
                 st_m3(bd + BD_RCP, R_cp); st_v3(bd + BD_PCP, p_cp);
-#if !ARB_COMPOSITE
-                st_m3(bd + BD_DA, dAd_cp.A); st_m3(bd + BD_DB, dAd_cp.B);
-#else
                 // T_rn = -(aw, av) is all phase B needs from here (dAd_cp = ad(W_c) Ad_cp, W_c = Ad_cp Ad_pr T_rn)
                 st_v3(bd + BD_OM, -aw); st_v3(bd + BD_OM + 3, -av);
-#endif
                 dA_cp = dAd_cp.A; dB_cp = dAd_cp.B;
                 // Ad_cn (dJ_nr gvel_j): the joint's own contribution to dJ_c gvel
                 {
@@ -498,10 +472,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         for (int j = 0; j < 3; ++j) rx.a[3 * i + j] = Mb[6 * i + 3 + j] * im;
                 }
                 const M3<T> Cm = sub(mul(rx, wx), mul(wx, rx));
-#if !ARB_COMPOSITE
-                st_m3(bd + BD_CM, Cm);
-                st_v3(bd + BD_W, wv);
-#endif
                 // increment form of core.py:975-976: Z (gvel+ - gvel) = gforce - (N + B) gvel, and
                 // (N gvel)|_b = M_b (dJ_b gvel) + N_b T_b ;  (B gvel)|_b = B_b T_b
                 const V3<T> mtt = v3<T>(mt[0], mt[1], mt[2]), mtb = v3<T>(mt[3], mt[4], mt[5]);
@@ -608,15 +578,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const T vz0 = (mv(R0, bv0) + cross(P0, mv(R0, bw0))).z;
                     const T dsd = vz1 - vz0;
                     active = ((double)sd_d + (double)dsd * (double)dt < (double)mp->cprox[c]);
-#if ARB_COMPOSITE
                     {   // phase B works on world-axes columns about the root body's origin: store world -> contact frame 0
                         const V3<double> p0w = ld_v3(PD + 9);
                         st_m3(cd + CD_R1, cvt_m3<T>(transpose(Rc))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(Rc, gc0 - p0w)));
                     }
-#else
-                    st_m3(cd + CD_R1, R1); st_v3(cd + CD_P1, P1);
-                    st_m3(cd + CD_R0, R0); st_v3(cd + CD_P0, P0);
-#endif
                     st_v3(cd + CD_GC0, cvt_v3<T>(gc0)); st_v3(cd + CD_GC1, cvt_v3<T>(gc1));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
@@ -639,15 +604,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<double> pP1 = mv(Rg1, pf1) + pg1;
                     st_v3(cd + CD_POS0, cvt_v3<T>(mtv(RP0, pP1 - pP0)));  // p_01  constraints.py:196-197
                     // body1 -> frame 0: Ad(inv(P0) H_gb1);  body0 -> frame 0: Ad(inv(bpose0))
-#if ARB_COMPOSITE
                     {
                         const V3<double> p0w = ld_v3(PD + 9);
                         st_m3(cd + CD_R1, cvt_m3<T>(transpose(RP0))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(RP0, pP0 - p0w)));
                     }
-#else
-                    st_m3(cd + CD_R1, cvt_m3<T>(mulTA(RP0, Rg1))); st_v3(cd + CD_P1, cvt_v3<T>(mtv(RP0, pg1 - pP0)));
-                    st_m3(cd + CD_R0, cvt_m3<T>(transpose(Rf0))); st_v3(cd + CD_P0, cvt_v3<T>(-mtv(Rf0, pf0)));
-#endif
                     active = true;
                 }
             }
@@ -665,7 +625,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) Z[i] = T(0);
         T rhsM = T(0), rhsG = T(0);
-#if ARB_COMPOSITE
         // ---- composite assembly ---------------------------------------------------------------------
         // With X_k = Ad(g<-body(k)) S_k the column of dof k in WORLD axes (about the root body's
         // origin; the same vector for every body below the joint), the reference's sums over bodies
@@ -829,7 +788,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             WAVE_SYNC();                       // the per-body blocks are dead from here: the region becomes STG
             // ---- subtree sums, deepest level first; children hand their sums over through STG ------
             ARB_BSTAMP(3);
-#if ARB_SCAN_SUMS
             const int bsrc = (lane < n) ? mp->dofbody[lane] : 0;
             {
                 // Bodies in DFS preorder: subtree(a) = lanes a .. a + subsize[a] - 1, so a subtree sum is a
@@ -853,67 +811,11 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // four chains in flight (eight: slower, measured)
                 }
             }
-#else
-            {
-                typedef double D2 __attribute__((ext_vector_type(2)));
-                const int mydep = (lane < nb) ? mp->depth[lane] : -1;
-                const int myrank = (lane < nb) ? mp->lvlrank[lane] : 0;
-                const int cs = (lane < nb) ? mp->child_start[lane] : 0;
-                const int cn = (lane < nb) ? mp->child_start[lane + 1] - cs : 0;
-                const int cap = mp->stage_cap;
-                // ranks of the first children in registers: no dependent global loads inside the level loop
-                constexpr int NCR = 4;
-                int crk[NCR];
-#pragma unroll
-                for (int j = 0; j < NCR; ++j) crk[j] = (j < cn) ? mp->lvlrank[mp->child_list[cs + j]] : -1;
-                for (int lvl = mp->maxdepth; lvl >= 1; --lvl) {
-                    const int width = mp->lvlwidth[lvl];
-                    const int maxch = mp->lvlmaxch[lvl - 1];           // wave-uniform bound of the child slots at this level
-                    for (int s0 = 0; s0 < width; s0 += cap) {
-                        if (mydep == lvl && myrank >= s0 && myrank < s0 + cap) {
-                            D2 *o = reinterpret_cast<D2 *>(STG + (myrank - s0) * STG_STRIDE);
-#pragma unroll
-                            for (int i = 0; i < NACC / 2; ++i) { D2 v; v.x = Acc[2 * i]; v.y = Acc[2 * i + 1]; o[i] = v; }
-                            if (NACC & 1) STG[(myrank - s0) * STG_STRIDE + NACC - 1] = Acc[NACC - 1];
-                        }
-                        WAVE_SYNC();
-                        if (mydep == lvl - 1) {
-#pragma unroll
-                            for (int j = 0; j < NCR; ++j) {
-                                if (j >= maxch) break;
-                                const int r = crk[j];
-                                if (r < s0 || r >= s0 + cap) continue;
-                                const D2 *in = reinterpret_cast<const D2 *>(STG + (r - s0) * STG_STRIDE);
-#pragma unroll
-                                for (int i = 0; i < NACC / 2; ++i) { const D2 v = in[i]; Acc[2 * i] += v.x; Acc[2 * i + 1] += v.y; }
-                                if (NACC & 1) Acc[NACC - 1] += STG[(r - s0) * STG_STRIDE + NACC - 1];
-                            }
-                            for (int j = NCR; j < cn; ++j) {          // bodies with many children (rare)
-                                const int r = mp->lvlrank[mp->child_list[cs + j]];
-                                if (r < s0 || r >= s0 + cap) continue;
-                                const D2 *in = reinterpret_cast<const D2 *>(STG + (r - s0) * STG_STRIDE);
-#pragma unroll
-                                for (int i = 0; i < NACC / 2; ++i) { const D2 v = in[i]; Acc[2 * i] += v.x; Acc[2 * i + 1] += v.y; }
-                                if (NACC & 1) Acc[NACC - 1] += STG[(r - s0) * STG_STRIDE + NACC - 1];
-                            }
-                        }
-                        WAVE_SYNC();
-                    }
-                }
-            }
-#endif
             // ---- lane = dof k: fetch the composites of body(k), own column, the three products -----
             ARB_BSTAMP(4);
-#if !ARB_SCAN_SUMS
-            const int bsrc = (lane < n) ? mp->dofbody[lane] : 0;
-#endif
             double Xk[6], dXk[6], Gk[6];
             {
                 // from here on Acc holds the composites of body(k), not of body(lane)
-#if !ARB_SCAN_SUMS
-#pragma unroll
-                for (int i = 0; i < NACC; ++i) Acc[i] = __shfl(Acc[i], bsrc);
-#endif
                 double (&Cc)[NACC] = Acc;
                 T omk[6];
 #pragma unroll
@@ -1047,168 +949,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
             }
         }
-#else
-        {
-            T Jw[3] = {T(0), T(0), T(0)}, Jv[3] = {T(0), T(0), T(0)};
-            T dJw[3] = {T(0), T(0), T(0)}, dJv[3] = {T(0), T(0), T(0)};
-            for (int b = 0; b < nb; ++b) {
-                const int *brow = mp->bi + 16 * b;
-                const int src = brow[0];
-                if (src == 0) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { Jw[i] = Jv[i] = dJw[i] = dJv[i] = T(0); }
-                } else if (src >= 2) {
-                    // parent's columns were parked in an LDS slot; only its ancestor dofs are non-zero
-                    const unsigned long long pm = (unsigned long long)(unsigned)brow[8] | ((unsigned long long)(unsigned)brow[9] << 32);
-                    const bool mine = (pm >> lane) & 1ull;
-                    const T *sl = SL + (src - 2) * mp->slot_elems + 12 * __popcll(pm & ((1ull << lane) - 1ull));
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        Jw[i] = mine ? sl[i] : T(0); Jv[i] = mine ? sl[3 + i] : T(0);
-                        dJw[i] = mine ? sl[6 + i] : T(0); dJv[i] = mine ? sl[9 + i] : T(0);
-                    }
-                }
-                const T *bd = BD + b * BD_STRIDE;
-                typedef T BV4 __attribute__((ext_vector_type(4)));
-                T bf[52];
-                {
-                    const BV4 *b4 = reinterpret_cast<const BV4 *>(bd);     // wave-uniform address: broadcast reads
-#pragma unroll
-                    for (int i = 0; i < 13; ++i) {
-                        const BV4 t4 = b4[i];
-                        bf[4 * i] = t4.x; bf[4 * i + 1] = t4.y; bf[4 * i + 2] = t4.z; bf[4 * i + 3] = t4.w;
-                    }
-                }
-                const M3<T> R = ld_m3(bf + BD_RCP); const V3<T> p = ld_v3(bf + BD_PCP);
-                const M3<T> dA = ld_m3(bf + BD_DA), dB = ld_m3(bf + BD_DB);
-                const V3<T> jw = v3<T>(Jw[0], Jw[1], Jw[2]), jv = v3<T>(Jv[0], Jv[1], Jv[2]);
-                const V3<T> djw = v3<T>(dJw[0], dJw[1], dJw[2]), djv = v3<T>(dJv[0], dJv[1], dJv[2]);
-                // child_jac = Ad_cp J_pg ; child_djac = dAd_cp J_pg + Ad_cp dJ_pg   core.py:1309-1313
-                V3<T> nw = mv(R, jw);
-                V3<T> nv = mv(R, jv) + cross(p, nw);
-                V3<T> tdw = mv(R, djw);
-                V3<T> ndw = mv(dA, jw) + tdw;
-                V3<T> ndv = mv(dB, jw) + mv(dA, jv) + mv(R, djv) + cross(p, tdw);
-                const int d0 = brow[1];
-                if (lane >= d0 && lane < d0 + brow[2] && !((MODE == 1 ? dbg.ablate : 0) & 4)) {
-                    nw = nw + v3<T>(SC[0 * RS + lane], SC[1 * RS + lane], SC[2 * RS + lane]);
-                    nv = nv + v3<T>(SC[3 * RS + lane], SC[4 * RS + lane], SC[5 * RS + lane]);
-                    ndw = ndw + v3<T>(SC[6 * RS + lane], SC[7 * RS + lane], SC[8 * RS + lane]);
-                    ndv = ndv + v3<T>(SC[9 * RS + lane], SC[10 * RS + lane], SC[11 * RS + lane]);
-                }
-                Jw[0] = nw.x; Jw[1] = nw.y; Jw[2] = nw.z; Jv[0] = nv.x; Jv[1] = nv.y; Jv[2] = nv.z;
-                dJw[0] = ndw.x; dJw[1] = ndw.y; dJw[2] = ndw.z; dJv[0] = ndv.x; dJv[1] = ndv.y; dJv[2] = ndv.z;
-                const unsigned long long bmask = (unsigned long long)(unsigned)brow[6] | ((unsigned long long)(unsigned)brow[7] << 32);
-                const int ss = brow[3];
-                if (ss >= 0) {
-                    const unsigned long long bm = bmask;
-                    if ((bm >> lane) & 1ull) {
-                        T *sl = SL + ss * mp->slot_elems + 12 * __popcll(bm & ((1ull << lane) - 1ull));
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) { sl[i] = Jw[i]; sl[3 + i] = Jv[i]; sl[6 + i] = dJw[i]; sl[9 + i] = dJv[i]; }
-                    }
-                }
-                if (MODE == 1 && step == 0 && lane < n) {
-                    if (dbg.jac != nullptr)
-                        for (int i = 0; i < 3; ++i) {
-                            dbg.jac[((w * nb + b) * 6 + i) * n + lane] = Jw[i];
-                            dbg.jac[((w * nb + b) * 6 + 3 + i) * n + lane] = Jv[i];
-                        }
-                    if (dbg.djac != nullptr)
-                        for (int i = 0; i < 3; ++i) {
-                            dbg.djac[((w * nb + b) * 6 + i) * n + lane] = dJw[i];
-                            dbg.djac[((w * nb + b) * 6 + 3 + i) * n + lane] = dJv[i];
-                        }
-                }
-                const int abl = (MODE == 1) ? dbg.ablate : 0;
-                // per-column wrenches: U = M_b J, W = M_b dJ + N_b J, V = B_b J   core.py:726-734
-                const T *Mb = mp->mass + 36 * b;
-                T x[6] = {Jw[0], Jw[1], Jw[2], Jv[0], Jv[1], Jv[2]};
-                T dx[6] = {dJw[0], dJw[1], dJw[2], dJv[0], dJv[1], dJv[2]};
-                T U[6], W[6], Q[6];
-                if (!(abl & 2)) { mat6_vec<T>(Mb, x, U); mat6_vec<T>(Mb, dx, W); }
-                else {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) { U[i] = x[i]; W[i] = dx[i]; }
-                }
-                {
-                    const V3<T> wv = ld_v3(bf + BD_W);
-                    const M3<T> Cm = ld_m3(bf + BD_CM);
-                    const V3<T> ut = v3<T>(U[0], U[1], U[2]), ub = v3<T>(U[3], U[4], U[5]);
-                    const V3<T> top = cross(wv, ut) + mv(Cm, ub);
-                    const V3<T> bot = cross(wv, ub);
-                    W[0] += top.x; W[1] += top.y; W[2] += top.z; W[3] += bot.x; W[4] += bot.y; W[5] += bot.z;
-                }
-                if (MODE == 1 && zmode != 0) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) Q[i] = (zmode == 1) ? U[i] : ((zmode == 3) ? W[i] : T(0));
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) Q[i] = U[i] * inv_dt + W[i];
-                }
-                if (mp->has_visc) {
-                    T V[6];
-                    mat6_vec<T>(mp->visc + 36 * b, x, V);
-                    if (MODE == 0 || zmode == 0 || zmode == 2) {
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) Q[i] += V[i];
-                    }
-                }
-                // rhs of the increment form, and (inspect only) the controllers' gforce J^T M_b g_b
-#pragma unroll
-                for (int i = 0; i < 6; ++i) rhsM += x[i] * bf[BD_PT + i];
-                if (MODE == 1) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) rhsG += x[i] * bd[BD_PG + i];
-                }
-                // constraint rows hanging on this body
-                if (do_constraints) {
-                    for (int a = brow[4]; a < brow[5]; ++a) {
-                        const int c = mp->att_c[a], kind = mp->att_kind[a];
-                        const T *cd = CD + c * CD_STRIDE;
-                        const T act = cd[CD_ACTIVE];
-                        const M3<T> Rx = ld_m3(cd + (kind >= 2 ? CD_R0 : CD_R1));
-                        const V3<T> px = ld_v3(cd + (kind >= 2 ? CD_P0 : CD_P1));
-                        const V3<T> cw = mv(Rx, nw);
-                        const V3<T> cv = mv(Rx, nv) + cross(px, cw);
-                        T *row = RT + (1 + 4 * c) * RS + (lane < RS ? lane : 0);
-                        if (lane >= RS) continue;
-                        if (kind == 0 || kind == 3) {   // SoftFinger rows (w_z, v_x, v_y, v_z), +body1 / -body0
-                            const T sgn = (kind == 0) ? act : -act;                     // constraints.py:429-433
-                            row[0] += sgn * cw.z; row[RS] += sgn * cv.x;
-                            row[2 * RS] += sgn * cv.y; row[3 * RS] += sgn * cv.z;
-                        } else {                    // BallAndSocket linear rows, +frame1 / -frame0  constraints.py:203-207
-                            const T sgn = (kind == 1) ? act : -act;
-                            row[0] += sgn * cv.x; row[RS] += sgn * cv.y; row[2 * RS] += sgn * cv.z;
-                        }
-                    }
-                }
-                // publish this body's Jacobian columns and accumulate Z[i][k] += J[:,i] . Q[:,k]
-                WAVE_SYNC();
-                if (lane < RS) {
-                    JB[8 * lane + 0] = x[0]; JB[8 * lane + 1] = x[1]; JB[8 * lane + 2] = x[2]; JB[8 * lane + 3] = x[3];
-                    JB[8 * lane + 4] = x[4]; JB[8 * lane + 5] = x[5]; JB[8 * lane + 6] = T(0); JB[8 * lane + 7] = T(0);
-                }
-                WAVE_SYNC();
-                // Columns of non-ancestor dofs are exactly zero, so rows can be taken in groups of
-                // eight without per-row tests: one wave-uniform test per group, then 16 back-to-back
-                // vector LDS reads (wave-uniform addresses) and 48 FMAs.
-                const unsigned long long mask = bmask;
-                typedef T V4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-                for (int g = 0; g < (NMAX + 7) / 8; ++g) {
-                    if (((mask >> (8 * g)) & 0xffull) && !(abl & 1)) {
-#pragma unroll
-                        for (int i = 8 * g; i < (8 * g + 8 < NMAX ? 8 * g + 8 : NMAX); ++i) {
-                            const V4 ja = *reinterpret_cast<const V4 *>(JB + 8 * i);
-                            const V4 jc = *reinterpret_cast<const V4 *>(JB + 8 * i + 4);
-                            Z[i] += ja.x * Q[0] + ja.y * Q[1] + ja.z * Q[2] + ja.w * Q[3] + jc.x * Q[4] + jc.y * Q[5];
-                        }
-                    }
-                }
-            }
-        }
-#endif
         // joint-limit rows are dof selectors                              constraints.py:46-48
         if (do_constraints) {
             for (int c = 0; c < nc; ++c)
@@ -1270,12 +1010,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         for (int i = 0; i < 3; ++i) {
                             for (int j = 0; j < 3; ++j) {
                                 double acc = 0.;
-#if ARB_COMPOSITE
                                 acc = (double)cd[CD_R1 + 3 * j + i];          // CD_R1 holds Rc^T
-#else
-                                for (int k = 0; k < 3; ++k)
-                                    acc += (b1 >= 0 ? PD[12 * b1 + 3 * i + k] : (i == k ? 1. : 0.)) * (double)cd[CD_R1 + 3 * j + k];
-#endif
                                 o[4 * i + j] = (T)acc;
                             }
                             o[4 * i + 3] = cd[(f ? CD_GC1 : CD_GC0) + i];
@@ -1296,23 +1031,41 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         if (lane < RS) RT[lane] = (lane < n) ? rhs : T(0);
         WAVE_SYNC();
         const int ncols = do_constraints ? mp->ncols : n + 1;
-        if (lane >= n) {
-            const int r = lane - n;                 // column r of [rhs | J'^T]
-            const bool have = lane < ncols;
+        {
+            // column r of [rhs | J'^T] = row r of RT, fetched as 16/32-byte vectors (lanes without a column
+            // read row 0 and discard it: unconditional loads, no per-element branches)
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            if (lane >= n) {
+                const bool have = lane < ncols;
+                const V4 *src = reinterpret_cast<const V4 *>(RT + (have ? lane - n : 0) * RS);
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) Z[i] = (have && i < n) ? RT[r * RS + i] : T(0);
-        }
-        if (NSETS == 2) {
-            const int r = WAVE + lane - n;
-            const bool have = (WAVE + lane) < ncols;
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    const V4 v = src[i4];
+                    Z[4 * i4] = (have && 4 * i4 < n) ? v.x : T(0);
+                    Z[4 * i4 + 1] = (have && 4 * i4 + 1 < n) ? v.y : T(0);
+                    Z[4 * i4 + 2] = (have && 4 * i4 + 2 < n) ? v.z : T(0);
+                    Z[4 * i4 + 3] = (have && 4 * i4 + 3 < n) ? v.w : T(0);
+                }
+            }
+            if (NSETS == 2) {
+                const bool have = (WAVE + lane) < ncols;
+                const V4 *src = reinterpret_cast<const V4 *>(RT + (have ? WAVE + lane - n : 0) * RS);
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) Z2[i] = (have && i < n) ? RT[r * RS + i] : T(0);
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    const V4 v = src[i4];
+                    Z2[4 * i4] = (have && 4 * i4 < n) ? v.x : T(0);
+                    Z2[4 * i4 + 1] = (have && 4 * i4 + 1 < n) ? v.y : T(0);
+                    Z2[4 * i4 + 2] = (have && 4 * i4 + 2 < n) ? v.z : T(0);
+                    Z2[4 * i4 + 3] = (have && 4 * i4 + 3 < n) ? v.w : T(0);
+                }
+            }
         }
         // Pivots are taken from the last dof to the first (extremities before the
         // root): on these graded, nearly-SPD matrices that order halves the float32
         // error of pivot-free elimination (measured).  The register file
         // is rotated one row per step so that the pivot row always sits in
         // Z[NMAX-1] and every index below is a compile-time constant.
+        ARB_CSTAMP(4);
         for (int j = n; j < NMAX; ++j) {           // bring row n-1 into Z[NMAX-1]
             const T t = Z[NMAX - 1];
             T t2 = T(0);
@@ -1322,44 +1075,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             Z[0] = t;
             if (NSETS == 2) Z2[0] = t2;
         }
-#if ARB_PIVOT_COLUMN_LDS
-        // The multipliers of a pivot step are the entries of column j, i.e. lane j's registers.  Lane j
-        // writes them to LDS and every lane reads them back as broadcast vector loads: the wave's vector
-        // ALU then issues one fma per row instead of a v_readlane + wait states + fma (the kernel is
-        // VALU-issue bound; the DS pipe has room).
-        {
-            typedef T V4 __attribute__((ext_vector_type(4)));
-            V4 *W4 = reinterpret_cast<V4 *>(WORK);          // 64 elements >= NMAX; the Gauss-Seidel stage uses it later
-            for (int j = n - 1; j >= 0; --j) {
-                if (lane == j) {
-#pragma unroll
-                    for (int i4 = 0; i4 < NMAX / 4; ++i4) {
-                        V4 z4; z4.x = Z[4 * i4]; z4.y = Z[4 * i4 + 1]; z4.z = Z[4 * i4 + 2]; z4.w = Z[4 * i4 + 3];
-                        W4[i4] = z4;
-                    }
-                }
-                WAVE_SYNC();
-                T F[NMAX];
-#pragma unroll
-                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
-                    const V4 f4 = W4[i4];
-                    F[4 * i4] = f4.x; F[4 * i4 + 1] = f4.y; F[4 * i4 + 2] = f4.z; F[4 * i4 + 3] = f4.w;
-                }
-                WAVE_SYNC();
-                const T ip = arb_rcp(F[NMAX - 1]);
-                const T t = Z[NMAX - 1] * ip;
-                T t2 = T(0);
-                if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
-#pragma unroll
-                for (int r = NMAX - 1; r >= 1; --r) {
-                    Z[r] = Z[r - 1] - F[r - 1] * t;
-                    if (NSETS == 2) Z2[r] = Z2[r - 1] - F[r - 1] * t2;
-                }
-                Z[0] = t;
-                if (NSETS == 2) Z2[0] = t2;
-            }
-        }
-#else
         for (int j = n - 1; j >= 0; --j) {
             const T piv = bcast(Z[NMAX - 1], j);
             const T ip = arb_rcp(piv);
@@ -1385,21 +1100,33 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             Z[0] = t;
             if (NSETS == 2) Z2[0] = t2;
         }
-#endif
+        ARB_CSTAMP(5);
         // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
-        if (lane == n) {
+        {
+            // (dqs is zero beyond ndof; rows >= ndof of the columns are never used)
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            const V4 *d4 = reinterpret_cast<const V4 *>(dqs);
+            if (lane == n) {
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) if (i < n) Z[i] += dqs[i];
-        }
-        if (NSETS == 2 && WAVE + lane == n) {
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    const V4 v = d4[i4];
+                    Z[4 * i4] += v.x; Z[4 * i4 + 1] += v.y; Z[4 * i4 + 2] += v.z; Z[4 * i4 + 3] += v.w;
+                }
+            }
+            if (NSETS == 2 && WAVE + lane == n) {
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) if (i < n) Z2[i] += dqs[i];
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    const V4 v = d4[i4];
+                    Z2[4 * i4] += v.x; Z2[4 * i4 + 1] += v.y; Z2[4 * i4 + 2] += v.z; Z2[4 * i4 + 3] += v.w;
+                }
+            }
         }
         // lanes >= n (and the second set) now hold Y rhs and Y J'^T columns
 
         // ================= phase D: constraint space + Gauss-Seidel ==========
         ARB_OPAQUE_LANE();
         ARB_STAMP(4);
+        ARB_CSTAMP(6);
         if (do_constraints) {
             // [v | Y'] = J' [Y rhs | Y J'^T]                                core.py:925-927
             typedef T V4 __attribute__((ext_vector_type(4)));
@@ -1425,13 +1152,29 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         }
         // solution columns -> LDS (row r of RT := column r of [Y rhs | Y J'^T])
         WAVE_SYNC();
-        if (lane >= n && lane < ncols) {
+        {
+            // (whole rows of RS elements, vector stores; entries >= ndof are written as zero: "columns >= ndof stay zero")
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            if (lane >= n && lane < ncols) {
+                V4 *dst = reinterpret_cast<V4 *>(RT + (lane - n) * RS);
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(lane - n) * RS + i] = Z[i];
-        }
-        if (NSETS == 2 && (WAVE + lane) < ncols) {
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    V4 v;
+                    v.x = (4 * i4 < n) ? Z[4 * i4] : T(0); v.y = (4 * i4 + 1 < n) ? Z[4 * i4 + 1] : T(0);
+                    v.z = (4 * i4 + 2 < n) ? Z[4 * i4 + 2] : T(0); v.w = (4 * i4 + 3 < n) ? Z[4 * i4 + 3] : T(0);
+                    dst[i4] = v;
+                }
+            }
+            if (NSETS == 2 && (WAVE + lane) < ncols) {
+                V4 *dst = reinterpret_cast<V4 *>(RT + (WAVE + lane - n) * RS);
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i) if (i < n) RT[(WAVE + lane - n) * RS + i] = Z2[i];
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    V4 v;
+                    v.x = (4 * i4 < n) ? Z2[4 * i4] : T(0); v.y = (4 * i4 + 1 < n) ? Z2[4 * i4 + 1] : T(0);
+                    v.z = (4 * i4 + 2 < n) ? Z2[4 * i4 + 2] : T(0); v.w = (4 * i4 + 3 < n) ? Z2[4 * i4 + 3] : T(0);
+                    dst[i4] = v;
+                }
+            }
         }
         WAVE_SYNC();
         if (MODE == 1 && dbg.vel_free != nullptr && lane < n) dbg.vel_free[w * n + lane] = RT[lane];
@@ -1465,6 +1208,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             }
             WAVE_SYNC();
             ARB_STAMP(5);
+            ARB_CSTAMP(7);
             // ---- Gauss-Seidel, core.py:929-935, register resident ----------------------
             // lane = row of the stacked constraint system: it keeps its velocity, its force,
             // its row of the constraint's own admittance block Y_cc and of inv(Y_cc).  Lane c
@@ -1916,38 +1660,23 @@ static std::vector<double> h12(const double *H16, int count) {
     return v;
 }
 
-// Size (in elements of T) of the per-body block region.  In the composite build the region is
-// reused, once phase A' is over, as float64 scratch: the level staging area of the tree
-// accumulation (stage_cap bodies x STG_STRIDE) and then the per-dof X | P | R vectors.
-static int bd_region_elems(int nb, int rs, int elems_per_double, int maxwidth, int *stage_cap) {
+// Size (in elements of T) of the per-body block region.  Once phase A' is over the region is
+// reused as float64 scratch for the per-dof X | P | R vectors of phase B.
+static int bd_region_elems(int nb, int rs, int elems_per_double) {
     auto al = [](int x) { return (x + 3) & ~3; };
-    int sz = al(nb * BD_STRIDE);
-#if ARB_COMPOSITE
-    sz = std::max(sz, al(XPR_STRIDE * rs * elems_per_double));
-    sz = std::max(sz, al(STG_STRIDE * elems_per_double));
-    *stage_cap = std::max(1, std::min(maxwidth, sz / (STG_STRIDE * elems_per_double)));
-#else
-    *stage_cap = 1;
-#endif
-    return sz;
+    return std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double));
 }
 
-static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot_elems, int rs, int elems_per_double, int maxwidth, int *total_elems) {
+static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
-    int cap;
     L.q = o; o += al(nq);
     L.dq = o; o += WAVE;
     L.qd = o; o += WAVE;
-    L.bd = o; o += bd_region_elems(nb, rs, elems_per_double, maxwidth, &cap);
-#if ARB_COMPOSITE
-    nslots = 0; slot_elems = 4;          // no Jacobian propagation: no parking slots
-#endif
+    L.bd = o; o += bd_region_elems(nb, rs, elems_per_double);
     L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
     L.sc = o; o += 12 * rs;
-    L.jb = o; o += ARB_COMPOSITE ? 4 : 8 * rs;
-    L.slots = o; o += al(std::max(nslots, 1) * std::max(slot_elems, 12));
     L.cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
     L.rt = o; o += (1 + ndol) * rs;
     L.am = o; o += al(std::max(ndol * ndol, 4));
@@ -1961,10 +1690,8 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int nslots, int slot
 }
 
 struct TreeTables {
-    std::vector<int> lvlrank, lvlwidth, lvlmaxch, child_start, child_list, dofbody, subsize;
-    int dfs_contig;
+    std::vector<int> dofbody, subsize;
     std::vector<unsigned long long> upmask, descmask;
-    int maxwidth;
 };
 
 // zaligned(normal), arboris/homogeneousmatrix.py:201-232 (constant for a contact plane)
@@ -1982,16 +1709,13 @@ static void zaligned_host(const double z[3], double R[9]) {
 
 template <typename T>
 static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<int> &jnd,
-                     const std::vector<int> &depth, const std::vector<int> &src,
-                     const std::vector<int> &sslot, const std::vector<unsigned long long> &anc,
-                     const std::vector<int> &dof2q, const std::vector<int> &att_start,
-                     const std::vector<int> &att_c, const std::vector<int> &att_kind,
-                     int maxdepth, int nslots, int slot_elems, const TreeTables &tt, DevModel<T> *out) {
+                     const std::vector<int> &depth, const std::vector<unsigned long long> &anc,
+                     const std::vector<int> &dof2q, int maxdepth, const TreeTables &tt, DevModel<T> *out) {
     DevModel<T> m;
     memset(&m, 0, sizeof(m));
     const int nb = d->nb, n = d->ndof, nc = d->nc;
     m.nb = nb; m.n = n; m.nq = d->nq; m.nc = nc; m.ndol = ARB_MAXDOL * nc; m.ncols = n + 1 + m.ndol;
-    m.maxdepth = maxdepth; m.nslots = nslots; m.natt = (int)att_c.size(); m.slot_elems = slot_elems;
+    m.maxdepth = maxdepth;
     int rc;
 #define UP_I(field, vec) if ((rc = upload<int>(M, vec, &m.field)) != ARB_OK) return rc
 #define UP_T(field, vec) if ((rc = upload<T>(M, vec, &m.field)) != ARB_OK) return rc
@@ -2000,32 +1724,13 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     UP_I(dof_off, std::vector<int>(d->dof_off, d->dof_off + nb));
     UP_I(jnd, jnd);
     UP_I(q_off, std::vector<int>(d->q_off, d->q_off + nb));
-    UP_I(depth, depth); UP_I(src, src); UP_I(sslot, sslot);
+    UP_I(depth, depth);
     UP_I(weighted, std::vector<int>(d->weighted, d->weighted + nb));
-    UP_I(dof2q, dof2q); UP_I(att_start, att_start); UP_I(att_c, att_c); UP_I(att_kind, att_kind);
-    UP_I(lvlrank, tt.lvlrank); UP_I(lvlwidth, tt.lvlwidth); UP_I(lvlmaxch, tt.lvlmaxch); UP_I(child_start, tt.child_start);
-    UP_I(child_list, tt.child_list); UP_I(dofbody, tt.dofbody); UP_I(subsize, tt.subsize);
-    m.dfs_contig = tt.dfs_contig;
+    UP_I(dof2q, dof2q);
+    UP_I(dofbody, tt.dofbody); UP_I(subsize, tt.subsize);
     if ((rc = upload<unsigned long long>(M, tt.upmask, &m.upmask)) != ARB_OK) return rc;
     if ((rc = upload<unsigned long long>(M, tt.descmask, &m.descmask)) != ARB_OK) return rc;
-    {
-        int cap;
-        (void)bd_region_elems(nb, M->nmax, sizeof(T) == 4 ? 2 : 1, tt.maxwidth, &cap);
-        m.stage_cap = cap;
-    }
     if ((rc = upload<unsigned long long>(M, anc, &m.anc)) != ARB_OK) return rc;
-    {
-        std::vector<int> bi(16 * (size_t)nb, 0);
-        for (int b = 0; b < nb; ++b) {
-            int *r = bi.data() + 16 * b;
-            const unsigned long long am = anc[b], pm = d->parent[b] >= 0 ? anc[d->parent[b]] : 0ull;
-            r[0] = src[b]; r[1] = d->dof_off[b]; r[2] = jnd[b]; r[3] = sslot[b];
-            r[4] = att_start[b]; r[5] = att_start[b + 1];
-            r[6] = (int)(unsigned)(am & 0xffffffffull); r[7] = (int)(unsigned)(am >> 32);
-            r[8] = (int)(unsigned)(pm & 0xffffffffull); r[9] = (int)(unsigned)(pm >> 32);
-        }
-        UP_I(bi, bi);
-    }
     UP_T(Hpr, conv<T>(h12(d->H_pr, nb).data(), 12 * nb));
     UP_T(Hcn, conv<T>(h12(d->H_cn, nb).data(), 12 * nb));
     if ((rc = upload<double>(M, h12(d->H_pr, nb), &m.Hpr_d)) != ARB_OK) return rc;
@@ -2149,7 +1854,7 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     const int ncols = n + 1 + ndol;
     if (ncols > 2 * WAVE || ndol > WAVE) return ARB_ERR_UNSUPPORTED;
     // ---- tree bookkeeping (counterpart of World.init, core.py:608-635) ----
-    std::vector<int> jnd(nb), depth(nb), src(nb), sslot(nb, -1), lastchild(nb, -1);
+    std::vector<int> jnd(nb), depth(nb);
     std::vector<unsigned long long> anc(nb);
     std::vector<int> dof2q(n, -1);
     int maxdepth = 0, ndof_chk = 0, nq_chk = 0;
@@ -2164,25 +1869,13 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         unsigned long long own = 0;
         for (int i = 0; i < jnd[b]; ++i) own |= 1ull << (d->dof_off[b] + i);
         anc[b] = own | (p < 0 ? 0ull : anc[p]);
-        if (p >= 0) lastchild[p] = b;
         if (jt != ARB_JT_FREE)
             for (int i = 0; i < jnd[b]; ++i) dof2q[d->dof_off[b] + i] = d->q_off[b] + i;
     }
     if (ndof_chk != n || nq_chk != d->nq) return ARB_ERR_INVALID;
     // composite phase B tables
     TreeTables tt;
-    tt.lvlrank.assign(nb, 0); tt.lvlwidth.assign(maxdepth + 1, 0); tt.child_start.assign(nb + 1, 0);
     tt.dofbody.assign(n, 0); tt.upmask.assign(n, 0ull); tt.descmask.assign(n, 0ull);
-    for (int b = 0; b < nb; ++b) tt.lvlrank[b] = tt.lvlwidth[depth[b]]++;
-    for (int b = 0; b < nb; ++b) {
-        tt.child_start[b] = (int)tt.child_list.size();
-        for (int c2 = b + 1; c2 < nb; ++c2) if (d->parent[c2] == b) tt.child_list.push_back(c2);
-    }
-    tt.child_start[nb] = (int)tt.child_list.size();
-    tt.lvlmaxch.assign(maxdepth + 1, 0);          // most children any body has at this level (children sit one level down)
-    for (int b = 0; b < nb; ++b)
-        tt.lvlmaxch[depth[b]] = std::max(tt.lvlmaxch[depth[b]], tt.child_start[b + 1] - tt.child_start[b]);
-    tt.maxwidth = *std::max_element(tt.lvlwidth.begin(), tt.lvlwidth.end());
     for (int b = 0; b < nb; ++b)
         for (int i = 0; i < jnd[b]; ++i) { tt.dofbody[d->dof_off[b] + i] = b; tt.upmask[d->dof_off[b] + i] = anc[b]; }
     for (int k = 0; k < n; ++k)
@@ -2192,18 +1885,12 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     // contiguous range of bodies, which lets phase B form the subtree sums from a prefix scan over the lanes
     tt.subsize.assign(nb, 1);
     for (int b = nb - 1; b > 0; --b) if (d->parent[b] >= 0) tt.subsize[d->parent[b]] += tt.subsize[b];   // -1: child of the ground
-    tt.dfs_contig = 1;
-    for (int b = 0; b < nb && tt.dfs_contig; ++b)
+    for (int b = 0; b < nb; ++b)
         for (int c2 = b + 1; c2 < b + tt.subsize[b]; ++c2) {
             int a = c2;
             while (a > b) a = d->parent[a];                 // (a root's parent is -1)
-            if (a != b) { tt.dfs_contig = 0; break; }
+            if (a != b) return ARB_ERR_UNSUPPORTED;         // bodies must come in DFS preorder (include/arbstep.h)
         }
-#if ARB_SCAN_SUMS
-    if (!tt.dfs_contig) return ARB_ERR_UNSUPPORTED;     // bodies must come in DFS preorder (include/arbstep.h)
-#endif
-    const int maxwidth = tt.maxwidth;
-#if ARB_COMPOSITE
     // The composite assembly writes N_b as -ad([w; c x w])^T M_b, which needs rigid-body mass matrices
     // [[I, m c^],[m c^T, m 1]] (everything arboris/massmatrix.py builds); anything else is refused.
     for (int b = 0; b < nb; ++b) {
@@ -2219,55 +1906,20 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         }
         if (!ok) return ARB_ERR_UNSUPPORTED;
     }
-#endif
-    // Jacobian save slots: a body whose columns are needed again after its first
-    // child's subtree keeps them in an LDS slot for the lifetime [b, lastchild[b]]
-    std::vector<int> slot_owner;
-    for (int b = 0; b < nb; ++b) {
-        const int p = d->parent[b];
-        if (p < 0) src[b] = 0;
-        else if (p == b - 1) src[b] = 1;
-        else src[b] = 2 + sslot[p];
-        bool need = false;
-        for (int c2 = b + 2; c2 < nb; ++c2) if (d->parent[c2] == b) need = true;
-        if (need) {
-            int s = -1;
-            for (size_t i = 0; i < slot_owner.size(); ++i)
-                if (lastchild[slot_owner[i]] <= b) { s = (int)i; break; }
-            if (s < 0) { s = (int)slot_owner.size(); slot_owner.push_back(b); } else slot_owner[s] = b;
-            sslot[b] = s;
-        }
-    }
-    for (int b = 0; b < nb; ++b) if (src[b] >= 2 && src[b] - 2 < 0) return ARB_ERR_INVALID;
-    const int nslots = (int)slot_owner.size();
-    int slot_elems = 12;
-    for (int b = 0; b < nb; ++b)
-        if (sslot[b] >= 0) slot_elems = std::max(slot_elems, 12 * (int)__builtin_popcountll(anc[b]));
-    // constraint attachments per body
-    std::vector<std::vector<std::pair<int, int>>> per_body(nb);
+    // constraint table checks
     for (int c = 0; c < nc; ++c) {
         const int ct = d->ctype[c];
         if (ct == ARB_CT_SOFTFINGER) {
             if (d->c_body[c] >= nb || d->c_body0[c] >= nb) return ARB_ERR_INVALID;
             if (d->c_geom[c] < ARB_CG_PLANE_SPHERE || d->c_geom[c] > ARB_CG_BOX_SPHERE) return ARB_ERR_INVALID;
-            if (d->c_body[c] >= 0) per_body[d->c_body[c]].push_back({c, 0});
-            if (d->c_body0[c] >= 0) per_body[d->c_body0[c]].push_back({c, 3});
         } else if (ct == ARB_CT_BALLSOCKET) {
             if (d->c_body[c] >= nb || d->c_body0[c] >= nb) return ARB_ERR_INVALID;
-            if (d->c_body[c] >= 0) per_body[d->c_body[c]].push_back({c, 1});
-            if (d->c_body0[c] >= 0) per_body[d->c_body0[c]].push_back({c, 2});
         } else if (ct == ARB_CT_JOINTLIMITS) {
             if (d->c_dof[c] < 0 || d->c_dof[c] >= n || dof2q[d->c_dof[c]] < 0) return ARB_ERR_INVALID;
         } else {
             return ARB_ERR_INVALID;
         }
     }
-    std::vector<int> att_start(nb + 1, 0), att_c, att_kind;
-    for (int b = 0; b < nb; ++b) {
-        att_start[b] = (int)att_c.size();
-        for (auto &pr : per_body[b]) { att_c.push_back(pr.first); att_kind.push_back(pr.second); }
-    }
-    att_start[nb] = (int)att_c.size();
 
     arb_model *M = new (std::nothrow) arb_model();
     if (!M) return ARB_ERR_NOMEM;
@@ -2278,9 +1930,9 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete M; return ARB_ERR_HIP; }
-    int rc = build_dev<float>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, tt, &M->df);
+    int rc = build_dev<float>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->df);
     if (rc == ARB_OK)
-        rc = build_dev<double>(M, d, jnd, depth, src, sslot, anc, dof2q, att_start, att_c, att_kind, maxdepth, nslots, slot_elems, tt, &M->dd);
+        rc = build_dev<double>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     {
         const DevModel<float> *pf = nullptr; const DevModel<double> *pd = nullptr;
@@ -2290,8 +1942,8 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         M->df_dev = const_cast<DevModel<float> *>(pf); M->dd_dev = const_cast<DevModel<double> *>(pd);
     }
     int tot;
-    M->lf = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 2, maxwidth, &tot);
-    M->ld = make_layout(nb, d->nq, nc, ndol, nslots, slot_elems, M->nmax, 1, maxwidth, &tot);
+    M->lf = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
+    M->ld = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     *out = M;
     return ARB_OK;
