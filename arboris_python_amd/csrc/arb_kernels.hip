@@ -10,15 +10,19 @@
 //                          (Body.update_dynamic core.py:1158-1315, uniform part)
 //   A'  lane = constraint  collision + contact frames (constraints.py:277-294,
 //                          collisions.py:161-205), activity test
-//   B   lane = dof column  Jacobian / dJacobian columns of the visited body,
-//                          Z = M/dt + B + N accumulated column-per-lane in
-//                          registers (core.py:722-734, 813), rhs = M gvel/dt + gforce
+//   B   lane = body, then  composite assembly of Z = M/dt + B + N in float64: per-body world-frame
+//       lane = dof column  blocks, subtree sums by a DPP prefix scan over the body lanes (bodies come
+//                          in DFS preorder), one column of Z per lane in registers
+//                          (core.py:722-734, 813), rhs of the increment form, constraint rows
 //   C   lane = column of the augmented system [Z | rhs | J'^T]: Gauss-Jordan in
 //                          registers with v_readlane broadcasts -> Y rhs, Y J'^T
 //                          (replaces numpy.linalg.inv, core.py:818, 925-927)
-//   D   wave-uniform       20 Gauss-Seidel sweeps (core.py:929-935)
+//   D   lane = constraint row: [v | Y'] = J' [Y rhs | Y J'^T], then the 20 Gauss-Seidel
+//                          sweeps (core.py:929-935), register resident
 //   E   lane = dof         new gvel, joint integration (core.py:974-980)
 //
+// The library is linked from several translation units of this file (csrc/Makefile): one per
+// (register tile NMAX, precision) with the kernels only, and the host unit with the C ABI.
 // No CUDA/CPU fallback exists: the library needs a gfx950 device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -92,8 +92,11 @@ enum {
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the
- * moving bodies in depth-first order (DOF numbering of core.py:611-615); body b
- * is attached to parent[b] (-1 = ground) through one joint.
+ * moving bodies in depth-first PREORDER (the DOF numbering of core.py:611-615):
+ * parent[b] < b, and the subtree of b is the contiguous range b .. b + size - 1
+ * (the kernel forms subtree sums from a prefix scan over that order; any other
+ * numbering is refused with ARB_ERR_UNSUPPORTED).  Body b is attached to
+ * parent[b] (-1 = ground; several roots are allowed) through one joint.
  */
 typedef struct arb_model_desc {
     int32_t abi_version;      /* ARB_ABI_VERSION */
