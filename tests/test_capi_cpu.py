@@ -49,6 +49,23 @@ def test_argument_validation_without_gpu():
     assert lib.arb_model_destroy(None) == 1
 
 
+@needs_lib
+def test_body_numbering_must_be_dfs_preorder():
+    """World.init numbers bodies depth first (core.py:611-615); the kernels rely on contiguous subtrees
+    (prefix-scan subtree sums) and arb_model_create refuses anything else before touching the device."""
+    lib = _capi.load()
+    h = C.c_void_p()
+    m, _, _ = load_model("human36_g")
+    desc, keep = _capi.make_desc(m)
+    parent = np.array(m.parent, dtype=np.int32).copy()
+    assert parent[1] == 0 and parent[-1] not in (0, 1)
+    parent[-1] = 1                      # the last body hangs below body 1, whose subtree ended long before
+    keep.append(parent)
+    desc.parent = parent.ctypes.data_as(C.POINTER(C.c_int32))
+    assert lib.arb_model_create(C.byref(desc), 0, C.byref(h)) == 2          # ARB_ERR_UNSUPPORTED
+    assert not h.value
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_capi, "_lib", None)
     monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libarbstep.so")
