@@ -332,7 +332,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // (sdist) is a difference of O(1 m) positions that is then divided by dt, so
             // float32 rounding of the pose chain alone would cost ~1e-7/dt = 2e-5 m/s.
             M3<T> R_pc, R_cp, R_cn, dA_cp, dB_cp; V3<T> p_pc, p_cp, p_cn, Tnw, Tnv, Bnw, Bnv;
-            M3<double> R_pc_d = m3_identity<double>(); V3<double> p_pc_d = v3<double>(0., 0., 0.);
             R_pc = R_cp = R_cn = m3_identity<T>();
             dA_cp = dB_cp = m3_zero<T>();
             p_pc = p_cp = p_cn = Tnw = Tnv = Bnw = Bnv = v3<T>(T(0), T(0), T(0));
@@ -356,11 +355,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const V3<double> ppr = ld_v3(mp->Hpr_d + 12 * b + 9), pcn = ld_v3(mp->Hcn_d + 12 * b + 9);
                     const M3<double> R_rc = mulBT(jld.R, Rcn);
                     const V3<double> p_rc = mv(jld.R, -mtv(Rcn, pcn)) + jld.p;
-                    R_pc_d = mul(Rpr, R_rc);
-                    p_pc_d = mv(Rpr, p_rc) + ppr;
+                    const M3<double> R_pc_d = mul(Rpr, R_rc);
+                    const V3<double> p_pc_d = mv(Rpr, p_rc) + ppr;
+                    // parked in the body's own pose slot until its depth level comes (24 registers less across
+                    // the level loop: phase A is the register-pressure peak of the kernel)
+                    st_m3(PD + 12 * b, R_pc_d); st_v3(PD + 12 * b + 9, p_pc_d);
+                    R_pc = cvt_m3<T>(R_pc_d);
+                    p_pc = cvt_v3<T>(p_pc_d);
                 }
-                R_pc = cvt_m3<T>(R_pc_d);
-                p_pc = cvt_v3<T>(p_pc_d);
                 R_cp = transpose(R_pc);                          // Ad_cp = Ad(inv(H_pc)) :1300
                 p_cp = -mtv(R_pc, p_pc);
                 // Ad_nr, T_rn = -Ad_nr T_nr, dAd_nr = Ad_nr ad(T_rn)   rigidmotion.py:47-73
@@ -427,6 +429,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
                         aw = ld_v3(pb + BD_AB); av = ld_v3(pb + BD_AB + 3);
                     }
+                    const M3<double> R_pc_d = ld_m3(PD + 12 * b);
+                    const V3<double> p_pc_d = ld_v3(PD + 12 * b + 9);
                     const M3<double> Rc_d = mul(Rg, R_pc_d);         // child_pose  core.py:1299
                     const V3<double> pc_d = mv(Rg, p_pc_d) + pg;
                     st_m3(PD + 12 * b, Rc_d); st_v3(PD + 12 * b + 9, pc_d);

@@ -204,6 +204,25 @@ ARB_HD double arb_abs(double x) { return x < 0. ? -x : x; }
 ARB_HD float arb_sqrt(float x) { return sqrtf(x); }
 ARB_HD double arb_sqrt(double x) { return sqrt(x); }
 ARB_HD void arb_sincos(float a, float *s, float *c) { *s = sinf(a); *c = cosf(a); }
+// A float64 constant materialised by two v_mov_b32 exactly where it is used (see arb_sincos): the
+// volatile asm cannot be hoisted out of the step loop.
+template <unsigned LO, unsigned HI>
+ARB_HD double arb_pinned_bits() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int lo, hi;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "n"(LO));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "n"(HI));
+    return __hiloint2double(hi, lo);
+#else
+    const unsigned long long b = ((unsigned long long)HI << 32) | LO;
+    double x;
+    memcpy(&x, &b, sizeof(x));
+    return x;
+#endif
+}
+#define arb_pinned_const(x)                                                                           \
+    arb_pinned_bits<(unsigned)(__builtin_bit_cast(unsigned long long, (double)(x)) & 0xffffffffull),    \
+                    (unsigned)(__builtin_bit_cast(unsigned long long, (double)(x)) >> 32)>()
 // float64 sin/cos for joint angles.  On the device this is a branch-free Cody-Waite
 // reduction by pi/2 (two constants, exact to ~1e-17 * |a| for |a| < 1e5 rad) followed by
 // the classic minimax kernels on [-pi/4, pi/4] (fdlibm __kernel_sin/__kernel_cos
@@ -216,10 +235,14 @@ ARB_HD void arb_sincos(double a, double *s, double *c) {
     r = fma(-k, 6.07710050650619224932e-11, r);
     r = fma(-k, 2.02226624879595063154e-21, r);
     const double z = r * r;
-    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04
-                    + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
-                    + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    // The coefficients are materialised where they are used (K): left to itself the compiler hoists the
+    // 64-bit literals out of the step loop into registers and then spills them to scratch memory.
+#define K(x) arb_pinned_const(x)
+    const double ps = K(-1.66666666666666324348e-01) + z * (K(8.33333333332248946124e-03) + z * (K(-1.98412698298579493134e-04)
+                    + z * (K(2.75573137070700676789e-06) + z * (K(-2.50507602534068634195e-08) + z * K(1.58969099521155010221e-10)))));
+    const double pc = K(4.16666666666666019037e-02) + z * (K(-1.38888888888741095749e-03) + z * (K(2.48015872894767294178e-05)
+                    + z * (K(-2.75573143513906633035e-07) + z * (K(2.08757232129817482790e-09) + z * K(-1.13596475577881948265e-11)))));
+#undef K
     const double sr = fma(r * z, ps, r);
     const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
     const int q = (int)k & 3;
