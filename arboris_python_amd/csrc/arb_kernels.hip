@@ -1294,37 +1294,38 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     // own-row products (meaningful on lanes base..base+3)
                     const T v0r = vr - (Yrow[0] * fc[0] + Yrow[1] * fc[1] + Yrow[2] * fc[2] + Yrow[3] * fc[3]);
                     if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
-                        const T sd = bcast(k_sd, c), mu = bcast(k_mu, c);
+                        // The release test and the static-friction candidate are evaluated side by side
+                        // (two independent dependent chains that overlap in the pipeline) before any
+                        // branch: the sweeps are one long latency chain, a few wasted instructions in
+                        // the release case are cheaper than serialising the two.
+                        const T sd = bcast(k_sd, c), mu = bcast(k_mu, c), sdt = bcast(k_sdt, c);
+                        const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
+                        const T dfr = -(Prow[0] * vc[0] + Prow[1] * vc[1] + Prow[2] * vc[2] + Prow[3] * (vc[3] + sdt));
+                        const T fnr = fr + dfr;
                         const T v0n = bcast(v0r, base + 3);
+                        T fn[4], dfs[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { fn[i] = bcast(fnr, base + i); dfs[i] = bcast(dfr, base + i); }
+                        T eps[3] = {T(1), T(1), T(1)};
+                        T lhs;
+                        if (eps1) {
+                            lhs = fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2];
+                        } else {
+                            eps[0] = bcast(k_e0, c); eps[1] = bcast(k_e1, c); eps[2] = bcast(k_e2, c);
+                            lhs = (fn[0] / eps[0]) * (fn[0] / eps[0]) + (fn[1] / eps[1]) * (fn[1] / eps[1])
+                                + (fn[2] / eps[2]) * (fn[2] / eps[2]);
+                        }
+                        const T rhs = (fn[3] * mu) * (fn[3] * mu);
                         if (sd + dt * v0n > T(0)) {                        // release
                             if (MODE == 1) ++st_rel;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { df[i] = -fc[i]; fnew[i] = T(0); }
                         } else {
-                            const T sdt = bcast(k_sdt, c);
-                            const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
-                            const T dfr = -(Prow[0] * vc[0] + Prow[1] * vc[1] + Prow[2] * vc[2] + Prow[3] * (vc[3] + sdt));
-                            const T fnr = fr + dfr;
-                            T fn[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) fn[i] = bcast(fnr, base + i);
-                            T eps[3] = {T(1), T(1), T(1)};
-                            T lhs;
-                            if (eps1) {
-                                lhs = fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2];
-                            } else {
-                                eps[0] = bcast(k_e0, c); eps[1] = bcast(k_e1, c); eps[2] = bcast(k_e2, c);
-                                lhs = (fn[0] / eps[0]) * (fn[0] / eps[0]) + (fn[1] / eps[1]) * (fn[1] / eps[1])
-                                    + (fn[2] / eps[2]) * (fn[2] / eps[2]);
-                            }
-                            const T rhs = (fn[3] * mu) * (fn[3] * mu);
                             if (lhs <= rhs) {                              // static friction
                                 if (MODE == 1) ++st_sta;
+                                // df is exactly -pinv(Y)(...) as in the reference, taken from the rows
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) fnew[i] = fn[i];
-                                // df must be exactly -pinv(Y)(...) as in the reference: recover it from the rows
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) df[i] = bcast(dfr, base + i);
+                                for (int i = 0; i < 4; ++i) { fnew[i] = fn[i]; df[i] = dfs[i]; }
                             } else {                                       // sliding friction
                                 T alpha[4], shift = T(0);
 #pragma unroll

@@ -244,3 +244,27 @@ def test_world_parse_order_and_scene_export(tmp_path):
     def count(node):
         return 1 + sum(count(l["child"]) for l in node["links"]) + sum(count(f) - 1 for f in node["frames"])
     assert count(scene["root"]) == 1 + len(w.getbodies()) - 1
+
+
+def test_human36_masses_against_reference_h5():
+    """tests/test_human36.py:93-115 (Human36Masses): the 6x6 mass matrix of every body of add_human36
+    against the reference's own golden file tests/human36.h5 (committed as a data fixture).  The file is
+    old-format contiguous HDF5: each /masses/<body> dataset is 36 consecutive float64 of the
+    8-byte aligned payload, so every body's matrix must occur in it (no h5py here)."""
+    import os
+    from conftest import GOLDEN
+    raw = open(os.path.join(GOLDEN, "ref_human36_masses.h5"), "rb").read()
+    a = np.frombuffer(raw[:(len(raw) // 8) * 8], dtype="<f8")
+    windows = np.lib.stride_tricks.sliding_window_view(a, 36)
+    w = scenes.human36_world(0)
+    bodies = [b for b in w.iterbodies()]
+    assert len(bodies) == 18                                    # ground + 17 moving bodies = the 18 datasets
+    found = set()
+    for b in bodies:
+        v = np.asarray(b.mass, dtype=np.float64).ravel()
+        hit = np.flatnonzero(np.all(np.abs(windows - v) <= 1e-12 * np.maximum(1., np.abs(v)), axis=1))
+        assert hit.size >= 1, "mass matrix of %s not in human36.h5" % b.name
+        found.update(int(h) for h in hit)
+    # 15 bodies carry mass (left/right pairs differ through the sign of m c^): 15 distinct datasets matched
+    M = np.array([np.asarray(b.mass).ravel() for b in bodies if np.any(np.asarray(b.mass))])
+    assert M.shape[0] == 15 and len({tuple(np.round(r, 12)) for r in M}) == 15
