@@ -265,6 +265,7 @@ def test_human36_masses_against_reference_h5():
         hit = np.flatnonzero(np.all(np.abs(windows - v) <= 1e-12 * np.maximum(1., np.abs(v)), axis=1))
         assert hit.size >= 1, "mass matrix of %s not in human36.h5" % b.name
         found.update(int(h) for h in hit)
-    # 15 bodies carry mass (left/right pairs differ through the sign of m c^): 15 distinct datasets matched
+    # 15 bodies carry mass; left and right limbs have equal matrices, so 10 distinct non-zero datasets
     M = np.array([np.asarray(b.mass).ravel() for b in bodies if np.any(np.asarray(b.mass))])
-    assert M.shape[0] == 15 and len({tuple(np.round(r, 12)) for r in M}) == 15
+    assert M.shape[0] == 15 and len({tuple(np.round(r, 12)) for r in M}) == 10
+    assert len(found) >= 15
