@@ -88,6 +88,14 @@ def load():
             "libarbstep.so is not built (%s missing). Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C arboris_python_amd/csrc`. "
             "There is no CPU fallback for the step." % LIB_PATH)
+    # The state lives in torch tensors, so the process must run on ONE HIP runtime: torch's wheel bundles its
+    # own libamdhip64.so.7, and libarbstep.so needs that soname too.  Whichever is loaded first serves both;
+    # if libarbstep.so came first it would pull /opt/rocm's copy, torch would then load a second runtime and
+    # hipSetDevice would report "no ROCm-capable device".  Importing torch first makes its copy the only one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:                                # pragma: no cover - symbol checks still work without torch
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.arb_abi_version.restype = C.c_int
     lib.arb_strerror.restype = C.c_char_p
