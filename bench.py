@@ -257,6 +257,18 @@ def main():
             res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
             res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
                                                "(profiles/%s); 4 B/lane accesses, reported uncorrected" % os.path.basename(prof))
+            # what actually bounds the kernel: the serial instruction stream of two waves per SIMD
+            ws = float(B * RESET_EVERY)
+            res["roofline"]["issue"] = {
+                "valu_insts_per_world_step": pm["SQ_INSTS_VALU"]["mean_per_launch"] / ws,
+                "salu_insts_per_world_step": pm["SQ_INSTS_SALU"]["mean_per_launch"] / ws,
+                "lds_insts_per_world_step": pm["SQ_INSTS_LDS"]["mean_per_launch"] / ws,
+                "wave_cycles_per_world_step": 4. * pm["SQ_WAVE_CYCLES"]["mean_per_launch"] / ws,
+                "wave_frac_issuing_valu": pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                "wave_frac_waiting": (pm["SQ_WAIT_ANY"]["mean_per_launch"] + pm["SQ_WAIT_INST_ANY"]["mean_per_launch"])
+                                     / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                "simd_valu_busy_frac": 2. * pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                "note": "SQ counters of profiles/%s (two waves per SIMD)" % os.path.basename(prof)}
         except Exception:
             pass
     if gather_ms is not None:
