@@ -12,4 +12,6 @@ from .robots.simplearm import add_simplearm
 from .robots.snake import add_snake
 from .robots.human36 import add_human36
 from .robots.simpleshapes import add_sphere, add_box, add_cylinder, add_groundplane
-from numpy import arange
+from .visu_collada import write_collada_animation, write_collada_scene
+from . import observers
+from numpy import arange, dot, allclose, pi
