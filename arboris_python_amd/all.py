@@ -1,7 +1,7 @@
 """Star-import convenience, mirroring arboris/all.py:13-24."""
 from . import core, homogeneousmatrix, twistvector, adjointmatrix, massmatrix
 from . import joints, shapes, collisions, constraints, controllers
-from .core import (World, Body, SubFrame, MovingSubFrame, Joint, JointsList,
+from .core import (World, Body, Frame, SubFrame, MovingSubFrame, Joint, JointsList,
                    LinearConfigurationSpaceJoint, NamedObjectsList, Constraint,
                    Controller, Shape, Observer, simulate)
 from .joints import *
