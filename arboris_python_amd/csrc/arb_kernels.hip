@@ -918,6 +918,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     if (ct == ARB_CT_JOINTLIMITS) continue;
                     const T *cd = CD + c * CD_STRIDE;
                     const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
+                    if (cd[CD_ACTIVE] == T(0)) {            // not in the active set: zero rows (core.py:913-918)
+                        if (lane < n) {
+                            T *row = RT + (1 + 4 * c) * RS + lane;
+                            row[0] = T(0); row[RS] = T(0); row[2 * RS] = T(0);
+                            if (ct == ARB_CT_SOFTFINGER) row[3 * RS] = T(0);
+                        }
+                        continue;
+                    }
                     const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
                     const double s = (double)cd[CD_ACTIVE] * ((double)((a1 >> lane) & 1ull) - (double)((a0 >> lane) & 1ull));
                     const M3<double> Rx = ld_m3_as<double>(cd + CD_R1);
@@ -1142,12 +1150,16 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 // row idx of J' (zero beyond ndof), read as 16/32-byte LDS vectors (wave-uniform address)
                 const V4 *jr4 = reinterpret_cast<const V4 *>(RT + (1 + idx) * RS);
                 T acc = T(0), acc2 = T(0);
+                // the rows of a constraint outside the active set are zero (phase B): nothing to multiply
+                // (free fall: the whole loop collapses to the stores)
+                if (CD[(idx >> 2) * CD_STRIDE + CD_ACTIVE] != T(0)) {
 #pragma unroll
-                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
-                    const V4 jv = jr4[i4];
-                    acc += jv.x * Z[4 * i4] + jv.y * Z[4 * i4 + 1] + jv.z * Z[4 * i4 + 2] + jv.w * Z[4 * i4 + 3];
-                    if (NSETS == 2)
-                        acc2 += jv.x * Z2[4 * i4] + jv.y * Z2[4 * i4 + 1] + jv.z * Z2[4 * i4 + 2] + jv.w * Z2[4 * i4 + 3];
+                    for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                        const V4 jv = jr4[i4];
+                        acc += jv.x * Z[4 * i4] + jv.y * Z[4 * i4 + 1] + jv.z * Z[4 * i4 + 2] + jv.w * Z[4 * i4 + 3];
+                        if (NSETS == 2)
+                            acc2 += jv.x * Z2[4 * i4] + jv.y * Z2[4 * i4 + 1] + jv.z * Z2[4 * i4 + 2] + jv.w * Z2[4 * i4 + 3];
+                    }
                 }
                 if (lane == n) VV[idx] = acc;
                 else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = acc;
