@@ -164,6 +164,20 @@ __device__ __forceinline__ double dpp_f64(double x) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// x of lane I of the caller's quad (lanes 4k .. 4k+3), a DPP quad_perm operand: no SGPR round trip
+template <int I>
+__device__ __forceinline__ float quad_bcast(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, I * 0x55, 0xF, 0xF, true));
+}
+template <int I>
+__device__ __forceinline__ double quad_bcast(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, I * 0x55, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), I * 0x55, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <typename T> __device__ __forceinline__ M3<T> ld_m3(const T *p) {
     M3<T> r;
 #pragma unroll
@@ -1245,6 +1259,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             bool k_act = false;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { Yrow[i] = T(0); Prow[i] = T(0); }
+            // the constants of a row's own constraint, replicated on the four lanes of its quad
+            T q_sd = T(0), q_sdt = T(0), q_mu = T(0);
             if (lane < ndol) {
                 const int cc = lane >> 2, rr = lane & 3;
                 vr = VV[lane]; fr = FF[lane];
@@ -1253,6 +1269,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     Yrow[i] = AM[lane * ndol + 4 * cc + i];
                     Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
                 }
+                q_sd = CD[cc * CD_STRIDE + CD_SDIST]; q_sdt = q_sd / dt; q_mu = mp->cmu[cc];
             }
             if (lane < nc) {
                 const T *cd = CD + lane * CD_STRIDE;
@@ -1301,47 +1318,53 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     }
                     const int ct = __builtin_amdgcn_readlane(k_ct, c);
                     T vc[4], fc[4], df[4], fnew[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { vc[i] = bcast(vr, base + i); fc[i] = bcast(fr, base + i); }
+                    // A constraint's four rows are one quad of lanes: what its local solve needs from its own
+                    // rows comes as DPP quad_perm operands (every quad evaluates ITS constraint; only the quad of
+                    // c is used).  Values go through SGPRs (v_readlane) only where the whole wave needs them.
+                    const T fq0 = quad_bcast<0>(fr), fq1 = quad_bcast<1>(fr), fq2 = quad_bcast<2>(fr), fq3 = quad_bcast<3>(fr);
                     // own-row products (meaningful on lanes base..base+3)
-                    const T v0r = vr - (Yrow[0] * fc[0] + Yrow[1] * fc[1] + Yrow[2] * fc[2] + Yrow[3] * fc[3]);
+                    const T v0r = vr - (Yrow[0] * fq0 + Yrow[1] * fq1 + Yrow[2] * fq2 + Yrow[3] * fq3);
+                    bool quad_done = false;      // softfinger release / static: per-lane results, see below
+                    T dfl = T(0), fnl = T(0);
+                    if (ct != ARB_CT_SOFTFINGER) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { vc[i] = bcast(vr, base + i); fc[i] = bcast(fr, base + i); }
+                    }
                     if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
                         // The release test and the static-friction candidate are evaluated side by side
-                        // (two independent dependent chains that overlap in the pipeline) before any
-                        // branch: the sweeps are one long latency chain, a few wasted instructions in
-                        // the release case are cheaper than serialising the two.
-                        const T sd = bcast(k_sd, c), mu = bcast(k_mu, c), sdt = bcast(k_sdt, c);
+                        // (two independent dependent chains that overlap in the pipeline), inside the quad.
                         const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
-                        const T dfr = -(Prow[0] * vc[0] + Prow[1] * vc[1] + Prow[2] * vc[2] + Prow[3] * (vc[3] + sdt));
+                        const T vq0 = quad_bcast<0>(vr), vq1 = quad_bcast<1>(vr), vq2 = quad_bcast<2>(vr), vq3 = quad_bcast<3>(vr);
+                        const T dfr = -(Prow[0] * vq0 + Prow[1] * vq1 + Prow[2] * vq2 + Prow[3] * (vq3 + q_sdt));
                         const T fnr = fr + dfr;
-                        const T v0n = bcast(v0r, base + 3);
-                        T fn[4], dfs[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { fn[i] = bcast(fnr, base + i); dfs[i] = bcast(dfr, base + i); }
+                        const T v0n = quad_bcast<3>(v0r);
+                        const T fn0 = quad_bcast<0>(fnr), fn1 = quad_bcast<1>(fnr), fn2 = quad_bcast<2>(fnr), fn3 = quad_bcast<3>(fnr);
                         T eps[3] = {T(1), T(1), T(1)};
                         T lhs;
                         if (eps1) {
-                            lhs = fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2];
+                            lhs = fn0 * fn0 + fn1 * fn1 + fn2 * fn2;
                         } else {
                             eps[0] = bcast(k_e0, c); eps[1] = bcast(k_e1, c); eps[2] = bcast(k_e2, c);
-                            lhs = (fn[0] / eps[0]) * (fn[0] / eps[0]) + (fn[1] / eps[1]) * (fn[1] / eps[1])
-                                + (fn[2] / eps[2]) * (fn[2] / eps[2]);
+                            lhs = (fn0 / eps[0]) * (fn0 / eps[0]) + (fn1 / eps[1]) * (fn1 / eps[1])
+                                + (fn2 / eps[2]) * (fn2 / eps[2]);
                         }
-                        const T rhs = (fn[3] * mu) * (fn[3] * mu);
-                        if (sd + dt * v0n > T(0)) {                        // release
+                        const T rhs = (fn3 * q_mu) * (fn3 * q_mu);
+                        // the quad of c decides for the wave
+                        const bool release = (__ballot(q_sd + dt * v0n > T(0)) >> base) & 1ull;
+                        const bool stat = (__ballot(lhs <= rhs) >> base) & 1ull;
+                        if (release) {                                     // release
                             if (MODE == 1) ++st_rel;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { df[i] = -fc[i]; fnew[i] = T(0); }
+                            dfl = -fr; fnl = T(0); quad_done = true;
                         } else {
-                            if (lhs <= rhs) {                              // static friction
+                            if (stat) {                                    // static friction
                                 if (MODE == 1) ++st_sta;
-                                // df is exactly -pinv(Y)(...) as in the reference, taken from the rows
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) { fnew[i] = fn[i]; df[i] = dfs[i]; }
+                                // df is exactly -pinv(Y)(...) as in the reference, row by row
+                                dfl = dfr; fnl = fnr; quad_done = true;
                             } else {                                       // sliding friction
                                 T alpha[4], shift = T(0);
+                                const T mu = bcast(k_mu, c), sdt = bcast(k_sdt, c);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) alpha[r] = bcast(v0r, base + r);
+                                for (int r = 0; r < 4; ++r) { alpha[r] = bcast(v0r, base + r); fc[r] = bcast(fr, base + r); }
                                 alpha[3] += sdt;
                                 // the constraint's own 4x4 admittance block (wave-uniform LDS reads)
                                 T Y[16];
@@ -1412,10 +1435,17 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                         for (int i = 1; i < 4; ++i) { df[i] = T(0); fnew[i] = fc[i]; }
                     }
+                    const int rr = lane - base;
+                    if (quad_done) {
+                        // release / static: the quad holds the new forces and the force increments row by row
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) df[i] = bcast(dfl, base + i);
+                        fr = (rr >= 0 && rr < 4) ? fnl : fr;
+                    } else {
+                        fr = (rr == 0) ? fnew[0] : (rr == 1) ? fnew[1] : (rr == 2) ? fnew[2] : (rr == 3) ? fnew[3] : fr;
+                    }
                     // vel += Y'[:, c] dforce                               core.py:935
                     vr += a4[0] * df[0] + a4[1] * df[1] + a4[2] * df[2] + a4[3] * df[3];
-                    const int rr = lane - base;
-                    fr = (rr == 0) ? fnew[0] : (rr == 1) ? fnew[1] : (rr == 2) ? fnew[2] : (rr == 3) ? fnew[3] : fr;
                 }
                 // A sweep that leaves every velocity and force bit-for-bit unchanged is a fixed point
                 // of the iteration: the remaining sweeps of core.py:929-935 would repeat it exactly.
