@@ -1252,15 +1252,16 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             T vr = T(0), fr = T(0), Yrow[4], Prow[4];
             T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
             T k_min = T(0), k_max = T(0);
-            T k_sdt = T(0), k_iyn = T(0), k_muyn = T(0), k_yc0 = T(0), k_yc1 = T(0), k_yc2 = T(0), k_bsq = T(0);
             bool k_eps1 = false;
-            double k_tr = 0., k_m2 = 0., k_det = 0., k_sQ = 0., k_sA = 0., k_nq = 0., k_warm = NAN;
             int k_ct = 0;
             bool k_act = false;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { Yrow[i] = T(0); Prow[i] = T(0); }
             // the constants of a row's own constraint, replicated on the four lanes of its quad
             T q_sd = T(0), q_sdt = T(0), q_mu = T(0);
+            T q_iyn = T(0), q_muyn = T(0), q_yc0 = T(0), q_yc1 = T(0), q_yc2 = T(0), q_bsq = T(0);
+            SlidePre q_sp = {0., 0., 0., 0., 0., 0.};
+            double q_warm = NAN;                    // root found for this constraint in the previous sweep
             if (lane < ndol) {
                 const int cc = lane >> 2, rr = lane & 3;
                 vr = VV[lane]; fr = FF[lane];
@@ -1270,6 +1271,20 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
                 }
                 q_sd = CD[cc * CD_STRIDE + CD_SDIST]; q_sdt = q_sd / dt; q_mu = mp->cmu[cc];
+                if (CD[cc * CD_STRIDE + CD_ACTIVE] != T(0) && mp->ctype[cc] == ARB_CT_SOFTFINGER) {
+                    // admittance-only part of the sliding-branch polynomial and the other per-step constants of
+                    // SoftFingerContact.solve (constraints.py:795, 808-812), once per step
+                    T Yc4[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * ndol + 4 * cc + j];
+                    q_sp = slide_precompute<T>(Yc4);
+                    q_iyn = T(1) / Yc4[15]; q_muyn = q_mu / Yc4[15];
+                    q_yc0 = Yc4[3]; q_yc1 = Yc4[7]; q_yc2 = Yc4[11];
+                    const T bq0 = q_muyn * q_yc0, bq1 = q_muyn * q_yc1, bq2 = q_muyn * q_yc2;
+                    q_bsq = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
+                }
             }
             if (lane < nc) {
                 const T *cd = CD + lane * CD_STRIDE;
@@ -1278,23 +1293,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
                 k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
                 k_min = mp->cmin[lane]; k_max = mp->cmax[lane];
-                if (k_act && k_ct == ARB_CT_SOFTFINGER) {
-                    // admittance-only part of the sliding-branch polynomial, once per step
-                    T Yc4[16];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * lane + i) * ndol + 4 * lane + j];
-                    const SlidePre sp = slide_precompute<T>(Yc4);
-                    k_tr = sp.tr; k_m2 = sp.m2; k_det = sp.det; k_sQ = sp.sQ; k_sA = sp.sA; k_nq = sp.nq;
-                    // other per-step constants of SoftFingerContact.solve (constraints.py:795, 808-812)
-                    k_sdt = k_sd / dt;
-                    k_iyn = T(1) / Yc4[15]; k_muyn = k_mu / Yc4[15];
-                    k_yc0 = Yc4[3]; k_yc1 = Yc4[7]; k_yc2 = Yc4[11];
-                    const T bq0 = k_muyn * k_yc0, bq1 = k_muyn * k_yc1, bq2 = k_muyn * k_yc2;
-                    k_bsq = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
-                    k_eps1 = (k_e0 == T(1)) && (k_e1 == T(1)) && (k_e2 == T(1));
-                }
+                k_eps1 = k_act && k_ct == ARB_CT_SOFTFINGER && (k_e0 == T(1)) && (k_e1 == T(1)) && (k_e2 == T(1));
             }
             const unsigned long long actmask = __ballot(k_act);
             const unsigned long long eps1mask = __ballot(k_eps1);
@@ -1361,11 +1360,16 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                                 // df is exactly -pinv(Y)(...) as in the reference, row by row
                                 dfl = dfr; fnl = fnr; quad_done = true;
                             } else {                                       // sliding friction
+                                // Also inside the quad: the four lanes of constraint c carry the live problem in
+                                // vector registers (the other quads run along on their own, unused data) and every
+                                // branch follows the quad of c (`uni`), so nothing travels through SGPRs but the
+                                // final force increments.
+                                const int rq = lane - base;
+                                const bool inquad = rq >= 0 && rq < 4;
+                                const auto uni = [&](bool b) { return (bool)((__ballot(b) >> base) & 1ull); };
                                 T alpha[4], shift = T(0);
-                                const T mu = bcast(k_mu, c), sdt = bcast(k_sdt, c);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { alpha[r] = bcast(v0r, base + r); fc[r] = bcast(fr, base + r); }
-                                alpha[3] += sdt;
+                                alpha[0] = quad_bcast<0>(v0r); alpha[1] = quad_bcast<1>(v0r); alpha[2] = quad_bcast<2>(v0r);
+                                alpha[3] = v0n + q_sdt;
                                 // the constraint's own 4x4 admittance block (wave-uniform LDS reads)
                                 T Y[16];
                                 {
@@ -1377,18 +1381,14 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                                     }
                                 }
                                 if (MODE == 1) ++st_fast;
-                                double warm = bcast(k_warm, c);
+                                double warm = q_warm;
                                 bool have = false;
                                 if (eps1) {
-                                    SlidePre sp;
-                                    sp.tr = bcast(k_tr, c); sp.m2 = bcast(k_m2, c); sp.det = bcast(k_det, c);
-                                    sp.sQ = bcast(k_sQ, c); sp.sA = bcast(k_sA, c); sp.nq = bcast(k_nq, c);
-                                    const T yc[3] = {bcast(k_yc0, c), bcast(k_yc1, c), bcast(k_yc2, c)};
-                                    const T muyn = bcast(k_muyn, c);
-                                    const T bq[3] = {muyn * yc[0], muyn * yc[1], muyn * yc[2]};
+                                    const T yc[3] = {q_yc0, q_yc1, q_yc2};
+                                    const T bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
                                     double c1, kappa, root;
-                                    slide_c1_kappa<T>(alpha, yc, bcast(k_iyn, c), muyn, bq, bcast(k_bsq, c), &c1, &kappa);
-                                    if (slide_leftmost_root(sp, c1, kappa, warm, &root, slide_step_tol<T>())) {
+                                    slide_c1_kappa<T>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
+                                    if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni)) {
                                         warm = root;
                                         // leftmost real eigenvalue; admissible when <= 0 (constraints.py:826-830)
                                         shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
@@ -1398,7 +1398,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                                 if (!have) {
                                     if (MODE == 1) { ++st_slow; --st_fast; }
                                     // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
-                                    softfinger_sliding_shift<T>(Y, alpha, mu, eps, WORK, &shift, false);
+                                    if (inquad) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
                                     WAVE_SYNC();
                                     if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
                                     WAVE_SYNC();
@@ -1406,15 +1406,17 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                                     WAVE_SYNC();
                                     warm = NAN;
                                 }
-                                if (lane == c) k_warm = warm;       // next sweep restarts next to this root
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) fnew[i] = fc[i];
+                                if (inquad) q_warm = warm;          // next sweep restarts next to this root
+                                fnew[0] = fq0; fnew[1] = fq1; fnew[2] = fq2; fnew[3] = fq3;
                                 T sie2[3] = {shift, shift, shift};
                                 if (!eps1) {
 #pragma unroll
                                     for (int i = 0; i < 3; ++i) sie2[i] = shift / (eps[i] * eps[i]);
                                 }
                                 softfinger_slide_finish_scaled<T>(Y, alpha, sie2, fnew, df);
+                                dfl = (rq == 0) ? df[0] : (rq == 1) ? df[1] : (rq == 2) ? df[2] : df[3];
+                                fnl = (rq == 0) ? fnew[0] : (rq == 1) ? fnew[1] : (rq == 2) ? fnew[2] : fnew[3];
+                                quad_done = true;
                             }
                         }
                     } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
@@ -2085,11 +2087,9 @@ static int launch_gs(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long 
 #endif
 }
 
-// Measured on MI355X (tools/split_vs_fused.py, human36): with 4 contacts the split execution
-// overtakes the fused kernel from ~8k worlds per launch (1.3x at 16k-64k); with 8 contacts it never
-// does.  Below that the lane-per-world kernel is a latency chain on too few wavefronts.
-#define ARB_SPLIT_MIN_WORLDS 16384
-#define ARB_SPLIT_MAX_NC 4
+// Measured on MI355X (tools/split_vs_fused.py, human36 + 4 contacts): the split execution overtakes the fused
+// kernel from ~8k worlds per launch (13.9 vs 12.8 M world-steps/s at 16k, 15.4 vs 13.6 at 64k); with 8 contacts
+// it never does.  Below that the lane-per-world kernel is a latency chain on too few wavefronts.
 
 template <typename T>
 static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext,
@@ -2100,7 +2100,10 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
     SplitIO<T> sio; memset(&sio, 0, sizeof(sio));
     const int nc = M->nc, ndol = M->ndol, n = M->n;
     const bool can_split = nc > 0 && nc <= 16 && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
-    const bool split = can_split && ((flags & ARB_STEP_SPLIT) || (nw >= ARB_SPLIT_MIN_WORLDS && nc <= ARB_SPLIT_MAX_NC));
+    // Opt-in (ARB_STEP_SPLIT) since round 1: the lane-per-world kernel is 1.1-1.15x faster from ~16k worlds, but
+    // its rare eig6 fallback (one private 6x6 work array per lane in LDS) proved sensitive to code generation --
+    // an otherwise equivalent build returned a 1e18 N contact force for one world in 2 M world-steps.
+    const bool split = can_split && (flags & ARB_STEP_SPLIT);
     if (!split)
         return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, st);
     // ---- split execution: step kernel (dynamics + system) / Gauss-Seidel kernel (lane = world) ----

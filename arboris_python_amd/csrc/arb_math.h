@@ -787,6 +787,88 @@ ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, doub
     return false;
 }
 
+// The same iteration for the fused kernel, where the four lanes of a constraint's quad carry the live
+// problem in vector registers and the rest of the wavefront runs along on don't-care data: every branch
+// condition goes through `uni`, which returns the quad's verdict for the whole wave.  (A separate copy
+// rather than a template of the function above: the scalar callers keep their text unchanged.)
+template <typename UNI>
+ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, double warm, double *root,
+                                    double step_tol, UNI uni) {
+#define U(x) uni(x)
+    const double d2 = -kappa;
+    const double l1 = -(3. * k.tr - k.sQ);
+    const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
+    const double o[3] = {k.m2 + d2, -2. * k.tr, 3.};                          // O_chi
+    const double er[3] = {k.sA + 3. * d2, l1, 3.};                            // E_rho
+    const double orr[2] = {l1, 6.};                                           // O_rho
+    double pc[7];
+    // E_chi^2 - d2 O_chi^2
+    pc[0] = e[0] * e[0] - d2 * (o[0] * o[0]);
+    pc[1] = 2. * e[0] * e[1] - d2 * (2. * o[0] * o[1]);
+    pc[2] = 2. * e[0] * e[2] + e[1] * e[1] - d2 * (2. * o[0] * o[2] + o[1] * o[1]);
+    pc[3] = 2. * (e[0] * e[3] + e[1] * e[2]) - d2 * (2. * o[1] * o[2]);
+    pc[4] = 2. * e[1] * e[3] + e[2] * e[2] - d2 * (o[2] * o[2]);
+    pc[5] = 2. * e[2] * e[3];
+    pc[6] = 1.;
+    // - c1 (E_rho E_chi - d2 O_rho O_chi)
+    pc[0] -= c1 * (er[0] * e[0] - d2 * (orr[0] * o[0]));
+    pc[1] -= c1 * (er[0] * e[1] + er[1] * e[0] - d2 * (orr[0] * o[1] + orr[1] * o[0]));
+    pc[2] -= c1 * (er[0] * e[2] + er[1] * e[1] + er[2] * e[0] - d2 * (orr[0] * o[2] + orr[1] * o[1]));
+    pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
+    pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
+    pc[5] -= c1 * (er[2] * e[3]);
+    double x = NAN;
+    if (U(warm == warm)) {
+        const double x0 = warm - 1e-3 * fabs(warm) - 1e-300;
+        double t[7];
+        for (int i = 0; i < 7; ++i) t[i] = pc[i];
+        for (int j = 0; j < 6; ++j)                 // Taylor shift: t[i] = p^(i)(x0) / i!
+            for (int i = 5; i >= j; --i) t[i] += x0 * t[i + 1];
+        if (U(t[0] > 0. && t[1] < 0. && t[2] > 0. && t[3] < 0. && t[4] > 0. && t[5] < 0.)) x = x0;
+    }
+    if (U(!(x == x))) {
+        // |P| <= |Q| + 3 |c1| (infinity norms); every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
+        const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
+        if (U(!(rb > 0.) || !(rb < 1e300))) return false;
+        x = -1.0001 * rb - 1e-300;
+    }
+    const double n = 6.;
+    for (int it = 0; it < 40; ++it) {
+        double p0 = pc[6], p1 = 0., p2 = 0., ee = fabs(pc[6]);
+        const double ax = fabs(x);
+        for (int i = 5; i >= 0; --i) {
+            p2 = p2 * x + p1; p1 = p1 * x + p0; p0 = p0 * x + pc[i];
+            ee = ee * ax + fabs(p0);                    // running Horner error bound
+        }
+        p2 *= 2.;
+        if (U(fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0)))) { *root = x; return true; }   // p(x) = 0 to rounding
+        if (U(!(p0 > 0.) || !(p1 < 0.))) return false;   // not left of all roots any more: anomaly
+        // Laguerre step  dx = n p / (p' - sqrt((n-1)((n-1) p'^2 - n p p'')))  (p' < 0 here).
+        // Only the step uses approximate sqrt / reciprocal (hardware v_rsq_f64 / v_rcp_f64,
+        // ~1e-8 relative): the accuracy of the root is set by the float64 Horner values and
+        // the stopping test above, not by the step.
+        const double rad = (n - 1.) * ((n - 1.) * p1 * p1 - n * p0 * p2);
+        if (U(!(rad >= 0.))) return false;               // complex roots nearby
+        const double den = p1 - arb_fast_sqrt(rad);   // both terms negative: no cancellation
+        // shortened by 2^-20 so that the ~1e-8 error of the approximate sqrt/rcp can never
+        // carry the iterate past the root (the exact Laguerre step from the left never does)
+        const double dx = (n * (1. - 9.5367431640625e-07)) * p0 * arb_fast_rcp(den); // negative
+        const double xn = x - dx;
+        if (U(!(xn > x))) { *root = x; return true; }    // no representable progress: converged
+        if (U(fabs(dx) <= step_tol * fabs(xn))) { *root = xn; return true; }
+        if (U(fabs(dx) <= 1e-2 * fabs(xn))) {
+            // Short step: accept xn when the Newton estimate of what is left, p(xn) / |p'(x)|, is
+            // below the tolerance (|p'| decreases towards the root, hence the factor 1/4).
+            double q0 = pc[6];
+            for (int i = 5; i >= 0; --i) q0 = q0 * xn + pc[i];
+            if (U(fabs(q0) <= 0.25 * step_tol * fabs(xn) * (-p1))) { *root = xn; return true; }
+        }
+        x = xn;
+    }
+    return false;
+#undef U
+}
+
 // The two sweep-dependent scalars of det(B - sI) from the constants of the constraint's own
 // admittance block: yc = Y_c, iyn = 1/y_n, muyn = mu/y_n, b = muyn Y_c, bsq = b.b   (constraints.py:808-812)
 template <typename T>

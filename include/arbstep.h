@@ -85,10 +85,9 @@ enum {
 
 /* arb_step flags */
 #define ARB_STEP_SKIP_CONSTRAINTS 1u  /* integrate with controller forces only */
-#define ARB_STEP_FUSED 2u             /* keep the Gauss-Seidel sweeps inside the step kernel (default except for
-                                         launches of >= 16384 worlds with <= 4 constraints, which run the sweeps
-                                         in a second kernel with one lane per world; same results to rounding) */
-#define ARB_STEP_SPLIT 4u             /* force that two-kernel execution whatever the batch size */
+#define ARB_STEP_FUSED 2u             /* keep the Gauss-Seidel sweeps inside the step kernel (the default) */
+#define ARB_STEP_SPLIT 4u             /* run the sweeps in a second kernel with one lane per world (same results to
+                                         rounding; faster from ~16k worlds with <= 4 constraints; opt-in) */
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the

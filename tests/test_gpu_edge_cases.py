@@ -145,7 +145,7 @@ def test_small_models_use_other_register_tiles():
 
 
 # ---------------------------------------------------------------------------
-# split execution (default for >= 16384 worlds with <= 4 constraints, forced here): the
+# split execution (opt-in, ARB_STEP_SPLIT): the
 # Gauss-Seidel sweeps run in a second kernel with one lane per world; it must agree with
 # the fused kernel.
 @pytest.mark.parametrize("name,nsteps", [("human36_c4", 6), ("human36_c8", 3)])
