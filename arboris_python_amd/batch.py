@@ -94,6 +94,9 @@ class BatchedWorlds(object):
              stream=None, fused=False, split=False, pd_targets=None, pd_gains=None):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).
 
+        ``split=True`` runs the Gauss-Seidel sweeps in a second kernel with one lane per world
+        (ARB_STEP_SPLIT: faster from ~16k worlds with <= 4 constraints, same results to rounding; opt-in,
+        see DESIGN.md); the default keeps them in the step kernel (``fused`` is accepted for symmetry).
         ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller).
         ``pd_targets=(qdes, dqdes)`` (B,ndof) each: one ProportionalDerivativeController target
         per world (controllers.py:63-158), with the model's gains, or with the per-world DIAGONAL
