@@ -1245,9 +1245,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             ARB_CSTAMP(7);
             // ---- Gauss-Seidel, core.py:929-935, register resident ----------------------
             // lane = row of the stacked constraint system: it keeps its velocity, its force,
-            // its row of the constraint's own admittance block Y_cc and of inv(Y_cc).  Lane c
-            // also keeps the scalars of constraint c.  Everything a solve needs from other
-            // lanes comes through v_readlane broadcasts (wave-uniform values), so the 20 x nc
+            // its row of the constraint's own admittance block Y_cc and of inv(Y_cc), and the
+            // per-step constants of its constraint.  The four rows of a constraint are one QUAD
+            // of lanes: the local solve of a SoftFingerContact runs inside that quad on DPP
+            // quad_perm operands (vector registers only, branches follow the quad through
+            // ballots); v_readlane broadcasts through SGPRs are left for what every row needs,
+            // the four force increments.  Lane c also keeps the flags of constraint c.  The 20 x nc
             // sequential solves touch LDS only to read their column block of Y' (read-only).
             T vr = T(0), fr = T(0), Yrow[4], Prow[4];
             T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
