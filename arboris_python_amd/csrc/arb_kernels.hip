@@ -1354,15 +1354,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         // the quad of c decides for the wave
                         const bool release = (__ballot(q_sd + dt * v0n > T(0)) >> base) & 1ull;
                         const bool stat = (__ballot(lhs <= rhs) >> base) & 1ull;
-                        if (release) {                                     // release
-                            if (MODE == 1) ++st_rel;
-                            dfl = -fr; fnl = T(0); quad_done = true;
+                        if (release || stat) {
+                            // release (zero force) or static friction (df exactly -pinv(Y)(...) as in the
+                            // reference, row by row): one branch, the two outcomes by selection
+                            if (MODE == 1) { if (release) ++st_rel; else ++st_sta; }
+                            dfl = release ? -fr : dfr; fnl = release ? T(0) : fnr; quad_done = true;
                         } else {
-                            if (stat) {                                    // static friction
-                                if (MODE == 1) ++st_sta;
-                                // df is exactly -pinv(Y)(...) as in the reference, row by row
-                                dfl = dfr; fnl = fnr; quad_done = true;
-                            } else {                                       // sliding friction
+                            {                                              // sliding friction
                                 // Also inside the quad: the four lanes of constraint c carry the live problem in
                                 // vector registers (the other quads run along on their own, unused data) and every
                                 // branch follows the quad of c (`uni`), so nothing travels through SGPRs but the

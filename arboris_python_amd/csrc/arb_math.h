@@ -817,6 +817,10 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
     pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
     pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
     pc[5] -= c1 * (er[2] * e[3]);
+    // Every data-dependent branch of this variant costs a compare, a ballot and a scalar test on the critical
+    // path of the sweeps: the exits of an iteration are evaluated arithmetically and tested once (measured:
+    // +2.5 %; going further -- start point by selection, the short-step residual on every pass -- costs more
+    // arithmetic than the branches it saves).
     double x = NAN;
     if (U(warm == warm)) {
         const double x0 = warm - 1e-3 * fabs(warm) - 1e-300;
@@ -841,21 +845,25 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
             ee = ee * ax + fabs(p0);                    // running Horner error bound
         }
         p2 *= 2.;
-        if (U(fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0)))) { *root = x; return true; }   // p(x) = 0 to rounding
-        if (U(!(p0 > 0.) || !(p1 < 0.))) return false;   // not left of all roots any more: anomaly
+        const bool zero = fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0));      // p(x) = 0 to rounding
         // Laguerre step  dx = n p / (p' - sqrt((n-1)((n-1) p'^2 - n p p'')))  (p' < 0 here).
         // Only the step uses approximate sqrt / reciprocal (hardware v_rsq_f64 / v_rcp_f64,
         // ~1e-8 relative): the accuracy of the root is set by the float64 Horner values and
-        // the stopping test above, not by the step.
+        // the stopping tests, not by the step.
         const double rad = (n - 1.) * ((n - 1.) * p1 * p1 - n * p0 * p2);
-        if (U(!(rad >= 0.))) return false;               // complex roots nearby
+        // anomalies: not left of all roots any more, or complex roots nearby
+        const bool bad = !zero && (!(p0 > 0.) || !(p1 < 0.) || !(rad >= 0.));
         const double den = p1 - arb_fast_sqrt(rad);   // both terms negative: no cancellation
         // shortened by 2^-20 so that the ~1e-8 error of the approximate sqrt/rcp can never
         // carry the iterate past the root (the exact Laguerre step from the left never does)
         const double dx = (n * (1. - 9.5367431640625e-07)) * p0 * arb_fast_rcp(den); // negative
         const double xn = x - dx;
-        if (U(!(xn > x))) { *root = x; return true; }    // no representable progress: converged
-        if (U(fabs(dx) <= step_tol * fabs(xn))) { *root = xn; return true; }
+        const bool stall = !(xn > x);                 // no representable progress: converged
+        if (U(zero || bad || stall || fabs(dx) <= step_tol * fabs(xn))) {
+            if (U(bad)) return false;
+            *root = (zero || stall) ? x : xn;
+            return true;
+        }
         if (U(fabs(dx) <= 1e-2 * fabs(xn))) {
             // Short step: accept xn when the Newton estimate of what is left, p(xn) / |p'(x)|, is
             // below the tolerance (|p'| decreases towards the root, hence the factor 1/4).
