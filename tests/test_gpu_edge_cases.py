@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import arb_oracle as O
-from conftest import load_model
+from conftest import load_golden, load_model
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -200,4 +200,29 @@ def test_split_execution_other_constraint_types():
         assert rel(ca.cpu().numpy(), cb.cpu().numpy()) < 1e-9
         oq, odq, ocf = O.rollout(m, q[:8], dq[:8], [dt] * nsteps)
         assert rel(a_q.cpu().numpy()[:8], oq) < 1e-8
+        bw.close()
+
+
+@pytest.mark.parametrize("mode", ["fused", "split"])
+def test_eig6_fallback_canary(mode):
+    """A state met in a 65536-world rollout (world 31974, step 19) whose Gauss-Seidel sweeps take the rare
+    generic-eigenvalue fallback of the sliding solve (no admissible eigenvalue: s = -1e10, constraints.py:826-830).
+    One build of the lane-per-world kernel returned a 1e18 N contact force here (DESIGN.md, split execution);
+    both executions must agree with the oracle."""
+    from arboris_python_amd.batch import BatchedWorlds
+    m, _, _ = load_model("human36_c4")
+    d = load_golden("canary_eig6_fallback.npz")
+    dt = 5e-3
+    oq, odq, ocf = O.step(m, d["q"].astype(np.float64), d["dq"].astype(np.float64), dt)
+    bw = BatchedWorlds(m)
+    try:
+        q = torch.as_tensor(d["q"], dtype=torch.float32, device=bw.device)
+        dq = torch.as_tensor(d["dq"], dtype=torch.float32, device=bw.device)
+        cf = bw.new_cforce(1, torch.float32)
+        bw.step(q, dq, dt, 1, cforce=cf, fused=(mode == "fused"), split=(mode == "split"))
+        torch.cuda.synchronize()
+        assert torch.isfinite(dq).all() and torch.isfinite(cf).all()
+        assert np.abs(dq.cpu().numpy() - odq).max() / max(1., np.abs(odq).max()) < 1e-5
+        assert np.abs(cf.cpu().numpy() - ocf).max() < 1e-2 * max(1., np.abs(ocf).max())
+    finally:
         bw.close()

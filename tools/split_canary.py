@@ -11,7 +11,7 @@ from conftest import load_model
 from arboris_python_amd.batch import BatchedWorlds
 m, _, _ = load_model("human36_c4")
 bw = BatchedWorlds(m)
-d = np.load(os.path.join(ROOT, "tools", "w31974_step19.npz"))
+d = np.load(os.path.join(ROOT, "tests", "golden", "canary_eig6_fallback.npz"))
 dt = 5e-3
 oq, odq, ocf = O.step(m, d["q"].astype(np.float64), d["dq"].astype(np.float64), dt)
 for mode in ("split", "fused"):
