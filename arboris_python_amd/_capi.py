@@ -72,7 +72,7 @@ class InspectOut(C.Structure):
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
             "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_step_ex", "arb_rollout", "arb_inspect"]
 # host-side self-test hooks (device math compiled for the CPU)
-TEST_HOOKS = ["arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_joint_local",
+TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_joint_local",
               "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
 
 _lib = None
@@ -121,6 +121,8 @@ def load():
     lib.arb_host_softfinger_solve.restype = C.c_int
     lib.arb_host_softfinger_solve.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double,
                                               C.c_double, _PD, _PD]
+    lib.arb_dev_softfinger_solve.restype = C.c_int
+    lib.arb_dev_softfinger_solve.argtypes = [C.c_int, C.c_int, C.c_int, _PD, _PD]
     lib.arb_host_softfinger_try.restype = C.c_int
     lib.arb_host_softfinger_try.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, _PD]
     lib.arb_host_slide_root.restype = C.c_int

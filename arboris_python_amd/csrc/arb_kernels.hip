@@ -1612,6 +1612,32 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
 }
 
 // ===========================================================================
+// Device unit test of the local solve (test hook arb_dev_softfinger_solve): one LANE per input tuple, the
+// same arb_math.h code the kernels run -- inverse of the 4x4 block, SoftFingerContact.solve with the fast
+// sliding shift or the eig6 fallback on a lane-private LDS work array, like arb_gs_kernel.
+// in: [n][27] = vel 4 | adm 16 | force 4 | sdist, dt, mu ;  out: [n][9] = force 4 | dforce 4 | branch
+// ===========================================================================
+template <typename T>
+__global__ __launch_bounds__(WAVE) void arb_softfinger_test_kernel(const double *__restrict__ in, double *__restrict__ out,
+                                                                   int n, int use_fast)
+{
+    T *lds = reinterpret_cast<T *>(arb_lds_raw);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * WAVE + lane;
+    T *work = lds + lane * 41;
+    if (i >= n) return;
+    const double *t = in + (size_t)i * 27;
+    T v[4], Y[16], P[16], f[4], df[4], eps[3] = {T(1), T(1), T(1)};
+    for (int k = 0; k < 4; ++k) { v[k] = (T)t[k]; f[k] = (T)t[20 + k]; }
+    for (int k = 0; k < 16; ++k) Y[k] = (T)t[4 + k];
+    inv_block<T>(Y, 4, 4, P);
+    const int br = softfinger_solve<T>(v, Y, P, f, df, (T)t[24], (T)t[25], (T)t[26], eps, work, use_fast != 0);
+    double *o = out + (size_t)i * 9;
+    for (int k = 0; k < 4; ++k) { o[k] = (double)f[k]; o[4 + k] = (double)df[k]; }
+    o[8] = (double)br;
+}
+
+// ===========================================================================
 // Host side: model upload, launch dispatch, C ABI
 // ===========================================================================
 #ifdef ARB_PART
@@ -2101,9 +2127,9 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
     SplitIO<T> sio; memset(&sio, 0, sizeof(sio));
     const int nc = M->nc, ndol = M->ndol, n = M->n;
     const bool can_split = nc > 0 && nc <= 16 && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
-    // Opt-in (ARB_STEP_SPLIT) since round 1: the lane-per-world kernel is 1.1-1.15x faster from ~16k worlds, but
-    // its rare eig6 fallback (one private 6x6 work array per lane in LDS) proved sensitive to code generation --
-    // an otherwise equivalent build returned a 1e18 N contact force for one world in 2 M world-steps.
+    // Opt-in (ARB_STEP_SPLIT) since round 1: the lane-per-world kernel is 1.1-1.15x faster from ~16k worlds, but it
+    // returned a 1e18 N contact force for one world in 2 M world-steps until a compiler workaround went into
+    // arb_math.h::softfinger_try (split execution); it stays opt-in until it has seen more inputs.
     const bool split = can_split && (flags & ARB_STEP_SPLIT);
     if (!split)
         return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, st);
@@ -2257,6 +2283,27 @@ extern "C" int arb_host_softfinger_solve(int dtype, const double *vel, const dou
     int br = softfinger_solve<float>(v, Y, P, f, df, (float)sdist, (float)dt, (float)mu, e, work, use_fast);
     for (int i = 0; i < 4; ++i) { force[i] = f[i]; dforce[i] = df[i]; }
     return br;
+}
+
+// the same solve executed on the device, one lane per tuple (see arb_softfinger_test_kernel); `dtype` as above
+extern "C" int arb_dev_softfinger_solve(int dtype, int device, int n, const double *in /*[n][27]*/, double *out /*[n][9]*/) {
+    if (!in || !out || n <= 0) return ARB_ERR_INVALID;
+    const int use_fast = !(dtype & 0x100);
+    dtype &= 0xff;
+    HIP_TRY(hipSetDevice(device));
+    double *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&din, sizeof(double) * 27 * (size_t)n));
+    HIP_TRY(hipMalloc(&dout, sizeof(double) * 9 * (size_t)n));
+    HIP_TRY(hipMemcpy(din, in, sizeof(double) * 27 * (size_t)n, hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)((n + WAVE - 1) / WAVE);
+    if (dtype == ARB_F64)
+        hipLaunchKernelGGL(arb_softfinger_test_kernel<double>, dim3(grid), dim3(WAVE), WAVE * 41 * sizeof(double), 0, din, dout, n, use_fast);
+    else
+        hipLaunchKernelGGL(arb_softfinger_test_kernel<float>, dim3(grid), dim3(WAVE), WAVE * 41 * sizeof(float), 0, din, dout, n, use_fast);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(dout);
+    return ARB_OK;
 }
 
 // raw branch code of softfinger_try (3 = the fast sliding-shift path declined and eig6 is needed)

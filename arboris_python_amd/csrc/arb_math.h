@@ -979,6 +979,14 @@ ARB_HD int softfinger_try(const T v[4], const T Y[16], const T P[16], T f[4], T 
     }
     // sliding, constraints.py:803-836
     alpha[0] = v0[0]; alpha[1] = v0[1]; alpha[2] = v0[2]; alpha[3] = v0[3] + sdist / dt;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Compiler workaround (hipcc 7.2, gfx950, -O2 and up): without this barrier the force that comes in, which
+    // the finish needs again AFTER the root finder (df = f_new - f), reached softfinger_slide_finish with wrong
+    // values in float32 lane-per-world code -- f_new right, df = 1e17 -- for one input in two million solves
+    // (-O1 and the host build are right; tests/test_gpu_device_solve.py holds the input).  Pinning f in
+    // vector registers here, before the long inlined float64 code, avoids it.
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+#endif
     return softfinger_sliding_shift<T>(Y, alpha, mu, eps, work, shift, use_fast, pre, warm) ? 2 : 3;
 }
 
