@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the packed Gauss-Seidel (ARB_GS_PACK=1, default) against one world per workgroup (=0):
-steps a batch whose size is not a multiple of 4 through the falling episode and writes/compares the
-final state.  usage: pack_check.py out.npz [ref.npz]"""
+"""A/B state check for development libraries (ARBSTEP_LIB): steps a batch whose size is not a multiple of 4
+through the falling episode and writes the state after 10/20/30/40 steps, or compares it with a file written
+by another library.  usage: pack_check.py out.npz [ref.npz]   (driven by tools/ab_bench.sh)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
