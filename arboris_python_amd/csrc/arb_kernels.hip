@@ -139,7 +139,7 @@ struct DebugOut {
     T *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next;
     T *energy;          // [nw][2] kinetic, potential energy (EnergyMonitor, observers.py:40-51)
     long long *stamps;  // [nw][8] s_memtime at the phase boundaries (diagnostic)
-    int ablate;         // diagnostic: bit mask of phase-B pieces to skip (timing experiments only, env ARB_ABLATE)
+    int ablate;         // diagnostic (env ARB_ABLATE, inspect only): bit 3 (8) = run all 20 Gauss-Seidel sweeps, no fixed-point exit
     int *gs_stats;      // [nw][4]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts
 };
 
