@@ -6,51 +6,88 @@ SoftFingerContacts, batch 4096 worlds per GPU (BASELINE config #3), synthetic
 standing/falling states, float32 state and arithmetic.
 
 A "step" is one pass of the hot path (update_dynamic -> update_controllers ->
-update_constraints -> integrate, arboris/core.py:1358-1363) over the whole batch
-= one arb_step launch advancing every world by one dt.  The state is restored
-from the pristine synthetic batch every 40 steps (the length of the reference's
-falling-human scenario, tests/test_human36_falling.py) so the workload stays the
-free-fall-then-impact regime; the restore is a device-to-device copy inside the
-timed region.
+update_constraints -> integrate, arboris/core.py:1358-1363) over the whole batch:
+every world advances by one dt.  The workload is the reference's falling scenario
+(tests/test_human36_falling.py): an EPISODE of 40 steps from the standing-drop
+states -- free fall, impact, sliding contacts.  The cost of a step depends on where in
+the episode it is, so the timed region is always a whole number of episodes: `--steps K`
+is rounded up to whole episodes and the episodes are repeated until the region lasts
+`--min-seconds` (and at least 50 launches).  One episode = one arb_step launch (the state
+stays on chip for its 40 steps); the state is restored from the pristine batch before
+every episode by a device-to-device copy inside the timed region.
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]
-         (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+Launch:  python bench.py [--gpus N --steps K --warmup W --config {2,3,4,5}]
+         With N > 1 and no WORLD_SIZE in the environment bench.py starts
+         `python -m torch.distributed.run --nproc-per-node N ... bench.py ...` itself
+         (a child process, before anything touches the GPU).
 Worlds are independent, so ranks shard the batch with no data-path collective
-(weak scaling: 4096 worlds per GPU); RCCL is used only for the barrier/max-time
+(weak scaling: the per-GPU batch is fixed; dist.shard_bounds gives each rank its
+contiguous range of the global batch); RCCL is used only for the barrier/max-time
 reduction and for the final state gather, which is timed separately.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3     # vector FP32 spec peak
-RESET_EVERY = 40
+
+# BASELINE.json configs that fit the bench (config 1 is the single-world CPU parity case)
+CONFIGS = {
+    2: dict(model="human36", contacts=0, batch=1024, dtype="f32", dt=5e-3, episode=40, states="random",
+            name="human36 (42 dof), no contacts, random states (BASELINE config #2)"),
+    3: dict(model="human36", contacts=4, batch=4096, dtype="f32", dt=5e-3, episode=40, states="standing",
+            name="human36 (42 dof) + 4 floor SoftFingerContact, standing-drop states (BASELINE config #3)"),
+    4: dict(model="snake64", contacts=0, batch=2048, dtype="f64", dt=1e-3, episode=40, states="random",
+            name="snake-64 (64 Rz joints), random states, 2048 worlds/GPU = 16384 on 8 GPUs (BASELINE config #4)"),
+    5: dict(model="human36", contacts=4, batch=8192, dtype="f32", dt=5e-3, episode=32, states="standing",
+            name="human36 + 4 contacts, 32-step horizon, 8192 worlds/GPU = 65536 on 8 GPUs (BASELINE config #5)"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="worlds per GPU")
-    ap.add_argument("--contacts", type=int, default=4, choices=(0, 4, 8))
-    ap.add_argument("--dtype", default="f32", choices=("f32", "f64"))
-    ap.add_argument("--dt", type=float, default=5e-3)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json config (3 = the headline metric)")
+    ap.add_argument("--batch", type=int, default=None, help="worlds per GPU (default: the config's)")
+    ap.add_argument("--contacts", type=int, default=None, choices=(0, 4, 8))
+    ap.add_argument("--dtype", default=None, choices=("f32", "f64"))
+    ap.add_argument("--dt", type=float, default=None)
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="lower bound of the timed region (whole episodes are repeated until it is reached)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--steps-per-launch", type=int, default=RESET_EVERY,
-                    help="steps advanced by one arb_step call (state stays on chip in between); "
-                         "%d = one falling episode per launch, 1 = one launch per step" % RESET_EVERY)
-    ap.add_argument("--extra", action="store_true", help="also time the other BASELINE configs")
-    return ap.parse_args()
+    ap.add_argument("--split", action="store_true", help="Gauss-Seidel sweeps in their own kernel (ARB_STEP_SPLIT)")
+    ap.add_argument("--no-per-step-leg", action="store_true", help="skip the one-launch-per-step comparison leg")
+    ap.add_argument("--extra", action="store_true", help="also time the other BASELINE configs (N=1)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher/sharding rehearsal on CPU: gloo backend, no GPU call, no stepping")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(gpus, argv):
+    """The command bench.py starts when asked for N > 1 ranks without a launcher."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+            os.path.abspath(__file__)] + list(argv)
 
 
 _CPU_WORKER = r"""
@@ -71,14 +108,14 @@ print(time.perf_counter() - t0)
 """
 
 
-def cpu_baseline(model, q, dq, dt, budget_s):
+def cpu_baseline(model, q, dq, dt, budget_s, episode):
     """The NumPy float64 oracle (a port of the reference algorithm) timed on the host:
     one core, then one single-threaded process per core over disjoint world shards
     (SURVEY 8d), both on a bounded sample of the bench workload."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import arb_oracle as O
     import contextlib
-    import subprocess
     import tempfile
     try:
         from threadpoolctl import threadpool_limits
@@ -95,7 +132,7 @@ def cpu_baseline(model, q, dq, dt, budget_s):
         while True:
             qs, dqs, cf = O.step(model, qs, dqs, dt, cf)
             done += nw
-            if time.perf_counter() - t0 > budget_s or done >= nw * RESET_EVERY:
+            if time.perf_counter() - t0 > budget_s or done >= nw * episode:
                 break
         el = time.perf_counter() - t0
     out = dict(value=done / el, unit="world-steps/s", cores=1, kind="port",
@@ -104,12 +141,11 @@ def cpu_baseline(model, q, dq, dt, budget_s):
     # all cores: child processes (they never touch the GPU), one BLAS thread each
     try:
         ncores = min(os.cpu_count() or 1, 128, q.shape[0] // 16)
-        nsteps = max(2, min(RESET_EVERY, int(budget_s * out["value"] / 16)))
+        nsteps = max(2, min(episode, int(budget_s * out["value"] / 16)))
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "shard.npz")
             np.savez(f, q=q[:16 * ncores], dq=dq[:16 * ncores], **model.to_npz_dict())
-            t0 = time.perf_counter()
             procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, f, str(r), "16", str(nsteps), repr(dt)],
                                       stdout=subprocess.PIPE, env=env) for r in range(ncores)]
             times = [float(p.communicate(timeout=600)[0].decode().strip().splitlines()[-1]) for p in procs]
@@ -121,55 +157,134 @@ def cpu_baseline(model, q, dq, dt, budget_s):
     return out
 
 
-def time_config(bw, q0, dq0, dt, steps, warmup, torch, dist=None, use_cf=True, spl=1):
-    """Time exactly `steps` steps (after `warmup` untimed ones).  The workload is the reference's
-    falling scenario: every RESET_EVERY steps the worlds restart from the initial states.  One
-    arb_step call advances min(spl, steps left in the episode) steps.  Returns wall seconds, the
-    mean duration of a launch (ms, events on the launch stream), the mean steps per launch,
-    finiteness of the final state and the final state."""
+def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True):
+    """Run `n_episodes` whole episodes: restore the pristine states, advance `episode` steps (one arb_step
+    launch per `spl` steps; default the whole episode in one launch).  Returns wall seconds between the
+    two barrier + synchronize brackets, the launch durations in ms (HIP events on the launch stream =
+    torch's current stream), and the final state."""
     dev = bw.device
+    spl = episode if spl is None else spl
     q, dq = q0.clone(), dq0.clone()
-    cf = bw.new_cforce(q.shape[0], q.dtype) if (bw.model.nc and use_cf) else None
-
-    def chunks(total):
-        k = 0
-        while k < total:
-            c = min(spl, RESET_EVERY - k % RESET_EVERY, total - k)
-            yield k, c
-            k += c
-    for k, c in chunks(warmup):
-        if k % RESET_EVERY == 0:
-            q.copy_(q0); dq.copy_(dq0)
-        bw.step(q, dq, dt, c, cforce=cf)
+    cf = bw.new_cforce(q.shape[0], q.dtype) if bw.model.nc else None
+    chunks = []
+    k = 0
+    while k < episode:
+        chunks.append(min(spl, episode - k))
+        k += chunks[-1]
+    ev = []
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    plan = list(chunks(steps))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plan]
     t0 = time.perf_counter()
-    for i, (k, c) in enumerate(plan):
-        if k % RESET_EVERY == 0:
-            q.copy_(q0); dq.copy_(dq0)
-        ev[i][0].record()               # on torch's current stream = the stream arb_step launches on
-        bw.step(q, dq, dt, c, cforce=cf)
-        ev[i][1].record()
+    for _ in range(n_episodes):
+        q.copy_(q0); dq.copy_(dq0)
+        if cf is not None:
+            cf.zero_()
+        for c in chunks:
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            bw.step(q, dq, dt, c, cforce=cf, split=split)
+            if timed:
+                b.record()
+                ev.append((a, b))
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    finite = bool(torch.isfinite(q).all() and torch.isfinite(dq).all())
-    return wall, kern_ms, steps / float(len(plan)), finite, (q, dq)
+    ms = [a.elapsed_time(b) for a, b in ev]
+    return wall, ms, (q, dq)
+
+
+def build_model(cfg):
+    from arboris_python_amd import scenes
+    if cfg["model"] == "snake64":
+        return scenes.flat(scenes.snake_world(64))
+    return scenes.flat(scenes.human36_world(cfg["contacts"]))
+
+
+def make_states(cfg, model, count, seed):
+    from arboris_python_amd import synth
+    if cfg["states"] == "standing":
+        # config 3/5 distribution: standing pose dropped from U(0, 3 cm), small velocities
+        return synth.standing_states(model, count, seed=seed, drop=0.03, vel=0.1)
+    if cfg["model"] == "snake64":
+        return synth.random_states(model, count, seed=seed, angle=0.5, vel=1.0)
+    return synth.random_states(model, count, seed=seed)
+
+
+def resolve_config(args):
+    cfg = dict(CONFIGS[args.config])
+    if args.batch is not None:
+        cfg["batch"] = args.batch
+    if args.contacts is not None and cfg["model"] == "human36":
+        cfg["contacts"] = args.contacts
+        cfg["states"] = "standing" if args.contacts else "random"
+    if args.dtype is not None:
+        cfg["dtype"] = args.dtype
+    if args.dt is not None:
+        cfg["dt"] = args.dt
+    return cfg
+
+
+def dry_run(args, cfg):
+    """Launcher / sharding rehearsal without a GPU: every rank joins a gloo group, takes its range of
+    the global batch from dist.shard_bounds, and the final gather runs on CPU stand-in tensors."""
+    import torch
+    import torch.distributed as dist
+    from arboris_python_amd.dist import shard_bounds, gather_state
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    ws = dist.get_world_size() if world > 1 else 1
+    B = cfg["batch"]
+    a, b = shard_bounds(ws * B, rank, ws)
+    shards = [None] * ws
+    if world > 1:
+        dist.all_gather_object(shards, (a, b))
+        q_loc = torch.arange(a, b, dtype=torch.float64).reshape(-1, 1).repeat(1, 3)
+        dq_loc = -torch.arange(a, b, dtype=torch.float64).reshape(-1, 1).repeat(1, 2)
+        q_all, dq_all = gather_state(q_loc, dq_loc, ws * B, dist)
+        ok = bool(torch.equal(q_all[:, 0], torch.arange(ws * B, dtype=torch.float64))
+                  and torch.equal(dq_all[:, 0], -torch.arange(ws * B, dtype=torch.float64)))
+    else:
+        shards, ok = [(a, b)], True
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": ws, "requested_gpus": args.gpus, "worlds_per_gpu": B,
+                          "global_batch": ws * B, "shards": [list(s) for s in shards], "gather_ok": ok,
+                          "config": args.config}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    cfg = resolve_config(args)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        # No launcher around us: start one rank per GPU as child processes.  This process has not
+        # imported torch nor made any HIP call, and it never does; it only waits for the children.
+        cmd = launcher_command(args.gpus, sys.argv[1:])
+        sys.stderr.write("[bench] starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write("[bench] --gpus %d but WORLD_SIZE=%d: refusing to report a mislabelled line\n"
+                         % (args.gpus, world))
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, cfg)
+
+    import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -177,27 +292,39 @@ def main():
         torch.cuda.set_device(local_rank)
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
-    n_gpus = world
-    from arboris_python_amd import scenes, synth
+    n_gpus = dist.get_world_size() if dist is not None else 1        # the ranks RCCL saw
     from arboris_python_amd.batch import BatchedWorlds
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    from arboris_python_amd.dist import shard_bounds
+    dtype = torch.float32 if cfg["dtype"] == "f32" else torch.float64
 
-    model = scenes.flat(scenes.human36_world(args.contacts))
+    model = build_model(cfg)
     bw = BatchedWorlds(model, local_rank)
-    B = args.batch
-    if args.contacts:
-        # config 3/5 distribution: standing pose dropped from U(0, 3 cm), small velocities
-        q, dq = synth.standing_states(model, B, seed=1000 + rank, drop=0.03, vel=0.1)
-    else:
-        q, dq = synth.random_states(model, B, seed=1000 + rank)
+    B = cfg["batch"]
+    lo, hi = shard_bounds(n_gpus * B, rank, n_gpus)                  # this rank's worlds of the global batch
+    q, dq = make_states(cfg, model, hi - lo, seed=1000 + rank)
     q0, dq0 = bw.to_device(q, dq, dtype)
+    dt, EP = cfg["dt"], cfg["episode"]
 
-    spl = max(1, args.steps_per_launch)
-    wall, kern_ms, spl_avg, finite, (qf, dqf) = time_config(bw, q0, dq0, args.dt, args.steps, args.warmup, torch, dist, spl=spl)
+    # ---- warmup: W steps rounded up to whole episodes (untimed), then one calibration episode -------------
+    warm_eps = max(1, -(-args.warmup // EP))
+    run_episodes(bw, q0, dq0, dt, EP, warm_eps, torch, dist, split=args.split, timed=False)
+    cal, _, _ = run_episodes(bw, q0, dq0, dt, EP, 2, torch, dist, split=args.split, timed=False)
+    n_ep = max(-(-args.steps // EP), 50, int(np.ceil(args.min_seconds / max(cal / 2, 1e-6))))
+    t = torch.tensor([n_ep], dtype=torch.int64, device=bw.device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # every rank times the same number of episodes
+    n_ep = int(t.item())
+
+    # ---- the timed region: n_ep whole episodes between barrier + synchronize brackets ----------------------
+    wall, ms, (qf, dqf) = run_episodes(bw, q0, dq0, dt, EP, n_ep, torch, dist, split=args.split)
     t = torch.tensor([wall], dtype=torch.float64, device=bw.device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
+    finite = bool(torch.isfinite(qf).all() and torch.isfinite(dqf).all())
+    steps_timed = n_ep * EP
+    launches_per_episode = len(ms) // n_ep
+    ep_ms = np.asarray(ms).reshape(n_ep, launches_per_episode).sum(axis=1)       # kernel time per episode
 
     # final state gather over RCCL/xGMI (outside the timed region, reported separately)
     gather_ms = None
@@ -205,99 +332,110 @@ def main():
         from arboris_python_amd.dist import gather_state
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        q_all, dq_all = gather_state(qf, dqf, world * B, dist)
+        q_all, dq_all = gather_state(qf, dqf, n_gpus * B, dist)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        assert q_all.shape[0] == world * B
+        assert q_all.shape[0] == n_gpus * B
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    elem = 4 if args.dtype == "f32" else 8
+    elem = 4 if cfg["dtype"] == "f32" else 8
     bytes_per_world_step = 2 * (model.nq + model.ndof) * elem           # state in + state out
-    value = n_gpus * B * args.steps / wall
+    if model.nc:
+        bytes_per_world_step += 2 * model.nc * 4 * elem                  # cforce in + out
+    value = n_gpus * B * steps_timed / wall
+    kern_ms = float(np.mean(ep_ms))
     # one launch reads and writes the state once, whatever the number of steps it advances on chip
     achieved_gbs = bytes_per_world_step * B / (kern_ms * 1e-3) / 1e9
-    flop_dense = {0: 1.66e6, 4: 1.9e6, 8: 2.13e6}[args.contacts]          # dense-as-written count, SURVEY 6
+    flop_dense = {0: 1.66e6, 4: 1.9e6, 8: 2.13e6}.get(cfg["contacts"], 1.66e6) if cfg["model"] == "human36" else 1.23e7
     res = {
         "metric": "world-steps/sec at batch, human36 ~40-DOF + 4 contacts, 1/2/4/8 MI355X",
         "value": value, "unit": "world-steps/s", "n_gpus": n_gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "human36 (42 dof) + %d floor SoftFingerContact, batch %d worlds/GPU, dt=%g, "
-                               "standing-drop states reset every %d steps (BASELINE config #3), "
-                               "%g steps per arb_step launch"
-                               % (args.contacts, B, args.dt, RESET_EVERY, spl_avg),
-                   "worlds_per_gpu": B, "global_batch": n_gpus * B, "parallelism": "dp%d" % n_gpus,
-                   "steps_per_launch": spl_avg},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "warmup": args.warmup, "ms_per_step": wall / steps_timed * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "steps_timed": steps_timed, "episodes": n_ep, "episode_steps": EP, "timed_region_s": wall,
+        "warmup_steps_run": (warm_eps + 2) * EP,
+        "steps_note": "a step's cost depends on its place in the %d-step episode (free fall, impact, sliding), so "
+                      "--steps is rounded up to whole episodes and episodes are repeated for >= %.1f s and >= 50 "
+                      "launches; value = worlds x steps_timed / timed_region_s" % (EP, args.min_seconds),
+        "episode_kernel_ms": {"median": float(np.median(ep_ms)), "mean": kern_ms, "p10": float(np.percentile(ep_ms, 10)),
+                              "p90": float(np.percentile(ep_ms, 90)), "min": float(ep_ms.min()), "max": float(ep_ms.max())},
+        "config": {"workload": "%s, batch %d worlds/GPU, dt=%g, %s, whole %d-step episodes, one arb_step launch per episode%s"
+                               % (cfg["name"], B, dt, cfg["dtype"], EP, ", split Gauss-Seidel kernel" if args.split else ""),
+                   "baseline_config": args.config, "worlds_per_gpu": B, "global_batch": n_gpus * B,
+                   "parallelism": "dp%d" % n_gpus, "steps_per_launch": EP / launches_per_episode},
+        "roofline": {"bound": "valu-issue",
+                     "bound_note": "north_star asks for the HBM fraction, which achieved/peak/frac report; compulsory "
+                                   "traffic is the state in+out once per episode launch, so the path is bound by the "
+                                   "per-wave VALU issue/latency chain (see `valu`), not by HBM",
+                     "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "arb_step_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": bytes_per_world_step * B,
-                     "algorithmic_bytes_per_world_step": bytes_per_world_step / spl_avg,
-                     "note": "compulsory traffic is state in+out only; the path is VALU/latency bound, "
-                             "see fp32_vector",
-                     "fp32_vector": {"dense_equiv_flop_per_world_step": flop_dense,
-                                     "achieved_tflops": flop_dense * B * spl_avg / (kern_ms * 1e-3) / 1e12,
-                                     "peak_tflops": FP32_PEAK_TFLOPS,
-                                     "frac": flop_dense * B * spl_avg / (kern_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
+                     "algorithmic_bytes_per_world_step": bytes_per_world_step / float(EP),
+                     "fp32_vector_context": {"dense_equiv_flop_per_world_step": flop_dense,
+                                             "achieved_tflops": flop_dense * B * EP / (kern_ms * 1e-3) / 1e12,
+                                             "peak_tflops": FP32_PEAK_TFLOPS,
+                                             "note": "dense-as-written FLOP count of the reference (SURVEY 6), not the "
+                                                     "instructions the kernel executes: context only"}},
         "state_finite": finite,
     }
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh,
-    # profiles/): only valid for the workload those passes were taken on
+    # HBM traffic + issue counters of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile_gpu.sh,
+    # profiles/): attached only when the profiled launch shape is the one timed here
     import glob
     profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))   # newest round last by name
     profs = [f for f in profs if "baseline" not in f]
     prof = profs[-1] if profs else ""
-    if os.path.exists(prof) and args.contacts == 4 and B == 4096 and args.dtype == "f32" and spl == RESET_EVERY:
+    shape = {"config": args.config, "batch": B, "dtype": cfg["dtype"], "contacts": cfg["contacts"],
+             "steps_per_launch": EP, "split": bool(args.split)}
+    if os.path.exists(prof) and launches_per_episode == 1:
         try:
-            pm = json.load(open(prof))["pmc_per_launch"]
-            res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
-            res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
-                                               "(profiles/%s); 4 B/lane accesses, reported uncorrected" % os.path.basename(prof))
-            # what actually bounds the kernel: the serial instruction stream of two waves per SIMD
-            ws = float(B * RESET_EVERY)
-            res["roofline"]["issue"] = {
-                "valu_insts_per_world_step": pm["SQ_INSTS_VALU"]["mean_per_launch"] / ws,
-                "salu_insts_per_world_step": pm["SQ_INSTS_SALU"]["mean_per_launch"] / ws,
-                "lds_insts_per_world_step": pm["SQ_INSTS_LDS"]["mean_per_launch"] / ws,
-                "wave_cycles_per_world_step": 4. * pm["SQ_WAVE_CYCLES"]["mean_per_launch"] / ws,
-                "wave_frac_issuing_valu": pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
-                "wave_frac_waiting": (pm["SQ_WAIT_ANY"]["mean_per_launch"] + pm["SQ_WAIT_INST_ANY"]["mean_per_launch"])
-                                     / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
-                "simd_valu_busy_frac": 2. * pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
-                "note": "SQ counters of profiles/%s (two waves per SIMD)" % os.path.basename(prof)}
+            pj = json.load(open(prof))
+            pshape = pj.get("launch_shape", {"config": 3, "batch": 4096, "dtype": "f32", "contacts": 4,
+                                             "steps_per_launch": 40, "split": False})
+            if pshape == shape:
+                pm = pj["pmc_per_launch"]
+                res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
+                res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
+                                                   "(profiles/%s); 4 B/lane accesses, reported uncorrected" % os.path.basename(prof))
+                ws = float(B * EP)
+                res["roofline"]["valu"] = {
+                    "valu_insts_per_world_step": pm["SQ_INSTS_VALU"]["mean_per_launch"] / ws,
+                    "salu_insts_per_world_step": pm["SQ_INSTS_SALU"]["mean_per_launch"] / ws,
+                    "lds_insts_per_world_step": pm["SQ_INSTS_LDS"]["mean_per_launch"] / ws,
+                    "wave_cycles_per_world_step": 4. * pm["SQ_WAVE_CYCLES"]["mean_per_launch"] / ws,
+                    "wave_frac_issuing_valu": pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                    "wave_frac_waiting": (pm["SQ_WAIT_ANY"]["mean_per_launch"] + pm["SQ_WAIT_INST_ANY"]["mean_per_launch"])
+                                         / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                    "note": "SQ counters of profiles/%s" % os.path.basename(prof)}
         except Exception:
             pass
     if gather_ms is not None:
         res["final_state_allgather_ms"] = gather_ms
-    if n_gpus == 1 and spl != 1:
-        # the same workload with one launch per step (how rounds up to r01b were measured)
-        w1, k1, _, _, _ = time_config(bw, q0, dq0, args.dt, 2 * RESET_EVERY, RESET_EVERY // 2, torch, None, spl=1)
-        res["per_step_launch"] = {"value": B * 2 * RESET_EVERY / w1, "unit": "world-steps/s", "kernel_ms": k1,
-                                  "steps": 2 * RESET_EVERY}
+    if n_gpus == 1 and not args.no_per_step_leg:
+        # the same workload with one launch per step (a non-uniform timeline, or observers between steps)
+        w1, m1, _ = run_episodes(bw, q0, dq0, dt, EP, 5, torch, None, spl=1, split=args.split)
+        res["per_step_launch"] = {"value": B * 5 * EP / w1, "unit": "world-steps/s", "kernel_ms": float(np.mean(m1)),
+                                  "steps": 5 * EP}
     if n_gpus == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(model, q, dq, args.dt, args.cpu_seconds)
+        res["cpu_baseline"] = cpu_baseline(model, q, dq, dt, args.cpu_seconds, EP)
         res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     if args.extra and n_gpus == 1:
         extra = {}
-        for name, mdl, gen, kw, bsz, dtt, dty in (
-                ("config2_human36_nocontact_b1024_f32", scenes.flat(scenes.human36_world(0)), synth.random_states,
-                 dict(seed=0), 1024, 5e-3, torch.float32),
-                ("config4_snake64_b2048_f64", scenes.flat(scenes.snake_world(64)), synth.random_states,
-                 dict(seed=0, angle=0.5, vel=1.0), 2048, 1e-3, torch.float64),
-                ("human36_8contacts_b4096_f32", scenes.flat(scenes.human36_world(8)), synth.standing_states,
-                 dict(seed=0, drop=0.03, vel=0.1), 4096, 5e-3, torch.float32)):
+        for cid in (2, 4, 5):
+            c2 = dict(CONFIGS[cid])
+            mdl = build_model(c2)
             b2 = BatchedWorlds(mdl, local_rank)
-            qa, da = gen(mdl, bsz, **kw)
-            ta, tb = b2.to_device(qa, da, dty)
-            wl, km, _, fin, _ = time_config(b2, ta, tb, dtt, 80, 10, torch, spl=1)
-            wr, kr, _, _, _ = time_config(b2, ta, tb, dtt, 80, 10, torch, spl=RESET_EVERY)
-            # (from the launch durations: these short runs are dominated by host-side setup otherwise)
-            extra[name] = {"world_steps_per_s": bsz * RESET_EVERY / (kr * 1e-3), "launch_ms_%d_steps" % RESET_EVERY: kr,
-                           "per_step_launch_world_steps_per_s": bsz / (km * 1e-3), "per_step_launch_ms": km, "finite": fin}
+            qa, da = make_states(c2, mdl, c2["batch"], seed=0)
+            ta, tb = b2.to_device(qa, da, torch.float32 if c2["dtype"] == "f32" else torch.float64)
+            run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 2, torch, timed=False)
+            wl, me, (qe, _) = run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 20, torch)
+            extra["config%d" % cid] = {"workload": c2["name"], "world_steps_per_s": c2["batch"] * 20 * c2["episode"] / wl,
+                                       "episode_kernel_ms_median": float(np.median(me)),
+                                       "finite": bool(torch.isfinite(qe).all())}
             b2.close()
         res["extra"] = extra
     print(json.dumps(res))

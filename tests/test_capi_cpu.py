@@ -112,6 +112,34 @@ def test_device_softfinger_solve_on_host(branch, code, route):
 
 
 @needs_lib
+def test_softfinger_solve_on_host_over_an_oracle_episode():
+    """The local solve the kernels run (arb_math.h, host build) over every SoftFingerContact.solve call of a
+    falling episode stepped by the oracle (8 worlds x 40 steps of config 3, ~1e4 tuples, all three branches):
+    float64 to 1e-8; decisions may only differ where the oracle's inequality is at rounding distance."""
+    import arb_oracle as O
+    from conftest import load_model
+    from arboris_python_amd import synth
+    lib = _capi.load()
+    m, _, _ = load_model("human36_c4")
+    q, dq = synth.standing_states(m, 8, seed=1000, drop=0.03, vel=0.1)
+    tr, cf = [], None
+    for _ in range(40):
+        q, dq, cf = O.step(m, q, dq, 5e-3, cf, trace=tr)
+    cnt = np.bincount([t["branch"] for t in tr], minlength=3)
+    assert len(tr) > 5000 and (cnt > 100).all(), cnt
+    eps = np.ones(3)
+    worst = 0.
+    for t in tr:
+        vel, adm, f = np.ascontiguousarray(t["vel"]), np.ascontiguousarray(t["adm"]), t["force"].copy()
+        df = np.zeros(4)
+        br = lib.arb_host_softfinger_solve(_capi.ARB_F64, _capi._dp(vel), _capi._dp(adm), _capi._dp(f), t["sdist"], t["dt"],
+                                           t["mu"], _capi._dp(eps), _capi._dp(df))
+        assert br == t["branch"], (br, t["branch"], t["sweep"], t["world"])
+        worst = max(worst, np.abs(df - t["dforce"]).max() / max(1., np.abs(t["dforce"]).max()))
+    assert worst < 1e-8, worst
+
+
+@needs_lib
 @pytest.mark.parametrize("dtype", [_capi.ARB_F64, _capi.ARB_F32])
 def test_sliding_shift_fast_path_is_taken(dtype):
     """The register-only sextic/Laguerre route must handle every captured sliding

@@ -58,3 +58,106 @@ def test_device_solve_equals_host_and_oracle(canary_tuples, dtype, tol, route):
     assert np.array_equal(dev[:, 8], host[:, 8]) and np.array_equal(np.minimum(dev[:, 8], 2), ref[:, 8])
     assert np.abs(dev[:, :8] - host[:, :8]).max() / scale < tol
     assert np.abs(dev[:, :8] - ref[:, :8]).max() / scale < tol
+
+
+# ---------------------------------------------------------------------------
+# The local solve over >= 1e5 input tuples harvested from the bench workloads (configs 3 and 5): the device
+# logs the states of a falling episode, the oracle replays every logged state for one step and records the
+# input and the result of each of its SoftFingerContact.solve calls (constraints.py:780-836).
+# ---------------------------------------------------------------------------
+def margin_of(t, P=None):
+    """relative distance of the tuple's release / friction-cone decisions from their inequalities"""
+    vel, adm, f, sd, dt, mu = t[0:4], t[4:20].reshape(4, 4), t[20:24], t[24], t[25], t[26]
+    v0 = vel - adm @ f
+    r = sd + dt * v0[3]
+    mg = abs(r) / max(abs(sd) + abs(dt * v0[3]), 1e-300)
+    if r <= 0:
+        fn = f - np.linalg.pinv(adm) @ np.hstack((vel[0:3], vel[3] + sd / dt))
+        lhs, rhs = float(np.sum(fn[0:3] ** 2)), float((fn[3] * mu) ** 2)
+        mg = min(mg, abs(lhs - rhs) / max(lhs, rhs, 1e-300))
+    return mg
+
+
+@pytest.fixture(scope="module")
+def harvested():
+    from arboris_python_amd.batch import BatchedWorlds
+    from arboris_python_amd import synth
+    tuples, results = [], []
+    for name, seed, T in (("human36_c4", 1000, 40), ("human36_c8", 5, 32)):
+        m, _, _ = load_model(name)
+        bw = BatchedWorlds(m)
+        B = 96 if m.nc == 4 else 32
+        q, dq = synth.standing_states(m, B, seed=seed, drop=0.03, vel=0.1)
+        if m.nc == 8:
+            q[:, 7] -= 0.02                              # config 5 of the full-size tests: feet near the floor
+        tq, tdq = bw.to_device(q, dq, torch.float32)
+        log = bw.rollout(tq, tdq, 5e-3, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False)
+        torch.cuda.synchronize()
+        lq, ldq = log["q"].double().cpu().numpy(), log["dq"].double().cpu().numpy()
+        bw.close()
+        for k in range(T):
+            tr = []
+            O.step(m, lq[k], ldq[k], 5e-3, trace=tr)
+            if tr:
+                tuples.append(tuples_of_trace(tr))
+                results.append(np.array([np.concatenate([t["force"] + t["dforce"], t["dforce"], [t["branch"]]]) for t in tr]))
+    return np.concatenate(tuples), np.concatenate(results)
+
+
+def test_device_solve_on_1e5_harvested_tuples_f64(harvested):
+    lib = _capi.load()
+    tuples, ref = harvested
+    cnt = np.bincount(ref[:, 8].astype(int), minlength=3)
+    print("harvested tuples: %d (release %d, static %d, sliding %d)" % (len(tuples), cnt[0], cnt[1], cnt[2]))
+    assert len(tuples) >= 100000 and (cnt >= 1000).all(), cnt
+    dev = device_solve(lib, _capi.ARB_F64, tuples)
+    assert np.isfinite(dev).all()
+    same = np.minimum(dev[:, 8], 2) == ref[:, 8]
+    # a decision may only differ where the oracle's own inequality is within rounding of equality
+    for i in np.flatnonzero(~same):
+        assert margin_of(tuples[i]) < 1e-9, (i, dev[i, 8], ref[i, 8], margin_of(tuples[i]))
+    scale = np.maximum(1., np.abs(ref[:, :4]).max(axis=1))
+    err = np.abs(dev[:, :8] - ref[:, :8]).max(axis=1) / scale
+    print("float64: %d decisions differ; max rel err %.2e" % ((~same).sum(), err[same].max()))
+    assert err[same].max() < 1e-8
+    # the generic eig6 route on a subsample of the sliding tuples
+    sl = np.flatnonzero(ref[:, 8] == 2)[::7][:5000]
+    dev6 = device_solve(lib, _capi.ARB_F64 | 0x100, tuples[sl])
+    ok6 = np.minimum(dev6[:, 8], 2) == 2
+    err6 = np.abs(dev6[:, :8] - ref[sl, :8]).max(axis=1) / scale[sl]
+    assert ok6.mean() > 0.999 and err6[ok6].max() < 1e-7, (ok6.mean(), err6[ok6].max())
+
+
+def test_device_solve_on_1e5_harvested_tuples_f32(harvested):
+    """float32 device solve against the float64 oracle on the SAME (float32-rounded) inputs, for a 20k subsample
+    the oracle can re-solve in test time; the host build of the same code over all tuples (bitwise)."""
+    lib = _capi.load()
+    tuples, ref = harvested
+    t32 = tuples.astype(np.float32).astype(np.float64)
+    dev = device_solve(lib, _capi.ARB_F32, t32)
+    assert np.isfinite(dev).all()
+    rng = np.random.default_rng(0)
+    sub = np.sort(rng.choice(len(t32), 20000, replace=False))
+    eps = np.ones(3)
+    bad = 0
+    errs = []
+    for i in sub:
+        t = t32[i]
+        df, newf, br = O._softfinger_solve_one(t[0:4], t[4:20].reshape(4, 4), t[20:24], t[24], t[26], eps, t[25])
+        if min(dev[i, 8], 2) != br:
+            # float32 decides differently only near the inequality (4x4 solves of cond ~1e3 in float32)
+            assert margin_of(t) < 1e-2, (i, dev[i, 8], br, margin_of(t))
+            bad += 1
+            continue
+        errs.append(np.abs(dev[i, :4] - newf).max() / max(1., np.abs(newf).max()))
+    errs = np.array(errs)
+    print("float32: %d of %d decisions differ; force rel err median %.2e p99 %.2e max %.2e"
+          % (bad, len(sub), np.median(errs), np.quantile(errs, 0.99), errs.max()))
+    assert bad <= 0.005 * len(sub)
+    assert np.quantile(errs, 0.99) < 2e-4 and errs.max() < 2e-2
+    # device == host build of the same arb_math.h code, over a 20k subsample (ctypes call per tuple)
+    host = np.array([host_solve(lib, _capi.ARB_F32, t32[i]) for i in sub])
+    hs = np.maximum(1., np.abs(host[:, :4]).max(axis=1))
+    assert (np.minimum(dev[sub, 8], 2) == np.minimum(host[:, 8], 2)).mean() > 0.999
+    eq = np.minimum(dev[sub, 8], 2) == np.minimum(host[:, 8], 2)
+    assert (np.abs(dev[sub, :8] - host[:, :8]).max(axis=1) / hs)[eq].max() < 1e-3

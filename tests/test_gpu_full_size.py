@@ -10,9 +10,12 @@ size-independent properties (the CPU oracle cannot step 65536 worlds in test tim
   * the opt-in split execution (Gauss-Seidel sweeps in a lane-per-world kernel) against the fused kernel.
 
 Tolerance: max|x_gpu - x_ref| / max(1, max|x_ref|) <= 1e-5 per world for one float32 step from
-identical inputs (north star); worlds whose contacts sit on a branch boundary of
-SoftFingerContact.solve (release / static / sliding decided by an inequality that float32 and
-float64 can resolve differently) are allowed as rare outliers, bounded in number and size.
+identical inputs (north star).  At least 99.5 % of the sampled world-steps must meet it (measured:
+99.9 %, tools/replay_stats.py) and EVERY outlier must be explained: the float32 device and the
+float64 oracle took different decisions in that step -- a different active set (constraints.py:292)
+or a different release / static / sliding sequence in the Gauss-Seidel sweeps (constraints.py:781,
+799) -- or one of the oracle's decisions sits within 1e-6 (relative) of its inequality.  Unexplained
+outliers fail the test; explained ones stay below 1e-3.
 """
 import numpy as np
 import pytest
@@ -47,17 +50,78 @@ def bws():
         bw.close()
 
 
-def replay_errors(m, log_q, log_dq, steps, worlds, dt):
+def replay_errors(m, log_q, log_dq, steps, worlds, dt, with_index=False):
     """Oracle step from the device's own logged state at `steps` for `worlds`; returns the per-world
-    errors of q and dq against the device's next logged state, stacked over the steps."""
-    eq, edq = [], []
+    errors of q and dq against the device's next logged state, stacked over the steps (and, with
+    `with_index`, the (step, world) pair of every entry)."""
+    eq, edq, idx = [], [], []
     for k in steps:
         q = log_q[k][worlds].double().cpu().numpy()
         dq = log_dq[k][worlds].double().cpu().numpy()
         oq, odq, _ = O.step(m, q, dq, dt)
         eq.append(world_err(log_q[k + 1][worlds].cpu().numpy(), oq))
         edq.append(world_err(log_dq[k + 1][worlds].cpu().numpy(), odq))
+        idx += [(k, int(w)) for w in worlds]
+    if with_index:
+        return np.concatenate(eq), np.concatenate(edq), idx
     return np.concatenate(eq), np.concatenate(edq)
+
+
+def decision_margins(tr):
+    """Smallest relative distance of the oracle's SoftFingerContact.solve decisions (constraints.py:781
+    release test, :799 friction cone test) from their inequalities, over the solves of a trace."""
+    best = np.inf
+    for t in tr:
+        vel, adm, f, sd, dt = t["vel"], np.asarray(t["adm"]), t["force"], t["sdist"], t["dt"]
+        v0 = vel - adm @ f
+        rel_lhs = sd + dt * v0[3]
+        best = min(best, abs(rel_lhs) / max(abs(sd) + abs(dt * v0[3]), 1e-300))
+        if rel_lhs > 0:
+            continue
+        fn = f - np.linalg.pinv(adm) @ np.hstack((vel[0:3], vel[3] + sd / dt))
+        lhs, rhs = float(np.sum(fn[0:3] ** 2)), float((fn[3] * t["mu"]) ** 2)
+        best = min(best, abs(lhs - rhs) / max(lhs, rhs, 1e-300))
+    return best
+
+
+def explain_outlier(bw, m, q, dq, dt):
+    """Why may a float32 step differ from the float64 oracle by more than rounding?  Returns a reason
+    string, or None.  `q`, `dq`: the float32 state the device stepped from (one world)."""
+    tq = torch.as_tensor(q[None], dtype=torch.float32, device=bw.device).contiguous()
+    tdq = torch.as_tensor(dq[None], dtype=torch.float32, device=bw.device).contiguous()
+    r = bw.inspect(tq, tdq, dt, ["gs_stats", "c_active"], cforce=bw.new_cforce(1, torch.float32))
+    st = r["gs_stats"].cpu().numpy()[0]                    # release, static, fast slide, eig6 slide, sweeps
+    dact = r["c_active"].cpu().numpy()[0].astype(bool)
+    tr = []
+    _, _, _, d = O.step(m, q[None].astype(np.float64), dq[None].astype(np.float64), dt, debug=True, trace=tr)
+    if not np.array_equal(dact, d["active"][0]):
+        return "active set differs"
+    # the device stops sweeping at a bit-exact fixed point: compare the sweeps it executed
+    nsw = int(st[4])
+    ob = np.zeros(3, int)
+    for t in tr:
+        if t["sweep"] < nsw:
+            ob[t["branch"]] += 1
+    db = np.array([st[0], st[1], st[2] + st[3]])
+    if not np.array_equal(ob, db):
+        return "branch sequence differs (oracle %s, device %s over %d sweeps)" % (ob, db, nsw)
+    mg = decision_margins(tr)
+    if mg < 1e-6:
+        return "decision within %.1e of its inequality" % mg
+    return None
+
+
+def check_replay(bw, m, log, steps, worlds, dt, min_ok=0.995, max_outlier=1e-3):
+    eq, edq, idx = replay_errors(m, log["q"], log["dq"], steps, worlds, dt, with_index=True)
+    ok = (eq < F32_TOL) & (edq < F32_TOL)
+    assert ok.mean() >= min_ok, (ok.mean(), eq.max(), edq.max())
+    for i in np.flatnonzero(~ok):
+        k, w = idx[i]
+        why = explain_outlier(bw, m, log["q"][k][w].cpu().numpy(), log["dq"][k][w].cpu().numpy(), dt)
+        assert why is not None, "unexplained outlier: step %d world %d, err q %.2e dq %.2e" % (k, w, eq[i], edq[i])
+        assert eq[i] < max_outlier and edq[i] < 10 * max_outlier, (k, w, eq[i], edq[i], why)
+        print("outlier step %d world %d: err q %.2e dq %.2e -- %s" % (k, w, eq[i], edq[i], why))
+    return ok.mean(), float(eq.max()), float(edq.max())
 
 
 # ---------------------------------------------------------------------------
@@ -101,11 +165,8 @@ def test_config3_falling_episode_4096(bws):
     # the feet reached the floor and push on it
     assert float(cf[:, :, 3].max()) > 10.
     # replay of sampled (step, world) pairs through the oracle: free fall, first impacts, sliding
-    worlds = np.arange(5, B, 128)                                   # 32 worlds
-    eq, edq = replay_errors(m, log["q"], log["dq"], (0, 10, 20, 30, 38), worlds, dt)
-    ok = (eq < F32_TOL) & (edq < F32_TOL)
-    assert ok.mean() >= 0.97, (ok.mean(), eq.max(), edq.max())
-    assert eq.max() < 1e-3 and edq.max() < 1e-2, (eq.max(), edq.max())   # branch-boundary outliers stay small
+    worlds = np.arange(5, B, 64)                                    # 64 worlds x 13 steps = 832 world-steps
+    print("config 3 replay: ok %.4f, max err q %.2e dq %.2e" % check_replay(bw, m, log, range(0, 39, 3), worlds, dt))
     # batch-position / batch-size independence over the whole episode, bitwise
     sub = np.arange(3, B, 37)
     sq, sdq = bw.to_device(q[sub], dq[sub], torch.float32)
@@ -159,11 +220,9 @@ def test_config5_65536_worlds_32_steps(bws, name):
     log = bw.rollout(tq, tdq, dt, T, cforce=cf, log_energy=False)          # default execution: fused kernel
     torch.cuda.synchronize()
     assert torch.isfinite(tq).all() and torch.isfinite(tdq).all() and torch.isfinite(cf).all()
-    worlds = np.arange(17, B, 4096)                                 # 16 worlds
-    eq, edq = replay_errors(m, log["q"], log["dq"], (0, 9, 30), worlds, dt)
-    ok = (eq < F32_TOL) & (edq < F32_TOL)
-    assert ok.mean() >= 0.95, (ok.mean(), eq.max(), edq.max())
-    assert eq.max() < 1e-3 and edq.max() < 1e-2, (eq.max(), edq.max())
+    worlds = np.arange(17, B, 1024)                                 # 64 worlds x 6 steps = 384 world-steps
+    print("config 5 (%s) replay: ok %.4f, max err q %.2e dq %.2e"
+          % ((name,) + check_replay(bw, m, log, (0, 5, 9, 16, 24, 30), worlds, dt)))
     # batch-position independence at this size, first step, bitwise
     sub = np.arange(11, B, 997)
     sq, sdq = bw.to_device(q[sub], dq[sub], torch.float32)
@@ -179,7 +238,7 @@ def test_config5_65536_worlds_32_steps(bws, name):
         torch.cuda.synchronize()
         e1 = world_err(pq.cpu().numpy(), log["q"][1].cpu().numpy())
         e2 = world_err(pdq.cpu().numpy(), log["dq"][1].cpu().numpy())
-        assert np.quantile(e1, 0.98) < F32_TOL and np.quantile(e2, 0.98) < F32_TOL, (e1.max(), e2.max())
+        assert np.quantile(e1, 0.995) < F32_TOL and np.quantile(e2, 0.995) < F32_TOL, (e1.max(), e2.max())
         bw.step(pq, pdq, dt, T - 1, cforce=pcf, split=True)
         torch.cuda.synchronize()
         assert torch.isfinite(pq).all() and torch.isfinite(pdq).all() and torch.isfinite(pcf).all()

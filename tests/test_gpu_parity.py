@@ -5,8 +5,10 @@ Tolerances (north star: trajectories within 1e-5 relative of the float64 NumPy
 reference, single step from identical inputs):
   * float64 kernels: 1e-9 -- they run the same algorithm with a different
     factorisation order, so agreement at this level pins the device algebra;
-  * float32 kernels: 1e-5 on q+ and dq+, measured as
-        max|x_gpu - x_ref| / max(1, max|x_ref|).
+  * float32 kernels: 1e-5 on q+ and dq+, measured PER WORLD as
+        max|x_gpu - x_ref| / max(1, max|x_ref|)   over the entries of that world,
+    and the largest of these over the batch is gated (one fast world does not loosen the
+    gate of the others).
 """
 import numpy as np
 import pytest
@@ -22,8 +24,16 @@ F32_TOL = 1e-5
 
 
 def rel(a, b):
+    """Largest per-world relative error: arrays with a leading batch axis are normalised world by
+    world (row by row), a single world's array as a whole."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.max(np.abs(a - b)) / max(1., float(np.max(np.abs(b)))))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.ndim < 2:
+        a, b = a.reshape(1, -1), b.reshape(1, -1)
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    if a.size == 0:
+        return 0.
+    return float(np.max(np.max(np.abs(a - b), axis=1) / np.maximum(1., np.max(np.abs(b), axis=1))))
 
 
 @pytest.fixture(scope="module")
@@ -371,30 +381,88 @@ def test_snake64_f32_error_is_reported(bw_cache):
     assert np.isfinite(dq).all()
 
 
-def test_ball_and_socket(bw_cache):
+@pytest.mark.parametrize("dtype,ftol,qtol", [(torch.float64, 1e-7, 1e-9), (torch.float32, 2e-4, 1e-6)])
+def test_ball_and_socket(bw_cache, dtype, ftol, qtol):
+    """tests/test_constraints.py:11-60: a unit-mass free body hanging from a ball-and-socket joint;
+    the force persists from step to step (warm start, constraints.py:235-237).  float32: the force is
+    ~9.81 N, so 2e-4 absolute is 2e-5 relative."""
     g = load_golden("g6_constraints.npz")
     bw, m, q0, dq0 = bw_cache("ballsocket")
-    tq, tdq = bw.to_device(q0[None], dq0[None], torch.float64)
-    tcf = bw.new_cforce(1, torch.float64)
+    tq, tdq = bw.to_device(q0[None], dq0[None], dtype)
+    tcf = bw.new_cforce(1, dtype)
     for k in range(5):
         bw.step(tq, tdq, 0.001, 1, cforce=tcf)
         torch.cuda.synchronize()
-        assert np.abs(tcf.cpu().numpy()[0, 0, :3] - g["bs_force"][k]).max() < 1e-7
+        assert np.abs(tcf.cpu().numpy()[0, 0, :3] - g["bs_force"][k]).max() < ftol
     assert np.abs(g["bs_force"][0] - g["bs_force_known"]).max() < 1e-7
-    assert rel(tq.cpu().numpy()[0], g["bs_q"][5]) < 1e-9
+    assert rel(tq.cpu().numpy()[0], g["bs_q"][5]) < qtol
+    # every step from the reference's own state, all five in one batch (float32: rounded inputs
+    # through the oracle, with the reference's force of the previous step as warm start)
+    cf0 = np.zeros((5, 1, 4)); cf0[1:, 0, :3] = g["bs_force"][:4]
+    q, dq, cf = gpu_step(bw, g["bs_q"][:5], g["bs_dq"][:5], 0.001, dtype, cforce=cf0)
+    if dtype == torch.float64:
+        rq, rdq = g["bs_q"][1:6], g["bs_dq"][1:6]
+    else:
+        f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        rq, rdq, _ = O.step(m, f(g["bs_q"][:5]), f(g["bs_dq"][:5]), 0.001, cforce=f(cf0))
+    assert rel(q, rq) < (1e-9 if dtype == torch.float64 else F32_TOL)
+    assert rel(dq, rdq) < (1e-9 if dtype == torch.float64 else F32_TOL)
+    assert np.abs(cf[:, 0, :3] - g["bs_force"][:5]).max() < ftol
 
 
 @pytest.mark.parametrize("tag", ["max", "min"])
-def test_joint_limits(bw_cache, tag):
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-5)])
+def test_joint_limits(bw_cache, tag, dtype, tol):
+    """JointLimits (constraints.py:35-90) on the simplearm shoulder, 99 steps against the reference's
+    trajectory (float32: error accumulated over the rollout), then every step from the reference's own
+    state in one batch at the single-step tolerance."""
     g = load_golden("g6_constraints.npz")
     bw, m, q0, dq0 = bw_cache("jointlimits_%s" % tag)
-    tq, tdq = bw.to_device(q0[None], dq0[None], torch.float64)
-    tcf = bw.new_cforce(1, torch.float64)
+    tq, tdq = bw.to_device(q0[None], dq0[None], dtype)
+    tcf = bw.new_cforce(1, dtype)
     for k in range(99):
-        assert rel(tq.cpu().numpy()[0], g["jl_%s_q" % tag][k]) < 1e-8
+        assert rel(tq.cpu().numpy()[0], g["jl_%s_q" % tag][k]) < tol
         bw.step(tq, tdq, 1e-3, 1, cforce=tcf)
     torch.cuda.synchronize()
-    assert abs(tq.cpu().numpy()[0, 0]) <= 3.14 / 2
+    assert abs(tq.cpu().numpy()[0, 0]) <= 3.14 / 2 + (0 if dtype == torch.float64 else 1e-6)
+    Q, DQ = g["jl_%s_q" % tag], g["jl_%s_dq" % tag]
+    q, dq, _ = gpu_step(bw, Q[:99], DQ[:99], 1e-3, dtype)
+    rq, rdq = ref_step(m, Q[:99], DQ[:99], 1e-3, dtype, Q[1:], DQ[1:])
+    assert rel(q, rq) < (1e-9 if dtype == torch.float64 else F32_TOL)
+    assert rel(dq, rdq) < (1e-9 if dtype == torch.float64 else F32_TOL)
+    # the limit is reached in this scenario: some step has the constraint pushing
+    tq, tdq = bw.to_device(Q[:99], DQ[:99], dtype)
+    r = bw.inspect(tq, tdq, 1e-3, ["c_active", "c_force"])
+    assert r["c_active"].any() and float(r["c_force"].abs().max()) > 0.
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, F32_TOL)])
+def test_txtytz_gantry(bw_cache, dtype, tol):
+    """TxTyTzJoint (joints.py:352-384) stepped on the device: a prismatic triple at the root and one below a
+    rotating arm, with a sphere/plane contact; single steps from random states and from every state of the
+    reference's rollout, world matrices in float64."""
+    g = load_golden("g11_txtytz.npz")
+    bw, m, _, _ = bw_cache("txtytz")
+    assert list(m.jtype) == [8, 1, 8, 7]
+    q, dq, _ = gpu_step(bw, g["q"], g["dq"], 5e-3, dtype)
+    rq, rdq = ref_step(m, g["q"], g["dq"], 5e-3, dtype, g["q_next"], g["dq_next"])
+    assert rel(q, rq) < tol
+    assert rel(dq, rdq) < tol
+    Q, DQ = g["roll_q"], g["roll_dq"]
+    q, dq, _ = gpu_step(bw, Q[:-1], DQ[:-1], 5e-3, dtype)
+    rq, rdq = ref_step(m, Q[:-1], DQ[:-1], 5e-3, dtype, Q[1:], DQ[1:])
+    assert rel(q, rq) < tol
+    assert rel(dq, rdq) < tol
+    if dtype == torch.float64:
+        tq, tdq = bw.to_device(g["q"], g["dq"], dtype)
+        r = bw.inspect(tq, tdq, 5e-3, ["M", "N", "c_active"])
+        assert rel(r["M"].cpu().numpy(), g["M"]) < F64_TOL
+        assert rel(r["N"].cpu().numpy(), g["N"]) < F64_TOL
+        assert r["c_active"].sum() >= 8
+        # the whole rollout in one launch
+        n = len(Q) - 1
+        q, dq, _ = gpu_step(bw, Q[:1], DQ[:1], 5e-3, dtype, nsteps=n)
+        assert rel(q[0], Q[n]) < 1e-8 and rel(dq[0], DQ[n]) < 1e-7
 
 
 def test_energy_drift_h5(bw_cache):

@@ -318,3 +318,19 @@ def test_body_viscosity():
     close(dyn["Bv"], g["B"], 1e-12)
     qn, dqn, _ = O.step(m, g["q"], g["dq"], 5e-3)
     close(qn, g["q_next"], 1e-9); close(dqn, g["dq_next"], 1e-9)
+
+
+# -- G11 TxTyTzJoint inside a tree (joints.py:352-384) ------------------------------
+def test_txtytz_gantry():
+    """A prismatic triple at the root and below rotating parents, with a sphere/plane contact."""
+    g = load_golden("g11_txtytz.npz")
+    m, _, _ = load_model("txtytz")
+    assert list(m.jtype) == [8, 1, 8, 7]
+    d = O.update_dynamic(m, g["q"], g["dq"])
+    close(d["M"], g["M"], 1e-12); close(d["N"], g["N"], 1e-12)
+    qn, dqn, _ = O.step(m, g["q"], g["dq"], 5e-3)
+    close(qn, g["q_next"], 1e-10); close(dqn, g["dq_next"], 1e-9)
+    Q, DQ = g["roll_q"], g["roll_dq"]
+    qn, dqn, _, dbg = O.step(m, Q[:-1], DQ[:-1], 5e-3, debug=True)
+    close(qn, Q[1:], 1e-12); close(dqn, DQ[1:], 1e-11)
+    assert np.array_equal(dbg["active"][:len(g["roll_active"])], g["roll_active"][:len(Q) - 1])

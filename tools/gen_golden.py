@@ -656,10 +656,96 @@ def gen_viscosity():
     save("g10_viscosity.npz", **out)
 
 
+# ---- G11: TxTyTzJoint on the device path (joints.py:352-384) ----
+def txtytz_world(W):
+    """A gantry: ground -TxTyTz-> cart -RzRyRx-> arm -TxTyTz-> slider -Rx-> tip (+ a ball under the
+    slider touching a ground plane), so that the prismatic joint occurs at the root and below rotating
+    parents.  `W` is a namespace of classes (the reference's or this package's)."""
+    Hg_ = W.Hg
+    w = W.World()
+    W.add_groundplane(w)
+    mm = W.massmatrix
+    cart = W.Body(name='cart', mass=mm.box((0.2, 0.1, 0.15), 2.0))
+    arm = W.Body(name='arm', mass=mm.transport(mm.box((0.05, 0.3, 0.05), 1.2), Hg_.transl(0., 0.3, 0.)))
+    slider = W.Body(name='slider', mass=mm.transport(mm.sphere(0.08, 0.7), Hg_.transl(0.02, -0.01, 0.03)))
+    tip = W.Body(name='tip', mass=mm.transport(mm.cylinder(0.2, 0.03, 0.3), Hg_.transl(0., 0., 0.1)))
+    f_cart = W.SubFrame(w.ground, Hg_.transl(0., 0.7, 0.), name='gantry base')
+    w.add_link(f_cart, W.TxTyTzJoint(gpos=[0.1, 0.2, -0.1], gvel=[0.3, -0.2, 0.1], name='gantry'), cart)
+    f_arm = W.SubFrame(cart, Hg_.transl(0.1, -0.1, 0.) @ Hg_.rotz(0.3), name='cart pivot')
+    w.add_link(f_arm, W.RzRyRxJoint(gpos=[0.2, -0.4, 0.3], gvel=[0.5, 0.4, -0.6], name='pivot'), arm)
+    f_sl = W.SubFrame(arm, Hg_.transl(0., -0.6, 0.) @ Hg_.rotx(0.2), name='arm end')
+    f_sl1 = W.SubFrame(slider, Hg_.transl(0.01, 0.02, 0.) @ Hg_.roty(-0.1), name='slider mount')
+    w.add_link(f_sl, W.TxTyTzJoint(gpos=[0.05, -0.02, 0.04], gvel=[-0.1, 0.2, 0.3], name='slide'), f_sl1)
+    w.add_link(W.SubFrame(slider, Hg_.transl(0., -0.1, 0.)), W.RxJoint(gpos=[0.7], gvel=[-1.0], name='wrist'), tip)
+    ball = W.SubFrame(slider, Hg_.transl(0., -0.12, 0.), name='slider ball frame')
+    w.register(W.Sphere(ball, 0.05, name='slider ball'))
+    w.register(W.WeightController())
+    for c in W.get_all_contacts(w, friction_coeff=0.5):
+        w.register(c)
+    w.init()
+    return w
+
+
+def gen_txtytz():
+    W = _ref_namespace()
+    W.TxTyTzJoint, W.RzRyRxJoint, W.RxJoint = RJ.TxTyTzJoint, RJ.RzRyRxJoint, RJ.RxJoint
+    w = txtytz_world(W)
+    m = save_model("txtytz", w)
+    assert 8 in list(m.jtype), m.jtype
+    cons = list(w._constraints)
+    out = {}
+    dt = 5e-3
+    # (a) rollout from the scene's own state: the ball reaches the floor, then contact
+    qs, dqs, act, frc = [], [], [], []
+    # (a sliding solve whose 6x6 matrix has complex eigenvalues makes the reference raise under NumPy 2 --
+    # constraints.py:833 casts a complex-typed `s` with zero imaginary part into a float array, which
+    # 2010-era NumPy allowed; the rollout stops there and such random states are skipped)
+    for step in range(80):
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        w.update_dynamic(); w.update_controllers(dt)
+        try:
+            w.update_constraints(dt)
+        except TypeError as e:
+            print("  txtytz: rollout stops at step %d (%s)" % (step, type(e).__name__))
+            qs.pop(); dqs.pop()
+            break
+        act.append([bool(c.is_active()) for c in cons]); frc.append([c._force.copy() for c in cons])
+        w.integrate(dt)
+    else:
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+    out["roll_q"], out["roll_dq"] = np.array(qs), np.array(dqs)
+    out["roll_active"], out["roll_force"] = np.array(act), np.array(frc)
+    print("  txtytz: contacts %d, active steps %d, max |f| %.2f" % (len(cons), int(np.array(act).any(1).sum()), np.abs(np.array(frc)).max()))
+    # (b) random states, single steps + world matrices
+    B = 24
+    q, dq = synth.random_states(m, B, seed=11, angle=0.8, vel=2.0)
+    qn, dqn, Ms, Ns = [], [], [], []
+    nact = 0
+    keep = np.ones(B, bool)
+    for i in range(B):
+        set_state(w, m, q[i], dq[i])
+        w.update_dynamic()
+        Ms.append(w.mass.copy()); Ns.append(w.nleffects.copy())
+        try:
+            w.update_controllers(dt); w.update_constraints(dt); w.integrate(dt)
+        except TypeError:
+            Ms.pop(); Ns.pop(); keep[i] = False
+            continue
+        nact += int(cons[0].is_active())
+        a, b = get_state(w, m)
+        qn.append(a); dqn.append(b)
+    print("  txtytz: random states with an active contact: %d of %d" % (nact, B))
+    q, dq = q[keep], dq[keep]
+    out.update(q=q, dq=dq, q_next=np.array(qn), dq_next=np.array(dqn), M=np.array(Ms), N=np.array(Ns))
+    save("g11_txtytz.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz)
     for k in which:
         table[k]()
