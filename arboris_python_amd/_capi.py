@@ -14,13 +14,14 @@ LIB_PATH = os.path.join(_HERE, "libarbstep.so")
 if os.environ.get("ARBSTEP_LIB"):                 # development: load a differently built library
     LIB_PATH = os.environ["ARBSTEP_LIB"]
 
-ARB_ABI_VERSION = 3
+ARB_ABI_VERSION = 4
 ARB_OK = 0
 ARB_F32, ARB_F64 = 0, 1
 ARB_MAXDOL = 4
 ARB_STEP_SKIP_CONSTRAINTS = 1
 ARB_STEP_FUSED = 2
 ARB_STEP_SPLIT = 4
+ARB_STEP_SPLIT_WAVE = 8
 
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)
@@ -50,7 +51,7 @@ class ModelInfo(C.Structure):
 
 
 INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
-                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps"]
+                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps", "gs_trace"]
 
 
 class RolloutLog(C.Structure):
@@ -61,7 +62,7 @@ class StepArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("dq", C.c_void_p), ("cforce", C.c_void_p), ("ext_gforce", C.c_void_p),
                 ("pd_qdes", C.c_void_p), ("pd_dqdes", C.c_void_p), ("pd_kp", C.c_void_p), ("pd_kd", C.c_void_p),
                 ("nworlds", C.c_int64), ("dt", C.c_double), ("nsteps", C.c_int32), ("flags", C.c_uint32),
-                ("log", C.POINTER(RolloutLog))]
+                ("log", C.POINTER(RolloutLog)), ("dt_steps", C.c_void_p)]
 
 
 class InspectOut(C.Structure):

@@ -89,10 +89,25 @@ class BatchedWorlds(object):
         torch = _torch()
         return torch.zeros((B, self.model.nc, _capi.ARB_MAXDOL), dtype=dtype, device=self.device)
 
+    def _dt_steps(self, dt, nsteps):
+        """A scalar ``dt`` -> None; a sequence / array / tensor of ``nsteps`` step lengths (a non-uniform
+        timeline, core.py:1357) -> float64 device tensor for ``arb_step_args.dt_steps``."""
+        torch = _torch()
+        if isinstance(dt, (int, float)):
+            return None
+        t = torch.as_tensor(np.asarray(dt.detach().cpu() if hasattr(dt, "detach") else dt, dtype=np.float64))
+        if t.ndim != 1 or t.shape[0] != int(nsteps):
+            raise ValueError("dt must be a scalar or a sequence of nsteps = %d step lengths" % int(nsteps))
+        if not bool((t > 0).all()):
+            raise ValueError("every dt must be positive")
+        return t.to(self.device).contiguous()
+
     # -- the step --------------------------------------------------------------
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
              stream=None, fused=False, split=False, pd_targets=None, pd_gains=None):
-        """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).
+        """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
+        step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
+        core.py:1357): the whole non-uniform timeline then runs inside one launch.
 
         ``split=True`` runs the Gauss-Seidel sweeps in a second kernel with one lane per world
         (ARB_STEP_SPLIT: faster from ~16k worlds with <= 4 constraints, same results to rounding; opt-in,
@@ -107,9 +122,12 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
             flags |= _capi.ARB_STEP_FUSED
-        if split:
+        if split == "wave":
+            flags |= _capi.ARB_STEP_SPLIT_WAVE
+        elif split:
             flags |= _capi.ARB_STEP_SPLIT
-        if pd_targets is None and pd_gains is None:
+        dts = self._dt_steps(dt, nsteps)
+        if pd_targets is None and pd_gains is None and dts is None:
             _capi.check(self._lib.arb_step(
                 self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
                 None if cforce is None else cforce.data_ptr(),
@@ -128,7 +146,11 @@ class BatchedWorlds(object):
                         or t.device != self.device:
                     raise ValueError("%s must be a contiguous (B, ndof) %s tensor on %s" % (name, q.dtype, self.device))
                 setattr(a, name, t.data_ptr())
-        a.nworlds, a.dt, a.nsteps, a.flags = B, float(dt), int(nsteps), flags
+        a.nworlds, a.nsteps, a.flags = B, int(nsteps), flags
+        if dts is None:
+            a.dt = float(dt)
+        else:
+            a.dt, a.dt_steps = 0., dts.data_ptr()
         _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
 
     def rollout(self, q, dq, dt, nsteps, cforce=None, ext_gforce=None, log_state=True, log_energy=True,
@@ -143,7 +165,9 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
             flags |= _capi.ARB_STEP_FUSED
-        if split:
+        if split == "wave":
+            flags |= _capi.ARB_STEP_SPLIT_WAVE
+        elif split:
             flags |= _capi.ARB_STEP_SPLIT
         out = {}
         log = _capi.RolloutLog()
@@ -154,11 +178,21 @@ class BatchedWorlds(object):
         if log_energy:
             out["energy"] = torch.empty((nsteps, B, 2), dtype=q.dtype, device=self.device)
             log.energy_log = out["energy"].data_ptr()
-        _capi.check(self._lib.arb_rollout(
-            self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
-            None if cforce is None else cforce.data_ptr(),
-            None if ext_gforce is None else ext_gforce.data_ptr(),
-            B, float(dt), int(nsteps), flags, C.byref(log), C.c_void_p(st.cuda_stream)))
+        dts = self._dt_steps(dt, nsteps)
+        if dts is None:
+            _capi.check(self._lib.arb_rollout(
+                self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
+                None if cforce is None else cforce.data_ptr(),
+                None if ext_gforce is None else ext_gforce.data_ptr(),
+                B, float(dt), int(nsteps), flags, C.byref(log), C.c_void_p(st.cuda_stream)))
+            return out
+        a = _capi.StepArgs()
+        a.q, a.dq = q.data_ptr(), dq.data_ptr()
+        a.cforce = None if cforce is None else cforce.data_ptr()
+        a.ext_gforce = None if ext_gforce is None else ext_gforce.data_ptr()
+        a.nworlds, a.nsteps, a.flags, a.dt, a.dt_steps = B, int(nsteps), flags, 0., dts.data_ptr()
+        a.log = C.pointer(log)
+        _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
         return out
 
     def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False):
@@ -172,15 +206,18 @@ class BatchedWorlds(object):
                       M=(B, n, n), B=(B, n, n), N=(B, n, n), Z=(B, n, n), gforce0=(B, n),
                       vel_free=(B, n), c_sdist=(B, nc), c_active=(B, nc), c_jac=(B, nc, 4, n),
                       c_force=(B, nc, 4), c_frame=(B, nc, 2, 4, 4), gforce=(B, n),
-                      q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 5), stamps=(B, 8), energy=(B, 2))
+                      q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 5), stamps=(B, 8), energy=(B, 2),
+                      gs_trace=(B, 20, nc))
         want = list(want)
         if "gforce" in want and nc and "c_jac" not in want:
             want.append("c_jac")
         out = _capi.InspectOut()
         res = {}
         for name in want:
-            dt_ = torch.int32 if name in ("c_active", "gs_stats") else (torch.int64 if name == "stamps" else q.dtype)
+            dt_ = torch.int32 if name in ("c_active", "gs_stats", "gs_trace") else (torch.int64 if name == "stamps" else q.dtype)
             t = torch.zeros(shapes[name], dtype=dt_, device=self.device)
+            if name == "gs_trace":
+                t.fill_(-1)                       # solves that are not executed leave their entry alone
             res[name] = t
             setattr(out, name, t.data_ptr())
         st = torch.cuda.current_stream(self.device)

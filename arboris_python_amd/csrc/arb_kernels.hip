@@ -84,26 +84,35 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
 __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_int(a) == __float_as_int(b); }
 __device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
 
+// The batch-shared model as ONE device-resident struct with fixed-capacity tables (a world has at most
+// 64 bodies / dofs / constraints: one wavefront): every table is reached from the single base pointer with a
+// compile-time offset, so the kernels hold one pointer pair in SGPRs instead of ~45 (round 1 spilled 284
+// SGPRs to VGPR lanes, most of them table pointers).
+#define ARB_CAP 64
 template <typename T>
 struct DevModel {
     int nb, n, nq, nc, ndol, ncols, maxdepth;
     int has_visc, has_pd, has_warm, has_grav;
-    const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *weighted;
-    const int *dof2q;
-    // composite phase B: body of every dof, bodies in the subtree of a body (DFS preorder: the subtree of b
-    // is b .. b + subsize[b] - 1), and per dof the dofs of ancestor-or-own / strictly descendant bodies
-    const int *dofbody, *subsize;
-    const unsigned long long *upmask, *descmask;
-    const unsigned long long *anc;            // [nb] dofs of the body's joint and of its ancestors'
-    const T *Hpr, *Hcn, *mass, *visc;         // [nb][12], [nb][12], [nb][36], [nb][36]
-    const double *Hpr_d, *Hcn_d;              // float64 copies for the pose chain
-    const double *clocal_d, *cradius_d, *cradius0_d, *chalf_d, *cplane_d, *cRz_d, *cb0_d, *cb1_d;
-    const double *com_d;                      // [nb][4] centre of mass in the body frame, mass (EnergyMonitor)
     double up[3];
     T grav[3];
-    const T *pd_kp, *pd_kd, *pd_tau0;
-    const int *ctype, *cen, *cbody, *cbody0, *cdof, *cgeom;
-    const T *cmu, *cprox, *ceps, *cmin, *cmax, *cb0, *cb1;
+    const T *pd_kp, *pd_kd, *pd_tau0;         // [n][n], [n][n], [n] (merged PD controllers; rarely present)
+    int parent[ARB_CAP], jtype[ARB_CAP], dof_off[ARB_CAP], jnd[ARB_CAP], q_off[ARB_CAP], depth[ARB_CAP], weighted[ARB_CAP];
+    int dof2q[ARB_CAP];
+    // composite phase B: body of every dof, bodies in the subtree of a body (DFS preorder: the subtree of b
+    // is b .. b + subsize[b] - 1), and per dof the dofs of ancestor-or-own / strictly descendant bodies
+    int dofbody[ARB_CAP], subsize[ARB_CAP];
+    unsigned long long upmask[ARB_CAP], descmask[ARB_CAP];
+    unsigned long long anc[ARB_CAP];          // [nb] dofs of the body's joint and of its ancestors'
+    int ctype[ARB_CAP], cen[ARB_CAP], cbody[ARB_CAP], cbody0[ARB_CAP], cdof[ARB_CAP], cgeom[ARB_CAP];
+    T Hpr[ARB_CAP * 12], Hcn[ARB_CAP * 12], mass[ARB_CAP * 36], visc[ARB_CAP * 36];
+    double Hpr_d[ARB_CAP * 12], Hcn_d[ARB_CAP * 12];          // float64 copies for the pose chain
+    double clocal_d[ARB_CAP * 3], cradius_d[ARB_CAP], cradius0_d[ARB_CAP], chalf_d[ARB_CAP * 3], cplane_d[ARB_CAP * 4],
+           cRz_d[ARB_CAP * 9], cb0_d[ARB_CAP * 12], cb1_d[ARB_CAP * 12];
+    double com_d[ARB_CAP * 4];                // [nb][4] centre of mass in the body frame, mass (EnergyMonitor)
+    T cmu[ARB_CAP], ceps[ARB_CAP * 3];
+    // thresholds compared against positions stay in float64: a float32-rounded joint limit moves by ~1e-7 rad,
+    // which the limit solve divides by dt (JointLimits.solve, constraints.py:73-90)
+    double cprox_d[ARB_CAP], cmin_d[ARB_CAP], cmax_d[ARB_CAP];
 };
 
 // Split execution (contact models, large batches): the step kernel stops after the
@@ -140,7 +149,9 @@ struct DebugOut {
     T *energy;          // [nw][2] kinetic, potential energy (EnergyMonitor, observers.py:40-51)
     long long *stamps;  // [nw][8] s_memtime at the phase boundaries (diagnostic)
     int ablate;         // diagnostic (env ARB_ABLATE, inspect only): bit 3 (8) = run all 20 Gauss-Seidel sweeps, no fixed-point exit
-    int *gs_stats;      // [nw][4]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts
+    int *gs_stats;      // [nw][5]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts, sweeps
+    int *gs_trace;      // [nw][GS_SWEEPS][nc]: decision of every solve (0 release, 1 static, 2 sliding fast shift,
+                        // 3 sliding eig6, 4 other constraint types); entries of solves not executed are left alone
 };
 
 // ---------------------------------------------------------------------------
@@ -235,15 +246,277 @@ extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
                          asm volatile("" ::: "memory"); } while (0)
 
 // ===========================================================================
+// The Gauss-Seidel stage of World.update_constraints (core.py:929-935) for ONE world held by ONE wavefront:
+// shared by the fused step kernel and by the wave-per-world sweep kernel of the split execution.
+// In LDS: AM = Y' (ndol x ndol), CD = per-constraint block (active, sdist, pos0 in; inverse block out),
+// VV = v' (in/out), FF = constraint forces (in: warm start, out), WORK = 64 elements of scratch.
+// ===========================================================================
+template <typename T, int MODE>
+__device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt,
+                                         const T inv_dt, const T *AM, T *CD, T *VV, T *FF, T *WORK,
+                                         const DebugOut<T> &dbg, const long w) {
+    // inverse of every active constraint's own admittance block (once per step)
+    if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
+        const int c = lane, ct = mp->ctype[c];
+        const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+        T P[16];
+        inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+    }
+    WAVE_SYNC();
+    // ---- Gauss-Seidel, core.py:929-935, register resident ----------------------
+    // lane = row of the stacked constraint system: it keeps its velocity, its force,
+    // its row of the constraint's own admittance block Y_cc and of inv(Y_cc), and the
+    // per-step constants of its constraint.  The four rows of a constraint are one QUAD
+    // of lanes: the local solve of a SoftFingerContact runs inside that quad on DPP
+    // quad_perm operands (vector registers only, branches follow the quad through
+    // ballots); v_readlane broadcasts through SGPRs are left for what every row needs,
+    // the four force increments.  Lane c also keeps the flags of constraint c.  The 20 x nc
+    // sequential solves touch LDS only to read their column block of Y' (read-only).
+    T vr = T(0), fr = T(0), Yrow[4], Prow[4];
+    T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
+    bool k_eps1 = false;
+    int k_ct = 0;
+    bool k_act = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Yrow[i] = T(0); Prow[i] = T(0); }
+    // the constants of a row's own constraint, replicated on the four lanes of its quad
+    T q_sd = T(0), q_sdt = T(0), q_mu = T(0);
+    T q_iyn = T(0), q_muyn = T(0), q_yc0 = T(0), q_yc1 = T(0), q_yc2 = T(0), q_bsq = T(0);
+    SlidePre q_sp = {0., 0., 0., 0., 0., 0.};
+    double q_warm = NAN;                    // root found for this constraint in the previous sweep
+    if (lane < ndol) {
+        const int cc = lane >> 2, rr = lane & 3;
+        vr = VV[lane]; fr = FF[lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Yrow[i] = AM[lane * ndol + 4 * cc + i];
+            Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
+        }
+        q_sd = CD[cc * CD_STRIDE + CD_SDIST]; q_sdt = q_sd / dt; q_mu = mp->cmu[cc];
+        if (CD[cc * CD_STRIDE + CD_ACTIVE] != T(0) && mp->ctype[cc] == ARB_CT_SOFTFINGER) {
+            // admittance-only part of the sliding-branch polynomial and the other per-step constants of
+            // SoftFingerContact.solve (constraints.py:795, 808-812), once per step
+            T Yc4[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * ndol + 4 * cc + j];
+            q_sp = slide_precompute<T>(Yc4);
+            q_iyn = T(1) / Yc4[15]; q_muyn = q_mu / Yc4[15];
+            q_yc0 = Yc4[3]; q_yc1 = Yc4[7]; q_yc2 = Yc4[11];
+            const T bq0 = q_muyn * q_yc0, bq1 = q_muyn * q_yc1, bq2 = q_muyn * q_yc2;
+            q_bsq = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
+        }
+    }
+    if (lane < nc) {
+        const T *cd = CD + lane * CD_STRIDE;
+        k_act = cd[CD_ACTIVE] != T(0);
+        k_sd = cd[CD_SDIST]; k_p0 = cd[CD_POS0]; k_p1 = cd[CD_POS0 + 1]; k_p2 = cd[CD_POS0 + 2];
+        k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
+        k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
+        k_eps1 = k_act && k_ct == ARB_CT_SOFTFINGER && (k_e0 == T(1)) && (k_e1 == T(1)) && (k_e2 == T(1));
+    }
+    const unsigned long long actmask = __ballot(k_act);
+    const unsigned long long eps1mask = __ballot(k_eps1);
+    int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
+    int tr_rel = 0, tr_sta = 0, tr_slow = 0;
+    T vr_prev = vr, fr_prev = fr;
+#if ARB_GS_PRIO
+    // the sweeps are one long dependent chain: let this wave issue ahead of the SIMD's other wave,
+    // whose bulk phases have independent instructions to fill the gaps
+    __builtin_amdgcn_s_setprio(ARB_GS_PRIO);
+#endif
+    for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+        if (MODE == 1) ++st_sweeps;
+        for (int c = 0; c < nc; ++c) {
+            if (!((actmask >> c) & 1ull)) continue;
+            const int base = 4 * c;
+            // column block Y'[:, 4c..4c+3] of this lane's row (issued early, used last)
+            T a4[4] = {T(0), T(0), T(0), T(0)};
+            if (lane < ndol) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a4[i] = AM[lane * ndol + base + i];
+            }
+            const int ct = __builtin_amdgcn_readlane(k_ct, c);
+            T vc[4], fc[4], df[4], fnew[4];
+            // A constraint's four rows are one quad of lanes: what its local solve needs from its own
+            // rows comes as DPP quad_perm operands (every quad evaluates ITS constraint; only the quad of
+            // c is used).  Values go through SGPRs (v_readlane) only where the whole wave needs them.
+            const T fq0 = quad_bcast<0>(fr), fq1 = quad_bcast<1>(fr), fq2 = quad_bcast<2>(fr), fq3 = quad_bcast<3>(fr);
+            // own-row products (meaningful on lanes base..base+3)
+            const T v0r = vr - (Yrow[0] * fq0 + Yrow[1] * fq1 + Yrow[2] * fq2 + Yrow[3] * fq3);
+            bool quad_done = false;      // softfinger release / static: per-lane results, see below
+            T dfl = T(0), fnl = T(0);
+            if (ct != ARB_CT_SOFTFINGER) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { vc[i] = bcast(vr, base + i); fc[i] = bcast(fr, base + i); }
+            }
+            if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
+                // The release test and the static-friction candidate are evaluated side by side
+                // (two independent dependent chains that overlap in the pipeline), inside the quad.
+                const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
+                const T vq0 = quad_bcast<0>(vr), vq1 = quad_bcast<1>(vr), vq2 = quad_bcast<2>(vr), vq3 = quad_bcast<3>(vr);
+                const T dfr = -(Prow[0] * vq0 + Prow[1] * vq1 + Prow[2] * vq2 + Prow[3] * (vq3 + q_sdt));
+                const T fnr = fr + dfr;
+                const T v0n = quad_bcast<3>(v0r);
+                const T fn0 = quad_bcast<0>(fnr), fn1 = quad_bcast<1>(fnr), fn2 = quad_bcast<2>(fnr), fn3 = quad_bcast<3>(fnr);
+                T eps[3] = {T(1), T(1), T(1)};
+                T lhs;
+                if (eps1) {
+                    lhs = fn0 * fn0 + fn1 * fn1 + fn2 * fn2;
+                } else {
+                    eps[0] = bcast(k_e0, c); eps[1] = bcast(k_e1, c); eps[2] = bcast(k_e2, c);
+                    lhs = (fn0 / eps[0]) * (fn0 / eps[0]) + (fn1 / eps[1]) * (fn1 / eps[1])
+                        + (fn2 / eps[2]) * (fn2 / eps[2]);
+                }
+                const T rhs = (fn3 * q_mu) * (fn3 * q_mu);
+                // the quad of c decides for the wave
+                const bool release = (__ballot(q_sd + dt * v0n > T(0)) >> base) & 1ull;
+                const bool stat = (__ballot(lhs <= rhs) >> base) & 1ull;
+                if (release || stat) {
+                    // release (zero force) or static friction (df exactly -pinv(Y)(...) as in the
+                    // reference, row by row): one branch, the two outcomes by selection
+                    if (MODE == 1) { if (release) ++st_rel; else ++st_sta; }
+                    dfl = release ? -fr : dfr; fnl = release ? T(0) : fnr; quad_done = true;
+                } else {
+                    {                                              // sliding friction
+                        // Also inside the quad: the four lanes of constraint c carry the live problem in
+                        // vector registers (the other quads run along on their own, unused data) and every
+                        // branch follows the quad of c (`uni`), so nothing travels through SGPRs but the
+                        // final force increments.
+                        const int rq = lane - base;
+                        const bool inquad = rq >= 0 && rq < 4;
+                        const auto uni = [&](bool b) { return (bool)((__ballot(b) >> base) & 1ull); };
+                        T alpha[4], shift = T(0);
+                        alpha[0] = quad_bcast<0>(v0r); alpha[1] = quad_bcast<1>(v0r); alpha[2] = quad_bcast<2>(v0r);
+                        alpha[3] = v0n + q_sdt;
+                        // the constraint's own 4x4 admittance block (wave-uniform LDS reads)
+                        T Y[16];
+                        {
+                            typedef T Y4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const Y4 y4 = *reinterpret_cast<const Y4 *>(AM + (base + r) * ndol + base);
+                                Y[4 * r] = y4.x; Y[4 * r + 1] = y4.y; Y[4 * r + 2] = y4.z; Y[4 * r + 3] = y4.w;
+                            }
+                        }
+                        if (MODE == 1) ++st_fast;
+                        double warm = q_warm;
+                        bool have = false;
+                        if (eps1) {
+                            const T yc[3] = {q_yc0, q_yc1, q_yc2};
+                            const T bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
+                            double c1, kappa, root;
+                            slide_c1_kappa<T>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
+                            if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni)) {
+                                warm = root;
+                                // leftmost real eigenvalue; admissible when <= 0 (constraints.py:826-830)
+                                shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
+                                have = true;
+                            }
+                        }
+                        if (!have) {
+                            if (MODE == 1) { ++st_slow; --st_fast; }
+                            // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
+                            if (inquad) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
+                            WAVE_SYNC();
+                            if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
+                            WAVE_SYNC();
+                            shift = WORK[40];
+                            WAVE_SYNC();
+                            warm = NAN;
+                        }
+                        if (inquad) q_warm = warm;          // next sweep restarts next to this root
+                        fnew[0] = fq0; fnew[1] = fq1; fnew[2] = fq2; fnew[3] = fq3;
+                        T sie2[3] = {shift, shift, shift};
+                        if (!eps1) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) sie2[i] = shift / (eps[i] * eps[i]);
+                        }
+                        softfinger_slide_finish_scaled<T>(Y, alpha, sie2, fnew, df);
+                        dfl = (rq == 0) ? df[0] : (rq == 1) ? df[1] : (rq == 2) ? df[2] : df[3];
+                        fnl = (rq == 0) ? fnew[0] : (rq == 1) ? fnew[1] : (rq == 2) ? fnew[2] : fnew[3];
+                        quad_done = true;
+                    }
+                }
+            } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
+                const T p0 = bcast(k_p0, c), p1 = bcast(k_p1, c), p2 = bcast(k_p2, c);
+                const T dfr = -(Prow[0] * (vc[0] + p0 * inv_dt) + Prow[1] * (vc[1] + p1 * inv_dt)
+                                + Prow[2] * (vc[2] + p2 * inv_dt));
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { df[i] = bcast(dfr, base + i); fnew[i] = fc[i] + df[i]; }
+                df[3] = T(0); fnew[3] = fc[3];
+            } else {                                               // JointLimits.solve constraints.py:73-90
+                // pred = pos0 + dt v0 <= min  <=>  v0 <= (min - pos0)/dt =: glo, and (min - pred)/dt = glo - v0
+                const T glo = bcast(k_p1, c), ghi = bcast(k_p2, c);
+                const T p00 = bcast(Prow[0], base);
+                const T v00 = bcast(v0r, base);
+                T nf = T(0);
+                if (v00 <= glo) nf = p00 * (glo - v00);
+                else if (ghi <= v00) nf = p00 * (ghi - v00);
+                df[0] = nf - fc[0]; fnew[0] = nf;
+#pragma unroll
+                for (int i = 1; i < 4; ++i) { df[i] = T(0); fnew[i] = fc[i]; }
+            }
+            if (MODE == 1 && dbg.gs_trace != nullptr && lane == 0) {
+                int code = 4;
+                if (ct == ARB_CT_SOFTFINGER) code = (st_rel != tr_rel) ? 0 : (st_sta != tr_sta) ? 1 : (st_slow != tr_slow) ? 3 : 2;
+                dbg.gs_trace[((long)w * GS_SWEEPS + sweep) * nc + c] = code;
+                tr_rel = st_rel; tr_sta = st_sta; tr_slow = st_slow;
+            }
+            const int rr = lane - base;
+            if (quad_done) {
+                // release / static: the quad holds the new forces and the force increments row by row
+#pragma unroll
+                for (int i = 0; i < 4; ++i) df[i] = bcast(dfl, base + i);
+                fr = (rr >= 0 && rr < 4) ? fnl : fr;
+            } else {
+                fr = (rr == 0) ? fnew[0] : (rr == 1) ? fnew[1] : (rr == 2) ? fnew[2] : (rr == 3) ? fnew[3] : fr;
+            }
+            // vel += Y'[:, c] dforce                               core.py:935
+            vr += a4[0] * df[0] + a4[1] * df[1] + a4[2] * df[2] + a4[3] * df[3];
+        }
+        // A sweep that leaves every velocity and force bit-for-bit unchanged is a fixed point
+        // of the iteration: the remaining sweeps of core.py:929-935 would repeat it exactly.
+        if (__all(same_bits(vr, vr_prev) && same_bits(fr, fr_prev)) && !(MODE == 1 && (dbg.ablate & 8))) break;
+        vr_prev = vr; fr_prev = fr;
+    }
+#if ARB_GS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if (MODE == 1 && dbg.gs_stats != nullptr && lane == 0) {
+        int *o = dbg.gs_stats + w * 5;
+        o[0] = st_rel; o[1] = st_sta; o[2] = st_fast; o[3] = st_slow; o[4] = st_sweeps;
+    }
+    WAVE_SYNC();
+    if (lane < ndol) { FF[lane] = fr; VV[lane] = vr; }
+    WAVE_SYNC();
+}
+
+// ===========================================================================
 // The step kernel.  MODE 0 = production, 1 = inspect (debug stores, no state
 // write-back).  zmode (inspect only): 0 full Z, 1 M only, 2 B only, 3 N only.
 // ===========================================================================
-template <typename T, int NMAX, int NSETS, int MODE>
+// FEAT 0 = the plain step (arb_step without user torques: no per-world PD inputs, no per-step logs, no split
+// execution) -- those arguments are compiled out, which keeps their kernargs and the predicates derived from them
+// out of the SGPR file; FEAT 1 = every input honoured.
+template <typename T, int NMAX, int NSETS, int MODE, int FEAT>
 __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
-    T *__restrict__ gcforce, const T *__restrict__ gext, const PerWorldPD<T> pwd, long nworlds, T dt, int nsteps,
-    unsigned flags, const DebugOut<T> dbg, int zmode, const LogOut<T> logo, const SplitIO<T> sio)
+    T *__restrict__ gcforce, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
+    unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
+    const double *__restrict__ dts_in)
 {
+    static_assert(MODE == 0 || FEAT == 1, "the inspect kernels take every input");
+    const T *__restrict__ gext = FEAT ? gext_in : nullptr;
+    const PerWorldPD<T> pwd = FEAT ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
+    const LogOut<T> logo = FEAT ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
+    const SplitIO<T> sio = FEAT ? sio_in : SplitIO<T>{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const unsigned flags = FEAT ? flags_in : 0u;
+    // per-step dt (core.py:1357: dt = next_time - current_time), or null = dt_in for every step
+    const double *__restrict__ dts = FEAT ? dts_in : nullptr;
     const DevModel<T> *mp = mp_in;     // device-resident model, fields fetched with scalar loads
     const int lane0 = threadIdx.x;
     int lane = lane0;
@@ -254,9 +527,17 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     double *PD = reinterpret_cast<double *>(lds + L.pd);
     T *CD = lds + L.cd, *RT = lds + L.rt;
     T *AM = lds + L.am, *VV = lds + L.vv, *FF = lds + L.ff, *FF0 = lds + L.ff0, *WORK = lds + L.work;
-    const int n = mp->n, nb = mp->nb, nq = mp->nq, nc = mp->nc, ndol = mp->ndol;
+    // (the sizes are re-laundered at every phase boundary, ARB_OPAQUE_LANE: left to itself the compiler hoists
+    // the ~90 wave-uniform predicates `i < n` of the unrolled row loops out of the step loop as 64-bit lane masks
+    // and then spills them -- 284 SGPR spills in round 1)
+    const int n0 = mp->n, nb0 = mp->nb, nc0 = mp->nc, ndol0 = mp->ndol;
+    int n = n0, nb = nb0, nc = nc0, ndol = ndol0;
+    const int nq = mp->nq;
+    // the host picks the smallest register tile that holds ndof (kNmaxChoices): rows below the previous tile
+    // size always exist, which folds their `i < n` predicates away
+    constexpr int NLOW = NMAX == 16 ? 0 : NMAX == 32 ? 16 : NMAX == 44 ? 32 : NMAX == 48 ? 44 : 48;
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
-    const T inv_dt = T(1) / dt;
+    T dt = dt_in, inv_dt = T(1) / dt_in;
     const bool do_constraints = (nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
 
     // ---- load state (coalesced, world-major) -----------------------------
@@ -284,7 +565,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #ifndef ARB_CSTAMP
 #define ARB_CSTAMP(k) do { } while (0)
 #endif
-#define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); } while (0)
+#define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); \
+                              n = n0; nb = nb0; nc = nc0; ndol = ndol0;                                             \
+                              asm volatile("" : "+s"(n), "+s"(nb), "+s"(nc), "+s"(ndol)); } while (0)
 
     // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
     // columns in RT, then every joint integrates its position.
@@ -326,6 +609,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         for (int i = lane; i < ncol_s * n; i += WAVE) RT[(i / n) * RS + (i % n)] = sio.sol[(long)w * ncol_s * n + i];
         for (int i = lane; i < ndol; i += WAVE) { FF[i] = sio.f[w * ndol + i]; FF0[i] = sio.f0[w * ndol + i]; }
         WAVE_SYNC();
+        if (FEAT && dts != nullptr) { dt = (T)dts[-1]; inv_dt = T(1) / dt; }      // the step being finished
         integrate_from_rt(true);
     }
     if (MODE == 0 && sio.mode != 0 && !(sio.mode & 2)) nsteps = 0;      // apply only
@@ -334,6 +618,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
+        if (FEAT && dts != nullptr) { dt = (T)dts[step]; inv_dt = T(1) / dt; }
         if (MODE == 0) {            // trajectory log: what an Observer sees at time t (core.py:1361-1362)
             if (logo.q != nullptr) for (int i = lane; i < nq; i += WAVE) logo.q[((long)step * nworlds + w) * nq + i] = qs[i];
             if (logo.dq != nullptr && lane < n) logo.dq[((long)step * nworlds + w) * n + lane] = dqs[lane];
@@ -599,7 +884,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     const T vz1 = (mv(R1, bv1) + cross(P1, mv(R1, bw1))).z;
                     const T vz0 = (mv(R0, bv0) + cross(P0, mv(R0, bw0))).z;
                     const T dsd = vz1 - vz0;
-                    active = ((double)sd_d + (double)dsd * (double)dt < (double)mp->cprox[c]);
+                    active = ((double)sd_d + (double)dsd * (double)dt < mp->cprox_d[c]);
                     {   // phase B works on world-axes columns about the root body's origin: store world -> contact frame 0
                         const V3<double> p0w = ld_v3(PD + 9);
                         st_m3(cd + CD_R1, cvt_m3<T>(transpose(Rc))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(Rc, gc0 - p0w)));
@@ -610,7 +895,11 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 } else if (ct == ARB_CT_JOINTLIMITS) {
                     const T p0 = qd[mp->cdof[c]];
                     cd[CD_POS0] = p0;
-                    active = (p0 - mp->cmin[c] < mp->cprox[c]) || (mp->cmax[c] - p0 < mp->cprox[c]);
+                    const double lo_d = mp->cmin_d[c], hi_d = mp->cmax_d[c], px_d = mp->cprox_d[c];
+                    active = ((double)p0 - lo_d < px_d) || (hi_d - (double)p0 < px_d);
+                    // per-step constants of the solve, formed in float64: (min - pos0)/dt, (max - pos0)/dt
+                    cd[CD_POS0 + 1] = (T)((lo_d - (double)p0) / (double)dt);
+                    cd[CD_POS0 + 2] = (T)((hi_d - (double)p0) / (double)dt);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:58-60
                     sd = p0;
@@ -908,7 +1197,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const int e_k = (lane < n) ? (mp->dof_off[bsrc] + mp->jnd[bsrc] - 1) : -1;
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i) {
+                    // (the wave-uniform branch per row also keeps the rows apart for the scheduler: as one
+                    // branch-free block the compiler hoists the LDS reads of all NMAX rows and spills ~1500 VGPRs)
                     if (i < n) {
+                        asm volatile("");          // not speculatable: a real scalar branch per row, no if-conversion into lane masks
                         const D2 *xi = reinterpret_cast<const D2 *>(STG + XPR_STRIDE * i);   // wave-uniform: broadcast reads
                         double tu = 0., td = 0.;
 #pragma unroll
@@ -1070,11 +1362,11 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 const V4 *src = reinterpret_cast<const V4 *>(RT + (have ? lane - n : 0) * RS);
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
-                    const V4 v = src[i4];
-                    Z[4 * i4] = (have && 4 * i4 < n) ? v.x : T(0);
-                    Z[4 * i4 + 1] = (have && 4 * i4 + 1 < n) ? v.y : T(0);
-                    Z[4 * i4 + 2] = (have && 4 * i4 + 2 < n) ? v.z : T(0);
-                    Z[4 * i4 + 3] = (have && 4 * i4 + 3 < n) ? v.w : T(0);
+                    const V4 v = src[i4];               // (entries >= ndof of a row of RT are zero: zeroed in A', never written)
+                    Z[4 * i4] = have ? v.x : T(0);
+                    Z[4 * i4 + 1] = have ? v.y : T(0);
+                    Z[4 * i4 + 2] = have ? v.z : T(0);
+                    Z[4 * i4 + 3] = have ? v.w : T(0);
                 }
             }
             if (NSETS == 2) {
@@ -1083,10 +1375,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     const V4 v = src[i4];
-                    Z2[4 * i4] = (have && 4 * i4 < n) ? v.x : T(0);
-                    Z2[4 * i4 + 1] = (have && 4 * i4 + 1 < n) ? v.y : T(0);
-                    Z2[4 * i4 + 2] = (have && 4 * i4 + 2 < n) ? v.z : T(0);
-                    Z2[4 * i4 + 3] = (have && 4 * i4 + 3 < n) ? v.w : T(0);
+                    Z2[4 * i4] = have ? v.x : T(0);
+                    Z2[4 * i4 + 1] = have ? v.y : T(0);
+                    Z2[4 * i4 + 2] = have ? v.z : T(0);
+                    Z2[4 * i4 + 3] = have ? v.w : T(0);
                 }
             }
         }
@@ -1187,15 +1479,15 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         // solution columns -> LDS (row r of RT := column r of [Y rhs | Y J'^T])
         WAVE_SYNC();
         {
-            // (whole rows of RS elements, vector stores; entries >= ndof are written as zero: "columns >= ndof stay zero")
+            // (whole rows of RS elements, vector stores; rows >= ndof of a column register tile are zero -- zero on
+            // entry, and an elimination step maps a zero row to 0 - 0 * t -- so "columns >= ndof stay zero" holds)
             typedef T V4 __attribute__((ext_vector_type(4)));
             if (lane >= n && lane < ncols) {
                 V4 *dst = reinterpret_cast<V4 *>(RT + (lane - n) * RS);
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     V4 v;
-                    v.x = (4 * i4 < n) ? Z[4 * i4] : T(0); v.y = (4 * i4 + 1 < n) ? Z[4 * i4 + 1] : T(0);
-                    v.z = (4 * i4 + 2 < n) ? Z[4 * i4 + 2] : T(0); v.w = (4 * i4 + 3 < n) ? Z[4 * i4 + 3] : T(0);
+                    v.x = Z[4 * i4]; v.y = Z[4 * i4 + 1]; v.z = Z[4 * i4 + 2]; v.w = Z[4 * i4 + 3];
                     dst[i4] = v;
                 }
             }
@@ -1204,8 +1496,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     V4 v;
-                    v.x = (4 * i4 < n) ? Z2[4 * i4] : T(0); v.y = (4 * i4 + 1 < n) ? Z2[4 * i4 + 1] : T(0);
-                    v.z = (4 * i4 + 2 < n) ? Z2[4 * i4 + 2] : T(0); v.w = (4 * i4 + 3 < n) ? Z2[4 * i4 + 3] : T(0);
+                    v.x = Z2[4 * i4]; v.y = Z2[4 * i4 + 1]; v.z = Z2[4 * i4 + 2]; v.w = Z2[4 * i4 + 3];
                     dst[i4] = v;
                 }
             }
@@ -1231,240 +1522,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         }
 
         if (do_constraints) {
-            // inverse of every active constraint's own admittance block (once per step)
-            if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
-                const int c = lane, ct = mp->ctype[c];
-                const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
-                T P[16];
-                inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
-            }
-            WAVE_SYNC();
             ARB_STAMP(5);
             ARB_CSTAMP(7);
-            // ---- Gauss-Seidel, core.py:929-935, register resident ----------------------
-            // lane = row of the stacked constraint system: it keeps its velocity, its force,
-            // its row of the constraint's own admittance block Y_cc and of inv(Y_cc), and the
-            // per-step constants of its constraint.  The four rows of a constraint are one QUAD
-            // of lanes: the local solve of a SoftFingerContact runs inside that quad on DPP
-            // quad_perm operands (vector registers only, branches follow the quad through
-            // ballots); v_readlane broadcasts through SGPRs are left for what every row needs,
-            // the four force increments.  Lane c also keeps the flags of constraint c.  The 20 x nc
-            // sequential solves touch LDS only to read their column block of Y' (read-only).
-            T vr = T(0), fr = T(0), Yrow[4], Prow[4];
-            T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
-            T k_min = T(0), k_max = T(0);
-            bool k_eps1 = false;
-            int k_ct = 0;
-            bool k_act = false;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { Yrow[i] = T(0); Prow[i] = T(0); }
-            // the constants of a row's own constraint, replicated on the four lanes of its quad
-            T q_sd = T(0), q_sdt = T(0), q_mu = T(0);
-            T q_iyn = T(0), q_muyn = T(0), q_yc0 = T(0), q_yc1 = T(0), q_yc2 = T(0), q_bsq = T(0);
-            SlidePre q_sp = {0., 0., 0., 0., 0., 0.};
-            double q_warm = NAN;                    // root found for this constraint in the previous sweep
-            if (lane < ndol) {
-                const int cc = lane >> 2, rr = lane & 3;
-                vr = VV[lane]; fr = FF[lane];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    Yrow[i] = AM[lane * ndol + 4 * cc + i];
-                    Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
-                }
-                q_sd = CD[cc * CD_STRIDE + CD_SDIST]; q_sdt = q_sd / dt; q_mu = mp->cmu[cc];
-                if (CD[cc * CD_STRIDE + CD_ACTIVE] != T(0) && mp->ctype[cc] == ARB_CT_SOFTFINGER) {
-                    // admittance-only part of the sliding-branch polynomial and the other per-step constants of
-                    // SoftFingerContact.solve (constraints.py:795, 808-812), once per step
-                    T Yc4[16];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * ndol + 4 * cc + j];
-                    q_sp = slide_precompute<T>(Yc4);
-                    q_iyn = T(1) / Yc4[15]; q_muyn = q_mu / Yc4[15];
-                    q_yc0 = Yc4[3]; q_yc1 = Yc4[7]; q_yc2 = Yc4[11];
-                    const T bq0 = q_muyn * q_yc0, bq1 = q_muyn * q_yc1, bq2 = q_muyn * q_yc2;
-                    q_bsq = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
-                }
-            }
-            if (lane < nc) {
-                const T *cd = CD + lane * CD_STRIDE;
-                k_act = cd[CD_ACTIVE] != T(0);
-                k_sd = cd[CD_SDIST]; k_p0 = cd[CD_POS0]; k_p1 = cd[CD_POS0 + 1]; k_p2 = cd[CD_POS0 + 2];
-                k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
-                k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
-                k_min = mp->cmin[lane]; k_max = mp->cmax[lane];
-                k_eps1 = k_act && k_ct == ARB_CT_SOFTFINGER && (k_e0 == T(1)) && (k_e1 == T(1)) && (k_e2 == T(1));
-            }
-            const unsigned long long actmask = __ballot(k_act);
-            const unsigned long long eps1mask = __ballot(k_eps1);
-            int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
-            T vr_prev = vr, fr_prev = fr;
-#if ARB_GS_PRIO
-            // the sweeps are one long dependent chain: let this wave issue ahead of the SIMD's other wave,
-            // whose bulk phases have independent instructions to fill the gaps
-            __builtin_amdgcn_s_setprio(ARB_GS_PRIO);
-#endif
-            for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
-                if (MODE == 1) ++st_sweeps;
-                for (int c = 0; c < nc; ++c) {
-                    if (!((actmask >> c) & 1ull)) continue;
-                    const int base = 4 * c;
-                    // column block Y'[:, 4c..4c+3] of this lane's row (issued early, used last)
-                    T a4[4] = {T(0), T(0), T(0), T(0)};
-                    if (lane < ndol) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a4[i] = AM[lane * ndol + base + i];
-                    }
-                    const int ct = __builtin_amdgcn_readlane(k_ct, c);
-                    T vc[4], fc[4], df[4], fnew[4];
-                    // A constraint's four rows are one quad of lanes: what its local solve needs from its own
-                    // rows comes as DPP quad_perm operands (every quad evaluates ITS constraint; only the quad of
-                    // c is used).  Values go through SGPRs (v_readlane) only where the whole wave needs them.
-                    const T fq0 = quad_bcast<0>(fr), fq1 = quad_bcast<1>(fr), fq2 = quad_bcast<2>(fr), fq3 = quad_bcast<3>(fr);
-                    // own-row products (meaningful on lanes base..base+3)
-                    const T v0r = vr - (Yrow[0] * fq0 + Yrow[1] * fq1 + Yrow[2] * fq2 + Yrow[3] * fq3);
-                    bool quad_done = false;      // softfinger release / static: per-lane results, see below
-                    T dfl = T(0), fnl = T(0);
-                    if (ct != ARB_CT_SOFTFINGER) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { vc[i] = bcast(vr, base + i); fc[i] = bcast(fr, base + i); }
-                    }
-                    if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
-                        // The release test and the static-friction candidate are evaluated side by side
-                        // (two independent dependent chains that overlap in the pipeline), inside the quad.
-                        const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
-                        const T vq0 = quad_bcast<0>(vr), vq1 = quad_bcast<1>(vr), vq2 = quad_bcast<2>(vr), vq3 = quad_bcast<3>(vr);
-                        const T dfr = -(Prow[0] * vq0 + Prow[1] * vq1 + Prow[2] * vq2 + Prow[3] * (vq3 + q_sdt));
-                        const T fnr = fr + dfr;
-                        const T v0n = quad_bcast<3>(v0r);
-                        const T fn0 = quad_bcast<0>(fnr), fn1 = quad_bcast<1>(fnr), fn2 = quad_bcast<2>(fnr), fn3 = quad_bcast<3>(fnr);
-                        T eps[3] = {T(1), T(1), T(1)};
-                        T lhs;
-                        if (eps1) {
-                            lhs = fn0 * fn0 + fn1 * fn1 + fn2 * fn2;
-                        } else {
-                            eps[0] = bcast(k_e0, c); eps[1] = bcast(k_e1, c); eps[2] = bcast(k_e2, c);
-                            lhs = (fn0 / eps[0]) * (fn0 / eps[0]) + (fn1 / eps[1]) * (fn1 / eps[1])
-                                + (fn2 / eps[2]) * (fn2 / eps[2]);
-                        }
-                        const T rhs = (fn3 * q_mu) * (fn3 * q_mu);
-                        // the quad of c decides for the wave
-                        const bool release = (__ballot(q_sd + dt * v0n > T(0)) >> base) & 1ull;
-                        const bool stat = (__ballot(lhs <= rhs) >> base) & 1ull;
-                        if (release || stat) {
-                            // release (zero force) or static friction (df exactly -pinv(Y)(...) as in the
-                            // reference, row by row): one branch, the two outcomes by selection
-                            if (MODE == 1) { if (release) ++st_rel; else ++st_sta; }
-                            dfl = release ? -fr : dfr; fnl = release ? T(0) : fnr; quad_done = true;
-                        } else {
-                            {                                              // sliding friction
-                                // Also inside the quad: the four lanes of constraint c carry the live problem in
-                                // vector registers (the other quads run along on their own, unused data) and every
-                                // branch follows the quad of c (`uni`), so nothing travels through SGPRs but the
-                                // final force increments.
-                                const int rq = lane - base;
-                                const bool inquad = rq >= 0 && rq < 4;
-                                const auto uni = [&](bool b) { return (bool)((__ballot(b) >> base) & 1ull); };
-                                T alpha[4], shift = T(0);
-                                alpha[0] = quad_bcast<0>(v0r); alpha[1] = quad_bcast<1>(v0r); alpha[2] = quad_bcast<2>(v0r);
-                                alpha[3] = v0n + q_sdt;
-                                // the constraint's own 4x4 admittance block (wave-uniform LDS reads)
-                                T Y[16];
-                                {
-                                    typedef T Y4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        const Y4 y4 = *reinterpret_cast<const Y4 *>(AM + (base + r) * ndol + base);
-                                        Y[4 * r] = y4.x; Y[4 * r + 1] = y4.y; Y[4 * r + 2] = y4.z; Y[4 * r + 3] = y4.w;
-                                    }
-                                }
-                                if (MODE == 1) ++st_fast;
-                                double warm = q_warm;
-                                bool have = false;
-                                if (eps1) {
-                                    const T yc[3] = {q_yc0, q_yc1, q_yc2};
-                                    const T bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
-                                    double c1, kappa, root;
-                                    slide_c1_kappa<T>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
-                                    if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni)) {
-                                        warm = root;
-                                        // leftmost real eigenvalue; admissible when <= 0 (constraints.py:826-830)
-                                        shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
-                                        have = true;
-                                    }
-                                }
-                                if (!have) {
-                                    if (MODE == 1) { ++st_slow; --st_fast; }
-                                    // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
-                                    if (inquad) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
-                                    WAVE_SYNC();
-                                    if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
-                                    WAVE_SYNC();
-                                    shift = WORK[40];
-                                    WAVE_SYNC();
-                                    warm = NAN;
-                                }
-                                if (inquad) q_warm = warm;          // next sweep restarts next to this root
-                                fnew[0] = fq0; fnew[1] = fq1; fnew[2] = fq2; fnew[3] = fq3;
-                                T sie2[3] = {shift, shift, shift};
-                                if (!eps1) {
-#pragma unroll
-                                    for (int i = 0; i < 3; ++i) sie2[i] = shift / (eps[i] * eps[i]);
-                                }
-                                softfinger_slide_finish_scaled<T>(Y, alpha, sie2, fnew, df);
-                                dfl = (rq == 0) ? df[0] : (rq == 1) ? df[1] : (rq == 2) ? df[2] : df[3];
-                                fnl = (rq == 0) ? fnew[0] : (rq == 1) ? fnew[1] : (rq == 2) ? fnew[2] : fnew[3];
-                                quad_done = true;
-                            }
-                        }
-                    } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
-                        const T p0 = bcast(k_p0, c), p1 = bcast(k_p1, c), p2 = bcast(k_p2, c);
-                        const T dfr = -(Prow[0] * (vc[0] + p0 * inv_dt) + Prow[1] * (vc[1] + p1 * inv_dt)
-                                        + Prow[2] * (vc[2] + p2 * inv_dt));
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) { df[i] = bcast(dfr, base + i); fnew[i] = fc[i] + df[i]; }
-                        df[3] = T(0); fnew[3] = fc[3];
-                    } else {                                               // JointLimits.solve constraints.py:73-90
-                        const T pos0 = bcast(k_p0, c), lo = bcast(k_min, c), hi = bcast(k_max, c);
-                        const T p00 = bcast(Prow[0], base);
-                        const T pred = pos0 + dt * bcast(v0r, base);
-                        T nf = T(0);
-                        if (pred <= lo) nf = p00 * ((lo - pred) * inv_dt);
-                        else if (hi <= pred) nf = p00 * ((hi - pred) * inv_dt);
-                        df[0] = nf - fc[0]; fnew[0] = nf;
-#pragma unroll
-                        for (int i = 1; i < 4; ++i) { df[i] = T(0); fnew[i] = fc[i]; }
-                    }
-                    const int rr = lane - base;
-                    if (quad_done) {
-                        // release / static: the quad holds the new forces and the force increments row by row
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) df[i] = bcast(dfl, base + i);
-                        fr = (rr >= 0 && rr < 4) ? fnl : fr;
-                    } else {
-                        fr = (rr == 0) ? fnew[0] : (rr == 1) ? fnew[1] : (rr == 2) ? fnew[2] : (rr == 3) ? fnew[3] : fr;
-                    }
-                    // vel += Y'[:, c] dforce                               core.py:935
-                    vr += a4[0] * df[0] + a4[1] * df[1] + a4[2] * df[2] + a4[3] * df[3];
-                }
-                // A sweep that leaves every velocity and force bit-for-bit unchanged is a fixed point
-                // of the iteration: the remaining sweeps of core.py:929-935 would repeat it exactly.
-                if (__all(same_bits(vr, vr_prev) && same_bits(fr, fr_prev)) && !(MODE == 1 && (dbg.ablate & 8))) break;
-                vr_prev = vr; fr_prev = fr;
-            }
-#if ARB_GS_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            if (MODE == 1 && dbg.gs_stats != nullptr && lane == 0) {
-                int *o = dbg.gs_stats + w * 5;
-                o[0] = st_rel; o[1] = st_sta; o[2] = st_fast; o[3] = st_slow; o[4] = st_sweeps;
-            }
-            WAVE_SYNC();
-            if (lane < ndol) { FF[lane] = fr; VV[lane] = vr; }
-            WAVE_SYNC();
+            gs_stage<T, MODE>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
         }
 
         // ================= phase E: new velocity, integrate ==================
@@ -1508,9 +1568,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 template <typename T, int NC, int WPB>
 __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
     const DevModel<T> *__restrict__ mp, const T *__restrict__ wsA, const T *__restrict__ wsv,
-    T *__restrict__ wsf, const T *__restrict__ wsc, long nworlds, T dt)
+    T *__restrict__ wsf, const T *__restrict__ wsc, long nworlds, T dt_in, const double *__restrict__ dts)
 {
     constexpr int ND = 4 * NC;
+    const T dt = dts != nullptr ? (T)dts[0] : dt_in;
     T *lds = reinterpret_cast<T *>(arb_lds_raw);
     const int nc = mp->nc, ndol = mp->ndol;
     const int nA = ndol * ndol, sA = nA + 1, sP = 16 * nc + 1, sW = 41;
@@ -1583,11 +1644,10 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
                     f4[i] += df[i];
                 }
             } else {                                               // JointLimits.solve constraints.py:73-90
-                const T pred = c_p0[c] + dt * (v4[0] - Y[0] * f4[0]);
-                const T lo = mp->cmin[c], hi = mp->cmax[c];
+                const T v00 = v4[0] - Y[0] * f4[0], glo = c_p1[c], ghi = c_p2[c];     // see the fused kernel
                 T nf = T(0);
-                if (pred <= lo) nf = P[0] * ((lo - pred) * inv_dt);
-                else if (hi <= pred) nf = P[0] * ((hi - pred) * inv_dt);
+                if (v00 <= glo) nf = P[0] * (glo - v00);
+                else if (ghi <= v00) nf = P[0] * (ghi - v00);
                 df[0] = nf - f4[0]; f4[0] = nf;
             }
             // vel += Y'[:, c] dforce                               core.py:935
@@ -1609,6 +1669,42 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
 #pragma unroll
         for (int i = 0; i < ND; ++i) if (i < ndol) wsf[w * ndol + i] = f[i];
     }
+}
+
+// ===========================================================================
+// Gauss-Seidel with one WAVEFRONT per world as its own kernel (split execution, ARB_STEP_SPLIT_WAVE): the
+// quad-local sweeps of gs_stage, fed from the SplitIO buffers.  The sweeps are one dependent chain per world
+// and need few registers, so this kernel is compiled for several waves per SIMD (the step kernel is pinned
+// at two by its 256 VGPRs): other worlds' chains fill the issue slots one chain leaves empty.
+// LDS per world: Y' (ndol^2) + the constraint blocks + 64 elements of scratch.
+// ===========================================================================
+template <typename T, int WV>
+__global__ __launch_bounds__(WAVE, WV) void arb_gsw_kernel(
+    const DevModel<T> *__restrict__ mp, const T *__restrict__ wsA, const T *__restrict__ wsv,
+    T *__restrict__ wsf, const T *__restrict__ wsc, long nworlds, T dt_in, const double *__restrict__ dts)
+{
+    const int lane = threadIdx.x;
+    const long w = blockIdx.x;
+    if (w >= nworlds) return;
+    const int nc = mp->nc, ndol = mp->ndol;
+    const T dt = dts != nullptr ? (T)dts[0] : dt_in;
+    const T inv_dt = T(1) / dt;
+    T *lds = reinterpret_cast<T *>(arb_lds_raw);
+    auto al = [](int x) { return (x + 3) & ~3; };
+    T *AM = lds, *CD = AM + al(ndol * ndol), *VV = CD + al(nc * CD_STRIDE), *FF = VV + al(ndol), *WORK = FF + al(ndol);
+    const int nA = ndol * ndol;
+    for (int i = lane; i < nA; i += WAVE) AM[i] = wsA[w * nA + i];
+    if (lane < ndol) { VV[lane] = wsv[w * ndol + lane]; FF[lane] = wsf[w * ndol + lane]; }
+    if (lane < nc) {
+        const T *cs = wsc + (w * nc + lane) * 8;
+        T *cd = CD + lane * CD_STRIDE;
+        cd[CD_ACTIVE] = cs[0]; cd[CD_SDIST] = cs[1]; cd[CD_POS0] = cs[2]; cd[CD_POS0 + 1] = cs[3]; cd[CD_POS0 + 2] = cs[4];
+    }
+    WAVE_SYNC();
+    DebugOut<T> nodbg;
+    nodbg.gs_stats = nullptr; nodbg.gs_trace = nullptr; nodbg.ablate = 0;
+    gs_stage<T, 0>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, nodbg, w);
+    if (lane < ndol) wsf[w * ndol + lane] = FF[lane];
 }
 
 // ===========================================================================
@@ -1661,16 +1757,16 @@ thread_local std::string g_hip_err;
 // kernels of one register tile and precision only (explicit instantiations below) and none of the
 // host code; the main unit declares them extern and holds the C ABI.
 // ---------------------------------------------------------------------------
-template <typename T, int NMAX, int NSETS, int MODE>
+template <typename T, int NMAX, int NSETS, int MODE, int FEAT>
 int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw, double dt,
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
-                      const SplitIO<T> &sio, hipStream_t st) {
-    auto kern = arb_step_kernel<T, NMAX, NSETS, MODE>;
+                      const SplitIO<T> &sio, const double *dts, hipStream_t st) {
+    auto kern = arb_step_kernel<T, NMAX, NSETS, MODE, FEAT>;
     const size_t lds = (size_t)L.total * sizeof(T);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio, dts);
     HIP_TRY(hipGetLastError());
     return ARB_OK;
 }
@@ -1680,23 +1776,48 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
 #endif
 #define ARB_LAUNCH_ONE_ARGS(T)                                                                                             \
     const DevModel<T> *, const Layout &, T *, T *, T *, const T *, const PerWorldPD<T> &, long, double, int, unsigned,   \
-    const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, hipStream_t
+    const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, const double *, hipStream_t
 #ifdef ARB_PART
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 #else
 #if defined(ARB_SPLIT_BUILD)
 #define ARB_EXTERN_TILE(T, NM)                                                        \
-    extern template int launch_one<T, NM, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));              \
-    extern template int launch_one<T, NM, 2, 0>(ARB_LAUNCH_ONE_ARGS(T));              \
-    extern template int launch_one<T, NM, 1, 1>(ARB_LAUNCH_ONE_ARGS(T));              \
-    extern template int launch_one<T, NM, 2, 1>(ARB_LAUNCH_ONE_ARGS(T));
+    extern template int launch_one<T, NM, 1, 0, 0>(ARB_LAUNCH_ONE_ARGS(T));           \
+    extern template int launch_one<T, NM, 2, 0, 0>(ARB_LAUNCH_ONE_ARGS(T));           \
+    extern template int launch_one<T, NM, 1, 0, 1>(ARB_LAUNCH_ONE_ARGS(T));           \
+    extern template int launch_one<T, NM, 2, 0, 1>(ARB_LAUNCH_ONE_ARGS(T));           \
+    extern template int launch_one<T, NM, 1, 1, 1>(ARB_LAUNCH_ONE_ARGS(T));           \
+    extern template int launch_one<T, NM, 2, 1, 1>(ARB_LAUNCH_ONE_ARGS(T));
 ARB_EXTERN_TILE(float, 16) ARB_EXTERN_TILE(float, 32) ARB_EXTERN_TILE(float, 44) ARB_EXTERN_TILE(float, 48) ARB_EXTERN_TILE(float, 64)
 ARB_EXTERN_TILE(double, 16) ARB_EXTERN_TILE(double, 32) ARB_EXTERN_TILE(double, 44) ARB_EXTERN_TILE(double, 48) ARB_EXTERN_TILE(double, 64)
 #undef ARB_EXTERN_TILE
 #endif
+
+// Makes `device` current for the scope of a C-ABI call and restores the caller's device afterwards (torch reads
+// its current device from the HIP runtime: leaving another device current would silently redirect the caller's
+// later allocations).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err != hipSuccess) prev = -1;
+        if (err == hipSuccess && prev == device) prev = -1;      // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ARB_GUARD_DEVICE(dev)                                                          \
+    DeviceGuard guard_(dev);                                                           \
+    if (guard_.err != hipSuccess) {                                                    \
+        g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err);     \
+        return ARB_ERR_HIP;                                                            \
+    }
 
 struct arb_model {
     int device;
@@ -1787,41 +1908,33 @@ static void zaligned_host(const double z[3], double R[9]) {
     for (int i = 0; i < 3; ++i) { R[3 * i] = x[i]; R[3 * i + 1] = y[i]; R[3 * i + 2] = z[i]; }
 }
 
+template <typename T, typename S, size_t N>
+static void fill(T (&dst)[N], const S *src, size_t count) {
+    for (size_t i = 0; i < N; ++i) dst[i] = (i < count && src) ? static_cast<T>(src[i]) : T(0);
+}
+
 template <typename T>
 static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<int> &jnd,
                      const std::vector<int> &depth, const std::vector<unsigned long long> &anc,
                      const std::vector<int> &dof2q, int maxdepth, const TreeTables &tt, DevModel<T> *out) {
-    DevModel<T> m;
+    DevModel<T> &m = *out;
     memset(&m, 0, sizeof(m));
     const int nb = d->nb, n = d->ndof, nc = d->nc;
     m.nb = nb; m.n = n; m.nq = d->nq; m.nc = nc; m.ndol = ARB_MAXDOL * nc; m.ncols = n + 1 + m.ndol;
     m.maxdepth = maxdepth;
     int rc;
-#define UP_I(field, vec) if ((rc = upload<int>(M, vec, &m.field)) != ARB_OK) return rc
-#define UP_T(field, vec) if ((rc = upload<T>(M, vec, &m.field)) != ARB_OK) return rc
-    UP_I(parent, std::vector<int>(d->parent, d->parent + nb));
-    UP_I(jtype, std::vector<int>(d->jtype, d->jtype + nb));
-    UP_I(dof_off, std::vector<int>(d->dof_off, d->dof_off + nb));
-    UP_I(jnd, jnd);
-    UP_I(q_off, std::vector<int>(d->q_off, d->q_off + nb));
-    UP_I(depth, depth);
-    UP_I(weighted, std::vector<int>(d->weighted, d->weighted + nb));
-    UP_I(dof2q, dof2q);
-    UP_I(dofbody, tt.dofbody); UP_I(subsize, tt.subsize);
-    if ((rc = upload<unsigned long long>(M, tt.upmask, &m.upmask)) != ARB_OK) return rc;
-    if ((rc = upload<unsigned long long>(M, tt.descmask, &m.descmask)) != ARB_OK) return rc;
-    if ((rc = upload<unsigned long long>(M, anc, &m.anc)) != ARB_OK) return rc;
-    UP_T(Hpr, conv<T>(h12(d->H_pr, nb).data(), 12 * nb));
-    UP_T(Hcn, conv<T>(h12(d->H_cn, nb).data(), 12 * nb));
-    if ((rc = upload<double>(M, h12(d->H_pr, nb), &m.Hpr_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, h12(d->H_cn, nb), &m.Hcn_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, conv<double>(d->c_local, 3 * nc), &m.clocal_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, conv<double>(d->c_radius, nc), &m.cradius_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, conv<double>(d->c_radius0, nc), &m.cradius0_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, conv<double>(d->c_half, 3 * nc), &m.chalf_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, conv<double>(d->c_plane, 4 * nc), &m.cplane_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, h12(d->c_bpose0, nc), &m.cb0_d)) != ARB_OK) return rc;
-    if ((rc = upload<double>(M, h12(d->c_bpose1, nc), &m.cb1_d)) != ARB_OK) return rc;
+    fill(m.parent, d->parent, nb); fill(m.jtype, d->jtype, nb); fill(m.dof_off, d->dof_off, nb);
+    fill(m.jnd, jnd.data(), nb); fill(m.q_off, d->q_off, nb); fill(m.depth, depth.data(), nb);
+    fill(m.weighted, d->weighted, nb); fill(m.dof2q, dof2q.data(), n);
+    fill(m.dofbody, tt.dofbody.data(), n); fill(m.subsize, tt.subsize.data(), nb);
+    fill(m.upmask, tt.upmask.data(), n); fill(m.descmask, tt.descmask.data(), n); fill(m.anc, anc.data(), nb);
+    const std::vector<double> hpr = h12(d->H_pr, nb), hcn = h12(d->H_cn, nb);
+    fill(m.Hpr, hpr.data(), 12 * nb); fill(m.Hcn, hcn.data(), 12 * nb);
+    fill(m.Hpr_d, hpr.data(), 12 * nb); fill(m.Hcn_d, hcn.data(), 12 * nb);
+    fill(m.clocal_d, d->c_local, 3 * nc); fill(m.cradius_d, d->c_radius, nc); fill(m.cradius0_d, d->c_radius0, nc);
+    fill(m.chalf_d, d->c_half, 3 * nc); fill(m.cplane_d, d->c_plane, 4 * nc);
+    const std::vector<double> cb0 = h12(d->c_bpose0, nc), cb1 = h12(d->c_bpose1, nc);
+    fill(m.cb0_d, cb0.data(), 12 * nc); fill(m.cb1_d, cb1.data(), 12 * nc);
     {
         // centre of mass of every body as massmatrix.principalframe places it (massmatrix.py:96-99),
         // and its mass; massless bodies contribute nothing
@@ -1834,45 +1947,32 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
                 com[4 * b + 2] = Mb[6 * 1 + 3] / mass_b; com[4 * b + 3] = Mb[21];
             }
         }
-        if ((rc = upload<double>(M, com, &m.com_d)) != ARB_OK) return rc;
+        fill(m.com_d, com.data(), com.size());
         for (int i = 0; i < 3; ++i) m.up[i] = d->up[i];
     }
-    UP_T(mass, conv<T>(d->mass, 36 * nb));
-    UP_T(visc, conv<T>(d->visc, 36 * nb));
+    fill(m.mass, d->mass, 36 * nb); fill(m.visc, d->visc, 36 * nb);
     bool hv = false;
     for (int i = 0; i < 36 * nb; ++i) hv = hv || (d->visc[i] != 0.0);
     m.has_visc = hv;
     m.has_grav = 0;
     for (int i = 0; i < 3; ++i) { m.grav[i] = (T)d->gravity[i]; if (d->gravity[i] != 0.0) m.has_grav = 1; }
     m.has_pd = (d->pd_kp != nullptr);
-    UP_T(pd_kp, conv<T>(d->pd_kp, m.has_pd ? n * n : 0));
-    UP_T(pd_kd, conv<T>(d->pd_kd, m.has_pd ? n * n : 0));
-    UP_T(pd_tau0, conv<T>(d->pd_tau0, m.has_pd ? n : 0));
+    if ((rc = upload<T>(M, conv<T>(d->pd_kp, m.has_pd ? n * n : 0), &m.pd_kp)) != ARB_OK) return rc;
+    if ((rc = upload<T>(M, conv<T>(d->pd_kd, m.has_pd ? n * n : 0), &m.pd_kd)) != ARB_OK) return rc;
+    if ((rc = upload<T>(M, conv<T>(d->pd_tau0, m.has_pd ? n : 0), &m.pd_tau0)) != ARB_OK) return rc;
     // constraints
-    std::vector<int> ctype(d->ctype, d->ctype + nc), cen(d->c_enabled, d->c_enabled + nc);
-    UP_I(ctype, ctype); UP_I(cen, cen);
-    UP_I(cbody, std::vector<int>(d->c_body, d->c_body + nc));
-    UP_I(cbody0, std::vector<int>(d->c_body0, d->c_body0 + nc));
-    UP_I(cdof, std::vector<int>(d->c_dof, d->c_dof + nc));
-    UP_I(cgeom, std::vector<int>(d->c_geom, d->c_geom + nc));
-    std::vector<double> rz(9 * (size_t)nc, 0.0);
+    fill(m.ctype, d->ctype, nc); fill(m.cen, d->c_enabled, nc); fill(m.cbody, d->c_body, nc);
+    fill(m.cbody0, d->c_body0, nc); fill(m.cdof, d->c_dof, nc); fill(m.cgeom, d->c_geom, nc);
+    std::vector<double> rz(9 * (size_t)std::max(nc, 1), 0.0);
     m.has_warm = 0;
     for (int c = 0; c < nc; ++c) {
-        if (ctype[c] == ARB_CT_SOFTFINGER && d->c_geom[c] == ARB_CG_PLANE_SPHERE)
+        if (d->ctype[c] == ARB_CT_SOFTFINGER && d->c_geom[c] == ARB_CG_PLANE_SPHERE)
             zaligned_host(d->c_plane + 4 * c, rz.data() + 9 * c);
-        if (ctype[c] == ARB_CT_BALLSOCKET) m.has_warm = 1;
+        if (d->ctype[c] == ARB_CT_BALLSOCKET) m.has_warm = 1;
     }
-    if ((rc = upload<double>(M, rz, &m.cRz_d)) != ARB_OK) return rc;
-    UP_T(cmu, conv<T>(d->c_mu, nc));
-    UP_T(cprox, conv<T>(d->c_prox, nc));
-    UP_T(ceps, conv<T>(d->c_eps, 3 * nc));
-    UP_T(cmin, conv<T>(d->c_min, nc));
-    UP_T(cmax, conv<T>(d->c_max, nc));
-    UP_T(cb0, conv<T>(h12(d->c_bpose0, nc).data(), 12 * nc));
-    UP_T(cb1, conv<T>(h12(d->c_bpose1, nc).data(), 12 * nc));
-#undef UP_I
-#undef UP_T
-    *out = m;
+    fill(m.cRz_d, rz.data(), 9 * nc);
+    fill(m.cmu, d->c_mu, nc); fill(m.cprox_d, d->c_prox, nc); fill(m.ceps, d->c_eps, 3 * nc);
+    fill(m.cmin_d, d->c_min, nc); fill(m.cmax_d, d->c_max, nc);
     return ARB_OK;
 }
 
@@ -2008,18 +2108,31 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     M->nsets = ncols > WAVE ? 2 : 1;
     M->nmax = 64;
     for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) { g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(e); delete M; return ARB_ERR_HIP; }
+    DeviceGuard guard_(device);
+    if (guard_.err != hipSuccess) {
+        g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err);
+        delete M;
+        return ARB_ERR_HIP;
+    }
     int rc = build_dev<float>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->df);
     if (rc == ARB_OK)
         rc = build_dev<double>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     {
-        const DevModel<float> *pf = nullptr; const DevModel<double> *pd = nullptr;
-        rc = upload<DevModel<float>>(M, std::vector<DevModel<float>>(1, M->df), &pf);
-        if (rc == ARB_OK) rc = upload<DevModel<double>>(M, std::vector<DevModel<double>>(1, M->dd), &pd);
-        if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
-        M->df_dev = const_cast<DevModel<float> *>(pf); M->dd_dev = const_cast<DevModel<double> *>(pd);
+        // one blob per precision
+        void *pf = nullptr, *pd = nullptr;
+        hipError_t e1 = hipMalloc(&pf, sizeof(DevModel<float>));
+        if (e1 == hipSuccess) M->allocs.push_back(pf);
+        hipError_t e2 = (e1 == hipSuccess) ? hipMalloc(&pd, sizeof(DevModel<double>)) : e1;
+        if (e2 == hipSuccess) M->allocs.push_back(pd);
+        if (e2 == hipSuccess) e2 = hipMemcpy(pf, &M->df, sizeof(DevModel<float>), hipMemcpyHostToDevice);
+        if (e2 == hipSuccess) e2 = hipMemcpy(pd, &M->dd, sizeof(DevModel<double>), hipMemcpyHostToDevice);
+        if (e2 != hipSuccess) {
+            g_hip_err = std::string("model upload: ") + hipGetErrorString(e2);
+            arb_model_destroy(M);
+            return ARB_ERR_HIP;
+        }
+        M->df_dev = static_cast<DevModel<float> *>(pf); M->dd_dev = static_cast<DevModel<double> *>(pd);
     }
     int tot;
     M->lf = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
@@ -2031,9 +2144,9 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
 
 extern "C" int arb_model_destroy(arb_model *M) {
     if (!M) return ARB_ERR_INVALID;
-    (void)hipSetDevice(M->device);
+    DeviceGuard guard_(M->device);
     for (void *p : M->allocs) (void)hipFree(p);
-    if (M->ws) (void)hipFree(M->ws);
+    if (M->ws) (void)hipFree(M->ws);          // (hipFree waits for the work that uses it)
     delete M;
     return ARB_OK;
 }
@@ -2051,35 +2164,40 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 template <typename T, int MODE>
 static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw,
                   double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
-                  const SplitIO<T> &sio, hipStream_t st) {
+                  const SplitIO<T> &sio, const double *dts, hipStream_t st) {
+    // the plain step (FEAT 0): nothing but the state and the constraint forces
+    const bool plain = MODE == 0 && ext == nullptr && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
+                       logo.dq == nullptr && logo.energy == nullptr && sio.mode == 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS) && dts == nullptr;
+#define ONE(NM, NS, FT) launch_one<T, NM, NS, MODE, FT>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #ifdef ARB_QUICK
-    // development build: a single instantiation (float, NMAX=48, one column set, production mode)
-#ifdef ARB_QUICK_INSPECT
+    // development build: a single register tile (float, NMAX=44, one column set)
     if constexpr (std::is_same<T, float>::value) {
-#else
-    if constexpr (std::is_same<T, float>::value && MODE == 0) {
-#endif
-        if (M->nmax == 44 && M->nsets == 1)
-            return launch_one<T, 44, 1, MODE>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
+        if (M->nmax == 44 && M->nsets == 1) {
+            if constexpr (MODE == 0) return plain ? ONE(44, 1, 0) : ONE(44, 1, 1);
+            else return ONE(44, 1, 1);
+        }
     }
     return ARB_ERR_UNSUPPORTED;
 #else
-#define CASE(NM)                                                                                                     \
-    case NM:                                                                                                         \
-        return (M->nsets == 2) ? launch_one<T, NM, 2, MODE>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st) \
-                               : launch_one<T, NM, 1, MODE>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, st);
+#define CASE(NM)                                                                                       \
+    case NM:                                                                                           \
+        if constexpr (MODE == 0) {                                                                     \
+            if (plain) return (M->nsets == 2) ? ONE(NM, 2, 0) : ONE(NM, 1, 0);                         \
+        }                                                                                              \
+        return (M->nsets == 2) ? ONE(NM, 2, 1) : ONE(NM, 1, 1);
     switch (M->nmax) {
         CASE(16) CASE(32) CASE(44) CASE(48) CASE(64)
         default: return ARB_ERR_UNSUPPORTED;
     }
 #undef CASE
 #endif
+#undef ONE
 }
 
 // Gauss-Seidel kernel launch (lane = world).  Picks the constraint-count tile NC and the
 // number of worlds per 64-thread block that fits the 160 KB LDS.
 template <typename T, int NC>
-static int launch_gs_nc(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, hipStream_t st) {
+static int launch_gs_nc(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st) {
     const int ndol = 4 * nc;
     const size_t per_world = ((size_t)ndol * ndol + 1 + 16 * nc + 1 + 41) * sizeof(T);
     int wpb = 64;
@@ -2093,7 +2211,7 @@ static int launch_gs_nc(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, lo
         if (lds > 64 * 1024)                                                                                      \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt);     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts); \
     } while (0)
     if (wpb == 64) GS_LAUNCH(64); else if (wpb == 32) GS_LAUNCH(32); else GS_LAUNCH(16);
 #undef GS_LAUNCH
@@ -2102,16 +2220,32 @@ static int launch_gs_nc(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, lo
 }
 
 template <typename T>
-static int launch_gs(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, hipStream_t st) {
+static int launch_gs(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st) {
 #ifdef ARB_QUICK
-    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, st);
+    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, dts, st);
     return ARB_ERR_UNSUPPORTED;
 #else
-    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, st);
-    if (nc <= 8) return launch_gs_nc<T, 8>(dm, nc, sio, nw, dt, st);
-    if (nc <= 16) return launch_gs_nc<T, 16>(dm, nc, sio, nw, dt, st);
+    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, dts, st);
+    if (nc <= 8) return launch_gs_nc<T, 8>(dm, nc, sio, nw, dt, dts, st);
+    if (nc <= 16) return launch_gs_nc<T, 16>(dm, nc, sio, nw, dt, dts, st);
     return ARB_ERR_UNSUPPORTED;
 #endif
+}
+
+template <typename T>
+static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st) {
+    auto al = [](int x) { return (x + 3) & ~3; };
+    const int ndol = 4 * nc;
+    const size_t lds = (size_t)(al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol) + 64) * sizeof(T);
+    // waves per SIMD the sweep kernel is compiled for (development knob ARB_GSW_WAVES: 3 = no spills, 4 = 128 VGPRs)
+    static const int wv = [] { const char *e = getenv("ARB_GSW_WAVES"); return e ? atoi(e) : 3; }();
+    if (lds > 64 * 1024) return ARB_ERR_UNSUPPORTED;
+    if (wv == 4)
+        hipLaunchKernelGGL((arb_gsw_kernel<T, 4>), dim3((unsigned)nw), dim3(WAVE), lds, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
+    else
+        hipLaunchKernelGGL((arb_gsw_kernel<T, 3>), dim3((unsigned)nw), dim3(WAVE), lds, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
+    HIP_TRY(hipGetLastError());
+    return ARB_OK;
 }
 
 // Measured on MI355X (tools/split_vs_fused.py, human36 + 4 contacts): the split execution overtakes the fused
@@ -2120,25 +2254,30 @@ static int launch_gs(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long 
 
 template <typename T>
 static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext,
-                      const PerWorldPD<T> &pwd, long nw, double dt, int nsteps, unsigned flags, const arb_rollout_log *log, hipStream_t st) {
+                      const PerWorldPD<T> &pwd, long nw, double dt, const double *dts, int nsteps, unsigned flags,
+                      const arb_rollout_log *log, hipStream_t st) {
     DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
     LogOut<T> lo; memset(&lo, 0, sizeof(lo));
     if (log) { lo.q = (T *)log->q_log; lo.dq = (T *)log->dq_log; lo.energy = (T *)log->energy_log; }
     SplitIO<T> sio; memset(&sio, 0, sizeof(sio));
     const int nc = M->nc, ndol = M->ndol, n = M->n;
-    const bool can_split = nc > 0 && nc <= 16 && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
+    const bool wave_gs = (flags & ARB_STEP_SPLIT_WAVE) != 0;
+    const bool can_split = nc > 0 && (nc <= 16 || wave_gs) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
     // Opt-in (ARB_STEP_SPLIT) since round 1: the lane-per-world kernel is 1.1-1.15x faster from ~16k worlds, but it
     // returned a 1e18 N contact force for one world in 2 M world-steps until a compiler workaround went into
     // arb_math.h::softfinger_try (split execution); it stays opt-in until it has seen more inputs.
-    const bool split = can_split && (flags & ARB_STEP_SPLIT);
+    const bool split = can_split && (flags & (ARB_STEP_SPLIT | ARB_STEP_SPLIT_WAVE));
     if (!split)
-        return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, st);
+        return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, dts, st);
     // ---- split execution: step kernel (dynamics + system) / Gauss-Seidel kernel (lane = world) ----
     const size_t per_world = (size_t)ndol * ndol + 3 * (size_t)ndol + 8 * (size_t)nc + (size_t)(1 + ndol) * n;
     const size_t need = per_world * (size_t)nw * sizeof(T);
     if (need > M->ws_bytes) {
-        if (M->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(M->ws)); M->ws = nullptr; M->ws_bytes = 0; }
-        HIP_TRY(hipMalloc(&M->ws, need));
+        // grow: the old block is released in stream order (work already queued on `st` keeps it until it has run)
+        // and the new one is allocated in stream order: no device-wide synchronisation.  One workspace per handle:
+        // a handle must not run split steps on two streams at once (include/arbstep.h).
+        if (M->ws) { HIP_TRY(hipFreeAsync(M->ws, st)); M->ws = nullptr; M->ws_bytes = 0; }
+        HIP_TRY(hipMallocAsync(&M->ws, need, st));
         M->ws_bytes = need;
     }
     T *p = (T *)M->ws;
@@ -2154,21 +2293,25 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
         if (lk.dq) lk.dq += (size_t)k * nw * n;
         if (lk.energy) lk.energy += (size_t)k * nw * 2;
         sio.mode = 2 | (k > 0 ? 1 : 0);
-        int rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, st);
+        // (kernel k finishes step k-1 with dts[k-1], then builds step k with dts[k])
+        int rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, dts ? dts + k : nullptr, st);
         if (rc != ARB_OK) return rc;
-        rc = launch_gs<T>(dm, nc, sio, nw, dt, st);
+        rc = wave_gs ? launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st)
+                     : launch_gs<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st);
         if (rc != ARB_OK) return rc;
     }
     sio.mode = 1;                                      // apply the last step's forces, write cforce
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
-    return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, sio, st);
+    return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, sio, dts ? dts + nsteps : nullptr, st);
 }
 
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                      const void *pd_qdes, const void *pd_dqdes, const void *pd_kp, const void *pd_kd,
-                     int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, const arb_rollout_log *log,
-                     void *stream) {
-    if (!M || nworlds < 0 || nsteps < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
+                     int64_t nworlds, double dt, const double *dt_steps, int32_t nsteps, uint32_t flags,
+                     const arb_rollout_log *log, void *stream) {
+    if (!M || nworlds < 0 || nsteps < 0) return ARB_ERR_INVALID;
+    if (dt_steps == nullptr && !(dt > 0.0)) return ARB_ERR_INVALID;
+    if (dt_steps != nullptr) dt = 1.0;                  // unused: every step reads its own dt
     if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
     // per-world PD inputs: targets come in pairs; diagonal gains come in pairs and need targets;
     // targets without gains use the model's gain matrices, so the model must hold a PD controller
@@ -2178,35 +2321,35 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (nworlds == 0 || nsteps == 0) return ARB_OK;     // empty batch: nothing to do (pointers may be null)
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
-    HIP_TRY(hipSetDevice(M->device));
+    ARB_GUARD_DEVICE(M->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32) {
         const PerWorldPD<float> pwd = {(const float *)pd_qdes, (const float *)pd_dqdes, (const float *)pd_kp, (const float *)pd_kd};
         return step_typed<float>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce,
-                                 (const float *)ext_gforce, pwd, (long)nworlds, dt, nsteps, flags, log, st);
+                                 (const float *)ext_gforce, pwd, (long)nworlds, dt, dt_steps, nsteps, flags, log, st);
     }
     const PerWorldPD<double> pwd = {(const double *)pd_qdes, (const double *)pd_dqdes, (const double *)pd_kp, (const double *)pd_kd};
     return step_typed<double>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce,
-                              (const double *)ext_gforce, pwd, (long)nworlds, dt, nsteps, flags, log, st);
+                              (const double *)ext_gforce, pwd, (long)nworlds, dt, dt_steps, nsteps, flags, log, st);
 }
 
 extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                         int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, void *stream) {
-    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nullptr, nullptr, nullptr, nullptr, nworlds, dt, nsteps,
+    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nullptr, nullptr, nullptr, nullptr, nworlds, dt, nullptr, nsteps,
                      flags, nullptr, stream);
 }
 
 extern "C" int arb_step_ex(arb_model *M, int dtype, const arb_step_args *a, void *stream) {
     if (!a) return ARB_ERR_INVALID;
     return step_impl(M, dtype, a->q, a->dq, a->cforce, a->ext_gforce, a->pd_qdes, a->pd_dqdes, a->pd_kp, a->pd_kd,
-                     a->nworlds, a->dt, a->nsteps, a->flags, a->log, stream);
+                     a->nworlds, a->dt, a->dt_steps, a->nsteps, a->flags, a->log, stream);
 }
 
 extern "C" int arb_rollout(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                            int64_t nworlds, double dt, int32_t nsteps, uint32_t flags,
                            const arb_rollout_log *log, void *stream) {
     if (!log) return ARB_ERR_INVALID;
-    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nullptr, nullptr, nullptr, nullptr, nworlds, dt, nsteps,
+    return step_impl(M, dtype, q, dq, cforce, ext_gforce, nullptr, nullptr, nullptr, nullptr, nworlds, dt, nullptr, nsteps,
                      flags, log, stream);
 }
 
@@ -2225,18 +2368,18 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
         d1.Zout = (T *)ps.ptr;
         LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
         SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
-        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, d1, ps.zmode, nolog, nosplit, st);
+        rc = launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, d1, ps.zmode, nolog, nosplit, nullptr, st);
         if (rc != ARB_OK) return rc;
     }
     dbg.pose = (T *)o->pose; dbg.twist = (T *)o->twist; dbg.jac = (T *)o->jac; dbg.djac = (T *)o->djac;
     dbg.Zout = (T *)o->Z; dbg.gforce0 = (T *)o->gforce0; dbg.vel_free = (T *)o->vel_free;
     dbg.c_sdist = (T *)o->c_sdist; dbg.c_active = (int *)o->c_active; dbg.c_jac = (T *)o->c_jac;
     dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
-    dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.stamps = (long long *)o->stamps; dbg.energy = (T *)o->energy;
+    dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.gs_trace = (int *)o->gs_trace; dbg.stamps = (long long *)o->stamps; dbg.energy = (T *)o->energy;
     { const char *ab = getenv("ARB_ABLATE"); dbg.ablate = ab ? atoi(ab) : 0; }
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
     SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
-    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, nosplit, st);
+    return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, nosplit, nullptr, st);
 }
 
 extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,
@@ -2248,7 +2391,7 @@ extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *d
     if (nworlds == 0) return ARB_OK;
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
-    HIP_TRY(hipSetDevice(M->device));
+    ARB_GUARD_DEVICE(M->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32)
         return inspect_t<float>(M, M->df_dev, M->lf, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
@@ -2290,7 +2433,7 @@ extern "C" int arb_dev_softfinger_solve(int dtype, int device, int n, const doub
     if (!in || !out || n <= 0) return ARB_ERR_INVALID;
     const int use_fast = !(dtype & 0x100);
     dtype &= 0xff;
-    HIP_TRY(hipSetDevice(device));
+    ARB_GUARD_DEVICE(device);
     double *din = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc(&din, sizeof(double) * 27 * (size_t)n));
     HIP_TRY(hipMalloc(&dout, sizeof(double) * 9 * (size_t)n));

@@ -67,7 +67,9 @@ def parse(argv=None):
                     help="lower bound of the timed region (whole episodes are repeated until it is reached)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--split", action="store_true", help="Gauss-Seidel sweeps in their own kernel (ARB_STEP_SPLIT)")
+    ap.add_argument("--split", default=None, choices=("lane", "wave"),
+                    help="Gauss-Seidel sweeps in their own kernel: one lane per world (ARB_STEP_SPLIT) or one "
+                         "wavefront per world (ARB_STEP_SPLIT_WAVE); default: inside the step kernel")
     ap.add_argument("--no-per-step-leg", action="store_true", help="skip the one-launch-per-step comparison leg")
     ap.add_argument("--extra", action="store_true", help="also time the other BASELINE configs (N=1)")
     ap.add_argument("--dry-run", action="store_true",
@@ -185,7 +187,7 @@ def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=Non
             if timed:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            bw.step(q, dq, dt, c, cforce=cf, split=split)
+            bw.step(q, dq, dt, c, cforce=cf, split=(split if split != "lane" else True))
             if timed:
                 b.record()
                 ev.append((a, b))
@@ -364,7 +366,7 @@ def main():
         "episode_kernel_ms": {"median": float(np.median(ep_ms)), "mean": kern_ms, "p10": float(np.percentile(ep_ms, 10)),
                               "p90": float(np.percentile(ep_ms, 90)), "min": float(ep_ms.min()), "max": float(ep_ms.max())},
         "config": {"workload": "%s, batch %d worlds/GPU, dt=%g, %s, whole %d-step episodes, one arb_step launch per episode%s"
-                               % (cfg["name"], B, dt, cfg["dtype"], EP, ", split Gauss-Seidel kernel" if args.split else ""),
+                               % (cfg["name"], B, dt, cfg["dtype"], EP, (", Gauss-Seidel in a %s-per-world kernel" % args.split) if args.split else ""),
                    "baseline_config": args.config, "worlds_per_gpu": B, "global_batch": n_gpus * B,
                    "parallelism": "dp%d" % n_gpus, "steps_per_launch": EP / launches_per_episode},
         "roofline": {"bound": "valu-issue",
@@ -390,7 +392,7 @@ def main():
     profs = [f for f in profs if "baseline" not in f]
     prof = profs[-1] if profs else ""
     shape = {"config": args.config, "batch": B, "dtype": cfg["dtype"], "contacts": cfg["contacts"],
-             "steps_per_launch": EP, "split": bool(args.split)}
+             "steps_per_launch": EP, "split": args.split or False}
     if os.path.exists(prof) and launches_per_episode == 1:
         try:
             pj = json.load(open(prof))

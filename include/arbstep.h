@@ -23,7 +23,9 @@
  *     torch.Tensor.data_ptr()); the library keeps only the immutable model.
  *   - calls are asynchronous with respect to `stream` (a hipStream_t passed as
  *     void*; NULL = the default stream); there is no hidden synchronisation.
- *   - one model handle per device; calls on different handles are re-entrant.
+ *   - one model handle per device; calls on different handles are re-entrant.  A handle may be
+ *     used from several streams, except with ARB_STEP_SPLIT (its workspace is per handle).
+ *     Every call makes the handle's device current and restores the caller's device on return.
  *   - twists/wrenches are ordered [angular; linear]; matrices are row-major.
  *
  * State layout (world-major): q[nworlds][nq], dq[nworlds][ndof].  q is the
@@ -39,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ARB_ABI_VERSION 3
+#define ARB_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -88,6 +90,8 @@ enum {
 #define ARB_STEP_FUSED 2u             /* keep the Gauss-Seidel sweeps inside the step kernel (the default) */
 #define ARB_STEP_SPLIT 4u             /* run the sweeps in a second kernel with one lane per world (same results to
                                          rounding; faster from ~16k worlds with <= 4 constraints; opt-in) */
+#define ARB_STEP_SPLIT_WAVE 8u        /* run the sweeps in a second kernel with one WAVEFRONT per world (the fused kernel's
+                                         quad-local sweeps, bit-identical results, compiled for more waves per SIMD) */
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the
@@ -178,6 +182,11 @@ typedef struct arb_inspect_out {
                         of sweeps executed before the iteration reached a bit-exact fixed point (diagnostic) */
     void *energy;    /* [nw][2]            kinetic and potential energy, EnergyMonitor.update observers.py:40-51 */
     void *stamps;    /* [nw][8] int64  shader clock at the phase boundaries A, A', B, C, D, GS, E, end (diagnostic) */
+    void *gs_trace;  /* [nw][20][nc] int32  decision of every local solve of the 20 sweeps (core.py:929-935) in execution
+                        order: 0 release, 1 static friction, 2 sliding (sextic shift), 3 sliding (eig6 fallback)
+                        (SoftFingerContact.solve, constraints.py:781-836), 4 = another constraint type.  Entries of solves
+                        that were not executed (inactive constraint, sweeps after the fixed point) are left untouched:
+                        pre-fill with -1. */
 } arb_inspect_out;
 
 int arb_abi_version(void);
@@ -233,6 +242,7 @@ int arb_rollout(arb_model *m, int dtype, void *q, void *dq, void *cforce, const 
  *   pd_kp, pd_kd  device [nworlds][ndof] or both NULL: per-world DIAGONAL gains; they replace the
  *            model's gain matrices altogether and need pd_qdes/pd_dqdes.
  *   log      NULL (arb_step) or the per-step logs (arb_rollout)
+ *   dt_steps one dt per step (device, float64) instead of the uniform `dt`
  * Other fields as in arb_step.  ext_gforce is the hook for user torques (MPC inputs).
  */
 typedef struct arb_step_args {
@@ -245,6 +255,9 @@ typedef struct arb_step_args {
     int32_t nsteps;
     uint32_t flags;
     const arb_rollout_log *log;
+    const double *dt_steps;   /* DEVICE pointer [nsteps] (always float64) or NULL: the dt of every step, for a
+                                 non-uniform timeline inside one launch (core.py:1357: dt = next_time - current_time);
+                                 when given, `dt` is ignored */
 } arb_step_args;
 
 int arb_step_ex(arb_model *m, int dtype, const arb_step_args *args, void *stream);

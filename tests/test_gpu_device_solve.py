@@ -119,7 +119,7 @@ def test_device_solve_on_1e5_harvested_tuples_f64(harvested):
     scale = np.maximum(1., np.abs(ref[:, :4]).max(axis=1))
     err = np.abs(dev[:, :8] - ref[:, :8]).max(axis=1) / scale
     print("float64: %d decisions differ; max rel err %.2e" % ((~same).sum(), err[same].max()))
-    assert err[same].max() < 1e-8
+    assert err[same].max() < 1e-10                                     # measured: 1e-12
     # the generic eig6 route on a subsample of the sliding tuples
     sl = np.flatnonzero(ref[:, 8] == 2)[::7][:5000]
     dev6 = device_solve(lib, _capi.ARB_F64 | 0x100, tuples[sl])
@@ -154,7 +154,7 @@ def test_device_solve_on_1e5_harvested_tuples_f32(harvested):
     print("float32: %d of %d decisions differ; force rel err median %.2e p99 %.2e max %.2e"
           % (bad, len(sub), np.median(errs), np.quantile(errs, 0.99), errs.max()))
     assert bad <= 0.005 * len(sub)
-    assert np.quantile(errs, 0.99) < 2e-4 and errs.max() < 2e-2
+    assert np.quantile(errs, 0.99) < 2e-6 and errs.max() < 1e-4      # measured: p99 2.3e-7, max 1.2e-6
     # device == host build of the same arb_math.h code, over a 20k subsample (ctypes call per tuple)
     host = np.array([host_solve(lib, _capi.ARB_F32, t32[i]) for i in sub])
     hs = np.maximum(1., np.abs(host[:, :4]).max(axis=1))

@@ -89,22 +89,21 @@ def explain_outlier(bw, m, q, dq, dt):
     string, or None.  `q`, `dq`: the float32 state the device stepped from (one world)."""
     tq = torch.as_tensor(q[None], dtype=torch.float32, device=bw.device).contiguous()
     tdq = torch.as_tensor(dq[None], dtype=torch.float32, device=bw.device).contiguous()
-    r = bw.inspect(tq, tdq, dt, ["gs_stats", "c_active"], cforce=bw.new_cforce(1, torch.float32))
+    r = bw.inspect(tq, tdq, dt, ["gs_stats", "gs_trace", "c_active"], cforce=bw.new_cforce(1, torch.float32))
     st = r["gs_stats"].cpu().numpy()[0]                    # release, static, fast slide, eig6 slide, sweeps
+    dtr = r["gs_trace"].cpu().numpy()[0]                   # (20, nc): decision of every executed solve, -1 = not run
     dact = r["c_active"].cpu().numpy()[0].astype(bool)
     tr = []
     _, _, _, d = O.step(m, q[None].astype(np.float64), dq[None].astype(np.float64), dt, debug=True, trace=tr)
     if not np.array_equal(dact, d["active"][0]):
         return "active set differs"
-    # the device stops sweeping at a bit-exact fixed point: compare the sweeps it executed
+    # the device stops sweeping at a bit-exact fixed point: compare the sweeps it executed, solve by solve
     nsw = int(st[4])
-    ob = np.zeros(3, int)
     for t in tr:
         if t["sweep"] < nsw:
-            ob[t["branch"]] += 1
-    db = np.array([st[0], st[1], st[2] + st[3]])
-    if not np.array_equal(ob, db):
-        return "branch sequence differs (oracle %s, device %s over %d sweeps)" % (ob, db, nsw)
+            dev = int(dtr[t["sweep"], t["c"]])
+            if min(dev, 2) != t["branch"]:
+                return "decision differs at sweep %d contact %d (oracle %d, device %d)" % (t["sweep"], t["c"], t["branch"], dev)
     mg = decision_margins(tr)
     if mg < 1e-6:
         return "decision within %.1e of its inequality" % mg
