@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
+#include <utility>
 
 #include "arbstep.h"
 #include "arb_math.h"
@@ -43,6 +44,9 @@
 #define ARB_WAVES_PER_EU 2      // 2nd __launch_bounds__ argument: min waves per SIMD (caps VGPRs at 256)
 #endif
 #define GS_SWEEPS 20            // core.py:929-931
+#ifndef ARB_PHASE_C_MFMA
+#define ARB_PHASE_C_MFMA 1      // float32 elimination of phase C on the matrix cores (v_mfma_f32_4x4x1_16b_f32); 0 = VALU
+#endif
 #ifndef ARB_GS_PRIO
 #define ARB_GS_PRIO 2           // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
 #endif
@@ -231,6 +235,12 @@ __device__ __forceinline__ void mat6_vec(const T *__restrict__ M, const T x[6], 
         for (int j = 0; j < 6; ++j) s += M[6 * i + j] * x[j];
         y[i] = s;
     }
+}
+
+// f(integral_constant<int, N-1>), ..., f(integral_constant<int, 0>): a loop whose index is a constant expression
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_desc(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, (int)sizeof...(I) - 1 - I>{}), ...);
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
@@ -1384,10 +1394,69 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         }
         // Pivots are taken from the last dof to the first (extremities before the
         // root): on these graded, nearly-SPD matrices that order halves the float32
-        // error of pivot-free elimination (measured).  The register file
+        // error of pivot-free elimination (measured).
+        ARB_CSTAMP(4);
+#if ARB_PHASE_C_MFMA
+        if constexpr (std::is_same<T, float>::value) {
+            // ---- matrix-core elimination (float32): one pivot = one rank-1 update of the whole register tile,
+            // issued as NMAX/4 v_mfma_f32_4x4x1_16b_f32: the 16 4x4 blocks of one instruction are the 64 columns
+            // (lane = column, B operand = this lane's entry of the scaled pivot row) times four rows (the four
+            // accumulator registers of a slab), and the A operand carries the four multipliers of the slab's rows,
+            // f[4g + lane % 4] -- the pivot column, which lane j hands over through LDS (NMAX/4 vector writes by one
+            // lane, NMAX/4 reads by all).  Exact float32 FMAs (one per element: K = 1), so the reversed pivot order
+            // and the error analysis of the VALU elimination carry over; what goes away are the NMAX v_readlane
+            // broadcasts + wait states per pivot.  Fully unrolled: the pivot row index is static, no register rotation.
+            typedef float F4 __attribute__((ext_vector_type(4)));
+            float *COL = reinterpret_cast<float *>(WORK);           // the pivot column, NMAX <= 64 elements
+            F4 *COL4 = reinterpret_cast<F4 *>(WORK);
+            const int lq = lane & 3;
+            // (pivot steps expanded at template level, NMAX-1 down to 0: with a `#pragma unroll` loop the index
+            // only becomes constant late in the pipeline and the register tile ends up in scratch memory)
+            static_for_desc(std::make_integer_sequence<int, NMAX>{}, [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j < n) {
+                    const float piv = bcast(Z[j], j);
+                    const float nip = -arb_rcp(piv);
+                    const float tn = Z[j] * nip;                  // minus this lane's entry of the scaled pivot row
+                    float tn2 = 0.f;
+                    if (NSETS == 2) tn2 = Z2[j] * nip;
+                    if (lane == j) {
+#pragma unroll
+                        for (int g = 0; g < NMAX / 4; ++g) {
+                            F4 v;
+                            v.x = (4 * g == j) ? 0.f : Z[4 * g]; v.y = (4 * g + 1 == j) ? 0.f : Z[4 * g + 1];
+                            v.z = (4 * g + 2 == j) ? 0.f : Z[4 * g + 2]; v.w = (4 * g + 3 == j) ? 0.f : Z[4 * g + 3];
+                            COL4[g] = v;                          // (row j itself: multiplier 0, the row is replaced below)
+                        }
+                    }
+                    WAVE_SYNC();
+                    float a[NMAX / 4];
+#pragma unroll
+                    for (int g = 0; g < NMAX / 4; ++g) a[g] = COL[4 * g + lq];
+                    WAVE_SYNC();
+#pragma unroll
+                    for (int g = 0; g < NMAX / 4; ++g) {
+                        F4 acc;
+                        acc.x = Z[4 * g]; acc.y = Z[4 * g + 1]; acc.z = Z[4 * g + 2]; acc.w = Z[4 * g + 3];
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g], tn, acc, 0, 0, 0);
+                        Z[4 * g] = acc.x; Z[4 * g + 1] = acc.y; Z[4 * g + 2] = acc.z; Z[4 * g + 3] = acc.w;
+                        if (NSETS == 2) {
+                            F4 ac2;
+                            ac2.x = Z2[4 * g]; ac2.y = Z2[4 * g + 1]; ac2.z = Z2[4 * g + 2]; ac2.w = Z2[4 * g + 3];
+                            ac2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g], tn2, ac2, 0, 0, 0);
+                            Z2[4 * g] = ac2.x; Z2[4 * g + 1] = ac2.y; Z2[4 * g + 2] = ac2.z; Z2[4 * g + 3] = ac2.w;
+                        }
+                    }
+                    Z[j] = -tn;
+                    if (NSETS == 2) Z2[j] = -tn2;
+                }
+            });
+        } else
+#endif
+        {
+        // VALU elimination (float64, and float32 when the matrix-core path is compiled out): the register file
         // is rotated one row per step so that the pivot row always sits in
         // Z[NMAX-1] and every index below is a compile-time constant.
-        ARB_CSTAMP(4);
         for (int j = n; j < NMAX; ++j) {           // bring row n-1 into Z[NMAX-1]
             const T t = Z[NMAX - 1];
             T t2 = T(0);
@@ -1421,6 +1490,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             }
             Z[0] = t;
             if (NSETS == 2) Z2[0] = t2;
+        }
         }
         ARB_CSTAMP(5);
         // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
