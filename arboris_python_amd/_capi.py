@@ -22,6 +22,7 @@ ARB_STEP_SKIP_CONSTRAINTS = 1
 ARB_STEP_FUSED = 2
 ARB_STEP_SPLIT = 4
 ARB_STEP_SPLIT_WAVE = 8
+ARB_STEP_MFMA_ELIM = 16
 
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)

@@ -44,9 +44,6 @@
 #define ARB_WAVES_PER_EU 2      // 2nd __launch_bounds__ argument: min waves per SIMD (caps VGPRs at 256)
 #endif
 #define GS_SWEEPS 20            // core.py:929-931
-#ifndef ARB_PHASE_C_MFMA
-#define ARB_PHASE_C_MFMA 1      // float32 elimination of phase C on the matrix cores (v_mfma_f32_4x4x1_16b_f32); 0 = VALU
-#endif
 #ifndef ARB_GS_PRIO
 #define ARB_GS_PRIO 2           // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
 #endif
@@ -512,7 +509,8 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 // FEAT 0 = the plain step (arb_step without user torques: no per-world PD inputs, no per-step logs, no split
 // execution) -- those arguments are compiled out, which keeps their kernargs and the predicates derived from them
 // out of the SGPR file; FEAT 1 = every input honoured.
-template <typename T, int NMAX, int NSETS, int MODE, int FEAT>
+// CM 1 = phase C eliminates on the matrix cores (float32 only; ARB_STEP_MFMA_ELIM), 0 = on the vector ALU.
+template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
 __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
     T *__restrict__ gcforce, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
@@ -520,6 +518,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     const double *__restrict__ dts_in)
 {
     static_assert(MODE == 0 || FEAT == 1, "the inspect kernels take every input");
+    static_assert(CM == 0 || (FEAT == 1 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
     const T *__restrict__ gext = FEAT ? gext_in : nullptr;
     const PerWorldPD<T> pwd = FEAT ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
     const LogOut<T> logo = FEAT ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
@@ -1396,8 +1395,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         // root): on these graded, nearly-SPD matrices that order halves the float32
         // error of pivot-free elimination (measured).
         ARB_CSTAMP(4);
-#if ARB_PHASE_C_MFMA
-        if constexpr (std::is_same<T, float>::value) {
+        if constexpr (CM == 1 && std::is_same<T, float>::value) {
             // ---- matrix-core elimination (float32): one pivot = one rank-1 update of the whole register tile,
             // issued as NMAX/4 v_mfma_f32_4x4x1_16b_f32: the 16 4x4 blocks of one instruction are the 64 columns
             // (lane = column, B operand = this lane's entry of the scaled pivot row) times four rows (the four
@@ -1406,6 +1404,10 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // lane, NMAX/4 reads by all).  Exact float32 FMAs (one per element: K = 1), so the reversed pivot order
             // and the error analysis of the VALU elimination carry over; what goes away are the NMAX v_readlane
             // broadcasts + wait states per pivot.  Fully unrolled: the pivot row index is static, no register rotation.
+            // MEASURED (MI355X, human36, in-kernel stamps under load, profiles/r02_phaseC_mfma.txt): 46-49 k cycles for
+            // the 42 pivots against 27-33 k of the VALU loop below (a variant rolled over slabs with a rotating register
+            // tile: 60 k): every pivot waits for an LDS write -> read round trip on its critical path and the one-lane
+            // column write costs 11 LDS issues.  Opt-in (ARB_STEP_MFMA_ELIM), parity-tested, not the default.
             typedef float F4 __attribute__((ext_vector_type(4)));
             float *COL = reinterpret_cast<float *>(WORK);           // the pivot column, NMAX <= 64 elements
             F4 *COL4 = reinterpret_cast<F4 *>(WORK);
@@ -1452,7 +1454,6 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 }
             });
         } else
-#endif
         {
         // VALU elimination (float64, and float32 when the matrix-core path is compiled out): the register file
         // is rotated one row per step so that the pivot row always sits in
@@ -1827,11 +1828,11 @@ thread_local std::string g_hip_err;
 // kernels of one register tile and precision only (explicit instantiations below) and none of the
 // host code; the main unit declares them extern and holds the C ABI.
 // ---------------------------------------------------------------------------
-template <typename T, int NMAX, int NSETS, int MODE, int FEAT>
+template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
 int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw, double dt,
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
                       const SplitIO<T> &sio, const double *dts, hipStream_t st) {
-    auto kern = arb_step_kernel<T, NMAX, NSETS, MODE, FEAT>;
+    auto kern = arb_step_kernel<T, NMAX, NSETS, MODE, FEAT, CM>;
     const size_t lds = (size_t)L.total * sizeof(T);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1848,21 +1849,30 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     const DevModel<T> *, const Layout &, T *, T *, T *, const T *, const PerWorldPD<T> &, long, double, int, unsigned,   \
     const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, const double *, hipStream_t
 #ifdef ARB_PART
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#if ARB_PART_IS_FLOAT
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#endif
 #else
 #if defined(ARB_SPLIT_BUILD)
 #define ARB_EXTERN_TILE(T, NM)                                                        \
-    extern template int launch_one<T, NM, 1, 0, 0>(ARB_LAUNCH_ONE_ARGS(T));           \
-    extern template int launch_one<T, NM, 2, 0, 0>(ARB_LAUNCH_ONE_ARGS(T));           \
-    extern template int launch_one<T, NM, 1, 0, 1>(ARB_LAUNCH_ONE_ARGS(T));           \
-    extern template int launch_one<T, NM, 2, 0, 1>(ARB_LAUNCH_ONE_ARGS(T));           \
-    extern template int launch_one<T, NM, 1, 1, 1>(ARB_LAUNCH_ONE_ARGS(T));           \
-    extern template int launch_one<T, NM, 2, 1, 1>(ARB_LAUNCH_ONE_ARGS(T));
+    extern template int launch_one<T, NM, 1, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 2, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 1, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 2, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 1, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 2, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));
+#define ARB_EXTERN_TILE_CM(NM)                                                          \
+    extern template int launch_one<float, NM, 1, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 2, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(float));
+ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_TILE_CM(48) ARB_EXTERN_TILE_CM(64)
+#undef ARB_EXTERN_TILE_CM
 ARB_EXTERN_TILE(float, 16) ARB_EXTERN_TILE(float, 32) ARB_EXTERN_TILE(float, 44) ARB_EXTERN_TILE(float, 48) ARB_EXTERN_TILE(float, 64)
 ARB_EXTERN_TILE(double, 16) ARB_EXTERN_TILE(double, 32) ARB_EXTERN_TILE(double, 44) ARB_EXTERN_TILE(double, 48) ARB_EXTERN_TILE(double, 64)
 #undef ARB_EXTERN_TILE
@@ -2238,12 +2248,14 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // the plain step (FEAT 0): nothing but the state and the constraint forces
     const bool plain = MODE == 0 && ext == nullptr && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
                        logo.dq == nullptr && logo.energy == nullptr && sio.mode == 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS) && dts == nullptr;
-#define ONE(NM, NS, FT) launch_one<T, NM, NS, MODE, FT>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
+    const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM);
+#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
+#define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44, one column set)
     if constexpr (std::is_same<T, float>::value) {
         if (M->nmax == 44 && M->nsets == 1) {
-            if constexpr (MODE == 0) return plain ? ONE(44, 1, 0) : ONE(44, 1, 1);
+            if constexpr (MODE == 0) return mfma ? ONE_(44, 1, 1, 1) : (plain ? ONE(44, 1, 0) : ONE(44, 1, 1));
             else return ONE(44, 1, 1);
         }
     }
@@ -2251,6 +2263,9 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #else
 #define CASE(NM)                                                                                       \
     case NM:                                                                                           \
+        if constexpr (MODE == 0 && std::is_same<T, float>::value) {                                    \
+            if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 1, 1) : ONE_(NM, 1, 1, 1);                  \
+        }                                                                                              \
         if constexpr (MODE == 0) {                                                                     \
             if (plain) return (M->nsets == 2) ? ONE(NM, 2, 0) : ONE(NM, 1, 0);                         \
         }                                                                                              \
@@ -2262,6 +2277,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #undef CASE
 #endif
 #undef ONE
+#undef ONE_
 }
 
 // Gauss-Seidel kernel launch (lane = world).  Picks the constraint-count tile NC and the

@@ -90,6 +90,9 @@ enum {
 #define ARB_STEP_FUSED 2u             /* keep the Gauss-Seidel sweeps inside the step kernel (the default) */
 #define ARB_STEP_SPLIT 4u             /* run the sweeps in a second kernel with one lane per world (same results to
                                          rounding; faster from ~16k worlds with <= 4 constraints; opt-in) */
+#define ARB_STEP_MFMA_ELIM 16u        /* float32 only: eliminate the augmented system [Z | rhs | J'^T] on the matrix cores
+                                         (v_mfma_f32_4x4x1_16b_f32 rank-1 updates) instead of the vector ALU; same results to
+                                         rounding, measured SLOWER on MI355X: opt-in */
 #define ARB_STEP_SPLIT_WAVE 8u        /* run the sweeps in a second kernel with one WAVEFRONT per world (the fused kernel's
                                          quad-local sweeps, bit-identical results, compiled for more waves per SIMD) */
 

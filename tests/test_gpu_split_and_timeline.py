@@ -129,3 +129,42 @@ def test_gs_trace_matches_oracle_decisions(bws):
     for w in range(len(Q)):
         assert (dtr[w, st[w, 4]:] == -1).all()
         assert int((dtr[w] >= 0).sum()) == int(st[w, :4].sum())
+
+
+@pytest.mark.parametrize("name", ["human36_g", "human36_c4", "human36_c8", "simplearm_g"])
+def test_matrix_core_elimination_parity(bws, name):
+    """ARB_STEP_MFMA_ELIM: phase C on v_mfma_f32_4x4x1 instead of the vector ALU (replaces numpy.linalg.inv,
+    core.py:818, 925-927) -- float32 single steps against the oracle at the same 1e-5 gate as the default path,
+    on the golden states of configs 1-3 (incl. the 75-column system of human36 + 8 contacts: two column sets)."""
+    bw, m, q0, dq0 = bws(name)
+    if name == "human36_g":
+        g = load_golden("g2_human36.npz"); Q, DQ, dt = g["q"][g["dt"] == 5e-3], g["dq"][g["dt"] == 5e-3], 5e-3
+    elif name == "simplearm_g":
+        g = load_golden("g1_simplearm.npz"); Q, DQ, dt = g["traj_q"], g["traj_dq"], 0.01
+    else:
+        g = load_golden("g3_contacts.npz"); nc = m.nc
+        Q = np.concatenate([g["drop%d_q" % nc][:39], g["rand%d_q" % nc]]); DQ = np.concatenate([g["drop%d_dq" % nc][:39], g["rand%d_dq" % nc]]); dt = 5e-3
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    oq, odq, _ = O.step(m, f(Q), f(DQ), dt)
+    res = {}
+    for mf in (False, True):
+        tq, tdq = bw.to_device(Q, DQ, torch.float32)
+        cf = bw.new_cforce(len(Q), torch.float32) if m.nc else None
+        bw.step(tq, tdq, dt, 1, cforce=cf, mfma=mf)
+        torch.cuda.synchronize()
+        eq = np.abs(tq.cpu().numpy() - oq).max(axis=1) / np.maximum(1., np.abs(oq).max(axis=1))
+        edq = np.abs(tdq.cpu().numpy() - odq).max(axis=1) / np.maximum(1., np.abs(odq).max(axis=1))
+        assert eq.max() < 1e-5 and edq.max() < 1e-5, (mf, eq.max(), edq.max())
+        res[mf] = (tq, tdq)
+    # exact float32 FMAs in the same pivot order: the two eliminations agree far below the gate
+    d = (res[True][1] - res[False][1]).abs().max().item()
+    assert d < 1e-4 * max(1., res[False][1].abs().max().item())
+    # a 20-step launch stays finite and close to the default path
+    tq, tdq = bw.to_device(Q[:4], DQ[:4], torch.float32)
+    sq, sdq = bw.to_device(Q[:4], DQ[:4], torch.float32)
+    cf1 = bw.new_cforce(4, torch.float32) if m.nc else None
+    cf2 = bw.new_cforce(4, torch.float32) if m.nc else None
+    bw.step(tq, tdq, dt, 20, cforce=cf1, mfma=True)
+    bw.step(sq, sdq, dt, 20, cforce=cf2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tq).all() and torch.isfinite(tdq).all()

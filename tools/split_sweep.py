@@ -26,14 +26,14 @@ for B in [int(x) for x in a.batches.split(",")]:
     q0, dq0 = bw.to_device(q, dq, torch.float32)
     row = {}
     for mode in a.modes.split(","):
-        split = {"fused": False, "lane": True, "wave": "wave"}[mode]
+        split = {"fused": False, "lane": True, "wave": "wave", "mfma": False}[mode]
         tq, tdq, cf = q0.clone(), dq0.clone(), bw.new_cforce(B, torch.float32)
         def episode():
             tq.copy_(q0); tdq.copy_(dq0)
             k = 0
             while k < EP:
                 c = min(a.spl, EP - k)
-                bw.step(tq, tdq, dt, c, cforce=cf, split=split)
+                bw.step(tq, tdq, dt, c, cforce=cf, split=split, mfma=(mode == "mfma"))
                 k += c
         episode(); torch.cuda.synchronize()
         n = max(2, min(a.episodes, int(a.episodes * 8192 / B) + 1))
