@@ -262,14 +262,31 @@ template <typename T, int MODE>
 __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt,
                                          const T inv_dt, const T *AM, T *CD, T *VV, T *FF, T *WORK,
                                          const DebugOut<T> &dbg, const long w) {
-    // inverse of every active constraint's own admittance block (once per step)
-    if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
-        const int c = lane, ct = mp->ctype[c];
-        const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
-        T P[16];
-        inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+    // (pseudo-)inverse of every active constraint's own admittance block (once per step): pinv(Y_cc) of
+    // constraints.py:79, 83, 235, 795.  Pivoted elimination for the regular blocks, all constraints side by side;
+    // the blocks it reports as rank deficient are redone one after the other with the SVD-based pinv_block.
+    {
+        bool deficient = false;
+        if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
+            const int c = lane, ct = mp->ctype[c];
+            const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+            T P[16];
+            deficient = !inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+            for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+        }
+        unsigned long long todo = __ballot(deficient);
+        while (todo != 0ull) {                           // wave-uniform, rare
+            const int c = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            if (lane == c) {
+                const int ct = mp->ctype[c];
+                const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                T P[16];
+                pinv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+                for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+            }
+        }
     }
     WAVE_SYNC();
     // ---- Gauss-Seidel, core.py:929-935, register resident ----------------------
@@ -1679,7 +1696,8 @@ __global__ __launch_bounds__(WAVE) void arb_gs_kernel(
                     const int ct = mp->ctype[c];
                     const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                     T P[16];
-                    inv_block<T>(Arow + (4 * c) * ndol + 4 * c, ndol, nd, P);
+                    if (!inv_block<T>(Arow + (4 * c) * ndol + 4 * c, ndol, nd, P))
+                        pinv_block<T>(Arow + (4 * c) * ndol + 4 * c, ndol, nd, P);      // rank deficient: constraints.py:795
 #pragma unroll
                     for (int i = 0; i < 16; ++i) Prow[16 * c + i] = P[i];
                 }
@@ -1797,7 +1815,7 @@ __global__ __launch_bounds__(WAVE) void arb_softfinger_test_kernel(const double 
     T v[4], Y[16], P[16], f[4], df[4], eps[3] = {T(1), T(1), T(1)};
     for (int k = 0; k < 4; ++k) { v[k] = (T)t[k]; f[k] = (T)t[20 + k]; }
     for (int k = 0; k < 16; ++k) Y[k] = (T)t[4 + k];
-    inv_block<T>(Y, 4, 4, P);
+    if (!inv_block<T>(Y, 4, 4, P)) pinv_block<T>(Y, 4, 4, P);
     const int br = softfinger_solve<T>(v, Y, P, f, df, (T)t[24], (T)t[25], (T)t[26], eps, work, use_fast != 0);
     double *o = out + (size_t)i * 9;
     for (int k = 0; k < 4; ++k) { o[k] = (double)f[k]; o[4 + k] = (double)df[k]; }
@@ -2498,7 +2516,7 @@ extern "C" int arb_host_softfinger_solve(int dtype, const double *vel, const dou
     dtype &= 0xff;
     if (dtype == ARB_F64) {
         double P[16], work[36], f[4], df[4];
-        inv_block<double>(adm, 4, 4, P);
+        if (!inv_block<double>(adm, 4, 4, P)) pinv_block<double>(adm, 4, 4, P);
         for (int i = 0; i < 4; ++i) f[i] = force[i];
         int br = softfinger_solve<double>(vel, adm, P, f, df, sdist, dt, mu, eps, work, use_fast);
         for (int i = 0; i < 4; ++i) { force[i] = f[i]; dforce[i] = df[i]; }
@@ -2508,7 +2526,7 @@ extern "C" int arb_host_softfinger_solve(int dtype, const double *vel, const dou
     for (int i = 0; i < 4; ++i) { v[i] = (float)vel[i]; f[i] = (float)force[i]; }
     for (int i = 0; i < 16; ++i) Y[i] = (float)adm[i];
     for (int i = 0; i < 3; ++i) e[i] = (float)eps[i];
-    inv_block<float>(Y, 4, 4, P);
+    if (!inv_block<float>(Y, 4, 4, P)) pinv_block<float>(Y, 4, 4, P);
     int br = softfinger_solve<float>(v, Y, P, f, df, (float)sdist, (float)dt, (float)mu, e, work, use_fast);
     for (int i = 0; i < 4; ++i) { force[i] = f[i]; dforce[i] = df[i]; }
     return br;
@@ -2557,6 +2575,28 @@ extern "C" int arb_host_softfinger_try(int dtype, const double *vel, const doubl
 extern "C" int arb_host_slide_root(const double *Y, double c1, double kappa, double warm, double *root) {
     const SlidePre k = slide_precompute<double>(Y);
     return slide_leftmost_root(k, c1, kappa, warm, root) ? 1 : 0;
+}
+
+// (pseudo-)inverse of an nd x nd block as the kernels form it: returns 1 when the pivoted elimination was kept,
+// 0 when the block was found rank deficient and the SVD route (numpy.linalg.pinv semantics) was taken
+extern "C" int arb_host_block_pinv(int dtype, int nd, const double *Y /*[nd][nd]*/, double *P /*[nd][nd]*/) {
+    if (!Y || !P || nd < 1 || nd > 4) return -1;
+    int regular;
+    double out[16];
+    if (dtype == ARB_F64) {
+        double p[16];
+        regular = inv_block<double>(Y, nd, nd, p);
+        if (!regular) pinv_block<double>(Y, nd, nd, p);
+        for (int i = 0; i < 16; ++i) out[i] = p[i];
+    } else {
+        float y[16], p[16];
+        for (int i = 0; i < nd * nd; ++i) y[i] = (float)Y[i];
+        regular = inv_block<float>(y, nd, nd, p);
+        if (!regular) pinv_block<float>(y, nd, nd, p);
+        for (int i = 0; i < 16; ++i) out[i] = p[i];
+    }
+    for (int i = 0; i < nd; ++i) for (int j = 0; j < nd; ++j) P[i * nd + j] = out[4 * i + j];
+    return regular ? 1 : 0;
 }
 
 extern "C" int arb_host_eig6(const double *A, double *wr, double *wi) {

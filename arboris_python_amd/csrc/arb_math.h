@@ -444,9 +444,18 @@ ARB_HD void gepp4(T A[4][4], T B[4][NR]) {
     }
 }
 
-// Inverse of a ND x ND block (ND <= 4) embedded in a 4x4 identity.
+// Conditioning thresholds of the constraint blocks, per arithmetic type.  numpy.linalg.pinv (constraints.py:79, 83,
+// 235, 795) zeroes the singular values below rcond * s_max with rcond = 1e-15: a float64 block gets exactly that
+// rule.  A float32 block of a rank-deficient system carries ~1e-7 of rounding noise where the float64 reference
+// has an exact zero, so its cut is placed above that noise.
+template <typename T> ARB_HD double pinv_rcond() { return sizeof(T) == 4 ? 2e-5 : 1e-15; }
+template <typename T> ARB_HD double pinv_guard() { return sizeof(T) == 4 ? 1e-4 : 1e-11; }
+
+// Inverse of a ND x ND block (ND <= 4) embedded in a 4x4 identity, by pivoted elimination.  Returns false when the
+// pivots say the block is (numerically) rank deficient -- smallest / largest pivot magnitude below pinv_guard --
+// in which case the caller must use pinv_block: the elimination's result is then meaningless.
 template <typename T>
-ARB_HD void inv_block(const T *Y, int ld, int nd, T P[16]) {
+ARB_HD bool inv_block(const T *Y, int ld, int nd, T P[16]) {
     T A[4][4], B[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -460,6 +469,70 @@ ARB_HD void inv_block(const T *Y, int ld, int nd, T P[16]) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) P[4 * i + j] = B[i][j];
+    // the diagonal of A holds the reciprocals of the pivots (rows >= nd: the padding's 1)
+    T rmin = T(0), rmax = T(0);
+    bool first = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nd) {
+            const T r = arb_abs(A[i][i]);
+            rmin = first ? r : (r < rmin ? r : rmin);
+            rmax = first ? r : (r > rmax ? r : rmax);
+            first = false;
+        }
+    // 1/|pivot|: min over max of the pivots = rmin / rmax; inf or NaN anywhere fails the test
+    return (double)rmin > pinv_guard<T>() * (double)rmax && rmax - rmax == T(0);
+}
+
+// Moore-Penrose pseudo-inverse of a ND x ND block (ND <= 4), numpy.linalg.pinv semantics (singular values below
+// rcond * s_max are dropped), by one-sided Jacobi rotations in float64: the columns of U = A are rotated until
+// mutually orthogonal (A V = U), then A^+ = sum_j v_j u_j^T / |u_j|^2 over the kept columns.  The result is embedded
+// in a 4x4 identity like inv_block's.  Rare path (rank-deficient admittance blocks: a planar arm's contact or
+// closed loop): clarity over speed.
+template <typename T>
+ARB_HD void pinv_block(const T *Y, int ld, int nd, T P[16]) {
+    double U[4][4], V[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            U[i][j] = (i < nd && j < nd) ? (double)Y[i * ld + j] : 0.;
+            V[i][j] = (i == j) ? 1. : 0.;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                if (q >= nd) continue;
+                double al = 0., be = 0., ga = 0.;
+                for (int i = 0; i < 4; ++i) { al += U[i][p] * U[i][p]; be += U[i][q] * U[i][q]; ga += U[i][p] * U[i][q]; }
+                const double lim = 1e-15 * sqrt(al * be);
+                if (!(fabs(ga) > lim) || ga == 0.) continue;
+                off = fmax(off, fabs(ga) / fmax(sqrt(al * be), 1e-300));
+                const double zeta = (be - al) / (2. * ga);
+                const double t = (zeta >= 0. ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+                const double c = 1. / sqrt(1. + t * t), sn = c * t;
+                for (int i = 0; i < 4; ++i) {
+                    const double up = U[i][p], uq = U[i][q];
+                    U[i][p] = c * up - sn * uq; U[i][q] = sn * up + c * uq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - sn * vq; V[i][q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-14) break;
+    }
+    double s2[4], s2max = 0.;
+    for (int j = 0; j < 4; ++j) {
+        s2[j] = 0.;
+        for (int i = 0; i < 4; ++i) s2[j] += U[i][j] * U[i][j];
+        if (j < nd) s2max = fmax(s2max, s2[j]);
+    }
+    const double cut = pinv_rcond<T>() * pinv_rcond<T>() * s2max;       // compare squared singular values
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 4; ++k) {
+            double acc = 0.;
+            for (int j = 0; j < 4; ++j)
+                if (j < nd && s2[j] > cut && s2[j] > 0.) acc += V[i][j] * U[k][j] / s2[j];
+            P[4 * i + k] = (i < nd && k < nd) ? (T)acc : (i == k ? T(1) : T(0));
+        }
 }
 
 // Eigenvalues of a real 6x6 matrix: scaling balance + elimination to Hessenberg

@@ -325,3 +325,33 @@ def test_device_narrow_phase_on_host(geom):
         assert np.abs(Rc.reshape(3, 3) - H1[0, 0:3, 0:3]).max() < 1e-12
     if geom == 2:
         assert n_inside > 50
+
+
+@needs_lib
+@pytest.mark.parametrize("dtype,tol", [(_capi.ARB_F64, 1e-9), (_capi.ARB_F32, 2e-3)])
+def test_block_pinv_matches_numpy_pinv(dtype, tol):
+    """The constraint blocks' (pseudo-)inverse as the kernels form it (arb_math.h inv_block + pinv_block, host build)
+    against numpy.linalg.pinv, the call the reference makes (constraints.py:79, 83, 235, 795): regular blocks keep
+    the pivoted elimination, rank-deficient ones (rank 1..nd-1, and the zero block) take the SVD route."""
+    lib = _capi.load()
+    rng = np.random.default_rng(3)
+    for nd in (1, 2, 3, 4):
+        for rank in range(0, nd + 1):
+            for _ in range(6):
+                A = rng.normal(size=(nd, rank)) @ rng.normal(size=(rank, nd)) if rank else np.zeros((nd, nd))
+                A = np.ascontiguousarray(A * 10. ** rng.uniform(-3, 1))
+                P = np.zeros((nd, nd))
+                regular = lib.arb_host_block_pinv(dtype, nd, _capi._dp(A), _capi._dp(P))
+                assert regular == (1 if rank == nd else 0), (nd, rank, regular)
+                ref = np.linalg.pinv(A if dtype == _capi.ARB_F64 else A.astype(np.float32).astype(np.float64),
+                                     rcond=1e-15 if dtype == _capi.ARB_F64 else 2e-5)
+                scale = max(np.abs(ref).max(), 1e-300)
+                if rank == nd:
+                    # regular: conditioning of a random block times the arithmetic's epsilon
+                    cond = np.linalg.cond(A)
+                    assert np.abs(P - ref).max() / scale < max(tol, cond * (1e-15 if dtype == _capi.ARB_F64 else 2e-6)), (nd, cond)
+                else:
+                    assert np.abs(P - ref).max() / scale < tol, (nd, rank, np.abs(P - ref).max() / scale)
+    # the blocks of the reference-generated singular scenarios (tests/golden/g12_singular.npz)
+    g = load_golden("g12_singular.npz")
+    assert g["loop_block_singular_values"][-1] < 1e-12 and g["contact_static_block_singular_values"][-1] < 1e-12

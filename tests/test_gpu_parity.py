@@ -465,6 +465,49 @@ def test_txtytz_gantry(bw_cache, dtype, tol):
         assert rel(q[0], Q[n]) < 1e-8 and rel(dq[0], DQ[n]) < 1e-7
 
 
+@pytest.mark.parametrize("dtype,ftol,tol", [(torch.float64, 1e-6, 1e-8), (torch.float32, 5e-3, 2e-5)])
+def test_singular_blocks_closed_loop(bw_cache, dtype, ftol, tol):
+    """Kinematic loop on a planar arm: the 3x3 admittance of the BallAndSocketConstraint has rank 2, the reference
+    solves it with numpy.linalg.pinv (constraints.py:235).  Every step from the reference's own state, with the
+    reference's force of the previous step as warm start; then the 40-step rollout in float64."""
+    g = load_golden("g12_singular.npz")
+    bw, m, _, _ = bw_cache("loop_arm")
+    Q, DQ, F = g["loop_q"], g["loop_dq"], g["loop_force"]
+    cf0 = np.zeros((40, 1, 4)); cf0[1:, 0, :3] = F[:39]
+    q, dq, cf = gpu_step(bw, Q[:40], DQ[:40], 5e-3, dtype, cforce=cf0)
+    if dtype == torch.float64:
+        rq, rdq = Q[1:], DQ[1:]
+    else:
+        f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        rq, rdq, _ = O.step(m, f(Q[:40]), f(DQ[:40]), 5e-3, cforce=f(cf0))
+    assert rel(q, rq) < tol and rel(dq, rdq) < tol, (rel(q, rq), rel(dq, rdq))
+    assert np.abs(cf[:, 0, :3] - F).max() < ftol * max(1., np.abs(F).max())
+    if dtype == torch.float64:
+        q, dq, cf = gpu_step(bw, Q[:1], DQ[:1], 5e-3, dtype, nsteps=40)
+        assert rel(q[0], Q[40]) < 1e-7 and rel(dq[0], DQ[40]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["contact_static", "contact_slide"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-7), (torch.float32, 2e-5)])
+def test_singular_blocks_planar_contact(bw_cache, tag, dtype, tol):
+    """A planar arm touching a plane: rank-2 4x4 admittance block in SoftFingerContact.solve (pinv at
+    constraints.py:795); release + static steps (high friction) and sliding steps (low friction)."""
+    g = load_golden("g12_singular.npz")
+    bw, m, _, _ = bw_cache("planar_" + tag)
+    Q, DQ = g[tag + "_q"], g[tag + "_dq"]
+    q, dq, cf = gpu_step(bw, Q[:-1], DQ[:-1], 5e-3, dtype)
+    rq, rdq = ref_step(m, Q[:-1], DQ[:-1], 5e-3, dtype, Q[1:], DQ[1:])
+    eq = np.abs(q - rq).max(axis=1) / np.maximum(1., np.abs(rq).max(axis=1))
+    edq = np.abs(dq - rdq).max(axis=1) / np.maximum(1., np.abs(rdq).max(axis=1))
+    print("planar %s %s: max err q %.2e dq %.2e, steps over tol %d" % (tag, dtype, eq.max(), edq.max(), int((edq >= tol).sum())))
+    if tag == "contact_static" or dtype == torch.float64:
+        assert eq.max() < tol and edq.max() < tol
+    else:
+        # sliding on a singular block in float32: the 4x4 solve (constraints.py:834) sees a nearly singular matrix
+        assert (edq < tol).mean() > 0.9 and edq.max() < 1e-2
+    assert g[tag + "_active"].sum() > 50 and float(np.abs(cf).max()) > 1.
+
+
 def test_energy_drift_h5(bw_cache):
     """tests/test_energy_drift.py golden series through the device (float64)."""
     g = load_golden("g5_energy.npz")

@@ -334,3 +334,22 @@ def test_txtytz_gantry():
     qn, dqn, _, dbg = O.step(m, Q[:-1], DQ[:-1], 5e-3, debug=True)
     close(qn, Q[1:], 1e-12); close(dqn, DQ[1:], 1e-11)
     assert np.array_equal(dbg["active"][:len(g["roll_active"])], g["roll_active"][:len(Q) - 1])
+
+
+# -- G12 rank-deficient constraint blocks: numpy.linalg.pinv semantics ------------------
+def test_singular_blocks_loop_and_planar_contact():
+    """A planar arm closed into a loop by a BallAndSocketConstraint (rank-2 3x3 admittance) and touching a
+    plane (rank-2 4x4 admittance): the reference's pinv (constraints.py:235, 795) decides the forces."""
+    g = load_golden("g12_singular.npz")
+    m, _, _ = load_model("loop_arm")
+    Q, DQ = g["loop_q"], g["loop_dq"]
+    q, dq, cf = Q[:1], DQ[:1], None
+    for k in range(40):
+        q, dq, cf = O.step(m, q, dq, 5e-3, cf)
+        close(cf[0, 0, :3], g["loop_force"][k], 1e-9)
+    close(q[0], Q[40], 1e-10); close(dq[0], DQ[40], 1e-9)
+    for tag in ("contact_static", "contact_slide"):
+        m, _, _ = load_model("planar_" + tag)
+        Q, DQ = g[tag + "_q"], g[tag + "_dq"]
+        qn, dqn, cfn = O.step(m, Q[:-1], DQ[:-1], 5e-3)
+        close(qn, Q[1:], 1e-12); close(dqn, DQ[1:], 1e-11); close(cfn[:, 0], g[tag + "_force"], 1e-9)

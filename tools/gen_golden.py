@@ -742,10 +742,83 @@ def gen_txtytz():
     save("g11_txtytz.npz", **out)
 
 
+# ---- G12: rank-deficient constraint blocks -> numpy.linalg.pinv semantics (constraints.py:79, 83, 235, 795) ----
+def gen_singular_blocks():
+    """A planar 3R arm cannot move along z: the 3x3 admittance of a ball-and-socket on its hand has rank 2 and the
+    4x4 admittance of a soft-finger contact rank <= 3.  The reference's pinv handles both; the goldens pin that."""
+    from arboris.core import SubFrame
+    from arboris.shapes import Plane, Point
+    out = {}
+    dt = 5e-3
+    # (a) closed loop: the end effector pinned to the ground point where it starts (kinematic loop)
+    w = World()
+    add_simplearm(w)
+    w.register(WeightController())
+    js = w.getjoints()
+    js['Shoulder'].gpos[0] = 0.9; js['Elbow'].gpos[0] = -1.1; js['Wrist'].gpos[0] = 0.6
+    w.update_geometric()
+    ee = w.getframes()['EndEffector']
+    anchor = SubFrame(w.ground, Hg.transl(*ee.pose[0:3, 3]), name='anchor')
+    c0 = BallAndSocketConstraint(frames=(anchor, ee))
+    w.register(c0)
+    w.init()
+    m = save_model("loop_arm", w)
+    qs, dqs, fr = [], [], []
+    for _ in range(40):
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+        fr.append(c0._force.copy())
+        w.integrate(dt)
+    a, b = get_state(w, m)
+    qs.append(a); dqs.append(b)
+    out["loop_q"], out["loop_dq"], out["loop_force"] = np.array(qs), np.array(dqs), np.array(fr)
+    w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+    Y = c0.jacobian @ w._admittance @ c0.jacobian.T
+    sv = np.linalg.svd(Y, compute_uv=False)
+    out["loop_block_singular_values"] = sv
+    print("  loop_arm: singular values of the 3x3 block %s, max |f| %.2f" % (sv, np.abs(out["loop_force"]).max()))
+    # (b) the arm comes down onto a plane: soft-finger contact at the end effector, once with a high friction
+    #     coefficient (release and static branches) and once with a low one (sliding branch on a singular block)
+    for tag, mu in (("contact_static", 3.0), ("contact_slide", 1.0)):
+        w = World()
+        w.register(Plane(w.ground, (0., 1., 0., -1.03), 'floor'))
+        add_simplearm(w)
+        w.register(WeightController())
+        js = w.getjoints()
+        js['Shoulder'].gpos[0] = 2.6; js['Elbow'].gpos[0] = 0.3; js['Wrist'].gpos[0] = 0.2
+        ee = w.getframes()['EndEffector']
+        w.register(Point(ee, 'tip'))
+        cons = get_all_contacts(w, friction_coeff=mu)
+        assert len(cons) == 1
+        w.register(cons[0])
+        w.init()
+        m = save_model("planar_" + tag, w)
+        qs, dqs, fr, act = [], [], [], []
+        sv = None
+        for step in range(120):
+            a, b = get_state(w, m)
+            qs.append(a); dqs.append(b)
+            w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+            act.append(bool(cons[0].is_active())); fr.append(cons[0]._force.copy())
+            if act[-1] and sv is None:
+                Y = cons[0].jacobian @ w._admittance @ cons[0].jacobian.T
+                sv = np.linalg.svd(Y, compute_uv=False)
+            w.integrate(dt)
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        out[tag + "_q"], out[tag + "_dq"] = np.array(qs), np.array(dqs)
+        out[tag + "_force"], out[tag + "_active"] = np.array(fr), np.array(act)
+        out[tag + "_block_singular_values"] = sv
+        print("  planar %s: active steps %d, max |f| %.2f, singular values of the 4x4 block %s"
+              % (tag, int(np.sum(act)), np.abs(out[tag + "_force"]).max(), sv))
+    save("g12_singular.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz, g12=gen_singular_blocks)
     for k in which:
         table[k]()
