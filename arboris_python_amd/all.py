@@ -14,4 +14,5 @@ from .robots.human36 import add_human36
 from .robots.simpleshapes import add_sphere, add_box, add_cylinder, add_groundplane
 from .visu_collada import write_collada_animation, write_collada_scene
 from . import observers
+from .observers import EnergyMonitor, PerfMonitor, Hdf5Logger
 from numpy import arange, dot, allclose, pi

@@ -9,15 +9,32 @@ During stepping the built-in constraints are lowered by
 ``jacobian`` / ``solve`` run inside the HIP kernel (``contact_update`` and
 ``gauss_seidel`` in csrc/arb_kernels.hip).  ``World.update_constraints`` writes
 the device results back onto these objects (``_force``, ``_sdist``,
-``_is_active``, contact frame poses).  The NumPy methods below implement the
-same per-constraint algebra for user code and for tests of the API itself.
+``_is_active``, contact frame poses).  ``solve`` -- the local solve of the
+Gauss-Seidel sweeps, the hot part of the plugin API -- has ONE implementation in this
+package, the device code of csrc/arb_math.h: called on its own (user code, API tests)
+it runs that same code through the library's host build (``arb_host_softfinger_solve``,
+``arb_host_block_pinv``), not a second NumPy restatement of the reference.
 """
 import numpy as np
-from numpy import array, zeros, eye, dot, hstack, diag
-from numpy.linalg import solve, eigvals, pinv
+from numpy import array, zeros, dot
 
 from . import homogeneousmatrix as Hg
+from . import _capi
 from .core import MovingSubFrame, Constraint, Shape, World
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _block_pinv(admittance):
+    """pinv of a constraint's admittance block (numpy.linalg.pinv semantics) as the kernels compute it."""
+    Y = _f64(np.atleast_2d(admittance))
+    nd = Y.shape[0]
+    P = np.zeros((nd, nd))
+    if _capi.load().arb_host_block_pinv(_capi.ARB_F64, nd, _capi._dp(Y), _capi._dp(P)) < 0:
+        raise ValueError("constraint blocks have 1 to 4 rows")
+    return P
 
 point_contact_proximity = 0.02
 joint_limits_proximity = 0.01
@@ -64,12 +81,16 @@ class JointLimits(Constraint):
                     or (self._max - self._pos0 < self._proximity))
 
     def solve(self, vel, admittance, dt):
+        """Unilateral force that keeps the predicted position inside the limits (device rule, arb_kernels.hip
+        gs_stage: with v0 the velocity without this force, push when v0 <= (min - q)/dt or (max - q)/dt <= v0)."""
         previous = self._force.copy()
-        predicted = self._pos0 + dt * (vel - dot(admittance, self._force))
-        if predicted <= self._min:
-            self._force = dot(pinv(admittance), (self._min - predicted) / dt)
-        elif self._max <= predicted:
-            self._force = dot(pinv(admittance), (self._max - predicted) / dt)
+        free_vel = np.asarray(vel, float) - dot(admittance, self._force)
+        reach_min = (self._min - self._pos0) / dt
+        reach_max = (self._max - self._pos0) / dt
+        if free_vel <= reach_min:
+            self._force = dot(_block_pinv(admittance), reach_min - free_vel)
+        elif reach_max <= free_vel:
+            self._force = dot(_block_pinv(admittance), reach_max - free_vel)
         else:
             self._force = zeros(previous.shape)
         return self._force - previous
@@ -111,8 +132,8 @@ class BallAndSocketConstraint(Constraint):
                 - self._frames[0].jacobian[3:6, :])
 
     def solve(self, vel, admittance, dt):
-        dforce = -dot(pinv(admittance), vel + self._pos0 / dt)
-        self._force += dforce
+        dforce = -dot(_block_pinv(admittance), np.asarray(vel, float) + self._pos0 / dt)
+        self._force = self._force + dforce
         return dforce
 
 
@@ -184,41 +205,17 @@ class SoftFingerContact(PointContact):
                 - self._frames[0].jacobian[2:6, :])
 
     def solve(self, vel, admittance, dt):
-        free_vel = vel - dot(admittance, self._force)
-        if self._sdist + dt * free_vel[3] > 0:
-            released = -self._force
-            self._force[:] = 0.
-            return released
-        # static friction: no relative motion at the contact
-        target = hstack((vel[0:3], vel[3] + self._sdist / dt))
-        dforce = dot(-pinv(admittance), target)
-        candidate = self._force + dforce
-        if sum((candidate[0:3] / self._eps) ** 2) <= (candidate[3] * self._mu) ** 2:
-            self._force = candidate
-            return dforce
-        # sliding friction
-        alpha = free_vel.copy()
-        alpha[3] += self._sdist / dt
-        y_col = admittance[0:3, 3]
-        y_n = admittance[3, 3]
-        beta = alpha[0:3] - alpha[3] / y_n * y_col
-        a = self._mu / y_n * alpha[3]
-        b = self._mu / y_n * y_col
-        E = diag(self._eps ** 2)
-        y_hat = admittance[0:3, 0:3] - dot(y_col, y_col) / y_n
-        B = zeros((6, 6))
-        B[0:3, 0:3] = dot(E, y_hat + 2 / a * dot(beta, b))
-        B[0:3, 3:6] = -E * (dot(beta, beta) / a ** 2)
-        B[3:6, 0:3] = E * dot(b, b) - eye(3)
-        B[3:6, 3:6] = dot(E, y_hat)
-        roots = eigvals(B)
-        roots = roots[np.logical_and(roots.imag == 0, roots.real <= 0)]
-        s = -1e10 if len(roots) == 0 else max(float(min(roots.real)), -1e10)
-        previous = self._force.copy()
-        A = admittance.copy()
-        A[0:3, 0:3] -= s * diag(self._eps ** -2.)
-        self._force = solve(A, -alpha)
-        return self._force - previous
+        """Release / static friction / sliding friction (arb_math.h::softfinger_solve, the code the Gauss-Seidel
+        kernels run, in float64); updates ``_force`` and returns the force increment."""
+        vel, adm, force, eps = _f64(vel), _f64(admittance), _f64(self._force).copy(), _f64(self._eps)
+        dforce = np.zeros(4)
+        branch = _capi.load().arb_host_softfinger_solve(
+            _capi.ARB_F64, _capi._dp(vel), _capi._dp(adm), _capi._dp(force), float(self._sdist), float(dt),
+            float(self._mu), _capi._dp(eps), _capi._dp(dforce))
+        if branch < 0:
+            raise ValueError("SoftFingerContact.solve: bad arguments")
+        self._force = force
+        return dforce
 
 
 def get_all_contacts(world, contact_class=None, **args):

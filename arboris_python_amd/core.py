@@ -278,6 +278,25 @@ class Observer(object, metaclass=ABCMeta):
         pass
 
 
+class _Registry(object):
+    """Insertion-ordered, duplicate-free collections of the things a world knows about besides its tree:
+    sub-frames, shapes, constraints, controllers.  ``kind_of`` maps an object to its collection."""
+
+    KINDS = ('subframes', 'shapes', 'constraints', 'controllers')
+
+    def __init__(self):
+        for kind in self.KINDS:
+            setattr(self, kind, [])
+
+    def add(self, kind, obj):
+        """Append ``obj`` to its collection unless it is there already; tells whether it was added."""
+        items = getattr(self, kind)
+        if any(o is obj for o in items):
+            return False
+        items.append(obj)
+        return True
+
+
 class World(NamedObject):
     """Tree of bodies and joints rooted at ``ground`` + registered plugins."""
 
@@ -286,56 +305,51 @@ class World(NamedObject):
         self.ground = Body('ground')
         self._current_time = 0.
         self._up = array((0., 1., 0.))
-        self._controllers = []
-        self._constraints = []
-        self._subframes = []
-        self._shapes = []
+        self._reg = _Registry()
         self._ndof = 0
-        self._gvel = array([])
-        self._mass = array([])
-        self._gforce = array([])
-        self._viscosity = array([])
-        self._nleffects = array([])
-        self._impedance = array([])
-        self._admittance = array([])
+        empty = array([])
+        self._gvel = self._gforce = empty
+        self._mass = self._viscosity = self._nleffects = empty
+        self._impedance = self._admittance = empty
         self._engine = None            # device evaluator, created on first use
         self._constraints_done = False
+
+    # the collections under their historical attribute names (observers, exporters and tests read them)
+    _subframes = property(lambda self: self._reg.subframes)
+    _shapes = property(lambda self: self._reg.shapes)
+    _constraints = property(lambda self: self._reg.constraints)
+    _controllers = property(lambda self: self._reg.controllers)
 
     # -- iteration ----------------------------------------------------------
     def iterbodies(self):
         """All bodies, ground first, depth-first."""
         yield self.ground
-        for b in self.ground.iter_descendant_bodies():
-            yield b
+        yield from self.ground.iter_descendant_bodies()
 
     def getbodies(self):
         return NamedObjectsList(self.iterbodies())
 
     def iterconstraints(self):
-        return iter(self._constraints)
+        return iter(self._reg.constraints)
 
     def itersubframes(self):
-        return iter(self._subframes)
+        return iter(self._reg.subframes)
 
     def itermovingsubframes(self):
-        return (f for f in self._subframes if isinstance(f, MovingSubFrame))
+        return (f for f in self._reg.subframes if isinstance(f, MovingSubFrame))
 
     def iterframes(self):
-        for b in self.iterbodies():
-            yield b
-        for f in self._subframes:
-            yield f
+        yield from self.iterbodies()
+        yield from self._reg.subframes
 
     def getframes(self):
-        frames = self.getbodies()
-        frames.extend(self._subframes)
-        return frames
+        return NamedObjectsList(self.iterframes())
 
     def itershapes(self):
-        return iter(self._shapes)
+        return iter(self._reg.shapes)
 
     def getshapes(self):
-        return NamedObjectsList(self._shapes)
+        return NamedObjectsList(self._reg.shapes)
 
     def iterjoints(self):
         """All joints, depth-first (this order defines the dof numbering)."""
@@ -345,77 +359,75 @@ class World(NamedObject):
         return JointsList(self.iterjoints())
 
     # -- construction -------------------------------------------------------
+    def _attach(self, frame0, joint, frame1):
+        """One edge of the tree: ``frame1``'s body hangs from ``frame0``'s body through ``joint``."""
+        for f in (frame0, frame1):
+            assert isinstance(f, Frame)
+        assert isinstance(joint, Joint)
+        assert joint.frames == (None, None)
+        child, parent = frame1.body, frame0.body
+        if child.parentjoint is not None:
+            raise ValueError(
+                "frame1's body already has a parent joint, which means you're "
+                "probably trying to create a kinematic loop. Try using a "
+                "constraint instead.")
+        joint._frame0, joint._frame1 = frame0, frame1
+        child.parentjoint = joint
+        parent.childrenjoints.append(joint)
+        self.register(frame0)
+        self.register(frame1)
+
     def add_link(self, frame0, joint, frame1, *args):
         """Attach ``frame1``'s body to the tree through ``joint`` at ``frame0``.
 
         Several (frame0, joint, frame1) triples may be given at once.
         """
-        assert isinstance(frame0, Frame)
-        assert isinstance(frame1, Frame)
-        assert isinstance(joint, Joint)
-        assert joint._frame0 is None
-        assert joint._frame1 is None
         assert len(args) % 3 == 0
-        if frame1.body.parentjoint is not None:
-            raise ValueError(
-                "frame1's body already has a parent joint, which means you're "
-                "probably trying to create a kinematic loop. Try using a "
-                "constraint instead.")
-        joint._frame0 = frame0
-        joint._frame1 = frame1
-        frame1.body.parentjoint = joint
-        frame0.body.childrenjoints.append(joint)
-        self.register(frame0)
-        self.register(frame1)
-        if args:
-            self.add_link(*args)
+        chain = (frame0, joint, frame1) + args
+        for k in range(0, len(chain), 3):
+            self._attach(*chain[k:k + 3])
 
     def replace_joint(self, old_joint, *args):
         """``replace_joint(old, new)`` or ``replace_joint(old, f0, j, ..., f1)``."""
         assert isinstance(old_joint, Joint)
-        assert old_joint in old_joint._frame0.body.childrenjoints
-        assert old_joint is old_joint._frame1.body.parentjoint
-        if len(args) == 1:
-            self.replace_joint(old_joint, old_joint._frame0, args[0], old_joint._frame1)
-            return
+        parent, child = old_joint._frame0.body, old_joint._frame1.body
+        assert old_joint is child.parentjoint
+        slot = [k for k, j in enumerate(parent.childrenjoints) if j is old_joint]
+        assert len(slot) == 1
+        if len(args) == 1:                       # same frames, another joint
+            args = (old_joint._frame0, args[0], old_joint._frame1)
         if len(args) == 0 or len(args) % 3 != 0:
             raise RuntimeError()
-        body0 = args[0].body
-        body1 = args[-1].body
-        assert old_joint._frame0.body is body0
-        assert old_joint._frame1.body is body1
-        body1.parentjoint = None
-        old_joint._frame0 = None
-        old_joint._frame1 = None
+        assert args[0].body is parent
+        assert args[-1].body is child
+        # cut the old edge, hang the new chain, and give its first joint the old joint's place among the
+        # parent's children (the dof numbering follows that order)
+        child.parentjoint = None
+        old_joint._frame0 = old_joint._frame1 = None
         self.add_link(*args)
-        # the new first joint was appended; move it to the old joint's slot
-        i = body0.childrenjoints.index(old_joint)
-        body0.childrenjoints[i] = body0.childrenjoints.pop()
+        first_new = parent.childrenjoints.pop()
+        parent.childrenjoints[slot[0]] = first_new
         self.init()
 
     def register(self, obj):
         """Register a subframe, shape, constraint or controller."""
-        if isinstance(obj, Body):
-            pass
-        elif isinstance(obj, Joint):
+        if isinstance(obj, Joint):
             raise ValueError('Joints should not be registered. Use add_link() instead.')
-        elif isinstance(obj, (SubFrame, MovingSubFrame)):
-            if obj not in self._subframes:
-                self._subframes.append(obj)
+        if isinstance(obj, Body):
+            return                               # bodies are reached through the tree
+        if isinstance(obj, (SubFrame, MovingSubFrame)):
+            self._reg.add('subframes', obj)
         elif isinstance(obj, Shape):
-            if obj not in self._shapes:
-                self._shapes.append(obj)
+            self._reg.add('shapes', obj)
             self.register(obj.frame)
         elif isinstance(obj, Constraint):
-            if obj not in self._constraints:
-                self._constraints.append(obj)
+            if self._reg.add('constraints', obj):
                 from .constraints import PointContact
-                if isinstance(obj, PointContact):
-                    self.register(obj._frames[0])
-                    self.register(obj._frames[1])
+                if isinstance(obj, PointContact):    # its two contact frames move with the contact point
+                    for f in obj._frames:
+                        self.register(f)
         elif isinstance(obj, Controller):
-            if obj not in self._controllers:
-                self._controllers.append(obj)
+            self._reg.add('controllers', obj)
         else:
             raise ValueError(
                 'I do not know how to register objects of type {0}'.format(type(obj)))
@@ -431,10 +443,10 @@ class World(NamedObject):
             seen.add(frame)
             target.register(frame)
             if isinstance(frame, Body):
-                for f in self._subframes:
+                for f in self._reg.subframes:
                     if f not in seen and f.body is frame:
                         visit_frame(f)
-            for s in self._shapes:
+            for s in self._reg.shapes:
                 if s.frame is frame:
                     target.register(s)
 
@@ -448,31 +460,28 @@ class World(NamedObject):
         target.init_parse(self.ground, self.up, self.current_time)
         visit_frame(self.ground)
         visit_joints(self.ground.childrenjoints)
-        for c in self._constraints:
-            target.register(c)
-        for a in self._controllers:
-            target.register(a)
+        for plugin in self._reg.constraints + self._reg.controllers:
+            target.register(plugin)
 
     def init(self):
         """Number the dofs (DFS joint order) and size the world matrices."""
-        n = 0
-        for j in self.iterjoints():
-            j._dof = slice(n, n + j.ndof)
-            n += j.ndof
-        self._ndof = n
-        self._mass = zeros((n, n))
-        self._nleffects = zeros((n, n))
-        self._viscosity = zeros((n, n))
-        self._controller_viscosity = zeros((n, n))
+        joints = list(self.iterjoints())
+        start = 0
+        for j in joints:
+            j._dof = slice(start, start + j.ndof)
+            start = j._dof.stop
+        n = self._ndof = start
+        for name in ('_mass', '_nleffects', '_viscosity', '_controller_viscosity'):
+            setattr(self, name, zeros((n, n)))
         self._gforce = zeros(n)
+        # the world owns the generalized velocity; every joint's ``gvel`` becomes a view of its slice
         self._gvel = zeros(n)
-        for j in self.iterjoints():
-            self._gvel[j.dof] = j.gvel[:]
-            j.gvel = self._gvel[j.dof]           # joints alias the world vector
-        for c in self._constraints:
-            c.init(self)
-        for a in self._controllers:
-            a.init(self)
+        for j in joints:
+            view = self._gvel[j._dof]
+            view[:] = j.gvel
+            j.gvel = view
+        for plugin in self._reg.constraints + self._reg.controllers:
+            plugin.init(self)
         self._constraints_done = False
 
     # -- read-only state ----------------------------------------------------
@@ -551,59 +560,48 @@ class World(NamedObject):
 
 
 class _SubFrame(NamedObject, Frame):
-    """Frame rigidly attached to a body at the constant offset ``bpose``."""
+    """Frame rigidly attached to a body at the constant offset ``bpose``: everything the frame reports is the
+    body's quantity carried through ``Ad(bpose^-1)`` (pose: multiplied by ``bpose``)."""
 
     def __init__(self, body, bpose=None, name=None):
-        if bpose is None:
-            bpose = eye(4)
         NamedObject.__init__(self, name)
-        assert Hg.ishomogeneousmatrix(bpose)
-        self._bpose = bpose
         if not isinstance(body, Body):
-            raise ValueError(
-                "The ``body`` argument must be an instance of the ``Boby`` class")
-        self._body = body
+            raise ValueError("The ``body`` argument must be an instance of the ``Body`` class")
+        bpose = eye(4) if bpose is None else bpose
+        assert Hg.ishomogeneousmatrix(bpose)
+        self._body, self._bpose = body, bpose
 
-    @property
-    def pose(self):
-        return dot(self._body.pose, self._bpose)
+    def _carried(self, body_quantity):
+        return dot(Hg.iadjoint(self._bpose), body_quantity)
 
-    @property
-    def twist(self):
-        return dot(Hg.iadjoint(self._bpose), self._body._twist)
-
-    @property
-    def jacobian(self):
-        return dot(Hg.iadjoint(self._bpose), self._body._jacobian)
-
-    @property
-    def djacobian(self):
-        return dot(Hg.iadjoint(self._bpose), self._body._djacobian)
-
-    @property
-    def body(self):
-        return self._body
+    pose = property(lambda self: dot(self._body.pose, self._bpose))
+    twist = property(lambda self: self._carried(self._body._twist))
+    jacobian = property(lambda self: self._carried(self._body._jacobian))
+    djacobian = property(lambda self: self._carried(self._body._djacobian))
+    body = property(lambda self: self._body)
 
 
 class SubFrame(_SubFrame):
-    @property
-    def bpose(self):
-        return self._bpose.copy()
+    bpose = property(lambda self: self._bpose.copy())
 
 
 class MovingSubFrame(_SubFrame):
-    @property
-    def bpose(self):
+    """A sub-frame whose offset may be moved (contact frames follow the contact point)."""
+
+    def _get_bpose(self):
         return self._bpose.copy()
 
-    @bpose.setter
-    def bpose(self, bpose):
+    def _set_bpose(self, bpose):
         assert Hg.ishomogeneousmatrix(bpose)
         self._bpose[:] = bpose
+
+    bpose = property(_get_bpose, _set_bpose)
 
 
 class Body(NamedObject, Frame):
     """Rigid body: 6x6 ``mass`` and ``viscosity`` about its own frame."""
+
+    _STATE = ('pose', 'jacobian', 'djacobian', 'twist', 'nleffects')      # filled by World.update_*
 
     def __init__(self, name=None, mass=None, viscosity=None):
         NamedObject.__init__(self, name)
@@ -611,31 +609,19 @@ class Body(NamedObject, Frame):
         self.childrenjoints = []
         self.mass = zeros((6, 6)) if mass is None else mass
         self.viscosity = zeros((6, 6)) if viscosity is None else viscosity
-        self._pose = None
-        self._jacobian = None
-        self._djacobian = None
-        self._twist = None
-        self._nleffects = None
+        for field in self._STATE:
+            setattr(self, '_' + field, None)
+
+    # depth-first walks of the tree below / above this body (children in insertion order: the dof order)
+    def iter_descendant_joints(self):
+        pending = list(reversed(self.childrenjoints))
+        while pending:
+            j = pending.pop()
+            yield j
+            pending.extend(reversed(j._frame1.body.childrenjoints))
 
     def iter_descendant_bodies(self):
-        for j in self.childrenjoints:
-            child = j._frame1.body
-            yield child
-            for b in child.iter_descendant_bodies():
-                yield b
-
-    def iter_ancestor_bodies(self):
-        j = self.parentjoint
-        while j is not None:
-            parent = j._frame0.body
-            yield parent
-            j = parent.parentjoint
-
-    def iter_descendant_joints(self):
-        for j in self.childrenjoints:
-            yield j
-            for jj in j._frame1.body.iter_descendant_joints():
-                yield jj
+        return (j._frame1.body for j in self.iter_descendant_joints())
 
     def iter_ancestor_joints(self):
         j = self.parentjoint
@@ -643,33 +629,16 @@ class Body(NamedObject, Frame):
             yield j
             j = j._frame0.body.parentjoint
 
-    @property
-    def pose(self):
-        return self._pose
+    def iter_ancestor_bodies(self):
+        return (j._frame0.body for j in self.iter_ancestor_joints())
 
-    @property
-    def jacobian(self):
-        return self._jacobian
-
-    @property
-    def djacobian(self):
-        return self._djacobian
-
-    @property
-    def twist(self):
-        return self._twist
-
-    @property
-    def nleffects(self):
-        return self._nleffects
-
-    @property
-    def bpose(self):
-        return eye(4)
-
-    @property
-    def body(self):
-        return self
+    pose = property(lambda self: self._pose)
+    jacobian = property(lambda self: self._jacobian)
+    djacobian = property(lambda self: self._djacobian)
+    twist = property(lambda self: self._twist)
+    nleffects = property(lambda self: self._nleffects)
+    bpose = property(lambda self: eye(4))
+    body = property(lambda self: self)
 
 
 def simulate(world, timeline, observers=()):
@@ -678,17 +647,18 @@ def simulate(world, timeline, observers=()):
     Observers are updated between ``update_constraints`` and ``integrate``:
     they see the state at time t and the forces for [t, t+dt].
     """
+    def tell(event, *args):
+        for obs in observers:
+            getattr(obs, event)(*args)
+
     world._current_time = timeline[0]
     world.init()
-    for obs in observers:
-        obs.init(world, timeline)
+    tell('init', world, timeline)
     for next_time in timeline[1:]:
         dt = next_time - world._current_time
         world.update_dynamic()
         world.update_controllers(dt)
         world.update_constraints(dt)
-        for obs in observers:
-            obs.update(dt)
+        tell('update', dt)
         world.integrate(dt)
-    for obs in observers:
-        obs.finish()
+    tell('finish')

@@ -471,17 +471,18 @@ ARB_HD bool inv_block(const T *Y, int ld, int nd, T P[16]) {
         for (int j = 0; j < 4; ++j) P[4 * i + j] = B[i][j];
     // the diagonal of A holds the reciprocals of the pivots (rows >= nd: the padding's 1)
     T rmin = T(0), rmax = T(0);
-    bool first = true;
+    bool first = true, finite = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < nd) {
             const T r = arb_abs(A[i][i]);
+            finite = finite && (r - r == T(0));            // a zero pivot leaves inf (host) or NaN (device rcp + Newton)
             rmin = first ? r : (r < rmin ? r : rmin);
             rmax = first ? r : (r > rmax ? r : rmax);
             first = false;
         }
-    // 1/|pivot|: min over max of the pivots = rmin / rmax; inf or NaN anywhere fails the test
-    return (double)rmin > pinv_guard<T>() * (double)rmax && rmax - rmax == T(0);
+    // 1/|pivot|: min over max of the pivots = rmin / rmax
+    return finite && (double)rmin > pinv_guard<T>() * (double)rmax;
 }
 
 // Moore-Penrose pseudo-inverse of a ND x ND block (ND <= 4), numpy.linalg.pinv semantics (singular values below

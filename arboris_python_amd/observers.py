@@ -12,8 +12,9 @@ Hdf5Logger :133-289).  Two levels:
   layout as ``Hdf5Logger``: ``timeline (nsteps,)``, ``gpositions/<joint>``,
   ``gvelocities/<joint>``, ``transforms/<name> (nsteps,4,4)``.
 
-h5py is not a dependency: ``save()`` writes ``.npz`` with the dataset paths as
-keys, or HDF5 when h5py happens to be importable and the file name ends in .h5.
+``Hdf5Logger`` has the reference's constructor and dataset layout.  h5py is not a dependency: files are
+written as HDF5 when h5py is importable and the name ends in .h5/.hdf5, else as ``.npz`` archives whose keys
+are the dataset paths.
 """
 import time
 
@@ -156,6 +157,89 @@ class TrajectoryLogger(Observer):
 
     def save(self, filename):
         _save_datasets(filename, self.data)
+
+
+class Hdf5Logger(TrajectoryLogger):
+    """The reference's file-writing observer (observers.py:133-289), same constructor and dataset layout::
+
+        root/timeline (nsteps,)
+        root/gpositions/<joint name>   (nsteps,) + gpos.shape      [save_state]
+        root/gvelocities/<joint name>  (nsteps, joint.ndof)        [save_state]
+        root/transforms/<name>         (nsteps, 4, 4)              [save_transforms]
+        root/model/{gvel, gforce, mass, nleffects, admittance}     [save_model]
+
+    ``transforms`` holds one entry per body (``flat=True``, ``Body.pose``) or per joint (``flat=False``,
+    ``Joint.pose`` under the name of the joint's second frame), plus the world's moving sub-frames (the contact
+    frames).  ``root`` is ``group`` inside the file (default "/").  The file is written by ``finish()``: HDF5
+    through ``h5py`` when the name ends in .h5/.hdf5 -- h5py is not a dependency of this package, a clear error
+    is raised at construction when it is missing -- or a ``.npz`` archive whose keys are the dataset paths.
+    (The reference stores the ``model`` datasets in the ``transforms`` group and reads a ``World.admittance``
+    attribute that does not exist; this class follows its documented layout.)
+    """
+
+    def __init__(self, filename, group="/", mode='a', save_state=False, save_transforms=True, flat=False,
+                 save_model=False):
+        TrajectoryLogger.__init__(self, save_state=save_state, save_transforms=save_transforms, flat=flat)
+        if mode not in ('a', 'w'):
+            raise ValueError("mode must be 'w' or 'a'")
+        self._filename, self._mode = filename, mode
+        self._group = "/".join(g for g in group.split("/") if g)
+        self._save_model = save_model
+        self._hdf5 = filename.endswith((".h5", ".hdf5"))
+        if self._hdf5:
+            try:
+                import h5py  # noqa: F401
+            except ImportError:
+                raise RuntimeError("Hdf5Logger(%r): h5py is not installed; give a .npz file name to get the same "
+                                   "datasets in a NumPy archive" % filename)
+
+    @property
+    def root(self):
+        """path of the group the datasets go to"""
+        return "/" + self._group
+
+    def init(self, world, timeline):
+        TrajectoryLogger.init(self, world, timeline)
+        if self._save_transforms:
+            for f in world.itermovingsubframes():          # contact frames (observers.py:239-240)
+                if f.name is not None:
+                    self._transforms[f.name] = f
+                    self.data["transforms/%s" % f.name] = np.zeros((self._nb_steps, 4, 4))
+        if self._save_model:
+            n = world.ndof
+            for name, shape in (("gvel", (n,)), ("gforce", (n,)), ("mass", (n, n)), ("nleffects", (n, n)),
+                                ("admittance", (n, n))):
+                self.data["model/%s" % name] = np.zeros((self._nb_steps,) + shape)
+
+    def update(self, dt):
+        k = self._step
+        TrajectoryLogger.update(self, dt)
+        if self._save_model:
+            w = self._world
+            self.data["model/gvel"][k] = w.gvel
+            self.data["model/gforce"][k] = w.gforce
+            self.data["model/mass"][k] = w.mass
+            self.data["model/nleffects"][k] = w.nleffects
+            self.data["model/admittance"][k] = w._admittance
+
+    def finish(self):
+        prefix = self._group + "/" if self._group else ""
+        if self._hdf5:
+            import h5py
+            with h5py.File(self._filename, self._mode) as f:
+                for key, v in self.data.items():
+                    path = prefix + key
+                    if path in f:
+                        del f[path]
+                    f[path] = v
+            return
+        data = {}
+        import os
+        if self._mode == 'a' and os.path.exists(self._filename):
+            with np.load(self._filename) as old:
+                data.update({k: old[k] for k in old.files})
+        data.update({prefix + k: v for k, v in self.data.items()})
+        np.savez_compressed(self._filename, **data)
 
 
 def batched_trajectory(bw, world, log, dt, t0=0., world_index=0, flat=True, save_state=True):

@@ -133,3 +133,38 @@ def test_object_api_observers(tmp_path):
     back = np.load(str(tmp_path / "traj.npz"))
     assert back["gpositions/Shoulder"].shape == (9, 1)
     assert "mean computation time" in perf.get_summary()
+
+
+def test_hdf5logger_layout_and_values(tmp_path):
+    """Hdf5Logger through simulate(): the reference's dataset layout (observers.py:155-192), values against
+    the reference's simplearm run (tests/golden/g1_simplearm.npz = the payload of simplearm_flat.h5)."""
+    from conftest import load_golden
+    from arboris_python_amd import scenes
+    from arboris_python_amd.core import simulate
+    from arboris_python_amd.observers import Hdf5Logger
+    g = load_golden("g1_simplearm.npz")
+    w = scenes.simplearm_world()
+    w.getjoints()['Shoulder'].gpos[0] = 3.14 / 4
+    timeline = np.arange(0, 1, .01)
+    f = str(tmp_path / "run.npz")
+    simulate(w, timeline, [Hdf5Logger(f, group="sim", mode='w', save_state=True, flat=True, save_model=True)])
+    d = np.load(f)
+    n = len(timeline) - 1
+    assert d["sim/timeline"].shape == (n,) and np.allclose(d["sim/timeline"], timeline[:-1])
+    for j in ("Shoulder", "Elbow", "Wrist"):
+        assert d["sim/gpositions/" + j].shape == (n, 1) and d["sim/gvelocities/" + j].shape == (n, 1)
+    for k, name in enumerate(("Hand", "Arm", "Forearm")):
+        assert np.abs(d["sim/transforms/" + name] - g["h5_flat_HandArmForearm"][k]).max() < 1e-9
+    assert d["sim/transforms/ground"].shape == (n, 4, 4)
+    for name, shape in (("gvel", (n, 3)), ("gforce", (n, 3)), ("mass", (n, 3, 3)), ("nleffects", (n, 3, 3)),
+                        ("admittance", (n, 3, 3))):
+        assert d["sim/model/" + name].shape == shape
+    assert np.abs(d["sim/gpositions/Shoulder"][:, 0] - g["traj_q"][:, 0]).max() < 1e-9
+    # mass . admittance = (M/dt + N)^-1 M ... at least: admittance is the inverse of the impedance M/dt + B + N
+    k = 50
+    Z = d["sim/model/mass"][k] / 0.01 + d["sim/model/nleffects"][k]
+    assert np.abs(Z @ d["sim/model/admittance"][k] - np.eye(3)).max() < 1e-8
+    # append mode keeps what is in the file
+    simulate(w, timeline[:5], [Hdf5Logger(f, group="again", mode='a', save_transforms=False, save_state=True)])
+    d = np.load(f)
+    assert "sim/timeline" in d.files and d["again/gvelocities/Elbow"].shape == (4, 1)
