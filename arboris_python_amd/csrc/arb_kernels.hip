@@ -79,7 +79,9 @@
 
 struct Layout {      // offsets in elements of T inside the wave's LDS block
     int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, total;
+    int lscan;       // phase B forms the subtree sums from a prefix table in LDS (small trees) instead of a DPP scan
 };
+#define TB_STRIDE 70     // float64 per body in that table: 63 (69 inspect) accumulators, padded; 560 B rows: bank-conflict free
 
 // exact (bit pattern) equality, also true for identical NaNs
 __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_int(a) == __float_as_int(b); }
@@ -235,6 +237,10 @@ __device__ __forceinline__ void mat6_vec(const T *__restrict__ M, const T x[6], 
 }
 
 // f(integral_constant<int, N-1>), ..., f(integral_constant<int, 0>): a loop whose index is a constant expression
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_asc(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
 template <int... I, typename F>
 __device__ __forceinline__ void static_for_desc(std::integer_sequence<int, I...>, F &&f) {
     (f(std::integral_constant<int, (int)sizeof...(I) - 1 - I>{}), ...);
@@ -1134,6 +1140,42 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 // dof lanes (lane k takes the composite of body(k)), so that only one element is in flight.
                 const bool two_rows = nb > 16, four_rows = nb > 32;
                 const int hi = (lane < nb) ? lane + mp->subsize[lane] - 1 : lane;
+                if (L.lscan) {
+                    // Small trees (the table fits the staging area): the same inclusive prefix sums, formed in LDS with
+                    // the roles transposed -- lane = accumulator, a serial pass over the bodies: nb additions in all
+                    // instead of 4-6 DPP steps + two lane exchanges per accumulator (~210 instead of ~1700 wave
+                    // instructions for human36; round 2).  (a) lane = body stores its accumulators as a table row;
+                    // (b) lane = accumulator i runs the prefix down its column; (c) lane = dof k reads the two rows that
+                    // bound the subtree of body(k) and subtracts, element by element as its products consume them.
+                    typedef double D2 __attribute__((ext_vector_type(2)));
+                    double *TB = STG;
+                    if (lane < nb) {
+                        D2 *row = reinterpret_cast<D2 *>(TB + TB_STRIDE * lane);
+#pragma unroll
+                        for (int i2 = 0; i2 < (NACC + 1) / 2; ++i2) {
+                            D2 v; v.x = Acc[2 * i2]; v.y = (2 * i2 + 1 < NACC) ? Acc[2 * i2 + 1] : 0.;
+                            row[i2] = v;
+                        }
+                    }
+                    WAVE_SYNC();
+                    for (int i = lane; i < NACC; i += WAVE) {
+                        double run = 0.;
+                        double *col = TB + i;
+                        for (int b0 = 0; b0 < nb; b0 += 4) {              // four bodies per round trip
+                            const double v0 = col[TB_STRIDE * b0];
+                            const double v1 = (b0 + 1 < nb) ? col[TB_STRIDE * (b0 + 1)] : 0.;
+                            const double v2 = (b0 + 2 < nb) ? col[TB_STRIDE * (b0 + 2)] : 0.;
+                            const double v3 = (b0 + 3 < nb) ? col[TB_STRIDE * (b0 + 3)] : 0.;
+                            run += v0; col[TB_STRIDE * b0] = run;
+                            run += v1; if (b0 + 1 < nb) col[TB_STRIDE * (b0 + 1)] = run;
+                            run += v2; if (b0 + 2 < nb) col[TB_STRIDE * (b0 + 2)] = run;
+                            run += v3; if (b0 + 3 < nb) col[TB_STRIDE * (b0 + 3)] = run;
+                        }
+                    }
+                    WAVE_SYNC();
+                    // (c) happens in the consumer below, which streams the two table rows of body(k) straight
+                    // into its products: the 63 composites never sit in registers all at once
+                } else {
 #pragma unroll
                 for (int i = 0; i < NACC; ++i) {
                     double x = Acc[i];
@@ -1147,13 +1189,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                     Acc[i] = __shfl(sub, bsrc);
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // four chains in flight (eight: slower, measured)
                 }
+                }
             }
             // ---- lane = dof k: fetch the composites of body(k), own column, the three products -----
             ARB_BSTAMP(4);
             double Xk[6], dXk[6], Gk[6];
             {
-                // from here on Acc holds the composites of body(k), not of body(lane)
-                double (&Cc)[NACC] = Acc;
+                // (DPP scan: from here on Acc holds the composites of body(k), not of body(lane))
                 T omk[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) omk[i] = __shfl(om_b[i], bsrc);
@@ -1178,30 +1220,50 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                     for (int i = 0; i < 6; ++i) { Xk[i] = 0.; dXk[i] = 0.; }
                 }
-                double Ms[36];                 // symmetric composite inertia, unpacked
-                {
-                    int t = 36;
+                // One pass over the composites of body(k) -- A (36, row-major) | M (upper triangle, 21) | rhs wrench (6)
+                // [| gravity wrench (6), inspect] -- accumulating G = A X + M dX', P = A^T X, R = M X and the rhs
+                // entries as each value arrives: from the registers (DPP scan) or from the prefix table in LDS.
+                double Pk[6], Rk[6], Mdk[6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-#pragma unroll
-                        for (int c2 = r; c2 < 6; ++c2) { Ms[6 * r + c2] = Cc[t]; Ms[6 * c2 + r] = Cc[t]; ++t; }
-                }
-                double Pk[6], Rk[6];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    double g = 0., pp = 0., rr = 0., md = 0.;
-#pragma unroll
-                    for (int c2 = 0; c2 < 6; ++c2) {
-                        g += Cc[6 * r + c2] * Xk[c2];           // A X
-                        pp += Cc[6 * c2 + r] * Xk[c2];          // A^T X
-                        rr += Ms[6 * r + c2] * Xk[c2];          // M X
-                        md += Ms[6 * r + c2] * dXk[c2];         // M dX'
-                    }
-                    Gk[r] = g + md; Pk[r] = pp; Rk[r] = rr;
-                }
+                for (int r = 0; r < 6; ++r) { Gk[r] = 0.; Pk[r] = 0.; Rk[r] = 0.; Mdk[r] = 0.; }
                 double rm = 0., rg = 0.;
+                auto visit = [&](auto ic, const double e) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i < 36) {
+                        constexpr int r = i / 6, c2 = i % 6;
+                        Gk[r] += e * Xk[c2];                    // A X
+                        Pk[c2] += e * Xk[r];                    // A^T X
+                    } else if constexpr (i < 57) {
+                        // packed upper triangle: i - 36 counts (r, c2 >= r) row by row
+                        constexpr int t = i - 36;
+                        constexpr int r = t < 6 ? 0 : t < 11 ? 1 : t < 15 ? 2 : t < 18 ? 3 : t < 20 ? 4 : 5;
+                        constexpr int c2 = r + (t - (r == 0 ? 0 : r == 1 ? 6 : r == 2 ? 11 : r == 3 ? 15 : r == 4 ? 18 : 20));
+                        Rk[r] += e * Xk[c2]; Mdk[r] += e * dXk[c2];                     // M X, M dX'
+                        if constexpr (r != c2) { Rk[c2] += e * Xk[r]; Mdk[c2] += e * dXk[r]; }
+                    } else if constexpr (i < 63) {
+                        rm += Xk[i - 57] * e;
+                    } else if constexpr (MODE == 1 && i >= NACC - 6 && i < NACC) {
+                        rg += Xk[i - (NACC - 6)] * e;
+                    }
+                };
+                if (L.lscan) {
+                    typedef double D2 __attribute__((ext_vector_type(2)));
+                    const int a = bsrc, top = a + mp->subsize[a] - 1;
+                    const D2 *ph = reinterpret_cast<const D2 *>(STG + TB_STRIDE * top);
+                    const D2 *pl = reinterpret_cast<const D2 *>(STG + TB_STRIDE * (a > 0 ? a - 1 : 0));
+                    const double keep = a > 0 ? 1. : 0.;
+                    static_for_asc(std::make_integer_sequence<int, (NACC + 1) / 2>{}, [&](auto i2c) {
+                        constexpr int i2 = decltype(i2c)::value;
+                        const D2 h = ph[i2], l = pl[i2];
+                        visit(std::integral_constant<int, 2 * i2>{}, h.x - keep * l.x);
+                        if constexpr (2 * i2 + 1 < NACC) visit(std::integral_constant<int, 2 * i2 + 1>{}, h.y - keep * l.y);
+                        if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
+                    });
+                } else {
+                    static_for_asc(std::make_integer_sequence<int, NACC>{}, [&](auto ic) { visit(ic, Acc[decltype(ic)::value]); });
+                }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { rm += Xk[i] * Cc[57 + i]; if (MODE == 1) rg += Xk[i] * Cc[NACC - 6 + i]; }
+                for (int r = 0; r < 6; ++r) Gk[r] += Mdk[r];
                 rhsM = (lane < n) ? (T)rm : T(0);
                 rhsG = (MODE == 1 && lane < n) ? (T)rg : T(0);
                 WAVE_SYNC();                   // every lane is done with the staging area: it becomes XPR
@@ -1961,9 +2023,12 @@ static std::vector<double> h12(const double *H16, int count) {
 
 // Size (in elements of T) of the per-body block region.  Once phase A' is over the region is
 // reused as float64 scratch for the per-dof X | P | R vectors of phase B.
+// (and, for small trees, the prefix table of the subtree sums: nb rows of TB_STRIDE float64)
+static bool lds_scan(int nb) { return nb <= 24; }
 static int bd_region_elems(int nb, int rs, int elems_per_double) {
     auto al = [](int x) { return (x + 3) & ~3; };
-    return std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double));
+    const int tb = lds_scan(nb) ? al(nb * TB_STRIDE * elems_per_double) : 0;
+    return std::max(std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double)), tb);
 }
 
 static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems) {
@@ -1984,6 +2049,7 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     L.ff0 = o; o += al(std::max(ndol, 4));
     L.work = o; o += 64;
     L.total = o;
+    L.lscan = lds_scan(nb) ? 1 : 0;
     *total_elems = o;
     return L;
 }

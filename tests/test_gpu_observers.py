@@ -58,7 +58,9 @@ def test_rollout_logs_equal_stepwise_states():
     for k in range(16):
         assert torch.equal(log["q"][k], sq) and torch.equal(log["dq"][k], sdq)
         e = bw.inspect(sq, sdq, 5e-3, ["energy"], cforce=scf)["energy"]
-        assert torch.equal(log["energy"][k], e)
+        # (two instantiations of the kernel -- production with logs, inspect: the same float64 sums, but the
+        # compiler is free to contract their multiply-adds differently: equal to float32 rounding, not bitwise)
+        assert torch.allclose(log["energy"][k], e, rtol=2e-6, atol=1e-6)
         bw.step(sq, sdq, 5e-3, 1, cforce=scf)
     torch.cuda.synchronize()
     assert torch.equal(tq, sq) and torch.equal(tdq, sdq)
