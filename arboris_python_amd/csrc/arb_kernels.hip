@@ -44,6 +44,9 @@
 #define ARB_WAVES_PER_EU 2      // 2nd __launch_bounds__ argument: min waves per SIMD (caps VGPRs at 256)
 #endif
 #define GS_SWEEPS 20            // core.py:929-931
+#ifndef ARB_PHASE_D_MFMA
+#define ARB_PHASE_D_MFMA 1      // float32: the constraint-space products J' [Y rhs | Y J'^T] on the matrix cores (0: vector ALU)
+#endif
 #ifndef ARB_GS_PRIO
 #define ARB_GS_PRIO 2           // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
 #endif
@@ -1602,6 +1605,57 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         if (do_constraints) {
             // [v | Y'] = J' [Y rhs | Y J'^T]                                core.py:925-927
             typedef T V4 __attribute__((ext_vector_type(4)));
+#if ARB_PHASE_D_MFMA
+            if constexpr (std::is_same<T, float>::value) {
+                // On the matrix cores (float32): the four rows of one constraint are the four accumulator registers of
+                // a v_mfma_f32_4x4x1_16b_f32 slab, the 64 lanes its 64 columns (B operand = this lane's entry Z[r] of
+                // the solution column), and the A operand of step r carries J'[4c + lane%4][r] -- read straight from
+                // the rows of J' in LDS, four r per 16-byte read.  Unlike the elimination of phase C nothing here waits
+                // for a lane exchange: all reads are independent of the accumulation, the ndof MFMAs of a slab issue
+                // back to back (NMAX x 8 cycles per active constraint instead of 4 x (NMAX/2 v_pk_fma + NMAX/4 reads)).
+                typedef float F4 __attribute__((ext_vector_type(4)));
+                const int lq = lane & 3;
+                for (int c = 0; c < nc; ++c) {
+                    F4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                    // the rows of a constraint outside the active set are zero (phase B): nothing to multiply
+                    if (CD[c * CD_STRIDE + CD_ACTIVE] != T(0)) {
+                        const F4 *jr4 = reinterpret_cast<const F4 *>(RT + (1 + 4 * c + lq) * RS);
+                        // four partial sums (r mod 4), added pairwise at the end: four independent accumulator chains in
+                        // the matrix pipe, and the rounding of a 44-term float32 dot product stays where the vector-ALU
+                        // version's grouped sums had it (one sequential chain measured 1.08e-5 on the hardest golden
+                        // states, against the 1e-5 gate)
+                        F4 pa = acc, pb = acc, pc = acc, pd = acc, qa = acc, qb = acc, qc = acc, qd = acc;
+#pragma unroll
+                        for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                            const F4 jv = jr4[i4];
+                            pa = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.x, Z[4 * i4], pa, 0, 0, 0);
+                            pb = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.y, Z[4 * i4 + 1], pb, 0, 0, 0);
+                            pc = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.z, Z[4 * i4 + 2], pc, 0, 0, 0);
+                            pd = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.w, Z[4 * i4 + 3], pd, 0, 0, 0);
+                            if (NSETS == 2) {
+                                qa = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.x, Z2[4 * i4], qa, 0, 0, 0);
+                                qb = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.y, Z2[4 * i4 + 1], qb, 0, 0, 0);
+                                qc = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.z, Z2[4 * i4 + 2], qc, 0, 0, 0);
+                                qd = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.w, Z2[4 * i4 + 3], qd, 0, 0, 0);
+                            }
+                        }
+                        acc = (pa + pb) + (pc + pd);
+                        if (NSETS == 2) acc2 = (qa + qb) + (qc + qd);
+                    }
+                    const float out[4] = {acc.x, acc.y, acc.z, acc.w}, out2[4] = {acc2.x, acc2.y, acc2.z, acc2.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int idx = 4 * c + i;
+                        if (lane == n) VV[idx] = out[i];
+                        else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = out[i];
+                        if (NSETS == 2) {
+                            if (WAVE + lane == n) VV[idx] = out2[i];
+                            else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = out2[i];
+                        }
+                    }
+                }
+            } else
+#endif
             for (int idx = 0; idx < ndol; ++idx) {
                 // row idx of J' (zero beyond ndof), read as 16/32-byte LDS vectors (wave-uniform address)
                 const V4 *jr4 = reinterpret_cast<const V4 *>(RT + (1 + idx) * RS);

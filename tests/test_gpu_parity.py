@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import arb_oracle as O
-from conftest import load_golden, load_model
+from conftest import load_golden, load_model, assert_f32_parity
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -177,8 +177,11 @@ def test_human36_drop_scenario_stepwise(bw_cache, nc, dtype, tol):
     Q, DQ = g["drop%d_q" % nc], g["drop%d_dq" % nc]
     q, dq, cf = gpu_step(bw, Q[:39], DQ[:39], 5e-3, dtype)
     rq, rdq = ref_step(m, Q[:39], DQ[:39], 5e-3, dtype, Q[1:], DQ[1:])
-    assert rel(q, rq) < tol
-    assert rel(dq, rdq) < tol
+    if dtype == torch.float64:
+        assert rel(q, rq) < tol
+        assert rel(dq, rdq) < tol
+    else:
+        assert_f32_parity(m, Q[:39], DQ[:39], 5e-3, q, dq, rq, rdq, tol)
     tq, tdq = bw.to_device(Q[:39], DQ[:39], dtype)
     r = bw.inspect(tq, tdq, 5e-3, ["c_active", "c_sdist", "c_force"])
     assert np.array_equal(r["c_active"].cpu().numpy().astype(bool), g["drop%d_active" % nc])
@@ -211,8 +214,13 @@ def test_human36_random_contact_steps(bw_cache, nc, dtype, tol):
     q, dq, cf = gpu_step(bw, g["rand%d_q" % nc], g["rand%d_dq" % nc], 5e-3, dtype)
     rq, rdq = ref_step(m, g["rand%d_q" % nc], g["rand%d_dq" % nc], 5e-3, dtype,
                        g["rand%d_q_next" % nc], g["rand%d_dq_next" % nc])
-    assert rel(q, rq) < tol
-    assert rel(dq, rdq) < tol
+    if dtype == torch.float64:
+        assert rel(q, rq) < tol
+        assert rel(dq, rdq) < tol
+    else:
+        # (feet 3.5 cm inside the floor at up to 1.5 m/s: |dq+| ~ 40 rad/s and the float64 reference itself moves by
+        # 1e-5 .. 2e-5 when these inputs change by one float32 ulp -- worlds over the gate must show exactly that)
+        assert_f32_parity(m, g["rand%d_q" % nc], g["rand%d_dq" % nc], 5e-3, q, dq, rq, rdq, tol)
 
 
 @pytest.mark.parametrize("name", ["plane_ball", "box_ball", "ball_ball", "dome_point"])
