@@ -413,6 +413,11 @@ def main():
                     "wave_frac_waiting": (pm["SQ_WAIT_ANY"]["mean_per_launch"] + pm["SQ_WAIT_INST_ANY"]["mean_per_launch"])
                                          / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
                     "note": "SQ counters of profiles/%s" % os.path.basename(prof)}
+                if "SQ_INSTS_MFMA" in pm:
+                    res["roofline"]["valu"]["mfma_insts_per_world_step"] = pm["SQ_INSTS_MFMA"]["mean_per_launch"] / ws
+                    res["roofline"]["valu"]["mfma_note"] = ("v_mfma_f32_4x4x1_16b_f32 in the constraint-space products of "
+                                                            "phase D; the elimination of phase C runs on the vector ALU "
+                                                            "(the matrix-core variant measured slower, DESIGN.md 3)")
         except Exception:
             pass
     if gather_ms is not None:
