@@ -536,8 +536,10 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 // execution) -- those arguments are compiled out, which keeps their kernargs and the predicates derived from them
 // out of the SGPR file; FEAT 1 = every input honoured.
 // CM 1 = phase C eliminates on the matrix cores (float32 only; ARB_STEP_MFMA_ELIM), 0 = on the vector ALU.
+// (float64 worlds on the 64-row tile -- snake-64 -- need 43 KB of LDS per wave: three waves per CU, less than one per
+// SIMD, so their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
-__global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
+__global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVES_PER_EU) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
     T *__restrict__ gcforce, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
     // the host picks the smallest register tile that holds ndof (kNmaxChoices): rows below the previous tile
     // size always exist, which folds their `i < n` predicates away
     constexpr int NLOW = NMAX == 16 ? 0 : NMAX == 32 ? 16 : NMAX == 44 ? 32 : NMAX == 48 ? 44 : 48;
+    constexpr bool LSCAN_OK = NMAX <= 48;      // (the 64-row tiles are register-bound: only the DPP scan is compiled in)
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
     T dt = dt_in, inv_dt = T(1) / dt_in;
     const bool do_constraints = (nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
@@ -1143,7 +1146,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                 // dof lanes (lane k takes the composite of body(k)), so that only one element is in flight.
                 const bool two_rows = nb > 16, four_rows = nb > 32;
                 const int hi = (lane < nb) ? lane + mp->subsize[lane] - 1 : lane;
-                if (L.lscan) {
+                if (LSCAN_OK && L.lscan) {
                     // Small trees (the table fits the staging area): the same inclusive prefix sums, formed in LDS with
                     // the roles transposed -- lane = accumulator, a serial pass over the bodies: nb additions in all
                     // instead of 4-6 DPP steps + two lane exchanges per accumulator (~210 instead of ~1700 wave
@@ -1249,7 +1252,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
                         rg += Xk[i - (NACC - 6)] * e;
                     }
                 };
-                if (L.lscan) {
+                if (LSCAN_OK && L.lscan) {
                     typedef double D2 __attribute__((ext_vector_type(2)));
                     const int a = bsrc, top = a + mp->subsize[a] - 1;
                     const D2 *ph = reinterpret_cast<const D2 *>(STG + TB_STRIDE * top);
@@ -1444,6 +1447,12 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         if (lane < RS) RT[lane] = (lane < n) ? rhs : T(0);
         WAVE_SYNC();
         const int ncols = do_constraints ? mp->ncols : n + 1;
+        // Late rhs: 64 dofs, no constraints, one register set (the host's choice for that case): every lane holds a
+        // column of Z, the rhs column waits in LDS (row 0 of RT) until the first pivot (dof n-1) has been taken;
+        // lane n-1 -- whose own column is finished by that pivot -- applies the pivot to the rhs instead and carries
+        // the rhs column from then on.  (A second register set of 64 float64 rows for ONE column is 128 VGPRs.)
+        const bool late_rhs = NSETS == 1 && n == WAVE && NMAX == WAVE;
+        const int rhs_lane = late_rhs ? n - 1 : n;
         {
             // column r of [rhs | J'^T] = row r of RT, fetched as 16/32-byte vectors (lanes without a column
             // read row 0 and discard it: unconditional loads, no per-element branches)
@@ -1552,9 +1561,13 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
         for (int j = n - 1; j >= 0; --j) {
             const T piv = bcast(Z[NMAX - 1], j);
             const T ip = arb_rcp(piv);
-            const T t = Z[NMAX - 1] * ip;
+            T t = Z[NMAX - 1] * ip;
             T t2 = T(0);
             if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
+            // late rhs, first pivot: lane j works on the rhs column, whose entries come from LDS (no rotation has
+            // happened yet with n == NMAX: register r holds row r)
+            const bool take_rhs = late_rhs && j == n - 1 && lane == j;
+            if (late_rhs && j == n - 1 && lane == j) t = RT[NMAX - 1] * ip;
             // multipliers in groups of 8 broadcasts: the v_readlane -> SGPR -> v_fma wait states of one row are
             // filled by the broadcasts of the next rows instead of s_nop
             constexpr int GB = 8;
@@ -1567,7 +1580,9 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
 #pragma unroll
                 for (int k = 0; k < GB; ++k) if (r0 - k >= 1) {
                     const int r = r0 - k;
-                    Z[r] = Z[r - 1] - f[k] * t;
+                    T prev = Z[r - 1];
+                    if (NMAX == WAVE && NSETS == 1) { if (take_rhs) prev = RT[r - 1]; }
+                    Z[r] = prev - f[k] * t;
                     if (NSETS == 2) Z2[r] = Z2[r - 1] - f[k] * t2;
                 }
             }
@@ -1581,7 +1596,7 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // (dqs is zero beyond ndof; rows >= ndof of the columns are never used)
             typedef T V4 __attribute__((ext_vector_type(4)));
             const V4 *d4 = reinterpret_cast<const V4 *>(dqs);
-            if (lane == n) {
+            if (lane == rhs_lane) {
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     const V4 v = d4[i4];
@@ -1686,8 +1701,8 @@ __global__ __launch_bounds__(WAVE, ARB_WAVES_PER_EU) void arb_step_kernel(
             // (whole rows of RS elements, vector stores; rows >= ndof of a column register tile are zero -- zero on
             // entry, and an elimination step maps a zero row to 0 - 0 * t -- so "columns >= ndof stay zero" holds)
             typedef T V4 __attribute__((ext_vector_type(4)));
-            if (lane >= n && lane < ncols) {
-                V4 *dst = reinterpret_cast<V4 *>(RT + (lane - n) * RS);
+            if ((lane >= n && lane < ncols) || (late_rhs && lane == rhs_lane)) {
+                V4 *dst = reinterpret_cast<V4 *>(RT + (late_rhs ? 0 : lane - n) * RS);
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     V4 v;
@@ -2078,10 +2093,10 @@ static std::vector<double> h12(const double *H16, int count) {
 // Size (in elements of T) of the per-body block region.  Once phase A' is over the region is
 // reused as float64 scratch for the per-dof X | P | R vectors of phase B.
 // (and, for small trees, the prefix table of the subtree sums: nb rows of TB_STRIDE float64)
-static bool lds_scan(int nb) { return nb <= 24; }
+static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
 static int bd_region_elems(int nb, int rs, int elems_per_double) {
     auto al = [](int x) { return (x + 3) & ~3; };
-    const int tb = lds_scan(nb) ? al(nb * TB_STRIDE * elems_per_double) : 0;
+    const int tb = lds_scan(nb, rs) ? al(nb * TB_STRIDE * elems_per_double) : 0;
     return std::max(std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double)), tb);
 }
 
@@ -2103,7 +2118,7 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     L.ff0 = o; o += al(std::max(ndol, 4));
     L.work = o; o += 64;
     L.total = o;
-    L.lscan = lds_scan(nb) ? 1 : 0;
+    L.lscan = lds_scan(nb, rs) ? 1 : 0;
     *total_elems = o;
     return L;
 }
@@ -2323,7 +2338,9 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     if (!M) return ARB_ERR_NOMEM;
     M->device = device;
     M->nb = nb; M->n = n; M->nq = d->nq; M->nc = nc; M->ndol = ndol; M->ncols = ncols;
-    M->nsets = ncols > WAVE ? 2 : 1;
+    // A world with exactly 64 dofs and no constraints has 65 columns: instead of a second register set for the one
+    // column that does not fit, the rhs column joins late (phase C: "late rhs") and one set is enough.
+    M->nsets = (ncols > WAVE && !(nc == 0 && n == WAVE)) ? 2 : 1;
     M->nmax = 64;
     for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
     DeviceGuard guard_(device);
@@ -2386,7 +2403,8 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // the plain step (FEAT 0): nothing but the state and the constraint forces
     const bool plain = MODE == 0 && ext == nullptr && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
                        logo.dq == nullptr && logo.energy == nullptr && sio.mode == 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS) && dts == nullptr;
-    const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM);
+    const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
+                      !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
 #define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
