@@ -142,18 +142,19 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
                       "(oracle/arb_oracle.py), single thread" % (nw, done // nw))
     # all cores: child processes (they never touch the GPU), one BLAS thread each
     try:
-        ncores = min(os.cpu_count() or 1, 128, q.shape[0] // 16)
-        nsteps = max(2, min(episode, int(budget_s * out["value"] / 16)))
+        per = 32                                         # worlds per process (the oracle batches its NumPy calls over worlds)
+        ncores = min(os.cpu_count() or 1, 128, q.shape[0] // per)
+        nsteps = max(2, min(episode, int(budget_s * out["value"] / per)))
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "shard.npz")
-            np.savez(f, q=q[:16 * ncores], dq=dq[:16 * ncores], **model.to_npz_dict())
-            procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, f, str(r), "16", str(nsteps), repr(dt)],
+            np.savez(f, q=q[:per * ncores], dq=dq[:per * ncores], **model.to_npz_dict())
+            procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, f, str(r), str(per), str(nsteps), repr(dt)],
                                       stdout=subprocess.PIPE, env=env) for r in range(ncores)]
             times = [float(p.communicate(timeout=600)[0].decode().strip().splitlines()[-1]) for p in procs]
-        out["all_cores"] = dict(value=16 * ncores * nsteps / max(times), unit="world-steps/s", cores=ncores,
-                                sample="%d single-threaded processes x 16 worlds x %d steps (stepping loops only, "
-                                       "slowest process)" % (ncores, nsteps))
+        out["all_cores"] = dict(value=per * ncores * nsteps / max(times), unit="world-steps/s", cores=ncores,
+                                sample="%d single-threaded processes x %d worlds x %d steps (stepping loops only, "
+                                       "slowest process)" % (ncores, per, nsteps))
     except Exception as e:                              # pragma: no cover
         out["all_cores"] = dict(value=None, error=repr(e))
     return out
