@@ -589,7 +589,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
     WAVE_SYNC();
 
-#ifdef ARB_CSTAMPS   /* development: slots 4..7 = inside phase C (columns loaded, pivot loop done, gvel added = start of D, end of D) */
+#ifdef ARB_ASTAMPS   /* development: slots 1..6 = inside phase A (joint kinematics + H_pc, block algebra, own columns, level loop, body wrenches, end) */
+#define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0 && (k) == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
+#define ARB_BSTAMP(k) do { } while (0)
+#define ARB_ASTAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
+#elif defined(ARB_CSTAMPS)   /* development: slots 4..7 = inside phase C (columns loaded, pivot loop done, gvel added = start of D, end of D) */
 #define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0 && (k) <= 3) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
 #define ARB_BSTAMP(k) do { } while (0)
 #define ARB_CSTAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
@@ -602,6 +606,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #endif
 #ifndef ARB_CSTAMP
 #define ARB_CSTAMP(k) do { } while (0)
+#endif
+#ifndef ARB_ASTAMP
+#define ARB_ASTAMP(k) do { } while (0)
 #endif
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); \
                               n = n0; nb = nb0; nc = nc0; ndol = ndol0;                                             \
@@ -700,6 +707,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     R_pc = cvt_m3<T>(R_pc_d);
                     p_pc = cvt_v3<T>(p_pc_d);
                 }
+                ARB_ASTAMP(1);
                 R_cp = transpose(R_pc);                          // Ad_cp = Ad(inv(H_pc)) :1300
                 p_cp = -mtv(R_pc, p_pc);
                 // Ad_nr, T_rn = -Ad_nr T_nr, dAd_nr = Ad_nr ad(T_rn)   rigidmotion.py:47-73
@@ -718,6 +726,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 // T_rn = -(aw, av) is all phase B needs from here (dAd_cp = ad(W_c) Ad_cp, W_c = Ad_cp Ad_pr T_rn)
                 st_v3(bd + BD_OM, -aw); st_v3(bd + BD_OM + 3, -av);
                 dA_cp = dAd_cp.A; dB_cp = dAd_cp.B;
+                ARB_ASTAMP(2);
                 // Ad_cn (dJ_nr gvel_j): the joint's own contribution to dJ_c gvel
                 {
                     V3<T> bw = v3<T>(T(0), T(0), T(0));
@@ -755,6 +764,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     }
                 }
             }
+            ARB_ASTAMP(3);
             // pose and twist down the tree, one depth level at a time
             for (int lvl = 0; lvl <= mp->maxdepth; ++lvl) {
                 if (on && dep == lvl) {
@@ -786,6 +796,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 }
                 WAVE_SYNC();
             }
+            ARB_ASTAMP(4);
             if (on) {
                 T *bd = BD + b * BD_STRIDE;
                 const T *Mb = mp->mass + 36 * b;
@@ -833,6 +844,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
                 for (int i = 0; i < 6; ++i) bd[BD_PT + i] = pt[i];
             }
+            ARB_ASTAMP(5);
             // dof-indexed copy of the linear joint positions (PD controller, joint limits)
             if (lane < n) { const int qi = mp->dof2q[lane]; qd[lane] = qi >= 0 ? qs[qi] : T(0); }
             WAVE_SYNC();
@@ -879,6 +891,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 
         // ================= phase A': lane = constraint =====================
         ARB_OPAQUE_LANE();
+        ARB_ASTAMP(6);
         ARB_STAMP(1);
         for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0);
         if (do_constraints && lane < nc) {
