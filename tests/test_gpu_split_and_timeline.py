@@ -167,3 +167,29 @@ def test_matrix_core_elimination_parity(bws, name):
     bw.step(sq, sdq, dt, 20, cforce=cf2)
     torch.cuda.synchronize()
     assert torch.isfinite(tq).all() and torch.isfinite(tdq).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_split_executions_on_rank_deficient_blocks(bws, dtype):
+    """The closed-loop planar arm (rank-2 3x3 admittance block, numpy.linalg.pinv semantics, constraints.py:235)
+    through the split executions: the wave-per-world sweep kernel runs the fused kernel's code (bitwise equal), the
+    lane-per-world kernel its own copy of the guard + SVD fallback (equal to rounding)."""
+    g = load_golden("g12_singular.npz")
+    bw, m, _, _ = bws("loop_arm")
+    Q, DQ, F = g["loop_q"], g["loop_dq"], g["loop_force"]
+    cf0 = np.zeros((40, 1, 4)); cf0[1:, 0, :3] = F[:39]
+    out = {}
+    for split in (False, "wave", True):
+        tq, tdq = bw.to_device(Q[:40], DQ[:40], dtype)
+        tcf = torch.as_tensor(cf0, dtype=dtype, device=bw.device).contiguous()
+        bw.step(tq, tdq, 5e-3, 1, cforce=tcf, split=split)
+        torch.cuda.synchronize()
+        assert torch.isfinite(tq).all() and torch.isfinite(tcf).all()
+        out[split] = (tq, tdq, tcf)
+    assert all(torch.equal(a, b) for a, b in zip(out[False], out["wave"]))
+    tol = 1e-10 if dtype == torch.float64 else 1e-5
+    for a, b in zip(out[False], out[True]):
+        assert float((a - b).abs().max()) <= tol * max(1., float(a.abs().max()))
+    # and the forces are the reference's
+    ftol = 1e-6 if dtype == torch.float64 else 5e-3
+    assert np.abs(out["wave"][2].cpu().numpy()[:, 0, :3] - F).max() < ftol * max(1., np.abs(F).max())
