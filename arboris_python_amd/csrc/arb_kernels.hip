@@ -81,9 +81,13 @@
 #define CD_STRIDE 56
 
 struct Layout {      // offsets in elements of T inside the wave's LDS block
-    int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, total;
+    int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, ci, total;
     int lscan;       // phase B forms the subtree sums from a prefix table in LDS (small trees) instead of a DPP scan
 };
+// per-constraint integer constants staged in LDS once per launch (int32 words): type, dof masks of the ancestors of
+// body 1 and of body 0 (lo, hi each), constrained dof -- the constraint-row loops of phase B read them with
+// wave-uniform LDS reads instead of chains of dependent scalar loads from the model
+#define CI_STRIDE 6
 #define TB_STRIDE 70     // float64 per body in that table: 63 (69 inspect) accumulators, padded; 560 B rows: bank-conflict free
 
 // exact (bit pattern) equality, also true for identical NaNs
@@ -587,6 +591,16 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         FF[i] = f;
     }
     const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
+    int *CI = reinterpret_cast<int *>(lds + L.ci);
+    if (lane < nc) {
+        const int b1 = mp->cbody[lane], b0 = mp->cbody0[lane];
+        const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
+        int *ci = CI + CI_STRIDE * lane;
+        ci[0] = mp->ctype[lane];
+        ci[1] = (int)(unsigned)a1; ci[2] = (int)(unsigned)(a1 >> 32);
+        ci[3] = (int)(unsigned)a0; ci[4] = (int)(unsigned)(a0 >> 32);
+        ci[5] = mp->cdof[lane];
+    }
     WAVE_SYNC();
 
 #ifdef ARB_ASTAMPS   /* development: slots 1..6 = inside phase A (joint kinematics + H_pc, block algebra, own columns, level loop, body wrenches, end) */
@@ -1327,10 +1341,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             ARB_BSTAMP(6);
             if (do_constraints) {
                 for (int c = 0; c < nc; ++c) {
-                    const int ct = mp->ctype[c];
+                    const int *ci = CI + CI_STRIDE * c;
+                    const int ct = ci[0];
                     if (ct == ARB_CT_JOINTLIMITS) continue;
                     const T *cd = CD + c * CD_STRIDE;
-                    const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
                     if (cd[CD_ACTIVE] == T(0)) {            // not in the active set: zero rows (core.py:913-918)
                         if (lane < n) {
                             T *row = RT + (1 + 4 * c) * RS + lane;
@@ -1339,7 +1353,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         }
                         continue;
                     }
-                    const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
+                    const unsigned long long a1 = ((unsigned long long)(unsigned)ci[2] << 32) | (unsigned)ci[1];
+                    const unsigned long long a0 = ((unsigned long long)(unsigned)ci[4] << 32) | (unsigned)ci[3];
                     const double s = (double)cd[CD_ACTIVE] * ((double)((a1 >> lane) & 1ull) - (double)((a0 >> lane) & 1ull));
                     const M3<double> Rx = ld_m3_as<double>(cd + CD_R1);
                     const V3<double> px = cvt_v3<double>(ld_v3(cd + CD_P1));
@@ -1381,7 +1396,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         // joint-limit rows are dof selectors                              constraints.py:46-48
         if (do_constraints) {
             for (int c = 0; c < nc; ++c)
-                if (mp->ctype[c] == ARB_CT_JOINTLIMITS && lane == mp->cdof[c])
+                if (CI[CI_STRIDE * c] == ARB_CT_JOINTLIMITS && lane == CI[CI_STRIDE * c + 5])
                     RT[(1 + 4 * c) * RS + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
         }
         // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
@@ -2130,6 +2145,10 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     L.ff = o; o += al(std::max(ndol, 4));
     L.ff0 = o; o += al(std::max(ndol, 4));
     L.work = o; o += 64;
+    {
+        const int words = CI_STRIDE * std::max(nc, 1);                      // int32 words, see CI_STRIDE
+        L.ci = o; o += al(elems_per_double == 2 ? words : (words + 1) / 2);     // (float: one word per element; double: two)
+    }
     L.total = o;
     L.lscan = lds_scan(nb, rs) ? 1 : 0;
     *total_elems = o;
