@@ -271,14 +271,6 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
     o.p = v3<T>(Z, Z, Z);
     for (int i = 0; i < 3; ++i) { o.jw[i] = v3<T>(Z, Z, Z); o.djw[i] = v3<T>(Z, Z, Z); }
     o.Tw = v3<T>(Z, Z, Z); o.Tv = v3<T>(Z, Z, Z);
-    // The sines and cosines of the joint's (up to three) angles are evaluated ONCE, ahead of the switch: with
-    // lane = body the wavefront walks through every case some lane takes, and a sincos pair inside each case
-    // meant ten float64 evaluations per step for human36's six joint types instead of three.
-    const int na = (jt == JT_FREE || jt == JT_TXTYTZ) ? 0 : joint_ndof(jt);
-    T sa = Z, ca = O, sb = Z, cb = O, sc = Z, cc = O;
-    if (na > 0) arb_sincos(T(q[0]), &sa, &ca);
-    if (na > 1) arb_sincos(T(q[1]), &sb, &cb);
-    if (na > 2) arb_sincos(T(q[2]), &sc, &cc);
     switch (jt) {
     case JT_FREE: {                                   // joints.py:10-57
         o.R.a[0] = q[0]; o.R.a[1] = q[1]; o.R.a[2] = q[2]; o.p.x = q[3];
@@ -288,7 +280,8 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.Tv = v3<T>(T(dq[3]), T(dq[4]), T(dq[5]));
     } break;
     case JT_RZRYRX: {                                 // joints.py:59-104, rotzyx :34-59
-        const T sz = sa, cz = ca, sy = sb, cy = cb, sx = sc, cx = cc;
+        T sz, cz, sy, cy, sx, cx;
+        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sy, &cy); arb_sincos(T(q[2]), &sx, &cx);
         o.R.a[0] = cz * cy; o.R.a[1] = cz * sy * sx - sz * cx; o.R.a[2] = cz * sy * cx + sz * sx;
         o.R.a[3] = sz * cy; o.R.a[4] = sz * sy * sx + cz * cx; o.R.a[5] = sz * sy * cx - cz * sx;
         o.R.a[6] = -sy;     o.R.a[7] = cy * sx;                o.R.a[8] = cy * cx;
@@ -301,7 +294,8 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1] + T(dq[2]) * o.jw[2];
     } break;
     case JT_RZRY: {                                   // joints.py:107-146, rotzy :60-80
-        const T sz = sa, cz = ca, sy = sb, cy = cb;
+        T sz, cz, sy, cy;
+        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sy, &cy);
         o.R.a[0] = cz * cy; o.R.a[1] = -sz; o.R.a[2] = cz * sy;
         o.R.a[3] = sz * cy; o.R.a[4] = cz;  o.R.a[5] = sz * sy;
         o.R.a[6] = -sy;     o.R.a[7] = Z;   o.R.a[8] = cy;
@@ -312,7 +306,8 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1];
     } break;
     case JT_RZRX: {                                   // joints.py:149-185, rotzx :82-102
-        const T sz = sa, cz = ca, sx = sb, cx = cb;
+        T sz, cz, sx, cx;
+        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sx, &cx);
         o.R.a[0] = cz; o.R.a[1] = -sz * cx; o.R.a[2] = sz * sx;
         o.R.a[3] = sz; o.R.a[4] = cz * cx;  o.R.a[5] = -cz * sx;
         o.R.a[6] = Z;  o.R.a[7] = sx;       o.R.a[8] = cx;
@@ -323,7 +318,8 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1];
     } break;
     case JT_RYRX: {                                   // joints.py:188-224, rotyx :104-124
-        const T sy = sa, cy = ca, sx = sb, cx = cb;
+        T sy, cy, sx, cx;
+        arb_sincos(T(q[0]), &sy, &cy); arb_sincos(T(q[1]), &sx, &cx);
         o.R.a[0] = cy;  o.R.a[1] = sy * sx; o.R.a[2] = sy * cx;
         o.R.a[3] = Z;   o.R.a[4] = cx;      o.R.a[5] = -sx;
         o.R.a[6] = -sy; o.R.a[7] = cy * sx; o.R.a[8] = cy * cx;
@@ -334,19 +330,19 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1];
     } break;
     case JT_RZ: {                                     // joints.py:227-303
-        const T s = sa, c = ca;
+        T s, c; arb_sincos(T(q[0]), &s, &c);
         o.R.a[0] = c; o.R.a[1] = -s; o.R.a[3] = s; o.R.a[4] = c;
         o.jw[0] = v3<T>(Z, Z, O);
         o.Tw = T(dq[0]) * o.jw[0];
     } break;
     case JT_RY: {                                     // joints.py:305-326
-        const T s = sa, c = ca;
+        T s, c; arb_sincos(T(q[0]), &s, &c);
         o.R.a[0] = c; o.R.a[2] = s; o.R.a[6] = -s; o.R.a[8] = c;
         o.jw[0] = v3<T>(Z, O, Z);
         o.Tw = T(dq[0]) * o.jw[0];
     } break;
     case JT_RX: {                                     // joints.py:328-349
-        const T s = sa, c = ca;
+        T s, c; arb_sincos(T(q[0]), &s, &c);
         o.R.a[4] = c; o.R.a[5] = -s; o.R.a[7] = s; o.R.a[8] = c;
         o.jw[0] = v3<T>(O, Z, Z);
         o.Tw = T(dq[0]) * o.jw[0];
