@@ -1598,7 +1598,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             if (late_rhs && j == n - 1 && lane == j) t = RT[NMAX - 1] * ip;
             // multipliers in groups of 8 broadcasts: the v_readlane -> SGPR -> v_fma wait states of one row are
             // filled by the broadcasts of the next rows instead of s_nop
-            constexpr int GB = 8;
+#ifndef ARB_PIVOT_GB
+#define ARB_PIVOT_GB 8
+#endif
+            constexpr int GB = ARB_PIVOT_GB;
 #pragma unroll
             for (int r0 = NMAX - 1; r0 >= 1; r0 -= GB) {
                 T f[GB];
