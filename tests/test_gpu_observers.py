@@ -170,3 +170,20 @@ def test_hdf5logger_layout_and_values(tmp_path):
     simulate(w, timeline[:5], [Hdf5Logger(f, group="again", mode='a', save_transforms=False, save_state=True)])
     d = np.load(f)
     assert "sim/timeline" in d.files and d["again/gvelocities/Elbow"].shape == (4, 1)
+
+
+@pytest.mark.parametrize("name", ["simplearm", "snake9_free"])
+def test_device_energy_matches_reference_energy_monitor(name):
+    """Kinetic AND potential energy of the device's energy monitor against EnergyMonitor.update executed on the
+    reference's objects with the reference's `principalframe` (tests/golden/g13_energy_monitor.npz;
+    observers.py:36-51).  float64 1e-10, float32 2e-6."""
+    g = load_golden("g13_energy_monitor.npz")
+    m, _, _ = load_model("energy_" + name)
+    bw = BatchedWorlds(m)
+    q, dq = g[name + "_q"], g[name + "_dq"]
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-6)):
+        tq, tdq = bw.to_device(q, dq, dtype)
+        e = bw.inspect(tq, tdq, 5e-3, ["energy"], skip_constraints=True)["energy"].cpu().numpy()
+        assert np.max(np.abs(e[:, 0] - g[name + "_ke"]) / np.maximum(1., np.abs(g[name + "_ke"]))) < tol
+        assert np.max(np.abs(e[:, 1] - g[name + "_pe"]) / np.maximum(1., np.abs(g[name + "_pe"]))) < tol
+    bw.close()

@@ -353,3 +353,22 @@ def test_singular_blocks_loop_and_planar_contact():
         Q, DQ = g[tag + "_q"], g[tag + "_dq"]
         qn, dqn, cfn = O.step(m, Q[:-1], DQ[:-1], 5e-3)
         close(qn, Q[1:], 1e-12); close(dqn, DQ[1:], 1e-11); close(cfn[:, 0], g[tag + "_force"], 1e-9)
+
+
+# -- G13 EnergyMonitor ---------------------------------------------------------------
+@pytest.mark.parametrize("name,model", [("simplearm", "energy_simplearm"), ("snake9_free", "energy_snake9_free")])
+def test_energy_monitor_formula(name, model):
+    """observers.py:36-51 on the reference's objects: KE = gvel.M.gvel / 2, PE = 9.81 sum_b m_b up.(H_gb c_b)."""
+    g = load_golden("g13_energy_monitor.npz")
+    m, _, _ = load_model(model)
+    q, dq = g[name + "_q"], g[name + "_dq"]
+    d = O.update_dynamic(m, q, dq)
+    ke = 0.5 * np.einsum('bi,bij,bj->b', dq, d["M"], dq)
+    pe = np.zeros(len(q))
+    for b in range(m.nb):
+        mass = m.mass[b]
+        if mass[5, 5] > 0:
+            rx = mass[0:3, 3:6] / mass[5, 5]
+            c = np.array([rx[2, 1], rx[0, 2], rx[1, 0], 1.])
+            pe += mass[3, 3] * (d["pose"][:, b] @ c)[:, 0:3] @ m.up
+    close(ke, g[name + "_ke"], 1e-11); close(9.81 * pe, g[name + "_pe"], 1e-11)

@@ -815,10 +815,45 @@ def gen_singular_blocks():
     save("g12_singular.npz", **out)
 
 
+# ---- G13: EnergyMonitor (observers.py:14-67; the module itself does not import under Python 3: TabError) ----
+def gen_energy_monitor():
+    """Kinetic and potential energy as EnergyMonitor.init/update compute them, statement by statement on the
+    reference's objects with the reference's own `principalframe` (massmatrix.py:72-107), at random states."""
+    from arboris.massmatrix import principalframe
+    out = {}
+    # (human36 is not in the list: `principalframe` asserts `ismassmatrix` and some of its bodies fail that test,
+    # so the reference's EnergyMonitor cannot run on it)
+    def arm():
+        w = World(); add_simplearm(w); w.register(WeightController()); w.init()
+        return w
+
+    def snake():
+        w = World(); add_snake(w, 9, is_fixed=False); w.register(WeightController()); w.init()
+        return w
+    for name, w in (("simplearm", arm()), ("snake9_free", snake())):
+        m = save_model("energy_" + name, w)
+        q, dq = synth.random_states(m, 8, seed=13, vel=1.5)
+        bodies = list(w.ground.iter_descendant_bodies())
+        com_pos = dict((b, principalframe(b.mass)[:, 3]) for b in bodies)          # observers.py:36-37
+        ke, pe = [], []
+        for i in range(len(q)):
+            set_state(w, m, q[i], dq[i])
+            w.update_dynamic()
+            ke.append(np.dot(w.gvel, np.dot(w.mass, w.gvel)) / 2.)                  # observers.py:41-43
+            Ep = 0.
+            for b in bodies:                                                        # observers.py:45-49
+                h = np.dot(np.dot(b.pose, com_pos[b])[0:3], w.up)
+                Ep += b.mass[3, 3] * h
+            pe.append(Ep * 9.81)
+        out[name + "_q"], out[name + "_dq"] = q, dq
+        out[name + "_ke"], out[name + "_pe"] = np.array(ke), np.array(pe)
+    save("g13_energy_monitor.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz, g12=gen_singular_blocks)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz, g12=gen_singular_blocks, g13=gen_energy_monitor)
     for k in which:
         table[k]()
