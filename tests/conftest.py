@@ -64,7 +64,8 @@ def assert_f32_parity(m, q_in, dq_in, dt, got_q, got_dq, ref_q, ref_dq, tol=1e-5
     over = np.flatnonzero((eq >= tol) | (edq >= tol))
     if len(over):
         f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
-        sq, sdq = oracle_sensitivity(m, f32(q_in)[over], f32(dq_in)[over], dt, **kw)
+        kw_over = {k: (np.asarray(v)[over] if hasattr(v, "__len__") and len(v) == len(eq) else v) for k, v in kw.items()}
+        sq, sdq = oracle_sensitivity(m, f32(q_in)[over], f32(dq_in)[over], dt, **kw_over)
         for k, w in enumerate(over):
             assert max(eq[w], edq[w]) < cap and eq[w] <= max(tol, 2 * sq[k]) and edq[w] <= max(tol, 2 * sdq[k]), \
                 "world %d: err q %.2e dq %.2e, oracle sensitivity q %.2e dq %.2e" % (w, eq[w], edq[w], sq[k], sdq[k])

@@ -289,3 +289,21 @@ def test_hdf5logger_needs_h5py_for_hdf5_files(tmp_path):
     assert obs.root == "/sim/run1"
     with pytest.raises(ValueError):
         Hdf5Logger(str(tmp_path / "a.npz"), mode='r')
+
+
+def test_random_trees_flatten_and_step_through_the_oracle():
+    """The randomised worlds of tests/test_gpu_random_models.py (general mounting frames on both sides of every
+    joint, interior FreeJoints, several roots, mixed constraints) flatten into DFS-preorder models the C ABI
+    accepts (checked without a GPU up to arb_model_create's own validation) and step through the oracle."""
+    import arb_oracle as O
+    from test_gpu_random_models import random_world
+    from arboris_python_amd.flatten import flatten_world
+    for seed in (0, 3, 8, 13):
+        w = random_world(seed)
+        m, q0, dq0 = flatten_world(w)
+        assert m.ndof == w.ndof and len(q0) == m.nq
+        # DFS preorder: every subtree is a contiguous range of bodies
+        for b in range(m.nb):
+            assert m.parent[b] < b
+        q, dq, cf = O.step(m, q0[None], dq0[None], 5e-3)
+        assert np.isfinite(q).all() and np.isfinite(dq).all()
