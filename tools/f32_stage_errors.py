@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does a float32 step lose accuracy?  Stage-by-stage relative errors (device float32 inspect outputs against
 the float64 oracle on the same float32-rounded inputs) for one randomised model of tests/test_gpu_random_models.py.
-usage (GPU box): python tools/f32_stage_errors.py [seed]"""
+usage (GPU box): python tools/f32_stage_errors.py [seed | rand4 | rand8]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -12,14 +12,23 @@ from test_gpu_random_models import random_world
 from arboris_python_amd.flatten import flatten_world
 from arboris_python_amd.batch import BatchedWorlds
 from arboris_python_amd import synth
-seed = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-w = random_world(seed)
-m, q0, dq0 = flatten_world(w)
-B = 12
-q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1))
-qr, dqr = synth.random_states(m, B, seed=seed, angle=0.8, vel=1.5, root_box=((-.3, .3), (-.2, .5), (-.3, .3)))
-q[1:], dq[1:] = qr[1:], dqr[1:]
-dt = float(np.random.default_rng(100 + seed).choice([2e-3, 5e-3]))
+if len(sys.argv) > 1 and sys.argv[1].startswith("rand"):
+    # the hardest golden states of the headline model: tests/golden/g3_contacts.npz rand4 / rand8
+    from conftest import load_golden, load_model
+    nc = int(sys.argv[1][4:])
+    m, _, _ = load_model("human36_c%d" % nc)
+    g = load_golden("g3_contacts.npz")
+    q, dq, dt = g["rand%d_q" % nc], g["rand%d_dq" % nc], 5e-3
+    B = len(q)
+else:
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    w = random_world(seed)
+    m, q0, dq0 = flatten_world(w)
+    B = 12
+    q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1))
+    qr, dqr = synth.random_states(m, B, seed=seed, angle=0.8, vel=1.5, root_box=((-.3, .3), (-.2, .5), (-.3, .3)))
+    q[1:], dq[1:] = qr[1:], dqr[1:]
+    dt = float(np.random.default_rng(100 + seed).choice([2e-3, 5e-3]))
 f = lambda a: np.asarray(a, np.float32).astype(np.float64)
 q, dq = f(q), f(dq)
 print("model: jtype", list(map(int, m.jtype)), "ctype", list(map(int, m.ctype)), "ndof", m.ndof, "dt", dt)
