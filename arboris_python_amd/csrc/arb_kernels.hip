@@ -103,6 +103,7 @@ template <typename T>
 struct DevModel {
     int nb, n, nq, nc, ndol, ncols, maxdepth;
     int has_visc, has_pd, has_warm, has_grav;
+    Layout lay;      // LDS offsets of this precision's kernels: re-read per phase instead of held in SGPRs for the whole launch
     double up[3];
     T grav[3];
     const T *pd_kp, *pd_kd, *pd_tau0;         // [n][n], [n][n], [n] (merged PD controllers; rarely present)
@@ -564,15 +565,22 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     const long w = blockIdx.x;
     if (w >= nworlds) return;
     T *lds = reinterpret_cast<T *>(arb_lds_raw);
-    T *qs = lds + L.q, *dqs = lds + L.dq, *qd = lds + L.qd, *BD = lds + L.bd, *SC = lds + L.sc;
-    double *PD = reinterpret_cast<double *>(lds + L.pd);
-    T *CD = lds + L.cd, *RT = lds + L.rt;
-    T *AM = lds + L.am, *VV = lds + L.vv, *FF = lds + L.ff, *FF0 = lds + L.ff0, *WORK = lds + L.work;
+    T *qs, *dqs, *qd, *BD, *SC, *CD, *RT, *AM, *VV, *FF, *FF0, *WORK;
+    double *PD;
+    int *CI;
+// (after the first global store the compiler no longer proves the model unclobbered and fetches it with vector
+// loads: readfirstlane puts the wave-uniform values back into SGPRs)
+#define ARB_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#define ARB_LDS_POINTERS() do { const Layout &lay_ = mp->lay;                                                              \
+        qs = lds + ARB_UNI(lay_.q); dqs = lds + ARB_UNI(lay_.dq); qd = lds + ARB_UNI(lay_.qd); BD = lds + ARB_UNI(lay_.bd); SC = lds + ARB_UNI(lay_.sc);               \
+        PD = reinterpret_cast<double *>(lds + ARB_UNI(lay_.pd)); CD = lds + ARB_UNI(lay_.cd); RT = lds + ARB_UNI(lay_.rt); AM = lds + ARB_UNI(lay_.am);       \
+        VV = lds + ARB_UNI(lay_.vv); FF = lds + ARB_UNI(lay_.ff); FF0 = lds + ARB_UNI(lay_.ff0); WORK = lds + ARB_UNI(lay_.work);                             \
+        CI = reinterpret_cast<int *>(lds + ARB_UNI(lay_.ci)); } while (0)
+    ARB_LDS_POINTERS();
     // (the sizes are re-laundered at every phase boundary, ARB_OPAQUE_LANE: left to itself the compiler hoists
     // the ~90 wave-uniform predicates `i < n` of the unrolled row loops out of the step loop as 64-bit lane masks
     // and then spills them -- 284 SGPR spills in round 1)
-    const int n0 = mp->n, nb0 = mp->nb, nc0 = mp->nc, ndol0 = mp->ndol;
-    int n = n0, nb = nb0, nc = nc0, ndol = ndol0;
+    int n = mp->n, nb = mp->nb, nc = mp->nc, ndol = mp->ndol;
     const int nq = mp->nq;
     // the host picks the smallest register tile that holds ndof (kNmaxChoices): rows below the previous tile
     // size always exist, which folds their `i < n` predicates away
@@ -580,7 +588,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     constexpr bool LSCAN_OK = NMAX <= 48;      // (the 64-row tiles are register-bound: only the DPP scan is compiled in)
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
     T dt = dt_in, inv_dt = T(1) / dt_in;
-    const bool do_constraints = (nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
+    // (evaluated where it is used, from the laundered nc: as one hoisted flag it lives in spilled lane masks)
+#define do_constraints ((nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS))
 
     // ---- load state (coalesced, world-major) -----------------------------
     for (int i = lane; i < nq; i += WAVE) qs[i] = gq[w * nq + i];
@@ -591,7 +600,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         FF[i] = f;
     }
     const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
-    int *CI = reinterpret_cast<int *>(lds + L.ci);
     if (lane < nc) {
         const int b1 = mp->cbody[lane], b0 = mp->cbody0[lane];
         const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
@@ -625,8 +633,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #define ARB_ASTAMP(k) do { } while (0)
 #endif
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); \
-                              n = n0; nb = nb0; nc = nc0; ndol = ndol0;                                             \
-                              asm volatile("" : "+s"(n), "+s"(nb), "+s"(nc), "+s"(ndol)); } while (0)
+                              n = ARB_UNI(mp->n); nb = ARB_UNI(mp->nb); nc = ARB_UNI(mp->nc); ndol = ARB_UNI(mp->ndol); \
+                              asm volatile("" : "+s"(n), "+s"(nb), "+s"(nc), "+s"(ndol)); ARB_LDS_POINTERS(); } while (0)
 
     // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
     // columns in RT, then every joint integrates its position.
@@ -1173,7 +1181,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 // dof lanes (lane k takes the composite of body(k)), so that only one element is in flight.
                 const bool two_rows = nb > 16, four_rows = nb > 32;
                 const int hi = (lane < nb) ? lane + mp->subsize[lane] - 1 : lane;
-                if (LSCAN_OK && L.lscan) {
+                if (LSCAN_OK && mp->lay.lscan) {
                     // Small trees (the table fits the staging area): the same inclusive prefix sums, formed in LDS with
                     // the roles transposed -- lane = accumulator, a serial pass over the bodies: nb additions in all
                     // instead of 4-6 DPP steps + two lane exchanges per accumulator (~210 instead of ~1700 wave
@@ -1279,7 +1287,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         rg += Xk[i - (NACC - 6)] * e;
                     }
                 };
-                if (LSCAN_OK && L.lscan) {
+                if (LSCAN_OK && mp->lay.lscan) {
                     typedef double D2 __attribute__((ext_vector_type(2)));
                     const int a = bsrc, top = a + mp->subsize[a] - 1;
                     const D2 *ph = reinterpret_cast<const D2 *>(STG + TB_STRIDE * top);
@@ -1427,9 +1435,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             gf0 += acc;
             rhs += acc - accv;
             if (MODE == 0 || zmode == 0) {
+                // (a size of its own: sharing `i < n` with the rows of phase B keeps 44 lane masks alive, spilled)
+                int npd = ARB_UNI(mp->n);
+                asm volatile("" : "+s"(npd));
+                const T *kpp = mp->pd_kp, *kdp = mp->pd_kd;
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i)
-                    if (i < n) Z[i] += dt * mp->pd_kp[i * n + lane] + mp->pd_kd[i * n + lane];
+                    if (i < npd) Z[i] += dt * kpp[i * npd + lane] + kdp[i * npd + lane];
             }
         }
         WAVE_SYNC();
@@ -1808,6 +1820,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (dbg.dq_next != nullptr && lane < n) dbg.dq_next[w * n + lane] = dqs[lane];
     }
 }
+#undef do_constraints
+#undef ARB_LDS_POINTERS
+#undef ARB_UNI
 
 // ===========================================================================
 // Gauss-Seidel with one LANE per world (split execution).  Same per-constraint
@@ -2388,6 +2403,10 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     if (rc == ARB_OK)
         rc = build_dev<double>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
+    int tot;
+    M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
+    M->ld = M->dd.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
+    if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     {
         // one blob per precision
         void *pf = nullptr, *pd = nullptr;
@@ -2404,10 +2423,6 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         }
         M->df_dev = static_cast<DevModel<float> *>(pf); M->dd_dev = static_cast<DevModel<double> *>(pd);
     }
-    int tot;
-    M->lf = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
-    M->ld = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
-    if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     *out = M;
     return ARB_OK;
 }
