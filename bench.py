@@ -284,6 +284,11 @@ def main():
     if args.dry_run:
         return dry_run(args, cfg)
 
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there while the job runs (RCCL
+    # prints its version banner on stdout at communicator creation) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -446,7 +451,8 @@ def main():
                                        "finite": bool(torch.isfinite(qe).all())}
             b2.close()
         res["extra"] = extra
-    print(json.dumps(res))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
