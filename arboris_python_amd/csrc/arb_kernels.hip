@@ -324,6 +324,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     T q_iyn = T(0), q_muyn = T(0), q_yc0 = T(0), q_yc1 = T(0), q_yc2 = T(0), q_bsq = T(0);
     SlidePre q_sp = {0., 0., 0., 0., 0., 0.};
     double q_warm = NAN;                    // root found for this constraint in the previous sweep
+    double q_wmove = NAN;                   // how far that root had moved from the sweep before
     if (lane < ndol) {
         const int cc = lane >> 2, rr = lane & 3;
         vr = VV[lane]; fr = FF[lane];
@@ -361,6 +362,14 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
     int tr_rel = 0, tr_sta = 0, tr_slow = 0;
     T vr_prev = vr, fr_prev = fr;
+#ifdef ARB_GSSTAMPS   /* development: cycles of the segments of a sliding solve, summed over the step's sliding solves */
+    long long gst[6] = {0, 0, 0, 0, 0, 0}, gt0 = 0, gt1 = 0, gt2 = 0, gt3 = 0, gt4 = 0;
+    int gprobe[2] = {0, 0};
+    bool gslid = false;
+#define ARB_GST(v) do { if (MODE == 1) v = (long long)clock64(); } while (0)
+#else
+#define ARB_GST(v) do { } while (0)
+#endif
 #if ARB_GS_PRIO
     // the sweeps are one long dependent chain: let this wave issue ahead of the SIMD's other wave,
     // whose bulk phases have independent instructions to fill the gaps
@@ -371,6 +380,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
         for (int c = 0; c < nc; ++c) {
             if (!((actmask >> c) & 1ull)) continue;
             const int base = 4 * c;
+            ARB_GST(gt0);
             // column block Y'[:, 4c..4c+3] of this lane's row (issued early, used last)
             T a4[4] = {T(0), T(0), T(0), T(0)};
             if (lane < ndol) {
@@ -424,6 +434,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                         // vector registers (the other quads run along on their own, unused data) and every
                         // branch follows the quad of c (`uni`), so nothing travels through SGPRs but the
                         // final force increments.
+                        ARB_GST(gt1);
                         const int rq = lane - base;
                         const bool inquad = rq >= 0 && rq < 4;
                         const auto uni = [&](bool b) { return (bool)((__ballot(b) >> base) & 1ull); };
@@ -448,7 +459,23 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                             const T bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
                             double c1, kappa, root;
                             slide_c1_kappa<T>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
-                            if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni)) {
+                            ARB_GST(gt2);
+                            // The sweeps converge linearly: the root moves less and less from one sweep to the next.
+                            // Float32 worlds restart the iteration twice the last move to the left of the previous
+                            // root (instead of a fixed 1e-3 |root|): close enough that ONE Laguerre step lands within
+                            // the tolerance, far enough that the no-root-to-the-left certificate still holds.  (Float64
+                            // worlds keep the fixed offset: their bit-exact fixed point needs a start that depends on
+                            // nothing but the previous root.)
+                            double woff = -1.;
+                            if (sizeof(T) == 4 && q_wmove == q_wmove)
+                                woff = fmin(fmax(2. * q_wmove, 1e-9 * fabs(warm)), 0.1 * fabs(warm));
+#ifdef ARB_GSSTAMPS
+                            int *const probe = (MODE == 1 && lane == base) ? gprobe : nullptr;
+                            if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni, probe, woff)) {
+#else
+                            if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni, nullptr, woff)) {
+#endif
+                                if (inquad) q_wmove = fabs(root - warm);      // (NaN after a cold start)
                                 warm = root;
                                 // leftmost real eigenvalue; admissible when <= 0 (constraints.py:826-830)
                                 shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
@@ -465,15 +492,21 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                             shift = WORK[40];
                             WAVE_SYNC();
                             warm = NAN;
+                            if (inquad) q_wmove = NAN;
                         }
                         if (inquad) q_warm = warm;          // next sweep restarts next to this root
+                        ARB_GST(gt3);
                         fnew[0] = fq0; fnew[1] = fq1; fnew[2] = fq2; fnew[3] = fq3;
                         T sie2[3] = {shift, shift, shift};
                         if (!eps1) {
 #pragma unroll
                             for (int i = 0; i < 3; ++i) sie2[i] = shift / (eps[i] * eps[i]);
                         }
-                        softfinger_slide_finish_scaled<T>(Y, alpha, sie2, fnew, df);
+                        softfinger_slide_finish_scaled<T>(Y, alpha, sie2, fnew, df, uni);
+                        ARB_GST(gt4);
+#ifdef ARB_GSSTAMPS
+                        gslid = true;
+#endif
                         dfl = (rq == 0) ? df[0] : (rq == 1) ? df[1] : (rq == 2) ? df[2] : df[3];
                         fnl = (rq == 0) ? fnew[0] : (rq == 1) ? fnew[1] : (rq == 2) ? fnew[2] : fnew[3];
                         quad_done = true;
@@ -515,6 +548,14 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             }
             // vel += Y'[:, c] dforce                               core.py:935
             vr += a4[0] * df[0] + a4[1] * df[1] + a4[2] * df[2] + a4[3] * df[3];
+#ifdef ARB_GSSTAMPS
+            if (MODE == 1 && gslid) {
+                asm volatile("" :: "v"(vr), "v"(fr));
+                const long long gt5 = (long long)clock64();
+                gst[0] += gt1 - gt0; gst[1] += gt2 - gt1; gst[2] += gt3 - gt2; gst[3] += gt4 - gt3; gst[4] += gt5 - gt4; gst[5] += 1;
+                gslid = false;
+            }
+#endif
         }
         // A sweep that leaves every velocity and force bit-for-bit unchanged is a fixed point
         // of the iteration: the remaining sweeps of core.py:929-935 would repeat it exactly.
@@ -523,6 +564,15 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     }
 #if ARB_GS_PRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef ARB_GSSTAMPS
+    if (MODE == 1 && dbg.stamps != nullptr && lane == 0)
+        for (int i = 0; i < 6; ++i) dbg.stamps[w * 8 + i] = gst[i];
+    if (MODE == 1 && dbg.stamps != nullptr) {      // (each quad's base lane counted its own constraint's solves)
+        int p0 = gprobe[0], p1 = gprobe[1];
+        for (int o = 4; o < 64; o <<= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+        if (lane == 0) { dbg.stamps[w * 8 + 6] = p0; dbg.stamps[w * 8 + 7] = p1; }
+    }
 #endif
     if (MODE == 1 && dbg.gs_stats != nullptr && lane == 0) {
         int *o = dbg.gs_stats + w * 5;
@@ -611,7 +661,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     }
     WAVE_SYNC();
 
-#ifdef ARB_ASTAMPS   /* development: slots 1..6 = inside phase A (joint kinematics + H_pc, block algebra, own columns, level loop, body wrenches, end) */
+#ifdef ARB_GSSTAMPS
+#define ARB_STAMP(k) do { } while (0)
+#define ARB_BSTAMP(k) do { } while (0)
+#elif defined(ARB_ASTAMPS)   /* development: slots 1..6 = inside phase A (joint kinematics + H_pc, block algebra, own columns, level loop, body wrenches, end) */
 #define ARB_STAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0 && (k) == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)
 #define ARB_BSTAMP(k) do { } while (0)
 #define ARB_ASTAMP(k) do { if (MODE == 1 && dbg.stamps != nullptr && lane0 == 0) dbg.stamps[w * 8 + (k)] = (long long)clock64(); } while (0)

@@ -867,7 +867,7 @@ ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, doub
 // rather than a template of the function above: the scalar callers keep their text unchanged.)
 template <typename UNI>
 ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, double warm, double *root,
-                                    double step_tol, UNI uni) {
+                                    double step_tol, UNI uni, int *probe = nullptr, double woff = -1.) {
 #define U(x) uni(x)
     const double d2 = -kappa;
     const double l1 = -(3. * k.tr - k.sQ);
@@ -897,13 +897,15 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
     // arithmetic than the branches it saves).
     double x = NAN;
     if (U(warm == warm)) {
-        const double x0 = warm - 1e-3 * fabs(warm) - 1e-300;
+        // restart just left of the previous root: by `woff` when the caller knows how far the root moved last time
+        const double x0 = warm - (woff >= 0. ? woff : 1e-3 * fabs(warm)) - 1e-300;
         double t[7];
         for (int i = 0; i < 7; ++i) t[i] = pc[i];
         for (int j = 0; j < 6; ++j)                 // Taylor shift: t[i] = p^(i)(x0) / i!
             for (int i = 5; i >= j; --i) t[i] += x0 * t[i + 1];
         if (U(t[0] > 0. && t[1] < 0. && t[2] > 0. && t[3] < 0. && t[4] > 0. && t[5] < 0.)) x = x0;
     }
+    if (probe) probe[0] += (x == x) ? 1 : 0;     // development: warm start certified
     if (U(!(x == x))) {
         // |P| <= |Q| + 3 |c1| (infinity norms); every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
         const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
@@ -912,6 +914,7 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
     }
     const double n = 6.;
     for (int it = 0; it < 40; ++it) {
+        if (probe) probe[1] += 1;                 // development: Laguerre iterations
         double p0 = pc[6], p1 = 0., p2 = 0., ee = fabs(pc[6]);
         const double ax = fabs(x);
         for (int i = 5; i >= 0; --i) {
@@ -1077,7 +1080,72 @@ ARB_HD T slide_shift_from_eig(AP work) {
     return any ? (smin > T(-1e10) ? smin : T(-1e10)) : T(-1e10);   // constraints.py:827-830
 }
 
-// `sie2` = s * eps**-2 (three values)
+// The elimination of gepp4 WITHOUT the row exchanges, for one right-hand side; returns true when partial pivoting
+// would not have exchanged anything (|A[r][c]| <= |A[c][c]| below every pivot), in which case x is bit for bit what
+// gepp4 returns: the same operations in the same order.  The sliding branch's matrix Y - s diag(eps^-2), s <= 0, is
+// an admittance block pushed further towards diagonal dominance: exchanges are the exception, and the 60 selects
+// that carry them out were half of the instructions of the solve.
+template <typename T>
+ARB_HD bool solve4_no_exchange(const T Ain[4][4], const T bin[4], T x[4]) {
+    T A[4][4], B[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[i][j] = Ain[i][j];
+        B[i] = bin[i];
+    }
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) ok = ok && !(arb_abs(A[r][c]) > arb_abs(A[c][c]));
+        const T ip = arb_rcp(A[c][c]);
+        A[c][c] = ip;
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            T f = A[r][c] * ip;
+#pragma unroll
+            for (int j = c + 1; j < 4; ++j) A[r][j] -= f * A[c][j];
+            B[r] -= f * B[c];
+        }
+    }
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+        T s = B[c];
+#pragma unroll
+        for (int k = c + 1; k < 4; ++k) s -= A[c][k] * B[k];
+        B[c] = s * A[c][c];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = B[i];
+    return ok;
+}
+
+// `sie2` = s * eps**-2 (three values).  `uni` (fused kernel: the verdict of the constraint's quad for the whole wave;
+// scalar callers: identity) decides between the exchange-free elimination and gepp4.
+template <typename T, typename UNI>
+ARB_HD void softfinger_slide_finish_scaled(const T Y[16], const T alpha[4], const T sie2[3], T f[4], T df[4], UNI uni) {
+    T A[4][4], b[4], x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[i][j] = Y[4 * i + j];
+        b[i] = -alpha[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) A[i][i] -= sie2[i];                // s * diag(eps**-2)
+    if (!uni(solve4_no_exchange<T>(A, b, x))) {
+        T Bv[4][1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bv[i][0] = b[i];
+        gepp4<T, 1>(A, Bv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = Bv[i][0];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { df[i] = x[i] - f[i]; f[i] = x[i]; }
+}
+
 template <typename T>
 ARB_HD void softfinger_slide_finish_scaled(const T Y[16], const T alpha[4], const T sie2[3], T f[4], T df[4]) {
     T A[4][4], Bv[4][1];
