@@ -896,6 +896,10 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
     // +2.5 %; going further -- start point by selection, the short-step residual on every pass -- costs more
     // arithmetic than the branches it saves).
     double x = NAN;
+    // value, slope and curvature at a certified warm start come with the certificate (the Taylor shift): the first
+    // Laguerre step uses them instead of a Horner pass of its own
+    double w0 = 0., w1 = 0., w2 = 0.;
+    bool from_shift = false;
     if (U(warm == warm)) {
         // restart just left of the previous root: by `woff` when the caller knows how far the root moved last time
         const double x0 = warm - (woff >= 0. ? woff : 1e-3 * fabs(warm)) - 1e-300;
@@ -903,10 +907,13 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
         for (int i = 0; i < 7; ++i) t[i] = pc[i];
         for (int j = 0; j < 6; ++j)                 // Taylor shift: t[i] = p^(i)(x0) / i!
             for (int i = 5; i >= j; --i) t[i] += x0 * t[i + 1];
-        if (U(t[0] > 0. && t[1] < 0. && t[2] > 0. && t[3] < 0. && t[4] > 0. && t[5] < 0.)) x = x0;
+        if (U(t[0] > 0. && t[1] < 0. && t[2] > 0. && t[3] < 0. && t[4] > 0. && t[5] < 0.)) {
+            x = x0; w0 = t[0]; w1 = t[1]; w2 = 2. * t[2]; from_shift = true;
+        }
     }
-    if (probe) probe[0] += (x == x) ? 1 : 0;     // development: warm start certified
-    if (U(!(x == x))) {
+    if (probe) probe[0] += from_shift ? 1 : 0;   // development: warm start certified
+    // (`from_shift` is only ever assigned under wave-uniform branches: a scalar flag, tested without a ballot)
+    if (!from_shift) {
         // |P| <= |Q| + 3 |c1| (infinity norms); every eigenvalue has |s| <= max(|P|,|Q|) + sqrt|kappa|
         const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
         if (U(!(rb > 0.) || !(rb < 1e300))) return false;
@@ -915,14 +922,22 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
     const double n = 6.;
     for (int it = 0; it < 40; ++it) {
         if (probe) probe[1] += 1;                 // development: Laguerre iterations
-        double p0 = pc[6], p1 = 0., p2 = 0., ee = fabs(pc[6]);
-        const double ax = fabs(x);
-        for (int i = 5; i >= 0; --i) {
-            p2 = p2 * x + p1; p1 = p1 * x + p0; p0 = p0 * x + pc[i];
-            ee = ee * ax + fabs(p0);                    // running Horner error bound
+        double p0, p1, p2;
+        bool zero = false;
+        if (from_shift) {
+            p0 = w0; p1 = w1; p2 = w2;           // (p > 0 > p' certified: the rounding-level zero test is not needed here)
+            from_shift = false;
+        } else {
+            double ee = fabs(pc[6]);
+            p0 = pc[6]; p1 = 0.; p2 = 0.;
+            const double ax = fabs(x);
+            for (int i = 5; i >= 0; --i) {
+                p2 = p2 * x + p1; p1 = p1 * x + p0; p0 = p0 * x + pc[i];
+                ee = ee * ax + fabs(p0);                    // running Horner error bound
+            }
+            p2 *= 2.;
+            zero = fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0));      // p(x) = 0 to rounding
         }
-        p2 *= 2.;
-        const bool zero = fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0));      // p(x) = 0 to rounding
         // Laguerre step  dx = n p / (p' - sqrt((n-1)((n-1) p'^2 - n p p'')))  (p' < 0 here).
         // Only the step uses approximate sqrt / reciprocal (hardware v_rsq_f64 / v_rcp_f64,
         // ~1e-8 relative): the accuracy of the root is set by the float64 Horner values and
