@@ -223,6 +223,8 @@ def resolve_config(args):
     if args.batch is not None:
         cfg["batch"] = args.batch
     if args.contacts is not None and cfg["model"] == "human36":
+        if args.contacts != cfg["contacts"]:
+            cfg["name"] += " -- overridden: %d floor contacts" % args.contacts
         cfg["contacts"] = args.contacts
         cfg["states"] = "standing" if args.contacts else "random"
     if args.dtype is not None:

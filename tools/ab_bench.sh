@@ -1,11 +1,9 @@
 #!/bin/bash
-# A/B of development builds on the GPU box: final-state comparison + bench.py for each library given.
-# usage (through gpurun): bash tools/ab_bench.sh build/libq_old.so build/libq_new.so
-R=${GRAFT_REPO_ROOT:-/root/repo}
-first=""
-for lib in "$@"; do
-  export ARBSTEP_LIB=$R/$lib
-  if [ -z "$first" ]; then timeout -k 10 120 python tools/pack_check.py /tmp/ab_ref.npz || exit 1; first=1
-  else timeout -k 10 120 python tools/pack_check.py /tmp/ab_new.npz /tmp/ab_ref.npz | grep -v "snap [12]" || exit 1; fi
-  timeout -k 10 200 python bench.py --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', 'M world-steps/s %.3f' % (d['value']/1e6), 'episode launch ms %.3f' % d['roofline']['kernel_ms'], 'per-step launches %.3f M, %.4f ms' % (d['per_step_launch']['value']/1e6, d['per_step_launch']['kernel_ms']))" || exit 1
+# Same-box A/B of development builds (tools/quick_build.sh): AB_VARIANTS="a b" [AB_ARGS="--batch 65536"] tools/ab_bench.sh
+# runs bench.py on build/ab/<variant>.so twice, interleaved, and prints world-steps/s.
+set -e
+for r in 1 2; do
+ for v in ${AB_VARIANTS:-old new}; do
+  echo -n "$v: "; ARBSTEP_LIB=build/ab/$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --no-per-step-leg --min-seconds 2 ${AB_ARGS} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])"
+ done
 done
