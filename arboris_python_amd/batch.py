@@ -104,7 +104,7 @@ class BatchedWorlds(object):
 
     # -- the step --------------------------------------------------------------
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
-             stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False):
+             stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
@@ -113,6 +113,8 @@ class BatchedWorlds(object):
         (ARB_STEP_SPLIT: faster from ~16k worlds with <= 4 constraints, same results to rounding; opt-in,
         see DESIGN.md); the default keeps them in the step kernel (``fused`` is accepted for symmetry).
         ``mfma=True`` (float32): phase C eliminates on the matrix cores (ARB_STEP_MFMA_ELIM; slower).
+        ``static_worlds=True``: one workgroup per world for the whole launch (ARB_STEP_STATIC_WORLDS) instead of the
+        device-side queue of (chunk of steps, world) items that multi-step launches of large batches use by default.
         ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller).
         ``pd_targets=(qdes, dqdes)`` (B,ndof) each: one ProportionalDerivativeController target
         per world (controllers.py:63-158), with the model's gains, or with the per-world DIAGONAL
@@ -129,6 +131,8 @@ class BatchedWorlds(object):
             flags |= _capi.ARB_STEP_SPLIT
         if mfma:
             flags |= _capi.ARB_STEP_MFMA_ELIM
+        if static_worlds:
+            flags |= _capi.ARB_STEP_STATIC_WORLDS
         dts = self._dt_steps(dt, nsteps)
         if pd_targets is None and pd_gains is None and dts is None:
             _capi.check(self._lib.arb_step(

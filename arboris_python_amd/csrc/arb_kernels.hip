@@ -83,6 +83,7 @@
 struct Layout {      // offsets in elements of T inside the wave's LDS block
     int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, ci, total;
     int lscan;       // phase B forms the subtree sums from a prefix table in LDS (small trees) instead of a DPP scan
+    int ndol;        // rows of the stacked constraint system (host side: does the model carry constraint forces?)
 };
 // per-constraint integer constants staged in LDS once per launch (int32 words): type, dof masks of the ancestors of
 // body 1 and of body 0 (lo, hi each), constrained dof -- the constraint-row loops of phase B read them with
@@ -595,10 +596,10 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 // SIMD, so their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
 __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVES_PER_EU) void arb_step_kernel(
-    const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq, T *__restrict__ gdq,
-    T *__restrict__ gcforce, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
+    const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
+    T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
-    const double *__restrict__ dts_in)
+    const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk)
 {
     static_assert(MODE == 0 || FEAT == 1, "the inspect kernels take every input");
     static_assert(CM == 0 || (FEAT == 1 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
@@ -612,8 +613,47 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     const DevModel<T> *mp = mp_in;     // device-resident model, fields fetched with scalar loads
     const int lane0 = threadIdx.x;
     int lane = lane0;
-    const long w = blockIdx.x;
-    if (w >= nworlds) return;
+    // Work queue (multi-step launches of more worlds than the chip holds wavefronts): a world's episode is cut into
+    // chunks of `queue_chunk` steps and the resident wavefronts draw (chunk, world) items from one atomic counter
+    // instead of owning one world each.  With one workgroup per world a launch lasts as long as its unluckiest
+    // slot -- the sum of two or three whole episodes whose lengths differ by tens of per cent (the sweeps) -- and
+    // 17 % of the wave slots sat idle at 4096 worlds; drawn chunk by chunk the slots stay full until the last
+    // chunk.  queue[0] = next item, queue[1 + w] = chunks of world w that are finished (release / acquire, agent
+    // scope: the state travels through global memory between wavefronts on different XCDs).  Items are numbered
+    // chunk-major, so the chunk an item waits for was drawn nworlds items earlier: it is finished, or it is running
+    // on a resident wavefront that waits for nothing drawn later -- no circular wait; the spin is capped all the same.
+    // (not in the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs: with
+    // the item loop around the body that instantiation faulted on its first launch -- queue or not -- on ROCm 7.2; the
+    // constant null below folds the loop away there and leaves the round-1 code shape)
+    constexpr bool QUEUE_OK = !(sizeof(T) == 8 && NMAX == 64);
+    int *const queue = (MODE == 0 && QUEUE_OK) ? queue_in : nullptr;
+    T *gq = gq_in, *gdq = gdq_in, *gcforce = gcforce_in;
+    long w = blockIdx.x;
+    int step_lo = 0, step_hi = nsteps, qitem_chunk = 0;
+    for (;;) {     // one pass per work item; a single pass without the queue
+    if (queue != nullptr) {
+        int item = 0;
+        if (lane0 == 0) item = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = __builtin_amdgcn_readfirstlane(item);
+        const int nchunks = (nsteps + queue_chunk - 1) / queue_chunk;
+        if ((long)item >= nworlds * (long)nchunks) return;
+        w = item % (int)nworlds;
+        qitem_chunk = item / (int)nworlds;
+        step_lo = qitem_chunk * queue_chunk;
+        step_hi = step_lo + queue_chunk < nsteps ? step_lo + queue_chunk : nsteps;
+        if (qitem_chunk > 0) {
+            int spins = 0;
+            while (__hip_atomic_load(queue + 1 + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < qitem_chunk && spins < (1 << 24)) {
+                __builtin_amdgcn_s_sleep(16);
+                ++spins;
+            }
+        }
+        // (the state pointers are `restrict` kernel arguments: hand the compiler pointers it knows nothing about, so
+        // that no load of the state is scheduled above the acquire)
+        asm volatile("" : "+s"(gq), "+s"(gdq), "+s"(gcforce));
+    } else if (w >= nworlds) {
+        return;
+    }
     T *lds = reinterpret_cast<T *>(arb_lds_raw);
     T *qs, *dqs, *qd, *BD, *SC, *CD, *RT, *AM, *VV, *FF, *FF0, *WORK;
     double *PD;
@@ -732,9 +772,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (FEAT && dts != nullptr) { dt = (T)dts[-1]; inv_dt = T(1) / dt; }      // the step being finished
         integrate_from_rt(true);
     }
-    if (MODE == 0 && sio.mode != 0 && !(sio.mode & 2)) nsteps = 0;      // apply only
+    if (MODE == 0 && sio.mode != 0 && !(sio.mode & 2)) step_hi = step_lo;      // apply only
 
-    for (int step = 0; step < nsteps; ++step) {
+    for (int step = step_lo; step < step_hi; ++step) {
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
@@ -1872,6 +1912,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (dbg.q_next != nullptr) for (int i = lane; i < nq; i += WAVE) dbg.q_next[w * nq + i] = qs[i];
         if (dbg.dq_next != nullptr && lane < n) dbg.dq_next[w * n + lane] = dqs[lane];
     }
+    if (queue == nullptr) break;
+    // publish the chunk: every lane's stores of the state, then the flag (release, agent scope), then the next item.
+    // (LDS is reused by the next item: all lanes are past their last LDS access -- one wavefront, program order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    WAVE_SYNC();
+    if (lane0 == 0) __hip_atomic_store(queue + 1 + w, qitem_chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }     // work items
 }
 #undef do_constraints
 #undef ARB_LDS_POINTERS
@@ -2076,6 +2123,16 @@ thread_local std::string g_hip_err;
 // kernels of one register tile and precision only (explicit instantiations below) and none of the
 // host code; the main unit declares them extern and holds the C ABI.
 // ---------------------------------------------------------------------------
+// Wave slots of the chip for a kernel (workgroups of one wavefront): CUs x resident workgroups per CU.
+template <typename K>
+static int wave_slots(K kern, size_t lds) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WAVE, lds) != hipSuccess) return 0;
+    return cus * per_cu;
+}
+
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
 int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw, double dt,
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
@@ -2085,8 +2142,33 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio, dts);
+    // Work queue (see the kernel): multi-step launches of more worlds than the chip has wave slots.  Constraint forces
+    // that persist from step to step travel between chunks through `cf`, so it must be there when the model has
+    // constraints.  ARB_STEP_STATIC_WORLDS (or ARB_QUEUE_CHUNK=0 in the environment) keeps one workgroup per world.
+    static const int chunk = [] { const char *e = getenv("ARB_QUEUE_CHUNK"); return e ? atoi(e) : 4; }();
+    int *queue = nullptr;
+    unsigned grid = (unsigned)nw;
+    constexpr bool QUEUE_OK = !(sizeof(T) == 8 && NMAX == 64);       // (see the kernel)
+    if (MODE == 0 && QUEUE_OK && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 * chunk &&
+        (cf != nullptr || L.ndol == 0) && nw * (long)((nsteps + chunk - 1) / chunk) < (1l << 30)) {
+        static size_t slots_lds = ~(size_t)0;
+        static int slots = 0;
+        if (slots_lds != lds) { slots = wave_slots(kern, lds); slots_lds = lds; }
+        if (slots > 0 && nw > slots) {
+            const size_t bytes = (size_t)(1 + nw) * sizeof(int);
+            if (hipMallocAsync(reinterpret_cast<void **>(&queue), bytes, st) == hipSuccess) {
+                HIP_TRY(hipMemsetAsync(queue, 0, bytes, st));
+                grid = (unsigned)slots;
+            } else {
+                (void)hipGetLastError();
+                queue = nullptr;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio, dts,
+                       queue, chunk > 0 ? chunk : 1);
     HIP_TRY(hipGetLastError());
+    if (queue != nullptr) HIP_TRY(hipFreeAsync(queue, st));
     return ARB_OK;
 }
 
@@ -2221,6 +2303,7 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
         L.ci = o; o += al(elems_per_double == 2 ? words : (words + 1) / 2);     // (float: one word per element; double: two)
     }
     L.total = o;
+    L.ndol = ndol;
     L.lscan = lds_scan(nb, rs) ? 1 : 0;
     *total_elems = o;
     return L;

@@ -93,6 +93,11 @@ enum {
 #define ARB_STEP_MFMA_ELIM 16u        /* float32 only: eliminate the augmented system [Z | rhs | J'^T] on the matrix cores
                                          (v_mfma_f32_4x4x1_16b_f32 rank-1 updates) instead of the vector ALU; same results to
                                          rounding, measured SLOWER on MI355X: opt-in */
+#define ARB_STEP_STATIC_WORLDS 32u     /* one workgroup per world for the whole launch.  Default for multi-step launches of more
+                                         worlds than the chip holds wavefronts: the resident wavefronts draw (chunk of 4 steps,
+                                         world) items from a device-side queue, which keeps the wave slots full until the last
+                                         chunk (same results bit for bit; the queue is a stream-ordered allocation, so a launch
+                                         has no hidden synchronisation) */
 #define ARB_STEP_SPLIT_WAVE 8u        /* run the sweeps in a second kernel with one WAVEFRONT per world (the fused kernel's
                                          quad-local sweeps, bit-identical results, compiled for more waves per SIMD) */
 
