@@ -599,7 +599,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
     T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
-    const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk)
+    const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail)
 {
     static_assert(MODE == 0 || FEAT == 1, "the inspect kernels take every input");
     static_assert(CM == 0 || (FEAT == 1 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
@@ -618,8 +618,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     // instead of owning one world each.  With one workgroup per world a launch lasts as long as its unluckiest
     // slot -- the sum of two or three whole episodes whose lengths differ by tens of per cent (the sweeps) -- and
     // 17 % of the wave slots sat idle at 4096 worlds; drawn chunk by chunk the slots stay full until the last
-    // chunk.  queue[0] = next item, queue[1 + w] = chunks of world w that are finished (release / acquire, agent
-    // scope: the state travels through global memory between wavefronts on different XCDs).  Items are numbered
+    // chunk.  queue[0] = next item, queue[1 + w] = chunks of world w that are finished (the state travels through
+    // global memory between wavefronts on different XCDs: coherent accesses, see `ldg` / `stg`).  Items are numbered
     // chunk-major, so the chunk an item waits for was drawn nworlds items earlier: it is finished, or it is running
     // on a resident wavefront that waits for nothing drawn later -- no circular wait; the spin is capped all the same.
     // (not in the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs: with
@@ -635,18 +635,27 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         int item = 0;
         if (lane0 == 0) item = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         item = __builtin_amdgcn_readfirstlane(item);
-        const int nchunks = (nsteps + queue_chunk - 1) / queue_chunk;
+        // chunks of queue_chunk steps, then the last queue_tail steps one by one: what is left of the idle time is the
+        // length of the last items
+        const int nhead = nsteps - queue_tail, nbig = (nhead + queue_chunk - 1) / queue_chunk;
+        const int nchunks = nbig + queue_tail;
         if ((long)item >= nworlds * (long)nchunks) return;
         w = item % (int)nworlds;
         qitem_chunk = item / (int)nworlds;
-        step_lo = qitem_chunk * queue_chunk;
-        step_hi = step_lo + queue_chunk < nsteps ? step_lo + queue_chunk : nsteps;
+        if (qitem_chunk < nbig) {
+            step_lo = qitem_chunk * queue_chunk;
+            step_hi = step_lo + queue_chunk < nhead ? step_lo + queue_chunk : nhead;
+        } else {
+            step_lo = nhead + (qitem_chunk - nbig);
+            step_hi = step_lo + 1;
+        }
         if (qitem_chunk > 0) {
             int spins = 0;
-            while (__hip_atomic_load(queue + 1 + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < qitem_chunk && spins < (1 << 24)) {
+            while (__hip_atomic_load(queue + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < qitem_chunk && spins < (1 << 24)) {
                 __builtin_amdgcn_s_sleep(16);
                 ++spins;
             }
+            asm volatile("" ::: "memory");      // (order only: the coherent loads of the state are issued after the flag was seen)
         }
         // (the state pointers are `restrict` kernel arguments: hand the compiler pointers it knows nothing about, so
         // that no load of the state is scheduled above the acquire)
@@ -682,11 +691,21 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #define do_constraints ((nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS))
 
     // ---- load state (coalesced, world-major) -----------------------------
-    for (int i = lane; i < nq; i += WAVE) qs[i] = gq[w * nq + i];
-    dqs[lane] = (lane < n) ? gdq[w * n + lane] : T(0);
+    // (queue mode: the state of a world passes from one wavefront to another, possibly on another XCD with its own
+    // L2: its loads and stores are agent-scope relaxed atomics -- coherent by themselves, sc1 -- ordered against the
+    // flag by s_waitcnt alone, instead of writing back and invalidating the whole L2 around every item)
+    auto ldg = [&](const T *p) -> T {
+        return queue != nullptr ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    };
+    auto stg = [&](T *p, T v) {
+        if (queue != nullptr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
+    for (int i = lane; i < nq; i += WAVE) qs[i] = ldg(gq + w * nq + i);
+    dqs[lane] = (lane < n) ? ldg(gdq + w * n + lane) : T(0);
     for (int i = lane; i < ndol; i += WAVE) {
         T f = T(0);
-        if (gcforce != nullptr) f = gcforce[w * ndol + i];
+        if (gcforce != nullptr) f = ldg(gcforce + w * ndol + i);
         FF[i] = f;
     }
     const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
@@ -1904,10 +1923,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     ARB_OPAQUE_LANE();
     ARB_STAMP(7);
     if (MODE == 0) {
-        for (int i = lane; i < nq; i += WAVE) gq[w * nq + i] = qs[i];
-        if (lane < n) gdq[w * n + lane] = dqs[lane];
+        for (int i = lane; i < nq; i += WAVE) stg(gq + w * nq + i, qs[i]);
+        if (lane < n) stg(gdq + w * n + lane, dqs[lane]);
         if (gcforce != nullptr && !(sio.mode & 2))
-            for (int i = lane; i < ndol; i += WAVE) gcforce[w * ndol + i] = FF[i];
+            for (int i = lane; i < ndol; i += WAVE) stg(gcforce + w * ndol + i, FF[i]);
     } else {
         if (dbg.q_next != nullptr) for (int i = lane; i < nq; i += WAVE) dbg.q_next[w * nq + i] = qs[i];
         if (dbg.dq_next != nullptr && lane < n) dbg.dq_next[w * n + lane] = dqs[lane];
@@ -1915,9 +1934,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     if (queue == nullptr) break;
     // publish the chunk: every lane's stores of the state, then the flag (release, agent scope), then the next item.
     // (LDS is reused by the next item: all lanes are past their last LDS access -- one wavefront, program order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the coherent stores above are performed
     WAVE_SYNC();
-    if (lane0 == 0) __hip_atomic_store(queue + 1 + w, qitem_chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane0 == 0) __hip_atomic_store(queue + 1 + w, qitem_chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }     // work items
 }
 #undef do_constraints
@@ -2146,11 +2165,13 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     // that persist from step to step travel between chunks through `cf`, so it must be there when the model has
     // constraints.  ARB_STEP_STATIC_WORLDS (or ARB_QUEUE_CHUNK=0 in the environment) keeps one workgroup per world.
     static const int chunk = [] { const char *e = getenv("ARB_QUEUE_CHUNK"); return e ? atoi(e) : 4; }();
+    static const int tail_env = [] { const char *e = getenv("ARB_QUEUE_TAIL"); return e ? atoi(e) : 4; }();
+    const int tail = std::max(0, std::min(tail_env, nsteps - 1));
     int *queue = nullptr;
     unsigned grid = (unsigned)nw;
     constexpr bool QUEUE_OK = !(sizeof(T) == 8 && NMAX == 64);       // (see the kernel)
     if (MODE == 0 && QUEUE_OK && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 * chunk &&
-        (cf != nullptr || L.ndol == 0) && nw * (long)((nsteps + chunk - 1) / chunk) < (1l << 30)) {
+        (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
         static size_t slots_lds = ~(size_t)0;
         static int slots = 0;
         if (slots_lds != lds) { slots = wave_slots(kern, lds); slots_lds = lds; }
@@ -2166,7 +2187,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio, dts,
-                       queue, chunk > 0 ? chunk : 1);
+                       queue, chunk > 0 ? chunk : 1, tail);
     HIP_TRY(hipGetLastError());
     if (queue != nullptr) HIP_TRY(hipFreeAsync(queue, st));
     return ARB_OK;
