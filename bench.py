@@ -376,7 +376,9 @@ def main():
         "config": {"workload": "%s, batch %d worlds/GPU, dt=%g, %s, whole %d-step episodes, one arb_step launch per episode%s"
                                % (cfg["name"], B, dt, cfg["dtype"], EP, (", Gauss-Seidel in a %s-per-world kernel" % args.split) if args.split else ""),
                    "baseline_config": args.config, "worlds_per_gpu": B, "global_batch": n_gpus * B,
-                   "parallelism": "dp%d" % n_gpus, "steps_per_launch": EP / launches_per_episode},
+                   "parallelism": "dp%d" % n_gpus, "steps_per_launch": EP / launches_per_episode,
+                   "launch": "arb_step default: with more worlds than resident wavefronts the kernel draws (4-step chunk, "
+                             "world) work items from a device-side queue (include/arbstep.h, ARB_STEP_STATIC_WORLDS turns it off)"},
         "roofline": {"bound": "valu-issue",
                      "bound_note": "north_star asks for the HBM fraction, which achieved/peak/frac report; compulsory "
                                    "traffic is the state in+out once per episode launch, so the path is bound by the "
