@@ -622,11 +622,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     // global memory between wavefronts on different XCDs: coherent accesses, see `ldg` / `stg`).  Items are numbered
     // chunk-major, so the chunk an item waits for was drawn nworlds items earlier: it is finished, or it is running
     // on a resident wavefront that waits for nothing drawn later -- no circular wait; the spin is capped all the same.
-    // (not in the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs: with
-    // the item loop around the body that instantiation faulted on its first launch -- queue or not -- on ROCm 7.2; the
-    // constant null below folds the loop away there and leaves the round-1 code shape)
-    constexpr bool QUEUE_OK = !(sizeof(T) == 8 && NMAX == 64);
-    int *const queue = (MODE == 0 && QUEUE_OK) ? queue_in : nullptr;
+    // (the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs, faulted on
+    // their first launch -- queue or not -- with the item loop around the body, ROCm 7.2: there every workgroup draws
+    // ONE item and the grid is the number of items; the hardware dispatcher does the looping)
+#ifndef ARB_QUEUE_LOOP
+#define ARB_QUEUE_LOOP 1
+#endif
+    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);
+    int *const queue = (MODE == 0) ? queue_in : nullptr;
     T *gq = gq_in, *gdq = gdq_in, *gcforce = gcforce_in;
     long w = blockIdx.x;
     int step_lo = 0, step_hi = nsteps, qitem_chunk = 0;
@@ -1937,6 +1940,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the coherent stores above are performed
     WAVE_SYNC();
     if (lane0 == 0) __hip_atomic_store(queue + 1 + w, qitem_chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!QUEUE_LOOP) break;
     }     // work items
 }
 #undef do_constraints
@@ -2169,8 +2173,8 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     const int tail = std::max(0, std::min(tail_env, nsteps - 1));
     int *queue = nullptr;
     unsigned grid = (unsigned)nw;
-    constexpr bool QUEUE_OK = !(sizeof(T) == 8 && NMAX == 64);       // (see the kernel)
-    if (MODE == 0 && QUEUE_OK && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 * chunk &&
+    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);     // (see the kernel)
+    if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 * chunk &&
         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
         static size_t slots_lds = ~(size_t)0;
         static int slots = 0;
@@ -2179,7 +2183,9 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
             const size_t bytes = (size_t)(1 + nw) * sizeof(int);
             if (hipMallocAsync(reinterpret_cast<void **>(&queue), bytes, st) == hipSuccess) {
                 HIP_TRY(hipMemsetAsync(queue, 0, bytes, st));
-                grid = (unsigned)slots;
+                // resident wavefronts that loop over items -- or one workgroup per item, looped by the dispatcher
+                const int nbig = (nsteps - tail + chunk - 1) / chunk;
+                grid = QUEUE_LOOP ? (unsigned)slots : (unsigned)(nw * (long)(nbig + tail));
             } else {
                 (void)hipGetLastError();
                 queue = nullptr;

@@ -119,8 +119,8 @@ def test_queue_warm_started_forces(bws):
     np.testing.assert_allclose(out["queue"][1][ws].cpu().numpy(), odq, rtol=0, atol=1e-7)
 
 
-def test_queue_snake64_keeps_static_assignment(bws):
-    """the float64 64-row kernels are built without the queue (csrc comment): a large multi-step launch still works"""
+def test_queue_snake64_one_item_per_workgroup(bws):
+    """the float64 64-row kernels take the queue without the in-kernel item loop (csrc comment): one workgroup per item"""
     bw, m, q0, dq0 = bws("snake64_g")
     B, T = 3000, 9
     rng = np.random.default_rng(2)
