@@ -2174,7 +2174,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     int *queue = nullptr;
     unsigned grid = (unsigned)nw;
     constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);     // (see the kernel)
-    if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 * chunk &&
+    if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 &&
         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
         static size_t slots_lds = ~(size_t)0;
         static int slots = 0;
