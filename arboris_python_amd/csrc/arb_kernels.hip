@@ -653,7 +653,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             step_hi = step_lo + 1;
         }
         if (qitem_chunk > 0) {
-            int spins = 0;
+            int spins = 0;      // (the cap, ~7 s of polling, only guarantees that every wavefront leaves the kernel whatever happens)
             while (__hip_atomic_load(queue + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < qitem_chunk && spins < (1 << 24)) {
                 __builtin_amdgcn_s_sleep(16);
                 ++spins;
@@ -2176,8 +2176,8 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);     // (see the kernel)
     if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 &&
         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
-        static size_t slots_lds = ~(size_t)0;
-        static int slots = 0;
+        static thread_local size_t slots_lds = ~(size_t)0;      // (per thread: no race; identical GPUs assumed per process)
+        static thread_local int slots = 0;
         if (slots_lds != lds) { slots = wave_slots(kern, lds); slots_lds = lds; }
         if (slots > 0 && nw > slots) {
             const size_t bytes = (size_t)(1 + nw) * sizeof(int);

@@ -422,6 +422,12 @@ def main():
                     "wave_frac_issuing_valu": pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
                     "wave_frac_waiting": (pm["SQ_WAIT_ANY"]["mean_per_launch"] + pm["SQ_WAIT_INST_ANY"]["mean_per_launch"])
                                          / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                    # the fraction that says something about this kernel: how busy the vector ALUs are, from the
+                    # profiled launch (quad-cycles of VALU execution summed over the SIMDs) and THIS run's kernel time
+                    "valu_pipe_busy_frac": 4. * pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]
+                                           / (kern_ms * 1e-3 * 1024 * 2.4e9),
+                    "valu_pipe_busy_note": "SQ_ACTIVE_INST_VALU x 4 cycles / (kernel time x 1024 SIMDs x 2.4 GHz peak clock): "
+                                           "a lower bound of the VALU issue utilisation (the sustained clock is lower)",
                     "note": "SQ counters of profiles/%s" % os.path.basename(prof)}
                 if "SQ_INSTS_MFMA" in pm:
                     res["roofline"]["valu"]["mfma_insts_per_world_step"] = pm["SQ_INSTS_MFMA"]["mean_per_launch"] / ws
