@@ -55,6 +55,28 @@ def test_queue_equals_static_bitwise(bws, name, B, T, dtype):
         assert torch.equal(out[True][2], out[False][2])
 
 
+@pytest.mark.parametrize("name", ["simplearm_pd", "txtytz", "jointlimits_min", "shapes_box_ball", "loop_arm", "snake9_free_g"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_queue_small_register_tiles(bws, name, dtype):
+    """the 16- and 32-row kernels hold more wavefronts per CU: a batch large enough to take the queue there too"""
+    bw, m, q0, dq0 = bws(name)
+    B, T = 40000, 6
+    rng = np.random.default_rng(3)
+    q = np.repeat(q0[None], B, 0)
+    dq = np.repeat(dq0[None], B, 0) + 0.05 * rng.standard_normal((B, m.ndof))
+    out = {}
+    for static in (True, False):
+        tq, tdq = bw.to_device(q, dq, dtype)
+        cf = bw.new_cforce(B, dtype) if m.nc else None
+        bw.step(tq, tdq, 2e-3, T, cforce=cf, static_worlds=static)
+        out[static] = (tq, tdq, cf)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[False][0]).all())
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    if m.nc:
+        assert torch.equal(out[True][2], out[False][2])
+
+
 def test_queue_per_step_dt_and_logs(bws):
     """arb_rollout (logs indexed by the absolute step) and a non-uniform timeline through the queue"""
     bw, m, _, _ = bws("human36_c4")
