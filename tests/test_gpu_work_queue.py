@@ -36,6 +36,7 @@ def _states(m, B, seed):
 
 
 @pytest.mark.parametrize("name,B,T", [("human36_c4", 4096 + 37, 24), ("human36_c4", 4096, 3), ("human36_c4", 5000, 5),
+                                      ("human36_c4", 2049, 41), ("human36_c4", 2050, 7), ("human36_c4", 3001, 4),
                                       ("human36_c8", 4096, 10), ("human36_g", 8192 + 5, 9), ("human36_g", 8192, 2)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_queue_equals_static_bitwise(bws, name, B, T, dtype):
