@@ -143,15 +143,17 @@ def test_queue_warm_started_forces(bws):
     np.testing.assert_allclose(out["queue"][1][ws].cpu().numpy(), odq, rtol=0, atol=1e-7)
 
 
-def test_queue_snake64_one_item_per_workgroup(bws):
-    """the float64 64-row kernels take the queue without the in-kernel item loop (csrc comment): one workgroup per item"""
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_queue_snake64_64_row_kernels(bws, dtype):
+    """the 64-row kernels: float64 takes the queue without the in-kernel item loop (csrc comment: one workgroup per
+    item), float32 with it (float32 is not accurate on this model, cond(Z) ~ 3e8, but it is deterministic)"""
     bw, m, q0, dq0 = bws("snake64_g")
     B, T = 3000, 9
     rng = np.random.default_rng(2)
     q = rng.uniform(-1., 1., (B, m.nq)); dq = rng.uniform(-1., 1., (B, m.ndof))
-    tq, tdq = bw.to_device(q, dq, torch.float64)
+    tq, tdq = bw.to_device(q, dq, dtype)
     bw.step(tq, tdq, 1e-3, T)
-    sq, sdq = bw.to_device(q, dq, torch.float64)
+    sq, sdq = bw.to_device(q, dq, dtype)
     for _ in range(T):
         bw.step(sq, sdq, 1e-3, 1)
     torch.cuda.synchronize()
