@@ -216,6 +216,9 @@ int arb_model_get_info(const arb_model *m, arb_model_info *info);
  *            last step (contact / joint-limit forces of that step)
  *   ext_gforce  device [nworlds][ndof] or NULL: extra generalized force with zero
  *            impedance, constant over the call (a user torque Controller)
+ * Multi-step calls on more worlds than the GPU holds wavefronts run through a device-side work queue (see
+ * ARB_STEP_STATIC_WORLDS): identical results; while the call runs, q / dq / cforce hold intermediate states of
+ * the worlds (they are the hand-over buffers between work items), as they would between single-step calls.
  */
 int arb_step(arb_model *m, int dtype, void *q, void *dq, void *cforce,
              const void *ext_gforce, int64_t nworlds, double dt, int32_t nsteps,
