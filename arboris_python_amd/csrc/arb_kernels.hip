@@ -35,6 +35,7 @@
 #include <cmath>
 #include <type_traits>
 #include <utility>
+#include <mutex>
 
 #include "arbstep.h"
 #include "arb_math.h"
@@ -2146,6 +2147,42 @@ thread_local std::string g_hip_err;
 // kernels of one register tile and precision only (explicit instantiations below) and none of the
 // host code; the main unit declares them extern and holds the C ABI.
 // ---------------------------------------------------------------------------
+// Stream-ordered scratch for the work queue: a pool of this library's own per device that keeps what it is given
+// back (release threshold = max), so a launch costs no driver allocation after the first; the default pool of the
+// device -- whose settings belong to the application -- is the fallback.
+static hipError_t queue_alloc(void **p, size_t bytes, hipStream_t st) {
+    static hipMemPool_t pools[64] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        hipMemPool_t pool = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (pools[dev] == nullptr) {
+                hipMemPoolProps props;
+                memset(&props, 0, sizeof(props));
+                props.allocType = hipMemAllocationTypePinned;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = dev;
+                hipMemPool_t np = nullptr;
+                if (hipMemPoolCreate(&np, &props) == hipSuccess) {
+                    uint64_t keep = ~(uint64_t)0;
+                    (void)hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &keep);
+                    pools[dev] = np;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            pool = pools[dev];
+        }
+        if (pool != nullptr) {
+            if (hipMallocFromPoolAsync(p, bytes, pool, st) == hipSuccess) return hipSuccess;
+            (void)hipGetLastError();
+        }
+    }
+    return hipMallocAsync(p, bytes, st);
+}
+
 // Wave slots of the chip for a kernel (workgroups of one wavefront): CUs x resident workgroups per CU.
 template <typename K>
 static int wave_slots(K kern, size_t lds) {
@@ -2181,7 +2218,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
         if (slots_lds != lds) { slots = wave_slots(kern, lds); slots_lds = lds; }
         if (slots > 0 && nw > slots) {
             const size_t bytes = (size_t)(1 + nw) * sizeof(int);
-            if (hipMallocAsync(reinterpret_cast<void **>(&queue), bytes, st) == hipSuccess) {
+            if (queue_alloc(reinterpret_cast<void **>(&queue), bytes, st) == hipSuccess) {
                 HIP_TRY(hipMemsetAsync(queue, 0, bytes, st));
                 // resident wavefronts that loop over items -- or one workgroup per item, looped by the dispatcher
                 const int nbig = (nsteps - tail + chunk - 1) / chunk;
