@@ -24,7 +24,7 @@ Constraint :269-315, Shape :318-324, Controller :327-339, World :342-980,
 SubFrame/MovingSubFrame :983-1053, Body :1055-1315, Observer :1318-1331,
 simulate :1334-1365.
 """
-from abc import ABCMeta, abstractmethod, abstractproperty
+from abc import ABCMeta
 
 import numpy
 from numpy import array, zeros, eye, dot
@@ -39,6 +39,29 @@ def simplearm():
     w = World()
     add_simplearm(w)
     return w
+
+
+def _interface(properties=(), methods=()):
+    """Class decorator: the named read-only properties and methods are abstract (what the reference declares one
+    by one with ``abstractproperty`` / ``abstractmethod``); the class must use ``ABCMeta``."""
+    def decorate(cls):
+        for name in properties:
+            def getter(self, _n=name):
+                raise NotImplementedError(_n)
+            getter.__isabstractmethod__ = True
+            getter.__name__ = name
+            setattr(cls, name, property(getter))
+        for name, nargs in methods:
+            args = ", ".join("a%d" % i for i in range(nargs))
+            ns = {}
+            exec("def %s(self%s):\n    raise NotImplementedError(%r)" % (name, (", " + args) if args else "", name), ns)
+            fn = ns[name]
+            fn.__isabstractmethod__ = True
+            setattr(cls, name, fn)
+        cls.__abstractmethods__ = frozenset(set(getattr(cls, "__abstractmethods__", ())) | set(properties)
+                                            | set(n for n, _ in methods))
+        return cls
+    return decorate
 
 
 class NamedObject(object):
@@ -88,46 +111,21 @@ class NamedObjectsList(list):
         return out
 
 
+@_interface(properties=("pose", "jacobian", "djacobian", "twist", "body", "bpose"))
 class Frame(object, metaclass=ABCMeta):
-    """Abstract frame: a body or a frame rigidly attached to one."""
-
-    @abstractproperty
-    def pose(self):
-        pass
-
-    @abstractproperty
-    def jacobian(self):
-        pass
-
-    @abstractproperty
-    def djacobian(self):
-        pass
-
-    @abstractproperty
-    def twist(self):
-        pass
-
-    @abstractproperty
-    def body(self):
-        pass
-
-    @abstractproperty
-    def bpose(self):
-        pass
+    """Abstract frame: a body or a frame rigidly attached to one (pose, jacobian, djacobian, twist, body, bpose)."""
 
 
+@_interface(properties=("ndof", "jacobian", "djacobian"), methods=(("integrate", 2),))
 class Joint(RigidMotion, NamedObject):
-    """Ideal joint between ``frames[0]`` (parent side) and ``frames[1]``."""
+    """Ideal joint between ``frames[0]`` (parent side) and ``frames[1]``; a concrete joint provides ``ndof``,
+    ``jacobian``, ``djacobian`` and ``integrate(gvel, dt)``."""
 
     def __init__(self, name=None):
         NamedObject.__init__(self, name)
         self._frame0 = None
         self._frame1 = None
         self._dof = None          # slice into the world dof vector, set by World.init()
-
-    @abstractproperty
-    def ndof(self):
-        pass
 
     @property
     def dof(self):
@@ -142,18 +140,6 @@ class Joint(RigidMotion, NamedObject):
     @property
     def twist(self):
         return dot(self.jacobian, self.gvel)
-
-    @abstractproperty
-    def jacobian(self):
-        pass
-
-    @abstractproperty
-    def djacobian(self):
-        pass
-
-    @abstractmethod
-    def integrate(self, gvel, dt):
-        pass
 
 
 class LinearConfigurationSpaceJoint(Joint):
@@ -196,48 +182,29 @@ class JointsList(NamedObjectsList):
         return self._dof
 
 
+@_interface(properties=("jacobian", "ndol"),
+            methods=(("init", 1), ("update", 1), ("is_active", 0), ("solve", 3)))
 class Constraint(NamedObject, metaclass=ABCMeta):
+    """A kinematic constraint.  Concrete classes provide ``jacobian``, ``ndol`` (degrees of "liaison": 6 minus the
+    dofs of the constrained motion), ``init(world)``, ``update(dt)``, ``is_active()`` and
+    ``solve(vel, admittance, dt)``; the generalized force is ``jacobian.T @ force``."""
 
     def __init__(self, name=None):
         NamedObject.__init__(self, name)
         self._is_enabled = True
 
-    def is_enabled(self):
-        return self._is_enabled
-
-    def enable(self):
-        self._is_enabled = True
+    def enable(self, on=True):
+        self._is_enabled = bool(on)
 
     def disable(self):
-        self._is_enabled = False
+        self.enable(False)
 
-    @abstractmethod
-    def init(self, world):
-        pass
+    def is_enabled(self):
+        return self._is_enabled
 
     @property
     def gforce(self):
         return dot(self.jacobian.T, self._force)
-
-    @abstractproperty
-    def jacobian(self):
-        pass
-
-    @abstractproperty
-    def ndol(self):
-        """Number of degrees of "liaison" (6 - ndof of the constrained motion)."""
-
-    @abstractmethod
-    def update(self, dt):
-        pass
-
-    @abstractmethod
-    def is_active(self):
-        pass
-
-    @abstractmethod
-    def solve(self, vel, admittance, dt):
-        pass
 
 
 class Shape(NamedObject):
@@ -249,33 +216,17 @@ class Shape(NamedObject):
         NamedObject.__init__(self, name)
 
 
+@_interface(methods=(("init", 1), ("update", 1)))
 class Controller(NamedObject, metaclass=ABCMeta):
+    """A controller: ``init(world)`` once, then ``update(dt)`` returns (gforce, impedance) every step."""
 
     def __init__(self, name=None):
         NamedObject.__init__(self, name)
 
-    @abstractmethod
-    def init(self, world):
-        pass
 
-    @abstractmethod
-    def update(self, dt):
-        pass
-
-
+@_interface(methods=(("init", 2), ("update", 1), ("finish", 0)))
 class Observer(object, metaclass=ABCMeta):
-
-    @abstractmethod
-    def init(self, world, timeline):
-        pass
-
-    @abstractmethod
-    def update(self, dt):
-        pass
-
-    @abstractmethod
-    def finish(self):
-        pass
+    """Watches a simulation: ``init(world, timeline)``, ``update(dt)`` before every step, ``finish()``."""
 
 
 class _Registry(object):
