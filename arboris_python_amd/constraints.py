@@ -40,6 +40,22 @@ point_contact_proximity = 0.02
 joint_limits_proximity = 0.01
 
 
+def _rows(count):
+    """`ndol` of a constraint class: a constant number of rows in the stacked constraint system."""
+    return property(lambda self: count)
+
+
+def _relative_jacobian(frames, rows):
+    """Rows `rows` of the twist of frames[1] relative to frames[0], expressed in frames[0], as a function of gvel."""
+    f0, f1 = frames
+    carry = Hg.adjoint(dot(Hg.inv(f0.pose), f1.pose))
+    return dot(carry[rows, :], f1.jacobian) - f0.jacobian[rows, :]
+
+
+def _column(values, k):
+    return array(values, dtype=float).reshape((k,))
+
+
 class JointLimits(Constraint):
     """Keep ``min <= q <= max`` on a 1-dof joint with a unilateral force."""
 
@@ -50,31 +66,22 @@ class JointLimits(Constraint):
         Constraint.__init__(self, name)
         k = joint.ndof
         self._joint = joint
-        self._min = array(min, dtype=float).reshape((k,))
-        self._max = array(max, dtype=float).reshape((k,))
-        if proximity is None:
-            self._proximity = joint_limits_proximity * np.ones((k,))
-        else:
-            self._proximity = array(proximity, dtype=float).reshape((k,))
-        self._pos0 = None
-        self._jacobian = None
-        self._force = zeros((k,))
+        self._min, self._max = _column(min, k), _column(max, k)
+        self._proximity = (np.full(k, joint_limits_proximity) if proximity is None else _column(proximity, k))
+        self._force = zeros(k)
+        self._pos0 = self._jacobian = None
+
+    ndol = _rows(1)
+    jacobian = property(lambda self: self._jacobian)
 
     def init(self, world):
-        self._jacobian = zeros((1, world.ndof))
-        self._jacobian[0, self._joint.dof] = 1
-
-    @property
-    def jacobian(self):
-        return self._jacobian
-
-    @property
-    def ndol(self):
-        return 1
+        selector = zeros((1, world.ndof))
+        selector[0, self._joint.dof] = 1
+        self._jacobian = selector
 
     def update(self, dt):
-        self._pos0 = self._joint.gpos
         self._force[:] = 0.
+        self._pos0 = self._joint.gpos
 
     def is_active(self):
         return bool((self._pos0 - self._min < self._proximity)
@@ -105,31 +112,23 @@ class BallAndSocketConstraint(Constraint):
     """
 
     def __init__(self, frames, name=None):
-        self._force = zeros(3)
-        self._pos0 = None
         Constraint.__init__(self, name)
         self._frames = frames
+        self._force = zeros(3)
+        self._pos0 = None
+
+    ndol = _rows(3)
+    jacobian = property(lambda self: _relative_jacobian(self._frames, slice(3, 6)))
 
     def init(self, world):
         pass
 
-    @property
-    def ndol(self):
-        return 3
-
-    def _h01(self):
-        return dot(Hg.inv(self._frames[0].pose), self._frames[1].pose)
-
-    def update(self, dt):
-        self._pos0 = self._h01()[0:3, 3]
-
     def is_active(self):
         return True
 
-    @property
-    def jacobian(self):
-        return (dot(Hg.adjoint(self._h01())[3:6, :], self._frames[1].jacobian)
-                - self._frames[0].jacobian[3:6, :])
+    def update(self, dt):
+        f0, f1 = self._frames
+        self._pos0 = dot(Hg.inv(f0.pose), f1.pose)[0:3, 3]
 
     def solve(self, vel, admittance, dt):
         dforce = -dot(_block_pinv(admittance), np.asarray(vel, float) + self._pos0 / dt)
@@ -151,27 +150,24 @@ class PointContact(Constraint):
         Constraint.__init__(self, name)
         if collision_solver is None:
             from .collisions import choose_solver
-            (shapes, collision_solver) = choose_solver(shapes[0], shapes[1])
-        self._shapes = shapes
-        self._is_active = None
-        self._sdist = None
-        self._frames = (MovingSubFrame(shapes[0].frame.body),
-                        MovingSubFrame(shapes[1].frame.body))
-        self._collision_solver = collision_solver
-        self._proximity = proximity
+            shapes, collision_solver = choose_solver(*shapes[:2])
+        self._shapes, self._collision_solver, self._proximity = shapes, collision_solver, proximity
+        # one moving frame per body, placed on the contact point by update()
+        self._frames = tuple(MovingSubFrame(shape.frame.body) for shape in shapes[:2])
+        self._is_active = self._sdist = None
 
     def init(self, world):
         pass
 
     def update(self, dt):
-        (sdist, H_gc0, H_gc1) = self._collision_solver(self._shapes)
-        for k, H_gc in enumerate((H_gc0, H_gc1)):
-            self._frames[k].bpose = dot(Hg.inv(self._shapes[k].frame.body.pose), H_gc)
-        H_c0c1 = dot(Hg.inv(H_gc0), H_gc1)
-        gap_rate = (dot(Hg.adjoint(H_c0c1)[5, :], self._frames[1].twist)
-                    - self._frames[0].twist[5])
-        self._is_active = (sdist + gap_rate * dt < self._proximity)
+        sdist, *contact_poses = self._collision_solver(self._shapes)
+        for frame, shape, H_gc in zip(self._frames, self._shapes, contact_poses):
+            frame.bpose = dot(Hg.inv(shape.frame.body.pose), H_gc)
+        # rate of change of the gap: z velocity of contact frame 1 relative to contact frame 0
+        carry = Hg.adjoint(dot(Hg.inv(contact_poses[0]), contact_poses[1]))
+        gap_rate = dot(carry[5, :], self._frames[1].twist) - self._frames[0].twist[5]
         self._sdist = sdist
+        self._is_active = bool(sdist + dt * gap_rate < self._proximity)
         self._force[:] = 0.
 
     def is_active(self):
@@ -194,15 +190,8 @@ class SoftFingerContact(PointContact):
         self._force = zeros(4)
         self._eps = array((1., 1., 1.))
 
-    @property
-    def ndol(self):
-        return 4
-
-    @property
-    def jacobian(self):
-        H_01 = dot(Hg.inv(self._frames[0].pose), self._frames[1].pose)
-        return (dot(Hg.adjoint(H_01)[2:6, :], self._frames[1].jacobian)
-                - self._frames[0].jacobian[2:6, :])
+    ndol = _rows(4)
+    jacobian = property(lambda self: _relative_jacobian(self._frames, slice(2, 6)))
 
     def solve(self, vel, admittance, dt):
         """Release / static friction / sliding friction (arb_math.h::softfinger_solve, the code the Gauss-Seidel
