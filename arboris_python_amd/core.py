@@ -436,37 +436,17 @@ class World(NamedObject):
         self._constraints_done = False
 
     # -- read-only state ----------------------------------------------------
-    @property
-    def current_time(self):
-        return self._current_time
+    def _view(attribute, copy=False):        # noqa: N805 -- builds the read-only properties below
+        if copy:
+            return property(lambda self: getattr(self, attribute).copy())
+        return property(lambda self: getattr(self, attribute))
 
-    @property
-    def up(self):
-        return self._up
-
-    @property
-    def mass(self):
-        return self._mass
-
-    @property
-    def viscosity(self):
-        return self._viscosity
-
-    @property
-    def nleffects(self):
-        return self._nleffects
-
-    @property
-    def ndof(self):
-        return self._ndof
-
-    @property
-    def gvel(self):
-        return self._gvel.copy()
-
-    @property
-    def gforce(self):
-        return self._gforce.copy()
+    current_time = _view("_current_time")
+    up = _view("_up")
+    ndof = _view("_ndof")
+    mass, viscosity, nleffects = _view("_mass"), _view("_viscosity"), _view("_nleffects")
+    gvel, gforce = _view("_gvel", copy=True), _view("_gforce", copy=True)
+    del _view
 
     # -- the step: all four stages run on the device -------------------------
     def _device(self):
