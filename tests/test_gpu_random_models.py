@@ -120,4 +120,19 @@ def test_random_model_single_steps(seed):
     calm = ok32 & (np.abs(odq32).max(axis=1) < 30.)       # worlds that are not being torn towards a violated loop closure
     if calm.sum() >= 3:
         assert e32[calm].max() < 1e-4 and (e32[calm] < 1e-5).mean() >= 0.7, (seed, e32[calm])
+    # a multi-step launch of more worlds than wave slots goes through the work queue (whatever register tile the
+    # model selects): bit-identical to one workgroup per world
+    reps = -(-5000 // B)
+    qb, dqb = np.tile(q, (reps, 1)), np.tile(dq, (reps, 1))
+    for dtype in (torch.float32, torch.float64):
+        res = []
+        for static in (True, False):
+            aq, adq = bw.to_device(qb, dqb, dtype)
+            acf = bw.new_cforce(len(qb), dtype)
+            bw.step(aq, adq, dt, 3, cforce=acf, static_worlds=static)
+            res.append((aq, adq, acf))
+        torch.cuda.synchronize()
+        # (NaN-safe: compare bit patterns)
+        bits = lambda t: t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int64)
+        assert all(torch.equal(bits(a), bits(b)) for a, b in zip(*res)), (seed, dtype)
     bw.close()
