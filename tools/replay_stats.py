@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Error distribution of the float32 fused kernel against the float64 oracle over many (world, step) pairs of
-the falling episode: every sampled state logged by the device is stepped once by the oracle."""
+the falling episode: every sampled state logged by the device is stepped once by the oracle.
+usage (GPU box): python tools/replay_stats.py [seed [world_stride [step_stride]]]   (defaults 1000, 16, 3)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,9 +18,9 @@ q, dq = synth.standing_states(m, B, seed=int(sys.argv[1]) if len(sys.argv) > 1 e
 tq, tdq = bw.to_device(q, dq, torch.float32)
 log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False)
 torch.cuda.synchronize()
-worlds = np.arange(0, B, 16)                      # 256 worlds
+worlds = np.arange(0, B, int(sys.argv[2]) if len(sys.argv) > 2 else 16)     # 256 worlds by default
 errs = []
-for k in range(0, T - 1, 3):                      # 13 steps
+for k in range(0, T - 1, int(sys.argv[3]) if len(sys.argv) > 3 else 3):       # 13 steps by default
     qk = log["q"][k][worlds].double().cpu().numpy(); dqk = log["dq"][k][worlds].double().cpu().numpy()
     oq, odq, _ = O.step(m, qk, dqk, dt)
     g = log["dq"][k + 1][worlds].double().cpu().numpy()
