@@ -14,13 +14,13 @@ LIB_PATH = os.path.join(_HERE, "libarbstep.so")
 if os.environ.get("ARBSTEP_LIB"):                 # development: load a differently built library
     LIB_PATH = os.environ["ARBSTEP_LIB"]
 
-ARB_ABI_VERSION = 4
+ARB_ABI_VERSION = 5
 ARB_OK = 0
+ARB_ERR_STALLED = 5
 ARB_F32, ARB_F64 = 0, 1
 ARB_MAXDOL = 4
 ARB_STEP_SKIP_CONSTRAINTS = 1
 ARB_STEP_FUSED = 2
-ARB_STEP_SPLIT = 4
 ARB_STEP_SPLIT_WAVE = 8
 ARB_STEP_MFMA_ELIM = 16
 ARB_STEP_STATIC_WORLDS = 32
@@ -73,8 +73,9 @@ class InspectOut(C.Structure):
 
 # every symbol include/arbstep.h declares (tests check they are all exported)
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
-            "arb_model_destroy", "arb_model_get_info", "arb_step", "arb_step_ex", "arb_rollout", "arb_inspect"]
-# host-side self-test hooks (device math compiled for the CPU)
+            "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_step", "arb_step_ex", "arb_rollout",
+            "arb_inspect"]
+# every symbol include/arbstep_hooks.h declares: host builds of the device math (unit tests, Constraint.solve)
 TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
               "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
 
@@ -110,6 +111,8 @@ def load():
     lib.arb_model_destroy.argtypes = [C.c_void_p]
     lib.arb_model_get_info.restype = C.c_int
     lib.arb_model_get_info.argtypes = [C.c_void_p, C.POINTER(ModelInfo)]
+    lib.arb_model_status.restype = C.c_int
+    lib.arb_model_status.argtypes = [C.c_void_p]
     lib.arb_step.restype = C.c_int
     lib.arb_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int64, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]

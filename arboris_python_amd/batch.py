@@ -89,18 +89,33 @@ class BatchedWorlds(object):
         torch = _torch()
         return torch.zeros((B, self.model.nc, _capi.ARB_MAXDOL), dtype=dtype, device=self.device)
 
-    def _dt_steps(self, dt, nsteps):
-        """A scalar ``dt`` -> None; a sequence / array / tensor of ``nsteps`` step lengths (a non-uniform
-        timeline, core.py:1357) -> float64 device tensor for ``arb_step_args.dt_steps``."""
+    def _dt_steps(self, dt, nsteps, st):
+        """A scalar ``dt`` (Python or NumPy number, 0-d array or tensor) -> None; a sequence / array / tensor of
+        ``nsteps`` step lengths (a non-uniform timeline, core.py:1357) -> float64 device tensor for
+        ``arb_step_args.dt_steps``, uploaded ON the launch stream ``st`` and kept alive on ``self`` until the
+        next call replaces it (the kernel reads it asynchronously)."""
         torch = _torch()
-        if isinstance(dt, (int, float)):
+        a = np.asarray(dt.detach().cpu() if hasattr(dt, "detach") else dt, dtype=np.float64)
+        if a.ndim == 0:
             return None
-        t = torch.as_tensor(np.asarray(dt.detach().cpu() if hasattr(dt, "detach") else dt, dtype=np.float64))
-        if t.ndim != 1 or t.shape[0] != int(nsteps):
+        if a.ndim != 1 or a.shape[0] != int(nsteps):
             raise ValueError("dt must be a scalar or a sequence of nsteps = %d step lengths" % int(nsteps))
-        if not bool((t > 0).all()):
+        if not bool((a > 0).all()):
             raise ValueError("every dt must be positive")
-        return t.to(self.device).contiguous()
+        host = torch.as_tensor(np.ascontiguousarray(a))
+        with torch.cuda.stream(st):                 # the copy is ordered before the kernel that reads it
+            t = host.to(self.device).contiguous()
+        t.record_stream(st)
+        self._dts_keep = (t, host)
+        return t
+
+    @staticmethod
+    def _split_flag(split):
+        if split in (None, False):
+            return 0
+        if split == "wave":
+            return _capi.ARB_STEP_SPLIT_WAVE
+        raise ValueError("split must be False or 'wave' (the lane-per-world sweep kernel of ABI <= 4 was removed)")
 
     # -- the step --------------------------------------------------------------
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
@@ -109,9 +124,9 @@ class BatchedWorlds(object):
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
 
-        ``split=True`` runs the Gauss-Seidel sweeps in a second kernel with one lane per world
-        (ARB_STEP_SPLIT: faster from ~16k worlds with <= 4 constraints, same results to rounding; opt-in,
-        see DESIGN.md); the default keeps them in the step kernel (``fused`` is accepted for symmetry).
+        ``split="wave"`` runs the Gauss-Seidel sweeps in a second kernel with one wavefront per world
+        (ARB_STEP_SPLIT_WAVE: bit-identical results, measured slower at every batch size, DESIGN.md 3; opt-in);
+        the default keeps them in the step kernel (``fused`` is accepted for symmetry).
         ``mfma=True`` (float32): phase C eliminates on the matrix cores (ARB_STEP_MFMA_ELIM; slower).
         ``static_worlds=True``: one workgroup per world for the whole launch (ARB_STEP_STATIC_WORLDS) instead of the
         device-side queue of (chunk of steps, world) items that multi-step launches of large batches use by default.
@@ -125,15 +140,12 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
             flags |= _capi.ARB_STEP_FUSED
-        if split == "wave":
-            flags |= _capi.ARB_STEP_SPLIT_WAVE
-        elif split:
-            flags |= _capi.ARB_STEP_SPLIT
+        flags |= self._split_flag(split)
         if mfma:
             flags |= _capi.ARB_STEP_MFMA_ELIM
         if static_worlds:
             flags |= _capi.ARB_STEP_STATIC_WORLDS
-        dts = self._dt_steps(dt, nsteps)
+        dts = self._dt_steps(dt, nsteps, st)
         if pd_targets is None and pd_gains is None and dts is None:
             _capi.check(self._lib.arb_step(
                 self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
@@ -172,10 +184,7 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
             flags |= _capi.ARB_STEP_FUSED
-        if split == "wave":
-            flags |= _capi.ARB_STEP_SPLIT_WAVE
-        elif split:
-            flags |= _capi.ARB_STEP_SPLIT
+        flags |= self._split_flag(split)
         out = {}
         log = _capi.RolloutLog()
         if log_state:
@@ -185,7 +194,7 @@ class BatchedWorlds(object):
         if log_energy:
             out["energy"] = torch.empty((nsteps, B, 2), dtype=q.dtype, device=self.device)
             log.energy_log = out["energy"].data_ptr()
-        dts = self._dt_steps(dt, nsteps)
+        dts = self._dt_steps(dt, nsteps, st)
         if dts is None:
             _capi.check(self._lib.arb_rollout(
                 self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
@@ -201,6 +210,12 @@ class BatchedWorlds(object):
         a.log = C.pointer(log)
         _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
         return out
+
+    def status(self):
+        """Health of this handle's launches so far (``arb_model_status``): raises ``ArbError`` (ARB_ERR_STALLED) when a
+        launch gave up waiting inside its device-side work queue -- its results are invalid.  Reads host memory only;
+        synchronise the stream first to learn about launches that are still queued."""
+        _capi.check(self._lib.arb_model_status(self._handle))
 
     def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False):
         """Evaluate one step without touching ``q``/``dq``; returns a dict of the

@@ -38,13 +38,16 @@
 #include <mutex>
 
 #include "arbstep.h"
+#include "arbstep_hooks.h"
 #include "arb_math.h"
 
 #define WAVE 64
 #ifndef ARB_WAVES_PER_EU
 #define ARB_WAVES_PER_EU 2      // 2nd __launch_bounds__ argument: min waves per SIMD (caps VGPRs at 256)
 #endif
-#define GS_SWEEPS 20            // core.py:929-931
+#ifndef GS_SWEEPS
+#define GS_SWEEPS 20            // core.py:929-931 (overridable only for timing experiments: the reference's count is 20)
+#endif
 #ifndef ARB_PHASE_D_MFMA
 #define ARB_PHASE_D_MFMA 1      // float32: the constraint-space products J' [Y rhs | Y J'^T] on the matrix cores (0: vector ALU)
 #endif
@@ -105,6 +108,7 @@ template <typename T>
 struct DevModel {
     int nb, n, nq, nc, ndol, ncols, maxdepth;
     int has_visc, has_pd, has_warm, has_grav;
+    int *status;     // host-visible word (mapped pinned memory) that a launch raises when it gives up waiting in the work queue
     Layout lay;      // LDS offsets of this precision's kernels: re-read per phase instead of held in SGPRs for the whole launch
     double up[3];
     T grav[3];
@@ -128,9 +132,9 @@ struct DevModel {
     double cprox_d[ARB_CAP], cmin_d[ARB_CAP], cmax_d[ARB_CAP];
 };
 
-// Split execution (contact models, large batches): the step kernel stops after the
-// constraint-space system is built and writes it here; arb_gs_kernel then runs the
-// Gauss-Seidel sweeps with one LANE per world, and the next step kernel launch starts
+// Split execution (opt-in, ARB_STEP_SPLIT_WAVE): the step kernel stops after the
+// constraint-space system is built and writes it here; arb_gsw_kernel then runs the
+// Gauss-Seidel sweeps (one wavefront per world), and the next step kernel launch starts
 // by applying the resulting forces (core.py:975-979).  World-major blocks.
 template <typename T>
 struct SplitIO {
@@ -589,9 +593,10 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 // The step kernel.  MODE 0 = production, 1 = inspect (debug stores, no state
 // write-back).  zmode (inspect only): 0 full Z, 1 M only, 2 B only, 3 N only.
 // ===========================================================================
-// FEAT 0 = the plain step (arb_step without user torques: no per-world PD inputs, no per-step logs, no split
+// FEAT (bit mask) 0 = the plain step (arb_step without user torques: no per-world PD inputs, no per-step logs, no split
 // execution) -- those arguments are compiled out, which keeps their kernargs and the predicates derived from them
-// out of the SGPR file; FEAT 1 = every input honoured.
+// out of the SGPR file; bit 0 = user torques (ext_gforce: the MPC rollouts' input, one extra load per item);
+// bit 1 = every other optional input (per-world PD, logs, split execution, per-step dt, flags); 3 = all of them.
 // CM 1 = phase C eliminates on the matrix cores (float32 only; ARB_STEP_MFMA_ELIM), 0 = on the vector ALU.
 // (float64 worlds on the 64-row tile -- snake-64 -- need 43 KB of LDS per wave: three waves per CU, less than one per
 // SIMD, so their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
@@ -600,17 +605,18 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
     T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
-    const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail)
+    const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail, int queue_spin_cap)
 {
-    static_assert(MODE == 0 || FEAT == 1, "the inspect kernels take every input");
-    static_assert(CM == 0 || (FEAT == 1 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
-    const T *__restrict__ gext = FEAT ? gext_in : nullptr;
-    const PerWorldPD<T> pwd = FEAT ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
-    const LogOut<T> logo = FEAT ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
-    const SplitIO<T> sio = FEAT ? sio_in : SplitIO<T>{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const unsigned flags = FEAT ? flags_in : 0u;
+    static_assert(MODE == 0 || FEAT == 3, "the inspect kernels take every input");
+    static_assert(CM == 0 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
+    constexpr bool FEAT_EXT = (FEAT & 1) != 0, FEAT_ALL = (FEAT & 2) != 0;
+    const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
+    const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
+    const LogOut<T> logo = FEAT_ALL ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
+    const SplitIO<T> sio = FEAT_ALL ? sio_in : SplitIO<T>{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const unsigned flags = FEAT_ALL ? flags_in : 0u;
     // per-step dt (core.py:1357: dt = next_time - current_time), or null = dt_in for every step
-    const double *__restrict__ dts = FEAT ? dts_in : nullptr;
+    const double *__restrict__ dts = FEAT_ALL ? dts_in : nullptr;
     const DevModel<T> *mp = mp_in;     // device-resident model, fields fetched with scalar loads
     const int lane0 = threadIdx.x;
     int lane = lane0;
@@ -622,7 +628,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     // chunk.  queue[0] = next item, queue[1 + w] = chunks of world w that are finished (the state travels through
     // global memory between wavefronts on different XCDs: coherent accesses, see `ldg` / `stg`).  Items are numbered
     // chunk-major, so the chunk an item waits for was drawn nworlds items earlier: it is finished, or it is running
-    // on a resident wavefront that waits for nothing drawn later -- no circular wait; the spin is capped all the same.
+    // on a resident wavefront that waits for nothing drawn later -- no circular wait.  The spin is capped all the same
+    // (a producer stalled by a debugger or by serialised workgroups must not hang the device): a wavefront whose wait
+    // expires raises the handle's host-visible status word, poisons the world's flag so that its later chunks do not
+    // wait again, and goes on to the next item WITHOUT touching the world; the host reports ARB_ERR_STALLED.
     // (the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs, faulted on
     // their first launch -- queue or not -- with the item loop around the body, ROCm 7.2: there every workgroup draws
     // ONE item and the grid is the number of items; the hardware dispatcher does the looping)
@@ -654,10 +663,21 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             step_hi = step_lo + 1;
         }
         if (qitem_chunk > 0) {
-            int spins = 0;      // (the cap, ~7 s of polling, only guarantees that every wavefront leaves the kernel whatever happens)
-            while (__hip_atomic_load(queue + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < qitem_chunk && spins < (1 << 24)) {
+            int spins = 0;      // (the cap, ~7 s of polling by default, guarantees that every wavefront leaves the kernel)
+            bool ready = false;
+            while (queue_spin_cap >= 0) {       // (a negative cap is the tests' fault injection: every wait "expires")
+                ready = __hip_atomic_load(queue + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= qitem_chunk;
+                if (ready || spins >= queue_spin_cap) break;
                 __builtin_amdgcn_s_sleep(16);
                 ++spins;
+            }
+            if (!ready) {
+                if (lane0 == 0) {
+                    __hip_atomic_store(mp->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(queue + 1 + w, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!QUEUE_LOOP) return;
+                continue;
             }
             asm volatile("" ::: "memory");      // (order only: the coherent loads of the state are issued after the flag was seen)
         }
@@ -787,12 +807,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     };
 
     if (MODE == 0 && (sio.mode & 1)) {
-        // split execution: finish the previous step with the forces arb_gs_kernel left in sio.f
+        // split execution: finish the previous step with the forces arb_gsw_kernel left in sio.f
         const int ncol_s = 1 + ndol;
         for (int i = lane; i < ncol_s * n; i += WAVE) RT[(i / n) * RS + (i % n)] = sio.sol[(long)w * ncol_s * n + i];
         for (int i = lane; i < ndol; i += WAVE) { FF[i] = sio.f[w * ndol + i]; FF0[i] = sio.f0[w * ndol + i]; }
         WAVE_SYNC();
-        if (FEAT && dts != nullptr) { dt = (T)dts[-1]; inv_dt = T(1) / dt; }      // the step being finished
+        if (FEAT_ALL && dts != nullptr) { dt = (T)dts[-1]; inv_dt = T(1) / dt; }      // the step being finished
         integrate_from_rt(true);
     }
     if (MODE == 0 && sio.mode != 0 && !(sio.mode & 2)) step_hi = step_lo;      // apply only
@@ -801,7 +821,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
-        if (FEAT && dts != nullptr) { dt = (T)dts[step]; inv_dt = T(1) / dt; }
+        if (FEAT_ALL && dts != nullptr) { dt = (T)dts[step]; inv_dt = T(1) / dt; }
         if (MODE == 0) {            // trajectory log: what an Observer sees at time t (core.py:1361-1362)
             if (logo.q != nullptr) for (int i = lane; i < nq; i += WAVE) logo.q[((long)step * nworlds + w) * nq + i] = qs[i];
             if (logo.dq != nullptr && lane < n) logo.dq[((long)step * nworlds + w) * n + lane] = dqs[lane];
@@ -1883,7 +1903,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (MODE == 1 && dbg.vel_free != nullptr && lane < n) dbg.vel_free[w * n + lane] = RT[lane];
 
         if (MODE == 0 && (sio.mode & 2)) {
-            // split execution: hand the constraint-space system to arb_gs_kernel and stop here;
+            // split execution: hand the constraint-space system to arb_gsw_kernel and stop here;
             // the next launch applies the forces (integrate_from_rt above)
             const int ncol_s = 1 + ndol;
             for (int i = lane; i < ncol_s * n; i += WAVE) sio.sol[(long)w * ncol_s * n + i] = RT[(i / n) * RS + (i % n)];
@@ -1949,119 +1969,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #undef ARB_UNI
 
 // ===========================================================================
-// Gauss-Seidel with one LANE per world (split execution).  Same per-constraint
-// algebra as the fused kernel (arb_math.h), 20 sweeps in registration order
-// (core.py:929-935).  The constraint-space matrix of the block's worlds is staged
-// in LDS (row padded by one element: lane-private rows on distinct banks).
-// ===========================================================================
-template <typename T, int NC, int WPB>
-__global__ __launch_bounds__(WAVE) void arb_gs_kernel(
-    const DevModel<T> *__restrict__ mp, const T *__restrict__ wsA, const T *__restrict__ wsv,
-    T *__restrict__ wsf, const T *__restrict__ wsc, long nworlds, T dt_in, const double *__restrict__ dts)
-{
-    constexpr int ND = 4 * NC;
-    const T dt = dts != nullptr ? (T)dts[0] : dt_in;
-    T *lds = reinterpret_cast<T *>(arb_lds_raw);
-    const int nc = mp->nc, ndol = mp->ndol;
-    const int nA = ndol * ndol, sA = nA + 1, sP = 16 * nc + 1, sW = 41;
-    T *Ash = lds, *Psh = Ash + WPB * sA, *Wsh = Psh + WPB * sP;
-    const int lane = threadIdx.x;
-    const long w0 = (long)blockIdx.x * WPB;
-    const long w = w0 + lane;
-    const bool on = lane < WPB && w < nworlds;
-    const long nblk = (nworlds - w0) < WPB ? (nworlds - w0) : WPB;
-    for (long i = lane; i < nblk * nA; i += WAVE) Ash[(i / nA) * sA + (i % nA)] = wsA[w0 * nA + i];
-    __syncthreads();
-    const T inv_dt = T(1) / dt;
-    T v[ND], f[ND];
-    T c_sd[NC], c_p0[NC], c_p1[NC], c_p2[NC];
-    double c_warm[NC];
-    bool c_act[NC];
-    const T *Arow = Ash + lane * sA;
-    T *Prow = Psh + lane * sP;
-    T *work = Wsh + lane * sW;
-#pragma unroll
-    for (int i = 0; i < ND; ++i) { v[i] = T(0); f[i] = T(0); }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { c_act[c] = false; c_sd[c] = c_p0[c] = c_p1[c] = c_p2[c] = T(0); c_warm[c] = NAN; }
-    if (on) {
-#pragma unroll
-        for (int i = 0; i < ND; ++i) if (i < ndol) { v[i] = wsv[w * ndol + i]; f[i] = wsf[w * ndol + i]; }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c < nc) {
-                const T *cs = wsc + (w * nc + c) * 8;
-                c_act[c] = cs[0] != T(0);
-                c_sd[c] = cs[1]; c_p0[c] = cs[2]; c_p1[c] = cs[3]; c_p2[c] = cs[4];
-                if (c_act[c]) {
-                    const int ct = mp->ctype[c];
-                    const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
-                    T P[16];
-                    if (!inv_block<T>(Arow + (4 * c) * ndol + 4 * c, ndol, nd, P))
-                        pinv_block<T>(Arow + (4 * c) * ndol + 4 * c, ndol, nd, P);      // rank deficient: constraints.py:795
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) Prow[16 * c + i] = P[i];
-                }
-            }
-        }
-    }
-    for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
-        bool moved = false;          // any velocity or force of this lane's world changed in this sweep
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c >= nc) continue;
-            const int ct = mp->ctype[c];                       // same model for every world: uniform
-            if (!(on && c_act[c])) continue;
-            T Y[16], P[16], v4[4], f4[4], df[4] = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v4[i] = v[4 * c + i]; f4[i] = f[4 * c + i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { Y[4 * i + j] = Arow[(4 * c + i) * ndol + 4 * c + j]; P[4 * i + j] = Prow[16 * c + 4 * i + j]; }
-            }
-            if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
-                const T eps[3] = {mp->ceps[3 * c], mp->ceps[3 * c + 1], mp->ceps[3 * c + 2]};
-                T alpha[4], shift = T(0);
-                int br = softfinger_try<T>(v4, Y, P, f4, df, c_sd[c], dt, mp->cmu[c], eps, work, alpha, &shift,
-                                           true, nullptr, &c_warm[c]);
-                if (br == 3) { shift = slide_shift_from_eig<T>(work); c_warm[c] = NAN; br = 2; }
-                if (br == 2) softfinger_slide_finish<T>(Y, alpha, eps, shift, f4, df);
-            } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
-                const T tg[3] = {v4[0] + c_p0[c] * inv_dt, v4[1] + c_p1[c] * inv_dt, v4[2] + c_p2[c] * inv_dt};
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    df[i] = -(P[4 * i] * tg[0] + P[4 * i + 1] * tg[1] + P[4 * i + 2] * tg[2]);
-                    f4[i] += df[i];
-                }
-            } else {                                               // JointLimits.solve constraints.py:73-90
-                const T v00 = v4[0] - Y[0] * f4[0], glo = c_p1[c], ghi = c_p2[c];     // see the fused kernel
-                T nf = T(0);
-                if (v00 <= glo) nf = P[0] * (glo - v00);
-                else if (ghi <= v00) nf = P[0] * (ghi - v00);
-                df[0] = nf - f4[0]; f4[0] = nf;
-            }
-            // vel += Y'[:, c] dforce                               core.py:935
-#pragma unroll
-            for (int i = 0; i < ND; ++i)
-                if (i < ndol) {
-                    const T *ar = Arow + i * ndol + 4 * c;
-                    const T vn = v[i] + (ar[0] * df[0] + ar[1] * df[1] + ar[2] * df[2] + ar[3] * df[3]);
-                    moved = moved || !same_bits(vn, v[i]);
-                    v[i] = vn;
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { moved = moved || !same_bits(f4[i], f[4 * c + i]); f[4 * c + i] = f4[i]; }
-        }
-        // fixed point reached by every world of the wave: the remaining sweeps would repeat it exactly
-        if (!__any(moved)) break;
-    }
-    if (on) {
-#pragma unroll
-        for (int i = 0; i < ND; ++i) if (i < ndol) wsf[w * ndol + i] = f[i];
-    }
-}
-
-// ===========================================================================
 // Gauss-Seidel with one WAVEFRONT per world as its own kernel (split execution, ARB_STEP_SPLIT_WAVE): the
 // quad-local sweeps of gs_stage, fed from the SplitIO buffers.  The sweeps are one dependent chain per world
 // and need few registers, so this kernel is compiled for several waves per SIMD (the step kernel is pinned
@@ -2100,7 +2007,7 @@ __global__ __launch_bounds__(WAVE, WV) void arb_gsw_kernel(
 // ===========================================================================
 // Device unit test of the local solve (test hook arb_dev_softfinger_solve): one LANE per input tuple, the
 // same arb_math.h code the kernels run -- inverse of the 4x4 block, SoftFingerContact.solve with the fast
-// sliding shift or the eig6 fallback on a lane-private LDS work array, like arb_gs_kernel.
+// sliding shift or the eig6 fallback on a lane-private LDS work array.
 // in: [n][27] = vel 4 | adm 16 | force 4 | sdist, dt, mu ;  out: [n][9] = force 4 | dforce 4 | branch
 // ===========================================================================
 template <typename T>
@@ -2147,10 +2054,13 @@ thread_local std::string g_hip_err;
 // kernels of one register tile and precision only (explicit instantiations below) and none of the
 // host code; the main unit declares them extern and holds the C ABI.
 // ---------------------------------------------------------------------------
-// Stream-ordered scratch for the work queue: a pool of this library's own per device that keeps what it is given
-// back (release threshold = max), so a launch costs no driver allocation after the first; the default pool of the
-// device -- whose settings belong to the application -- is the fallback.
-static hipError_t queue_alloc(void **p, size_t bytes, hipStream_t st) {
+// Stream-ordered scratch (the work queue's flags, the split execution's hand-over buffers): a pool of this library's
+// own per device that keeps what it is given back (release threshold = max), so a launch costs no driver allocation
+// after the first; the default pool of the device -- whose settings belong to the application -- is the fallback.
+// One definition, in the host unit: the kernel units of the split build call it.
+hipError_t arb_scratch_alloc(void **p, size_t bytes, hipStream_t st);
+#ifndef ARB_PART
+hipError_t arb_scratch_alloc(void **p, size_t bytes, hipStream_t st) {
     static hipMemPool_t pools[64] = {};
     static std::mutex mu;
     int dev = 0;
@@ -2182,6 +2092,13 @@ static hipError_t queue_alloc(void **p, size_t bytes, hipStream_t st) {
     }
     return hipMallocAsync(p, bytes, st);
 }
+#endif
+
+// development knobs read from the environment at every launch (cheap; they must be changeable between launches of
+// one process): ARB_LDS_PAD = bytes of dynamic LDS added to every step-kernel workgroup (occupancy experiments),
+// ARB_QUEUE_SPIN_CAP = polls after which a wavefront gives up waiting for a chunk (negative: every wait of a later chunk
+// expires at once -- the fault injection of the ARB_ERR_STALLED tests)
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 // Wave slots of the chip for a kernel (workgroups of one wavefront): CUs x resident workgroups per CU.
 template <typename K>
@@ -2198,28 +2115,35 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
                       const SplitIO<T> &sio, const double *dts, hipStream_t st) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE, FEAT, CM>;
-    const size_t lds = (size_t)L.total * sizeof(T);
+    const size_t lds = (size_t)L.total * sizeof(T) + (size_t)std::max(0, env_int("ARB_LDS_PAD", 0));
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // Work queue (see the kernel): multi-step launches of more worlds than the chip has wave slots.  Constraint forces
     // that persist from step to step travel between chunks through `cf`, so it must be there when the model has
     // constraints.  ARB_STEP_STATIC_WORLDS (or ARB_QUEUE_CHUNK=0 in the environment) keeps one workgroup per world.
-    static const int chunk = [] { const char *e = getenv("ARB_QUEUE_CHUNK"); return e ? atoi(e) : 4; }();
-    static const int tail_env = [] { const char *e = getenv("ARB_QUEUE_TAIL"); return e ? atoi(e) : 4; }();
-    const int tail = std::max(0, std::min(tail_env, nsteps - 1));
+    const int chunk = env_int("ARB_QUEUE_CHUNK", 4);
+    const int tail = std::max(0, std::min(env_int("ARB_QUEUE_TAIL", 4), nsteps - 1));
+    const int spin_cap = env_int("ARB_QUEUE_SPIN_CAP", 1 << 24);
     int *queue = nullptr;
     unsigned grid = (unsigned)nw;
     constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);     // (see the kernel)
     if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 &&
         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
-        static thread_local size_t slots_lds = ~(size_t)0;      // (per thread: no race; identical GPUs assumed per process)
-        static thread_local int slots = 0;
-        if (slots_lds != lds) { slots = wave_slots(kern, lds); slots_lds = lds; }
+        // wave slots of this kernel on the current device, cached per thread for the last (device, LDS size) asked
+        static thread_local size_t slots_lds = ~(size_t)0;
+        static thread_local int slots_dev = -1, slots = 0;
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (slots_lds != lds || slots_dev != dev) { slots = wave_slots(kern, lds); slots_lds = lds; slots_dev = dev; }
         if (slots > 0 && nw > slots) {
             const size_t bytes = (size_t)(1 + nw) * sizeof(int);
-            if (queue_alloc(reinterpret_cast<void **>(&queue), bytes, st) == hipSuccess) {
-                HIP_TRY(hipMemsetAsync(queue, 0, bytes, st));
+            if (arb_scratch_alloc(reinterpret_cast<void **>(&queue), bytes, st) == hipSuccess) {
+                if (hipMemsetAsync(queue, 0, bytes, st) != hipSuccess) {
+                    g_hip_err = "hipMemsetAsync(queue)";
+                    (void)hipFreeAsync(queue, st);
+                    return ARB_ERR_HIP;
+                }
                 // resident wavefronts that loop over items -- or one workgroup per item, looped by the dispatcher
                 const int nbig = (nsteps - tail + chunk - 1) / chunk;
                 grid = QUEUE_LOOP ? (unsigned)slots : (unsigned)(nw * (long)(nbig + tail));
@@ -2230,9 +2154,13 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio, dts,
-                       queue, chunk > 0 ? chunk : 1, tail);
-    HIP_TRY(hipGetLastError());
-    if (queue != nullptr) HIP_TRY(hipFreeAsync(queue, st));
+                       queue, chunk > 0 ? chunk : 1, tail, spin_cap);
+    const hipError_t le = hipGetLastError();
+    if (queue != nullptr) {
+        const hipError_t fe = hipFreeAsync(queue, st);         // (also after a failed launch: nothing leaks)
+        if (le == hipSuccess && fe != hipSuccess) { g_hip_err = std::string("hipFreeAsync(queue): ") + hipGetErrorString(fe); return ARB_ERR_HIP; }
+    }
+    if (le != hipSuccess) { g_hip_err = std::string("kernel launch: ") + hipGetErrorString(le); return ARB_ERR_HIP; }
     return ARB_OK;
 }
 
@@ -2247,11 +2175,13 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 0>(ARB_LAUNCH_ONE_AR
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 3, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 1, 3, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1, 3, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 #if ARB_PART_IS_FLOAT
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 #endif
 #else
 #if defined(ARB_SPLIT_BUILD)
@@ -2260,11 +2190,13 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 1, 1>(ARB_LAUNCH_ONE_AR
     extern template int launch_one<T, NM, 2, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
     extern template int launch_one<T, NM, 1, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
     extern template int launch_one<T, NM, 2, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
-    extern template int launch_one<T, NM, 1, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
-    extern template int launch_one<T, NM, 2, 1, 1, 0>(ARB_LAUNCH_ONE_ARGS(T));
+    extern template int launch_one<T, NM, 1, 0, 3, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 2, 0, 3, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 1, 1, 3, 0>(ARB_LAUNCH_ONE_ARGS(T));        \
+    extern template int launch_one<T, NM, 2, 1, 3, 0>(ARB_LAUNCH_ONE_ARGS(T));
 #define ARB_EXTERN_TILE_CM(NM)                                                          \
-    extern template int launch_one<float, NM, 1, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(float));  \
-    extern template int launch_one<float, NM, 2, 0, 1, 1>(ARB_LAUNCH_ONE_ARGS(float));
+    extern template int launch_one<float, NM, 1, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 2, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(float));
 ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_TILE_CM(48) ARB_EXTERN_TILE_CM(64)
 #undef ARB_EXTERN_TILE_CM
 ARB_EXTERN_TILE(float, 16) ARB_EXTERN_TILE(float, 32) ARB_EXTERN_TILE(float, 44) ARB_EXTERN_TILE(float, 48) ARB_EXTERN_TILE(float, 64)
@@ -2301,10 +2233,16 @@ struct arb_model {
     DevModel<double> dd;
     DevModel<float> *df_dev;
     DevModel<double> *dd_dev;
-    void *ws = nullptr;            // split-execution workspace (grow-only)
-    size_t ws_bytes = 0;
+    int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
     Layout lf, ld;
 };
+
+// ARB_ERR_STALLED when an earlier launch of the handle raised the status word (host memory: no synchronisation)
+static int take_status(arb_model *M) {
+    if (M->status_host == nullptr) return ARB_OK;
+    const int v = __atomic_exchange_n(M->status_host, 0, __ATOMIC_RELAXED);
+    return v != 0 ? ARB_ERR_STALLED : ARB_OK;
+}
 
 template <typename T>
 static int upload(arb_model *M, const std::vector<T> &h, const T **out) {
@@ -2491,6 +2429,7 @@ extern "C" const char *arb_strerror(int status) {
         case ARB_ERR_UNSUPPORTED: return "model not supported by the device step";
         case ARB_ERR_HIP: return "HIP runtime error";
         case ARB_ERR_NOMEM: return "out of memory";
+        case ARB_ERR_STALLED: return "an earlier launch on this handle gave up waiting in its work queue: its results are invalid";
         default: return "unknown status";
     }
 }
@@ -2603,6 +2542,17 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     if (rc == ARB_OK)
         rc = build_dev<double>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
+    {
+        void *hp = nullptr, *dp = nullptr;
+        hipError_t e = hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped);
+        if (e == hipSuccess) { M->status_host = static_cast<int *>(hp); *M->status_host = 0; e = hipHostGetDevicePointer(&dp, hp, 0); }
+        if (e != hipSuccess) {
+            g_hip_err = std::string("status word: ") + hipGetErrorString(e);
+            arb_model_destroy(M);
+            return ARB_ERR_HIP;
+        }
+        M->df.status = M->dd.status = static_cast<int *>(dp);
+    }
     int tot;
     M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
     M->ld = M->dd.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
@@ -2630,10 +2580,15 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
 extern "C" int arb_model_destroy(arb_model *M) {
     if (!M) return ARB_ERR_INVALID;
     DeviceGuard guard_(M->device);
-    for (void *p : M->allocs) (void)hipFree(p);
-    if (M->ws) (void)hipFree(M->ws);          // (hipFree waits for the work that uses it)
+    for (void *p : M->allocs) (void)hipFree(p);       // (hipFree waits for the work that uses it)
+    if (M->status_host) (void)hipHostFree(M->status_host);
     delete M;
     return ARB_OK;
+}
+
+extern "C" int arb_model_status(arb_model *M) {
+    if (!M) return ARB_ERR_INVALID;
+    return take_status(M);
 }
 
 extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
@@ -2650,9 +2605,10 @@ template <typename T, int MODE>
 static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw,
                   double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
                   const SplitIO<T> &sio, const double *dts, hipStream_t st) {
-    // the plain step (FEAT 0): nothing but the state and the constraint forces
-    const bool plain = MODE == 0 && ext == nullptr && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
+    // the plain step (FEAT 0): nothing but the state and the constraint forces; FEAT 1: + user torques (MPC rollouts)
+    const bool noopt = MODE == 0 && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
                        logo.dq == nullptr && logo.energy == nullptr && sio.mode == 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS) && dts == nullptr;
+    const bool plain = noopt && ext == nullptr;
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
 #define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
@@ -2661,8 +2617,8 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // development build: a single register tile (float, NMAX=44, one column set)
     if constexpr (std::is_same<T, float>::value) {
         if (M->nmax == 44 && M->nsets == 1) {
-            if constexpr (MODE == 0) return mfma ? ONE_(44, 1, 1, 1) : (plain ? ONE(44, 1, 0) : ONE(44, 1, 1));
-            else return ONE(44, 1, 1);
+            if constexpr (MODE == 0) return mfma ? ONE_(44, 1, 3, 1) : (plain ? ONE(44, 1, 0) : noopt ? ONE(44, 1, 1) : ONE(44, 1, 3));
+            else return ONE(44, 1, 3);
         }
     }
     return ARB_ERR_UNSUPPORTED;
@@ -2670,12 +2626,13 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #define CASE(NM)                                                                                       \
     case NM:                                                                                           \
         if constexpr (MODE == 0 && std::is_same<T, float>::value) {                                    \
-            if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 1, 1) : ONE_(NM, 1, 1, 1);                  \
+            if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 3, 1) : ONE_(NM, 1, 3, 1);                  \
         }                                                                                              \
         if constexpr (MODE == 0) {                                                                     \
             if (plain) return (M->nsets == 2) ? ONE(NM, 2, 0) : ONE(NM, 1, 0);                         \
+            if (noopt) return (M->nsets == 2) ? ONE(NM, 2, 1) : ONE(NM, 1, 1);                         \
         }                                                                                              \
-        return (M->nsets == 2) ? ONE(NM, 2, 1) : ONE(NM, 1, 1);
+        return (M->nsets == 2) ? ONE(NM, 2, 3) : ONE(NM, 1, 3);
     switch (M->nmax) {
         CASE(16) CASE(32) CASE(44) CASE(48) CASE(64)
         default: return ARB_ERR_UNSUPPORTED;
@@ -2684,44 +2641,6 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #endif
 #undef ONE
 #undef ONE_
-}
-
-// Gauss-Seidel kernel launch (lane = world).  Picks the constraint-count tile NC and the
-// number of worlds per 64-thread block that fits the 160 KB LDS.
-template <typename T, int NC>
-static int launch_gs_nc(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st) {
-    const int ndol = 4 * nc;
-    const size_t per_world = ((size_t)ndol * ndol + 1 + 16 * nc + 1 + 41) * sizeof(T);
-    int wpb = 64;
-    while (wpb > 16 && per_world * wpb > 160 * 1024) wpb >>= 1;
-    if (per_world * wpb > 160 * 1024) return ARB_ERR_UNSUPPORTED;
-    const size_t lds = per_world * wpb;
-    const unsigned grid = (unsigned)((nw + wpb - 1) / wpb);
-#define GS_LAUNCH(W)                                                                                              \
-    do {                                                                                                          \
-        auto kern = arb_gs_kernel<T, NC, W>;                                                                      \
-        if (lds > 64 * 1024)                                                                                      \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts); \
-    } while (0)
-    if (wpb == 64) GS_LAUNCH(64); else if (wpb == 32) GS_LAUNCH(32); else GS_LAUNCH(16);
-#undef GS_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return ARB_OK;
-}
-
-template <typename T>
-static int launch_gs(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st) {
-#ifdef ARB_QUICK
-    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, dts, st);
-    return ARB_ERR_UNSUPPORTED;
-#else
-    if (nc <= 4) return launch_gs_nc<T, 4>(dm, nc, sio, nw, dt, dts, st);
-    if (nc <= 8) return launch_gs_nc<T, 8>(dm, nc, sio, nw, dt, dts, st);
-    if (nc <= 16) return launch_gs_nc<T, 16>(dm, nc, sio, nw, dt, dts, st);
-    return ARB_ERR_UNSUPPORTED;
-#endif
 }
 
 template <typename T>
@@ -2740,10 +2659,6 @@ static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long
     return ARB_OK;
 }
 
-// Measured on MI355X (tools/split_vs_fused.py, human36 + 4 contacts): the split execution overtakes the fused
-// kernel from ~8k worlds per launch (13.9 vs 12.8 M world-steps/s at 16k, 15.4 vs 13.6 at 64k); with 8 contacts
-// it never does.  Below that the lane-per-world kernel is a latency chain on too few wavefronts.
-
 template <typename T>
 static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext,
                       const PerWorldPD<T> &pwd, long nw, double dt, const double *dts, int nsteps, unsigned flags,
@@ -2753,48 +2668,41 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
     if (log) { lo.q = (T *)log->q_log; lo.dq = (T *)log->dq_log; lo.energy = (T *)log->energy_log; }
     SplitIO<T> sio; memset(&sio, 0, sizeof(sio));
     const int nc = M->nc, ndol = M->ndol, n = M->n;
-    const bool wave_gs = (flags & ARB_STEP_SPLIT_WAVE) != 0;
-    const bool can_split = nc > 0 && (nc <= 16 || wave_gs) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
-    // Opt-in (ARB_STEP_SPLIT) since round 1: the lane-per-world kernel is 1.1-1.15x faster from ~16k worlds, but it
-    // returned a 1e18 N contact force for one world in 2 M world-steps until a compiler workaround went into
-    // arb_math.h::softfinger_try (split execution); it stays opt-in until it has seen more inputs.
-    const bool split = can_split && (flags & (ARB_STEP_SPLIT | ARB_STEP_SPLIT_WAVE));
+    const bool split = nc > 0 && (flags & ARB_STEP_SPLIT_WAVE) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
     if (!split)
         return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, dts, st);
-    // ---- split execution: step kernel (dynamics + system) / Gauss-Seidel kernel (lane = world) ----
+    // ---- split execution (opt-in): step kernel (dynamics + system) / Gauss-Seidel kernel (one wavefront per world) ----
+    // The hand-over buffers are allocated per call in stream order and freed in stream order after the last launch:
+    // no per-handle state, so a handle may run split steps on several streams at once.
     const size_t per_world = (size_t)ndol * ndol + 3 * (size_t)ndol + 8 * (size_t)nc + (size_t)(1 + ndol) * n;
     const size_t need = per_world * (size_t)nw * sizeof(T);
-    if (need > M->ws_bytes) {
-        // grow: the old block is released in stream order (work already queued on `st` keeps it until it has run)
-        // and the new one is allocated in stream order: no device-wide synchronisation.  One workspace per handle:
-        // a handle must not run split steps on two streams at once (include/arbstep.h).
-        if (M->ws) { HIP_TRY(hipFreeAsync(M->ws, st)); M->ws = nullptr; M->ws_bytes = 0; }
-        HIP_TRY(hipMallocAsync(&M->ws, need, st));
-        M->ws_bytes = need;
-    }
-    T *p = (T *)M->ws;
+    void *ws = nullptr;
+    HIP_TRY(arb_scratch_alloc(&ws, need, st));
+    T *p = (T *)ws;
     sio.A = p; p += (size_t)nw * ndol * ndol;
     sio.v = p; p += (size_t)nw * ndol;
     sio.f = p; p += (size_t)nw * ndol;
     sio.f0 = p; p += (size_t)nw * ndol;
     sio.c = p; p += (size_t)nw * nc * 8;
     sio.sol = p;
-    for (int k = 0; k < nsteps; ++k) {
+    int rc = ARB_OK;
+    for (int k = 0; k < nsteps && rc == ARB_OK; ++k) {
         LogOut<T> lk = lo;
         if (lk.q) lk.q += (size_t)k * nw * M->nq;
         if (lk.dq) lk.dq += (size_t)k * nw * n;
         if (lk.energy) lk.energy += (size_t)k * nw * 2;
         sio.mode = 2 | (k > 0 ? 1 : 0);
         // (kernel k finishes step k-1 with dts[k-1], then builds step k with dts[k])
-        int rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, dts ? dts + k : nullptr, st);
-        if (rc != ARB_OK) return rc;
-        rc = wave_gs ? launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st)
-                     : launch_gs<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st);
-        if (rc != ARB_OK) return rc;
+        rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, dts ? dts + k : nullptr, st);
+        if (rc == ARB_OK) rc = launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st);
     }
-    sio.mode = 1;                                      // apply the last step's forces, write cforce
-    LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
-    return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, sio, dts ? dts + nsteps : nullptr, st);
+    if (rc == ARB_OK) {
+        sio.mode = 1;                                      // apply the last step's forces, write cforce
+        LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
+        rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, sio, dts ? dts + nsteps : nullptr, st);
+    }
+    (void)hipFreeAsync(ws, st);
+    return rc;
 }
 
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
@@ -2805,6 +2713,7 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (dt_steps == nullptr && !(dt > 0.0)) return ARB_ERR_INVALID;
     if (dt_steps != nullptr) dt = 1.0;                  // unused: every step reads its own dt
     if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
+    if (flags & ~ARB_STEP_KNOWN_FLAGS) return ARB_ERR_INVALID;     // (4u was ARB_STEP_SPLIT up to ABI 4)
     // per-world PD inputs: targets come in pairs; diagonal gains come in pairs and need targets;
     // targets without gains use the model's gain matrices, so the model must hold a PD controller
     if ((pd_qdes == nullptr) != (pd_dqdes == nullptr) || (pd_kp == nullptr) != (pd_kd == nullptr)) return ARB_ERR_INVALID;
@@ -2813,6 +2722,7 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (nworlds == 0 || nsteps == 0) return ARB_OK;     // empty batch: nothing to do (pointers may be null)
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
+    if (int stalled = take_status(M)) return stalled;
     ARB_GUARD_DEVICE(M->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32) {
@@ -2883,6 +2793,7 @@ extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *d
     if (nworlds == 0) return ARB_OK;
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
+    if (int stalled = take_status(M)) return stalled;
     ARB_GUARD_DEVICE(M->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32)

@@ -47,3 +47,16 @@ def standing_states(model, B, seed=0, drop=0.03, vel=0.1):
             H[:, 1, 3] = y
             q[:, qs] = H.reshape(B, 16)
     return q, dq
+
+
+def world_states(model, worlds, kind="standing", seed=0, **kw):
+    """States of the worlds with GLOBAL indices ``worlds`` (an iterable of ints) of a seeded batch in which world w
+    is drawn from its own stream ``default_rng([seed, w])`` ("seed = rollout index"): whatever range of
+    the batch a rank takes, and however large the batch is, world w is the same world -- so a 1-GPU run and rank 0 of
+    an 8-GPU run step identical worlds.  ``kind``: "standing" (standing_states) or "random" (random_states)."""
+    gen = standing_states if kind == "standing" else random_states
+    worlds = list(worlds)
+    q = np.zeros((len(worlds), model.nq)); dq = np.zeros((len(worlds), model.ndof))
+    for i, w in enumerate(worlds):
+        q[i], dq[i] = (a[0] for a in gen(model, 1, seed=[int(seed), int(w)], **kw))
+    return q, dq

@@ -50,6 +50,12 @@ CONFIGS = {
     5: dict(model="human36", contacts=4, batch=8192, dtype="f32", dt=5e-3, episode=32, states="standing",
             name="human36 + 4 contacts, 32-step horizon, 8192 worlds/GPU = 65536 on 8 GPUs (BASELINE config #5)"),
 }
+# the literal MPC shape of config 5 (secondary run): 2048 rollouts x 32 in-kernel steps over 8 GPUs = 256
+# rollouts per GPU, every rollout with its own user torques (arb_step's ext_gforce, controllers.py:63-158's hook);
+# one launch per horizon, only the final state is written.  The latency regime: one world per wave slot at most.
+MPC = dict(model="human36", contacts=4, batch=256, dtype="f32", dt=5e-3, episode=32, states="standing", torques=True,
+           name="human36 + 4 contacts, MPC shape: 32-step horizon resident in one launch, per-rollout torques, "
+                "256 rollouts/GPU = 2048 on 8 GPUs (BASELINE config #5, literal shape)")
 
 
 def parse(argv=None):
@@ -67,9 +73,12 @@ def parse(argv=None):
                     help="lower bound of the timed region (whole episodes are repeated until it is reached)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--split", default=None, choices=("lane", "wave"),
-                    help="Gauss-Seidel sweeps in their own kernel: one lane per world (ARB_STEP_SPLIT) or one "
-                         "wavefront per world (ARB_STEP_SPLIT_WAVE); default: inside the step kernel")
+    ap.add_argument("--split", default=None, choices=("wave",),
+                    help="Gauss-Seidel sweeps in their own kernel, one wavefront per world (ARB_STEP_SPLIT_WAVE); "
+                         "default: inside the step kernel")
+    ap.add_argument("--mpc", action="store_true",
+                    help="with --config 5: the literal MPC shape (2048 rollouts x 32 in-kernel steps over 8 GPUs = 256 "
+                         "rollouts per GPU, per-rollout torques) instead of 65536 independent worlds")
     ap.add_argument("--no-per-step-leg", action="store_true", help="skip the one-launch-per-step comparison leg")
     ap.add_argument("--extra", action="store_true", help="also time the other BASELINE configs (N=1)")
     ap.add_argument("--dry-run", action="store_true",
@@ -160,7 +169,7 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
     return out
 
 
-def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True):
+def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True, ext=None):
     """Run `n_episodes` whole episodes: restore the pristine states, advance `episode` steps (one arb_step
     launch per `spl` steps; default the whole episode in one launch).  Returns wall seconds between the
     two barrier + synchronize brackets, the launch durations in ms (HIP events on the launch stream =
@@ -188,7 +197,7 @@ def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=Non
             if timed:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            bw.step(q, dq, dt, c, cforce=cf, split=(split if split != "lane" else True))
+            bw.step(q, dq, dt, c, cforce=cf, split=split or False, ext_gforce=ext)
             if timed:
                 b.record()
                 ev.append((a, b))
@@ -208,18 +217,28 @@ def build_model(cfg):
     return scenes.flat(scenes.human36_world(cfg["contacts"]))
 
 
-def make_states(cfg, model, count, seed):
+def make_states(cfg, model, lo, hi, seed):
+    """Worlds [lo, hi) of the config's seeded global batch (world w has its own stream, seed = (seed, w))."""
     from arboris_python_amd import synth
     if cfg["states"] == "standing":
         # config 3/5 distribution: standing pose dropped from U(0, 3 cm), small velocities
-        return synth.standing_states(model, count, seed=seed, drop=0.03, vel=0.1)
+        return synth.world_states(model, range(lo, hi), "standing", seed, drop=0.03, vel=0.1)
     if cfg["model"] == "snake64":
-        return synth.random_states(model, count, seed=seed, angle=0.5, vel=1.0)
-    return synth.random_states(model, count, seed=seed)
+        return synth.world_states(model, range(lo, hi), "random", seed, angle=0.5, vel=1.0)
+    return synth.world_states(model, range(lo, hi), "random", seed)
+
+
+def make_torques(model, lo, hi, seed):
+    """Per-rollout user torques of the MPC shape for rollouts [lo, hi): U(-0.05, 0.05) N m on every joint dof, none on
+    the floating base (the distal bodies of human36 are light); rollout w draws from its own stream (seed, w)."""
+    import numpy as np
+    tau = np.stack([np.random.default_rng([seed, w]).uniform(-0.05, 0.05, size=model.ndof) for w in range(lo, hi)])
+    tau[:, :6] = 0.
+    return tau
 
 
 def resolve_config(args):
-    cfg = dict(CONFIGS[args.config])
+    cfg = dict(MPC if (args.mpc and args.config == 5) else CONFIGS[args.config])
     if args.batch is not None:
         cfg["batch"] = args.batch
     if args.contacts is not None and cfg["model"] == "human36":
@@ -311,14 +330,19 @@ def main():
     bw = BatchedWorlds(model, local_rank)
     B = cfg["batch"]
     lo, hi = shard_bounds(n_gpus * B, rank, n_gpus)                  # this rank's worlds of the global batch
-    q, dq = make_states(cfg, model, hi - lo, seed=1000 + rank)
+    # ONE seeded global batch in which world w has its own random stream: rank r of N steps worlds [lo, hi) of it,
+    # and world w is the same world in an N = 1 and in an N = 8 run
+    q, dq = make_states(cfg, model, lo, hi, seed=1000)
     q0, dq0 = bw.to_device(q, dq, dtype)
     dt, EP = cfg["dt"], cfg["episode"]
+    ext = None
+    if cfg.get("torques"):
+        ext = torch.as_tensor(make_torques(model, lo, hi, seed=2000), dtype=dtype, device=bw.device).contiguous()
 
     # ---- warmup: W steps rounded up to whole episodes (untimed), then one calibration episode -------------
     warm_eps = max(1, -(-args.warmup // EP))
-    run_episodes(bw, q0, dq0, dt, EP, warm_eps, torch, dist, split=args.split, timed=False)
-    cal, _, _ = run_episodes(bw, q0, dq0, dt, EP, 2, torch, dist, split=args.split, timed=False)
+    run_episodes(bw, q0, dq0, dt, EP, warm_eps, torch, dist, split=args.split, timed=False, ext=ext)
+    cal, _, _ = run_episodes(bw, q0, dq0, dt, EP, 2, torch, dist, split=args.split, timed=False, ext=ext)
     n_ep = max(-(-args.steps // EP), 50, int(np.ceil(args.min_seconds / max(cal / 2, 1e-6))))
     t = torch.tensor([n_ep], dtype=torch.int64, device=bw.device)
     if dist is not None:
@@ -326,7 +350,7 @@ def main():
     n_ep = int(t.item())
 
     # ---- the timed region: n_ep whole episodes between barrier + synchronize brackets ----------------------
-    wall, ms, (qf, dqf) = run_episodes(bw, q0, dq0, dt, EP, n_ep, torch, dist, split=args.split)
+    wall, ms, (qf, dqf) = run_episodes(bw, q0, dq0, dt, EP, n_ep, torch, dist, split=args.split, ext=ext)
     t = torch.tensor([wall], dtype=torch.float64, device=bw.device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -356,6 +380,8 @@ def main():
     bytes_per_world_step = 2 * (model.nq + model.ndof) * elem           # state in + state out
     if model.nc:
         bytes_per_world_step += 2 * model.nc * 4 * elem                  # cforce in + out
+    if ext is not None:
+        bytes_per_world_step += model.ndof * elem                        # the rollout's torques, read once per launch
     value = n_gpus * B * steps_timed / wall
     kern_ms = float(np.mean(ep_ms))
     # one launch reads and writes the state once, whatever the number of steps it advances on chip
@@ -403,6 +429,8 @@ def main():
     prof = profs[-1] if profs else ""
     shape = {"config": args.config, "batch": B, "dtype": cfg["dtype"], "contacts": cfg["contacts"],
              "steps_per_launch": EP, "split": args.split or False}
+    if cfg.get("torques"):
+        shape["mpc"] = True
     if os.path.exists(prof) and launches_per_episode == 1:
         try:
             pj = json.load(open(prof))
@@ -411,13 +439,20 @@ def main():
             if pshape == shape:
                 pm = pj["pmc_per_launch"]
                 res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
+                # hand-overs of a world's state between wavefronts in the work queue (csrc launch_one: ARB_QUEUE_CHUNK /
+                # ARB_QUEUE_TAIL defaults 4 / 4): chunks of 4 steps, then the last 4 steps one by one
+                chunk_, tail_ = int(os.environ.get("ARB_QUEUE_CHUNK", "4")), min(int(os.environ.get("ARB_QUEUE_TAIL", "4")), EP - 1)
+                items_ = (-(-(EP - tail_) // chunk_) + tail_) if chunk_ > 0 else 1
                 res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
                                                    "(profiles/%s); 4 B/lane accesses, reported uncorrected.  With the work queue the "
-                                                   "state of every world is handed from wavefront to wavefront 13 times per "
-                                                   "40-step episode (13 x 880 B x worlds = 46.9 MB of the figure): that, not re-reads, "
-                                                   "is the excess over the algorithmic bytes" % os.path.basename(prof))
+                                                   "state of every world is handed from wavefront to wavefront %d times per "
+                                                   "%d-step episode (%d x %d B x worlds = %.1f MB of the figure): that, not re-reads, "
+                                                   "is the excess over the algorithmic bytes"
+                                                   % (os.path.basename(prof), items_, EP, items_, bytes_per_world_step,
+                                                      items_ * bytes_per_world_step * B / 1e6))
                 ws = float(B * EP)
-                res["roofline"]["valu"] = {
+                simds, clk = 1024, 2.4e9                     # 256 CUs x 4 SIMD-32; peak shader clock
+                valu = {
                     "valu_insts_per_world_step": pm["SQ_INSTS_VALU"]["mean_per_launch"] / ws,
                     "salu_insts_per_world_step": pm["SQ_INSTS_SALU"]["mean_per_launch"] / ws,
                     "lds_insts_per_world_step": pm["SQ_INSTS_LDS"]["mean_per_launch"] / ws,
@@ -425,13 +460,23 @@ def main():
                     "wave_frac_issuing_valu": pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
                     "wave_frac_waiting": (pm["SQ_WAIT_ANY"]["mean_per_launch"] + pm["SQ_WAIT_INST_ANY"]["mean_per_launch"])
                                          / pm["SQ_WAVE_CYCLES"]["mean_per_launch"],
-                    # the fraction that says something about this kernel: how busy the vector ALUs are, from the
-                    # profiled launch (quad-cycles of VALU execution summed over the SIMDs) and THIS run's kernel time
-                    "valu_pipe_busy_frac": 4. * pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]
-                                           / (kern_ms * 1e-3 * 1024 * 2.4e9),
-                    "valu_pipe_busy_note": "SQ_ACTIVE_INST_VALU x 4 cycles / (kernel time x 1024 SIMDs x 2.4 GHz peak clock): "
-                                           "a lower bound of the VALU issue utilisation (the sustained clock is lower)",
+                    # The fraction that says something about this kernel.  CDNA4 SIMDs are SIMD-32: a wave64 VALU
+                    # instruction occupies the pipe for 2 cycles (MI355X_MICROARCH.md; 4 is what ONE wave alone
+                    # sustains), so the issue roof is 1024 SIMDs x 2.4 GHz / 2 wave-instructions per second.
+                    "valu_issue_frac": 2. * pm["SQ_INSTS_VALU"]["mean_per_launch"] / (kern_ms * 1e-3 * simds * clk),
+                    "valu_issue_frac_note": "SQ_INSTS_VALU x 2 cycles (wave64 on SIMD-32) / (kernel time x 1024 SIMDs x 2.4 GHz): "
+                                            "the profiled launch's wave-instructions against THIS run's kernel time.  Round 2 "
+                                            "reported SQ_ACTIVE_INST_VALU x 4 cycles (0.80): that is the occupancy of a single "
+                                            "wave's issue slot, not of the SIMD's pipe",
                     "note": "SQ counters of profiles/%s" % os.path.basename(prof)}
+                if "valu_lane_utilisation" in pj:
+                    # active lanes per executed VALU instruction: thread-cycles over 64 x instruction-cycles, one pass
+                    valu["valu_lane_utilisation"] = pj["valu_lane_utilisation"]
+                    valu["valu_lane_utilisation_note"] = ("SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): the share of the 64 "
+                                                          "lanes enabled (EXEC) when a VALU instruction executes; lanes that run "
+                                                          "along on don't-care data (the quads beside a constraint's own quad in "
+                                                          "the Gauss-Seidel sweeps) count as enabled")
+                res["roofline"]["valu"] = valu
                 if "SQ_INSTS_MFMA" in pm:
                     res["roofline"]["valu"]["mfma_insts_per_world_step"] = pm["SQ_INSTS_MFMA"]["mean_per_launch"] / ws
                     res["roofline"]["valu"]["mfma_note"] = ("v_mfma_f32_4x4x1_16b_f32 in the constraint-space products of "
@@ -443,7 +488,7 @@ def main():
         res["final_state_allgather_ms"] = gather_ms
     if n_gpus == 1 and not args.no_per_step_leg:
         # the same workload with one launch per step (a non-uniform timeline, or observers between steps)
-        w1, m1, _ = run_episodes(bw, q0, dq0, dt, EP, 5, torch, None, spl=1, split=args.split)
+        w1, m1, _ = run_episodes(bw, q0, dq0, dt, EP, 5, torch, None, spl=1, split=args.split, ext=ext)
         res["per_step_launch"] = {"value": B * 5 * EP / w1, "unit": "world-steps/s", "kernel_ms": float(np.mean(m1)),
                                   "steps": 5 * EP}
     if n_gpus == 1 and not args.no_cpu_baseline:
@@ -451,15 +496,19 @@ def main():
         res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     if args.extra and n_gpus == 1:
         extra = {}
-        for cid in (2, 4, 5):
-            c2 = dict(CONFIGS[cid])
+        for cid in (2, 4, 5, "5mpc"):
+            c2 = dict(MPC if cid == "5mpc" else CONFIGS[cid])
             mdl = build_model(c2)
             b2 = BatchedWorlds(mdl, local_rank)
-            qa, da = make_states(c2, mdl, c2["batch"], seed=0)
-            ta, tb = b2.to_device(qa, da, torch.float32 if c2["dtype"] == "f32" else torch.float64)
-            run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 2, torch, timed=False)
-            wl, me, (qe, _) = run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 20, torch)
-            extra["config%d" % cid] = {"workload": c2["name"], "world_steps_per_s": c2["batch"] * 20 * c2["episode"] / wl,
+            qa, da = make_states(c2, mdl, 0, c2["batch"], seed=0)
+            dt2 = torch.float32 if c2["dtype"] == "f32" else torch.float64
+            ta, tb = b2.to_device(qa, da, dt2)
+            ex2 = None
+            if c2.get("torques"):
+                ex2 = torch.as_tensor(make_torques(mdl, 0, c2["batch"], seed=2000), dtype=dt2, device=b2.device).contiguous()
+            run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 2, torch, timed=False, ext=ex2)
+            wl, me, (qe, _) = run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 20, torch, ext=ex2)
+            extra["config%s" % cid] = {"workload": c2["name"], "world_steps_per_s": c2["batch"] * 20 * c2["episode"] / wl,
                                        "episode_kernel_ms_median": float(np.median(me)),
                                        "finite": bool(torch.isfinite(qe).all())}
             b2.close()

@@ -23,8 +23,8 @@
  *     torch.Tensor.data_ptr()); the library keeps only the immutable model.
  *   - calls are asynchronous with respect to `stream` (a hipStream_t passed as
  *     void*; NULL = the default stream); there is no hidden synchronisation.
- *   - one model handle per device; calls on different handles are re-entrant.  A handle may be
- *     used from several streams, except with ARB_STEP_SPLIT (its workspace is per handle).
+ *   - one model handle per device; calls on different handles are re-entrant, and a handle may be
+ *     used from several streams at once (all scratch memory is allocated per call, in stream order).
  *     Every call makes the handle's device current and restores the caller's device on return.
  *   - twists/wrenches are ordered [angular; linear]; matrices are row-major.
  *
@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ARB_ABI_VERSION 4
+#define ARB_ABI_VERSION 5
 
 /* status codes */
 enum {
@@ -49,7 +49,9 @@ enum {
     ARB_ERR_INVALID = 1,      /* bad argument (null pointer, negative size, bad enum) */
     ARB_ERR_UNSUPPORTED = 2,  /* model outside what the kernels handle (ndof > 64 ...) */
     ARB_ERR_HIP = 3,          /* a HIP runtime call failed (see arb_last_hip_error) */
-    ARB_ERR_NOMEM = 4
+    ARB_ERR_NOMEM = 4,
+    ARB_ERR_STALLED = 5       /* an EARLIER launch on this handle gave up waiting inside its device-side work queue (see
+                                 arb_model_status): the states that launch wrote are not valid */
 };
 
 /* scalar type of the state buffers and of the arithmetic */
@@ -88,8 +90,8 @@ enum {
 /* arb_step flags */
 #define ARB_STEP_SKIP_CONSTRAINTS 1u  /* integrate with controller forces only */
 #define ARB_STEP_FUSED 2u             /* keep the Gauss-Seidel sweeps inside the step kernel (the default) */
-#define ARB_STEP_SPLIT 4u             /* run the sweeps in a second kernel with one lane per world (same results to
-                                         rounding; faster from ~16k worlds with <= 4 constraints; opt-in) */
+                                      /* (4u was ARB_STEP_SPLIT, the lane-per-world sweep kernel of ABI <= 4: removed, the
+                                         bit is refused with ARB_ERR_INVALID) */
 #define ARB_STEP_MFMA_ELIM 16u        /* float32 only: eliminate the augmented system [Z | rhs | J'^T] on the matrix cores
                                          (v_mfma_f32_4x4x1_16b_f32 rank-1 updates) instead of the vector ALU; same results to
                                          rounding, measured SLOWER on MI355X: opt-in */
@@ -99,7 +101,9 @@ enum {
                                          chunk (same results bit for bit; the queue is a stream-ordered allocation, so a launch
                                          has no hidden synchronisation) */
 #define ARB_STEP_SPLIT_WAVE 8u        /* run the sweeps in a second kernel with one WAVEFRONT per world (the fused kernel's
-                                         quad-local sweeps, bit-identical results, compiled for more waves per SIMD) */
+                                         quad-local sweeps, bit-identical results, compiled for more waves per SIMD).
+                                         Measured slower than the default at every batch size: opt-in */
+#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u)
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the
@@ -206,6 +210,17 @@ const char *arb_last_hip_error(void);
 int arb_model_create(const arb_model_desc *desc, int device, arb_model **out);
 int arb_model_destroy(arb_model *m);
 int arb_model_get_info(const arb_model *m, arb_model_info *info);
+
+/*
+ * Health of the handle's launches.  The device-side work queue of multi-step launches orders the chunks of a world
+ * through a flag per world; a wavefront that waits for a flag longer than ~10 s (a stalled producer: a debugger, a
+ * preempted queue, counter collection that serialises workgroups) gives up, does NOT advance or publish its item and
+ * raises a status word in host-visible memory.  arb_model_status returns ARB_OK or ARB_ERR_STALLED and clears the
+ * word; it reads host memory only (no synchronisation: call it after synchronising the stream to learn about the
+ * launches queued so far).  Every arb_step / arb_step_ex / arb_rollout / arb_inspect call makes the same check on entry
+ * and returns ARB_ERR_STALLED instead of launching when an earlier launch of the handle stalled.
+ */
+int arb_model_status(arb_model *m);
 
 /*
  * Advance `nworlds` independent worlds by `nsteps` steps of `dt`, in place.

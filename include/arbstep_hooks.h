@@ -1,0 +1,71 @@
+/*
+ * arbstep_hooks.h -- unit-test and single-constraint entry points of libarbstep.so.
+ *
+ * The kernels' small hand-written solvers (arboris_python_amd/csrc/arb_math.h) are written once and compiled twice:
+ * for gfx950 inside the step kernels, and for the host behind the `arb_host_*` functions below, so that the CPU test
+ * suite can check them against captured reference tuples without a GPU, and so that the object API's
+ * `Constraint.solve` (arboris/constraints.py:73-90, 235-237, 780-836 called on its own, outside a step) runs the
+ * SAME code as the kernels instead of a second implementation.  `arb_dev_*` runs the device build on explicit inputs.
+ *
+ * They are not part of the batched step boundary (include/arbstep.h): plain C, host pointers, float64 in and out
+ * whatever `dtype` (ARB_F32 rounds the inputs and computes in float32 like the float32 kernels do).
+ */
+#ifndef ARBSTEP_HOOKS_H
+#define ARBSTEP_HOOKS_H
+
+#include "arbstep.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Hg.zaligned(z) -> rotation matrix R[9] (row-major), arboris/homogeneousmatrix.py:201-232. */
+void arb_host_zaligned(const double z[3], double R[9]);
+
+/* Narrow phase of one shape pair (ARB_CG_*), arboris/collisions.py:67-299: shape 0's frame pose H_s0 (4x4), centre of
+ * shape 1 p_g1, its radius `rad`, shape 0's radius / half extents / plane coefficients; returns the signed distance
+ * and writes the contact-frame origins gc0, gc1 and their common rotation Rc[9]. */
+double arb_host_narrow_phase(int geom, const double H_s0[16], const double p_g1[3], double rad,
+                             double r0, const double half[3], const double plane[4],
+                             double gc0[3], double gc1[3], double Rc[9]);
+
+/* SoftFingerContact.solve, arboris/constraints.py:780-836: vel[4], adm[16], force[4] (in: current, out: new),
+ * eps[3], dforce[4] (out).  dtype: ARB_F32 / ARB_F64, optionally | 0x100 to force the generic eig6 route of the
+ * sliding branch.  Returns the branch taken: 0 release, 1 static, 2 sliding; -1 on a null argument. */
+int arb_host_softfinger_solve(int dtype, const double *vel, const double *adm, double *force,
+                              double sdist, double dt, double mu, const double *eps, double *dforce);
+
+/* The same solve executed ON THE DEVICE, one lane per tuple (needs a GPU): in [n][27] = vel 4 | adm 16 | force 4 |
+ * sdist, dt, mu;  out [n][9] = force 4 | dforce 4 | branch.  Returns an ARB_* status. */
+int arb_dev_softfinger_solve(int dtype, int device, int n, const double *in, double *out);
+
+/* Raw branch code of the first stage of the solve: 0, 1, 2 as above, 3 = sliding but the register-only shift
+ * declined and the 6x6 eigenvalue fallback is needed. */
+int arb_host_softfinger_try(int dtype, const double *vel, const double *adm, const double *force,
+                            double sdist, double dt, double mu, const double *eps);
+
+/* Leftmost real root of the sliding branch's sextic det(B - sI) (constraints.py:805-830 with eps = (1,1,1)) for the
+ * 4x4 admittance block Y and the two sweep-dependent scalars c1, kappa; `warm` = previous root or NaN.
+ * Returns 1 and *root on success, 0 when the caller must fall back to eig6. */
+int arb_host_slide_root(const double *Y, double c1, double kappa, double warm, double *root);
+
+/* (Pseudo-)inverse of an nd x nd constraint block as the kernels form it (numpy.linalg.pinv at
+ * constraints.py:79, 83, 235, 795): returns 1 when pivoted elimination was kept, 0 when the block was found rank
+ * deficient and the Jacobi-SVD route was taken, -1 on a bad argument. */
+int arb_host_block_pinv(int dtype, int nd, const double *Y, double *P);
+
+/* Eigenvalues of a real 6x6 matrix (numpy.linalg.eigvals at constraints.py:825): wr/wi[6]; returns how many of the
+ * trailing entries converged. */
+int arb_host_eig6(const double *A, double *wr, double *wi);
+
+/* Joint-local kinematics of one joint (ARB_JT_*), arboris/joints.py: out = R 9 | p 3 | Jacobian angular columns 9 |
+ * their derivatives 9 | relative twist 6. */
+int arb_host_joint_local(int jt, const double *q, const double *dq, double *out);
+
+/* twistvector.exp, arboris/twistvector.py:35-70: tw[6] -> H[16]. */
+int arb_host_exp_twist(const double *tw, double *H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARBSTEP_HOOKS_H */

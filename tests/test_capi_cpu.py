@@ -24,9 +24,19 @@ def test_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(arb_[a-z_0-9]+)\s*\(", header))
     declared -= {"arb_model_desc", "arb_inspect_out", "arb_model_info"}
     assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
+    # the unit-test / single-constraint hooks have a header of their own since round 3: everything the product or the
+    # tests bind must be declared in one of the two
+    hooks_h = open(os.path.join(ROOT, "include", "arbstep_hooks.h")).read()
+    hooks = set(re.findall(r"\b(arb_[a-z_0-9]+)\s*\(", hooks_h))
+    assert hooks == set(_capi.TEST_HOOKS), hooks ^ set(_capi.TEST_HOOKS)
     lib = C.CDLL(_capi.LIB_PATH)
     for name in _capi.EXPORTED + _capi.TEST_HOOKS:
         assert hasattr(lib, name), name
+    # and nothing else is exported under the library's prefix
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if l.split() and l.split()[-1].startswith("arb_") and " T " in l}
+    assert exported == set(_capi.EXPORTED) | set(_capi.TEST_HOOKS), exported ^ (set(_capi.EXPORTED) | set(_capi.TEST_HOOKS))
     assert _capi.load().arb_abi_version() == _capi.ARB_ABI_VERSION
     assert _capi.load().arb_strerror(0) == b"ok"
 

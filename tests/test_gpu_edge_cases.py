@@ -144,71 +144,12 @@ def test_small_models_use_other_register_tiles():
         bw.close()
 
 
-# ---------------------------------------------------------------------------
-# split execution (opt-in, ARB_STEP_SPLIT): the
-# Gauss-Seidel sweeps run in a second kernel with one lane per world; it must agree with
-# the fused kernel.
-@pytest.mark.parametrize("name,nsteps", [("human36_c4", 6), ("human36_c8", 3)])
-def test_split_execution_equals_fused(name, nsteps):
-    m, _, _ = load_model(name)
-    bw = BatchedWorlds(m)
-    B = 768
-    q, dq = synth.standing_states(m, B, seed=11, drop=0.01, vel=0.3)
-    q[:, 7] -= 0.004                      # feet slightly into the floor: static + sliding contacts
-    dq[::3, 3] += 0.8
-    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
-        a_q, a_dq = bw.to_device(q, dq, dtype)
-        b_q, b_dq = bw.to_device(q, dq, dtype)
-        ca, cb = bw.new_cforce(B, dtype), bw.new_cforce(B, dtype)
-        la = bw.rollout(a_q, a_dq, 5e-3, nsteps, cforce=ca, split=True)
-        lb = bw.rollout(b_q, b_dq, 5e-3, nsteps, cforce=cb, fused=True)
-        torch.cuda.synchronize()
-        assert rel(a_q.cpu().numpy(), b_q.cpu().numpy()) < tol
-        assert rel(a_dq.cpu().numpy(), b_dq.cpu().numpy()) < tol * 10
-        assert rel(ca.cpu().numpy(), cb.cpu().numpy()) < tol * 100
-        for k in ("q", "dq", "energy"):
-            assert rel(la[k].cpu().numpy(), lb[k].cpu().numpy()) < tol * 10
-        assert float(ca.abs().max()) > 10.                                  # contacts really engaged
-    # and against the oracle for one step
-    oq, odq, ocf = O.step(m, q[:64], dq[:64], 5e-3)
-    s_q, s_dq = bw.to_device(q, dq, torch.float64)
-    cs = bw.new_cforce(B, torch.float64)
-    bw.step(s_q, s_dq, 5e-3, 1, cforce=cs, split=True)
-    torch.cuda.synchronize()
-    assert rel(s_dq.cpu().numpy()[:64], odq) < 1e-8
-    assert rel(cs.cpu().numpy()[:64], ocf) < 1e-6
-    bw.close()
-
-
-def test_split_execution_other_constraint_types():
-    """BallAndSocket (warm-started forces) and JointLimits through the lane-per-world kernel."""
-    for name, dt, nsteps in (("ballsocket", 1e-3, 5), ("jointlimits_max", 1e-3, 60)):
-        m, q0, dq0 = load_model(name)
-        bw = BatchedWorlds(m)
-        B = 512
-        rng = np.random.default_rng(3)
-        q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1))
-        dq += 0.05 * rng.normal(size=dq.shape)
-        a_q, a_dq = bw.to_device(q, dq, torch.float64)
-        b_q, b_dq = bw.to_device(q, dq, torch.float64)
-        ca, cb = bw.new_cforce(B, torch.float64), bw.new_cforce(B, torch.float64)
-        bw.step(a_q, a_dq, dt, nsteps, cforce=ca, split=True)
-        bw.step(b_q, b_dq, dt, nsteps, cforce=cb, fused=True)
-        torch.cuda.synchronize()
-        assert rel(a_q.cpu().numpy(), b_q.cpu().numpy()) < 1e-11
-        assert rel(a_dq.cpu().numpy(), b_dq.cpu().numpy()) < 1e-10
-        assert rel(ca.cpu().numpy(), cb.cpu().numpy()) < 1e-9
-        oq, odq, ocf = O.rollout(m, q[:8], dq[:8], [dt] * nsteps)
-        assert rel(a_q.cpu().numpy()[:8], oq) < 1e-8
-        bw.close()
-
-
-@pytest.mark.parametrize("mode", ["fused", "split"])
+@pytest.mark.parametrize("mode", ["fused", "wave"])
 def test_eig6_fallback_canary(mode):
     """A state met in a 65536-world rollout (world 31974, step 19) whose Gauss-Seidel sweeps take the rare
     generic-eigenvalue fallback of the sliding solve (no admissible eigenvalue: s = -1e10, constraints.py:826-830).
-    One build of the lane-per-world kernel returned a 1e18 N contact force here (DESIGN.md, split execution);
-    both executions must agree with the oracle."""
+    One build of the (since removed) lane-per-world sweep kernel returned a 1e18 N contact force here; the fused
+    kernel and the wave-per-world sweep kernel must both agree with the oracle."""
     from arboris_python_amd.batch import BatchedWorlds
     m, _, _ = load_model("human36_c4")
     d = load_golden("canary_eig6_fallback.npz")
@@ -219,7 +160,7 @@ def test_eig6_fallback_canary(mode):
         q = torch.as_tensor(d["q"], dtype=torch.float32, device=bw.device)
         dq = torch.as_tensor(d["dq"], dtype=torch.float32, device=bw.device)
         cf = bw.new_cforce(1, torch.float32)
-        bw.step(q, dq, dt, 1, cforce=cf, fused=(mode == "fused"), split=(mode == "split"))
+        bw.step(q, dq, dt, 1, cforce=cf, fused=(mode == "fused"), split=("wave" if mode == "wave" else False))
         torch.cuda.synchronize()
         assert torch.isfinite(dq).all() and torch.isfinite(cf).all()
         assert np.abs(dq.cpu().numpy() - odq).max() / max(1., np.abs(odq).max()) < 1e-5

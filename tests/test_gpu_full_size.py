@@ -6,35 +6,32 @@ size-independent properties (the CPU oracle cannot step 65536 worlds in test tim
     check" of config 5, SURVEY.md 8d) on a subsample of worlds and steps;
   * batch-position independence: a world's trajectory does not depend on where it sits in the
     batch or on the batch size (bitwise, same execution path);
-  * launch-shape independence: N steps in one launch == N one-step launches (bitwise);
-  * the opt-in split execution (Gauss-Seidel sweeps in a lane-per-world kernel) against the fused kernel.
+  * launch-shape independence: N steps in one launch == N one-step launches (bitwise).
 
 Tolerance: max|x_gpu - x_ref| / max(1, max|x_ref|) <= 1e-5 per world for one float32 step from
 identical inputs (north star).  At least 99.5 % of the sampled world-steps must meet it (measured:
 99.9 %, tools/replay_stats.py) and EVERY outlier must be explained: the float32 device and the
 float64 oracle took different decisions in that step -- a different active set (constraints.py:292)
 or a different release / static / sliding decision in some solve of the Gauss-Seidel sweeps
-(constraints.py:781, 799; the device reports the decision of every solve, arb_inspect_out.gs_trace) -- or one of
-the oracle's decisions sits within 1e-6 (relative) of its inequality, or (errors below 3e-5 only) the step is so
-ill-conditioned that the float64 oracle itself moves by half the observed error when its input moves by one
-float32 ulp.  Unexplained outliers fail the test; explained ones stay below 1e-3.
+(constraints.py:781, 799; the device reports the decision of every solve, arb_inspect_out.gs_trace) -- AND that
+decision was marginal for the oracle itself: at the first solve where the traces part, the oracle's inequality is
+within 1e-5 of equality or the oracle's own trace changes under a one-ulp (float32) change of its input
+(tests/parity_tools.py; round 3: a decision difference alone no longer counts).  Errors below 3e-5 with identical
+decisions are accepted when the step is so ill-conditioned that the float64 oracle itself moves by half the
+observed error when its input moves by one float32 ulp.  Unexplained outliers fail the test; explained ones stay
+below 1e-3.
 """
 import numpy as np
 import pytest
 
 import arb_oracle as O
 from conftest import load_model, oracle_sensitivity
+from parity_tools import explain_outlier, world_err
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-5
-
-
-def world_err(a, b):
-    """Per-world relative error (B,)"""
-    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return np.max(np.abs(a - b), axis=1) / np.maximum(1., np.max(np.abs(b), axis=1))
 
 
 @pytest.fixture(scope="module")
@@ -67,49 +64,6 @@ def replay_errors(m, log_q, log_dq, steps, worlds, dt, with_index=False):
     if with_index:
         return np.concatenate(eq), np.concatenate(edq), idx
     return np.concatenate(eq), np.concatenate(edq)
-
-
-def decision_margins(tr):
-    """Smallest relative distance of the oracle's SoftFingerContact.solve decisions (constraints.py:781
-    release test, :799 friction cone test) from their inequalities, over the solves of a trace."""
-    best = np.inf
-    for t in tr:
-        vel, adm, f, sd, dt = t["vel"], np.asarray(t["adm"]), t["force"], t["sdist"], t["dt"]
-        v0 = vel - adm @ f
-        rel_lhs = sd + dt * v0[3]
-        best = min(best, abs(rel_lhs) / max(abs(sd) + abs(dt * v0[3]), 1e-300))
-        if rel_lhs > 0:
-            continue
-        fn = f - np.linalg.pinv(adm) @ np.hstack((vel[0:3], vel[3] + sd / dt))
-        lhs, rhs = float(np.sum(fn[0:3] ** 2)), float((fn[3] * t["mu"]) ** 2)
-        best = min(best, abs(lhs - rhs) / max(lhs, rhs, 1e-300))
-    return best
-
-
-def explain_outlier(bw, m, q, dq, dt):
-    """Why may a float32 step differ from the float64 oracle by more than rounding?  Returns a reason
-    string, or None.  `q`, `dq`: the float32 state the device stepped from (one world)."""
-    tq = torch.as_tensor(q[None], dtype=torch.float32, device=bw.device).contiguous()
-    tdq = torch.as_tensor(dq[None], dtype=torch.float32, device=bw.device).contiguous()
-    r = bw.inspect(tq, tdq, dt, ["gs_stats", "gs_trace", "c_active"], cforce=bw.new_cforce(1, torch.float32))
-    st = r["gs_stats"].cpu().numpy()[0]                    # release, static, fast slide, eig6 slide, sweeps
-    dtr = r["gs_trace"].cpu().numpy()[0]                   # (20, nc): decision of every executed solve, -1 = not run
-    dact = r["c_active"].cpu().numpy()[0].astype(bool)
-    tr = []
-    _, _, _, d = O.step(m, q[None].astype(np.float64), dq[None].astype(np.float64), dt, debug=True, trace=tr)
-    if not np.array_equal(dact, d["active"][0]):
-        return "active set differs"
-    # the device stops sweeping at a bit-exact fixed point: compare the sweeps it executed, solve by solve
-    nsw = int(st[4])
-    for t in tr:
-        if t["sweep"] < nsw:
-            dev = int(dtr[t["sweep"], t["c"]])
-            if min(dev, 2) != t["branch"]:
-                return "decision differs at sweep %d contact %d (oracle %d, device %d)" % (t["sweep"], t["c"], t["branch"], dev)
-    mg = decision_margins(tr)
-    if mg < 1e-6:
-        return "decision within %.1e of its inequality" % mg
-    return None
 
 
 def check_replay(bw, m, log, steps, worlds, dt, min_ok=0.995, max_outlier=1e-3):
@@ -238,19 +192,6 @@ def test_config5_65536_worlds_32_steps(bws, name):
     bw.step(sq, sdq, dt, 1, cforce=bw.new_cforce(len(sub), torch.float32))
     torch.cuda.synchronize()
     assert torch.equal(sq, log["q"][1][sub]) and torch.equal(sdq, log["dq"][1][sub])
-    if m.nc <= 4:
-        # the opt-in split execution (Gauss-Seidel sweeps in a lane-per-world kernel) on the whole batch:
-        # stays finite over the rollout and agrees with the fused kernel after one step
-        pq, pdq = bw.to_device(q, dq, torch.float32)
-        pcf = bw.new_cforce(B, torch.float32)
-        bw.step(pq, pdq, dt, 1, cforce=pcf, split=True)
-        torch.cuda.synchronize()
-        e1 = world_err(pq.cpu().numpy(), log["q"][1].cpu().numpy())
-        e2 = world_err(pdq.cpu().numpy(), log["dq"][1].cpu().numpy())
-        assert np.quantile(e1, 0.995) < F32_TOL and np.quantile(e2, 0.995) < F32_TOL, (e1.max(), e2.max())
-        bw.step(pq, pdq, dt, T - 1, cforce=pcf, split=True)
-        torch.cuda.synchronize()
-        assert torch.isfinite(pq).all() and torch.isfinite(pdq).all() and torch.isfinite(pcf).all()
 
 
 def test_config5_mpc_2048_rollouts_x_32_step_horizon(bws):

@@ -32,14 +32,21 @@ if trace:
                                   single_step_launches=len(one), mean_ms_single_step_launch=(sum(one) / len(one)) if one else None,
                                   single_step_ms_first_episode=[round(x, 3) for x in one[:40]])
 pmc = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+lanes = {}
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     acc = {}
     rows = [r for r in csv.DictReader(open(f)) if "arb_step_kernel" in r["Kernel_Name"]]
     for r in rows:                      # every dispatch of these passes is a whole-episode launch (--no-per-step-leg)
         a = acc.setdefault(r["Counter_Name"], [0.0, set()])
         a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
     for name, (tot, ids) in acc.items():
+        if os.sep + "pmc_lanes" + os.sep in f:
+            lanes[name] = tot / len(ids)
+            if name == "SQ_ACTIVE_INST_VALU":
+                continue                  # (the issue fractions use the value of the pmc_sq2 pass)
         pmc[name] = dict(mean_per_launch=tot / len(ids), launches=len(ids))
+if "SQ_THREAD_CYCLES_VALU" in lanes and lanes.get("SQ_ACTIVE_INST_VALU"):
+    out["valu_lane_utilisation"] = lanes["SQ_THREAD_CYCLES_VALU"] / (64. * lanes["SQ_ACTIVE_INST_VALU"])
 out["pmc_per_launch"] = pmc
 out["notes"] = ("bench.py config 3: human36 + 4 contacts, 4096 worlds, f32, one 40-step episode per launch; kernel-trace pass: "
                 "--steps 40 --warmup 40 --min-seconds 1 (>= 50 timed episode launches + the one-launch-per-step leg); each --pmc "
