@@ -69,7 +69,7 @@ def test_wave_split_ball_and_socket_and_joint_limits(bws):
     assert np.abs(tq.cpu().numpy()[0] - g["jl_max_q"][99]).max() < 1e-8
 
 
-@pytest.mark.parametrize("split", [False, "wave", True])
+@pytest.mark.parametrize("split", [False, "wave"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-5)])
 def test_non_uniform_timeline_in_one_launch(bws, dtype, tol, split):
     """simulate() takes dt from the timeline (core.py:1356-1357); here 24 steps with 24 different dt."""
@@ -172,14 +172,13 @@ def test_matrix_core_elimination_parity(bws, name):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_split_executions_on_rank_deficient_blocks(bws, dtype):
     """The closed-loop planar arm (rank-2 3x3 admittance block, numpy.linalg.pinv semantics, constraints.py:235)
-    through the split executions: the wave-per-world sweep kernel runs the fused kernel's code (bitwise equal), the
-    lane-per-world kernel its own copy of the guard + SVD fallback (equal to rounding)."""
+    through the split execution: the wave-per-world sweep kernel runs the fused kernel's code (bitwise equal)."""
     g = load_golden("g12_singular.npz")
     bw, m, _, _ = bws("loop_arm")
     Q, DQ, F = g["loop_q"], g["loop_dq"], g["loop_force"]
     cf0 = np.zeros((40, 1, 4)); cf0[1:, 0, :3] = F[:39]
     out = {}
-    for split in (False, "wave", True):
+    for split in (False, "wave"):
         tq, tdq = bw.to_device(Q[:40], DQ[:40], dtype)
         tcf = torch.as_tensor(cf0, dtype=dtype, device=bw.device).contiguous()
         bw.step(tq, tdq, 5e-3, 1, cforce=tcf, split=split)
@@ -187,9 +186,6 @@ def test_split_executions_on_rank_deficient_blocks(bws, dtype):
         assert torch.isfinite(tq).all() and torch.isfinite(tcf).all()
         out[split] = (tq, tdq, tcf)
     assert all(torch.equal(a, b) for a, b in zip(out[False], out["wave"]))
-    tol = 1e-10 if dtype == torch.float64 else 1e-5
-    for a, b in zip(out[False], out[True]):
-        assert float((a - b).abs().max()) <= tol * max(1., float(a.abs().max()))
     # and the forces are the reference's
     ftol = 1e-6 if dtype == torch.float64 else 5e-3
     assert np.abs(out["wave"][2].cpu().numpy()[:, 0, :3] - F).max() < ftol * max(1., np.abs(F).max())
