@@ -93,7 +93,12 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
 // body 1 and of body 0 (lo, hi each), constrained dof -- the constraint-row loops of phase B read them with
 // wave-uniform LDS reads instead of chains of dependent scalar loads from the model
 #define CI_STRIDE 6
-#define TB_STRIDE 70     // float64 per body in that table: 63 (69 inspect) accumulators, padded; 560 B rows: bank-conflict free
+// float64 per body in the prefix table of phase B.  The 63 (69 inspect) accumulators go through the table in TWO passes
+// (A: 36 values, then M | rhs: 27 (33)) so that the table is no larger than the X | P | R vectors that take its place
+// afterwards (round 3: 2380 -> 1292 float32 words for human36, one of the three changes that bring the wave's LDS
+// from 19.4 KB to 13.1 KB = twelve waves per CU).  304 B rows.
+#define TB_STRIDE 38
+#define TB_PASS1 36
 
 // exact (bit pattern) equality, also true for identical NaNs
 __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_int(a) == __float_as_int(b); }
@@ -1051,7 +1056,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         ARB_OPAQUE_LANE();
         ARB_ASTAMP(6);
         ARB_STAMP(1);
-        for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0);
+        // (RT -- the rhs and the rows of J' -- is zeroed in phase B, once the joints' own columns SC, which share its
+        // space since round 3, have been consumed)
         if (do_constraints && lane < nc) {
             const int c = lane;
             T *cd = CD + c * CD_STRIDE;
@@ -1206,6 +1212,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { twb[i] = bd[BD_TW + i]; om_b[i] = bd[BD_OM + i]; ptb[i] = bd[BD_PT + i]; pgb[i] = bd[BD_PG + i]; }
             }
+            // Small trees: the body lanes write the M | rhs part of their accumulators straight into the prefix table,
+            // which takes the place of the per-body blocks: every lane has its own block in registers by now.
+            const bool use_table = LSCAN_OK && mp->lay.lscan;
+            WAVE_SYNC();
             // ---- lane = body: world-frame matrices of the body -----------------------------------
             if (lane < nb) {
                 const int b = lane;
@@ -1246,15 +1256,16 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         }
                 }
                 // (before the 3x3 blocks, so that R and p die with them) wrenches to world axes: Ad(b<-g)^T f = (R tau + p x R f, R f)
+                double wr[NACC - 57];              // world wrench of the increment rhs (6) [| gravity wrench (6), inspect]
                 {
                     const V3<double> f = mv(R, v3<double>((double)ptb[3], (double)ptb[4], (double)ptb[5]));
                     const V3<double> tq = mv(R, v3<double>((double)ptb[0], (double)ptb[1], (double)ptb[2])) + cross(p, f);
-                    Acc[57] = tq.x; Acc[58] = tq.y; Acc[59] = tq.z; Acc[60] = f.x; Acc[61] = f.y; Acc[62] = f.z;
+                    wr[0] = tq.x; wr[1] = tq.y; wr[2] = tq.z; wr[3] = f.x; wr[4] = f.y; wr[5] = f.z;
                 }
                 if (MODE == 1) {
                     const V3<double> f = mv(R, v3<double>((double)pgb[3], (double)pgb[4], (double)pgb[5]));
                     const V3<double> tq = mv(R, v3<double>((double)pgb[0], (double)pgb[1], (double)pgb[2])) + cross(p, f);
-                    Acc[NACC - 6] = tq.x; Acc[NACC - 5] = tq.y; Acc[NACC - 4] = tq.z; Acc[NACC - 3] = f.x; Acc[NACC - 2] = f.y; Acc[NACC - 1] = f.z;
+                    wr[NACC - 63] = tq.x; wr[NACC - 62] = tq.y; wr[NACC - 61] = tq.z; wr[NACC - 60] = f.x; wr[NACC - 59] = f.y; wr[NACC - 58] = f.z;
                 }
                 double G[36];                  // Mg = Ad(b<-g)^T M_b Ad(b<-g), symmetric
                 {
@@ -1269,6 +1280,21 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                             G[6 * i + j] = G11.a[3 * i + j]; G[6 * i + 3 + j] = G12.a[3 * i + j];
                             G[6 * (3 + i) + j] = G21.a[3 * i + j]; G[6 * (3 + i) + 3 + j] = M22.a[3 * i + j];
                         }
+                }
+                // M (upper triangle, 21) | rhs wrench (6) [| gravity wrench (6)]: final as soon as Mg is -- into the prefix
+                // table at once (small trees: these 27 values never occupy registers beside the 36 of A), or into Acc
+                // (large trees -- the DPP scan -- keep them in Acc, assigned at the end of this block as before)
+                auto mr_at = [&](int i) -> double {           // entry i of [M upper triangle | rhs wrench | gravity wrench]
+                    constexpr int RW[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+                    constexpr int CL[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+                    if (i < 21) return useN ? G[6 * RW[i] + CL[i]] : 0.;
+                    return i < NACC - TB_PASS1 ? wr[i - 21] : 0.;
+                };
+                if (use_table) {
+                    typedef double D2 __attribute__((ext_vector_type(2)));
+                    D2 *row = reinterpret_cast<D2 *>(STG + TB_STRIDE * b);
+#pragma unroll
+                    for (int i2 = 0; i2 < (NACC - TB_PASS1 + 1) / 2; ++i2) { D2 v; v.x = mr_at(2 * i2); v.y = mr_at(2 * i2 + 1); row[i2] = v; }
                 }
                 // T* = [w; c x w] (c = centre of mass, core.py:1276-1288) and Om, both in world axes
                 const V3<double> wb = v3<double>((double)twb[0], (double)twb[1], (double)twb[2]);
@@ -1297,15 +1323,46 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         Acc[6 * r + 3] += u.x; Acc[6 * r + 4] += u.y; Acc[6 * r + 5] += u.z;
                     }
                 }
-                {
-                    int t = 36;
+                if (!use_table) {
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-#pragma unroll
-                        for (int c2 = r; c2 < 6; ++c2) Acc[t++] = useN ? G[6 * r + c2] : 0.;
+                    for (int i = 0; i < NACC - TB_PASS1; ++i) Acc[TB_PASS1 + i] = mr_at(i);
                 }
             }
-            WAVE_SYNC();                       // the per-body blocks are dead from here: the region becomes STG
+            WAVE_SYNC();                       // (table rows / accumulators of every body are complete)
+            // One pass of the LDS prefix table over the accumulators OFF .. OFF + CNT - 1: (a) lane = body stores them
+            // as a table row, (b) lane = accumulator runs the inclusive prefix down its column.
+            // (the rows of the M | rhs pass were written by the body block above: `written`)
+            auto tb_pass = [&](auto offc, auto cntc, bool written) {
+                constexpr int OFF = decltype(offc)::value, CNT = decltype(cntc)::value;
+                typedef double D2 __attribute__((ext_vector_type(2)));
+                double *TB = STG;
+                if (!written) {
+                    if (lane < nb) {
+                        D2 *row = reinterpret_cast<D2 *>(TB + TB_STRIDE * lane);
+#pragma unroll
+                        for (int i2 = 0; i2 < (CNT + 1) / 2; ++i2) {
+                            D2 v; v.x = Acc[OFF + 2 * i2]; v.y = (2 * i2 + 1 < CNT) ? Acc[OFF + 2 * i2 + 1] : 0.;
+                            row[i2] = v;
+                        }
+                    }
+                    WAVE_SYNC();
+                }
+                for (int i = lane; i < CNT; i += WAVE) {
+                    double run = 0.;
+                    double *col = TB + i;
+                    for (int b0 = 0; b0 < nb; b0 += 4) {              // four bodies per round trip
+                        const double v0 = col[TB_STRIDE * b0];
+                        const double v1 = (b0 + 1 < nb) ? col[TB_STRIDE * (b0 + 1)] : 0.;
+                        const double v2 = (b0 + 2 < nb) ? col[TB_STRIDE * (b0 + 2)] : 0.;
+                        const double v3 = (b0 + 3 < nb) ? col[TB_STRIDE * (b0 + 3)] : 0.;
+                        run += v0; col[TB_STRIDE * b0] = run;
+                        run += v1; if (b0 + 1 < nb) col[TB_STRIDE * (b0 + 1)] = run;
+                        run += v2; if (b0 + 2 < nb) col[TB_STRIDE * (b0 + 2)] = run;
+                        run += v3; if (b0 + 3 < nb) col[TB_STRIDE * (b0 + 3)] = run;
+                    }
+                }
+                WAVE_SYNC();
+            };
             // ---- subtree sums, deepest level first; children hand their sums over through STG ------
             ARB_BSTAMP(3);
             const int bsrc = (lane < n) ? mp->dofbody[lane] : 0;
@@ -1324,32 +1381,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     // instructions for human36; round 2).  (a) lane = body stores its accumulators as a table row;
                     // (b) lane = accumulator i runs the prefix down its column; (c) lane = dof k reads the two rows that
                     // bound the subtree of body(k) and subtracts, element by element as its products consume them.
-                    typedef double D2 __attribute__((ext_vector_type(2)));
-                    double *TB = STG;
-                    if (lane < nb) {
-                        D2 *row = reinterpret_cast<D2 *>(TB + TB_STRIDE * lane);
-#pragma unroll
-                        for (int i2 = 0; i2 < (NACC + 1) / 2; ++i2) {
-                            D2 v; v.x = Acc[2 * i2]; v.y = (2 * i2 + 1 < NACC) ? Acc[2 * i2 + 1] : 0.;
-                            row[i2] = v;
-                        }
-                    }
-                    WAVE_SYNC();
-                    for (int i = lane; i < NACC; i += WAVE) {
-                        double run = 0.;
-                        double *col = TB + i;
-                        for (int b0 = 0; b0 < nb; b0 += 4) {              // four bodies per round trip
-                            const double v0 = col[TB_STRIDE * b0];
-                            const double v1 = (b0 + 1 < nb) ? col[TB_STRIDE * (b0 + 1)] : 0.;
-                            const double v2 = (b0 + 2 < nb) ? col[TB_STRIDE * (b0 + 2)] : 0.;
-                            const double v3 = (b0 + 3 < nb) ? col[TB_STRIDE * (b0 + 3)] : 0.;
-                            run += v0; col[TB_STRIDE * b0] = run;
-                            run += v1; if (b0 + 1 < nb) col[TB_STRIDE * (b0 + 1)] = run;
-                            run += v2; if (b0 + 2 < nb) col[TB_STRIDE * (b0 + 2)] = run;
-                            run += v3; if (b0 + 3 < nb) col[TB_STRIDE * (b0 + 3)] = run;
-                        }
-                    }
-                    WAVE_SYNC();
+                    // first pass: M | rhs, whose rows the body lanes have written already (the pass over the 36 entries of
+                    // A, still in registers, runs inside the consumer below once the first has been consumed: the table is
+                    // half as large that way, and the body block never holds more than A and Mg in registers)
+                    tb_pass(std::integral_constant<int, TB_PASS1>{}, std::integral_constant<int, NACC - TB_PASS1>{}, true);
                     // (c) happens in the consumer below, which streams the two table rows of body(k) straight
                     // into its products: the 63 composites never sit in registers all at once
                 } else {
@@ -1429,11 +1464,23 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const D2 *ph = reinterpret_cast<const D2 *>(STG + TB_STRIDE * top);
                     const D2 *pl = reinterpret_cast<const D2 *>(STG + TB_STRIDE * (a > 0 ? a - 1 : 0));
                     const double keep = a > 0 ? 1. : 0.;
-                    static_for_asc(std::make_integer_sequence<int, (NACC + 1) / 2>{}, [&](auto i2c) {
+                    static_assert(TB_PASS1 % 2 == 0 && NACC - TB_PASS1 <= TB_STRIDE, "prefix table passes");
+                    // (the accumulators of the two passes are disjoint -- R, M dX', rhs from M | rhs; G, P from A -- so the
+                    // order of the passes does not change a bit of the results)
+                    static_for_asc(std::make_integer_sequence<int, (NACC - TB_PASS1 + 1) / 2>{}, [&](auto i2c) {
+                        constexpr int i2 = decltype(i2c)::value;
+                        const D2 h = ph[i2], l = pl[i2];
+                        visit(std::integral_constant<int, TB_PASS1 + 2 * i2>{}, h.x - keep * l.x);
+                        if constexpr (TB_PASS1 + 2 * i2 + 1 < NACC) visit(std::integral_constant<int, TB_PASS1 + 2 * i2 + 1>{}, h.y - keep * l.y);
+                        if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
+                    });
+                    WAVE_SYNC();                   // every lane has consumed the first pass: the table is rewritten
+                    tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, TB_PASS1>{}, false);
+                    static_for_asc(std::make_integer_sequence<int, TB_PASS1 / 2>{}, [&](auto i2c) {
                         constexpr int i2 = decltype(i2c)::value;
                         const D2 h = ph[i2], l = pl[i2];
                         visit(std::integral_constant<int, 2 * i2>{}, h.x - keep * l.x);
-                        if constexpr (2 * i2 + 1 < NACC) visit(std::integral_constant<int, 2 * i2 + 1>{}, h.y - keep * l.y);
+                        visit(std::integral_constant<int, 2 * i2 + 1>{}, h.y - keep * l.y);
                         if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
                     });
                 } else {
@@ -1444,6 +1491,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 rhsM = (lane < n) ? (T)rm : T(0);
                 rhsG = (MODE == 1 && lane < n) ? (T)rg : T(0);
                 WAVE_SYNC();                   // every lane is done with the staging area: it becomes XPR
+                // ... and with the joints' own columns SC: their space becomes RT = [rhs | rows of J'], zero before
+                // the constraint rows and the joint-limit selectors are written (entries >= ndof of a row stay zero)
+                for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0);
                 if (lane < n) {
                     double *o = STG + XPR_STRIDE * lane;
 #pragma unroll
@@ -2273,14 +2323,18 @@ static std::vector<double> h12(const double *H16, int count) {
     return v;
 }
 
-// Size (in elements of T) of the per-body block region.  Once phase A' is over the region is
-// reused as float64 scratch for the per-dof X | P | R vectors of phase B.
-// (and, for small trees, the prefix table of the subtree sums: nb rows of TB_STRIDE float64)
+// LDS layout of one wavefront (elements of T).  Two regions are shared by arrays that are never live together:
+//   bd : per-body blocks BD (phases A, A') -> prefix table of the subtree sums (phase B, small trees: nb rows of
+//        TB_STRIDE float64) -> per-dof X | P | R vectors (phase B) -> AM = Y' (phase D .. Gauss-Seidel)
+//   rt : the joints' own columns SC (phase A .. dof products of phase B) -> RT = [rhs | rows of J'] (end of phase B,
+//        phase C) -> solution columns [Y rhs | Y J'^T] (phase D .. E)
+// (round 3: SC and AM had regions of their own and the prefix table was 70 float64 wide: 19.4 KB per human36 world;
+// 13.1 KB now, which lets twelve wavefronts share a CU's LDS instead of eight)
 static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
-static int bd_region_elems(int nb, int rs, int elems_per_double) {
+static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int tb = lds_scan(nb, rs) ? al(nb * TB_STRIDE * elems_per_double) : 0;
-    return std::max(std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double)), tb);
+    return std::max(std::max(std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double)), tb), al(std::max(ndol * ndol, 4)));
 }
 
 static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems) {
@@ -2290,12 +2344,10 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     L.q = o; o += al(nq);
     L.dq = o; o += WAVE;
     L.qd = o; o += WAVE;
-    L.bd = o; o += bd_region_elems(nb, rs, elems_per_double);
+    L.bd = o; L.am = o; o += bd_region_elems(nb, rs, ndol, elems_per_double);
     L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
-    L.sc = o; o += 12 * rs;
+    L.rt = o; L.sc = o; o += std::max(1 + ndol, 12) * rs;
     L.cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
-    L.rt = o; o += (1 + ndol) * rs;
-    L.am = o; o += al(std::max(ndol * ndol, 4));
     L.vv = o; o += al(std::max(ndol, 4));
     L.ff = o; o += al(std::max(ndol, 4));
     L.ff0 = o; o += al(std::max(ndol, 4));
@@ -2614,12 +2666,27 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
-    // development build: a single register tile (float, NMAX=44, one column set)
+    // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
+    // two column sets, the inspect kernel and the optional inputs)
     if constexpr (std::is_same<T, float>::value) {
         if (M->nmax == 44 && M->nsets == 1) {
-            if constexpr (MODE == 0) return mfma ? ONE_(44, 1, 3, 1) : (plain ? ONE(44, 1, 0) : noopt ? ONE(44, 1, 1) : ONE(44, 1, 3));
+            if constexpr (MODE == 0) {
+                if (plain) return ONE(44, 1, 0);
+                if (noopt) return ONE(44, 1, 1);
+#if ARB_QUICK >= 2
+                return mfma ? ONE_(44, 1, 3, 1) : ONE(44, 1, 3);
+#endif
+            }
+#if ARB_QUICK >= 2
             else return ONE(44, 1, 3);
+#endif
         }
+#if ARB_QUICK >= 2
+        if (M->nmax == 44 && M->nsets == 2) {
+            if constexpr (MODE == 0) return plain ? ONE(44, 2, 0) : noopt ? ONE(44, 2, 1) : ONE(44, 2, 3);
+            else return ONE(44, 2, 3);
+        }
+#endif
     }
     return ARB_ERR_UNSUPPORTED;
 #else
