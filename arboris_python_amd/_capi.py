@@ -24,6 +24,8 @@ ARB_STEP_FUSED = 2
 ARB_STEP_SPLIT_WAVE = 8
 ARB_STEP_MFMA_ELIM = 16
 ARB_STEP_STATIC_WORLDS = 32
+ARB_STEP_WAVES2 = 64
+ARB_STEP_WAVES3 = 128
 
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)

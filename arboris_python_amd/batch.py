@@ -118,8 +118,17 @@ class BatchedWorlds(object):
         raise ValueError("split must be False or 'wave' (the lane-per-world sweep kernel of ABI <= 4 was removed)")
 
     # -- the step --------------------------------------------------------------
+    @staticmethod
+    def _waves_flag(waves):
+        if waves is None:
+            return 0
+        if waves in (2, 3):
+            return _capi.ARB_STEP_WAVES2 if waves == 2 else _capi.ARB_STEP_WAVES3
+        raise ValueError("waves must be None (the library picks by batch size), 2 or 3")
+
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
-             stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False):
+             stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False,
+             waves=None):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
@@ -130,6 +139,8 @@ class BatchedWorlds(object):
         ``mfma=True`` (float32): phase C eliminates on the matrix cores (ARB_STEP_MFMA_ELIM; slower).
         ``static_worlds=True``: one workgroup per world for the whole launch (ARB_STEP_STATIC_WORLDS) instead of the
         device-side queue of (chunk of steps, world) items that multi-step launches of large batches use by default.
+        ``waves=2|3`` pins the float32 kernel build (ARB_STEP_WAVES2/3, include/arbstep.h): by default the library picks
+        by batch size; the builds agree to rounding, each is bit-reproducible across launch shapes.
         ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller).
         ``pd_targets=(qdes, dqdes)`` (B,ndof) each: one ProportionalDerivativeController target
         per world (controllers.py:63-158), with the model's gains, or with the per-world DIAGONAL
@@ -145,6 +156,7 @@ class BatchedWorlds(object):
             flags |= _capi.ARB_STEP_MFMA_ELIM
         if static_worlds:
             flags |= _capi.ARB_STEP_STATIC_WORLDS
+        flags |= self._waves_flag(waves)
         dts = self._dt_steps(dt, nsteps, st)
         if pd_targets is None and pd_gains is None and dts is None:
             _capi.check(self._lib.arb_step(
@@ -173,7 +185,7 @@ class BatchedWorlds(object):
         _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
 
     def rollout(self, q, dq, dt, nsteps, cforce=None, ext_gforce=None, log_state=True, log_energy=True,
-                skip_constraints=False, stream=None, fused=False, split=False):
+                skip_constraints=False, stream=None, fused=False, split=False, waves=None):
         """Advance ``nsteps`` steps in ONE launch and return the per-step logs an Observer
         would have recorded (state and energies at the beginning of every step):
         ``{"q": (nsteps,B,nq), "dq": (nsteps,B,ndof), "energy": (nsteps,B,2)}``."""
@@ -184,7 +196,7 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
             flags |= _capi.ARB_STEP_FUSED
-        flags |= self._split_flag(split)
+        flags |= self._split_flag(split) | self._waves_flag(waves)
         out = {}
         log = _capi.RolloutLog()
         if log_state:

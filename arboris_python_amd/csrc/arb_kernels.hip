@@ -42,14 +42,29 @@
 #include "arb_math.h"
 
 #define WAVE 64
-#ifndef ARB_WAVES_PER_EU
-#define ARB_WAVES_PER_EU 2      // 2nd __launch_bounds__ argument: min waves per SIMD (caps VGPRs at 256)
+// 2nd __launch_bounds__ argument of the step kernels: minimum waves per SIMD = the VGPR budget (512 / waves).
+// Round 3: the float32 production kernels with one register column set are compiled for THREE waves per SIMD (168
+// VGPRs) now that a human36 world needs 13.1 KB of LDS instead of 19.4 (twelve wavefronts per CU): the kernel is
+// latency-bound -- measured with ARB_LDS_PAD: 4 / 6 / 7 / 8 waves per CU give 10.3 / 13.8 / 15.5 / 17.1 M
+// world-steps/s -- and a third wave per SIMD pays for the ~500 register spills it costs (none of them in a loop):
+// +5.5 % at 4096 worlds, +7.5 % at 65536 (same box, twice).  Two column sets (8 contacts: 26 KB of LDS, six waves
+// per CU whatever the register budget) and float64 stay at two; the float64 64-row tile at one (see the kernel).
+// Both builds of those kernels are in the library (template parameter CM = 2: three waves) and the host picks per
+// launch: a wave of the three-wave build is ~10 % slower (spills), so it only pays when the batch fills the extra
+// wave slots -- 1024 worlds without contacts (BASELINE config 2, one wave per world): 25.9 M at two waves, 18.7 M at three.
+#ifdef ARB_WAVES_PER_EU
+#define ARB_WAVES(CM) ARB_WAVES_PER_EU
+#else
+#define ARB_WAVES(CM) ((CM) == 2 ? 3 : 2)
 #endif
 #ifndef GS_SWEEPS
 #define GS_SWEEPS 20            // core.py:929-931 (overridable only for timing experiments: the reference's count is 20)
 #endif
 #ifndef ARB_PHASE_D_MFMA
 #define ARB_PHASE_D_MFMA 1      // float32: the constraint-space products J' [Y rhs | Y J'^T] on the matrix cores (0: vector ALU)
+#endif
+#ifndef ARB_ROWS_SPLIT
+#define ARB_ROWS_SPLIT 1
 #endif
 #ifndef ARB_GS_PRIO
 #define ARB_GS_PRIO 2           // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
@@ -97,7 +112,8 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
 // (A: 36 values, then M | rhs: 27 (33)) so that the table is no larger than the X | P | R vectors that take its place
 // afterwards (round 3: 2380 -> 1292 float32 words for human36, one of the three changes that bring the wave's LDS
 // from 19.4 KB to 13.1 KB = twelve waves per CU).  304 B rows.
-#define TB_STRIDE 38
+#define TB_STRIDE 38      // two-pass table (the three-wave kernels)
+#define TB_STRIDE1 70     // single-pass table (the two-wave kernels: 560 B rows, bank-conflict free)
 #define TB_PASS1 36
 
 // exact (bit pattern) equality, also true for identical NaNs
@@ -115,6 +131,7 @@ struct DevModel {
     int has_visc, has_pd, has_warm, has_grav;
     int *status;     // host-visible word (mapped pinned memory) that a launch raises when it gives up waiting in the work queue
     Layout lay;      // LDS offsets of this precision's kernels: re-read per phase instead of held in SGPRs for the whole launch
+    Layout lay3;     // ... of the three-wave kernels (two-pass prefix table: a smaller bd region)
     double up[3];
     T grav[3];
     const T *pd_kp, *pd_kd, *pd_tau0;         // [n][n], [n][n], [n] (merged PD controllers; rarely present)
@@ -602,18 +619,20 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 // execution) -- those arguments are compiled out, which keeps their kernargs and the predicates derived from them
 // out of the SGPR file; bit 0 = user torques (ext_gforce: the MPC rollouts' input, one extra load per item);
 // bit 1 = every other optional input (per-world PD, logs, split execution, per-step dt, flags); 3 = all of them.
-// CM 1 = phase C eliminates on the matrix cores (float32 only; ARB_STEP_MFMA_ELIM), 0 = on the vector ALU.
+// CM 1 = phase C eliminates on the matrix cores (float32 only; ARB_STEP_MFMA_ELIM), 0 = on the vector ALU;
+// CM 2 = as 0, compiled for three waves per SIMD (float32, one column set, tiles up to 48 rows; see ARB_WAVES).
 // (float64 worlds on the 64-row tile -- snake-64 -- need 43 KB of LDS per wave: three waves per CU, less than one per
 // SIMD, so their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
-__global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVES_PER_EU) void arb_step_kernel(
+__global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVES(CM)) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
     T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
     const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail, int queue_spin_cap)
 {
     static_assert(MODE == 0 || FEAT == 3, "the inspect kernels take every input");
-    static_assert(CM == 0 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
+    static_assert(CM != 1 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
+    static_assert(CM != 2 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && std::is_same<T, float>::value), "three-wave build: float32, one column set");
     constexpr bool FEAT_EXT = (FEAT & 1) != 0, FEAT_ALL = (FEAT & 2) != 0;
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
     const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
@@ -699,7 +718,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 // (after the first global store the compiler no longer proves the model unclobbered and fetches it with vector
 // loads: readfirstlane puts the wave-uniform values back into SGPRs)
 #define ARB_UNI(x) __builtin_amdgcn_readfirstlane(x)
-#define ARB_LDS_POINTERS() do { const Layout &lay_ = mp->lay;                                                              \
+#define ARB_LDS_POINTERS() do { const Layout &lay_ = (CM == 2) ? mp->lay3 : mp->lay;                                                              \
         qs = lds + ARB_UNI(lay_.q); dqs = lds + ARB_UNI(lay_.dq); qd = lds + ARB_UNI(lay_.qd); BD = lds + ARB_UNI(lay_.bd); SC = lds + ARB_UNI(lay_.sc);               \
         PD = reinterpret_cast<double *>(lds + ARB_UNI(lay_.pd)); CD = lds + ARB_UNI(lay_.cd); RT = lds + ARB_UNI(lay_.rt); AM = lds + ARB_UNI(lay_.am);       \
         VV = lds + ARB_UNI(lay_.vv); FF = lds + ARB_UNI(lay_.ff); FF0 = lds + ARB_UNI(lay_.ff0); WORK = lds + ARB_UNI(lay_.work);                             \
@@ -1214,7 +1233,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             }
             // Small trees: the body lanes write the M | rhs part of their accumulators straight into the prefix table,
             // which takes the place of the per-body blocks: every lane has its own block in registers by now.
-            const bool use_table = LSCAN_OK && mp->lay.lscan;
+            // (the three-wave kernels pass the accumulators through a half-size table in two passes -- less LDS, more
+            // registers held across the first pass --, the two-wave kernels through a full table in one)
+            constexpr bool TWO_PASS = (CM == 2);
+            constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
+            const bool lscan = LSCAN_OK && mp->lay.lscan;
+            const bool use_table = lscan && TWO_PASS;
             WAVE_SYNC();
             // ---- lane = body: world-frame matrices of the body -----------------------------------
             if (lane < nb) {
@@ -1292,7 +1316,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 };
                 if (use_table) {
                     typedef double D2 __attribute__((ext_vector_type(2)));
-                    D2 *row = reinterpret_cast<D2 *>(STG + TB_STRIDE * b);
+                    D2 *row = reinterpret_cast<D2 *>(STG + TBS * b);
 #pragma unroll
                     for (int i2 = 0; i2 < (NACC - TB_PASS1 + 1) / 2; ++i2) { D2 v; v.x = mr_at(2 * i2); v.y = mr_at(2 * i2 + 1); row[i2] = v; }
                 }
@@ -1338,7 +1362,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 double *TB = STG;
                 if (!written) {
                     if (lane < nb) {
-                        D2 *row = reinterpret_cast<D2 *>(TB + TB_STRIDE * lane);
+                        D2 *row = reinterpret_cast<D2 *>(TB + TBS * lane);
 #pragma unroll
                         for (int i2 = 0; i2 < (CNT + 1) / 2; ++i2) {
                             D2 v; v.x = Acc[OFF + 2 * i2]; v.y = (2 * i2 + 1 < CNT) ? Acc[OFF + 2 * i2 + 1] : 0.;
@@ -1351,14 +1375,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     double run = 0.;
                     double *col = TB + i;
                     for (int b0 = 0; b0 < nb; b0 += 4) {              // four bodies per round trip
-                        const double v0 = col[TB_STRIDE * b0];
-                        const double v1 = (b0 + 1 < nb) ? col[TB_STRIDE * (b0 + 1)] : 0.;
-                        const double v2 = (b0 + 2 < nb) ? col[TB_STRIDE * (b0 + 2)] : 0.;
-                        const double v3 = (b0 + 3 < nb) ? col[TB_STRIDE * (b0 + 3)] : 0.;
-                        run += v0; col[TB_STRIDE * b0] = run;
-                        run += v1; if (b0 + 1 < nb) col[TB_STRIDE * (b0 + 1)] = run;
-                        run += v2; if (b0 + 2 < nb) col[TB_STRIDE * (b0 + 2)] = run;
-                        run += v3; if (b0 + 3 < nb) col[TB_STRIDE * (b0 + 3)] = run;
+                        const double v0 = col[TBS * b0];
+                        const double v1 = (b0 + 1 < nb) ? col[TBS * (b0 + 1)] : 0.;
+                        const double v2 = (b0 + 2 < nb) ? col[TBS * (b0 + 2)] : 0.;
+                        const double v3 = (b0 + 3 < nb) ? col[TBS * (b0 + 3)] : 0.;
+                        run += v0; col[TBS * b0] = run;
+                        run += v1; if (b0 + 1 < nb) col[TBS * (b0 + 1)] = run;
+                        run += v2; if (b0 + 2 < nb) col[TBS * (b0 + 2)] = run;
+                        run += v3; if (b0 + 3 < nb) col[TBS * (b0 + 3)] = run;
                     }
                 }
                 WAVE_SYNC();
@@ -1374,7 +1398,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 // dof lanes (lane k takes the composite of body(k)), so that only one element is in flight.
                 const bool two_rows = nb > 16, four_rows = nb > 32;
                 const int hi = (lane < nb) ? lane + mp->subsize[lane] - 1 : lane;
-                if (LSCAN_OK && mp->lay.lscan) {
+                if (lscan) {
                     // Small trees (the table fits the staging area): the same inclusive prefix sums, formed in LDS with
                     // the roles transposed -- lane = accumulator, a serial pass over the bodies: nb additions in all
                     // instead of 4-6 DPP steps + two lane exchanges per accumulator (~210 instead of ~1700 wave
@@ -1384,7 +1408,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     // first pass: M | rhs, whose rows the body lanes have written already (the pass over the 36 entries of
                     // A, still in registers, runs inside the consumer below once the first has been consumed: the table is
                     // half as large that way, and the body block never holds more than A and Mg in registers)
-                    tb_pass(std::integral_constant<int, TB_PASS1>{}, std::integral_constant<int, NACC - TB_PASS1>{}, true);
+                    if constexpr (TWO_PASS) tb_pass(std::integral_constant<int, TB_PASS1>{}, std::integral_constant<int, NACC - TB_PASS1>{}, true);
+                    else tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NACC>{}, false);
                     // (c) happens in the consumer below, which streams the two table rows of body(k) straight
                     // into its products: the 63 composites never sit in registers all at once
                 } else {
@@ -1458,13 +1483,26 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         rg += Xk[i - (NACC - 6)] * e;
                     }
                 };
-                if (LSCAN_OK && mp->lay.lscan) {
+                if (lscan && !TWO_PASS) {
                     typedef double D2 __attribute__((ext_vector_type(2)));
                     const int a = bsrc, top = a + mp->subsize[a] - 1;
-                    const D2 *ph = reinterpret_cast<const D2 *>(STG + TB_STRIDE * top);
-                    const D2 *pl = reinterpret_cast<const D2 *>(STG + TB_STRIDE * (a > 0 ? a - 1 : 0));
+                    const D2 *ph = reinterpret_cast<const D2 *>(STG + TBS * top);
+                    const D2 *pl = reinterpret_cast<const D2 *>(STG + TBS * (a > 0 ? a - 1 : 0));
                     const double keep = a > 0 ? 1. : 0.;
-                    static_assert(TB_PASS1 % 2 == 0 && NACC - TB_PASS1 <= TB_STRIDE, "prefix table passes");
+                    static_for_asc(std::make_integer_sequence<int, (NACC + 1) / 2>{}, [&](auto i2c) {
+                        constexpr int i2 = decltype(i2c)::value;
+                        const D2 h = ph[i2], l = pl[i2];
+                        visit(std::integral_constant<int, 2 * i2>{}, h.x - keep * l.x);
+                        if constexpr (2 * i2 + 1 < NACC) visit(std::integral_constant<int, 2 * i2 + 1>{}, h.y - keep * l.y);
+                        if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
+                    });
+                } else if (lscan) {
+                    typedef double D2 __attribute__((ext_vector_type(2)));
+                    const int a = bsrc, top = a + mp->subsize[a] - 1;
+                    const D2 *ph = reinterpret_cast<const D2 *>(STG + TBS * top);
+                    const D2 *pl = reinterpret_cast<const D2 *>(STG + TBS * (a > 0 ? a - 1 : 0));
+                    const double keep = a > 0 ? 1. : 0.;
+                    static_assert(TB_PASS1 % 2 == 0 && NACC - TB_PASS1 <= TB_STRIDE && NACC <= TB_STRIDE1, "prefix table passes");
                     // (the accumulators of the two passes are disjoint -- R, M dX', rhs from M | rhs; G, P from A -- so the
                     // order of the passes does not change a bit of the results)
                     static_for_asc(std::make_integer_sequence<int, (NACC - TB_PASS1 + 1) / 2>{}, [&](auto i2c) {
@@ -1510,6 +1548,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 const unsigned long long rel = (lane < n) ? (mp->upmask[lane] | mp->descmask[lane]) : 0ull;
                 const unsigned rel_lo = (unsigned)rel, rel_hi = (unsigned)(rel >> 32);
                 const int e_k = (lane < n) ? (mp->dof_off[bsrc] + mp->jnd[bsrc] - 1) : -1;
+#if ARB_ROWS_SPLIT
+                // Live ranges split by hand: the 18 float64 operands of the rows below become new values here, defined
+                // right in front of their 44 x 18 uses.  (Compiled for three waves per SIMD the register allocator had
+                // spilled six of them at their definition, far above, and reloaded them in every row: 265 scratch loads
+                // per step, each waited for.)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(Gk[i]), "+v"(Xk[i]), "+v"(dXk[i]));
+#endif
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i) {
                     // (the wave-uniform branch per row also keeps the rows apart for the scheduler: as one
@@ -2232,6 +2278,11 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1, 3, 0>(ARB_LAUNCH_ONE_AR
 #if ARB_PART_IS_FLOAT
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#if ARB_PART_NMAX <= 48
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#endif
 #endif
 #else
 #if defined(ARB_SPLIT_BUILD)
@@ -2249,6 +2300,12 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 3, 1>(ARB_LAUNCH_ONE_AR
     extern template int launch_one<float, NM, 2, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(float));
 ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_TILE_CM(48) ARB_EXTERN_TILE_CM(64)
 #undef ARB_EXTERN_TILE_CM
+#define ARB_EXTERN_TILE_W3(NM)                                                          \
+    extern template int launch_one<float, NM, 1, 0, 0, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 1, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));
+ARB_EXTERN_TILE_W3(16) ARB_EXTERN_TILE_W3(32) ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
+#undef ARB_EXTERN_TILE_W3
 ARB_EXTERN_TILE(float, 16) ARB_EXTERN_TILE(float, 32) ARB_EXTERN_TILE(float, 44) ARB_EXTERN_TILE(float, 48) ARB_EXTERN_TILE(float, 64)
 ARB_EXTERN_TILE(double, 16) ARB_EXTERN_TILE(double, 32) ARB_EXTERN_TILE(double, 44) ARB_EXTERN_TILE(double, 48) ARB_EXTERN_TILE(double, 64)
 #undef ARB_EXTERN_TILE
@@ -2284,7 +2341,7 @@ struct arb_model {
     DevModel<float> *df_dev;
     DevModel<double> *dd_dev;
     int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
-    Layout lf, ld;
+    Layout lf, lf3, ld;            // LDS layouts: float32 two-wave kernels, float32 three-wave kernels, float64
 };
 
 // ARB_ERR_STALLED when an earlier launch of the handle raised the status word (host memory: no synchronisation)
@@ -2331,20 +2388,20 @@ static std::vector<double> h12(const double *H16, int count) {
 // (round 3: SC and AM had regions of their own and the prefix table was 70 float64 wide: 19.4 KB per human36 world;
 // 13.1 KB now, which lets twelve wavefronts share a CU's LDS instead of eight)
 static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
-static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double) {
+static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass) {
     auto al = [](int x) { return (x + 3) & ~3; };
-    const int tb = lds_scan(nb, rs) ? al(nb * TB_STRIDE * elems_per_double) : 0;
+    const int tb = lds_scan(nb, rs) ? al(nb * (two_pass ? TB_STRIDE : TB_STRIDE1) * elems_per_double) : 0;
     return std::max(std::max(std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double)), tb), al(std::max(ndol * ndol, 4)));
 }
 
-static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems) {
+static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems, bool two_pass = false) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
     L.q = o; o += al(nq);
     L.dq = o; o += WAVE;
     L.qd = o; o += WAVE;
-    L.bd = o; L.am = o; o += bd_region_elems(nb, rs, ndol, elems_per_double);
+    L.bd = o; L.am = o; o += bd_region_elems(nb, rs, ndol, elems_per_double, two_pass);
     L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
     L.rt = o; L.sc = o; o += std::max(1 + ndol, 12) * rs;
     L.cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
@@ -2607,7 +2664,8 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     }
     int tot;
     M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
-    M->ld = M->dd.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
+    M->lf3 = M->df.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true);
+    M->ld = M->dd.lay = M->dd.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     {
         // one blob per precision
@@ -2660,10 +2718,35 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // the plain step (FEAT 0): nothing but the state and the constraint forces; FEAT 1: + user torques (MPC rollouts)
     const bool noopt = MODE == 0 && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
                        logo.dq == nullptr && logo.energy == nullptr && sio.mode == 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS) && dts == nullptr;
+    // (the kernels only look at ARB_STEP_SKIP_CONSTRAINTS; the other flags are for the host)
     const bool plain = noopt && ext == nullptr;
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
-#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
+    // Two or three waves per SIMD (float32 production kernels with one column set, see ARB_WAVES)?  Three when the
+    // batch fills the extra wave slots -- by the batch size ALONE, so that every launch shape of a batch (one launch or
+    // one per step, logs, torques) runs the same build and gives the same bits; ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin
+    // the build (runs of different batch sizes that must agree bit for bit); ARB_FORCE_WAVES=2|3 in the environment
+    // overrides both (development).
+    bool w3 = false;
+    if (MODE == 0 && std::is_same<T, float>::value && M->nsets == 1 && M->nmax <= 48 && !mfma) {
+        static thread_local int cus_dev = -1, cus = 0;
+        if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
+        const long pad = std::max(0, env_int("ARB_LDS_PAD", 0));
+        const long lds2 = (long)L.total * (long)sizeof(T) + pad, lds3 = (long)M->lf3.total * (long)sizeof(T) + pad;
+        const long s2 = (long)cus * std::min(8l, (160 * 1024) / lds2), s3 = (long)cus * std::min(12l, (160 * 1024) / lds3);
+        if (s3 > s2 && s2 > 0) {
+            // measured (human36 + 4 contacts, M world-steps/s, two / three waves): 2048 worlds 14.6 / 13.4, 2560: 16.6 / 13.8,
+            // 3072: 16.7 / 11.6, 4096: 17.1 / 18.0, 6144: 17.6 / 18.7, 65536: 18.4 / 19.8
+            // (one launch per step, 4096 worlds: 10.4 / 9.7 -- two rounds of workgroups either way --; 6144: 12.2 / 12.1)
+            w3 = 3 * nw >= 4 * s3;
+            if (flags & ARB_STEP_WAVES2) w3 = false;
+            if (flags & ARB_STEP_WAVES3) w3 = true;
+        }
+        const int force = env_int("ARB_FORCE_WAVES", 0);
+        if (force == 2) w3 = false;
+        if (force == 3) w3 = true;
+    }
+#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 2 ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
@@ -2671,6 +2754,8 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     if constexpr (std::is_same<T, float>::value) {
         if (M->nmax == 44 && M->nsets == 1) {
             if constexpr (MODE == 0) {
+                if (w3 && plain) return ONE_(44, 1, 0, 2);
+                if (w3 && noopt) return ONE_(44, 1, 1, 2);
                 if (plain) return ONE(44, 1, 0);
                 if (noopt) return ONE(44, 1, 1);
 #if ARB_QUICK >= 2
@@ -2694,6 +2779,9 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     case NM:                                                                                           \
         if constexpr (MODE == 0 && std::is_same<T, float>::value) {                                    \
             if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 3, 1) : ONE_(NM, 1, 3, 1);                  \
+        }                                                                                              \
+        if constexpr (MODE == 0 && std::is_same<T, float>::value && NM <= 48) {                        \
+            if (w3) return plain ? ONE_(NM, 1, 0, 2) : noopt ? ONE_(NM, 1, 1, 2) : ONE_(NM, 1, 3, 2);  \
         }                                                                                              \
         if constexpr (MODE == 0) {                                                                     \
             if (plain) return (M->nsets == 2) ? ONE(NM, 2, 0) : ONE(NM, 1, 0);                         \

@@ -148,7 +148,7 @@ def test_unknown_flags_are_refused():
     q, dq = synth.standing_states(m, 4, seed=2)
     tq, tdq = bw.to_device(q, dq, torch.float32)
     before = tq.clone()
-    for bad in (4, 64, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel)
+    for bad in (4, 256, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel)
         rc = bw._lib.arb_step(bw._handle, _capi.ARB_F32, tq.data_ptr(), tdq.data_ptr(), None, None, 4, 5e-3, 1, bad, None)
         assert rc == 1
     with pytest.raises(ValueError):
@@ -223,7 +223,7 @@ q, dq = synth.world_states(m, range(lo, hi), "standing", 77, drop=0.03, vel=0.1)
 tq, tdq = bw.to_device(q, dq, torch.float32)
 cf = bw.new_cforce(hi - lo, torch.float32)
 dist.barrier()
-bw.step(tq, tdq, 5e-3, T, cforce=cf)
+bw.step(tq, tdq, 5e-3, T, cforce=cf, waves=3)      # the kernel build the unsharded batch runs (picked by batch size)
 torch.cuda.synchronize()
 bw.status()
 q_all, dq_all = gather_state(tq.cpu(), tdq.cpu(), B, dist)     # gloo: the collective runs on host copies
@@ -251,7 +251,7 @@ def test_two_process_shards_equal_unsharded_bitwise(tmp_path):
     bw = BatchedWorlds(m)
     q, dq = synth.world_states(m, range(B), "standing", 77, drop=0.03, vel=0.1)
     tq, tdq = bw.to_device(q, dq, torch.float32)
-    bw.step(tq, tdq, 5e-3, T, cforce=bw.new_cforce(B, torch.float32))
+    bw.step(tq, tdq, 5e-3, T, cforce=bw.new_cforce(B, torch.float32), waves=3)
     torch.cuda.synchronize()
     assert g["q"].shape == (B, m.nq) and g["dq"].shape == (B, m.ndof)
     assert np.array_equal(g["q"], tq.cpu().numpy()) and np.array_equal(g["dq"], tdq.cpu().numpy())
@@ -261,13 +261,14 @@ def test_two_process_shards_equal_unsharded_bitwise(tmp_path):
     for r in range(3):
         lo, hi = __import__("arboris_python_amd.dist", fromlist=["shard_bounds"]).shard_bounds(B, r, 3)
         sq, sdq = bw.to_device(q[lo:hi], dq[lo:hi], torch.float32)
+        scf = bw.new_cforce(hi - lo, torch.float32)
         st = torch.cuda.Stream(device=bw.device)
-        st.wait_stream(torch.cuda.current_stream(bw.device))
-        bw.step(sq, sdq, 5e-3, T, cforce=bw.new_cforce(hi - lo, torch.float32), stream=st)
-        parts_q.append((sq, st))
-    for _, st in parts_q:
-        st.synchronize()
-    assert torch.equal(torch.cat([p for p, _ in parts_q]), tq)
+        st.wait_stream(torch.cuda.current_stream(bw.device))      # uploads and the zero fill are done before the shard runs
+        bw.step(sq, sdq, 5e-3, T, cforce=scf, stream=st, waves=3)
+        parts_q.append((sq, st, sdq, scf))
+    for p in parts_q:
+        p[1].synchronize()
+    assert torch.equal(torch.cat([p[0] for p in parts_q]), tq)
     bw.close()
 
 
