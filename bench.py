@@ -443,13 +443,20 @@ def main():
                 # ARB_QUEUE_TAIL defaults 4 / 4): chunks of 4 steps, then the last 4 steps one by one
                 chunk_, tail_ = int(os.environ.get("ARB_QUEUE_CHUNK", "4")), min(int(os.environ.get("ARB_QUEUE_TAIL", "4")), EP - 1)
                 items_ = (-(-(EP - tail_) // chunk_) + tail_) if chunk_ > 0 else 1
+                handover = items_ * bytes_per_world_step * B
                 res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
                                                    "(profiles/%s); 4 B/lane accesses, reported uncorrected.  With the work queue the "
                                                    "state of every world is handed from wavefront to wavefront %d times per "
-                                                   "%d-step episode (%d x %d B x worlds = %.1f MB of the figure): that, not re-reads, "
-                                                   "is the excess over the algorithmic bytes"
-                                                   % (os.path.basename(prof), items_, EP, items_, bytes_per_world_step,
-                                                      items_ * bytes_per_world_step * B / 1e6))
+                                                   "%d-step episode (%d x %d B x worlds = %.1f MB of the figure)."
+                                                   % (os.path.basename(prof), items_, EP, items_, bytes_per_world_step, handover / 1e6))
+                if res["roofline"]["traffic"] > 20 * handover:
+                    res["roofline"]["traffic_note"] += (
+                        "  The rest is SCRATCH traffic: at this batch size the library runs the kernel build compiled for three "
+                        "waves per SIMD (168 VGPRs, ~500 spilled registers, none in a loop), whose spill stores and reloads go "
+                        "through the memory hierarchy (%.0f GB/s of the 8000 GB/s roof at this launch duration) -- the price of the "
+                        "third wave, which pays +5.5 %% end to end on this latency-bound kernel (DESIGN.md 3); the two-wave "
+                        "build (ARB_STEP_WAVES2) moves %.1f MB per launch"
+                        % (res["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9, (handover + bytes_per_world_step * B) / 1e6))
                 ws = float(B * EP)
                 simds, clk = 1024, 2.4e9                     # 256 CUs x 4 SIMD-32; peak shader clock
                 valu = {
