@@ -55,7 +55,7 @@ class ModelInfo(C.Structure):
 
 
 INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
-                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps", "gs_trace"]
+                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps", "gs_trace", "c_adm", "c_vel"]
 
 
 class RolloutLog(C.Structure):

@@ -241,7 +241,7 @@ class BatchedWorlds(object):
                       vel_free=(B, n), c_sdist=(B, nc), c_active=(B, nc), c_jac=(B, nc, 4, n),
                       c_force=(B, nc, 4), c_frame=(B, nc, 2, 4, 4), gforce=(B, n),
                       q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 5), stamps=(B, 8), energy=(B, 2),
-                      gs_trace=(B, 20, nc))
+                      gs_trace=(B, 20, nc), c_adm=(B, 4 * nc, 4 * nc), c_vel=(B, 4 * nc))
         want = list(want)
         if "gforce" in want and nc and "c_jac" not in want:
             want.append("c_jac")

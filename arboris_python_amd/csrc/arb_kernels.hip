@@ -63,6 +63,9 @@
 #ifndef ARB_PHASE_D_MFMA
 #define ARB_PHASE_D_MFMA 1      // float32: the constraint-space products J' [Y rhs | Y J'^T] on the matrix cores (0: vector ALU)
 #endif
+#ifndef ARB_GS_F64
+#define ARB_GS_F64 0            // 1: the Gauss-Seidel sweeps of float32 worlds in float64 arithmetic (measured, not the default: DESIGN.md 2)
+#endif
 #ifndef ARB_ROWS_SPLIT
 #define ARB_ROWS_SPLIT 1
 #endif
@@ -189,6 +192,7 @@ struct DebugOut {
     long long *stamps;  // [nw][8] s_memtime at the phase boundaries (diagnostic)
     int ablate;         // diagnostic (env ARB_ABLATE, inspect only): bit 3 (8) = run all 20 Gauss-Seidel sweeps, no fixed-point exit
     int *gs_stats;      // [nw][5]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts, sweeps
+    T *c_adm, *c_vel;   // [nw][ndol][ndol], [nw][ndol]: the constraint-space system Y' = J' Y J'^T, v' the sweeps start from
     int *gs_trace;      // [nw][GS_SWEEPS][nc]: decision of every solve (0 release, 1 static, 2 sliding fast shift,
                         // 3 sliding eig6, 4 other constraint types); entries of solves not executed are left alone
 };
@@ -300,14 +304,18 @@ extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 // In LDS: AM = Y' (ndol x ndol), CD = per-constraint block (active, sdist, pos0 in; inverse block out),
 // VV = v' (in/out), FF = constraint forces (in: warm start, out), WORK = 64 elements of scratch.
 // ===========================================================================
-template <typename T, int MODE>
-__device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt,
-                                         const T inv_dt, const T *AM, T *CD, T *VV, T *FF, T *WORK,
+// G = the arithmetic type of the sweeps (round 3 experiment, -DARB_GS_F64: float32 worlds whose sweeps -- velocities, forces,
+// the two decision inequalities, the (pseudo-)inverse blocks -- run in float64 on the float32 system Y', v'; G = T otherwise)
+template <typename T, int MODE, typename G = T>
+__device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt_t,
+                                         const T inv_dt_t, const T *AM, T *CD, T *VV, T *FF, T *WORK,
                                          const DebugOut<T> &dbg, const long w) {
+    constexpr bool SAME = std::is_same<T, G>::value;
+    const G dt = (G)dt_t, inv_dt = SAME ? (G)inv_dt_t : G(1) / (G)dt_t;
     // (pseudo-)inverse of every active constraint's own admittance block (once per step): pinv(Y_cc) of
     // constraints.py:79, 83, 235, 795.  Pivoted elimination for the regular blocks, all constraints side by side;
     // the blocks it reports as rank deficient are redone one after the other with the SVD-based pinv_block.
-    {
+    if constexpr (SAME) {
         bool deficient = false;
         if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
             const int c = lane, ct = mp->ctype[c];
@@ -340,16 +348,16 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     // ballots); v_readlane broadcasts through SGPRs are left for what every row needs,
     // the four force increments.  Lane c also keeps the flags of constraint c.  The 20 x nc
     // sequential solves touch LDS only to read their column block of Y' (read-only).
-    T vr = T(0), fr = T(0), Yrow[4], Prow[4];
-    T k_sd = T(0), k_mu = T(0), k_e0 = T(1), k_e1 = T(1), k_e2 = T(1), k_p0 = T(0), k_p1 = T(0), k_p2 = T(0);
+    G vr = G(0), fr = G(0), Yrow[4], Prow[4];
+    G k_sd = G(0), k_mu = G(0), k_e0 = G(1), k_e1 = G(1), k_e2 = G(1), k_p0 = G(0), k_p1 = G(0), k_p2 = G(0);
     bool k_eps1 = false;
     int k_ct = 0;
     bool k_act = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { Yrow[i] = T(0); Prow[i] = T(0); }
+    for (int i = 0; i < 4; ++i) { Yrow[i] = G(0); Prow[i] = G(0); }
     // the constants of a row's own constraint, replicated on the four lanes of its quad
-    T q_sd = T(0), q_sdt = T(0), q_mu = T(0);
-    T q_iyn = T(0), q_muyn = T(0), q_yc0 = T(0), q_yc1 = T(0), q_yc2 = T(0), q_bsq = T(0);
+    G q_sd = G(0), q_sdt = G(0), q_mu = G(0);
+    G q_iyn = G(0), q_muyn = G(0), q_yc0 = G(0), q_yc1 = G(0), q_yc2 = G(0), q_bsq = G(0);
     SlidePre q_sp = {0., 0., 0., 0., 0., 0.};
     double q_warm = NAN;                    // root found for this constraint in the previous sweep
     double q_wmove = NAN;                   // how far that root had moved from the sweep before
@@ -359,37 +367,53 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             Yrow[i] = AM[lane * ndol + 4 * cc + i];
-            Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
+            if constexpr (SAME) Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
+        }
+        if constexpr (!SAME) {
+            // the (pseudo-)inverse of the row's own constraint block in the arithmetic of the sweeps, by every row lane
+            // for itself (the four lanes of a quad do the same work side by side: no hand-over through LDS)
+            if (CD[cc * CD_STRIDE + CD_ACTIVE] != T(0)) {
+                const int ct = mp->ctype[cc];
+                const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                G Yb[16], P[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Yb[4 * i + j] = (G)AM[(4 * cc + i) * ndol + 4 * cc + j];
+                if (!inv_block<G, T>(Yb, 4, nd, P)) pinv_block<G, T>(Yb, 4, nd, P);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Prow[i] = (rr == 0) ? P[i] : (rr == 1) ? P[4 + i] : (rr == 2) ? P[8 + i] : P[12 + i];
+            }
         }
         q_sd = CD[cc * CD_STRIDE + CD_SDIST]; q_sdt = q_sd / dt; q_mu = mp->cmu[cc];
-        if (CD[cc * CD_STRIDE + CD_ACTIVE] != T(0) && mp->ctype[cc] == ARB_CT_SOFTFINGER) {
+        if (CD[cc * CD_STRIDE + CD_ACTIVE] != G(0) && mp->ctype[cc] == ARB_CT_SOFTFINGER) {
             // admittance-only part of the sliding-branch polynomial and the other per-step constants of
             // SoftFingerContact.solve (constraints.py:795, 808-812), once per step
-            T Yc4[16];
+            G Yc4[16];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * ndol + 4 * cc + j];
-            q_sp = slide_precompute<T>(Yc4);
-            q_iyn = T(1) / Yc4[15]; q_muyn = q_mu / Yc4[15];
+            q_sp = slide_precompute<G>(Yc4);
+            q_iyn = G(1) / Yc4[15]; q_muyn = q_mu / Yc4[15];
             q_yc0 = Yc4[3]; q_yc1 = Yc4[7]; q_yc2 = Yc4[11];
-            const T bq0 = q_muyn * q_yc0, bq1 = q_muyn * q_yc1, bq2 = q_muyn * q_yc2;
+            const G bq0 = q_muyn * q_yc0, bq1 = q_muyn * q_yc1, bq2 = q_muyn * q_yc2;
             q_bsq = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
         }
     }
     if (lane < nc) {
         const T *cd = CD + lane * CD_STRIDE;
-        k_act = cd[CD_ACTIVE] != T(0);
+        k_act = cd[CD_ACTIVE] != G(0);
         k_sd = cd[CD_SDIST]; k_p0 = cd[CD_POS0]; k_p1 = cd[CD_POS0 + 1]; k_p2 = cd[CD_POS0 + 2];
         k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
         k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
-        k_eps1 = k_act && k_ct == ARB_CT_SOFTFINGER && (k_e0 == T(1)) && (k_e1 == T(1)) && (k_e2 == T(1));
+        k_eps1 = k_act && k_ct == ARB_CT_SOFTFINGER && (k_e0 == G(1)) && (k_e1 == G(1)) && (k_e2 == G(1));
     }
     const unsigned long long actmask = __ballot(k_act);
     const unsigned long long eps1mask = __ballot(k_eps1);
     int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
     int tr_rel = 0, tr_sta = 0, tr_slow = 0;
-    T vr_prev = vr, fr_prev = fr;
+    G vr_prev = vr, fr_prev = fr;
 #ifdef ARB_GSSTAMPS   /* development: cycles of the segments of a sliding solve, summed over the step's sliding solves */
     long long gst[6] = {0, 0, 0, 0, 0, 0}, gt0 = 0, gt1 = 0, gt2 = 0, gt3 = 0, gt4 = 0;
     int gprobe[2] = {0, 0};
@@ -410,21 +434,21 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             const int base = 4 * c;
             ARB_GST(gt0);
             // column block Y'[:, 4c..4c+3] of this lane's row (issued early, used last)
-            T a4[4] = {T(0), T(0), T(0), T(0)};
+            G a4[4] = {G(0), G(0), G(0), G(0)};
             if (lane < ndol) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a4[i] = AM[lane * ndol + base + i];
             }
             const int ct = __builtin_amdgcn_readlane(k_ct, c);
-            T vc[4], fc[4], df[4], fnew[4];
+            G vc[4], fc[4], df[4], fnew[4];
             // A constraint's four rows are one quad of lanes: what its local solve needs from its own
             // rows comes as DPP quad_perm operands (every quad evaluates ITS constraint; only the quad of
             // c is used).  Values go through SGPRs (v_readlane) only where the whole wave needs them.
-            const T fq0 = quad_bcast<0>(fr), fq1 = quad_bcast<1>(fr), fq2 = quad_bcast<2>(fr), fq3 = quad_bcast<3>(fr);
+            const G fq0 = quad_bcast<0>(fr), fq1 = quad_bcast<1>(fr), fq2 = quad_bcast<2>(fr), fq3 = quad_bcast<3>(fr);
             // own-row products (meaningful on lanes base..base+3)
-            const T v0r = vr - (Yrow[0] * fq0 + Yrow[1] * fq1 + Yrow[2] * fq2 + Yrow[3] * fq3);
+            const G v0r = vr - (Yrow[0] * fq0 + Yrow[1] * fq1 + Yrow[2] * fq2 + Yrow[3] * fq3);
             bool quad_done = false;      // softfinger release / static: per-lane results, see below
-            T dfl = T(0), fnl = T(0);
+            G dfl = G(0), fnl = G(0);
             if (ct != ARB_CT_SOFTFINGER) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { vc[i] = bcast(vr, base + i); fc[i] = bcast(fr, base + i); }
@@ -433,13 +457,13 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                 // The release test and the static-friction candidate are evaluated side by side
                 // (two independent dependent chains that overlap in the pipeline), inside the quad.
                 const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
-                const T vq0 = quad_bcast<0>(vr), vq1 = quad_bcast<1>(vr), vq2 = quad_bcast<2>(vr), vq3 = quad_bcast<3>(vr);
-                const T dfr = -(Prow[0] * vq0 + Prow[1] * vq1 + Prow[2] * vq2 + Prow[3] * (vq3 + q_sdt));
-                const T fnr = fr + dfr;
-                const T v0n = quad_bcast<3>(v0r);
-                const T fn0 = quad_bcast<0>(fnr), fn1 = quad_bcast<1>(fnr), fn2 = quad_bcast<2>(fnr), fn3 = quad_bcast<3>(fnr);
-                T eps[3] = {T(1), T(1), T(1)};
-                T lhs;
+                const G vq0 = quad_bcast<0>(vr), vq1 = quad_bcast<1>(vr), vq2 = quad_bcast<2>(vr), vq3 = quad_bcast<3>(vr);
+                const G dfr = -(Prow[0] * vq0 + Prow[1] * vq1 + Prow[2] * vq2 + Prow[3] * (vq3 + q_sdt));
+                const G fnr = fr + dfr;
+                const G v0n = quad_bcast<3>(v0r);
+                const G fn0 = quad_bcast<0>(fnr), fn1 = quad_bcast<1>(fnr), fn2 = quad_bcast<2>(fnr), fn3 = quad_bcast<3>(fnr);
+                G eps[3] = {G(1), G(1), G(1)};
+                G lhs;
                 if (eps1) {
                     lhs = fn0 * fn0 + fn1 * fn1 + fn2 * fn2;
                 } else {
@@ -447,15 +471,15 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                     lhs = (fn0 / eps[0]) * (fn0 / eps[0]) + (fn1 / eps[1]) * (fn1 / eps[1])
                         + (fn2 / eps[2]) * (fn2 / eps[2]);
                 }
-                const T rhs = (fn3 * q_mu) * (fn3 * q_mu);
+                const G rhs = (fn3 * q_mu) * (fn3 * q_mu);
                 // the quad of c decides for the wave
-                const bool release = (__ballot(q_sd + dt * v0n > T(0)) >> base) & 1ull;
+                const bool release = (__ballot(q_sd + dt * v0n > G(0)) >> base) & 1ull;
                 const bool stat = (__ballot(lhs <= rhs) >> base) & 1ull;
                 if (release || stat) {
                     // release (zero force) or static friction (df exactly -pinv(Y)(...) as in the
                     // reference, row by row): one branch, the two outcomes by selection
                     if (MODE == 1) { if (release) ++st_rel; else ++st_sta; }
-                    dfl = release ? -fr : dfr; fnl = release ? T(0) : fnr; quad_done = true;
+                    dfl = release ? -fr : dfr; fnl = release ? G(0) : fnr; quad_done = true;
                 } else {
                     {                                              // sliding friction
                         // Also inside the quad: the four lanes of constraint c carry the live problem in
@@ -466,13 +490,13 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                         const int rq = lane - base;
                         const bool inquad = rq >= 0 && rq < 4;
                         const auto uni = [&](bool b) { return (bool)((__ballot(b) >> base) & 1ull); };
-                        T alpha[4], shift = T(0);
+                        G alpha[4], shift = G(0);
                         alpha[0] = quad_bcast<0>(v0r); alpha[1] = quad_bcast<1>(v0r); alpha[2] = quad_bcast<2>(v0r);
                         alpha[3] = v0n + q_sdt;
                         // the constraint's own 4x4 admittance block (wave-uniform LDS reads)
-                        T Y[16];
+                        G Y[16];
                         {
-                            typedef T Y4 __attribute__((ext_vector_type(4)));
+                            typedef T Y4 __attribute__((ext_vector_type(4)));      // (storage type)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const Y4 y4 = *reinterpret_cast<const Y4 *>(AM + (base + r) * ndol + base);
@@ -483,10 +507,10 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                         double warm = q_warm;
                         bool have = false;
                         if (eps1) {
-                            const T yc[3] = {q_yc0, q_yc1, q_yc2};
-                            const T bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
+                            const G yc[3] = {q_yc0, q_yc1, q_yc2};
+                            const G bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
                             double c1, kappa, root;
-                            slide_c1_kappa<T>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
+                            slide_c1_kappa<G>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
                             ARB_GST(gt2);
                             // The sweeps converge linearly: the root moves less and less from one sweep to the next.
                             // Float32 worlds restart the iteration twice the last move to the left of the previous
@@ -506,14 +530,14 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                                 if (inquad) q_wmove = fabs(root - warm);      // (NaN after a cold start)
                                 warm = root;
                                 // leftmost real eigenvalue; admissible when <= 0 (constraints.py:826-830)
-                                shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
+                                shift = (root <= 0.) ? (G)(root > -1e10 ? root : -1e10) : G(-1e10);
                                 have = true;
                             }
                         }
                         if (!have) {
                             if (MODE == 1) { ++st_slow; --st_fast; }
                             // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
-                            if (inquad) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
+                            if (inquad) softfinger_sliding_shift<G>(Y, alpha, q_mu, eps, WORK, &shift, false);
                             WAVE_SYNC();
                             if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
                             WAVE_SYNC();
@@ -525,12 +549,12 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                         if (inquad) q_warm = warm;          // next sweep restarts next to this root
                         ARB_GST(gt3);
                         fnew[0] = fq0; fnew[1] = fq1; fnew[2] = fq2; fnew[3] = fq3;
-                        T sie2[3] = {shift, shift, shift};
+                        G sie2[3] = {shift, shift, shift};
                         if (!eps1) {
 #pragma unroll
                             for (int i = 0; i < 3; ++i) sie2[i] = shift / (eps[i] * eps[i]);
                         }
-                        softfinger_slide_finish_scaled<T>(Y, alpha, sie2, fnew, df, uni);
+                        softfinger_slide_finish_scaled<G>(Y, alpha, sie2, fnew, df, uni);
                         ARB_GST(gt4);
 #ifdef ARB_GSSTAMPS
                         gslid = true;
@@ -541,23 +565,23 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                     }
                 }
             } else if (ct == ARB_CT_BALLSOCKET) {                  // constraints.py:235-237
-                const T p0 = bcast(k_p0, c), p1 = bcast(k_p1, c), p2 = bcast(k_p2, c);
-                const T dfr = -(Prow[0] * (vc[0] + p0 * inv_dt) + Prow[1] * (vc[1] + p1 * inv_dt)
+                const G p0 = bcast(k_p0, c), p1 = bcast(k_p1, c), p2 = bcast(k_p2, c);
+                const G dfr = -(Prow[0] * (vc[0] + p0 * inv_dt) + Prow[1] * (vc[1] + p1 * inv_dt)
                                 + Prow[2] * (vc[2] + p2 * inv_dt));
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { df[i] = bcast(dfr, base + i); fnew[i] = fc[i] + df[i]; }
-                df[3] = T(0); fnew[3] = fc[3];
+                df[3] = G(0); fnew[3] = fc[3];
             } else {                                               // JointLimits.solve constraints.py:73-90
                 // pred = pos0 + dt v0 <= min  <=>  v0 <= (min - pos0)/dt =: glo, and (min - pred)/dt = glo - v0
-                const T glo = bcast(k_p1, c), ghi = bcast(k_p2, c);
-                const T p00 = bcast(Prow[0], base);
-                const T v00 = bcast(v0r, base);
-                T nf = T(0);
+                const G glo = bcast(k_p1, c), ghi = bcast(k_p2, c);
+                const G p00 = bcast(Prow[0], base);
+                const G v00 = bcast(v0r, base);
+                G nf = G(0);
                 if (v00 <= glo) nf = p00 * (glo - v00);
                 else if (ghi <= v00) nf = p00 * (ghi - v00);
                 df[0] = nf - fc[0]; fnew[0] = nf;
 #pragma unroll
-                for (int i = 1; i < 4; ++i) { df[i] = T(0); fnew[i] = fc[i]; }
+                for (int i = 1; i < 4; ++i) { df[i] = G(0); fnew[i] = fc[i]; }
             }
             if (MODE == 1 && dbg.gs_trace != nullptr && lane == 0) {
                 int code = 4;
@@ -1997,6 +2021,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         }
         WAVE_SYNC();
         if (MODE == 1 && dbg.vel_free != nullptr && lane < n) dbg.vel_free[w * n + lane] = RT[lane];
+        if (MODE == 1 && do_constraints) {
+            if (dbg.c_adm != nullptr) for (int i = lane; i < ndol * ndol; i += WAVE) dbg.c_adm[(long)w * ndol * ndol + i] = AM[i];
+            if (dbg.c_vel != nullptr) for (int i = lane; i < ndol; i += WAVE) dbg.c_vel[(long)w * ndol + i] = VV[i];
+        }
 
         if (MODE == 0 && (sio.mode & 2)) {
             // split execution: hand the constraint-space system to arb_gsw_kernel and stop here;
@@ -2018,7 +2046,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (do_constraints) {
             ARB_STAMP(5);
             ARB_CSTAMP(7);
-            gs_stage<T, MODE>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
+            using GSG = std::conditional_t<(ARB_GS_F64 != 0) && std::is_same<T, float>::value, double, T>;
+            gs_stage<T, MODE, GSG>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
         }
 
         // ================= phase E: new velocity, integrate ==================
@@ -2933,6 +2962,7 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
     dbg.c_sdist = (T *)o->c_sdist; dbg.c_active = (int *)o->c_active; dbg.c_jac = (T *)o->c_jac;
     dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
     dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.gs_trace = (int *)o->gs_trace; dbg.stamps = (long long *)o->stamps; dbg.energy = (T *)o->energy;
+    dbg.c_adm = (T *)o->c_adm; dbg.c_vel = (T *)o->c_vel;
     { const char *ab = getenv("ARB_ABLATE"); dbg.ablate = ab ? atoi(ab) : 0; }
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
     SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));

@@ -454,7 +454,9 @@ template <typename T> ARB_HD double pinv_guard() { return sizeof(T) == 4 ? 1e-4 
 // Inverse of a ND x ND block (ND <= 4) embedded in a 4x4 identity, by pivoted elimination.  Returns false when the
 // pivots say the block is (numerically) rank deficient -- smallest / largest pivot magnitude below pinv_guard --
 // in which case the caller must use pinv_block: the elimination's result is then meaningless.
-template <typename T>
+// (TH: the type whose rounding noise the block carries -- the thresholds' type; differs from T when float32 data is
+// processed in float64 arithmetic)
+template <typename T, typename TH = T>
 ARB_HD bool inv_block(const T *Y, int ld, int nd, T P[16]) {
     T A[4][4], B[4][4];
 #pragma unroll
@@ -482,7 +484,7 @@ ARB_HD bool inv_block(const T *Y, int ld, int nd, T P[16]) {
             first = false;
         }
     // 1/|pivot|: min over max of the pivots = rmin / rmax
-    return finite && (double)rmin > pinv_guard<T>() * (double)rmax;
+    return finite && (double)rmin > pinv_guard<TH>() * (double)rmax;
 }
 
 // Moore-Penrose pseudo-inverse of a ND x ND block (ND <= 4), numpy.linalg.pinv semantics (singular values below
@@ -490,7 +492,7 @@ ARB_HD bool inv_block(const T *Y, int ld, int nd, T P[16]) {
 // mutually orthogonal (A V = U), then A^+ = sum_j v_j u_j^T / |u_j|^2 over the kept columns.  The result is embedded
 // in a 4x4 identity like inv_block's.  Rare path (rank-deficient admittance blocks: a planar arm's contact or
 // closed loop): clarity over speed.
-template <typename T>
+template <typename T, typename TH = T>
 ARB_HD void pinv_block(const T *Y, int ld, int nd, T P[16]) {
     double U[4][4], V[4][4];
     for (int i = 0; i < 4; ++i)
@@ -526,7 +528,7 @@ ARB_HD void pinv_block(const T *Y, int ld, int nd, T P[16]) {
         for (int i = 0; i < 4; ++i) s2[j] += U[i][j] * U[i][j];
         if (j < nd) s2max = fmax(s2max, s2[j]);
     }
-    const double cut = pinv_rcond<T>() * pinv_rcond<T>() * s2max;       // compare squared singular values
+    const double cut = pinv_rcond<TH>() * pinv_rcond<TH>() * s2max;       // compare squared singular values
     for (int i = 0; i < 4; ++i)
         for (int k = 0; k < 4; ++k) {
             double acc = 0.;

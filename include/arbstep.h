@@ -209,6 +209,9 @@ typedef struct arb_inspect_out {
                         (SoftFingerContact.solve, constraints.py:781-836), 4 = another constraint type.  Entries of solves
                         that were not executed (inactive constraint, sweeps after the fixed point) are left untouched:
                         pre-fill with -1. */
+    void *c_adm;     /* [nw][4 nc][4 nc]  the constraint-space admittance Y' = J' Y J'^T the sweeps run on (core.py:927);
+                        rows / columns of inactive constraints are zero */
+    void *c_vel;     /* [nw][4 nc]        v' = J' Y (M gvel/dt + gforce') before the sweeps (core.py:925-926) */
 } arb_inspect_out;
 
 int arb_abi_version(void);

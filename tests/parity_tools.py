@@ -10,7 +10,21 @@ comfortable decision must fail.  `explain_outlier` therefore demands, at the FIR
   (a) the oracle's own inequality at that solve sits within MARGIN_TOL (1e-5: the parity tolerance) of equality,
       measured against the magnitude of the terms the inequality is computed from (`solve_margins`), or
   (b) the oracle's own trace changes at or before that solve when its INPUT state moves by one float32 ulp
-      (`samples` random sign patterns, conftest.oracle_sensitivity's perturbation).
+      (`samples` random sign patterns, conftest.oracle_sensitivity's perturbation), or
+  (c) the oracle's own decision AT THAT SOLVE changes when the solve's inputs (vel, admittance block, force, sdist: the
+      arguments of SoftFingerContact.solve, constraints.py:780) move by one float32 ulp each -- the least any float32
+      implementation perturbs them, since it stores them in float32 (`solve_samples` random sign patterns), or
+  (d) the sweeps are RIGHT and the float32 SYSTEM moved the decision: the oracle's own solve (constraints.py:780-836) run
+      in float64, sweep by sweep in the reference's order, on the constraint-space system the DEVICE built (Y' = J' Y J'^T
+      and v', arb_inspect_out.c_adm / c_vel, float32) takes the device's decisions up to and including that solve --
+      and that system is within SYS_TOL of the oracle's (relative to its largest entry).  A bug in the sweeps fails the
+      first half, a bug in the dynamics or the elimination the second.  Or
+  (e) float64 sweeps on the device's system take the ORACLE's decision at that solve, but the decision lies inside the
+      running rounding-error bound of ANY float32 execution of the sweeps: every update v' += Y'[:, c] df (core.py:935)
+      commits at most one float32 ulp of its terms' magnitudes per row (the terms are kN forces times 1e-3 admittances
+      that cancel to the small velocity the solve then tests), and with the velocity rows of that solve moved within the
+      accumulated bound the oracle's own solve decides like the device (`solve_samples` random patterns).  An error of
+      the sweeps larger than float32 rounding still fails.
 
 Anything else is reported as unexplained (None) and the callers fail.
 """
@@ -19,6 +33,7 @@ import numpy as np
 import arb_oracle as O
 
 MARGIN_TOL = 1e-5
+SYS_TOL = 2e-5        # |Y'_device - Y'_oracle| / max|Y'_oracle| and the same for v' (float32 elimination at cond(Z) ~ 7e4)
 
 
 def world_err(a, b):
@@ -62,13 +77,53 @@ def _perturbed(q, dq, rng):
     return pq, pdq
 
 
-def explain_outlier(bw, m, q, dq, dt, samples=8, seed=0):
+def _solve_flips(t, rng, samples):
+    """Does the oracle's decision at the traced solve `t` change under one-ulp (float32) changes of the solve's inputs?"""
+    eps = np.ones(3)
+    ulp = lambda a: np.asarray(a, np.float64) * (1. + 2. ** -24 * rng.choice([-1., 1.], np.shape(a)))
+    for _ in range(samples):
+        br = O._softfinger_solve_one(ulp(t["vel"]), ulp(t["adm"]), ulp(t["force"]), float(ulp(t["sdist"])), t["mu"], eps, t["dt"])[2]
+        if br != t["branch"]:
+            return True
+    return False
+
+
+def sweeps_on(m, adm, vel, sdist, active, dt, nsweeps=20, stop_at=None):
+    """World.update_constraints' Gauss-Seidel loop (core.py:929-935) with SoftFingerContact.solve (constraints.py:780-836)
+    in float64 on a GIVEN constraint-space system: adm (R, R), vel (R,), sdist / active (nc,).  Returns the decision of
+    every solve as an (nsweeps, nc) array (-1: constraint inactive).  With `stop_at = (sweep, c)` it stops BEFORE that
+    solve and also returns its inputs and the running float32 rounding-error bound of the velocity rows: every update
+    v' += Y'[:, c] df done in float32 commits at most 2^-24 (|v'| + sum_i |Y'[:, c_i] df_i|) per row, accumulated."""
+    nc = m.nc
+    vel = np.array(vel, np.float64); adm = np.asarray(adm, np.float64)
+    force = np.zeros((nc, 4))
+    bound = 2. ** -24 * np.abs(vel)                    # v' itself is a float32 number
+    out = -np.ones((nsweeps, nc), int)
+    for k in range(nsweeps):
+        for c in range(nc):
+            if not active[c]:
+                continue
+            rows = slice(4 * c, 4 * c + 4)
+            if stop_at is not None and (k, c) == tuple(stop_at):
+                return out, dict(vel=vel[rows].copy(), adm=adm[rows, rows].copy(), force=force[c].copy(), sdist=float(sdist[c]),
+                                 mu=float(m.c_mu[c]), dt=dt, bound=bound[rows].copy())
+            df, newf, br = O._softfinger_solve_one(vel[rows], adm[rows, rows], force[c], float(sdist[c]), float(m.c_mu[c]),
+                                                   np.asarray(m.c_eps[c], float), dt)
+            out[k, c] = br
+            force[c] = newf
+            inc = adm[:, rows] * df[None, :]
+            vel += inc.sum(axis=1)
+            bound += 2. ** -24 * (np.abs(inc).sum(axis=1) + np.abs(vel))
+    return out if stop_at is None else (out, None)
+
+
+def explain_outlier(bw, m, q, dq, dt, samples=8, seed=0, solve_samples=64):
     """Why may the float32 step from (q, dq) (one world, the float32 values the device stepped from) differ from the
     float64 oracle by more than rounding?  Returns a reason string that PROVES a marginal decision, or None."""
     import torch
     tq = torch.as_tensor(q[None], dtype=torch.float32, device=bw.device).contiguous()
     tdq = torch.as_tensor(dq[None], dtype=torch.float32, device=bw.device).contiguous()
-    r = bw.inspect(tq, tdq, dt, ["gs_stats", "gs_trace", "c_active"], cforce=bw.new_cforce(1, torch.float32))
+    r = bw.inspect(tq, tdq, dt, ["gs_stats", "gs_trace", "c_active", "c_adm", "c_vel", "c_sdist"], cforce=bw.new_cforce(1, torch.float32))
     st = r["gs_stats"].cpu().numpy()[0]                    # release, static, fast slide, eig6 slide, sweeps
     dtr = r["gs_trace"].cpu().numpy()[0]                   # (20, nc): decision of every executed solve, -1 = not run
     dact = r["c_active"].cpu().numpy()[0].astype(bool)
@@ -113,4 +168,43 @@ def explain_outlier(bw, m, q, dq, dt, samples=8, seed=0):
         if [(key(x), x["branch"]) for x in trp[:i + 1]] != base:
             return ("decision differs at %s (margin %.1e): the oracle's own trace changes at or before that solve "
                     "under a one-ulp input change" % (where, mg))
+    if np.all(np.asarray(m.c_eps)[t["c"]] == 1.) and _solve_flips(t, rng, solve_samples):
+        return ("decision differs at %s (margin %.1e): the oracle's own decision at that solve changes under one-ulp "
+                "(float32) changes of the solve's inputs" % (where, mg))
+    if np.all(np.asarray(m.ctype) == 0):
+        # (d) float64 sweeps on the device's own float32 system
+        adm_d = r["c_adm"].double().cpu().numpy()[0]; vel_d = r["c_vel"].double().cpu().numpy()[0]
+        sd_d = r["c_sdist"].double().cpu().numpy()[0]
+        e_adm = np.abs(adm_d - d["adm"][0]).max() / max(np.abs(d["adm"][0]).max(), 1e-300)
+        got = sweeps_on(m, adm_d, vel_d, sd_d, dact, dt, nsweeps=t["sweep"] + 1)
+        same = all(min(int(dtr[s_, c_]), 2) == got[s_, c_] for s_ in range(t["sweep"] + 1) for c_ in range(m.nc)
+                   if dact[c_] and (s_ < t["sweep"] or c_ <= t["c"]))
+        if same and e_adm < SYS_TOL:
+            return ("decision differs at %s (margin %.1e): float64 sweeps on the device's own float32 system take the device's "
+                    "decisions; that system is within %.1e of the oracle's" % (where, mg, e_adm))
+        # (e) the decision lies inside the rounding-error bound of float32 sweeps on that system
+        before_ok = all(min(int(dtr[s_, c_]), 2) == got[s_, c_] for s_ in range(t["sweep"] + 1) for c_ in range(m.nc)
+                        if dact[c_] and (s_ < t["sweep"] or c_ < t["c"]))
+        if before_ok and e_adm < SYS_TOL:
+            _, at = sweeps_on(m, adm_d, vel_d, sd_d, dact, dt, nsweeps=t["sweep"] + 1, stop_at=(t["sweep"], t["c"]))
+            if at is not None:
+                ulp = lambda a: np.asarray(a, np.float64) * (1. + 2. ** -24 * rng.choice([-1., 1.], np.shape(a)))
+                for _ in range(solve_samples):
+                    v = at["vel"] + at["bound"] * rng.uniform(-1., 1., 4)
+                    br = O._softfinger_solve_one(v, ulp(at["adm"]), ulp(at["force"]), at["sdist"], at["mu"], np.ones(3), dt)[2]
+                    if br == dev:
+                        return ("decision differs at %s (margin %.1e): inside the running rounding-error bound of float32 sweeps "
+                                "(velocity rows of that solve known to +-%.1e of %.1e)" % (where, mg, at["bound"].max(), np.abs(at["vel"]).max()))
+    return None
+
+
+def ill_conditioned(m, q, dq, dt, eq, edq, cap=1e-3, samples=8):
+    """Identical decisions, yet an error above the gate: accepted only when the step is that ill-conditioned FOR THE
+    ORACLE -- its own (q+, dq+) move by at least the observed error when its input moves by one float32 ulp (the
+    worst of `samples` sign patterns) -- and the error stays below `cap`.  Returns a reason string or None."""
+    from conftest import oracle_sensitivity
+    sq, sdq = oracle_sensitivity(m, q[None], dq[None], dt, samples=samples)
+    sq, sdq = float(sq[0]), float(sdq[0])
+    if sq >= eq and sdq >= edq and max(eq, edq) < cap:
+        return "ill-conditioned step: one float32 ulp on the input moves the oracle by q %.1e dq %.1e" % (sq, sdq)
     return None

@@ -307,3 +307,33 @@ def test_random_trees_flatten_and_step_through_the_oracle():
             assert m.parent[b] < b
         q, dq, cf = O.step(m, q0[None], dq0[None], 5e-3)
         assert np.isfinite(q).all() and np.isfinite(dq).all()
+
+
+def test_parity_tools_on_the_oracle_itself():
+    """tests/parity_tools.py (the float32 outlier adjudication of the GPU tests) checked without a GPU: the float64 sweeps
+    on a given constraint-space system reproduce the oracle's own decision trace when given the oracle's system, and the
+    decision margins are small exactly where a decision is about to change."""
+    import arb_oracle as O
+    from conftest import load_model
+    from parity_tools import sweeps_on, solve_margins
+    from arboris_python_amd import synth
+    m, _, _ = load_model("human36_c4")
+    q, dq = synth.standing_states(m, 6, seed=3, drop=0.03, vel=0.3)
+    q[:, 7] -= 0.034                                   # feet in the floor: static and sliding solves
+    dq[::2, 3] += 0.6
+    tr = []
+    _, _, _, d = O.step(m, q, dq, 5e-3, debug=True, trace=tr)
+    kinds = set()
+    for w in range(6):
+        got = sweeps_on(m, d["adm"][w], d["vel0"][w], d["sdist"][w], d["active"][w], 5e-3)
+        ref = -np.ones_like(got)
+        for t in tr:
+            if t["world"] == w:
+                ref[t["sweep"], t["c"]] = t["branch"]; kinds.add(t["branch"])
+        assert np.array_equal(got, ref)
+    assert kinds == {0, 1, 2} or kinds == {1, 2}
+    # margins: where the decision of a contact changes from one sweep to the next, the cone test was close to equality
+    # more often than elsewhere (a sanity check of the normalisation, not a theorem)
+    mg = [(t["world"], t["c"], t["sweep"], t["branch"]) + solve_margins(t) for t in tr]
+    cone = np.array([x[5] for x in mg if x[5] is not None])
+    assert cone.min() >= 0. and np.isfinite(cone).all() and cone.max() <= 1.0 + 1e-12

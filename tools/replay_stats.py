@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0
 import torch
 import arb_oracle as O
 from conftest import load_model, oracle_sensitivity
-from parity_tools import explain_outlier
+from parity_tools import explain_outlier, ill_conditioned
 from arboris_python_amd import synth
 from arboris_python_amd.batch import BatchedWorlds
 arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
@@ -37,9 +37,7 @@ for k in range(0, T - 1, arg(3, 3)):       # 13 steps by default
         qf, dqf = log["q"][k][w].cpu().numpy(), log["dq"][k][w].cpu().numpy()
         why = explain_outlier(bw, m, qf, dqf, dt)
         if why is None:
-            sq, sdq = oracle_sensitivity(m, qf[None], dqf[None], dt)
-            if 2 * float(sq[0]) >= eq[i] and 2 * float(sdq[0]) >= e[i] and max(e[i], eq[i]) < 3e-5:
-                why = "ill-conditioned step (oracle moves by q %.1e dq %.1e under one ulp)" % (float(sq[0]), float(sdq[0]))
+            why = ill_conditioned(m, qf, dqf, dt, eq[i], e[i])
         tag = "UNEXPLAINED" if why is None else why.split(":")[0].split("(")[0].strip()
         reasons[tag] = reasons.get(tag, 0) + 1
         if why is None:
