@@ -24,7 +24,7 @@ Constraint :269-315, Shape :318-324, Controller :327-339, World :342-980,
 SubFrame/MovingSubFrame :983-1053, Body :1055-1315, Observer :1318-1331,
 simulate :1334-1365.
 """
-from abc import ABCMeta
+from abc import ABCMeta, abstractmethod, abstractproperty
 
 import numpy
 from numpy import array, zeros, eye, dot
@@ -41,27 +41,14 @@ def simplearm():
     return w
 
 
-def _interface(properties=(), methods=()):
-    """Class decorator: the named read-only properties and methods are abstract (what the reference declares one
-    by one with ``abstractproperty`` / ``abstractmethod``); the class must use ``ABCMeta``."""
-    def decorate(cls):
-        for name in properties:
-            def getter(self, _n=name):
-                raise NotImplementedError(_n)
-            getter.__isabstractmethod__ = True
-            getter.__name__ = name
-            setattr(cls, name, property(getter))
-        for name, nargs in methods:
-            args = ", ".join("a%d" % i for i in range(nargs))
-            ns = {}
-            exec("def %s(self%s):\n    raise NotImplementedError(%r)" % (name, (", " + args) if args else "", name), ns)
-            fn = ns[name]
-            fn.__isabstractmethod__ = True
-            setattr(cls, name, fn)
-        cls.__abstractmethods__ = frozenset(set(getattr(cls, "__abstractmethods__", ())) | set(properties)
-                                            | set(n for n, _ in methods))
-        return cls
-    return decorate
+def _abstract(*names):
+    """Read-only abstract properties ``names`` for a class body: ``locals().update(_abstract("pose", ...))``."""
+    def make(name):
+        def getter(self):
+            raise NotImplementedError(name)
+        getter.__name__ = name
+        return abstractproperty(getter)
+    return dict((n, make(n)) for n in names)
 
 
 class NamedObject(object):
@@ -111,15 +98,19 @@ class NamedObjectsList(list):
         return out
 
 
-@_interface(properties=("pose", "jacobian", "djacobian", "twist", "body", "bpose"))
 class Frame(object, metaclass=ABCMeta):
     """Abstract frame: a body or a frame rigidly attached to one (pose, jacobian, djacobian, twist, body, bpose)."""
+    locals().update(_abstract("pose", "jacobian", "djacobian", "twist", "body", "bpose"))
 
 
-@_interface(properties=("ndof", "jacobian", "djacobian"), methods=(("integrate", 2),))
 class Joint(RigidMotion, NamedObject):
     """Ideal joint between ``frames[0]`` (parent side) and ``frames[1]``; a concrete joint provides ``ndof``,
     ``jacobian``, ``djacobian`` and ``integrate(gvel, dt)``."""
+    locals().update(_abstract("ndof", "jacobian", "djacobian"))
+
+    @abstractmethod
+    def integrate(self, gvel, dt):
+        raise NotImplementedError("integrate")
 
     def __init__(self, name=None):
         NamedObject.__init__(self, name)
@@ -182,12 +173,27 @@ class JointsList(NamedObjectsList):
         return self._dof
 
 
-@_interface(properties=("jacobian", "ndol"),
-            methods=(("init", 1), ("update", 1), ("is_active", 0), ("solve", 3)))
 class Constraint(NamedObject, metaclass=ABCMeta):
     """A kinematic constraint.  Concrete classes provide ``jacobian``, ``ndol`` (degrees of "liaison": 6 minus the
     dofs of the constrained motion), ``init(world)``, ``update(dt)``, ``is_active()`` and
     ``solve(vel, admittance, dt)``; the generalized force is ``jacobian.T @ force``."""
+    locals().update(_abstract("jacobian", "ndol"))
+
+    @abstractmethod
+    def init(self, world):
+        raise NotImplementedError("init")
+
+    @abstractmethod
+    def update(self, dt):
+        raise NotImplementedError("update")
+
+    @abstractmethod
+    def is_active(self):
+        raise NotImplementedError("is_active")
+
+    @abstractmethod
+    def solve(self, vel, admittance, dt):
+        raise NotImplementedError("solve")
 
     def __init__(self, name=None):
         NamedObject.__init__(self, name)
@@ -216,17 +222,35 @@ class Shape(NamedObject):
         NamedObject.__init__(self, name)
 
 
-@_interface(methods=(("init", 1), ("update", 1)))
 class Controller(NamedObject, metaclass=ABCMeta):
     """A controller: ``init(world)`` once, then ``update(dt)`` returns (gforce, impedance) every step."""
 
     def __init__(self, name=None):
         NamedObject.__init__(self, name)
 
+    @abstractmethod
+    def init(self, world):
+        raise NotImplementedError("init")
 
-@_interface(methods=(("init", 2), ("update", 1), ("finish", 0)))
+    @abstractmethod
+    def update(self, dt):
+        raise NotImplementedError("update")
+
+
 class Observer(object, metaclass=ABCMeta):
     """Watches a simulation: ``init(world, timeline)``, ``update(dt)`` before every step, ``finish()``."""
+
+    @abstractmethod
+    def init(self, world, timeline):
+        raise NotImplementedError("init")
+
+    @abstractmethod
+    def update(self, dt):
+        raise NotImplementedError("update")
+
+    @abstractmethod
+    def finish(self):
+        raise NotImplementedError("finish")
 
 
 class _Registry(object):

@@ -1,6 +1,7 @@
 // valu_issue_probe.hip -- what does one SIMD of an MI355X sustain, in wave64 VALU instructions per cycle, with 1, 2, 3 or
 // 4 resident waves?  (round 3, VERDICT item 2: the denominator of the step kernel's VALU roofline.)
 //
+// (256 instructions per loop iteration: the first version looped over 16 and measured its branch.)
 // Every workgroup is one wavefront; the grid is waves_per_simd x 1024 (256 CUs x 4 SIMDs) and a dynamic-LDS pad pins the
 // number of resident workgroups per CU, so each SIMD holds exactly `waves_per_simd` waves.  Each wave issues N blocks of
 // 16 instructions: either 16 INDEPENDENT chains (issue-bound) or ONE dependent chain (latency-bound), float32 or float64,
@@ -26,6 +27,8 @@ __global__ __launch_bounds__(64) void probe(long long *out, float *sink, int ite
     if (pad_lds[threadIdx.x] == 77 && seed == 123.f) a[0] += 1.f;     // keep the LDS allocation
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int rep = 0; rep < 16; ++rep) {
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
@@ -42,6 +45,7 @@ __global__ __launch_bounds__(64) void probe(long long *out, float *sink, int ite
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("v_add_f32_dpp %0, %0, %1 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(a[0]) : "v"(y));
         }
+      }
     }
     const long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
@@ -69,7 +73,7 @@ static void run(const char *name, int wps, int iters) {
     std::vector<long long> h(grid);
     hipMemcpy(h.data(), out, sizeof(long long) * grid, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
-    const double insts = 16.0 * iters;
+    const double insts = 256.0 * iters;
     const double cyc_med = (double)h[grid / 2];
     // s_memtime ticks at a constant 100 MHz on this part when read through readcyclecounter? report both views
     printf("%-28s waves/SIMD %d: median wave %.0f ticks for %.0f insts; kernel %.3f ms -> %.3f wave-insts/cycle/SIMD at 2.4 GHz "
@@ -79,7 +83,7 @@ static void run(const char *name, int wps, int iters) {
 }
 
 int main() {
-    const int iters = 200000;
+    const int iters = 20000;
     for (int wps = 1; wps <= 4; ++wps) {
         run<0>("v_fma_f32 independent", wps, iters);
         run<1>("v_fma_f32 dependent chain", wps, iters);
