@@ -636,6 +636,201 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 }
 
 // ===========================================================================
+// The Gauss-Seidel stage for TWO worlds held by one wavefront (round 3): world h on lanes 32 h .. 32 h + ndol - 1
+// (ndol <= 32: up to eight SoftFingerContacts with eps = (1,1,1), which the host checks).  The sweeps are one dependent
+// instruction chain in which one quad of lanes does useful work; here the quad of constraint c of BOTH worlds works at
+// once.  A stage of the local solve is executed when either world needs it and its results are taken lane by lane
+// under the conditions of gs_stage, whose arithmetic every lane repeats operation for operation: a world's forces and
+// velocities are bit-identical to gs_stage's.  A world that has reached its bit-exact fixed point (or has no partner:
+// `two` false) takes no further part -- its lanes keep their values, as gs_stage's break would.
+// LDS per world: AM = Y', CD, VV, FF as for gs_stage; WORK is shared scratch.
+// ===========================================================================
+template <typename T>
+__device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt,
+                                          const T *AM0, T *CD0, T *VV0, T *FF0w, const T *AM1, T *CD1, T *VV1, T *FF1w,
+                                          T *WORK, const bool two) {
+    const int half = lane >> 5, hl = lane & 31;
+    const T *AM = half ? AM1 : AM0;
+    T *CD = half ? CD1 : CD0, *VV = half ? VV1 : VV0, *FF = half ? FF1w : FF0w;
+    const bool mine = (half == 0) || two;                 // this lane's world exists
+    {
+        bool deficient = false;
+        if (mine && hl < nc && CD[hl * CD_STRIDE + CD_ACTIVE] != T(0)) {
+            const int c = hl;
+            T P[16];
+            deficient = !inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, 4, P);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+        }
+        unsigned long long todo = __ballot(deficient);
+        while (todo != 0ull) {                           // wave-uniform, rare
+            const int L = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            if (lane == L) {
+                const int c = hl;
+                T P[16];
+                pinv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, 4, P);
+                for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+            }
+        }
+    }
+    WAVE_SYNC();
+    T vr = T(0), fr = T(0), Yrow[4], Prow[4];
+    bool k_act = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Yrow[i] = T(0); Prow[i] = T(0); }
+    T q_sd = T(0), q_sdt = T(0), q_mu = T(0);
+    T q_iyn = T(0), q_muyn = T(0), q_yc0 = T(0), q_yc1 = T(0), q_yc2 = T(0), q_bsq = T(0);
+    SlidePre q_sp = {0., 0., 0., 0., 0., 0.};
+    double q_warm = NAN, q_wmove = NAN;
+    if (mine && hl < ndol) {
+        const int cc = hl >> 2, rr = hl & 3;
+        vr = VV[hl]; fr = FF[hl];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Yrow[i] = AM[hl * ndol + 4 * cc + i];
+            Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
+        }
+        q_sd = CD[cc * CD_STRIDE + CD_SDIST]; q_sdt = q_sd / dt; q_mu = mp->cmu[cc];
+        if (CD[cc * CD_STRIDE + CD_ACTIVE] != T(0)) {
+            T Yc4[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * ndol + 4 * cc + j];
+            q_sp = slide_precompute<T>(Yc4);
+            q_iyn = T(1) / Yc4[15]; q_muyn = q_mu / Yc4[15];
+            q_yc0 = Yc4[3]; q_yc1 = Yc4[7]; q_yc2 = Yc4[11];
+            const T bq0 = q_muyn * q_yc0, bq1 = q_muyn * q_yc1, bq2 = q_muyn * q_yc2;
+            q_bsq = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
+        }
+    }
+    if (mine && hl < nc) k_act = CD[hl * CD_STRIDE + CD_ACTIVE] != T(0);
+    const unsigned long long actmask = __ballot(k_act);          // bit c: world 0, bit 32 + c: world 1
+    bool done0 = false, done1 = !two;
+    T vr_prev = vr, fr_prev = fr;
+#if ARB_GS_PRIO
+    __builtin_amdgcn_s_setprio(ARB_GS_PRIO);
+#endif
+    for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+        if (done0 && done1) break;
+        for (int c = 0; c < nc; ++c) {
+            const bool on0 = !done0 && ((actmask >> c) & 1ull), on1 = !done1 && ((actmask >> (32 + c)) & 1ull);
+            if (!on0 && !on1) continue;
+            const int base = 4 * c;
+            const bool my_on = half ? on1 : on0;                 // this lane's world takes part in this solve
+            const int rq = hl - base;
+            const bool inquad = rq >= 0 && rq < 4;
+            // bit masks of the quads' leading lanes (base, 32 + base) of the worlds taking part
+            const unsigned long long lead = (on0 ? (1ull << base) : 0ull) | (on1 ? (1ull << (32 + base)) : 0ull);
+            T a4[4] = {T(0), T(0), T(0), T(0)};
+            if (mine && hl < ndol) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a4[i] = AM[hl * ndol + base + i];
+            }
+            T df[4], fnew[4];
+            const T fq0 = quad_bcast<0>(fr), fq1 = quad_bcast<1>(fr), fq2 = quad_bcast<2>(fr), fq3 = quad_bcast<3>(fr);
+            const T v0r = vr - (Yrow[0] * fq0 + Yrow[1] * fq1 + Yrow[2] * fq2 + Yrow[3] * fq3);
+            const T vq0 = quad_bcast<0>(vr), vq1 = quad_bcast<1>(vr), vq2 = quad_bcast<2>(vr), vq3 = quad_bcast<3>(vr);
+            const T dfr = -(Prow[0] * vq0 + Prow[1] * vq1 + Prow[2] * vq2 + Prow[3] * (vq3 + q_sdt));
+            const T fnr = fr + dfr;
+            const T v0n = quad_bcast<3>(v0r);
+            const T fn0 = quad_bcast<0>(fnr), fn1 = quad_bcast<1>(fnr), fn2 = quad_bcast<2>(fnr), fn3 = quad_bcast<3>(fnr);
+            const T lhs = fn0 * fn0 + fn1 * fn1 + fn2 * fn2;
+            const T rhs = (fn3 * q_mu) * (fn3 * q_mu);
+            // the verdicts of the two quads of constraint c
+            const unsigned long long relb = __ballot(q_sd + dt * v0n > T(0)), statb = __ballot(lhs <= rhs);
+            const bool rel0 = (relb >> base) & 1ull, rel1 = (relb >> (32 + base)) & 1ull;
+            const bool sta0 = (statb >> base) & 1ull, sta1 = (statb >> (32 + base)) & 1ull;
+            const bool release = half ? rel1 : rel0, stat = half ? sta1 : sta0;
+            const bool slide0 = on0 && !rel0 && !sta0, slide1 = on1 && !rel1 && !sta1;
+            const bool my_slide = half ? slide1 : slide0;
+            T dfl = release ? -fr : dfr, fnl = release ? T(0) : fnr;             // release / static, row by row
+            if (slide0 || slide1) {                                              // sliding friction: either world
+                const unsigned long long slm = (slide0 ? (1ull << base) : 0ull) | (slide1 ? (1ull << (32 + base)) : 0ull);
+                const auto anyq = [&](bool b) { return (bool)((__ballot(b) & slm) != 0ull); };
+                const bool want = my_slide && inquad;
+                T alpha[4], shift = T(0);
+                alpha[0] = quad_bcast<0>(v0r); alpha[1] = quad_bcast<1>(v0r); alpha[2] = quad_bcast<2>(v0r);
+                alpha[3] = v0n + q_sdt;
+                T Y[16];
+                {
+                    typedef T Y4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const Y4 y4 = *reinterpret_cast<const Y4 *>(AM + (base + r) * ndol + base);
+                        Y[4 * r] = y4.x; Y[4 * r + 1] = y4.y; Y[4 * r + 2] = y4.z; Y[4 * r + 3] = y4.w;
+                    }
+                }
+                double warm = q_warm;
+                bool have = false;
+                {
+                    const T yc[3] = {q_yc0, q_yc1, q_yc2};
+                    const T bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
+                    double c1, kappa, root;
+                    slide_c1_kappa<T>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
+                    double woff = -1.;
+                    if (sizeof(T) == 4 && q_wmove == q_wmove)
+                        woff = fmin(fmax(2. * q_wmove, 1e-9 * fabs(warm)), 0.1 * fabs(warm));
+                    bool ok;
+                    slide_leftmost_root_pk(q_sp, c1, kappa, warm, slide_step_tol<T>(), woff, want, anyq, &root, &ok);
+                    if (ok) {
+                        if (want) q_wmove = fabs(root - warm);
+                        warm = root;
+                        shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
+                        have = true;
+                    }
+                }
+                // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one world after the other
+                const unsigned long long needfb = __ballot(want && !have) & slm;
+                if (needfb != 0ull) {
+                    const T eps[3] = {T(1), T(1), T(1)};
+                    for (int h = 0; h < 2; ++h) {
+                        if (!((needfb >> (32 * h + base)) & 1ull)) continue;
+                        const bool hq = want && half == h;
+                        if (hq) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
+                        WAVE_SYNC();
+                        if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
+                        WAVE_SYNC();
+                        if (hq) { shift = WORK[40]; warm = NAN; q_wmove = NAN; }
+                        WAVE_SYNC();
+                    }
+                }
+                if (want) q_warm = warm;                     // next sweep restarts next to this root
+                fnew[0] = fq0; fnew[1] = fq1; fnew[2] = fq2; fnew[3] = fq3;
+                const T sie2[3] = {shift, shift, shift};
+                softfinger_slide_finish_pk<T>(Y, alpha, sie2, fnew, df, want, anyq);
+                const T dfs = (rq == 0) ? df[0] : (rq == 1) ? df[1] : (rq == 2) ? df[2] : df[3];
+                const T fns = (rq == 0) ? fnew[0] : (rq == 1) ? fnew[1] : (rq == 2) ? fnew[2] : fnew[3];
+                dfl = my_slide ? dfs : dfl; fnl = my_slide ? fns : fnl;
+            }
+            // the force increments of this lane's world: from the quad of c in its own half
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T d0 = bcast(dfl, base + i), d1 = bcast(dfl, 32 + base + i);
+                df[i] = half ? d1 : d0;
+            }
+            if (my_on) {
+                fr = inquad ? fnl : fr;
+                vr += a4[0] * df[0] + a4[1] * df[1] + a4[2] * df[2] + a4[3] * df[3];      // core.py:935
+            }
+            (void)lead;
+        }
+        // a sweep that leaves every velocity and force of a world bit for bit unchanged is its fixed point
+        const unsigned long long sameb = __ballot(same_bits(vr, vr_prev) && same_bits(fr, fr_prev));
+        if (!done0 && (unsigned)(sameb & 0xffffffffull) == 0xffffffffu) done0 = true;
+        if (!done1 && (unsigned)(sameb >> 32) == 0xffffffffu) done1 = true;
+        vr_prev = vr; fr_prev = fr;
+    }
+#if ARB_GS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    WAVE_SYNC();
+    if (mine && hl < ndol) { FF[hl] = fr; VV[hl] = vr; }
+    WAVE_SYNC();
+}
+
+// ===========================================================================
 // The step kernel.  MODE 0 = production, 1 = inspect (debug stores, no state
 // write-back).  zmode (inspect only): 0 full Z, 1 M only, 2 B only, 3 N only.
 // ===========================================================================
@@ -2129,6 +2324,45 @@ __global__ __launch_bounds__(WAVE, WV) void arb_gsw_kernel(
     if (lane < ndol) wsf[w * ndol + lane] = FF[lane];
 }
 
+// The same with TWO worlds per wavefront (gs_stage2): worlds 2 p and 2 p + 1 in workgroup p.  Development / test vehicle
+// of the packed sweeps (ARB_GSW_PACK=1 in the environment selects it for ARB_STEP_SPLIT_WAVE): bit-identical to
+// arb_gsw_kernel by construction, checked in tests/test_gpu_round3.py.
+template <typename T, int WV>
+__global__ __launch_bounds__(WAVE, WV) void arb_gsw2_kernel(
+    const DevModel<T> *__restrict__ mp, const T *__restrict__ wsA, const T *__restrict__ wsv,
+    T *__restrict__ wsf, const T *__restrict__ wsc, long nworlds, T dt_in, const double *__restrict__ dts)
+{
+    const int lane = threadIdx.x;
+    const long w0 = 2l * blockIdx.x;
+    if (w0 >= nworlds) return;
+    const bool two = w0 + 1 < nworlds;
+    const int nc = mp->nc, ndol = mp->ndol;
+    const T dt = dts != nullptr ? (T)dts[0] : dt_in;
+    T *lds = reinterpret_cast<T *>(arb_lds_raw);
+    auto al = [](int x) { return (x + 3) & ~3; };
+    const int per = al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol);
+    T *AMw[2], *CDw[2], *VVw[2], *FFw[2];
+    for (int h = 0; h < 2; ++h) {
+        AMw[h] = lds + h * per; CDw[h] = AMw[h] + al(ndol * ndol); VVw[h] = CDw[h] + al(nc * CD_STRIDE); FFw[h] = VVw[h] + al(ndol);
+    }
+    T *WORK = lds + 2 * per;
+    const int nA = ndol * ndol;
+    for (int h = 0; h < (two ? 2 : 1); ++h) {
+        const long w = w0 + h;
+        for (int i = lane; i < nA; i += WAVE) AMw[h][i] = wsA[w * nA + i];
+        if (lane < ndol) { VVw[h][lane] = wsv[w * ndol + lane]; FFw[h][lane] = wsf[w * ndol + lane]; }
+        if (lane < nc) {
+            const T *cs = wsc + (w * nc + lane) * 8;
+            T *cd = CDw[h] + lane * CD_STRIDE;
+            cd[CD_ACTIVE] = cs[0]; cd[CD_SDIST] = cs[1]; cd[CD_POS0] = cs[2]; cd[CD_POS0 + 1] = cs[3]; cd[CD_POS0 + 2] = cs[4];
+        }
+    }
+    WAVE_SYNC();
+    gs_stage2<T>(mp, lane, nc, ndol, dt, AMw[0], CDw[0], VVw[0], FFw[0], AMw[1], CDw[1], VVw[1], FFw[1], WORK, two);
+    for (int h = 0; h < (two ? 2 : 1); ++h)
+        if (lane < ndol) wsf[(w0 + h) * ndol + lane] = FFw[h][lane];
+}
+
 // ===========================================================================
 // Device unit test of the local solve (test hook arb_dev_softfinger_solve): one LANE per input tuple, the
 // same arb_math.h code the kernels run -- inverse of the 4x4 block, SoftFingerContact.solve with the fast
@@ -2369,6 +2603,7 @@ struct arb_model {
     DevModel<double> dd;
     DevModel<float> *df_dev;
     DevModel<double> *dd_dev;
+    bool packable = false;         // every constraint a SoftFingerContact with eps = (1,1,1), at most eight: two worlds per wavefront in the sweeps
     int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
     Layout lf, lf3, ld;            // LDS layouts: float32 two-wave kernels, float32 three-wave kernels, float64
 };
@@ -2670,6 +2905,9 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     M->nsets = (ncols > WAVE && !(nc == 0 && n == WAVE)) ? 2 : 1;
     M->nmax = 64;
     for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
+    M->packable = nc >= 1 && nc <= 8;
+    for (int c = 0; c < nc; ++c)
+        M->packable = M->packable && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_eps[3 * c] == 1. && d->c_eps[3 * c + 1] == 1. && d->c_eps[3 * c + 2] == 1.;
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) {
         g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err);
@@ -2828,13 +3066,20 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 }
 
 template <typename T>
-static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st) {
+static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st, bool pack = false) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int ndol = 4 * nc;
     const size_t lds = (size_t)(al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol) + 64) * sizeof(T);
     // waves per SIMD the sweep kernel is compiled for (development knob ARB_GSW_WAVES: 3 = no spills, 4 = 128 VGPRs)
     static const int wv = [] { const char *e = getenv("ARB_GSW_WAVES"); return e ? atoi(e) : 3; }();
     if (lds > 64 * 1024) return ARB_ERR_UNSUPPORTED;
+    if (pack) {
+        // (development: two worlds per wavefront; the caller has checked that the model qualifies)
+        const size_t lds2 = (size_t)(2 * (al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol)) + 64) * sizeof(T);
+        hipLaunchKernelGGL((arb_gsw2_kernel<T, 3>), dim3((unsigned)((nw + 1) / 2)), dim3(WAVE), lds2, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
+        HIP_TRY(hipGetLastError());
+        return ARB_OK;
+    }
     if (wv == 4)
         hipLaunchKernelGGL((arb_gsw_kernel<T, 4>), dim3((unsigned)nw), dim3(WAVE), lds, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
     else
@@ -2878,7 +3123,7 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
         sio.mode = 2 | (k > 0 ? 1 : 0);
         // (kernel k finishes step k-1 with dts[k-1], then builds step k with dts[k])
         rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, dts ? dts + k : nullptr, st);
-        if (rc == ARB_OK) rc = launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st);
+        if (rc == ARB_OK) rc = launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st, M->packable && env_int("ARB_GSW_PACK", 0) != 0);
     }
     if (rc == ARB_OK) {
         sio.mode = 1;                                      // apply the last step's forces, write cforce

@@ -305,3 +305,33 @@ def test_bench_mpc_shape():
     assert r["config"]["worlds_per_gpu"] == 256 and r["episode_steps"] == 32 and r["config"]["steps_per_launch"] == 32
     assert "MPC" in r["config"]["workload"]
     assert r["state_finite"] and r["value"] > 1e5
+
+
+# ---------------------------------------------------------------------------
+# two worlds per wavefront in the Gauss-Seidel sweeps (gs_stage2) == one world per wavefront, bit for bit
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,B", [("human36_c4", 1001), ("human36_c8", 301)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
+    """The packed sweep kernel of the split execution (ARB_GSW_PACK=1: worlds 2p and 2p+1 share a wavefront, a stage of
+    the local solve runs when either world needs it, results are taken lane by lane) against the one-world sweep kernel
+    and against the fused kernel: same forces, velocities and positions bit for bit over a whole falling episode, odd
+    batch sizes included (the last wavefront holds one world)."""
+    from arboris_python_amd import synth
+    from arboris_python_amd.batch import BatchedWorlds
+    m, _, _ = load_model(name)
+    bw = BatchedWorlds(m)
+    q, dq = synth.world_states(m, range(B), "standing", 11, drop=0.03, vel=0.2)
+    q[:, 7] -= 0.01
+    res = {}
+    for mode in ("fused", "wave", "pack"):
+        monkeypatch.setenv("ARB_GSW_PACK", "1" if mode == "pack" else "0")
+        tq, tdq = bw.to_device(q, dq, dtype)
+        cf = bw.new_cforce(B, dtype)
+        bw.step(tq, tdq, 5e-3, 40, cforce=cf, split=("wave" if mode != "fused" else False))
+        torch.cuda.synchronize()
+        res[mode] = (tq, tdq, cf)
+    assert float(res["fused"][2][:, :, 3].max()) > 100.                      # contacts engaged, sliding included
+    for mode in ("wave", "pack"):
+        assert all(torch.equal(a, b) for a, b in zip(res["fused"], res[mode])), mode
+    bw.close()
