@@ -55,7 +55,7 @@
 #ifdef ARB_WAVES_PER_EU
 #define ARB_WAVES(CM) ARB_WAVES_PER_EU
 #else
-#define ARB_WAVES(CM) ((CM) == 2 ? 3 : 2)
+#define ARB_WAVES(CM) ((CM) == 2 ? 3 : 2)      // (CM = 3, the packed build: two)
 #endif
 #ifndef GS_SWEEPS
 #define GS_SWEEPS 20            // core.py:929-931 (overridable only for timing experiments: the reference's count is 20)
@@ -65,6 +65,9 @@
 #endif
 #ifndef ARB_GS_F64
 #define ARB_GS_F64 0            // 1: the Gauss-Seidel sweeps of float32 worlds in float64 arithmetic (measured, not the default: DESIGN.md 2)
+#endif
+#ifndef ARB_PACK_MIN_ROUNDS
+#define ARB_PACK_MIN_ROUNDS 4   // the packed build is picked from this many pairs of worlds per wave slot on (16384 worlds on an MI355X: measured +2 %; +0..2 % at 8192, -8 % at 4096, where the three-wave build wins)
 #endif
 #ifndef ARB_ROWS_SPLIT
 #define ARB_ROWS_SPLIT 1
@@ -104,6 +107,9 @@
 
 struct Layout {      // offsets in elements of T inside the wave's LDS block
     int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, ci, total;
+    // packed build (two worlds per wavefront, CM = 3): world A's state and the results of its phases A-D wait here while
+    // world B goes through the same phases in the arrays above; `sb*`: world B's state while world A is in those arrays
+    int sa_q, sa_dq, sa_am, sa_cd, sa_vv, sa_ff, sa_ff0, sa_rt, sb_q, sb_dq, sb_ff;
     int lscan;       // phase B forms the subtree sums from a prefix table in LDS (small trees) instead of a DPP scan
     int ndol;        // rows of the stacked constraint system (host side: does the model carry constraint forces?)
 };
@@ -135,6 +141,7 @@ struct DevModel {
     int *status;     // host-visible word (mapped pinned memory) that a launch raises when it gives up waiting in the work queue
     Layout lay;      // LDS offsets of this precision's kernels: re-read per phase instead of held in SGPRs for the whole launch
     Layout lay3;     // ... of the three-wave kernels (two-pass prefix table: a smaller bd region)
+    Layout layp;     // ... of the packed kernels (two worlds per wavefront: the two-pass layout + the stash)
     double up[3];
     T grav[3];
     const T *pd_kp, *pd_kd, *pd_tau0;         // [n][n], [n][n], [n] (merged PD controllers; rarely present)
@@ -840,6 +847,11 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
 // bit 1 = every other optional input (per-world PD, logs, split execution, per-step dt, flags); 3 = all of them.
 // CM 1 = phase C eliminates on the matrix cores (float32 only; ARB_STEP_MFMA_ELIM), 0 = on the vector ALU;
 // CM 2 = as 0, compiled for three waves per SIMD (float32, one column set, tiles up to 48 rows; see ARB_WAVES).
+// CM 3 = the PACKED build (round 3): a wavefront owns TWO worlds (2 p, 2 p + 1).  Phases A-D run for world A, whose
+// constraint-space system, solution columns and state then wait in a stash, then for world B; the Gauss-Seidel sweeps
+// -- one dependent chain in which one quad of lanes works -- run for both worlds at once (gs_stage2); phase E follows
+// for each.  Same arithmetic world by world: bit-identical to the one-world kernels.  Float32, one column set, models
+// whose constraints are all SoftFingerContacts with eps = (1,1,1) and fit half a wavefront (nc <= 8), FEAT <= 1.
 // (float64 worlds on the 64-row tile -- snake-64 -- need 43 KB of LDS per wave: three waves per CU, less than one per
 // SIMD, so their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
@@ -852,6 +864,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     static_assert(MODE == 0 || FEAT == 3, "the inspect kernels take every input");
     static_assert(CM != 1 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
     static_assert(CM != 2 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && std::is_same<T, float>::value), "three-wave build: float32, one column set");
+    static_assert(CM != 3 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && FEAT <= 1 && std::is_same<T, float>::value), "packed build: float32, one column set, plain inputs");
+    constexpr bool PACK = (CM == 3);
     constexpr bool FEAT_EXT = (FEAT & 1) != 0, FEAT_ALL = (FEAT & 2) != 0;
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
     const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
@@ -885,6 +899,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     int *const queue = (MODE == 0) ? queue_in : nullptr;
     T *gq = gq_in, *gdq = gdq_in, *gcforce = gcforce_in;
     long w = blockIdx.x;
+    const long nunits = (CM == 3) ? (nworlds + 1) / 2 : nworlds;      // work units: worlds, or pairs of worlds
     int step_lo = 0, step_hi = nsteps, qitem_chunk = 0;
     for (;;) {     // one pass per work item; a single pass without the queue
     if (queue != nullptr) {
@@ -895,9 +910,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         // length of the last items
         const int nhead = nsteps - queue_tail, nbig = (nhead + queue_chunk - 1) / queue_chunk;
         const int nchunks = nbig + queue_tail;
-        if ((long)item >= nworlds * (long)nchunks) return;
-        w = item % (int)nworlds;
-        qitem_chunk = item / (int)nworlds;
+        if ((long)item >= nunits * (long)nchunks) return;
+        w = item % (int)nunits;
+        qitem_chunk = item / (int)nunits;
         if (qitem_chunk < nbig) {
             step_lo = qitem_chunk * queue_chunk;
             step_hi = step_lo + queue_chunk < nhead ? step_lo + queue_chunk : nhead;
@@ -927,9 +942,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         // (the state pointers are `restrict` kernel arguments: hand the compiler pointers it knows nothing about, so
         // that no load of the state is scheduled above the acquire)
         asm volatile("" : "+s"(gq), "+s"(gdq), "+s"(gcforce));
-    } else if (w >= nworlds) {
+    } else if (w >= nunits) {
         return;
     }
+    // (packed build: `w` is the pair, its worlds are w0 = 2 w and w0 + 1; otherwise w0 = w)
+    const long w0 = PACK ? 2 * w : w;
+    const bool two = PACK && (w0 + 1 < nworlds);
     T *lds = reinterpret_cast<T *>(arb_lds_raw);
     T *qs, *dqs, *qd, *BD, *SC, *CD, *RT, *AM, *VV, *FF, *FF0, *WORK;
     double *PD;
@@ -937,7 +955,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 // (after the first global store the compiler no longer proves the model unclobbered and fetches it with vector
 // loads: readfirstlane puts the wave-uniform values back into SGPRs)
 #define ARB_UNI(x) __builtin_amdgcn_readfirstlane(x)
-#define ARB_LDS_POINTERS() do { const Layout &lay_ = (CM == 2) ? mp->lay3 : mp->lay;                                                              \
+#define ARB_LAY() ((CM == 3) ? mp->layp : (CM == 2) ? mp->lay3 : mp->lay)
+#define ARB_LDS_POINTERS() do { const Layout &lay_ = ARB_LAY();                                                              \
         qs = lds + ARB_UNI(lay_.q); dqs = lds + ARB_UNI(lay_.dq); qd = lds + ARB_UNI(lay_.qd); BD = lds + ARB_UNI(lay_.bd); SC = lds + ARB_UNI(lay_.sc);               \
         PD = reinterpret_cast<double *>(lds + ARB_UNI(lay_.pd)); CD = lds + ARB_UNI(lay_.cd); RT = lds + ARB_UNI(lay_.rt); AM = lds + ARB_UNI(lay_.am);       \
         VV = lds + ARB_UNI(lay_.vv); FF = lds + ARB_UNI(lay_.ff); FF0 = lds + ARB_UNI(lay_.ff0); WORK = lds + ARB_UNI(lay_.work);                             \
@@ -968,14 +987,30 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (queue != nullptr) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
     };
-    for (int i = lane; i < nq; i += WAVE) qs[i] = ldg(gq + w * nq + i);
-    dqs[lane] = (lane < n) ? ldg(gdq + w * n + lane) : T(0);
-    for (int i = lane; i < ndol; i += WAVE) {
-        T f = T(0);
-        if (gcforce != nullptr) f = ldg(gcforce + w * ndol + i);
-        FF[i] = f;
+    // (packed build: world A = w0 into the stash, world B = w0 + 1 into the working arrays)
+    T *SAq = nullptr, *SAdq = nullptr, *SAff = nullptr;
+    if constexpr (PACK) { const Layout &lp = mp->layp; SAq = lds + ARB_UNI(lp.sa_q); SAdq = lds + ARB_UNI(lp.sa_dq); SAff = lds + ARB_UNI(lp.sa_ff); }
+    {
+        T *q_to = PACK ? SAq : qs, *dq_to = PACK ? SAdq : dqs, *ff_to = PACK ? SAff : FF;
+        for (int i = lane; i < nq; i += WAVE) q_to[i] = ldg(gq + w0 * nq + i);
+        dq_to[lane] = (lane < n) ? ldg(gdq + w0 * n + lane) : T(0);
+        for (int i = lane; i < ndol; i += WAVE) {
+            T f = T(0);
+            if (gcforce != nullptr) f = ldg(gcforce + w0 * ndol + i);
+            ff_to[i] = f;
+        }
     }
-    const T ext_k = (gext != nullptr && lane < n) ? gext[w * n + lane] : T(0);
+    if (PACK && two) {
+        for (int i = lane; i < nq; i += WAVE) qs[i] = ldg(gq + (w0 + 1) * nq + i);
+        dqs[lane] = (lane < n) ? ldg(gdq + (w0 + 1) * n + lane) : T(0);
+        for (int i = lane; i < ndol; i += WAVE) {
+            T f = T(0);
+            if (gcforce != nullptr) f = ldg(gcforce + (w0 + 1) * ndol + i);
+            FF[i] = f;
+        }
+    }
+    const T ext_kA = (gext != nullptr && lane < n) ? gext[w0 * n + lane] : T(0);
+    const T ext_kB = (PACK && two && gext != nullptr && lane < n) ? gext[(w0 + 1) * n + lane] : T(0);
     if (lane < nc) {
         const int b1 = mp->cbody[lane], b0 = mp->cbody0[lane];
         const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
@@ -1017,7 +1052,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 
     // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
     // columns in RT, then every joint integrates its position.
-    auto integrate_from_rt = [&](bool with_forces) {
+    auto integrate_on = [&](const T *RT, const T *FF, const T *FF0, T *qs, T *dqs, bool with_forces) {
         T vnew = T(0);
         if (lane < n) {
             vnew = RT[lane];
@@ -1048,6 +1083,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         }
         WAVE_SYNC();
     };
+    auto integrate_from_rt = [&](bool with_forces) { integrate_on(RT, FF, FF0, qs, dqs, with_forces); };
 
     if (MODE == 0 && (sio.mode & 1)) {
         // split execution: finish the previous step with the forces arb_gsw_kernel left in sio.f
@@ -1061,6 +1097,29 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     if (MODE == 0 && sio.mode != 0 && !(sio.mode & 2)) step_hi = step_lo;      // apply only
 
     for (int step = step_lo; step < step_hi; ++step) {
+        T gf0 = T(0);          // controllers' generalized force (inspect output)
+        // Packed build: phases A-D for world A (isub 0), then for world B (isub 1), in the same working arrays; each
+        // world's state is copied in before (world B's is parked meanwhile), world A's results are stashed after.
+        const int nsub = (PACK && two) ? 2 : 1;
+        for (int isub = 0; isub < nsub; ++isub) {
+        if constexpr (PACK) {
+            ARB_OPAQUE_LANE();
+            const Layout &lp = mp->layp;
+            T *SBq = lds + ARB_UNI(lp.sb_q), *SBdq = lds + ARB_UNI(lp.sb_dq), *SBff = lds + ARB_UNI(lp.sb_ff);
+            T *Sq = lds + ARB_UNI(lp.sa_q), *Sdq = lds + ARB_UNI(lp.sa_dq), *Sff = lds + ARB_UNI(lp.sa_ff);
+            if (isub == 0 && two) {        // park world B's state
+                for (int i = lane; i < nq; i += WAVE) SBq[i] = qs[i];
+                SBdq[lane] = dqs[lane];
+                for (int i = lane; i < ndol; i += WAVE) SBff[i] = FF[i];
+            }
+            WAVE_SYNC();
+            const T *fq = isub == 0 ? Sq : SBq, *fdq = isub == 0 ? Sdq : SBdq, *fff = isub == 0 ? Sff : SBff;
+            for (int i = lane; i < nq; i += WAVE) qs[i] = fq[i];
+            dqs[lane] = fdq[lane];
+            for (int i = lane; i < ndol; i += WAVE) FF[i] = fff[i];
+            WAVE_SYNC();
+        }
+        const T ext_k = (PACK && isub == 1) ? ext_kB : ext_kA;
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
@@ -1454,7 +1513,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // which takes the place of the per-body blocks: every lane has its own block in registers by now.
             // (the three-wave kernels pass the accumulators through a half-size table in two passes -- less LDS, more
             // registers held across the first pass --, the two-wave kernels through a full table in one)
-            constexpr bool TWO_PASS = (CM == 2);
+            constexpr bool TWO_PASS = (CM == 2 || CM == 3);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
             const bool lscan = LSCAN_OK && mp->lay.lscan;
             const bool use_table = lscan && TWO_PASS;
@@ -1859,7 +1918,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     RT[(1 + 4 * c) * RS + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
         }
         // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
-        T gf0 = rhsG + ext_k;          // controllers' generalized force (inspect output)
+        gf0 = rhsG + ext_k;
         T rhs = rhsM + ext_k;          // gforce - (N + B + Z_pd) gvel
         if (pwd.kp != nullptr) {
             // per-world diagonal gains and targets (arb_step_ex): tau0 = kp (qdes - q) + kd dqdes, Z += dt kp + kd
@@ -2221,6 +2280,20 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             if (dbg.c_vel != nullptr) for (int i = lane; i < ndol; i += WAVE) dbg.c_vel[(long)w * ndol + i] = VV[i];
         }
 
+        if constexpr (PACK) {
+            if (isub == 0) {               // stash world A: its system, its solution columns, the forces
+                ARB_OPAQUE_LANE();
+                const Layout &lp = mp->layp;
+                T *Sam = lds + ARB_UNI(lp.sa_am), *Scd = lds + ARB_UNI(lp.sa_cd), *Svv = lds + ARB_UNI(lp.sa_vv);
+                T *Sff = lds + ARB_UNI(lp.sa_ff), *Sff0 = lds + ARB_UNI(lp.sa_ff0), *Srt = lds + ARB_UNI(lp.sa_rt);
+                for (int i = lane; i < ndol * ndol; i += WAVE) Sam[i] = AM[i];
+                for (int i = lane; i < nc * CD_STRIDE; i += WAVE) Scd[i] = CD[i];
+                for (int i = lane; i < ndol; i += WAVE) { Svv[i] = VV[i]; Sff[i] = FF[i]; Sff0[i] = FF0[i]; }
+                for (int i = lane; i < (1 + ndol) * RS; i += WAVE) Srt[i] = RT[i];
+                WAVE_SYNC();
+            }
+        }
+        }   // isub (one pass unless packed)
         if (MODE == 0 && (sio.mode & 2)) {
             // split execution: hand the constraint-space system to arb_gsw_kernel and stop here;
             // the next launch applies the forces (integrate_from_rt above)
@@ -2241,8 +2314,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (do_constraints) {
             ARB_STAMP(5);
             ARB_CSTAMP(7);
-            using GSG = std::conditional_t<(ARB_GS_F64 != 0) && std::is_same<T, float>::value, double, T>;
-            gs_stage<T, MODE, GSG>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
+            if constexpr (PACK) {
+                const Layout &lp = mp->layp;
+                gs_stage2<T>(mp, lane, nc, ndol, dt, lds + ARB_UNI(lp.sa_am), lds + ARB_UNI(lp.sa_cd), lds + ARB_UNI(lp.sa_vv),
+                             lds + ARB_UNI(lp.sa_ff), AM, CD, VV, FF, WORK, two);
+            } else {
+                using GSG = std::conditional_t<(ARB_GS_F64 != 0) && std::is_same<T, float>::value, double, T>;
+                gs_stage<T, MODE, GSG>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
+            }
         }
 
         // ================= phase E: new velocity, integrate ==================
@@ -2260,17 +2339,34 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             if (dbg.c_force != nullptr)
                 for (int i = lane; i < ndol; i += WAVE) dbg.c_force[w * ndol + i] = FF[i];
         }
-        integrate_from_rt(do_constraints);
+        if constexpr (PACK) {
+            const Layout &lp = mp->layp;
+            integrate_on(lds + ARB_UNI(lp.sa_rt), lds + ARB_UNI(lp.sa_ff), lds + ARB_UNI(lp.sa_ff0), lds + ARB_UNI(lp.sa_q),
+                         lds + ARB_UNI(lp.sa_dq), do_constraints);
+            if (two) integrate_from_rt(do_constraints);
+        } else {
+            integrate_from_rt(do_constraints);
+        }
     }
 
     // ---- store state -------------------------------------------------------
     ARB_OPAQUE_LANE();
     ARB_STAMP(7);
     if (MODE == 0) {
-        for (int i = lane; i < nq; i += WAVE) stg(gq + w * nq + i, qs[i]);
-        if (lane < n) stg(gdq + w * n + lane, dqs[lane]);
-        if (gcforce != nullptr && !(sio.mode & 2))
-            for (int i = lane; i < ndol; i += WAVE) stg(gcforce + w * ndol + i, FF[i]);
+        if constexpr (PACK) {
+            const Layout &lp = mp->layp;
+            const T *Sq = lds + ARB_UNI(lp.sa_q), *Sdq = lds + ARB_UNI(lp.sa_dq), *Sff = lds + ARB_UNI(lp.sa_ff);
+            for (int i = lane; i < nq; i += WAVE) stg(gq + w0 * nq + i, Sq[i]);
+            if (lane < n) stg(gdq + w0 * n + lane, Sdq[lane]);
+            if (gcforce != nullptr) for (int i = lane; i < ndol; i += WAVE) stg(gcforce + w0 * ndol + i, Sff[i]);
+        }
+        const long wm = PACK ? w0 + 1 : w;         // the world in the working arrays
+        if (!PACK || two) {
+            for (int i = lane; i < nq; i += WAVE) stg(gq + wm * nq + i, qs[i]);
+            if (lane < n) stg(gdq + wm * n + lane, dqs[lane]);
+            if (gcforce != nullptr && !(sio.mode & 2))
+                for (int i = lane; i < ndol; i += WAVE) stg(gcforce + wm * ndol + i, FF[i]);
+        }
     } else {
         if (dbg.q_next != nullptr) for (int i = lane; i < nq; i += WAVE) dbg.q_next[w * nq + i] = qs[i];
         if (dbg.dq_next != nullptr && lane < n) dbg.dq_next[w * n + lane] = dqs[lane];
@@ -2485,7 +2581,8 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     const int tail = std::max(0, std::min(env_int("ARB_QUEUE_TAIL", 4), nsteps - 1));
     const int spin_cap = env_int("ARB_QUEUE_SPIN_CAP", 1 << 24);
     int *queue = nullptr;
-    unsigned grid = (unsigned)nw;
+    const long units = (CM == 3) ? (nw + 1) / 2 : nw;        // work units: worlds, or pairs of worlds (packed build)
+    unsigned grid = (unsigned)units;
     constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);     // (see the kernel)
     if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 &&
         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
@@ -2495,8 +2592,8 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
         int dev = -1;
         (void)hipGetDevice(&dev);
         if (slots_lds != lds || slots_dev != dev) { slots = wave_slots(kern, lds); slots_lds = lds; slots_dev = dev; }
-        if (slots > 0 && nw > slots) {
-            const size_t bytes = (size_t)(1 + nw) * sizeof(int);
+        if (slots > 0 && units > slots) {
+            const size_t bytes = (size_t)(1 + units) * sizeof(int);
             if (arb_scratch_alloc(reinterpret_cast<void **>(&queue), bytes, st) == hipSuccess) {
                 if (hipMemsetAsync(queue, 0, bytes, st) != hipSuccess) {
                     g_hip_err = "hipMemsetAsync(queue)";
@@ -2505,7 +2602,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
                 }
                 // resident wavefronts that loop over items -- or one workgroup per item, looped by the dispatcher
                 const int nbig = (nsteps - tail + chunk - 1) / chunk;
-                grid = QUEUE_LOOP ? (unsigned)slots : (unsigned)(nw * (long)(nbig + tail));
+                grid = QUEUE_LOOP ? (unsigned)slots : (unsigned)(units * (long)(nbig + tail));
             } else {
                 (void)hipGetLastError();
                 queue = nullptr;
@@ -2545,6 +2642,8 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 3, 1>(ARB_LAUNCH_ONE_AR
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 #endif
 #endif
 #else
@@ -2566,7 +2665,9 @@ ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_
 #define ARB_EXTERN_TILE_W3(NM)                                                          \
     extern template int launch_one<float, NM, 1, 0, 0, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<float, NM, 1, 0, 1, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
-    extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));
+    extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));
 ARB_EXTERN_TILE_W3(16) ARB_EXTERN_TILE_W3(32) ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
 #undef ARB_EXTERN_TILE_W3
 ARB_EXTERN_TILE(float, 16) ARB_EXTERN_TILE(float, 32) ARB_EXTERN_TILE(float, 44) ARB_EXTERN_TILE(float, 48) ARB_EXTERN_TILE(float, 64)
@@ -2605,7 +2706,7 @@ struct arb_model {
     DevModel<double> *dd_dev;
     bool packable = false;         // every constraint a SoftFingerContact with eps = (1,1,1), at most eight: two worlds per wavefront in the sweeps
     int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
-    Layout lf, lf3, ld;            // LDS layouts: float32 two-wave kernels, float32 three-wave kernels, float64
+    Layout lf, lf3, lfp, ld;       // LDS layouts: float32 two-wave kernels, three-wave kernels, packed kernels; float64
 };
 
 // ARB_ERR_STALLED when an earlier launch of the handle raised the status word (host memory: no synchronisation)
@@ -2658,7 +2759,8 @@ static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool 
     return std::max(std::max(std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double)), tb), al(std::max(ndol * ndol, 4)));
 }
 
-static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems, bool two_pass = false) {
+static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems, bool two_pass = false,
+                          bool pack = false) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
@@ -2676,6 +2778,20 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     {
         const int words = CI_STRIDE * std::max(nc, 1);                      // int32 words, see CI_STRIDE
         L.ci = o; o += al(elems_per_double == 2 ? words : (words + 1) / 2);     // (float: one word per element; double: two)
+    }
+    L.sa_q = L.sa_dq = L.sa_am = L.sa_cd = L.sa_vv = L.sa_ff = L.sa_ff0 = L.sa_rt = L.sb_q = L.sb_dq = L.sb_ff = 0;
+    if (pack) {
+        L.sa_rt = o; o += (1 + ndol) * rs;
+        L.sa_am = o; o += al(std::max(ndol * ndol, 4));
+        L.sa_cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
+        L.sa_vv = o; o += al(std::max(ndol, 4));
+        L.sa_ff = o; o += al(std::max(ndol, 4));
+        L.sa_ff0 = o; o += al(std::max(ndol, 4));
+        L.sa_q = o; o += al(nq);
+        L.sa_dq = o; o += WAVE;
+        L.sb_q = o; o += al(nq);
+        L.sb_dq = o; o += WAVE;
+        L.sb_ff = o; o += al(std::max(ndol, 4));
     }
     L.total = o;
     L.ndol = ndol;
@@ -2932,7 +3048,8 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
     int tot;
     M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
     M->lf3 = M->df.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true);
-    M->ld = M->dd.lay = M->dd.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
+    M->lfp = M->df.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true, true);
+    M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     {
         // one blob per precision
@@ -2994,7 +3111,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // one per step, logs, torques) runs the same build and gives the same bits; ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin
     // the build (runs of different batch sizes that must agree bit for bit); ARB_FORCE_WAVES=2|3 in the environment
     // overrides both (development).
-    bool w3 = false;
+    bool w3 = false, pack = false;
     if (MODE == 0 && std::is_same<T, float>::value && M->nsets == 1 && M->nmax <= 48 && !mfma) {
         static thread_local int cus_dev = -1, cus = 0;
         if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
@@ -3012,8 +3129,21 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         const int force = env_int("ARB_FORCE_WAVES", 0);
         if (force == 2) w3 = false;
         if (force == 3) w3 = true;
+        // Two worlds per wavefront (the packed build: bit-identical results, the sweeps of both worlds in one instruction
+        // stream): models whose constraints are all SoftFingerContacts with eps = (1,1,1), plain inputs or user torques,
+        // a stash that still leaves eight wavefronts per CU, and a batch large enough that pairs of worlds fill and
+        // balance the wave slots.  ARB_FORCE_PACK=0|1 in the environment overrides the batch-size rule (development).
+        if (M->packable && noopt && M->lfp.lscan) {
+            const long ldsp = (long)M->lfp.total * (long)sizeof(T) + pad;
+            const long sp = (long)cus * std::min(8l, (160 * 1024) / ldsp);
+            pack = sp >= s2 && (nw + 1) / 2 >= ARB_PACK_MIN_ROUNDS * sp;
+            const int fp = env_int("ARB_FORCE_PACK", -1);
+            if (fp == 0) pack = false;
+            if (fp == 1) pack = true;
+            if (flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3)) pack = false;      // (a pinned build is a pinned build)
+        }
     }
-#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 2 ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
+#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : (CMV) == 2 ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
@@ -3021,6 +3151,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     if constexpr (std::is_same<T, float>::value) {
         if (M->nmax == 44 && M->nsets == 1) {
             if constexpr (MODE == 0) {
+                if (pack) return plain ? ONE_(44, 1, 0, 3) : ONE_(44, 1, 1, 3);
                 if (w3 && plain) return ONE_(44, 1, 0, 2);
                 if (w3 && noopt) return ONE_(44, 1, 1, 2);
                 if (plain) return ONE(44, 1, 0);
@@ -3048,6 +3179,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
             if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 3, 1) : ONE_(NM, 1, 3, 1);                  \
         }                                                                                              \
         if constexpr (MODE == 0 && std::is_same<T, float>::value && NM <= 48) {                        \
+            if (pack) return plain ? ONE_(NM, 1, 0, 3) : ONE_(NM, 1, 1, 3);                            \
             if (w3) return plain ? ONE_(NM, 1, 0, 2) : noopt ? ONE_(NM, 1, 1, 2) : ONE_(NM, 1, 3, 2);  \
         }                                                                                              \
         if constexpr (MODE == 0) {                                                                     \

@@ -335,3 +335,41 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
     for mode in ("wave", "pack"):
         assert all(torch.equal(a, b) for a, b in zip(res["fused"], res[mode])), mode
     bw.close()
+
+
+@pytest.mark.parametrize("name,cases", [
+    ("human36_c4", ((701, 40, False, False), (5001, 24, False, False), (2, 12, False, True), (1, 12, False, False),
+                    (333, 12, True, True), (9001, 13, False, True))),
+    ("human36_c8", ((257, 24, False, False),)),           # 32 constraint rows: each world fills its half of the wavefront
+])
+def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, cases):
+    """The packed build of the step kernel (two worlds per wavefront: phases A-D world after world, the Gauss-Seidel
+    sweeps of both at once, ARB_FORCE_PACK=1) against the one-world builds (ARB_FORCE_PACK=0): states and forces bit
+    for bit -- one workgroup per pair and the work queue over pairs, odd batch sizes, a lone world, user torques (the
+    FEAT 1 kernel), one launch per step."""
+    from arboris_python_amd import synth
+    from arboris_python_amd.batch import BatchedWorlds
+    m, _, _ = load_model(name)
+    bw = BatchedWorlds(m)
+    for B, T, per_step, ext in cases:
+        q, dq = synth.world_states(m, range(B), "standing", 31, drop=0.03, vel=0.2)
+        q[:, 7] -= 0.012
+        tau = torch.as_tensor(np.random.default_rng(5).uniform(-0.05, 0.05, size=(B, m.ndof)), dtype=torch.float32, device=bw.device)
+        tau[:, :6] = 0.
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("ARB_FORCE_PACK", mode)
+            tq, tdq = bw.to_device(q, dq, torch.float32)
+            cf = bw.new_cforce(B, torch.float32)
+            kw = dict(ext_gforce=tau.contiguous()) if ext else {}
+            if per_step:
+                for _ in range(T):
+                    bw.step(tq, tdq, 5e-3, 1, cforce=cf, **kw)
+            else:
+                bw.step(tq, tdq, 5e-3, T, cforce=cf, **kw)
+            torch.cuda.synchronize()
+            bw.status()
+            res[mode] = (tq, tdq, cf)
+        assert float(res["1"][2][:, :, 3].max()) > 10.
+        assert all(torch.equal(a, b) for a, b in zip(res["0"], res["1"])), (B, T, per_step, ext)
+    bw.close()
