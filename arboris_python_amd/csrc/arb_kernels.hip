@@ -3107,10 +3107,8 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
     // Two or three waves per SIMD (float32 production kernels with one column set, see ARB_WAVES)?  Three when the
-    // batch fills the extra wave slots -- by the batch size ALONE, so that every launch shape of a batch (one launch or
-    // one per step, logs, torques) runs the same build and gives the same bits; ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin
-    // the build (runs of different batch sizes that must agree bit for bit); ARB_FORCE_WAVES=2|3 in the environment
-    // overrides both (development).
+    // batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin the build; ARB_FORCE_WAVES=2|3 in the
+    // environment overrides both (development).
     bool w3 = false, pack = false;
     if (MODE == 0 && std::is_same<T, float>::value && M->nsets == 1 && M->nmax <= 48 && !mfma) {
         static thread_local int cus_dev = -1, cus = 0;
@@ -3121,8 +3119,11 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         if (s3 > s2 && s2 > 0) {
             // measured (human36 + 4 contacts, M world-steps/s, two / three waves): 2048 worlds 14.6 / 13.4, 2560: 16.6 / 13.8,
             // 3072: 16.7 / 11.6, 4096: 17.1 / 18.0, 6144: 17.6 / 18.7, 65536: 18.4 / 19.8
-            // (one launch per step, 4096 worlds: 10.4 / 9.7 -- two rounds of workgroups either way --; 6144: 12.2 / 12.1)
-            w3 = 3 * nw >= 4 * s3;
+            // one launch per step (no queue): three waves when they save a round of workgroups (4096 worlds: 10.4 / 9.7,
+            // two rounds either way; 6144: 12.2 / 12.1).  (Since the library is compiled with -ffp-contract=on the builds
+            // are bit-identical, so the choice may depend on the launch shape.)
+            if (nsteps >= 2) w3 = 3 * nw >= 4 * s3;
+            else w3 = 112 * ((nw + s3 - 1) / s3) < 100 * ((nw + s2 - 1) / s2);
             if (flags & ARB_STEP_WAVES2) w3 = false;
             if (flags & ARB_STEP_WAVES3) w3 = true;
         }

@@ -105,14 +105,15 @@ enum {
                                          Measured slower than the default at every batch size: opt-in */
 #define ARB_STEP_WAVES2 64u            /* pin the float32 step kernel build: compiled for two waves per SIMD (no register spills: */
 #define ARB_STEP_WAVES3 128u           /* the faster wave) or for three (more waves in flight: the faster chip once the batch fills
-                                         them).  Default: the library picks by batch size alone (three from ~4100 worlds on an
-                                         MI355X, for models that have both builds: float32, <= 48 dofs, ndof + 1 + 4 nc <= 64).
-                                         Every launch shape of ONE build gives bit-identical results for a world (queue or
-                                         not, batch position, steps per launch, logs, torques ...); the two builds are separate
-                                         compilations of the same source and agree to rounding only (measured: one world-step in
-                                         ~200 000 differs in its last bits).  Callers that compare runs of different batch sizes
-                                         bit for bit (shards of one batch against the whole batch) pin one build; a pin the model
-                                         has no build for is ignored. */
+                                         them).  Default: the library picks by batch size and launch shape (three waves from
+                                         ~4100 worlds on an MI355X; from 16384 worlds a third build that holds TWO worlds per
+                                         wavefront), for models that have those builds: float32, <= 48 dofs, ndof + 1 + 4 nc
+                                         <= 64.  All builds execute the same float operations in the same order per world --
+                                         the library is compiled with -ffp-contract=on, so no fused multiply-add depends on how
+                                         the compiler inlined a function -- and give bit-identical results (tested across
+                                         builds, batch positions, launch shapes; tests/test_gpu_round3.py).  The pins exist
+                                         for performance experiments and as a belt for callers that compare runs bit for bit;
+                                         a pin the model has no build for is ignored. */
 #define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u)
 
 /*
