@@ -26,6 +26,7 @@ ARB_STEP_MFMA_ELIM = 16
 ARB_STEP_STATIC_WORLDS = 32
 ARB_STEP_WAVES2 = 64
 ARB_STEP_WAVES3 = 128
+ARB_STEP_ONE_WORLD = 256
 
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)
@@ -51,11 +52,17 @@ class ModelDesc(C.Structure):
 class ModelInfo(C.Structure):
     _fields_ = [("nb", C.c_int32), ("ndof", C.c_int32), ("nq", C.c_int32), ("nc", C.c_int32),
                 ("nmax", C.c_int32), ("ncols", C.c_int32), ("nsets", C.c_int32),
-                ("lds_bytes_f32", C.c_int32), ("lds_bytes_f64", C.c_int32), ("device", C.c_int32)]
+                ("lds_bytes_f32", C.c_int32), ("lds_bytes_f64", C.c_int32), ("device", C.c_int32),
+                ("forest_copies", C.c_int32)]
 
 
 INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
                   "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps", "gs_trace", "c_adm", "c_vel"]
+
+
+class StepPlan(C.Structure):
+    _fields_ = [("waves_per_simd", C.c_int32), ("worlds_per_wavefront", C.c_int32), ("feat", C.c_int32),
+                ("lds_bytes", C.c_int32), ("wave_slots", C.c_int32), ("work_queue", C.c_int32)]
 
 
 class RolloutLog(C.Structure):
@@ -75,7 +82,7 @@ class InspectOut(C.Structure):
 
 # every symbol include/arbstep.h declares (tests check they are all exported)
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
-            "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_step", "arb_step_ex", "arb_rollout",
+            "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_step_plan", "arb_step", "arb_step_ex", "arb_rollout",
             "arb_inspect"]
 # every symbol include/arbstep_hooks.h declares: host builds of the device math (unit tests, Constraint.solve)
 TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
@@ -115,6 +122,8 @@ def load():
     lib.arb_model_get_info.argtypes = [C.c_void_p, C.POINTER(ModelInfo)]
     lib.arb_model_status.restype = C.c_int
     lib.arb_model_status.argtypes = [C.c_void_p]
+    lib.arb_step_plan.restype = C.c_int
+    lib.arb_step_plan.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_uint32, C.c_int32, C.POINTER(StepPlan)]
     lib.arb_step.restype = C.c_int
     lib.arb_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int64, C.c_double, C.c_int32, C.c_uint32, C.c_void_p]

@@ -128,7 +128,7 @@ class BatchedWorlds(object):
 
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
              stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False,
-             waves=None):
+             waves=None, one_world=False):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
@@ -141,6 +141,9 @@ class BatchedWorlds(object):
         device-side queue of (chunk of steps, world) items that multi-step launches of large batches use by default.
         ``waves=2|3`` pins the float32 kernel build (ARB_STEP_WAVES2/3, include/arbstep.h): by default the library picks
         by batch size; the builds agree to rounding, each is bit-reproducible across launch shapes.
+        ``one_world=True``: one world per wavefront even for a small model (ARB_STEP_ONE_WORLD).  By default the worlds
+        of a model of at most 16 dofs share wavefronts once the batch exceeds the device's wave slots: the library
+        steps ``B // k`` worlds of a forest of ``k = self.info["forest_copies"]`` copies of the model on the same buffers.
         ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller).
         ``pd_targets=(qdes, dqdes)`` (B,ndof) each: one ProportionalDerivativeController target
         per world (controllers.py:63-158), with the model's gains, or with the per-world DIAGONAL
@@ -157,6 +160,8 @@ class BatchedWorlds(object):
         if static_worlds:
             flags |= _capi.ARB_STEP_STATIC_WORLDS
         flags |= self._waves_flag(waves)
+        if one_world:
+            flags |= _capi.ARB_STEP_ONE_WORLD
         dts = self._dt_steps(dt, nsteps, st)
         if pd_targets is None and pd_gains is None and dts is None:
             _capi.check(self._lib.arb_step(
@@ -185,7 +190,7 @@ class BatchedWorlds(object):
         _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
 
     def rollout(self, q, dq, dt, nsteps, cforce=None, ext_gforce=None, log_state=True, log_energy=True,
-                skip_constraints=False, stream=None, fused=False, split=False, waves=None):
+                skip_constraints=False, stream=None, fused=False, split=False, waves=None, one_world=False):
         """Advance ``nsteps`` steps in ONE launch and return the per-step logs an Observer
         would have recorded (state and energies at the beginning of every step):
         ``{"q": (nsteps,B,nq), "dq": (nsteps,B,ndof), "energy": (nsteps,B,2)}``."""
@@ -196,7 +201,7 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
             flags |= _capi.ARB_STEP_FUSED
-        flags |= self._split_flag(split) | self._waves_flag(waves)
+        flags |= self._split_flag(split) | self._waves_flag(waves) | (_capi.ARB_STEP_ONE_WORLD if one_world else 0)
         out = {}
         log = _capi.RolloutLog()
         if log_state:
@@ -222,6 +227,19 @@ class BatchedWorlds(object):
         a.log = C.pointer(log)
         _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
         return out
+
+    def plan(self, nworlds, nsteps=1, dtype=None, ext_gforce=False, other_inputs=False, waves=None, split=False,
+             static_worlds=False, one_world=False):
+        """Which kernel build and launch shape ``step`` would use (``arb_step_plan``): a dict with ``waves_per_simd``,
+        ``worlds_per_wavefront`` (2 = the packed build; the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``."""
+        torch = _torch()
+        code = _capi.ARB_F64 if dtype == torch.float64 else _capi.ARB_F32
+        flags = self._waves_flag(waves) | self._split_flag(split) | (_capi.ARB_STEP_STATIC_WORLDS if static_worlds else 0)
+        flags |= _capi.ARB_STEP_ONE_WORLD if one_world else 0
+        p = _capi.StepPlan()
+        _capi.check(self._lib.arb_step_plan(self._handle, code, int(nworlds), int(nsteps), flags,
+                                            3 if other_inputs else (1 if ext_gforce else 0), C.byref(p)))
+        return {k: getattr(p, k) for k, _ in _capi.StepPlan._fields_}
 
     def status(self):
         """Health of this handle's launches so far (``arb_model_status``): raises ``ArbError`` (ARB_ERR_STALLED) when a

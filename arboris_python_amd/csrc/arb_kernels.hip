@@ -2707,12 +2707,18 @@ struct arb_model {
     bool packable = false;         // every constraint a SoftFingerContact with eps = (1,1,1), at most eight: two worlds per wavefront in the sweeps
     int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
     Layout lf, lf3, lfp, ld;       // LDS layouts: float32 two-wave kernels, three-wave kernels, packed kernels; float64
+    // Small worlds: `forest_k` independent copies of the model as ONE model (copy k owns bodies k nb.., dofs k n.., position
+    // scalars k nq.., constraints k nc..), so that a batch of states [nw][nq] of this model IS a batch [nw / k][k nq] of
+    // the forest: k worlds share a wavefront's lanes.  Built by arb_model_create for models of at most 16 dofs.
+    arb_model *forest = nullptr;
+    int forest_k = 1;
 };
 
 // ARB_ERR_STALLED when an earlier launch of the handle raised the status word (host memory: no synchronisation)
 static int take_status(arb_model *M) {
     if (M->status_host == nullptr) return ARB_OK;
-    const int v = __atomic_exchange_n(M->status_host, 0, __ATOMIC_RELAXED);
+    int v = __atomic_exchange_n(M->status_host, 0, __ATOMIC_RELAXED);
+    if (M->forest && M->forest->status_host) v |= __atomic_exchange_n(M->forest->status_host, 0, __ATOMIC_RELAXED);
     return v != 0 ? ARB_ERR_STALLED : ARB_OK;
 }
 
@@ -2927,7 +2933,36 @@ extern "C" const char *arb_last_hip_error(void) { return g_hip_err.c_str(); }
 
 static const int kNmaxChoices[] = {16, 32, 44, 48, 64};    // 44: human36 (42 dofs) wastes 2 rows instead of 6
 
+static int forest_create(const arb_model_desc *d, int K, int device, arb_model **out);
+
+// How many copies of a small model share a wavefront (0 or 1: none).  Measured on an MI355X (tools/forest_probe.py, 40 320
+// worlds x 64 steps, M world-steps/s): simplearm (3 dofs) float32 63 alone, 288 with 5 copies (still the 16-row tile), 552
+// with 10 (32-row tile), 575 with 15 (48 rows), 242 with 21 (64 rows); float64 97 / 385 / 411 / 345 / 103; the 15-dof
+// free snake 50 alone, 87 as a pair; ball and socket (6 dofs, 1 constraint) 57 alone, 208 with 5 copies, 197 with 7 (two
+// column sets).  Hence: as many copies as fit the 32-row tile with ONE set of columns.  ARB_FOREST=0 in the environment
+// turns the forest off, ARB_FOREST=k asks for k copies (development).
+static int forest_copies(int nb, int n, int nc) {
+    const int want = env_int("ARB_FOREST", -1);
+    if (want == 0 || want == 1) return 1;
+    int K = 1;
+    for (int k = 2; k <= WAVE; ++k) {
+        const bool fits = k * nb <= WAVE && k * nc * ARB_MAXDOL <= WAVE &&
+                          (want > 1 ? (k * n <= WAVE && k * n + 1 + ARB_MAXDOL * k * nc <= 2 * WAVE)
+                                    : (k * n <= 32 && k * n + 1 + ARB_MAXDOL * k * nc <= WAVE));
+        if (!fits) break;
+        K = k;
+        if (want > 1 && k == want) break;
+    }
+    return K;
+}
+
+static int model_create(const arb_model_desc *d, int device, arb_model **out, bool with_forest);
+
 extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model **out) {
+    return model_create(d, device, out, true);
+}
+
+static int model_create(const arb_model_desc *d, int device, arb_model **out, bool with_forest) {
     if (d == nullptr || out == nullptr) return ARB_ERR_INVALID;
     *out = nullptr;
     if (d->abi_version != ARB_ABI_VERSION) return ARB_ERR_INVALID;
@@ -3067,8 +3102,83 @@ extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model *
         }
         M->df_dev = static_cast<DevModel<float> *>(pf); M->dd_dev = static_cast<DevModel<double> *>(pd);
     }
+    if (with_forest) {
+        const int K = forest_copies(nb, n, nc);
+        if (K > 1) {
+            // (a forest the device step cannot take is not an error of the model: it then runs one world per wavefront)
+            arb_model *F = nullptr;
+            const int frc = forest_create(d, K, device, &F);
+            if (frc == ARB_OK) { M->forest = F; M->forest_k = K; }
+            else if (frc == ARB_ERR_HIP || frc == ARB_ERR_NOMEM) { arb_model_destroy(M); return frc; }
+        }
+    }
     *out = M;
     return ARB_OK;
+}
+
+// K copies of the described world as one description (see arb_model::forest), handed to model_create.
+static int forest_create(const arb_model_desc *d, int K, int device, arb_model **out) {
+    const int nb = d->nb, n = d->ndof, nq = d->nq, nc = d->nc;
+    arb_model_desc f = *d;
+    f.nb = K * nb; f.ndof = K * n; f.nq = K * nq; f.nc = K * nc;
+    // index arrays: entries >= 0 shift by k * step; everything else is repeated
+    auto reps_i = [&](const int32_t *src, int count, int step) {
+        std::vector<int32_t> v;
+        if (!src) return v;
+        v.resize((size_t)K * count);
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < count; ++i) v[(size_t)k * count + i] = (step > 0 && src[i] >= 0) ? src[i] + k * step : src[i];
+        return v;
+    };
+    auto reps_d = [&](const double *src, int count) {
+        std::vector<double> v;
+        if (!src) return v;
+        v.resize((size_t)K * count);
+        for (int k = 0; k < K; ++k) std::copy(src, src + count, v.begin() + (size_t)k * count);
+        return v;
+    };
+    auto ptr_i = [](const std::vector<int32_t> &v) { return v.empty() ? nullptr : v.data(); };
+    auto ptr_d = [](const std::vector<double> &v) { return v.empty() ? nullptr : v.data(); };
+    const auto parent = reps_i(d->parent, nb, nb), jtype = reps_i(d->jtype, nb, 0), weighted = reps_i(d->weighted, nb, 0);
+    std::vector<int32_t> dof_off2((size_t)K * nb), q_off2((size_t)K * nb);
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < nb; ++i) { dof_off2[(size_t)k * nb + i] = d->dof_off[i] + k * n; q_off2[(size_t)k * nb + i] = d->q_off[i] + k * nq; }
+    const auto H_pr = reps_d(d->H_pr, 16 * nb), H_cn = reps_d(d->H_cn, 16 * nb), mass = reps_d(d->mass, 36 * nb),
+               visc = reps_d(d->visc, 36 * nb);
+    f.parent = ptr_i(parent); f.jtype = ptr_i(jtype); f.dof_off = dof_off2.data(); f.q_off = q_off2.data();
+    f.weighted = ptr_i(weighted);
+    f.H_pr = ptr_d(H_pr); f.H_cn = ptr_d(H_cn); f.mass = ptr_d(mass); f.visc = ptr_d(visc);
+    // merged PD controllers: block-diagonal gain matrices
+    std::vector<double> kp, kd, tau0;
+    if (d->pd_kp) {
+        const size_t N = (size_t)K * n;
+        kp.assign(N * N, 0.); kd.assign(N * N, 0.); tau0.assign(N, 0.);
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < n; ++i) {
+                for (int j = 0; j < n; ++j) {
+                    kp[((size_t)k * n + i) * N + (size_t)k * n + j] = d->pd_kp[(size_t)i * n + j];
+                    kd[((size_t)k * n + i) * N + (size_t)k * n + j] = d->pd_kd ? d->pd_kd[(size_t)i * n + j] : 0.;
+                }
+                tau0[(size_t)k * n + i] = d->pd_tau0 ? d->pd_tau0[i] : 0.;
+            }
+        f.pd_kp = kp.data(); f.pd_kd = kd.data(); f.pd_tau0 = tau0.data();
+    }
+    const auto ctype = reps_i(d->ctype, nc, 0), c_enabled = reps_i(d->c_enabled, nc, 0), c_geom = reps_i(d->c_geom, nc, 0),
+               c_body = reps_i(d->c_body, nc, nb), c_body0 = reps_i(d->c_body0, nc, nb);
+    std::vector<int32_t> c_dof = reps_i(d->c_dof, nc, 0);
+    if (d->c_dof)
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < nc; ++c) c_dof[(size_t)k * nc + c] = d->c_dof[c] >= 0 ? d->c_dof[c] + k * n : d->c_dof[c];
+    const auto c_local = reps_d(d->c_local, 3 * nc), c_radius = reps_d(d->c_radius, nc), c_radius0 = reps_d(d->c_radius0, nc),
+               c_half = reps_d(d->c_half, 3 * nc), c_plane = reps_d(d->c_plane, 4 * nc), c_mu = reps_d(d->c_mu, nc),
+               c_prox = reps_d(d->c_prox, nc), c_eps = reps_d(d->c_eps, 3 * nc), c_min = reps_d(d->c_min, nc),
+               c_max = reps_d(d->c_max, nc), c_bpose0 = reps_d(d->c_bpose0, 16 * nc), c_bpose1 = reps_d(d->c_bpose1, 16 * nc);
+    f.ctype = ptr_i(ctype); f.c_enabled = ptr_i(c_enabled); f.c_geom = ptr_i(c_geom); f.c_body = ptr_i(c_body);
+    f.c_body0 = ptr_i(c_body0); f.c_dof = ptr_i(c_dof);
+    f.c_local = ptr_d(c_local); f.c_radius = ptr_d(c_radius); f.c_radius0 = ptr_d(c_radius0); f.c_half = ptr_d(c_half);
+    f.c_plane = ptr_d(c_plane); f.c_mu = ptr_d(c_mu); f.c_prox = ptr_d(c_prox); f.c_eps = ptr_d(c_eps);
+    f.c_min = ptr_d(c_min); f.c_max = ptr_d(c_max); f.c_bpose0 = ptr_d(c_bpose0); f.c_bpose1 = ptr_d(c_bpose1);
+    return model_create(&f, device, out, false);
 }
 
 extern "C" int arb_model_destroy(arb_model *M) {
@@ -3076,6 +3186,7 @@ extern "C" int arb_model_destroy(arb_model *M) {
     DeviceGuard guard_(M->device);
     for (void *p : M->allocs) (void)hipFree(p);       // (hipFree waits for the work that uses it)
     if (M->status_host) (void)hipHostFree(M->status_host);
+    if (M->forest) (void)arb_model_destroy(M->forest);
     delete M;
     return ARB_OK;
 }
@@ -3092,7 +3203,54 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
     info->lds_bytes_f32 = M->lf.total * (int)sizeof(float);
     info->lds_bytes_f64 = M->ld.total * (int)sizeof(double);
     info->device = M->device;
+    info->forest_copies = M->forest ? M->forest_k : 1;
     return ARB_OK;
+}
+
+// Which build of the float32 production kernel runs a launch (models with one column set and a tile of up to 48 rows;
+// every other model has the two-wave build only)?  The builds are bit-identical (-ffp-contract=on): a pure performance
+// decision, also reported by arb_step_plan.
+struct BuildChoice { bool w3 = false, pack = false; long slots2 = 0, slots3 = 0, slotsp = 0; };
+static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nsteps, unsigned flags) {
+    BuildChoice bc;
+    if (!(M->nsets == 1 && M->nmax <= 48)) return bc;
+    static thread_local int cus_dev = -1, cus = 0;
+    if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
+    const long pad = std::max(0, env_int("ARB_LDS_PAD", 0));
+    const long lds2 = (long)M->lf.total * 4 + pad, lds3 = (long)M->lf3.total * 4 + pad;
+    const long s2 = (long)cus * std::min(8l, (160 * 1024) / lds2), s3 = (long)cus * std::min(12l, (160 * 1024) / lds3);
+    bc.slots2 = s2; bc.slots3 = s3;
+    // Two or three waves per SIMD?  Three when the batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3
+    // pin the build; ARB_FORCE_WAVES=2|3 in the environment overrides both (development).
+    if (s3 > s2 && s2 > 0) {
+        // measured (human36 + 4 contacts, M world-steps/s, two / three waves): 2048 worlds 14.6 / 13.4, 2560: 16.6 / 13.8,
+        // 3072: 16.7 / 11.6, 3584: 16.7 / 17.1, 4096: 17.1 / 18.0, 6144: 17.6 / 18.7, 65536: 18.4 / 19.8;
+        // one launch per step (no queue): three waves when they save a round of workgroups (4096 worlds: 10.4 / 9.7,
+        // two rounds either way; 6144: 12.2 / 12.1)
+        if (nsteps >= 2) bc.w3 = 3 * nw >= 4 * s3;
+        else bc.w3 = 112 * ((nw + s3 - 1) / s3) < 100 * ((nw + s2 - 1) / s2);
+        if (flags & ARB_STEP_WAVES2) bc.w3 = false;
+        if (flags & ARB_STEP_WAVES3) bc.w3 = true;
+    }
+    const int force = env_int("ARB_FORCE_WAVES", 0);
+    if (force == 2) bc.w3 = false;
+    if (force == 3) bc.w3 = true;
+    // Two worlds per wavefront (the packed build: the sweeps of both worlds in one instruction stream): models whose
+    // constraints are all SoftFingerContacts with eps = (1,1,1), plain inputs or user torques, a stash that still leaves
+    // eight wavefronts per CU, and a batch large enough that pairs of worlds fill and balance the wave slots (measured,
+    // three-wave / packed: 4096 worlds 18.2 / 16.8, 8192: 19.3 / 19.4, 16384: 19.6 / 20.0, 65536: 20.0 / 20.4).
+    // ARB_FORCE_PACK=0|1 in the environment overrides the batch-size rule (development).
+    if (M->packable && noopt && M->lfp.lscan) {
+        const long ldsp = (long)M->lfp.total * 4 + pad;
+        const long sp = (long)cus * std::min(8l, (160 * 1024) / ldsp);
+        bc.slotsp = sp;
+        bc.pack = sp >= s2 && sp > 0 && (nw + 1) / 2 >= ARB_PACK_MIN_ROUNDS * sp;
+        const int fp = env_int("ARB_FORCE_PACK", -1);
+        if (fp == 0) bc.pack = false;
+        if (fp == 1) bc.pack = true;
+        if (flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3)) bc.pack = false;      // (a pinned build is a pinned build)
+    }
+    return bc;
 }
 
 template <typename T, int MODE>
@@ -3106,44 +3264,8 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     const bool plain = noopt && ext == nullptr;
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
-    // Two or three waves per SIMD (float32 production kernels with one column set, see ARB_WAVES)?  Three when the
-    // batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin the build; ARB_FORCE_WAVES=2|3 in the
-    // environment overrides both (development).
-    bool w3 = false, pack = false;
-    if (MODE == 0 && std::is_same<T, float>::value && M->nsets == 1 && M->nmax <= 48 && !mfma) {
-        static thread_local int cus_dev = -1, cus = 0;
-        if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
-        const long pad = std::max(0, env_int("ARB_LDS_PAD", 0));
-        const long lds2 = (long)L.total * (long)sizeof(T) + pad, lds3 = (long)M->lf3.total * (long)sizeof(T) + pad;
-        const long s2 = (long)cus * std::min(8l, (160 * 1024) / lds2), s3 = (long)cus * std::min(12l, (160 * 1024) / lds3);
-        if (s3 > s2 && s2 > 0) {
-            // measured (human36 + 4 contacts, M world-steps/s, two / three waves): 2048 worlds 14.6 / 13.4, 2560: 16.6 / 13.8,
-            // 3072: 16.7 / 11.6, 4096: 17.1 / 18.0, 6144: 17.6 / 18.7, 65536: 18.4 / 19.8
-            // one launch per step (no queue): three waves when they save a round of workgroups (4096 worlds: 10.4 / 9.7,
-            // two rounds either way; 6144: 12.2 / 12.1).  (Since the library is compiled with -ffp-contract=on the builds
-            // are bit-identical, so the choice may depend on the launch shape.)
-            if (nsteps >= 2) w3 = 3 * nw >= 4 * s3;
-            else w3 = 112 * ((nw + s3 - 1) / s3) < 100 * ((nw + s2 - 1) / s2);
-            if (flags & ARB_STEP_WAVES2) w3 = false;
-            if (flags & ARB_STEP_WAVES3) w3 = true;
-        }
-        const int force = env_int("ARB_FORCE_WAVES", 0);
-        if (force == 2) w3 = false;
-        if (force == 3) w3 = true;
-        // Two worlds per wavefront (the packed build: bit-identical results, the sweeps of both worlds in one instruction
-        // stream): models whose constraints are all SoftFingerContacts with eps = (1,1,1), plain inputs or user torques,
-        // a stash that still leaves eight wavefronts per CU, and a batch large enough that pairs of worlds fill and
-        // balance the wave slots.  ARB_FORCE_PACK=0|1 in the environment overrides the batch-size rule (development).
-        if (M->packable && noopt && M->lfp.lscan) {
-            const long ldsp = (long)M->lfp.total * (long)sizeof(T) + pad;
-            const long sp = (long)cus * std::min(8l, (160 * 1024) / ldsp);
-            pack = sp >= s2 && (nw + 1) / 2 >= ARB_PACK_MIN_ROUNDS * sp;
-            const int fp = env_int("ARB_FORCE_PACK", -1);
-            if (fp == 0) pack = false;
-            if (fp == 1) pack = true;
-            if (flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3)) pack = false;      // (a pinned build is a pinned build)
-        }
-    }
+    const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma) ? choose_build(M, noopt, nw, nsteps, flags) : BuildChoice();
+    const bool w3 = bc.w3, pack = bc.pack;
 #define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : (CMV) == 2 ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
@@ -3267,6 +3389,21 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
     return rc;
 }
 
+// Does a launch run on the forest of a small model (arb_model::forest, ARB_STEP_ONE_WORLD)?  When the batch is larger than
+// the device has wave slots -- below that every world has a wavefront to itself anyway and the forest's larger tile
+// only lengthens the step --, and when its logs keep their layout: state logs [step][world][..] of a batch that is a
+// multiple of k are the forest's logs; energies are per world, which a forest world does not have.
+static int device_cus(int device) {
+    static thread_local int cus_dev = -1, cus = 0;
+    if (cus_dev != device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device); cus_dev = device; }
+    return cus;
+}
+static bool use_forest(const arb_model *M, int64_t nworlds, uint32_t flags, const arb_rollout_log *log) {
+    if (!M->forest || (flags & (ARB_STEP_ONE_WORLD | ARB_STEP_SPLIT_WAVE | ARB_STEP_MFMA_ELIM))) return false;
+    if (log && (log->energy_log || ((log->q_log || log->dq_log) && nworlds % M->forest_k != 0))) return false;
+    return nworlds > 8l * device_cus(M->device);
+}
+
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                      const void *pd_qdes, const void *pd_dqdes, const void *pd_kp, const void *pd_kd,
                      int64_t nworlds, double dt, const double *dt_steps, int32_t nsteps, uint32_t flags,
@@ -3286,6 +3423,21 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     if (int stalled = take_status(M)) return stalled;
     ARB_GUARD_DEVICE(M->device);
+    if (use_forest(M, nworlds, flags, log)) {
+        // small worlds share wavefronts: nworlds / k worlds of the forest on the same buffers, the rest one per wavefront
+        const int K = M->forest_k;
+        const int64_t nf = nworlds / K, done = nf * K;
+        const size_t es = dtype == ARB_F32 ? sizeof(float) : sizeof(double);
+        int rc = step_impl(M->forest, dtype, q, dq, cforce, ext_gforce, pd_qdes, pd_dqdes, pd_kp, pd_kd, nf, dt, dt_steps, nsteps,
+                           flags | ARB_STEP_ONE_WORLD, log, stream);
+        if (rc != ARB_OK || done == nworlds) return rc;
+        auto at = [&](const void *p, size_t per_world) -> void * {
+            return p ? (void *)((const char *)p + (size_t)done * per_world * es) : nullptr;
+        };
+        return step_impl(M, dtype, at(q, M->nq), at(dq, M->n), at(cforce, (size_t)M->nc * ARB_MAXDOL), at(ext_gforce, M->n),
+                         at(pd_qdes, M->n), at(pd_dqdes, M->n), at(pd_kp, M->n), at(pd_kd, M->n), nworlds - done, dt, dt_steps,
+                         nsteps, flags | ARB_STEP_ONE_WORLD, nullptr, stream);
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32) {
         const PerWorldPD<float> pwd = {(const float *)pd_qdes, (const float *)pd_dqdes, (const float *)pd_kp, (const float *)pd_kd};
@@ -3301,6 +3453,38 @@ extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce
                         int64_t nworlds, double dt, int32_t nsteps, uint32_t flags, void *stream) {
     return step_impl(M, dtype, q, dq, cforce, ext_gforce, nullptr, nullptr, nullptr, nullptr, nworlds, dt, nullptr, nsteps,
                      flags, nullptr, stream);
+}
+
+extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t nsteps, uint32_t flags, int32_t optional_inputs,
+                             arb_step_plan_info *out) {
+    if (!M || !out || nworlds < 0 || nsteps < 0 || (dtype != ARB_F32 && dtype != ARB_F64)) return ARB_ERR_INVALID;
+    if (flags & ~ARB_STEP_KNOWN_FLAGS) return ARB_ERR_INVALID;
+    ARB_GUARD_DEVICE(M->device);
+    if (optional_inputs <= 3 && use_forest(M, nworlds, flags, nullptr)) {
+        const int rc = arb_step_plan(M->forest, dtype, nworlds / M->forest_k, nsteps, flags | ARB_STEP_ONE_WORLD, optional_inputs, out);
+        if (rc == ARB_OK) out->worlds_per_wavefront = M->forest_k;
+        return rc;
+    }
+    memset(out, 0, sizeof(*out));
+    const bool split = M->nc > 0 && (flags & ARB_STEP_SPLIT_WAVE) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
+    const bool noopt = optional_inputs <= 1 && !split && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
+    const bool mfma = dtype == ARB_F32 && (flags & ARB_STEP_MFMA_ELIM) && !(M->n == WAVE && M->nc == 0);
+    BuildChoice bc;
+    if (dtype == ARB_F32 && !mfma) bc = choose_build(M, noopt, (long)nworlds, split ? 1 : nsteps, flags);
+    out->worlds_per_wavefront = bc.pack ? 2 : 1;
+    out->waves_per_simd = (dtype == ARB_F64 && M->nmax == 64) ? 1 : (bc.w3 && !bc.pack) ? 3 : 2;
+    const Layout &L = dtype == ARB_F64 ? M->ld : bc.pack ? M->lfp : bc.w3 ? M->lf3 : M->lf;
+    out->lds_bytes = L.total * (dtype == ARB_F64 ? 8 : 4);
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device);
+    const long per_cu = std::min((long)(4 * out->waves_per_simd), (160l * 1024) / std::max(out->lds_bytes, 1));
+    out->wave_slots = (int32_t)(cus * per_cu);                    // (an estimate: the launch asks the occupancy API)
+    const long units = bc.pack ? (nworlds + 1) / 2 : nworlds;
+    out->work_queue = (!split && nsteps >= 2 && !(flags & ARB_STEP_STATIC_WORLDS) && units > out->wave_slots &&
+                       env_int("ARB_QUEUE_CHUNK", 4) > 0) ? 1 : 0;
+    out->feat = optional_inputs <= 0 ? 0 : optional_inputs == 1 ? 1 : 3;
+    if (!noopt) out->feat = 3;
+    return ARB_OK;
 }
 
 extern "C" int arb_step_ex(arb_model *M, int dtype, const arb_step_args *a, void *stream) {

@@ -153,6 +153,49 @@ class FlatModel(object):
         return m
 
 
+def replicate_model(m, copies):
+    """``copies`` independent instances of the flattened world ``m`` as ONE flattened world (a forest): copy k owns bodies
+    ``k nb ..``, dofs ``k ndof ..``, position scalars ``k nq ..`` and constraints ``k nc ..``, so that a batch of states
+    ``(B, nq)`` of ``m`` IS a batch ``(B / copies, copies nq)`` of the forest, without a copy.  The copies share ground,
+    gravity and dt and nothing else: the impedance matrix is block diagonal, the Gauss-Seidel sweeps of one copy never
+    see another's forces.  This is how several small worlds share one wavefront (a 3-dof simplearm uses 3 of its 64
+    lanes, five of them 15), see ``BatchedWorlds(..., pack=)``."""
+    K = int(copies)
+    if K < 1:
+        raise ValueError("copies must be >= 1")
+    f = FlatModel()
+    f.nb, f.ndof, f.nq = K * m.nb, K * m.ndof, K * m.nq
+    tag = lambda names: [("%s#%d" % (s, k) if K > 1 else s) for k in range(K) for s in names]
+    f.body_names, f.joint_names, f.c_names = tag(m.body_names), tag(m.joint_names), tag(m.c_names)
+
+    def tile(a, step=None):
+        """concatenate K copies of ``a``; entries >= 0 of index arrays are shifted by k * step"""
+        a = np.asarray(a)
+        if step is None:
+            return np.concatenate([a] * K, axis=0)
+        return np.concatenate([np.where(a >= 0, a + k * step, a) for k in range(K)], axis=0).astype(a.dtype)
+
+    f.parent = tile(m.parent, m.nb)
+    f.jtype, f.jnd, f.jnq = tile(m.jtype), tile(m.jnd), tile(m.jnq)
+    f.dof_off, f.q_off = tile(m.dof_off, m.ndof), tile(m.q_off, m.nq)
+    f.dof2q = tile(m.dof2q, m.nq)
+    f.H_pr, f.H_cn, f.mass, f.visc = tile(m.H_pr), tile(m.H_cn), tile(m.mass), tile(m.visc)
+    f.weighted = tile(m.weighted)
+    f.gravity, f.up = np.array(m.gravity, float), np.array(m.up, float)
+    f.has_pd = bool(m.has_pd)
+    if m.has_pd:
+        eye = np.eye(K)
+        f.pd_kp, f.pd_kd = np.kron(eye, m.pd_kp), np.kron(eye, m.pd_kd)
+        f.pd_tau0, f.pd_mask = tile(m.pd_tau0), tile(m.pd_mask)
+    f.ctype, f.c_geom, f.c_enabled = tile(m.ctype), tile(m.c_geom), tile(m.c_enabled)
+    f.c_body, f.c_body0 = tile(m.c_body, m.nb), tile(m.c_body0, m.nb)
+    f.c_dof = tile(m.c_dof, m.ndof)
+    for name in ("c_local", "c_radius", "c_radius0", "c_half", "c_plane", "c_mu", "c_prox", "c_eps", "c_min", "c_max",
+                 "c_bpose0", "c_bpose1"):
+        setattr(f, name, tile(getattr(m, name)))
+    return f
+
+
 def _bpose(frame):
     return np.array(frame.bpose, dtype=np.float64).reshape(4, 4)
 

@@ -358,6 +358,8 @@ def main():
     finite = bool(torch.isfinite(qf).all() and torch.isfinite(dqf).all())
     steps_timed = n_ep * EP
     launches_per_episode = len(ms) // n_ep
+    # which build of the step kernel the library picked for this launch shape (arb_step_plan)
+    kernel_build = bw.plan(B, EP // launches_per_episode, dtype=dtype, ext_gforce=bool(cfg.get("torques")), split=args.split or False)
     ep_ms = np.asarray(ms).reshape(n_ep, launches_per_episode).sum(axis=1)       # kernel time per episode
 
     # final state gather over RCCL/xGMI (outside the timed region, reported separately)
@@ -403,6 +405,7 @@ def main():
                                % (cfg["name"], B, dt, cfg["dtype"], EP, (", Gauss-Seidel in a %s-per-world kernel" % args.split) if args.split else ""),
                    "baseline_config": args.config, "worlds_per_gpu": B, "global_batch": n_gpus * B,
                    "parallelism": "dp%d" % n_gpus, "steps_per_launch": EP / launches_per_episode,
+                   "kernel_build": kernel_build,
                    "launch": "arb_step default: with more worlds than resident wavefronts the kernel draws (4-step chunk, "
                              "world) work items from a device-side queue (include/arbstep.h, ARB_STEP_STATIC_WORLDS turns it off)"},
         "roofline": {"bound": "valu-issue",

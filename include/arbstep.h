@@ -114,7 +114,18 @@ enum {
                                          builds, batch positions, launch shapes; tests/test_gpu_round3.py).  The pins exist
                                          for performance experiments and as a belt for callers that compare runs bit for bit;
                                          a pin the model has no build for is ignored. */
-#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u)
+#define ARB_STEP_ONE_WORLD 256u        /* one world per wavefront even for a small model.  Default: the worlds of a model of at most
+                                         16 dofs share wavefronts -- arb_model_create also builds a FOREST of k independent
+                                         copies of the model (as many as fit a 32-row tile and one set of columns: 10 simplearms),
+                                         and a batch of nw worlds runs as nw / k forest worlds on the same buffers (world w is
+                                         copy w % k of forest world w / k; the last nw % k worlds run one per wavefront) once
+                                         nw exceeds the wave slots of the device.  The copies share nothing but ground, gravity
+                                         and dt: the augmented system is block diagonal, products with the exact zeros between the
+                                         blocks change nothing, and float32 results were bit-identical on every model tried
+                                         (float64: to 1e-13, the composites of phase B being differences of prefix sums over all
+                                         bodies of the wavefront).  Launches that log energies (per world) or that log states for
+                                         a batch that is not a multiple of k run one world per wavefront. */
+#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u)
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the
@@ -174,6 +185,7 @@ typedef struct arb_model_info {
     int32_t lds_bytes_f32;    /* dynamic LDS per world (= per wavefront) */
     int32_t lds_bytes_f64;
     int32_t device;
+    int32_t forest_copies;    /* small models: worlds per wavefront of the forest build (ARB_STEP_ONE_WORLD), 1 = none */
 } arb_model_info;
 
 /*
@@ -224,6 +236,26 @@ const char *arb_last_hip_error(void);
 int arb_model_create(const arb_model_desc *desc, int device, arb_model **out);
 int arb_model_destroy(arb_model *m);
 int arb_model_get_info(const arb_model *m, arb_model_info *info);
+
+/*
+ * Which kernel build and launch shape arb_step / arb_step_ex would use for a batch (diagnostics: the benchmark records it,
+ * the tests check the batch-size rules).  The float32 step kernel of a model with ndof <= 48 and ndof + 1 + 4 nc <= 64
+ * exists in three bit-identical builds -- two waves per SIMD (no register spills), three waves per SIMD (more waves in
+ * flight), and two WORLDS per wavefront (their Gauss-Seidel sweeps in one instruction stream; contact-only models) --
+ * picked by batch size and launch shape; ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin one.
+ *   optional_inputs: 0 = none, 1 = ext_gforce only, 3 = per-world PD inputs / logs / dt_steps
+ */
+typedef struct arb_step_plan_info {
+    int32_t waves_per_simd;        /* register budget the chosen build was compiled for: 1, 2 or 3 */
+    int32_t worlds_per_wavefront;  /* 1, 2 (the packed build), or the copies of a small model's forest (the other fields
+                                      then describe the launch of the forest) */
+    int32_t feat;                  /* optional-input set of the kernel instantiation: 0, 1 or 3 */
+    int32_t lds_bytes;             /* dynamic LDS per wavefront */
+    int32_t wave_slots;            /* resident wavefronts of that build on the device (estimate) */
+    int32_t work_queue;            /* 1: the resident wavefronts draw (chunk of steps, world or pair) items from a device-side queue */
+} arb_step_plan_info;
+int arb_step_plan(arb_model *m, int dtype, int64_t nworlds, int32_t nsteps, uint32_t flags, int32_t optional_inputs,
+                  arb_step_plan_info *out);
 
 /*
  * Health of the handle's launches.  The device-side work queue of multi-step launches orders the chunks of a world

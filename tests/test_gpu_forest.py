@@ -1,0 +1,214 @@
+"""Small worlds share wavefronts (the FOREST of a model of at most 16 dofs: arb_model_create builds k independent copies
+of it as one model, and a large batch runs as nw / k forest worlds on the same buffers; include/arbstep.h,
+ARB_STEP_ONE_WORLD; SURVEY 7.1 step 7: "pack several small worlds per wavefront for n << 64").
+
+The forest launch is checked against the float64 reference (golden trajectories; float32: the oracle on the rounded
+inputs) at the gates of the one-world kernels, and against the one-world launch of the same batch: copies share nothing
+but ground, gravity and dt, the augmented system is block diagonal and products with its exact zeros change nothing.
+"""
+import numpy as np
+import pytest
+
+import arb_oracle as O
+from conftest import load_golden, load_model
+from test_gpu_parity import rel, F32_TOL
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+CASES = {
+    # name: (golden file, q key, dq key, dt)
+    "jointlimits_min": ("g6_constraints.npz", "jl_min_q", "jl_min_dq", 1e-3),
+    "jointlimits_max": ("g6_constraints.npz", "jl_max_q", "jl_max_dq", 1e-3),
+    "shapes_plane_ball": ("g7_shapes.npz", "plane_ball_q", "plane_ball_dq", 5e-3),
+    "shapes_box_ball": ("g7_shapes.npz", "box_ball_q", "box_ball_dq", 5e-3),
+    "shapes_ball_ball": ("g7_shapes.npz", "ball_ball_q", "ball_ball_dq", 5e-3),
+    "shapes_dome_point": ("g7_shapes.npz", "dome_point_q", "dome_point_dq", 5e-3),
+    "txtytz": ("g11_txtytz.npz", "roll_q", "roll_dq", 5e-3),
+}
+
+
+def _tiled(Q, DQ, B):
+    reps = -(-B // (len(Q) - 1))
+    q = np.tile(Q[:-1], (reps, 1))[:B]
+    dq = np.tile(DQ[:-1], (reps, 1))[:B]
+    qn = np.tile(Q[1:], (reps, 1))[:B]
+    dqn = np.tile(DQ[1:], (reps, 1))[:B]
+    return q, dq, qn, dqn
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_forest_single_steps_match_the_reference(name, dtype):
+    """Every step of the reference's trajectory from the reference's own state, tiled to a batch that runs on the forest
+    (more worlds than wave slots, not a multiple of the copies: the last worlds run one per wavefront)."""
+    from arboris_python_amd.batch import BatchedWorlds
+    gfile, kq, kdq, dt = CASES[name]
+    g = load_golden(gfile)
+    m, _, _ = load_model(name)
+    bw = BatchedWorlds(m)
+    K = bw.info["forest_copies"]
+    assert K >= 2, "a %d-dof model should have a forest" % m.ndof
+    cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
+    B = 8 * cus + 3 * K + 1
+    B += 1 if B % K == 0 else 0
+    p = bw.plan(B, 1, dtype=dtype)
+    assert p["worlds_per_wavefront"] == K
+    assert bw.plan(B, 1, dtype=dtype, one_world=True)["worlds_per_wavefront"] == 1
+    assert bw.plan(8 * cus, 1, dtype=dtype)["worlds_per_wavefront"] == 1          # every world has a wavefront anyway
+    q, dq, qn, dqn = _tiled(g[kq], g[kdq], B)
+    if dtype == torch.float32:
+        f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        n0 = len(g[kq]) - 1
+        oq, odq, _ = O.step(m, f(q[:n0]), f(dq[:n0]), dt)          # (the batch repeats its first n0 worlds)
+        reps = -(-B // n0)
+        qn, dqn = np.tile(oq, (reps, 1))[:B], np.tile(odq, (reps, 1))[:B]
+    res = {}
+    for one in (False, True):
+        tq, tdq = bw.to_device(q, dq, dtype)
+        cf = bw.new_cforce(B, dtype) if m.nc else None
+        bw.step(tq, tdq, dt, 1, cforce=cf, one_world=one)
+        torch.cuda.synchronize()
+        res[one] = (tq.cpu().numpy(), tdq.cpu().numpy(), None if cf is None else cf.cpu().numpy())
+    tol = 1e-8 if dtype == torch.float64 else F32_TOL
+    for one in (False, True):
+        assert rel(res[one][0], qn) < tol, (one, rel(res[one][0], qn))
+        assert rel(res[one][1], dqn) < tol, (one, rel(res[one][1], dqn))
+    # forest against one world per wavefront
+    ftol = 1e-12 if dtype == torch.float64 else 2e-7
+    assert rel(res[False][0], res[True][0]) < ftol and rel(res[False][1], res[True][1]) < ftol
+    if m.nc:
+        assert rel(res[False][2].reshape(B, -1), res[True][2].reshape(B, -1)) < (1e-9 if dtype == torch.float64 else 1e-5)
+    bw.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_forest_simplearm_rollout_logs_and_timeline(dtype):
+    """simplearm (3 dofs, 10 copies per wavefront): a 64-step launch with a non-uniform timeline and state logs on the
+    forest (batch a multiple of the copies) against the one-world launch and, world by world, against the oracle's
+    rollout; a batch that is not a multiple logs through the one-world kernels and gives the same states."""
+    from arboris_python_amd.batch import BatchedWorlds
+    m, q0, dq0 = load_model("simplearm")
+    bw = BatchedWorlds(m)
+    K = bw.info["forest_copies"]
+    assert K == 10
+    cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
+    B = (8 * cus // K + 7) * K
+    rng = np.random.default_rng(4)
+    q = np.tile(q0, (B, 1)) + 0.5 * rng.standard_normal((B, m.nq))
+    dq = np.tile(dq0, (B, 1)) + 0.5 * rng.standard_normal((B, m.ndof))
+    T = 64
+    dts = 1e-3 * (1. + 0.5 * np.sin(np.arange(T)))
+    out = {}
+    for one in (False, True):
+        tq, tdq = bw.to_device(q, dq, dtype)
+        logs = bw.rollout(tq, tdq, dts, T, log_energy=False, one_world=one)
+        torch.cuda.synchronize()
+        bw.status()
+        out[one] = (tq.cpu().numpy(), tdq.cpu().numpy(), logs["q"].cpu().numpy(), logs["dq"].cpu().numpy())
+    ftol = 1e-11 if dtype == torch.float64 else 1e-6
+    for a, b in zip(out[False], out[True]):
+        assert rel(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])) < ftol
+    # the oracle on a sample of worlds (float32: accumulated rounding over 64 steps)
+    sel = np.arange(0, B, 97)
+    f = (lambda a: a) if dtype == torch.float64 else (lambda a: np.asarray(a, np.float32).astype(np.float64))
+    oq, odq, _ = O.rollout(m, f(q[sel]), f(dq[sel]), list(dts))
+    tol = 1e-9 if dtype == torch.float64 else 2e-5
+    assert rel(out[False][0][sel], oq) < tol and rel(out[False][1][sel], odq) < tol
+    # logs hold the state at the BEGINNING of every step
+    assert rel(out[False][2][0], f(q)) < 1e-12
+    # not a multiple of the copies, with logs: one world per wavefront, same states
+    B2 = B - 3
+    tq, tdq = bw.to_device(q[:B2], dq[:B2], dtype)
+    logs = bw.rollout(tq, tdq, dts, T, log_energy=False)
+    torch.cuda.synchronize()
+    assert rel(tq.cpu().numpy(), out[True][0][:B2]) < ftol
+    assert rel(logs["q"].cpu().numpy()[-1], out[True][2][-1][:B2]) < ftol
+    # energies are per world: the launch runs one world per wavefront and still returns them
+    tq, tdq = bw.to_device(q, dq, dtype)
+    logs = bw.rollout(tq, tdq, 1e-3, 8)
+    torch.cuda.synchronize()
+    assert logs["energy"].shape == (8, B, 2) and bool(torch.isfinite(logs["energy"]).all())
+    bw.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, F32_TOL)])
+def test_forest_per_world_pd_inputs_and_torques(dtype, tol):
+    """One PD controller per world (targets; targets + diagonal gains) and user torques on the forest: every world of the
+    golden per-world-PD runs of simplearm, tiled over the wave slots, against the reference."""
+    from arboris_python_amd.batch import BatchedWorlds
+    g = load_golden("g8_pd_per_world.npz")
+    m, _, _ = load_model("simplearm_pdw")
+    bw = BatchedWorlds(m)
+    K = bw.info["forest_copies"]
+    assert K >= 2
+    cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=bw.device).contiguous()
+    f = (lambda a: np.asarray(a, np.float64)) if dtype == torch.float64 else (lambda a: np.asarray(a, np.float32).astype(np.float64))
+    for tag, with_gains in (("arm_t", False), ("arm_g", True)):
+        Q, DQ = g[tag + "_q"], g[tag + "_dq"]
+        S, W = Q.shape[0] - 1, Q.shape[1]
+        n0 = S * W
+        B = 8 * cus + K + 1
+        reps = -(-B // n0)
+        til = lambda a: np.tile(a, (reps, 1))[:B]
+        q, dq = til(Q[:S].reshape(n0, -1)), til(DQ[:S].reshape(n0, -1))
+        pd = dict(qdes=til(np.tile(g[tag + "_qdes"], (S, 1))), dqdes=til(np.tile(g[tag + "_dqdes"], (S, 1))))
+        if with_gains:
+            pd.update(kp=til(np.tile(g[tag + "_kp"], (S, 1))), kd=til(np.tile(g[tag + "_kd"], (S, 1))))
+        tau = 0.05 * np.random.default_rng(8).standard_normal((B, m.ndof))
+        oq, odq, _ = O.step(m, f(q), f(dq), 5e-3, pd={k: f(v) for k, v in pd.items()}, ext_gforce=f(tau))
+        res = {}
+        for one in (False, True):
+            tq, tdq = bw.to_device(q, dq, dtype)
+            bw.step(tq, tdq, 5e-3, 1, pd_targets=(dev(pd["qdes"]), dev(pd["dqdes"])),
+                    pd_gains=(dev(pd["kp"]), dev(pd["kd"])) if with_gains else None, ext_gforce=dev(tau), one_world=one)
+            torch.cuda.synchronize()
+            res[one] = (tq.cpu().numpy(), tdq.cpu().numpy())
+            assert rel(res[one][0], oq) < tol and rel(res[one][1], odq) < tol, (tag, one)
+        ftol = 1e-12 if dtype == torch.float64 else 2e-7
+        assert rel(res[False][0], res[True][0]) < ftol and rel(res[False][1], res[True][1]) < ftol
+    bw.close()
+
+
+def test_forest_contact_worlds_through_the_work_queue():
+    """A sphere bouncing on a plane (3 translational dofs, one SoftFingerContact): 40 steps in one launch -- the forest
+    worlds go through the device-side work queue, forces persist from step to step through cforce -- against the one-world
+    launch (bit for bit in float32 here) and the oracle's rollout of a sample."""
+    from arboris_python_amd.batch import BatchedWorlds
+    g = load_golden("g7_shapes.npz")
+    m, _, _ = load_model("shapes_plane_ball")
+    bw = BatchedWorlds(m)
+    K = bw.info["forest_copies"]
+    assert K >= 2
+    cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
+    B = 16 * cus * K + 5                  # more forest worlds than wave slots: the work queue
+    Q, DQ = g["plane_ball_q"], g["plane_ball_dq"]
+    rng = np.random.default_rng(11)
+    pick = rng.integers(0, len(Q) - 1, size=B)
+    q, dq = Q[pick].copy(), DQ[pick].copy()
+    dq += 0.05 * rng.standard_normal(dq.shape)
+    p = bw.plan(B, 40)
+    assert p["worlds_per_wavefront"] == K and p["work_queue"] == 1
+    res = {}
+    for one in (False, True):
+        tq, tdq = bw.to_device(q, dq, torch.float32)
+        cf = bw.new_cforce(B, torch.float32)
+        bw.step(tq, tdq, 5e-3, 40, cforce=cf, one_world=one)
+        torch.cuda.synchronize()
+        bw.status()
+        res[one] = (tq.cpu().numpy(), tdq.cpu().numpy(), cf.cpu().numpy())
+    assert float(np.abs(res[True][2]).max()) > 0.1
+    # (the forest's composites are differences of prefix sums over all bodies of the wavefront: float64 rounding that now
+    # and then moves a float32 entry of Z by an ulp; a contact force is (mass / dt) x a velocity difference, so the forces
+    # agree to 1e-3 of their 20 N where the velocities agree to 1e-5)
+    for (a, b), tol in zip(zip(res[False], res[True]), (1e-5, 1e-5, 2e-3)):
+        assert rel(a.reshape(B, -1), b.reshape(B, -1)) < tol
+    same = np.mean([np.array_equal(res[False][0][w], res[True][0][w]) for w in range(B)])
+    print("forest vs one world per wavefront after 40 steps: %.2f %% of the worlds bit-identical" % (100 * same))
+    sel = np.arange(0, B, 401)
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    oq, odq, _ = O.rollout(m, f(q[sel]), f(dq[sel]), [5e-3] * 40)
+    assert rel(res[False][0][sel], oq) < 1e-4 and rel(res[False][1][sel], odq) < 1e-3
+    bw.close()

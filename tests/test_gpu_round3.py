@@ -148,7 +148,7 @@ def test_unknown_flags_are_refused():
     q, dq = synth.standing_states(m, 4, seed=2)
     tq, tdq = bw.to_device(q, dq, torch.float32)
     before = tq.clone()
-    for bad in (4, 256, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel)
+    for bad in (4, 512, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel)
         rc = bw._lib.arb_step(bw._handle, _capi.ARB_F32, tq.data_ptr(), tdq.data_ptr(), None, None, 4, 5e-3, 1, bad, None)
         assert rc == 1
     with pytest.raises(ValueError):
@@ -372,4 +372,52 @@ def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, 
             res[mode] = (tq, tdq, cf)
         assert float(res["1"][2][:, :, 3].max()) > 10.
         assert all(torch.equal(a, b) for a, b in zip(res["0"], res["1"])), (B, T, per_step, ext)
+    bw.close()
+
+
+# ---------------------------------------------------------------------------
+# arb_step_plan: which build of the step kernel a launch gets
+# ---------------------------------------------------------------------------
+def test_step_plan_reports_the_batch_size_rules(monkeypatch):
+    """The float32 step kernel of a human36-sized model exists as a two-wave, a three-wave and a packed (two worlds
+    per wavefront) build; arb_step_plan reports which one a launch shape gets.  On an MI355X (256 CUs): two waves for
+    small batches and one-step launches, three from ~4100 worlds of a multi-step launch, packed from 16384 worlds of a
+    contact-only model with plain inputs or torques; pins and per-world PD inputs turn the packed build off; float64 and
+    models with two column sets have the two-wave build only."""
+    from arboris_python_amd.batch import BatchedWorlds
+    monkeypatch.delenv("ARB_FORCE_WAVES", raising=False)
+    monkeypatch.delenv("ARB_FORCE_PACK", raising=False)
+    m, _, _ = load_model("human36_c4")
+    bw = BatchedWorlds(m)
+    cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
+    build = lambda p: (p["waves_per_simd"], p["worlds_per_wavefront"])
+    p = bw.plan(4 * cus, 40)
+    assert build(p) == (2, 1) and p["work_queue"] == 0 and p["feat"] == 0 and p["wave_slots"] == 8 * cus
+    p = bw.plan(16 * cus, 40)
+    assert build(p) == (3, 1) and p["work_queue"] == 1 and p["wave_slots"] == 12 * cus
+    assert p["lds_bytes"] * 12 <= 160 * 1024
+    assert build(bw.plan(16 * cus, 1)) == (2, 1) and bw.plan(16 * cus, 1)["work_queue"] == 0
+    assert build(bw.plan(16 * cus, 40, waves=2)) == (2, 1)
+    assert build(bw.plan(4 * cus, 40, waves=3)) == (3, 1)
+    p = bw.plan(64 * cus, 40, ext_gforce=True)
+    assert build(p) == (2, 2) and p["feat"] == 1 and p["work_queue"] == 1
+    assert p["lds_bytes"] * 8 <= 160 * 1024
+    assert build(bw.plan(64 * cus, 40, other_inputs=True)) == (3, 1) and bw.plan(64 * cus, 40, other_inputs=True)["feat"] == 3
+    assert build(bw.plan(64 * cus, 40, waves=3)) == (3, 1)
+    assert build(bw.plan(64 * cus, 40, dtype=torch.float64)) == (2, 1)
+    assert bw.plan(64 * cus, 40, static_worlds=True)["work_queue"] == 0
+    monkeypatch.setenv("ARB_FORCE_PACK", "1")
+    assert build(bw.plan(100, 40)) == (2, 2)
+    monkeypatch.setenv("ARB_FORCE_PACK", "0")
+    assert build(bw.plan(64 * cus, 40)) == (3, 1)
+    bw.close()
+    # a model with a kinematic constraint (not only SoftFingerContacts) has no packed build
+    m, _, _ = load_model("ballsocket")
+    bw = BatchedWorlds(m)
+    monkeypatch.delenv("ARB_FORCE_PACK", raising=False)
+    assert bw.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
+    monkeypatch.setenv("ARB_FORCE_PACK", "1")
+    assert bw.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
+    # (by default its worlds share wavefronts another way: a forest of 5 copies, tests/test_gpu_forest.py)
+    assert bw.plan(64 * cus, 40)["worlds_per_wavefront"] == bw.info["forest_copies"] == 5
     bw.close()

@@ -337,3 +337,30 @@ def test_parity_tools_on_the_oracle_itself():
     mg = [(t["world"], t["c"], t["sweep"], t["branch"]) + solve_margins(t) for t in tr]
     cone = np.array([x[5] for x in mg if x[5] is not None])
     assert cone.min() >= 0. and np.isfinite(cone).all() and cone.max() <= 1.0 + 1e-12
+
+
+def test_replicate_model_is_k_independent_worlds():
+    """flatten.replicate_model: k copies of a world as one forest world (the host-side statement of what the library
+    builds for small models, include/arbstep.h ARB_STEP_ONE_WORLD) -- a batch (B, nq) of the model viewed as
+    (B / k, k nq) steps through the oracle to the same states and constraint forces, copy by copy."""
+    import arb_oracle as O
+    from arboris_python_amd.flatten import replicate_model
+    rng = np.random.default_rng(1)
+    for name, K in (("simplearm", 10), ("simplearm_pd", 4), ("jointlimits_min", 9), ("ballsocket", 5),
+                    ("shapes_plane_ball", 5), ("txtytz", 3), ("human36_c4", 2)):
+        m, q0, dq0 = load_model(name)
+        B = 2 * K
+        q = np.tile(q0, (B, 1))
+        dq = np.tile(dq0, (B, 1)) + 0.05 * rng.standard_normal((B, m.ndof))
+        lin = m.dof2q >= 0
+        q[:, m.dof2q[lin]] += 0.05 * rng.standard_normal((B, int(lin.sum())))
+        f = replicate_model(m, K)
+        assert (f.nb, f.ndof, f.nq, f.nc) == (K * m.nb, K * m.ndof, K * m.nq, K * m.nc)
+        assert int(f.parent.max()) < f.nb and all(f.parent[k * m.nb] == -1 for k in range(K))
+        cf = np.zeros((B, m.nc, 4)) if m.nc else None
+        qa, dqa, cfa = O.step(m, q, dq, 5e-3, cforce=cf)
+        cff = np.zeros((B // K, K * m.nc, 4)) if m.nc else None
+        qb, dqb, cfb = O.step(f, q.reshape(B // K, -1), dq.reshape(B // K, -1), 5e-3, cforce=cff)
+        assert np.abs(qb.reshape(B, -1) - qa).max() < 1e-12 and np.abs(dqb.reshape(B, -1) - dqa).max() < 1e-10, name
+        if m.nc:
+            assert np.abs(cfb.reshape(B, m.nc, 4) - cfa).max() < 1e-9 * max(1., np.abs(cfa).max()), name

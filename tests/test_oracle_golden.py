@@ -195,6 +195,28 @@ def test_snake64():
     close(q, g["roll10_q"], 1e-8); close(dq, g["roll10_dq"], 1e-6)
 
 
+def test_snake64_needs_float64_assembly():
+    """Why snake-64 runs with the float64 kernels only: cond(Z) = 3e8, so an
+    impedance matrix that is merely ROUNDED to float32 entry by entry -- the best a float32 assembly of Z could deliver --
+    and then solved exactly misses dq+ by 3e-2..1e-1, and a float32 right-hand side alone by 2e-4..4e-4, against the
+    north-star gate of 1e-5; the increment form dq+ = dq + Z^-1 (gforce - (B + N) dq) in float64 agrees to 1e-9."""
+    g = load_golden("g4_snake64.npz")
+    m, _, _ = load_model("snake64_g")
+    dt, q, dq = float(g["dt"]), g["q"], g["dq"]
+    dyn = O.update_dynamic(m, q, dq)
+    gf, Z, _ = O.update_controllers(m, dyn, q, dq, dt)
+    assert 1e8 < np.linalg.cond(Z[0]) < 1e9
+    rhs = (dyn["M"] @ dq[..., None])[..., 0] / dt + gf
+    ref = np.linalg.solve(Z, rhs[..., None])[..., 0]
+    rel = lambda x: (np.abs(x - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+    assert rel(g["dq_next"]) < 1e-5                                   # the reference's explicit inverse: 2.3e-6
+    r2 = gf - ((dyn["Bv"] + dyn["N"]) @ dq[..., None])[..., 0]
+    assert rel(dq + np.linalg.solve(Z, r2[..., None])[..., 0]) < 1e-8
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    assert rel(dq + np.linalg.solve(f32(Z), r2[..., None])[..., 0]) > 1e-2
+    assert rel(dq + np.linalg.solve(Z, f32(r2)[..., None])[..., 0]) > 1e-4
+
+
 # -- G5 energy drift ----------------------------------------------------------
 def test_energy_drift_h5():
     """tests/test_energy_drift.py: kinetic energy series of the 9-link free snake;
