@@ -522,6 +522,31 @@ def main():
                                        "episode_kernel_ms_median": float(np.median(me)),
                                        "finite": bool(torch.isfinite(qe).all())}
             b2.close()
+        # BASELINE config #1's robot as a batch: simplearm (3 dofs), 65 536 worlds x 64 steps, float32 -- small worlds
+        # share wavefronts (the library's forest of 10 copies, include/arbstep.h ARB_STEP_ONE_WORLD), against one world
+        # per wavefront
+        from arboris_python_amd import scenes
+        mdl = scenes.flat(scenes.simplearm_world())
+        b2 = BatchedWorlds(mdl, local_rank)
+        rng = np.random.default_rng(7)
+        nb1, ns1 = 65536, 64
+        ta, tb = b2.to_device(rng.uniform(-1., 1., (nb1, mdl.nq)), rng.uniform(-1., 1., (nb1, mdl.ndof)), torch.float32)
+        arm = {"workload": "simplearm (3 dof), %d worlds x %d steps in one launch, float32 (BASELINE config #1's robot, batched)"
+                           % (nb1, ns1), "forest_copies": b2.info["forest_copies"]}
+        for key, one in (("world_steps_per_s", False), ("world_steps_per_s_one_world_per_wavefront", True)):
+            best = None
+            for _ in range(6):
+                qa, da = ta.clone(), tb.clone()
+                torch.cuda.synchronize(b2.device)
+                t0 = time.perf_counter()
+                b2.step(qa, da, 1e-3, ns1, one_world=one)
+                torch.cuda.synchronize(b2.device)
+                el = time.perf_counter() - t0
+                best = el if best is None else min(best, el)
+            arm[key] = nb1 * ns1 / best
+            arm["finite"] = bool(torch.isfinite(qa).all()) and arm.get("finite", True)
+        extra["config1_batched"] = arm
+        b2.close()
         res["extra"] = extra
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(res) + "\n").encode())
