@@ -116,7 +116,7 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
 // per-constraint integer constants staged in LDS once per launch (int32 words): type, dof masks of the ancestors of
 // body 1 and of body 0 (lo, hi each), constrained dof -- the constraint-row loops of phase B read them with
 // wave-uniform LDS reads instead of chains of dependent scalar loads from the model
-#define CI_STRIDE 6
+#define CI_STRIDE 7
 // float64 per body in the prefix table of phase B.  The 63 (69 inspect) accumulators go through the table in TWO passes
 // (A: 36 values, then M | rhs: 27 (33)) so that the table is no larger than the X | P | R vectors that take its place
 // afterwards (round 3: 2380 -> 1292 float32 words for human36, one of the three changes that bring the wave's LDS
@@ -145,11 +145,20 @@ struct DevModel {
     double up[3];
     T grav[3];
     const T *pd_kp, *pd_kd, *pd_tau0;         // [n][n], [n][n], [n] (merged PD controllers; rarely present)
+    // forest worlds (arb_model::forest): fk copies of a model with fn dofs, fnq position scalars, fnc constraints;
+    // qdef = a valid state of rest (identity poses, zero angles) for retired copies, see the step kernel
+    int fk, fn, fnq, fnc;
+    const T *qdef;                            // [nq]
     int parent[ARB_CAP], jtype[ARB_CAP], dof_off[ARB_CAP], jnd[ARB_CAP], q_off[ARB_CAP], depth[ARB_CAP], weighted[ARB_CAP];
     int dof2q[ARB_CAP];
     // composite phase B: body of every dof, bodies in the subtree of a body (DFS preorder: the subtree of b
     // is b .. b + subsize[b] - 1), and per dof the dofs of ancestor-or-own / strictly descendant bodies
     int dofbody[ARB_CAP], subsize[ARB_CAP];
+    // Several trees below the ground (a ball beside a robot; the copies of a forest): every tree is assembled about the
+    // origin of ITS OWN root body and the prefix sums of phase B restart at every root, so that a tree's numbers never
+    // see another tree's positions or magnitudes.  root[b] = root body of b's tree, rootmask = bit b: b is a root.
+    int root[ARB_CAP];
+    unsigned long long rootmask;
     unsigned long long upmask[ARB_CAP], descmask[ARB_CAP];
     unsigned long long anc[ARB_CAP];          // [nb] dofs of the body's joint and of its ancestors'
     int ctype[ARB_CAP], cen[ARB_CAP], cbody[ARB_CAP], cbody0[ARB_CAP], cdof[ARB_CAP], cgeom[ARB_CAP];
@@ -1009,6 +1018,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             FF[i] = f;
         }
     }
+    // Forest worlds (several copies of a small model in this wavefront, arb_model::forest): bit j = copy j is RETIRED.
+    // The copies share the elimination and the sweeps, where a product "exact zero x NaN" would carry one copy's NaN
+    // into all the others; so a copy whose state is not finite -- or beyond +-1e8 (float32) / 1e100, i.e. diverged -- at
+    // the beginning of a step computes on a state of rest from then on and has NaN written to its state, forces and
+    // logs: what the one-world kernels leave behind for a world that overflowed, without touching its neighbours.
+    unsigned dead = 0u;
     const T ext_kA = (gext != nullptr && lane < n) ? gext[w0 * n + lane] : T(0);
     const T ext_kB = (PACK && two && gext != nullptr && lane < n) ? gext[(w0 + 1) * n + lane] : T(0);
     if (lane < nc) {
@@ -1019,6 +1034,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         ci[1] = (int)(unsigned)a1; ci[2] = (int)(unsigned)(a1 >> 32);
         ci[3] = (int)(unsigned)a0; ci[4] = (int)(unsigned)(a0 >> 32);
         ci[5] = mp->cdof[lane];
+        ci[6] = b1 >= 0 ? mp->root[b1] : (b0 >= 0 ? mp->root[b0] : 0);      // the tree whose origin the constraint's frame refers to
     }
     WAVE_SYNC();
 
@@ -1124,9 +1140,40 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
         if (FEAT_ALL && dts != nullptr) { dt = (T)dts[step]; inv_dt = T(1) / dt; }
+        // (forests are built on the 16- and 32-row tiles only: the larger kernels carry none of this)
+        const int fk = (PACK || NMAX > 32) ? 1 : ARB_UNI(mp->fk);
+        if (fk > 1) {               // forest world: retire the copies that have left the finite range (see `dead`)
+            const int fn = ARB_UNI(mp->fn), fnq = ARB_UNI(mp->fnq), fnd = ARB_MAXDOL * ARB_UNI(mp->fnc);
+            const T lim = (T)(sizeof(T) == 4 ? 1e8 : 1e100);
+            unsigned bad = 0u;
+            for (int i = lane; i < nq; i += WAVE) if (!(fabs(qs[i]) <= lim)) bad |= 1u << (i / fnq);
+            if (lane < n && !(fabs(dqs[lane]) <= lim)) bad |= 1u << (lane / fn);
+            for (int i = lane; i < ndol; i += WAVE) if (!(fabs(FF[i]) <= lim)) bad |= 1u << (i / fnd);
+            unsigned long long some = __ballot(bad != 0u);
+            while (some != 0ull) {                           // wave-uniform, rare
+                dead |= (unsigned)__builtin_amdgcn_readlane((int)bad, __builtin_ctzll(some));
+                some &= some - 1ull;
+            }
+        }
         if (MODE == 0) {            // trajectory log: what an Observer sees at time t (core.py:1361-1362)
-            if (logo.q != nullptr) for (int i = lane; i < nq; i += WAVE) logo.q[((long)step * nworlds + w) * nq + i] = qs[i];
-            if (logo.dq != nullptr && lane < n) logo.dq[((long)step * nworlds + w) * n + lane] = dqs[lane];
+            if (dead == 0u) {
+                if (logo.q != nullptr) for (int i = lane; i < nq; i += WAVE) logo.q[((long)step * nworlds + w) * nq + i] = qs[i];
+                if (logo.dq != nullptr && lane < n) logo.dq[((long)step * nworlds + w) * n + lane] = dqs[lane];
+            } else {
+                const int fn = ARB_UNI(mp->fn), fnq = ARB_UNI(mp->fnq);
+                if (logo.q != nullptr)
+                    for (int i = lane; i < nq; i += WAVE)
+                        logo.q[((long)step * nworlds + w) * nq + i] = ((dead >> (i / fnq)) & 1u) ? (T)NAN : qs[i];
+                if (logo.dq != nullptr && lane < n)
+                    logo.dq[((long)step * nworlds + w) * n + lane] = ((dead >> (lane / fn)) & 1u) ? (T)NAN : dqs[lane];
+            }
+        }
+        if (dead != 0u) {           // retired copies compute on a state of rest
+            const int fn = ARB_UNI(mp->fn), fnq = ARB_UNI(mp->fnq), fnd = ARB_MAXDOL * ARB_UNI(mp->fnc);
+            for (int i = lane; i < nq; i += WAVE) if ((dead >> (i / fnq)) & 1u) qs[i] = mp->qdef[i];
+            if (lane < n && ((dead >> (lane / fn)) & 1u)) dqs[lane] = T(0);
+            for (int i = lane; i < ndol; i += WAVE) if ((dead >> (i / fnd)) & 1u) FF[i] = T(0);
+            WAVE_SYNC();
         }
         {
             const int b = lane;
@@ -1397,8 +1444,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const T vz0 = (mv(R0, bv0) + cross(P0, mv(R0, bw0))).z;
                     const T dsd = vz1 - vz0;
                     active = ((double)sd_d + (double)dsd * (double)dt < mp->cprox_d[c]);
-                    {   // phase B works on world-axes columns about the root body's origin: store world -> contact frame 0
-                        const V3<double> p0w = ld_v3(PD + 9);
+                    {   // phase B works on world-axes columns about the origin of a tree's root body: store world -> contact
+                        // frame 0 about the root of body 1's tree (the rows of another tree's dofs shift it, see there)
+                        const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
                         st_m3(cd + CD_R1, cvt_m3<T>(transpose(Rc))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(Rc, gc0 - p0w)));
                     }
                     st_v3(cd + CD_GC0, cvt_v3<T>(gc0)); st_v3(cd + CD_GC1, cvt_v3<T>(gc1));
@@ -1428,7 +1476,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     st_v3(cd + CD_POS0, cvt_v3<T>(mtv(RP0, pP1 - pP0)));  // p_01  constraints.py:196-197
                     // body1 -> frame 0: Ad(inv(P0) H_gb1);  body0 -> frame 0: Ad(inv(bpose0))
                     {
-                        const V3<double> p0w = ld_v3(PD + 9);
+                        const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
                         st_m3(cd + CD_R1, cvt_m3<T>(transpose(RP0))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(RP0, pP0 - p0w)));
                     }
                     active = true;
@@ -1464,7 +1512,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             double Acc[NACC];
             T om_b[6];
             double *STG = reinterpret_cast<double *>(BD);
-            const V3<double> p0w = ld_v3(PD + 9);
             const bool useM = (MODE == 0) || zmode == 0 || zmode == 1;     // mass term of Z
             const bool useN = (MODE == 0) || zmode == 0 || zmode == 3;     // N (incl. the M dJ part)
             const bool useB = (MODE == 0) || zmode == 0 || zmode == 2;     // viscosity
@@ -1513,7 +1560,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // which takes the place of the per-body blocks: every lane has its own block in registers by now.
             // (the three-wave kernels pass the accumulators through a half-size table in two passes -- less LDS, more
             // registers held across the first pass --, the two-wave kernels through a full table in one)
-            constexpr bool TWO_PASS = (CM == 2 || CM == 3);
+            // (the kernels of the 16- and 32-row tiles too, all builds and precisions: their tables hold up to 32 bodies -- the
+            // forests of small models -- and registers are not what limits them)
+            constexpr bool TWO_PASS = (CM == 2 || CM == 3 || NMAX <= 32);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
             const bool lscan = LSCAN_OK && mp->lay.lscan;
             const bool use_table = lscan && TWO_PASS;
@@ -1522,7 +1571,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             if (lane < nb) {
                 const int b = lane;
                 const M3<double> R = ld_m3(PD + 12 * b);
-                const V3<double> p = ld_v3(PD + 12 * b + 9) - p0w;
+                const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);      // about its tree's root
                 const T *Mb = mp->mass + 36 * b;
                 auto blk = [](const T *m6, int r0, int c0) {
                     M3<double> o;
@@ -1649,6 +1698,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     }
                     WAVE_SYNC();
                 }
+                const unsigned long long roots = mp->rootmask;       // (the sums restart at the root of every tree)
                 for (int i = lane; i < CNT; i += WAVE) {
                     double run = 0.;
                     double *col = TB + i;
@@ -1657,10 +1707,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         const double v1 = (b0 + 1 < nb) ? col[TBS * (b0 + 1)] : 0.;
                         const double v2 = (b0 + 2 < nb) ? col[TBS * (b0 + 2)] : 0.;
                         const double v3 = (b0 + 3 < nb) ? col[TBS * (b0 + 3)] : 0.;
-                        run += v0; col[TBS * b0] = run;
-                        run += v1; if (b0 + 1 < nb) col[TBS * (b0 + 1)] = run;
-                        run += v2; if (b0 + 2 < nb) col[TBS * (b0 + 2)] = run;
-                        run += v3; if (b0 + 3 < nb) col[TBS * (b0 + 3)] = run;
+                        const unsigned r4 = (unsigned)(roots >> b0) & 15u;
+                        run = (r4 & 1u) ? v0 : run + v0; col[TBS * b0] = run;
+                        run = (r4 & 2u) ? v1 : run + v1; if (b0 + 1 < nb) col[TBS * (b0 + 1)] = run;
+                        run = (r4 & 4u) ? v2 : run + v2; if (b0 + 2 < nb) col[TBS * (b0 + 2)] = run;
+                        run = (r4 & 8u) ? v3 : run + v3; if (b0 + 3 < nb) col[TBS * (b0 + 3)] = run;
                     }
                 }
                 WAVE_SYNC();
@@ -1709,13 +1760,15 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // ---- lane = dof k: fetch the composites of body(k), own column, the three products -----
             ARB_BSTAMP(4);
             double Xk[6], dXk[6], Gk[6];
+            V3<double> p0k;                    // origin of the root body of dof k's tree
             {
                 // (DPP scan: from here on Acc holds the composites of body(k), not of body(lane))
                 T omk[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) omk[i] = __shfl(om_b[i], bsrc);
                 const M3<double> R = ld_m3(PD + 12 * bsrc);
-                const V3<double> p = ld_v3(PD + 12 * bsrc + 9) - p0w;
+                p0k = ld_v3(PD + 12 * mp->root[bsrc] + 9);
+                const V3<double> p = ld_v3(PD + 12 * bsrc + 9) - p0k;
                 const int kc = lane < RS ? lane : 0;
                 const V3<double> sw = v3<double>((double)SC[0 * RS + kc], (double)SC[1 * RS + kc], (double)SC[2 * RS + kc]);
                 const V3<double> sv = v3<double>((double)SC[3 * RS + kc], (double)SC[4 * RS + kc], (double)SC[5 * RS + kc]);
@@ -1766,12 +1819,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const int a = bsrc, top = a + mp->subsize[a] - 1;
                     const D2 *ph = reinterpret_cast<const D2 *>(STG + TBS * top);
                     const D2 *pl = reinterpret_cast<const D2 *>(STG + TBS * (a > 0 ? a - 1 : 0));
-                    const double keep = a > 0 ? 1. : 0.;
+                    const bool keep = !((mp->rootmask >> a) & 1ull);       // (a root's sums start with itself: nothing to subtract,
+                                                                            //  and the row before it belongs to another tree)
                     static_for_asc(std::make_integer_sequence<int, (NACC + 1) / 2>{}, [&](auto i2c) {
                         constexpr int i2 = decltype(i2c)::value;
                         const D2 h = ph[i2], l = pl[i2];
-                        visit(std::integral_constant<int, 2 * i2>{}, h.x - keep * l.x);
-                        if constexpr (2 * i2 + 1 < NACC) visit(std::integral_constant<int, 2 * i2 + 1>{}, h.y - keep * l.y);
+                        visit(std::integral_constant<int, 2 * i2>{}, (keep ? h.x - l.x : h.x));
+                        if constexpr (2 * i2 + 1 < NACC) visit(std::integral_constant<int, 2 * i2 + 1>{}, (keep ? h.y - l.y : h.y));
                         if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
                     });
                 } else if (lscan) {
@@ -1779,15 +1833,16 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const int a = bsrc, top = a + mp->subsize[a] - 1;
                     const D2 *ph = reinterpret_cast<const D2 *>(STG + TBS * top);
                     const D2 *pl = reinterpret_cast<const D2 *>(STG + TBS * (a > 0 ? a - 1 : 0));
-                    const double keep = a > 0 ? 1. : 0.;
+                    const bool keep = !((mp->rootmask >> a) & 1ull);       // (a root's sums start with itself: nothing to subtract,
+                                                                            //  and the row before it belongs to another tree)
                     static_assert(TB_PASS1 % 2 == 0 && NACC - TB_PASS1 <= TB_STRIDE && NACC <= TB_STRIDE1, "prefix table passes");
                     // (the accumulators of the two passes are disjoint -- R, M dX', rhs from M | rhs; G, P from A -- so the
                     // order of the passes does not change a bit of the results)
                     static_for_asc(std::make_integer_sequence<int, (NACC - TB_PASS1 + 1) / 2>{}, [&](auto i2c) {
                         constexpr int i2 = decltype(i2c)::value;
                         const D2 h = ph[i2], l = pl[i2];
-                        visit(std::integral_constant<int, TB_PASS1 + 2 * i2>{}, h.x - keep * l.x);
-                        if constexpr (TB_PASS1 + 2 * i2 + 1 < NACC) visit(std::integral_constant<int, TB_PASS1 + 2 * i2 + 1>{}, h.y - keep * l.y);
+                        visit(std::integral_constant<int, TB_PASS1 + 2 * i2>{}, (keep ? h.x - l.x : h.x));
+                        if constexpr (TB_PASS1 + 2 * i2 + 1 < NACC) visit(std::integral_constant<int, TB_PASS1 + 2 * i2 + 1>{}, (keep ? h.y - l.y : h.y));
                         if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
                     });
                     WAVE_SYNC();                   // every lane has consumed the first pass: the table is rewritten
@@ -1795,8 +1850,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     static_for_asc(std::make_integer_sequence<int, TB_PASS1 / 2>{}, [&](auto i2c) {
                         constexpr int i2 = decltype(i2c)::value;
                         const D2 h = ph[i2], l = pl[i2];
-                        visit(std::integral_constant<int, 2 * i2>{}, h.x - keep * l.x);
-                        visit(std::integral_constant<int, 2 * i2 + 1>{}, h.y - keep * l.y);
+                        visit(std::integral_constant<int, 2 * i2>{}, (keep ? h.x - l.x : h.x));
+                        visit(std::integral_constant<int, 2 * i2 + 1>{}, (keep ? h.y - l.y : h.y));
                         if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
                     });
                 } else {
@@ -1875,7 +1930,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const unsigned long long a0 = ((unsigned long long)(unsigned)ci[4] << 32) | (unsigned)ci[3];
                     const double s = (double)cd[CD_ACTIVE] * ((double)((a1 >> lane) & 1ull) - (double)((a0 >> lane) & 1ull));
                     const M3<double> Rx = ld_m3_as<double>(cd + CD_R1);
-                    const V3<double> px = cvt_v3<double>(ld_v3(cd + CD_P1));
+                    // (the frame was stored about the root of body 1's tree; the columns of a dof of another tree are about
+                    // that tree's root: shift by the difference -- exactly zero inside the frame's own tree)
+                    const V3<double> px = cvt_v3<double>(ld_v3(cd + CD_P1)) + mv(Rx, p0k - ld_v3(PD + 12 * ci[6] + 9));
                     const V3<double> cw = mv(Rx, v3<double>(Xk[0], Xk[1], Xk[2]));
                     const V3<double> cv = mv(Rx, v3<double>(Xk[3], Xk[4], Xk[5])) + cross(px, cw);
                     if (lane < n) {
@@ -1892,7 +1949,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             if (MODE == 1 && step == 0 && (dbg.jac != nullptr || dbg.djac != nullptr)) {
                 for (int b = 0; b < nb; ++b) {
                     const M3<double> R = ld_m3(PD + 12 * b);
-                    const V3<double> p = ld_v3(PD + 12 * b + 9) - p0w;
+                    const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);
                     const V3<double> obw = v3<double>((double)bcast(om_b[0], b), (double)bcast(om_b[1], b), (double)bcast(om_b[2], b));
                     const V3<double> obv = v3<double>((double)bcast(om_b[3], b), (double)bcast(om_b[4], b), (double)bcast(om_b[5], b));
                     const bool mine = (lane < n) && ((mp->anc[b] >> lane) & 1ull);
@@ -2352,6 +2409,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     // ---- store state -------------------------------------------------------
     ARB_OPAQUE_LANE();
     ARB_STAMP(7);
+    if (dead != 0u) {               // retired copies of a forest world leave NaN behind
+        const int fn = ARB_UNI(mp->fn), fnq = ARB_UNI(mp->fnq), fnd = ARB_MAXDOL * ARB_UNI(mp->fnc);
+        for (int i = lane; i < nq; i += WAVE) if ((dead >> (i / fnq)) & 1u) qs[i] = (T)NAN;
+        if (lane < n && ((dead >> (lane / fn)) & 1u)) dqs[lane] = (T)NAN;
+        for (int i = lane; i < ndol; i += WAVE) if ((dead >> (i / fnd)) & 1u) FF[i] = (T)NAN;
+        WAVE_SYNC();
+    }
     if (MODE == 0) {
         if constexpr (PACK) {
             const Layout &lp = mp->layp;
@@ -2758,7 +2822,9 @@ static std::vector<double> h12(const double *H16, int count) {
 //        phase C) -> solution columns [Y rhs | Y J'^T] (phase D .. E)
 // (round 3: SC and AM had regions of their own and the prefix table was 70 float64 wide: 19.4 KB per human36 world;
 // 13.1 KB now, which lets twelve wavefronts share a CU's LDS instead of eight)
-static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
+// (up to 32 bodies on the tiles of up to 32 rows: the forests of small models, whose copies the table's restart at
+// every root keeps apart -- the DPP scan of the larger trees runs across all bodies of the wavefront)
+static bool lds_scan(int nb, int rs) { return (nb <= 24 && rs <= 48) || (nb <= 32 && rs <= 32); }
 static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int tb = lds_scan(nb, rs) ? al(nb * (two_pass ? TB_STRIDE : TB_STRIDE1) * elems_per_double) : 0;
@@ -2832,10 +2898,19 @@ static void fill(T (&dst)[N], const S *src, size_t count) {
 template <typename T>
 static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<int> &jnd,
                      const std::vector<int> &depth, const std::vector<unsigned long long> &anc,
-                     const std::vector<int> &dof2q, int maxdepth, const TreeTables &tt, DevModel<T> *out) {
+                     const std::vector<int> &dof2q, int maxdepth, const TreeTables &tt, int fk, DevModel<T> *out) {
     DevModel<T> &m = *out;
     memset(&m, 0, sizeof(m));
     const int nb = d->nb, n = d->ndof, nc = d->nc;
+    m.fk = fk; m.fn = n / fk; m.fnq = d->nq / fk; m.fnc = nc / fk;
+    {
+        std::vector<T> qdef((size_t)d->nq, T(0));
+        for (int b = 0; b < nb; ++b)
+            if (d->jtype[b] == ARB_JT_FREE)
+                for (int i = 0; i < 4; ++i) qdef[(size_t)d->q_off[b] + 5 * i] = T(1);
+        int rcq;
+        if ((rcq = upload<T>(M, qdef, &m.qdef)) != ARB_OK) return rcq;
+    }
     m.nb = nb; m.n = n; m.nq = d->nq; m.nc = nc; m.ndol = ARB_MAXDOL * nc; m.ncols = n + 1 + m.ndol;
     m.maxdepth = maxdepth;
     int rc;
@@ -2843,6 +2918,11 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
     fill(m.jnd, jnd.data(), nb); fill(m.q_off, d->q_off, nb); fill(m.depth, depth.data(), nb);
     fill(m.weighted, d->weighted, nb); fill(m.dof2q, dof2q.data(), n);
     fill(m.dofbody, tt.dofbody.data(), n); fill(m.subsize, tt.subsize.data(), nb);
+    m.rootmask = 0ull;
+    for (int b = 0; b < nb; ++b) {
+        m.root[b] = d->parent[b] < 0 ? b : m.root[d->parent[b]];
+        if (d->parent[b] < 0) m.rootmask |= 1ull << b;
+    }
     fill(m.upmask, tt.upmask.data(), n); fill(m.descmask, tt.descmask.data(), n); fill(m.anc, anc.data(), nb);
     const std::vector<double> hpr = h12(d->H_pr, nb), hcn = h12(d->H_cn, nb);
     fill(m.Hpr, hpr.data(), 12 * nb); fill(m.Hcn, hcn.data(), 12 * nb);
@@ -2935,20 +3015,20 @@ static const int kNmaxChoices[] = {16, 32, 44, 48, 64};    // 44: human36 (42 do
 
 static int forest_create(const arb_model_desc *d, int K, int device, arb_model **out);
 
-// How many copies of a small model share a wavefront (0 or 1: none).  Measured on an MI355X (tools/forest_probe.py, 40 320
-// worlds x 64 steps, M world-steps/s): simplearm (3 dofs) float32 63 alone, 288 with 5 copies (still the 16-row tile), 552
-// with 10 (32-row tile), 575 with 15 (48 rows), 242 with 21 (64 rows); float64 97 / 385 / 411 / 345 / 103; the 15-dof
-// free snake 50 alone, 87 as a pair; ball and socket (6 dofs, 1 constraint) 57 alone, 208 with 5 copies, 197 with 7 (two
-// column sets).  Hence: as many copies as fit the 32-row tile with ONE set of columns.  ARB_FOREST=0 in the environment
-// turns the forest off, ARB_FOREST=k asks for k copies (development).
+// How many copies of a small model share a wavefront (1: none).  Measured on an MI355X (tools/forest_probe.py, 40 320
+// worlds x 64 steps, M world-steps/s): simplearm (3 dofs) float32 60 alone, 274 with 5 copies (still the
+// 16-row tile), 447 with 10 (32-row tile), 241 with 21 (64 rows); float64 86 / 345 / 414 / 104; the 15-dof free snake 50
+// alone, 88 as a pair; ball and socket (6 dofs, 1 constraint) 54 alone, 212 with 5 copies, 193 with 7 (two column
+// sets).  Hence: as many copies as fit the 32-row tile with ONE set of columns, and the 32-body prefix table whose
+// restart at every root keeps the copies apart.  ARB_FOREST=0 in the environment turns the forest off, ARB_FOREST=k
+// asks for k copies (development).
 static int forest_copies(int nb, int n, int nc) {
     const int want = env_int("ARB_FOREST", -1);
     if (want == 0 || want == 1) return 1;
     int K = 1;
     for (int k = 2; k <= WAVE; ++k) {
-        const bool fits = k * nb <= WAVE && k * nc * ARB_MAXDOL <= WAVE &&
-                          (want > 1 ? (k * n <= WAVE && k * n + 1 + ARB_MAXDOL * k * nc <= 2 * WAVE)
-                                    : (k * n <= 32 && k * n + 1 + ARB_MAXDOL * k * nc <= WAVE));
+        const bool fits = k * nb <= 32 && k * nc * ARB_MAXDOL <= WAVE &&      // (32 bodies: the prefix table of phase B)
+                          k * n <= 32 && k * n + 1 + ARB_MAXDOL * k * nc <= (want > 1 ? 2 * WAVE : WAVE);
         if (!fits) break;
         K = k;
         if (want > 1 && k == want) break;
@@ -2956,13 +3036,15 @@ static int forest_copies(int nb, int n, int nc) {
     return K;
 }
 
-static int model_create(const arb_model_desc *d, int device, arb_model **out, bool with_forest);
+// fk = 1: the described world, plus its forest when it is small; fk > 1: `d` describes a forest of fk copies
+static int model_create(const arb_model_desc *d, int device, arb_model **out, int fk);
 
 extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model **out) {
-    return model_create(d, device, out, true);
+    return model_create(d, device, out, 1);
 }
 
-static int model_create(const arb_model_desc *d, int device, arb_model **out, bool with_forest) {
+static int model_create(const arb_model_desc *d, int device, arb_model **out, int fk) {
+    const bool with_forest = fk == 1;
     if (d == nullptr || out == nullptr) return ARB_ERR_INVALID;
     *out = nullptr;
     if (d->abi_version != ARB_ABI_VERSION) return ARB_ERR_INVALID;
@@ -3056,7 +3138,7 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, bo
     M->nsets = (ncols > WAVE && !(nc == 0 && n == WAVE)) ? 2 : 1;
     M->nmax = 64;
     for (int c : kNmaxChoices) if (c >= n) { M->nmax = c; break; }
-    M->packable = nc >= 1 && nc <= 8;
+    M->packable = nc >= 1 && nc <= 8 && fk == 1;      // (a forest's copies are retired one by one, which the packed build does not do)
     for (int c = 0; c < nc; ++c)
         M->packable = M->packable && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_eps[3 * c] == 1. && d->c_eps[3 * c + 1] == 1. && d->c_eps[3 * c + 2] == 1.;
     DeviceGuard guard_(device);
@@ -3065,9 +3147,9 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, bo
         delete M;
         return ARB_ERR_HIP;
     }
-    int rc = build_dev<float>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->df);
+    int rc = build_dev<float>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, fk, &M->df);
     if (rc == ARB_OK)
-        rc = build_dev<double>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, &M->dd);
+        rc = build_dev<double>(M, d, jnd, depth, anc, dof2q, maxdepth, tt, fk, &M->dd);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     {
         void *hp = nullptr, *dp = nullptr;
@@ -3081,10 +3163,11 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, bo
         M->df.status = M->dd.status = static_cast<int *>(dp);
     }
     int tot;
-    M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
+    const bool small_tile = M->nmax <= 32;             // (two-pass prefix table in every build, see the kernel)
+    M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, small_tile);
     M->lf3 = M->df.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true);
     M->lfp = M->df.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true, true);
-    M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
+    M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot, small_tile);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     {
         // one blob per precision
@@ -3178,7 +3261,7 @@ static int forest_create(const arb_model_desc *d, int K, int device, arb_model *
     f.c_local = ptr_d(c_local); f.c_radius = ptr_d(c_radius); f.c_radius0 = ptr_d(c_radius0); f.c_half = ptr_d(c_half);
     f.c_plane = ptr_d(c_plane); f.c_mu = ptr_d(c_mu); f.c_prox = ptr_d(c_prox); f.c_eps = ptr_d(c_eps);
     f.c_min = ptr_d(c_min); f.c_max = ptr_d(c_max); f.c_bpose0 = ptr_d(c_bpose0); f.c_bpose1 = ptr_d(c_bpose1);
-    return model_create(&f, device, out, false);
+    return model_create(&f, device, out, K);
 }
 
 extern "C" int arb_model_destroy(arb_model *M) {

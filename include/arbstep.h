@@ -116,15 +116,18 @@ enum {
                                          a pin the model has no build for is ignored. */
 #define ARB_STEP_ONE_WORLD 256u        /* one world per wavefront even for a small model.  Default: the worlds of a model of at most
                                          16 dofs share wavefronts -- arb_model_create also builds a FOREST of k independent
-                                         copies of the model (as many as fit a 32-row tile and one set of columns: 10 simplearms),
-                                         and a batch of nw worlds runs as nw / k forest worlds on the same buffers (world w is
-                                         copy w % k of forest world w / k; the last nw % k worlds run one per wavefront) once
-                                         nw exceeds the wave slots of the device.  The copies share nothing but ground, gravity
-                                         and dt: the augmented system is block diagonal, products with the exact zeros between the
-                                         blocks change nothing, and float32 results were bit-identical on every model tried
-                                         (float64: to 1e-13, the composites of phase B being differences of prefix sums over all
-                                         bodies of the wavefront).  Launches that log energies (per world) or that log states for
-                                         a batch that is not a multiple of k run one world per wavefront. */
+                                         copies of the model (as many as fit a 32-row tile, one set of columns and 32 bodies:
+                                         10 simplearms), and a batch of nw worlds runs as nw / k forest worlds on the same
+                                         buffers (world w is copy w % k of forest world w / k; the last nw % k worlds run one per
+                                         wavefront) once nw exceeds the wave slots of the device.  The copies share nothing but
+                                         ground, gravity and dt: the augmented system is block diagonal and products with the
+                                         exact zeros between the blocks change nothing, every tree is assembled about its own
+                                         root -- results are bit-identical to one world per wavefront (tests/test_gpu_forest.py).
+                                         A copy whose state is not finite, or beyond +-1e8 (float32) / 1e100, at the beginning
+                                         of a step is retired: NaN in its state, forces and logs from then on, its neighbours
+                                         untouched (a NaN in a user torque or PD input of one copy is NOT contained).  Launches
+                                         that log energies (per world) or that log states for a batch that is not a multiple of
+                                         k run one world per wavefront. */
 #define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u)
 
 /*

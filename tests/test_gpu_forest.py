@@ -212,3 +212,71 @@ def test_forest_contact_worlds_through_the_work_queue():
     oq, odq, _ = O.rollout(m, f(q[sel]), f(dq[sel]), [5e-3] * 40)
     assert rel(res[False][0][sel], oq) < 1e-4 and rel(res[False][1][sel], odq) < 1e-3
     bw.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_forest_retires_diverged_copies_without_touching_their_neighbours(dtype):
+    """The copies of a forest world share the elimination, where "exact zero x NaN" would spread one copy's NaN to all the
+    others.  A copy whose state is not finite (or beyond 1e8 / 1e100) at the beginning of a step is retired instead:
+    NaN in its state, forces and logs from then on -- as the one-world kernels leave a world that overflowed -- and
+    every other world exactly what it is without the sick ones."""
+    from arboris_python_amd.batch import BatchedWorlds
+    g = load_golden("g7_shapes.npz")
+    m, _, _ = load_model("shapes_plane_ball")
+    bw = BatchedWorlds(m)
+    K = bw.info["forest_copies"]
+    cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
+    B = 16 * cus * K                        # (through the work queue: a retired copy stays retired from chunk to chunk)
+    Q, DQ = g["plane_ball_q"], g["plane_ball_dq"]
+    rng = np.random.default_rng(12)
+    pick = rng.integers(0, len(Q) - 1, size=B)
+    q, dq = Q[pick].copy(), DQ[pick].copy()
+    sick = rng.choice(B, size=200, replace=False)
+    kinds = rng.integers(0, 4, size=len(sick))
+    qs, dqs = q.copy(), dq.copy()
+    for w, kind in zip(sick, kinds):
+        if kind == 0:
+            qs[w, 3] = np.nan                # a NaN position
+        elif kind == 1:
+            dqs[w, 4] = np.inf               # an infinite velocity
+        elif kind == 2:
+            dqs[w, 1] = 3e9 if dtype == torch.float32 else 1e120   # diverged: beyond the retirement range
+        else:
+            qs[w, :] = np.nan
+    T = 12
+    healthy = np.setdiff1d(np.arange(B), sick)
+    out = {}
+    for name, (qq, dd) in (("clean", (q, dq)), ("sick", (qs, dqs))):
+        tq, tdq = bw.to_device(qq, dd, dtype)
+        cf = bw.new_cforce(B, dtype)
+        assert bw.plan(B, T, dtype=dtype)["worlds_per_wavefront"] == K
+        logs = bw.rollout(tq, tdq, 5e-3, T, cforce=cf, log_energy=False)
+        torch.cuda.synchronize()
+        bw.status()
+        out[name] = [t.cpu().numpy() for t in (tq, tdq, cf, logs["q"], logs["dq"])]
+    # (to rounding, not bit for bit: a retired copy's state of rest changes the prefix sums the composites of the copies
+    # after it are differences of, in float64)
+    tol = 1e-11 if dtype == torch.float64 else 1e-5
+    for k, (a, b) in enumerate(zip(out["clean"], out["sick"])):
+        if a.ndim == 3 and a.shape[0] == T:          # logs [step][world][..]
+            a, b = a[:, healthy].reshape(T * len(healthy), -1), b[:, healthy].reshape(T * len(healthy), -1)
+        else:
+            a, b = a[healthy].reshape(len(healthy), -1), b[healthy].reshape(len(healthy), -1)
+        assert np.isfinite(b).all()
+        assert rel(b, a) < (tol if k != 2 else 1e3 * tol), (k, rel(b, a))
+    sq, sdq, scf, lq, ldq = out["sick"]
+    assert np.isnan(sq[sick]).all() and np.isnan(sdq[sick]).all() and np.isnan(scf[sick]).all()
+    assert np.isnan(lq[1:, sick]).all() and np.isnan(ldq[1:, sick]).all()
+    assert np.isfinite(sq[healthy]).all()
+    # a world that diverges DURING the launch: huge but finite velocity, retired at the next step it exceeds the range
+    q2, dq2 = q.copy(), dq.copy()
+    w = int(healthy[7])
+    dq2[w, 3:] = 2e7 if dtype == torch.float32 else 1e60
+    tq, tdq = bw.to_device(q2, dq2, dtype)
+    cf = bw.new_cforce(B, dtype)
+    bw.step(tq, tdq, 5e-3, T, cforce=cf)
+    torch.cuda.synchronize()
+    r = tq.cpu().numpy()
+    others = np.setdiff1d(np.arange(B), [w])
+    assert np.isfinite(r[others]).all() and rel(r[others], out["clean"][0][others]) < tol
+    bw.close()

@@ -1,9 +1,12 @@
 #!/bin/bash
-# Same-box A/B of development builds (tools/quick_build.sh): AB_VARIANTS="a b" [AB_ARGS="--batch 65536"] tools/ab_bench.sh
-# runs bench.py on build/ab/<variant>.so twice, interleaved, and prints world-steps/s.
-set -e
-for r in 1 2; do
- for v in ${AB_VARIANTS:-old new}; do
-  echo -n "$v: "; ARBSTEP_LIB=build/ab/$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --no-per-step-leg --min-seconds 2 ${AB_ARGS} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])"
- done
+# Run on the GPU box: A/B of development builds (tools/quick_build.sh) on the headline workload, interleaved, 3 rounds.
+# usage: tools/ab_bench.sh <out-name> <lib-a> <lib-b> [bench args]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$1.txt; A=$2; B=$3; shift 3
+: > $OUT
+for round in 1 2 3; do
+  for lib in $A $B; do
+    v=$(ARBSTEP_LIB=$R/build/ab/$lib.so python3 $R/bench.py --steps 40 --warmup 40 --min-seconds 2 --no-cpu-baseline --no-per-step-leg "$@" 2>/dev/null | python3 -c "import sys,json; print('%.3f' % (json.loads(sys.stdin.readline())['value']/1e6))") || exit 1
+    echo "round $round $lib: $v M" | tee -a $OUT
+  done
 done
