@@ -142,7 +142,7 @@ class BatchedWorlds(object):
         ``waves=2|3`` pins the float32 kernel build (ARB_STEP_WAVES2/3, include/arbstep.h): by default the library picks
         by batch size; the builds agree to rounding, each is bit-reproducible across launch shapes.
         ``one_world=True``: one world per wavefront even for a small model (ARB_STEP_ONE_WORLD).  By default the worlds
-        of a model of at most 16 dofs share wavefronts once the batch exceeds the device's wave slots: the library
+        of a model of at most 16 dofs share wavefronts once the batch exceeds twice the device's wave slots: the library
         steps ``B // k`` worlds of a forest of ``k = self.info["forest_copies"]`` copies of the model on the same buffers.
         ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller).
         ``pd_targets=(qdes, dqdes)`` (B,ndof) each: one ProportionalDerivativeController target

@@ -2702,7 +2702,7 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 1, 3, 0>(ARB_LAUNCH_ONE_AR
 #if ARB_PART_IS_FLOAT
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 3, 1>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
-#if ARB_PART_NMAX <= 48
+#if ARB_PART_NMAX >= 44 && ARB_PART_NMAX <= 48      /* (the 16- and 32-row tiles: two waves are faster at every batch size, see choose_build) */
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
@@ -3296,7 +3296,10 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 struct BuildChoice { bool w3 = false, pack = false; long slots2 = 0, slots3 = 0, slotsp = 0; };
 static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nsteps, unsigned flags) {
     BuildChoice bc;
-    if (!(M->nsets == 1 && M->nmax <= 48)) return bc;
+    // (tiles of 44 and 48 rows.  The 16- and 32-row kernels use ~100 VGPRs less: their two-wave build has no spills and
+    // measured faster than a three-wave build at every batch size -- simplearm, one world per wavefront: 101 against
+    // 60 M world-steps/s; its forest of 10: 494 against 389 M at 65 536 worlds --, so they have no other)
+    if (!(M->nsets == 1 && M->nmax >= 44 && M->nmax <= 48)) return bc;
     static thread_local int cus_dev = -1, cus = 0;
     if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
     const long pad = std::max(0, env_int("ARB_LDS_PAD", 0));
@@ -3384,7 +3387,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         if constexpr (MODE == 0 && std::is_same<T, float>::value) {                                    \
             if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 3, 1) : ONE_(NM, 1, 3, 1);                  \
         }                                                                                              \
-        if constexpr (MODE == 0 && std::is_same<T, float>::value && NM <= 48) {                        \
+        if constexpr (MODE == 0 && std::is_same<T, float>::value && NM >= 44 && NM <= 48) {            \
             if (pack) return plain ? ONE_(NM, 1, 0, 3) : ONE_(NM, 1, 1, 3);                            \
             if (w3) return plain ? ONE_(NM, 1, 0, 2) : noopt ? ONE_(NM, 1, 1, 2) : ONE_(NM, 1, 3, 2);  \
         }                                                                                              \
@@ -3473,7 +3476,7 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
 }
 
 // Does a launch run on the forest of a small model (arb_model::forest, ARB_STEP_ONE_WORLD)?  When the batch is larger than
-// the device has wave slots -- below that every world has a wavefront to itself anyway and the forest's larger tile
+// twice the wave slots of the device -- below that every world has a wavefront to itself anyway and the forest's larger tile
 // only lengthens the step --, and when its logs keep their layout: state logs [step][world][..] of a batch that is a
 // multiple of k are the forest's logs; energies are per world, which a forest world does not have.
 static int device_cus(int device) {
@@ -3484,7 +3487,7 @@ static int device_cus(int device) {
 static bool use_forest(const arb_model *M, int64_t nworlds, uint32_t flags, const arb_rollout_log *log) {
     if (!M->forest || (flags & (ARB_STEP_ONE_WORLD | ARB_STEP_SPLIT_WAVE | ARB_STEP_MFMA_ELIM))) return false;
     if (log && (log->energy_log || ((log->q_log || log->dq_log) && nworlds % M->forest_k != 0))) return false;
-    return nworlds > 8l * device_cus(M->device);
+    return nworlds > 16l * device_cus(M->device);      // (measured, simplearm: 4096 worlds 98 alone / 91 M as a forest, 8192: 100 / 181)
 }
 
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,

@@ -119,7 +119,7 @@ enum {
                                          copies of the model (as many as fit a 32-row tile, one set of columns and 32 bodies:
                                          10 simplearms), and a batch of nw worlds runs as nw / k forest worlds on the same
                                          buffers (world w is copy w % k of forest world w / k; the last nw % k worlds run one per
-                                         wavefront) once nw exceeds the wave slots of the device.  The copies share nothing but
+                                         wavefront) once nw exceeds twice the wave slots of the device (4096 on an MI355X).  The copies share nothing but
                                          ground, gravity and dt: the augmented system is block diagonal and products with the
                                          exact zeros between the blocks change nothing, every tree is assembled about its own
                                          root -- results are bit-identical to one world per wavefront (tests/test_gpu_forest.py).

@@ -42,7 +42,7 @@ def _tiled(Q, DQ, B):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_forest_single_steps_match_the_reference(name, dtype):
     """Every step of the reference's trajectory from the reference's own state, tiled to a batch that runs on the forest
-    (more worlds than wave slots, not a multiple of the copies: the last worlds run one per wavefront)."""
+    (more worlds than twice the wave slots, not a multiple of the copies: the last worlds run one per wavefront)."""
     from arboris_python_amd.batch import BatchedWorlds
     gfile, kq, kdq, dt = CASES[name]
     g = load_golden(gfile)
@@ -51,12 +51,12 @@ def test_forest_single_steps_match_the_reference(name, dtype):
     K = bw.info["forest_copies"]
     assert K >= 2, "a %d-dof model should have a forest" % m.ndof
     cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
-    B = 8 * cus + 3 * K + 1
+    B = 16 * cus + 3 * K + 1
     B += 1 if B % K == 0 else 0
     p = bw.plan(B, 1, dtype=dtype)
     assert p["worlds_per_wavefront"] == K
     assert bw.plan(B, 1, dtype=dtype, one_world=True)["worlds_per_wavefront"] == 1
-    assert bw.plan(8 * cus, 1, dtype=dtype)["worlds_per_wavefront"] == 1          # every world has a wavefront anyway
+    assert bw.plan(16 * cus, 1, dtype=dtype)["worlds_per_wavefront"] == 1          # every world has a wavefront anyway
     q, dq, qn, dqn = _tiled(g[kq], g[kdq], B)
     if dtype == torch.float32:
         f = lambda a: np.asarray(a, np.float32).astype(np.float64)
@@ -94,7 +94,7 @@ def test_forest_simplearm_rollout_logs_and_timeline(dtype):
     K = bw.info["forest_copies"]
     assert K == 10
     cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
-    B = (8 * cus // K + 7) * K
+    B = (16 * cus // K + 7) * K
     rng = np.random.default_rng(4)
     q = np.tile(q0, (B, 1)) + 0.5 * rng.standard_normal((B, m.nq))
     dq = np.tile(dq0, (B, 1)) + 0.5 * rng.standard_normal((B, m.ndof))
@@ -150,7 +150,7 @@ def test_forest_per_world_pd_inputs_and_torques(dtype, tol):
         Q, DQ = g[tag + "_q"], g[tag + "_dq"]
         S, W = Q.shape[0] - 1, Q.shape[1]
         n0 = S * W
-        B = 8 * cus + K + 1
+        B = 16 * cus + K + 1
         reps = -(-B // n0)
         til = lambda a: np.tile(a, (reps, 1))[:B]
         q, dq = til(Q[:S].reshape(n0, -1)), til(DQ[:S].reshape(n0, -1))
