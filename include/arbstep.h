@@ -122,7 +122,9 @@ enum {
                                          wavefront) once nw exceeds twice the wave slots of the device (4096 on an MI355X).  The copies share nothing but
                                          ground, gravity and dt: the augmented system is block diagonal and products with the
                                          exact zeros between the blocks change nothing, every tree is assembled about its own
-                                         root -- results are bit-identical to one world per wavefront (tests/test_gpu_forest.py).
+                                         root -- results are bit-identical to one world per wavefront for models without constraints, and within a
+                                         few ulps with constraints (the constraint-space products sum the dofs in groups of four;
+                                         tests/test_gpu_forest.py, test_gpu_random_models.py).
                                          A copy whose state is not finite, or beyond +-1e8 (float32) / 1e100, at the beginning
                                          of a step is retired: NaN in its state, forces and logs from then on, its neighbours
                                          untouched (a NaN in a user torque or PD input of one copy is NOT contained).  Launches

@@ -135,4 +135,29 @@ def test_random_model_single_steps(seed):
         # (NaN-safe: compare bit patterns)
         bits = lambda t: t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int64)
         assert all(torch.equal(bits(a), bits(b)) for a, b in zip(*res)), (seed, dtype)
+    # small models: the worlds of a large batch share wavefronts (the library's forest of k copies) -- bit for bit what
+    # one world per wavefront computes, for every world that stays finite there; worlds that do not are retired (NaN)
+    if bw.info["forest_copies"] > 1:
+        for dtype in (torch.float32, torch.float64):
+            res = []
+            for one in (True, False):
+                aq, adq = bw.to_device(qb, dqb, dtype)
+                acf = bw.new_cforce(len(qb), dtype)
+                assert bw.plan(len(qb), 3, dtype=dtype, one_world=one)["worlds_per_wavefront"] == (1 if one else bw.info["forest_copies"])
+                bw.step(aq, adq, dt, 3, cforce=acf, one_world=one)
+                res.append((aq.cpu().numpy(), adq.cpu().numpy(), acf.cpu().numpy().reshape(len(qb), -1)))
+            torch.cuda.synchronize()
+            lim = 1e8 if dtype == torch.float32 else 1e100
+            fin = np.all(np.abs(res[0][0]) < lim, axis=1) & np.all(np.abs(res[0][1]) < lim, axis=1) & np.all(np.abs(res[0][2]) < lim, axis=1)
+            assert fin.sum() >= len(qb) // 6
+            # (bit for bit when the model has no constraints or ndof is a multiple of four; otherwise to a few ulps: the
+            # constraint-space products of phase D sum over the dof index in groups of four, and copy j's dofs start at
+            # j * ndof.  Forces are (mass / dt) x velocity differences: 1e3 x the tolerance)
+            for k, (a1, af) in enumerate(zip(res[0], res[1])):
+                if m.nc == 0 or m.ndof % 4 == 0:
+                    assert np.array_equal(a1[fin], af[fin]), (seed, dtype, bw.info["forest_copies"])
+                else:
+                    err = np.abs(a1[fin] - af[fin]).max(axis=1) / np.maximum(1., np.abs(a1[fin]).max(axis=1))
+                    tol = (2e-5 if dtype == torch.float32 else 1e-11) * (1e3 if k == 2 else 1.)
+                    assert err.max() < tol, (seed, dtype, bw.info["forest_copies"], k, err.max())
     bw.close()
