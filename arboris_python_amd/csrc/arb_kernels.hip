@@ -1560,9 +1560,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // which takes the place of the per-body blocks: every lane has its own block in registers by now.
             // (the three-wave kernels pass the accumulators through a half-size table in two passes -- less LDS, more
             // registers held across the first pass --, the two-wave kernels through a full table in one)
-            // (the kernels of the 16- and 32-row tiles too, all builds and precisions: their tables hold up to 32 bodies -- the
-            // forests of small models -- and registers are not what limits them)
-            constexpr bool TWO_PASS = (CM == 2 || CM == 3 || NMAX <= 32);
+            // (measured on the 16- and 32-row tiles, whose register peak is the same phase A / B as the 44-row tile's: two passes
+            // in their two-wave kernels cost 65 spilled VGPRs and 3-6 %, tools/forest_rate.py)
+            constexpr bool TWO_PASS = (CM == 2 || CM == 3);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
             const bool lscan = LSCAN_OK && mp->lay.lscan;
             const bool use_table = lscan && TWO_PASS;
@@ -2822,9 +2822,9 @@ static std::vector<double> h12(const double *H16, int count) {
 //        phase C) -> solution columns [Y rhs | Y J'^T] (phase D .. E)
 // (round 3: SC and AM had regions of their own and the prefix table was 70 float64 wide: 19.4 KB per human36 world;
 // 13.1 KB now, which lets twelve wavefronts share a CU's LDS instead of eight)
-// (up to 32 bodies on the tiles of up to 32 rows: the forests of small models, whose copies the table's restart at
-// every root keeps apart -- the DPP scan of the larger trees runs across all bodies of the wavefront)
-static bool lds_scan(int nb, int rs) { return (nb <= 24 && rs <= 48) || (nb <= 32 && rs <= 32); }
+// (the table restarts at every root, which keeps the trees of a wavefront -- the copies of a forest -- apart; the DPP
+// scan of the larger trees runs across all bodies of the wavefront)
+static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
 static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int tb = lds_scan(nb, rs) ? al(nb * (two_pass ? TB_STRIDE : TB_STRIDE1) * elems_per_double) : 0;
@@ -3015,19 +3015,19 @@ static const int kNmaxChoices[] = {16, 32, 44, 48, 64};    // 44: human36 (42 do
 
 static int forest_create(const arb_model_desc *d, int K, int device, arb_model **out);
 
-// How many copies of a small model share a wavefront (1: none).  Measured on an MI355X (tools/forest_probe.py, 40 320
-// worlds x 64 steps, M world-steps/s): simplearm (3 dofs) float32 60 alone, 274 with 5 copies (still the
-// 16-row tile), 447 with 10 (32-row tile), 241 with 21 (64 rows); float64 86 / 345 / 414 / 104; the 15-dof free snake 50
-// alone, 88 as a pair; ball and socket (6 dofs, 1 constraint) 54 alone, 212 with 5 copies, 193 with 7 (two column
-// sets).  Hence: as many copies as fit the 32-row tile with ONE set of columns, and the 32-body prefix table whose
-// restart at every root keeps the copies apart.  ARB_FOREST=0 in the environment turns the forest off, ARB_FOREST=k
-// asks for k copies (development).
+// How many copies of a small model share a wavefront (1: none).  Measured on an MI355X (tools/forest_probe.py,
+// tools/forest_rate.py, M world-steps/s at 65 536 worlds x 64 steps): simplearm (3 dofs) float32 106
+// alone, 274 with 5 copies (still the 16-row tile), 526 with 8, 241 with 21 (64 rows); float64 86 / 345 / ~400 / 104;
+// the 15-dof free snake 62 alone, 95 as a pair; ball and socket (6 dofs, 1 constraint) 83 alone, 198 with 5 copies,
+// 193 with 7 (two column sets).  Hence: as many copies as fit the 32-row tile with ONE set of columns, and the 24-body
+// prefix table whose restart at every root keeps the copies apart.  ARB_FOREST=0 in the environment turns the forest
+// off, ARB_FOREST=k asks for k copies (development).
 static int forest_copies(int nb, int n, int nc) {
     const int want = env_int("ARB_FOREST", -1);
     if (want == 0 || want == 1) return 1;
     int K = 1;
     for (int k = 2; k <= WAVE; ++k) {
-        const bool fits = k * nb <= 32 && k * nc * ARB_MAXDOL <= WAVE &&      // (32 bodies: the prefix table of phase B)
+        const bool fits = k * nb <= 24 && k * nc * ARB_MAXDOL <= WAVE &&      // (24 bodies: the prefix table of phase B)
                           k * n <= 32 && k * n + 1 + ARB_MAXDOL * k * nc <= (want > 1 ? 2 * WAVE : WAVE);
         if (!fits) break;
         K = k;
@@ -3163,11 +3163,10 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
         M->df.status = M->dd.status = static_cast<int *>(dp);
     }
     int tot;
-    const bool small_tile = M->nmax <= 32;             // (two-pass prefix table in every build, see the kernel)
-    M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, small_tile);
+    M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
     M->lf3 = M->df.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true);
     M->lfp = M->df.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true, true);
-    M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot, small_tile);
+    M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     {
         // one blob per precision

@@ -527,7 +527,7 @@ def main():
                                        "finite": bool(torch.isfinite(qe).all())}
             b2.close()
         # BASELINE config #1's robot as a batch: simplearm (3 dofs), 65 536 worlds x 64 steps, float32 -- small worlds
-        # share wavefronts (the library's forest of 10 copies, include/arbstep.h ARB_STEP_ONE_WORLD), against one world
+        # share wavefronts (the library's forest of 8 copies, include/arbstep.h ARB_STEP_ONE_WORLD), against one world
         # per wavefront
         from arboris_python_amd import scenes
         mdl = scenes.flat(scenes.simplearm_world())

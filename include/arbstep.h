@@ -116,8 +116,8 @@ enum {
                                          a pin the model has no build for is ignored. */
 #define ARB_STEP_ONE_WORLD 256u        /* one world per wavefront even for a small model.  Default: the worlds of a model of at most
                                          16 dofs share wavefronts -- arb_model_create also builds a FOREST of k independent
-                                         copies of the model (as many as fit a 32-row tile, one set of columns and 32 bodies:
-                                         10 simplearms), and a batch of nw worlds runs as nw / k forest worlds on the same
+                                         copies of the model (as many as fit a 32-row tile, one set of columns and 24 bodies:
+                                         8 simplearms), and a batch of nw worlds runs as nw / k forest worlds on the same
                                          buffers (world w is copy w % k of forest world w / k; the last nw % k worlds run one per
                                          wavefront) once nw exceeds twice the wave slots of the device (4096 on an MI355X).  The copies share nothing but
                                          ground, gravity and dt: the augmented system is block diagonal and products with the

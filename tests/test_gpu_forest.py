@@ -85,14 +85,14 @@ def test_forest_single_steps_match_the_reference(name, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_forest_simplearm_rollout_logs_and_timeline(dtype):
-    """simplearm (3 dofs, 10 copies per wavefront): a 64-step launch with a non-uniform timeline and state logs on the
+    """simplearm (3 dofs, 8 copies per wavefront): a 64-step launch with a non-uniform timeline and state logs on the
     forest (batch a multiple of the copies) against the one-world launch and, world by world, against the oracle's
     rollout; a batch that is not a multiple logs through the one-world kernels and gives the same states."""
     from arboris_python_amd.batch import BatchedWorlds
     m, q0, dq0 = load_model("simplearm")
     bw = BatchedWorlds(m)
     K = bw.info["forest_copies"]
-    assert K == 10
+    assert K == 8
     cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
     B = (16 * cus // K + 7) * K
     rng = np.random.default_rng(4)
