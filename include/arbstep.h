@@ -107,8 +107,9 @@ enum {
 #define ARB_STEP_WAVES3 128u           /* the faster wave) or for three (more waves in flight: the faster chip once the batch fills
                                          them).  Default: the library picks by batch size and launch shape (three waves from
                                          ~4100 worlds on an MI355X; from 16384 worlds a third build that holds TWO worlds per
-                                         wavefront), for models that have those builds: float32, <= 48 dofs, ndof + 1 + 4 nc
-                                         <= 64.  All builds execute the same float operations in the same order per world --
+                                         wavefront), for models that have those builds: float32, 33 .. 48 dofs (the 44- and 48-row
+                                         register tiles; smaller models run faster on two waves at every batch size), ndof + 1 +
+                                         4 nc <= 64.  All builds execute the same float operations in the same order per world --
                                          the library is compiled with -ffp-contract=on, so no fused multiply-add depends on how
                                          the compiler inlined a function -- and give bit-identical results (tested across
                                          builds, batch positions, launch shapes; tests/test_gpu_round3.py).  The pins exist
