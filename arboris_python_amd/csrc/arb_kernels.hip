@@ -83,11 +83,11 @@
 #define BD_OM 12     // W_c, then the accumulated pseudo twist Om_b (6), see phase B
 #define BD_PT 18     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form
 #define BD_PG 24     // M_b g_b (6)
-#define BD_RG 30     // R of H_gb (9)
-#define BD_PGB 39    // p of H_gb (3)
-#define BD_TW 42     // body twist (6)
-#define BD_AB 48     // bias acceleration dJ_b * gvel (6)
-#define BD_STRIDE 54
+#define BD_TW 30     // body twist (6)
+#define BD_AB 36     // bias acceleration dJ_b * gvel (6)
+#define BD_STRIDE 42
+// (the world pose H_gb of a body lives in PD, in float64, only: a copy in T here cost 12 elements per body -- 6 KB of the
+// 43 KB of a float64 snake-64 wavefront, which kept its kernels at three wavefronts per CU instead of four)
 // Composite assembly of Z (phase B): per-body accumulators travelling up the tree, in float64:
 // A (36) | M upper triangle (21) | wrench of the increment rhs (6) | gravity wrench (6, inspect only)
 #define XPR_STRIDE 18     // float64 per dof: X (6) | P = A^T X (6) | R = M X (6)
@@ -861,8 +861,8 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
 // -- one dependent chain in which one quad of lanes works -- run for both worlds at once (gs_stage2); phase E follows
 // for each.  Same arithmetic world by world: bit-identical to the one-world kernels.  Float32, one column set, models
 // whose constraints are all SoftFingerContacts with eps = (1,1,1) and fit half a wavefront (nc <= 8), FEAT <= 1.
-// (float64 worlds on the 64-row tile -- snake-64 -- need 43 KB of LDS per wave: three waves per CU, less than one per
-// SIMD, so their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
+// (float64 worlds on the 64-row tile -- snake-64 -- need 36 KB of LDS per wave: four waves per CU, one per SIMD, so
+// their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
 __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVES(CM)) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
@@ -1288,12 +1288,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const M3<double> Rc_d = mul(Rg, R_pc_d);         // child_pose  core.py:1299
                     const V3<double> pc_d = mv(Rg, p_pc_d) + pg;
                     st_m3(PD + 12 * b, Rc_d); st_v3(PD + 12 * b + 9, pc_d);
-                    const M3<T> Rc = cvt_m3<T>(Rc_d);
-                    const V3<T> pc = cvt_v3<T>(pc_d);
                     const V3<T> cw = mv(R_cp, tw) + Tnw;             // child_twist core.py:1308
                     const V3<T> cv = cross(p_cp, mv(R_cp, tw)) + mv(R_cp, tv) + Tnv;
                     T *bd = BD + b * BD_STRIDE;
-                    st_m3(bd + BD_RG, Rc); st_v3(bd + BD_PGB, pc);
                     st_v3(bd + BD_TW, cw); st_v3(bd + BD_TW + 3, cv);
                     // dJ_c gvel = dAd_cp T_p + Ad_cp (dJ_p gvel) + Ad_cn dJ_nr gvel_j   (core.py:1312-1313 times gvel)
                     const V3<T> raw = mv(R_cp, aw);
@@ -1315,7 +1312,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 // gravity in the body frame: Ad(inv(H_gb)) [0; g up]   controllers.py:56-58
                 T g6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
                 if (mp->has_grav && mp->weighted[b]) {
-                    const M3<T> Rg = ld_m3(bd + BD_RG);
+                    const M3<T> Rg = cvt_m3<T>(ld_m3(PD + 12 * b));
                     const V3<T> gl = mtv(Rg, v3<T>(mp->grav[0], mp->grav[1], mp->grav[2]));
                     g6[3] = gl.x; g6[4] = gl.y; g6[5] = gl.z;
                 }
@@ -1358,11 +1355,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         }
         if (MODE == 1 && step == 0) {
             if (dbg.pose != nullptr && lane < nb) {
-                const T *bd = BD + lane * BD_STRIDE;
+                const double *pw = PD + 12 * lane;
                 T *o = dbg.pose + (w * nb + lane) * 16;
                 for (int i = 0; i < 3; ++i) {
-                    for (int j = 0; j < 3; ++j) o[4 * i + j] = bd[BD_RG + 3 * i + j];
-                    o[4 * i + 3] = bd[BD_PGB + i];
+                    for (int j = 0; j < 3; ++j) o[4 * i + j] = (T)pw[3 * i + j];
+                    o[4 * i + 3] = (T)pw[9 + i];
                 }
                 o[12] = o[13] = o[14] = T(0); o[15] = T(1);
             }
