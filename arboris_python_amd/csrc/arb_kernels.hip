@@ -2162,16 +2162,24 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             Z[0] = t;
             if (NSETS == 2) Z2[0] = t2;
         }
+        // "Late rhs" worlds (64 dofs, no constraints: 65 columns on 64 lanes): lane 63 holds the column of dof 63 until the
+        // first pivot has used it, then the rhs column, whose entries wait in LDS.  Its own first update,
+        // Z[r] = rhs[r-1] - Z_old[r-1] t, runs AFTER the generic step of the first pivot from a copy of its old column in
+        // WORK.  (Round 2 had `if (take_rhs) prev = RT[r-1]` inside the row update: the compiler kept that conditional LDS
+        // read -- an exec-mask branch per row -- in EVERY pivot of the rolled loop, ~10 instructions per row instead of 3,
+        // and snake-64 spent 57 % of its step in this loop.)
+        if constexpr (NMAX == WAVE && NSETS == 1) {
+            if (late_rhs && lane == n - 1) {
+#pragma unroll
+                for (int r = 0; r < NMAX; ++r) WORK[r] = Z[r];
+            }
+        }
         for (int j = n - 1; j >= 0; --j) {
             const T piv = bcast(Z[NMAX - 1], j);
             const T ip = arb_rcp(piv);
-            T t = Z[NMAX - 1] * ip;
+            const T t = Z[NMAX - 1] * ip;
             T t2 = T(0);
             if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
-            // late rhs, first pivot: lane j works on the rhs column, whose entries come from LDS (no rotation has
-            // happened yet with n == NMAX: register r holds row r)
-            const bool take_rhs = late_rhs && j == n - 1 && lane == j;
-            if (late_rhs && j == n - 1 && lane == j) t = RT[NMAX - 1] * ip;
             // multipliers in groups of 8 broadcasts: the v_readlane -> SGPR -> v_fma wait states of one row are
             // filled by the broadcasts of the next rows instead of s_nop
 #ifndef ARB_PIVOT_GB
@@ -2187,14 +2195,23 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
                 for (int k = 0; k < GB; ++k) if (r0 - k >= 1) {
                     const int r = r0 - k;
-                    T prev = Z[r - 1];
-                    if (NMAX == WAVE && NSETS == 1) { if (take_rhs) prev = RT[r - 1]; }
-                    Z[r] = prev - f[k] * t;
+                    Z[r] = Z[r - 1] - f[k] * t;
                     if (NSETS == 2) Z2[r] = Z2[r - 1] - f[k] * t2;
                 }
             }
             Z[0] = t;
             if (NSETS == 2) Z2[0] = t2;
+            if constexpr (NMAX == WAVE && NSETS == 1) {
+                if (late_rhs && j == n - 1) {                  // (wave-uniform: once per step)
+                    asm volatile("");
+                    if (lane == j) {
+                        const T tr = RT[NMAX - 1] * arb_rcp(WORK[NMAX - 1]);
+#pragma unroll
+                        for (int r = NMAX - 1; r >= 1; --r) Z[r] = RT[r - 1] - WORK[r - 1] * tr;
+                        Z[0] = tr;
+                    }
+                }
+            }
         }
         }
         ARB_CSTAMP(5);

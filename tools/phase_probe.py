@@ -11,13 +11,14 @@ from arboris_python_amd.batch import BatchedWorlds
 from arboris_python_amd.flatten import replicate_model
 names = ["A", "A'", "B", "C", "D", "GS", "E"]
 for name, K, dtype in (("simplearm", 1, torch.float32), ("simplearm", 10, torch.float32), ("simplearm", 1, torch.float64),
-                       ("snake9_free_g", 1, torch.float32), ("human36_g", 1, torch.float32), ("human36_c4", 1, torch.float32)):
+                       ("snake9_free_g", 1, torch.float32), ("human36_g", 1, torch.float32), ("human36_c4", 1, torch.float32),
+                       ("snake64_g", 1, torch.float64)):
     m, q0, dq0 = load_model(name)
     if K > 1:
         m = replicate_model(m, K); q0 = np.tile(q0, K); dq0 = np.tile(dq0, K)
     os.environ["ARB_FOREST"] = "0"
     bw = BatchedWorlds(m)
-    B = 4096
+    B = 4096 if name != "snake64_g" else 2048
     rng = np.random.default_rng(0)
     q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1)) + 0.1 * rng.standard_normal((B, m.ndof))
     tq, tdq = bw.to_device(q, dq, dtype)
