@@ -587,6 +587,7 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
         int i = m;
         for (int j = m; j < n; ++j)
             if (arb_abs(E_(j, m - 1)) > arb_abs(x)) { x = E_(j, m - 1); i = j; }
+        if constexpr (sizeof(T) == 4) {
         // (loops over a data-dependent range run over all six indices with a predicate, operands read up front: in the
         // kernel the matrix is in LDS and ONE lane works on it -- every read the next operation waits for costs an LDS
         // round trip, so reads that do not depend on one another must be issued together.  Same arithmetic, element by
@@ -621,7 +622,24 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
                 }
             }
         }
-    }
+            } else {      // (float64: 36 more live registers than the kernels have)
+        if (i != m) {
+            for (int j = m - 1; j < n; ++j) { T t = E_(i, j); E_(i, j) = E_(m, j); E_(m, j) = t; }
+            for (int j = 0; j < n; ++j) { T t = E_(j, i); E_(j, i) = E_(j, m); E_(j, m) = t; }
+        }
+        if (x != T(0)) {
+            for (i = m + 1; i < n; ++i) {
+                T y = E_(i, m - 1);
+                if (y != T(0)) {
+                    y /= x;
+                    E_(i, m - 1) = y;
+                    for (int j = m; j < n; ++j) E_(i, j) -= y * E_(m, j);
+                    for (int j = 0; j < n; ++j) E_(j, m) += y * E_(j, i);
+                }
+            }
+        }
+            }
+}
     for (int i = 2; i < n; ++i)
         for (int j = 0; j < i - 1; ++j) E_(i, j) = T(0);
     // --- shifted QR on the Hessenberg matrix ---
@@ -712,6 +730,7 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
                             p += s;
                             x = p / s; y = q / s; z = r / s;
                             q /= p; r /= p;
+                            if constexpr (sizeof(T) == 4) {
                             const bool three = k != nn - 1;
                             const int k2 = three ? k + 2 : k + 1;            // (row / column k + 2 only exists then)
                             {
@@ -742,6 +761,21 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
                                         E_(i, k) = c0[i] - pp;
                                     }
                                 }
+                            }
+                            } else {
+                            for (int j = k; j <= nn; ++j) {
+                                p = E_(k, j) + q * E_(k + 1, j);
+                                if (k != nn - 1) { p += r * E_(k + 2, j); E_(k + 2, j) -= p * z; }
+                                E_(k + 1, j) -= p * y;
+                                E_(k, j) -= p * x;
+                            }
+                            int mmin = nn < k + 3 ? nn : k + 3;
+                            for (int i = l; i <= mmin; ++i) {
+                                p = x * E_(i, k) + y * E_(i, k + 1);
+                                if (k != nn - 1) { p += z * E_(i, k + 2); E_(i, k + 2) -= p * r; }
+                                E_(i, k + 1) -= p * q;
+                                E_(i, k) -= p;
+                            }
                             }
                         }
                     }
