@@ -1272,7 +1272,97 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 }
             }
             ARB_ASTAMP(3);
+#ifndef ARB_JUMP_DEPTH
+#define ARB_JUMP_DEPTH 12      // float64 kernels: trees deeper than this chain pose, twist and bias acceleration in log2(depth) rounds
+#endif
+            // Deep trees (the 64-link snake: 65 levels of ~2 k cycles each, one lane working -- 133 k of the step's 346 k
+            // cycles), float64 kernels: log-depth instead.  (1) Poses by pointer jumping: every body composes its pose
+            // with its current ancestor's and takes over that ancestor's ancestor, ceil(log2(depth + 1)) rounds.
+            // (2) Twists: in WORLD axes about the world origin a body's twist is its parent's plus its own joint's,
+            // Ad(H_gc) T_c = Ad(H_gp) T_p + Ad(H_gc) Tn_c, a prefix sum over the ancestors -- pointer jumping again -- and
+            // back to body axes.  (3) Bias accelerations likewise: Ad(H_gc) a_c = Ad(H_gp) a_p + Ad(H_gc)(dAd_cp T_p + Bn_c)
+            // with the parent's twist from (2).  World-frame sums carry lever arms of the size of the robot: float64 only
+            // (the float32 kernels and shallow trees keep the level loop below, whose operation order they are tested with).
+            bool jumped = false;
+            if constexpr (sizeof(T) == 8) {
+                const int maxdep = ARB_UNI(mp->maxdepth);
+                if (maxdep >= ARB_JUMP_DEPTH) {
+                    jumped = true;
+                    int rounds = 0;
+                    while ((1 << rounds) < maxdep + 1) ++rounds;
+                    T *const bdl = BD + (on ? b : 0) * BD_STRIDE;
+                    // ancestor pointers travel in the first element of the (still unused) gravity slot
+                    auto jump_sum = [&](int slot) {          // inclusive sum over the ancestors of the 6-vectors in `slot`
+                        if (on) bdl[BD_PG] = (T)par;
+                        WAVE_SYNC();
+                        for (int r = 0; r < rounds; ++r) {
+                            const int a = on ? (int)bdl[BD_PG] : -1;
+                            T add6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+                            T na = T(-1);
+                            if (a >= 0) {
+                                const T *ab = BD + a * BD_STRIDE;
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) add6[i] = ab[slot + i];
+                                na = ab[BD_PG];
+                            }
+                            WAVE_SYNC();
+                            if (a >= 0) {
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) bdl[slot + i] += add6[i];
+                                bdl[BD_PG] = na;
+                            }
+                            WAVE_SYNC();
+                        }
+                    };
+                    // (1) poses: PD[b] holds H_pc; after the rounds H_gb
+                    if (on) bdl[BD_PG] = (T)par;
+                    WAVE_SYNC();
+                    for (int r = 0; r < rounds; ++r) {
+                        const int a = on ? (int)bdl[BD_PG] : -1;
+                        M3<double> Ra = m3_identity<double>(); V3<double> pa = v3<double>(0., 0., 0.);
+                        T na = T(-1);
+                        if (a >= 0) { Ra = ld_m3(PD + 12 * a); pa = ld_v3(PD + 12 * a + 9); na = BD[a * BD_STRIDE + BD_PG]; }
+                        WAVE_SYNC();
+                        if (a >= 0) {
+                            const M3<double> Rb = ld_m3(PD + 12 * b);
+                            const V3<double> pb2 = ld_v3(PD + 12 * b + 9);
+                            st_m3(PD + 12 * b, mul(Ra, Rb)); st_v3(PD + 12 * b + 9, mv(Ra, pb2) + pa);
+                            bdl[BD_PG] = na;
+                        }
+                        WAVE_SYNC();
+                    }
+                    // (2) twists
+                    M3<double> Rgb = m3_identity<double>(); V3<double> pgb = v3<double>(0., 0., 0.);
+                    if (on) {
+                        Rgb = ld_m3(PD + 12 * b); pgb = ld_v3(PD + 12 * b + 9);
+                        const V3<double> ww = mv(Rgb, Tnw);
+                        st_v3(bdl + BD_TW, ww); st_v3(bdl + BD_TW + 3, cross(pgb, ww) + mv(Rgb, Tnv));
+                    }
+                    jump_sum(BD_TW);
+                    if (on) {
+                        const V3<double> ww = ld_v3(bdl + BD_TW), wv = ld_v3(bdl + BD_TW + 3);
+                        st_v3(bdl + BD_TW, mtv(Rgb, ww)); st_v3(bdl + BD_TW + 3, mtv(Rgb, wv - cross(pgb, ww)));
+                    }
+                    WAVE_SYNC();
+                    // (3) bias accelerations: dAd_cp T_p + Bn_c in body axes, to world axes, summed, back
+                    if (on) {
+                        V3<double> tw = v3<double>(0., 0., 0.), tv = tw;
+                        if (par >= 0) { const T *pb = BD + par * BD_STRIDE; tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3); }
+                        const V3<double> lw = mv(dA_cp, tw) + Bnw;
+                        const V3<double> lv = mv(dB_cp, tw) + mv(dA_cp, tv) + Bnv;
+                        const V3<double> ww = mv(Rgb, lw);
+                        st_v3(bdl + BD_AB, ww); st_v3(bdl + BD_AB + 3, cross(pgb, ww) + mv(Rgb, lv));
+                    }
+                    jump_sum(BD_AB);
+                    if (on) {
+                        const V3<double> ww = ld_v3(bdl + BD_AB), wv = ld_v3(bdl + BD_AB + 3);
+                        st_v3(bdl + BD_AB, mtv(Rgb, ww)); st_v3(bdl + BD_AB + 3, mtv(Rgb, wv - cross(pgb, ww)));
+                    }
+                    WAVE_SYNC();
+                }
+            }
             // pose and twist down the tree, one depth level at a time
+            if (!jumped)
             for (int lvl = 0; lvl <= mp->maxdepth; ++lvl) {
                 if (on && dep == lvl) {
                     M3<double> Rg = m3_identity<double>(); V3<double> pg = v3<double>(0., 0., 0.);
