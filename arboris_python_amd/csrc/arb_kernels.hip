@@ -1622,6 +1622,53 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     st_v3(bd + BD_OM + 3, cross(p_cp, ww) + mv(R_cp, uv));
                 }
                 WAVE_SYNC();
+                // (float64 kernels, deep trees: the same sum in log2(depth) rounds, as phase A does for twists -- in world axes
+                // Ad(H_gc) Om_c = Ad(H_gp) Om_p + Ad(H_gc) W_c is a prefix sum over the ancestors; the ancestor pointers
+                // travel in the bias-acceleration slot, which phase A is done with)
+                bool jumped = false;
+                if constexpr (sizeof(T) == 8) {
+                    const int maxdep = ARB_UNI(mp->maxdepth);
+                    if (maxdep >= ARB_JUMP_DEPTH) {
+                        jumped = true;
+                        int rounds = 0;
+                        while ((1 << rounds) < maxdep + 1) ++rounds;
+                        const bool onb = lane < nb;
+                        T *const bdl = BD + (onb ? lane : 0) * BD_STRIDE;
+                        M3<double> Rgb = m3_identity<double>(); V3<double> pgb2 = v3<double>(0., 0., 0.);
+                        if (onb) {
+                            Rgb = ld_m3(PD + 12 * lane); pgb2 = ld_v3(PD + 12 * lane + 9);
+                            const V3<double> ww = mv(Rgb, ld_v3(bdl + BD_OM));
+                            const V3<double> wv = cross(pgb2, ww) + mv(Rgb, ld_v3(bdl + BD_OM + 3));
+                            st_v3(bdl + BD_OM, ww); st_v3(bdl + BD_OM + 3, wv);
+                            bdl[BD_AB] = (T)par;
+                        }
+                        WAVE_SYNC();
+                        for (int r = 0; r < rounds; ++r) {
+                            const int a = onb ? (int)bdl[BD_AB] : -1;
+                            T add6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+                            T na = T(-1);
+                            if (a >= 0) {
+                                const T *ab = BD + a * BD_STRIDE;
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) add6[i] = ab[BD_OM + i];
+                                na = ab[BD_AB];
+                            }
+                            WAVE_SYNC();
+                            if (a >= 0) {
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) bdl[BD_OM + i] += add6[i];
+                                bdl[BD_AB] = na;
+                            }
+                            WAVE_SYNC();
+                        }
+                        if (onb) {
+                            const V3<double> ww = ld_v3(bdl + BD_OM), wv = ld_v3(bdl + BD_OM + 3);
+                            st_v3(bdl + BD_OM, mtv(Rgb, ww)); st_v3(bdl + BD_OM + 3, mtv(Rgb, wv - cross(pgb2, ww)));
+                        }
+                        WAVE_SYNC();
+                    }
+                }
+                if (!jumped)
                 for (int lvl = 1; lvl <= mp->maxdepth; ++lvl) {
                     if (mydep == lvl) {
                         T *bd = BD + lane * BD_STRIDE;
