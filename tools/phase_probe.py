@@ -12,7 +12,8 @@ from arboris_python_amd.flatten import replicate_model
 names = ["A", "A'", "B", "C", "D", "GS", "E"]
 for name, K, dtype in (("simplearm", 1, torch.float32), ("simplearm", 10, torch.float32), ("simplearm", 1, torch.float64),
                        ("snake9_free_g", 1, torch.float32), ("human36_g", 1, torch.float32), ("human36_c4", 1, torch.float32),
-                       ("snake64_g", 1, torch.float64)):
+                       ("snake64_g", 1, torch.float64), ("human36_c4", 1, torch.float64), ("human36_c8", 1, torch.float32),
+                       ("human36_g", 1, torch.float64)):
     m, q0, dq0 = load_model(name)
     if K > 1:
         m = replicate_model(m, K); q0 = np.tile(q0, K); dq0 = np.tile(dq0, K)
