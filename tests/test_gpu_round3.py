@@ -421,3 +421,72 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     # (by default its worlds share wavefronts another way: a forest of 5 copies, tests/test_gpu_forest.py)
     assert bw.plan(64 * cus, 40)["worlds_per_wavefront"] == bw.info["forest_copies"] == 5
     bw.close()
+
+
+# ---------------------------------------------------------------------------
+# deep trees in the float64 kernels: log-depth pose / twist / acceleration chains (ARB_JUMP_DEPTH)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nlinks,free_root", [(20, False), (24, True)])
+def test_deep_chain_with_contacts_float64(nlinks, free_root):
+    """A 20-link hinge chain bolted to the ground and a free-floating 24-link one (30 dofs), each with spheres touching a
+    wall (and one another) and a joint limit -- trees deeper than ARB_JUMP_DEPTH, so the float64 kernels chain poses, twists and bias
+    accelerations by pointer jumping / world-frame prefix sums instead of level by level -- against the oracle: single
+    steps from random states and a 12-step launch (work queue), at the float64 gates."""
+    from arboris_python_amd.core import World, SubFrame
+    from arboris_python_amd.robots.snake import add_snake
+    from arboris_python_amd.shapes import Sphere, Plane
+    from arboris_python_amd.controllers import WeightController
+    from arboris_python_amd.constraints import get_all_contacts, JointLimits
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    from arboris_python_amd import synth
+    w = World()
+    w.register(Plane(w.ground, (1., 0., 0., -0.06), "wall"))             # (the chains stand along y: a wall beside them)
+    add_snake(w, nlinks, is_fixed=not free_root, lengths=[0.07] * nlinks, masses=[0.3] * nlinks)
+    bodies = [b for b in w.getbodies() if b is not w.ground]
+    for k, b in enumerate((bodies[-1], bodies[len(bodies) // 2], bodies[3])):
+        w.register(Sphere(SubFrame(b, np.eye(4), name="sf%d" % k), 0.04, name="ball%d" % k))
+    w.register(WeightController())
+    for c in get_all_contacts(w, friction_coeff=0.7):
+        w.register(c)
+    hinge = [j for j in w.getjoints() if j.ndof == 1][5]
+    w.register(JointLimits(hinge, -0.3, 0.3))
+    w.init()
+    m, q0, dq0 = flatten_world(w)
+    assert int(max(m.parent)) >= 12 and m.nc >= 3
+    bw = BatchedWorlds(m)
+    B = 64
+    q, dq = synth.random_states(m, B, seed=3, angle=0.25, vel=0.8, root_box=((-.05, .15), (-.1, .1), (-.1, .1)), root_rot=False)
+    q[0], dq[0] = q0, dq0
+    cf0 = np.zeros((B, m.nc, 4))
+    oq, odq, ocf = O.step(m, q, dq, 2e-3, cforce=cf0)
+    ok = np.isfinite(odq).all(axis=1) & (np.abs(odq).max(axis=1) < 1e3)
+    assert ok.sum() >= B // 2
+    assert (np.abs(ocf[ok]).max(axis=(1, 2)) > 0).sum() >= 4              # some worlds touch the floor
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    tcf = bw.new_cforce(B, torch.float64)
+    bw.step(tq, tdq, 2e-3, 1, cforce=tcf)
+    torch.cuda.synchronize()
+    eq = np.abs(tq.cpu().numpy() - oq).max(axis=1) / np.maximum(1., np.abs(oq).max(axis=1))
+    edq = np.abs(tdq.cpu().numpy() - odq).max(axis=1) / np.maximum(1., np.abs(odq).max(axis=1))
+    assert eq[ok].max() < 1e-8 and edq[ok].max() < 1e-7, (eq[ok].max(), edq[ok].max())
+    # 12 steps in one launch, more worlds than wave slots: the queue, against one workgroup per world bit for bit, and
+    # a sample against the oracle's rollout
+    reps = -(-3000 // B)
+    qb, dqb = np.tile(q, (reps, 1)), np.tile(dq, (reps, 1))
+    res = []
+    for static in (True, False):
+        aq, adq = bw.to_device(qb, dqb, torch.float64)
+        acf = bw.new_cforce(len(qb), torch.float64)
+        bw.step(aq, adq, 2e-3, 12, cforce=acf, static_worlds=static)
+        res.append((aq, adq, acf))
+    torch.cuda.synchronize()
+    bits = lambda t: t.contiguous().view(torch.int64)
+    assert all(torch.equal(bits(a), bits(b)) for a, b in zip(*res))
+    sel = np.flatnonzero(ok)[:6]
+    rq, rdq, _ = O.rollout(m, q[sel], dq[sel], [2e-3] * 12)
+    good = np.isfinite(rdq).all(axis=1) & (np.abs(rdq).max(axis=1) < 1e3)
+    got_q, got_dq = res[0][0].cpu().numpy()[sel], res[0][1].cpu().numpy()[sel]
+    assert good.sum() >= 3
+    assert (np.abs(got_q - rq)[good].max(axis=1) / np.maximum(1., np.abs(rq)[good].max(axis=1))).max() < 1e-6
+    bw.close()
