@@ -82,10 +82,11 @@
 #define BD_PCP 9     // p of Ad_cp (3)
 #define BD_OM 12     // W_c, then the accumulated pseudo twist Om_b (6), see phase B
 #define BD_PT 18     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form
-#define BD_PG 24     // M_b g_b (6)
-#define BD_TW 30     // body twist (6)
-#define BD_AB 36     // bias acceleration dJ_b * gvel (6)
-#define BD_STRIDE 42
+#define BD_TW 24     // body twist (6)
+#define BD_AB 30     // bias acceleration dJ_b * gvel (6)
+#define BD_STRIDE 36         // the step kernels
+#define BD_PG 36     // M_b g_b (6): the inspect kernels only (World._gforce of the controllers alone), hence last
+#define BD_STRIDE_INSPECT 42
 // (the world pose H_gb of a body lives in PD, in float64, only: a copy in T here cost 12 elements per body -- 6 KB of the
 // 43 KB of a float64 snake-64 wavefront, which kept its kernels at three wavefronts per CU instead of four)
 // Composite assembly of Z (phase B): per-body accumulators travelling up the tree, in float64:
@@ -107,6 +108,7 @@
 
 struct Layout {      // offsets in elements of T inside the wave's LDS block
     int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, ci, total;
+    int total_inspect;   // ... of the inspect kernels, whose per-body blocks carry six more elements (BD_STRIDE_INSPECT)
     // packed build (two worlds per wavefront, CM = 3): world A's state and the results of its phases A-D wait here while
     // world B goes through the same phases in the arrays above; `sb*`: world B's state while world A is in those arrays
     int sa_q, sa_dq, sa_am, sa_cd, sa_vv, sa_ff, sa_ff0, sa_rt, sb_q, sb_dq, sb_ff;
@@ -981,6 +983,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     constexpr int NLOW = NMAX == 16 ? 0 : NMAX == 32 ? 16 : NMAX == 44 ? 32 : NMAX == 48 ? 44 : 48;
     constexpr bool LSCAN_OK = NMAX <= 48;      // (the 64-row tiles are register-bound: only the DPP scan is compiled in)
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
+    constexpr int BDS = (MODE == 1) ? BD_STRIDE_INSPECT : BD_STRIDE;      // per-body block (the gravity wrench slot: inspect only)
     T dt = dt_in, inv_dt = T(1) / dt_in;
     // (evaluated where it is used, from the laundered nc: as one hoisted flag it lives in spilled lane masks)
 #define do_constraints ((nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS))
@@ -1228,7 +1231,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 const Blk<T> Ad_cn = blk_adjoint(R_cn, p_cn);
                 const Blk<T> Ad_rp = blk_adjoint(transpose(R_pr), -mtv(R_pr, p_pr));
                 const Blk<T> dAd_cp = blk_mul(Ad_cn, blk_mul(dAd_nr, Ad_rp));
-                T *bd = BD + b * BD_STRIDE;
+                T *bd = BD + b * BDS;
                 st_m3(bd + BD_RCP, R_cp); st_v3(bd + BD_PCP, p_cp);
                 // T_rn = -(aw, av) is all phase B needs from here (dAd_cp = ad(W_c) Ad_cp, W_c = Ad_cp Ad_pr T_rn)
                 st_v3(bd + BD_OM, -aw); st_v3(bd + BD_OM + 3, -av);
@@ -1290,44 +1293,44 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     jumped = true;
                     int rounds = 0;
                     while ((1 << rounds) < maxdep + 1) ++rounds;
-                    T *const bdl = BD + (on ? b : 0) * BD_STRIDE;
-                    // ancestor pointers travel in the first element of the (still unused) gravity slot
+                    T *const bdl = BD + (on ? b : 0) * BDS;
+                    // ancestor pointers travel in the first element of the (still unused) rhs-wrench slot
                     auto jump_sum = [&](int slot) {          // inclusive sum over the ancestors of the 6-vectors in `slot`
-                        if (on) bdl[BD_PG] = (T)par;
+                        if (on) bdl[BD_PT] = (T)par;
                         WAVE_SYNC();
                         for (int r = 0; r < rounds; ++r) {
-                            const int a = on ? (int)bdl[BD_PG] : -1;
+                            const int a = on ? (int)bdl[BD_PT] : -1;
                             T add6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
                             T na = T(-1);
                             if (a >= 0) {
-                                const T *ab = BD + a * BD_STRIDE;
+                                const T *ab = BD + a * BDS;
 #pragma unroll
                                 for (int i = 0; i < 6; ++i) add6[i] = ab[slot + i];
-                                na = ab[BD_PG];
+                                na = ab[BD_PT];
                             }
                             WAVE_SYNC();
                             if (a >= 0) {
 #pragma unroll
                                 for (int i = 0; i < 6; ++i) bdl[slot + i] += add6[i];
-                                bdl[BD_PG] = na;
+                                bdl[BD_PT] = na;
                             }
                             WAVE_SYNC();
                         }
                     };
                     // (1) poses: PD[b] holds H_pc; after the rounds H_gb
-                    if (on) bdl[BD_PG] = (T)par;
+                    if (on) bdl[BD_PT] = (T)par;
                     WAVE_SYNC();
                     for (int r = 0; r < rounds; ++r) {
-                        const int a = on ? (int)bdl[BD_PG] : -1;
+                        const int a = on ? (int)bdl[BD_PT] : -1;
                         M3<double> Ra = m3_identity<double>(); V3<double> pa = v3<double>(0., 0., 0.);
                         T na = T(-1);
-                        if (a >= 0) { Ra = ld_m3(PD + 12 * a); pa = ld_v3(PD + 12 * a + 9); na = BD[a * BD_STRIDE + BD_PG]; }
+                        if (a >= 0) { Ra = ld_m3(PD + 12 * a); pa = ld_v3(PD + 12 * a + 9); na = BD[a * BDS + BD_PT]; }
                         WAVE_SYNC();
                         if (a >= 0) {
                             const M3<double> Rb = ld_m3(PD + 12 * b);
                             const V3<double> pb2 = ld_v3(PD + 12 * b + 9);
                             st_m3(PD + 12 * b, mul(Ra, Rb)); st_v3(PD + 12 * b + 9, mv(Ra, pb2) + pa);
-                            bdl[BD_PG] = na;
+                            bdl[BD_PT] = na;
                         }
                         WAVE_SYNC();
                     }
@@ -1347,7 +1350,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     // (3) bias accelerations: dAd_cp T_p + Bn_c in body axes, to world axes, summed, back
                     if (on) {
                         V3<double> tw = v3<double>(0., 0., 0.), tv = tw;
-                        if (par >= 0) { const T *pb = BD + par * BD_STRIDE; tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3); }
+                        if (par >= 0) { const T *pb = BD + par * BDS; tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3); }
                         const V3<double> lw = mv(dA_cp, tw) + Bnw;
                         const V3<double> lv = mv(dB_cp, tw) + mv(dA_cp, tv) + Bnv;
                         const V3<double> ww = mv(Rgb, lw);
@@ -1368,7 +1371,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     M3<double> Rg = m3_identity<double>(); V3<double> pg = v3<double>(0., 0., 0.);
                     V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw;
                     if (par >= 0) {
-                        const T *pb = BD + par * BD_STRIDE;
+                        const T *pb = BD + par * BDS;
                         Rg = ld_m3(PD + 12 * par); pg = ld_v3(PD + 12 * par + 9);
                         tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
                         aw = ld_v3(pb + BD_AB); av = ld_v3(pb + BD_AB + 3);
@@ -1380,7 +1383,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     st_m3(PD + 12 * b, Rc_d); st_v3(PD + 12 * b + 9, pc_d);
                     const V3<T> cw = mv(R_cp, tw) + Tnw;             // child_twist core.py:1308
                     const V3<T> cv = cross(p_cp, mv(R_cp, tw)) + mv(R_cp, tv) + Tnv;
-                    T *bd = BD + b * BD_STRIDE;
+                    T *bd = BD + b * BDS;
                     st_v3(bd + BD_TW, cw); st_v3(bd + BD_TW + 3, cv);
                     // dJ_c gvel = dAd_cp T_p + Ad_cp (dJ_p gvel) + Ad_cn dJ_nr gvel_j   (core.py:1312-1313 times gvel)
                     const V3<T> raw = mv(R_cp, aw);
@@ -1392,7 +1395,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             }
             ARB_ASTAMP(4);
             if (on) {
-                T *bd = BD + b * BD_STRIDE;
+                T *bd = BD + b * BDS;
                 const T *Mb = mp->mass + 36 * b;
                 T tw[6], ab[6], mt[6], ma[6], mg[6];
 #pragma unroll
@@ -1408,7 +1411,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 }
                 mat6_vec<T>(Mb, g6, mg);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) bd[BD_PG + i] = mg[i];
+                for (int i = 0; i < 6; ++i) if (MODE == 1) bd[BD_PG + i] = mg[i];
                 // N_b = [[wx, rx wx - wx rx],[0, wx]] M_b              core.py:1276-1288
                 const V3<T> wv = v3<T>(tw[0], tw[1], tw[2]);
                 const M3<T> wx = hat(wv);
@@ -1454,7 +1457,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 o[12] = o[13] = o[14] = T(0); o[15] = T(1);
             }
             if (dbg.twist != nullptr && lane < nb)
-                for (int i = 0; i < 6; ++i) dbg.twist[(w * nb + lane) * 6 + i] = BD[lane * BD_STRIDE + BD_TW + i];
+                for (int i = 0; i < 6; ++i) dbg.twist[(w * nb + lane) * 6 + i] = BD[lane * BDS + BD_TW + i];
         }
 
         // ---- energies (EnergyMonitor.update, observers.py:40-51): KE = 1/2 sum_b T_b . M_b T_b
@@ -1462,7 +1465,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if ((MODE == 0 && logo.energy != nullptr) || (MODE == 1 && dbg.energy != nullptr && step == 0)) {
             double ke = 0., pe = 0.;
             if (lane < nb) {
-                const T *bd = BD + lane * BD_STRIDE;
+                const T *bd = BD + lane * BDS;
                 const T *Mb = mp->mass + 36 * lane;
                 T tw[6], mt[6];
 #pragma unroll
@@ -1504,11 +1507,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     V3<T> bw0 = v3<T>(T(0), T(0), T(0)), bv0 = bw0, bw1 = bw0, bv1 = bw0;
                     if (b0 >= 0) {
                         Rg0 = ld_m3(PD + 12 * b0); pg0 = ld_v3(PD + 12 * b0 + 9);
-                        bw0 = ld_v3(BD + b0 * BD_STRIDE + BD_TW); bv0 = ld_v3(BD + b0 * BD_STRIDE + BD_TW + 3);
+                        bw0 = ld_v3(BD + b0 * BDS + BD_TW); bv0 = ld_v3(BD + b0 * BDS + BD_TW + 3);
                     }
                     if (b1 >= 0) {
                         Rg1 = ld_m3(PD + 12 * b1); pg1 = ld_v3(PD + 12 * b1 + 9);
-                        bw1 = ld_v3(BD + b1 * BD_STRIDE + BD_TW); bv1 = ld_v3(BD + b1 * BD_STRIDE + BD_TW + 3);
+                        bw1 = ld_v3(BD + b1 * BDS + BD_TW); bv1 = ld_v3(BD + b1 * BDS + BD_TW + 3);
                     }
                     // pose of shape 0's frame and centre of shape 1 (a Sphere or a Point)
                     const M3<double> Rs0 = mul(Rg0, ld_m3(mp->cb0_d + 12 * c));
@@ -1612,7 +1615,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 const int par = (lane < nb) ? mp->parent[lane] : -1;
                 if (lane < nb) {
                     // W_c = Ad_cn Ad_nr T_rn = Ad_cp Ad_pr T_rn   (H_cn H_nr = H_cp H_pr)
-                    T *bd = BD + lane * BD_STRIDE;
+                    T *bd = BD + lane * BDS;
                     const M3<T> R_pr = ld_m3(mp->Hpr + 12 * lane), R_cp = ld_m3(bd + BD_RCP);
                     const V3<T> p_pr = ld_v3(mp->Hpr + 12 * lane + 9), p_cp = ld_v3(bd + BD_PCP);
                     const V3<T> uw = mv(R_pr, ld_v3(bd + BD_OM));
@@ -1633,7 +1636,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         int rounds = 0;
                         while ((1 << rounds) < maxdep + 1) ++rounds;
                         const bool onb = lane < nb;
-                        T *const bdl = BD + (onb ? lane : 0) * BD_STRIDE;
+                        T *const bdl = BD + (onb ? lane : 0) * BDS;
                         M3<double> Rgb = m3_identity<double>(); V3<double> pgb2 = v3<double>(0., 0., 0.);
                         if (onb) {
                             Rgb = ld_m3(PD + 12 * lane); pgb2 = ld_v3(PD + 12 * lane + 9);
@@ -1648,7 +1651,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                             T add6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
                             T na = T(-1);
                             if (a >= 0) {
-                                const T *ab = BD + a * BD_STRIDE;
+                                const T *ab = BD + a * BDS;
 #pragma unroll
                                 for (int i = 0; i < 6; ++i) add6[i] = ab[BD_OM + i];
                                 na = ab[BD_AB];
@@ -1671,8 +1674,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 if (!jumped)
                 for (int lvl = 1; lvl <= mp->maxdepth; ++lvl) {
                     if (mydep == lvl) {
-                        T *bd = BD + lane * BD_STRIDE;
-                        const T *pb = BD + par * BD_STRIDE;
+                        T *bd = BD + lane * BDS;
+                        const T *pb = BD + par * BDS;
                         const M3<T> R_cp = ld_m3(bd + BD_RCP);
                         const V3<T> p_cp = ld_v3(bd + BD_PCP);
                         const V3<T> rw = mv(R_cp, ld_v3(pb + BD_OM));
@@ -1686,9 +1689,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
             for (int i = 0; i < 6; ++i) { om_b[i] = T(0); twb[i] = T(0); ptb[i] = T(0); pgb[i] = T(0); }
             if (lane < nb) {
-                const T *bd = BD + lane * BD_STRIDE;
+                const T *bd = BD + lane * BDS;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { twb[i] = bd[BD_TW + i]; om_b[i] = bd[BD_OM + i]; ptb[i] = bd[BD_PT + i]; pgb[i] = bd[BD_PG + i]; }
+                for (int i = 0; i < 6; ++i) { twb[i] = bd[BD_TW + i]; om_b[i] = bd[BD_OM + i]; ptb[i] = bd[BD_PT + i]; pgb[i] = (MODE == 1) ? bd[BD_PG + i] : T(0); }
             }
             // Small trees: the body lanes write the M | rhs part of their accumulators straight into the prefix table,
             // which takes the place of the per-body blocks: every lane has its own block in registers by now.
@@ -2801,7 +2804,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
                       const SplitIO<T> &sio, const double *dts, hipStream_t st) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE, FEAT, CM>;
-    const size_t lds = (size_t)L.total * sizeof(T) + (size_t)std::max(0, env_int("ARB_LDS_PAD", 0));
+    const size_t lds = (size_t)(MODE == 1 ? L.total_inspect : L.total) * sizeof(T) + (size_t)std::max(0, env_int("ARB_LDS_PAD", 0));
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -2992,10 +2995,10 @@ static std::vector<double> h12(const double *H16, int count) {
 // (the table restarts at every root, which keeps the trees of a wavefront -- the copies of a forest -- apart; the DPP
 // scan of the larger trees runs across all bodies of the wavefront)
 static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
-static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass) {
+static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass, int bd_stride = BD_STRIDE) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int tb = lds_scan(nb, rs) ? al(nb * (two_pass ? TB_STRIDE : TB_STRIDE1) * elems_per_double) : 0;
-    return std::max(std::max(std::max(al(nb * BD_STRIDE), al(XPR_STRIDE * rs * elems_per_double)), tb), al(std::max(ndol * ndol, 4)));
+    return std::max(std::max(std::max(al(nb * bd_stride), al(XPR_STRIDE * rs * elems_per_double)), tb), al(std::max(ndol * ndol, 4)));
 }
 
 static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems, bool two_pass = false,
@@ -3005,19 +3008,31 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     int o = 0;
     L.q = o; o += al(nq);
     L.dq = o; o += WAVE;
-    L.qd = o; o += WAVE;
-    L.bd = o; L.am = o; o += bd_region_elems(nb, rs, ndol, elems_per_double, two_pass);
     L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
     L.rt = o; L.sc = o; o += std::max(1 + ndol, 12) * rs;
-    L.cd = o; o += al(std::max(nc, 1) * CD_STRIDE);
+    L.cd = o; o += al(nc * CD_STRIDE);               // (nothing without constraints: every access is inside a loop over them)
     L.vv = o; o += al(std::max(ndol, 4));
     L.ff = o; o += al(std::max(ndol, 4));
     L.ff0 = o; o += al(std::max(ndol, 4));
-    L.work = o; o += 64;
+    // the dof-indexed copy of the joint positions (phase A .. the controllers at the end of phase B) shares the scratch
+    // array of the later phases (the late-rhs column copy of phase C, the eigenvalue fallback of the sweeps)
+    // (44 elements for the eigenvalue fallback; one per dof / per row for the other two.  Sizes matter by the LDS allocation
+    // granule, which tools/lds_granule_probe.hip measures at 1280 B -- twelve wavefronts per CU need <= 12 800 B each, not
+    // the 13 653 B that 160 KB / 12 and hipOccupancyMaxActiveBlocksPerMultiprocessor suggest: the three-wave human36 + 4
+    // contacts layout is 12 800 B with this line, 12 880 B with 64 elements here)
+    L.work = o; L.qd = o; o += std::max(44, al(rs));
     {
         const int words = CI_STRIDE * std::max(nc, 1);                      // int32 words, see CI_STRIDE
         L.ci = o; o += al(elems_per_double == 2 ? words : (words + 1) / 2);     // (float: one word per element; double: two)
     }
+    // the per-body blocks (and what takes their place) come last: the inspect kernels' larger blocks (BD_STRIDE_INSPECT:
+    // the gravity wrench, 6 elements per body more -- 3 KB for a float64 snake-64, the difference between four and five
+    // wavefronts per CU for the step kernels) then only lengthen the allocation, every other offset is shared
+    L.bd = o; L.am = o;
+    const int bd_step = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass);
+    const int bd_insp = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE_INSPECT);
+    L.total_inspect = o + bd_insp;
+    o += bd_step;
     L.sa_q = L.sa_dq = L.sa_am = L.sa_cd = L.sa_vv = L.sa_ff = L.sa_ff0 = L.sa_rt = L.sb_q = L.sb_dq = L.sb_ff = 0;
     if (pack) {
         L.sa_rt = o; o += (1 + ndol) * rs;
@@ -3033,6 +3048,7 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
         L.sb_ff = o; o += al(std::max(ndol, 4));
     }
     L.total = o;
+    if (pack) L.total_inspect = std::max(L.total_inspect, o);      // (no inspect kernel uses the packed layout)
     L.ndol = ndol;
     L.lscan = lds_scan(nb, rs) ? 1 : 0;
     *total_elems = o;
@@ -3475,11 +3491,12 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     // Two or three waves per SIMD?  Three when the batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3
     // pin the build; ARB_FORCE_WAVES=2|3 in the environment overrides both (development).
     if (s3 > s2 && s2 > 0) {
-        // measured (human36 + 4 contacts, M world-steps/s, two / three waves): 2048 worlds 14.6 / 13.4, 2560: 16.6 / 13.8,
-        // 3072: 16.7 / 11.6, 3584: 16.7 / 17.1, 4096: 17.1 / 18.0, 6144: 17.6 / 18.7, 65536: 18.4 / 19.8;
+        // measured (human36 + 4 contacts, M world-steps/s, two / three waves; end of round 3, twelve wavefronts per CU
+        // for real): 2048 worlds 14.6 / 13.5, 2560: 16.7 / 13.9, 3072: 17.1 / 16.2, 3584: 16.8 / 18.0, 4096: 16.6 / 18.7,
+        // 6144: 17.8 / 19.8, 8192: 17.8 / 20.1
         // one launch per step (no queue): three waves when they save a round of workgroups (4096 worlds: 10.4 / 9.7,
         // two rounds either way; 6144: 12.2 / 12.1)
-        if (nsteps >= 2) bc.w3 = 3 * nw >= 4 * s3;
+        if (nsteps >= 2) bc.w3 = 10 * nw >= 11 * s3;
         else bc.w3 = 112 * ((nw + s3 - 1) / s3) < 100 * ((nw + s2 - 1) / s2);
         if (flags & ARB_STEP_WAVES2) bc.w3 = false;
         if (flags & ARB_STEP_WAVES3) bc.w3 = true;
@@ -3496,7 +3513,12 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
         const long ldsp = (long)M->lfp.total * 4 + pad;
         const long sp = (long)cus * std::min(8l, (160 * 1024) / ldsp);
         bc.slotsp = sp;
-        bc.pack = sp >= s2 && sp > 0 && (nw + 1) / 2 >= ARB_PACK_MIN_ROUNDS * sp;
+        // (end of round 3: with its LDS trimmed to the 1280-byte allocation granule the three-wave build really has twelve
+        // wavefronts per CU -- eleven until then, whatever the occupancy API said -- and beats the packed build at every
+        // batch size: 20.5 against 19.3 M world-steps/s at 16 384 worlds, 20.9 against 19.7 M at 65 536.  The packed
+        // build stays in the library, bit-identical and tested, behind ARB_FORCE_PACK=1.)
+        bc.pack = false;
+        (void)ARB_PACK_MIN_ROUNDS;
         const int fp = env_int("ARB_FORCE_PACK", -1);
         if (fp == 0) bc.pack = false;
         if (fp == 1) bc.pack = true;
