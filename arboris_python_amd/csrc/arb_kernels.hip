@@ -81,12 +81,12 @@
 #define BD_RCP 0     // R of Ad_cp (9)
 #define BD_PCP 9     // p of Ad_cp (3)
 #define BD_OM 12     // W_c, then the accumulated pseudo twist Om_b (6), see phase B
-#define BD_PT 18     // M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form
-#define BD_TW 24     // body twist (6)
-#define BD_AB 30     // bias acceleration dJ_b * gvel (6)
-#define BD_STRIDE 36         // the step kernels
-#define BD_PG 36     // M_b g_b (6): the inspect kernels only (World._gforce of the controllers alone), hence last
-#define BD_STRIDE_INSPECT 42
+#define BD_TW 18     // body twist (6)
+#define BD_AB 24     // bias acceleration dJ_b * gvel (6): phase A, until the rhs wrench is formed from it ...
+#define BD_PT 24     // ... M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form, in the same slot
+#define BD_STRIDE 30         // the step kernels
+#define BD_PG 30     // M_b g_b (6): the inspect kernels only (World._gforce of the controllers alone), hence last
+#define BD_STRIDE_INSPECT 36
 // (the world pose H_gb of a body lives in PD, in float64, only: a copy in T here cost 12 elements per body -- 6 KB of the
 // 43 KB of a float64 snake-64 wavefront, which kept its kernels at three wavefronts per CU instead of four)
 // Composite assembly of Z (phase B): per-body accumulators travelling up the tree, in float64:
@@ -1294,43 +1294,43 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     int rounds = 0;
                     while ((1 << rounds) < maxdep + 1) ++rounds;
                     T *const bdl = BD + (on ? b : 0) * BDS;
-                    // ancestor pointers travel in the first element of the (still unused) rhs-wrench slot
+                    // ancestor pointers travel in the scratch array (unused until the end of phase A)
                     auto jump_sum = [&](int slot) {          // inclusive sum over the ancestors of the 6-vectors in `slot`
-                        if (on) bdl[BD_PT] = (T)par;
+                        if (on) WORK[b] = (T)par;
                         WAVE_SYNC();
                         for (int r = 0; r < rounds; ++r) {
-                            const int a = on ? (int)bdl[BD_PT] : -1;
+                            const int a = on ? (int)WORK[b] : -1;
                             T add6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
                             T na = T(-1);
                             if (a >= 0) {
                                 const T *ab = BD + a * BDS;
 #pragma unroll
                                 for (int i = 0; i < 6; ++i) add6[i] = ab[slot + i];
-                                na = ab[BD_PT];
+                                na = WORK[a];
                             }
                             WAVE_SYNC();
                             if (a >= 0) {
 #pragma unroll
                                 for (int i = 0; i < 6; ++i) bdl[slot + i] += add6[i];
-                                bdl[BD_PT] = na;
+                                WORK[b] = na;
                             }
                             WAVE_SYNC();
                         }
                     };
                     // (1) poses: PD[b] holds H_pc; after the rounds H_gb
-                    if (on) bdl[BD_PT] = (T)par;
+                    if (on) WORK[b] = (T)par;
                     WAVE_SYNC();
                     for (int r = 0; r < rounds; ++r) {
-                        const int a = on ? (int)bdl[BD_PT] : -1;
+                        const int a = on ? (int)WORK[b] : -1;
                         M3<double> Ra = m3_identity<double>(); V3<double> pa = v3<double>(0., 0., 0.);
                         T na = T(-1);
-                        if (a >= 0) { Ra = ld_m3(PD + 12 * a); pa = ld_v3(PD + 12 * a + 9); na = BD[a * BDS + BD_PT]; }
+                        if (a >= 0) { Ra = ld_m3(PD + 12 * a); pa = ld_v3(PD + 12 * a + 9); na = WORK[a]; }
                         WAVE_SYNC();
                         if (a >= 0) {
                             const M3<double> Rb = ld_m3(PD + 12 * b);
                             const V3<double> pb2 = ld_v3(PD + 12 * b + 9);
                             st_m3(PD + 12 * b, mul(Ra, Rb)); st_v3(PD + 12 * b + 9, mv(Ra, pb2) + pa);
-                            bdl[BD_PT] = na;
+                            WORK[b] = na;
                         }
                         WAVE_SYNC();
                     }
@@ -1608,6 +1608,16 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             const double cM = (MODE == 1 && zmode == 1) ? 1. : (double)inv_dt;
 #pragma unroll
             for (int i = 0; i < NACC; ++i) Acc[i] = 0.;
+            // (twist, rhs wrench and gravity wrench of the body first: the log-depth sum below borrows the rhs slot)
+            T twb[6], ptb[6], pgb[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { twb[i] = T(0); ptb[i] = T(0); pgb[i] = T(0); }
+            if (lane < nb) {
+                const T *bd = BD + lane * BDS;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { twb[i] = bd[BD_TW + i]; ptb[i] = bd[BD_PT + i]; pgb[i] = (MODE == 1) ? bd[BD_PG + i] : T(0); }
+            }
+            WAVE_SYNC();
             // accumulated pseudo twist down the tree: Om_c = Ad_cp Om_p + W_c (phase A left W_c in BD_OM; done here,
             // one depth level per iteration, because phase A is the register-pressure peak of the kernel)
             {
@@ -1627,7 +1637,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 WAVE_SYNC();
                 // (float64 kernels, deep trees: the same sum in log2(depth) rounds, as phase A does for twists -- in world axes
                 // Ad(H_gc) Om_c = Ad(H_gp) Om_p + Ad(H_gc) W_c is a prefix sum over the ancestors; the ancestor pointers
-                // travel in the bias-acceleration slot, which phase A is done with)
+                // travel in the rhs-wrench slot, whose value every lane has taken into registers above)
                 bool jumped = false;
                 if constexpr (sizeof(T) == 8) {
                     const int maxdep = ARB_UNI(mp->maxdepth);
@@ -1685,13 +1695,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     WAVE_SYNC();
                 }
             }
-            T twb[6], ptb[6], pgb[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { om_b[i] = T(0); twb[i] = T(0); ptb[i] = T(0); pgb[i] = T(0); }
+            for (int i = 0; i < 6; ++i) om_b[i] = T(0);
             if (lane < nb) {
                 const T *bd = BD + lane * BDS;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { twb[i] = bd[BD_TW + i]; om_b[i] = bd[BD_OM + i]; ptb[i] = bd[BD_PT + i]; pgb[i] = (MODE == 1) ? bd[BD_PG + i] : T(0); }
+                for (int i = 0; i < 6; ++i) om_b[i] = bd[BD_OM + i];
             }
             // Small trees: the body lanes write the M | rhs part of their accumulators straight into the prefix table,
             // which takes the place of the per-body blocks: every lane has its own block in registers by now.
@@ -3486,7 +3495,9 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
     const long pad = std::max(0, env_int("ARB_LDS_PAD", 0));
     const long lds2 = (long)M->lf.total * 4 + pad, lds3 = (long)M->lf3.total * 4 + pad;
-    const long s2 = (long)cus * std::min(8l, (160 * 1024) / lds2), s3 = (long)cus * std::min(12l, (160 * 1024) / lds3);
+    // (wavefronts per CU by LDS: the 160 KB come in 128 granules of 1280 B, tools/lds_granule_probe.hip)
+    auto by_lds = [](long bytes) { return 128l / std::max(1l, (bytes + 1279) / 1280); };
+    const long s2 = (long)cus * std::min(8l, by_lds(lds2)), s3 = (long)cus * std::min(12l, by_lds(lds3));
     bc.slots2 = s2; bc.slots3 = s3;
     // Two or three waves per SIMD?  Three when the batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3
     // pin the build; ARB_FORCE_WAVES=2|3 in the environment overrides both (development).
@@ -3511,7 +3522,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     // ARB_FORCE_PACK=0|1 in the environment overrides the batch-size rule (development).
     if (M->packable && noopt && M->lfp.lscan) {
         const long ldsp = (long)M->lfp.total * 4 + pad;
-        const long sp = (long)cus * std::min(8l, (160 * 1024) / ldsp);
+        const long sp = (long)cus * std::min(8l, by_lds(ldsp));
         bc.slotsp = sp;
         // (end of round 3: with its LDS trimmed to the 1280-byte allocation granule the three-wave build really has twelve
         // wavefronts per CU -- eleven until then, whatever the occupancy API said -- and beats the packed build at every
@@ -3746,12 +3757,14 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     BuildChoice bc;
     if (dtype == ARB_F32 && !mfma) bc = choose_build(M, noopt, (long)nworlds, split ? 1 : nsteps, flags);
     out->worlds_per_wavefront = bc.pack ? 2 : 1;
-    out->waves_per_simd = (dtype == ARB_F64 && M->nmax == 64) ? 1 : (bc.w3 && !bc.pack) ? 3 : 2;
+    // (the float64 64-row kernels may use the whole register file of a SIMD: those with two column sets do -- one
+    // wavefront per SIMD --, those with one fit 256 registers)
+    out->waves_per_simd = (dtype == ARB_F64 && M->nmax == 64 && M->nsets == 2) ? 1 : (bc.w3 && !bc.pack) ? 3 : 2;
     const Layout &L = dtype == ARB_F64 ? M->ld : bc.pack ? M->lfp : bc.w3 ? M->lf3 : M->lf;
     out->lds_bytes = L.total * (dtype == ARB_F64 ? 8 : 4);
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device);
-    const long per_cu = std::min((long)(4 * out->waves_per_simd), (160l * 1024) / std::max(out->lds_bytes, 1));
+    const long per_cu = std::min((long)(4 * out->waves_per_simd), 128l / std::max(1l, ((long)out->lds_bytes + 1279) / 1280));
     out->wave_slots = (int32_t)(cus * per_cu);                    // (an estimate: the launch asks the occupancy API)
     const long units = bc.pack ? (nworlds + 1) / 2 : nworlds;
     out->work_queue = (!split && nsteps >= 2 && !(flags & ARB_STEP_STATIC_WORLDS) && units > out->wave_slots &&
