@@ -124,7 +124,9 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
 // afterwards (round 3: 2380 -> 1292 float32 words for human36, one of the three changes that bring the wave's LDS
 // from 19.4 KB to 13.1 KB = twelve waves per CU).  304 B rows.
 #define TB_STRIDE 38      // two-pass table (the three-wave kernels)
-#define TB_STRIDE1 70     // single-pass table (the two-wave kernels: 560 B rows, bank-conflict free)
+#define TB_STRIDE1 66     // single-pass table (the two-wave step kernels, 63 accumulators: 528 B rows, consecutive bodies 16 B
+                          // apart in the banks; 70 until the inspect kernels, which have 69, went over to two passes -- the 68
+                          // float64 words less per human36 world are its eighth wavefront per CU in float64)
 #define TB_PASS1 36
 
 // exact (bit pattern) equality, also true for identical NaNs
@@ -1708,7 +1710,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // registers held across the first pass --, the two-wave kernels through a full table in one)
             // (measured on the 16- and 32-row tiles, whose register peak is the same phase A / B as the 44-row tile's: two passes
             // in their two-wave kernels cost 65 spilled VGPRs and 3-6 %, tools/forest_rate.py)
-            constexpr bool TWO_PASS = (CM == 2 || CM == 3);
+            constexpr bool TWO_PASS = (CM == 2 || CM == 3 || MODE == 1);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
             const bool lscan = LSCAN_OK && mp->lay.lscan;
             const bool use_table = lscan && TWO_PASS;
@@ -1981,7 +1983,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const D2 *pl = reinterpret_cast<const D2 *>(STG + TBS * (a > 0 ? a - 1 : 0));
                     const bool keep = !((mp->rootmask >> a) & 1ull);       // (a root's sums start with itself: nothing to subtract,
                                                                             //  and the row before it belongs to another tree)
-                    static_assert(TB_PASS1 % 2 == 0 && NACC - TB_PASS1 <= TB_STRIDE && NACC <= TB_STRIDE1, "prefix table passes");
+                    static_assert(TB_PASS1 % 2 == 0 && NACC - TB_PASS1 <= TB_STRIDE && TB_STRIDE <= TB_STRIDE1, "prefix table passes");
                     // (the accumulators of the two passes are disjoint -- R, M dX', rhs from M | rhs; G, P from A -- so the
                     // order of the passes does not change a bit of the results)
                     static_for_asc(std::make_integer_sequence<int, (NACC - TB_PASS1 + 1) / 2>{}, [&](auto i2c) {
