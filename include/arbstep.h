@@ -106,8 +106,9 @@ enum {
 #define ARB_STEP_WAVES2 64u            /* pin the float32 step kernel build: compiled for two waves per SIMD (no register spills: */
 #define ARB_STEP_WAVES3 128u           /* the faster wave) or for three (more waves in flight: the faster chip once the batch fills
                                          them).  Default: the library picks by batch size and launch shape (three waves from
-                                         ~4100 worlds on an MI355X; from 16384 worlds a third build that holds TWO worlds per
-                                         wavefront), for models that have those builds: float32, 33 .. 48 dofs (the 44- and 48-row
+                                         ~3400 worlds on an MI355X; a third build that holds TWO worlds per wavefront is in the
+                                         library, bit-identical, but loses to three waves since their LDS fits twelve wavefronts
+                                         per CU: ARB_FORCE_PACK=1 in the environment selects it), for models that have those builds: float32, 33 .. 48 dofs (the 44- and 48-row
                                          register tiles; smaller models run faster on two waves at every batch size), ndof + 1 +
                                          4 nc <= 64.  All builds execute the same float operations in the same order per world --
                                          the library is compiled with -ffp-contract=on, so no fused multiply-add depends on how
