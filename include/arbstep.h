@@ -246,10 +246,14 @@ int arb_model_get_info(const arb_model *m, arb_model_info *info);
 
 /*
  * Which kernel build and launch shape arb_step / arb_step_ex would use for a batch (diagnostics: the benchmark records it,
- * the tests check the batch-size rules).  The float32 step kernel of a model with ndof <= 48 and ndof + 1 + 4 nc <= 64
- * exists in three bit-identical builds -- two waves per SIMD (no register spills), three waves per SIMD (more waves in
- * flight), and two WORLDS per wavefront (their Gauss-Seidel sweeps in one instruction stream; contact-only models) --
- * picked by batch size and launch shape; ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin one.
+ * the tests check the batch-size rules).  The float32 step kernel of a model with 33 <= ndof <= 48 and ndof + 1 + 4 nc
+ * <= 64 exists in three bit-identical builds -- two waves per SIMD (no register spills), three waves per SIMD (more waves
+ * in flight), and two WORLDS per wavefront (their Gauss-Seidel sweeps in one instruction stream; contact-only models; on
+ * request only: ARB_FORCE_PACK=1 in the environment) -- picked by batch size and launch shape; ARB_STEP_WAVES2 /
+ * ARB_STEP_WAVES3 pin one.  Models of at most 16 dofs: see ARB_STEP_ONE_WORLD.
+ *   wave_slots is an estimate from the registers of the build and the 1280-byte granule in which a CU's 160 KB of LDS are
+ *   handed out (hipOccupancyMaxActiveBlocksPerMultiprocessor divides 160 KB by the request and overestimates: twelve
+ *   wavefronts per CU fit up to 12 800 B each, not 13 653 B).
  *   optional_inputs: 0 = none, 1 = ext_gforce only, 3 = per-world PD inputs / logs / dt_steps
  */
 typedef struct arb_step_plan_info {
