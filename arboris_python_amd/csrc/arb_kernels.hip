@@ -252,6 +252,33 @@ __device__ __forceinline__ double quad_bcast(double x) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// Lane-dense execution (round 4).  tools/exec_mask_probe.hip: a wavefront whose EXEC mask has 8 or fewer lanes set issues
+// a vector instruction every 15 cycles (independent) / 17-26 cycles (dependent chain) instead of every 4.7 / 8.1 -- float32,
+// float64 and DPP alike, whatever the position of the lanes, 12 lanes or more run at full speed, and a co-resident dense
+// wave is not slowed down.  The step kernel had such sparse regions all over phase A (one tree level = 1-4 bodies, one
+// joint type = 1-7 bodies, 4 contacts, the one FreeJoint of phase E).  They now run on ALL lanes -- lanes without work
+// compute on clamped indices, their results are never stored -- and only the stores stay predicated.  `keep` marks a
+// value as used by every enabled lane at that point, so that the compiler cannot sink its computation into the
+// predicated store block that follows.  Same arithmetic on the lanes that count: bit-identical results.
+#ifndef ARB_DENSE
+#define ARB_DENSE 0x7f      // bit mask (development): 1 level loops, 2 phase A', 4 FreeJoint integration, 8 gvel add, 16 block inverses, 32 own columns, 64 sin/cos
+#endif
+#define ARB_DENSE_LVL (ARB_DENSE & 1)
+#define ARB_DENSE_AP (ARB_DENSE & 2)
+#define ARB_DENSE_FJ (ARB_DENSE & 4)
+#define ARB_DENSE_GV (ARB_DENSE & 8)
+#define ARB_DENSE_INV (ARB_DENSE & 16)
+#define ARB_DENSE_COL (ARB_DENSE & 32)
+#define ARB_DENSE_SC (ARB_DENSE & 64)
+__device__ __forceinline__ void keep(float x) { asm volatile("" :: "v"(x)); }
+__device__ __forceinline__ void keep(double x) { asm volatile("" :: "v"(x)); }
+__device__ __forceinline__ void keep(int x) { asm volatile("" :: "v"(x)); }
+template <typename T> __device__ __forceinline__ void keep(V3<T> v) { keep(v.x); keep(v.y); keep(v.z); }
+template <typename T> __device__ __forceinline__ void keep(const M3<T> &m) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) keep(m.a[i]);
+}
+
 template <typename T> __device__ __forceinline__ M3<T> ld_m3(const T *p) {
     M3<T> r;
 #pragma unroll
@@ -337,13 +364,25 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     // the blocks it reports as rank deficient are redone one after the other with the SVD-based pinv_block.
     if constexpr (SAME) {
         bool deficient = false;
-        if (lane < nc && CD[lane * CD_STRIDE + CD_ACTIVE] != T(0)) {
-            const int c = lane, ct = mp->ctype[c];
-            const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
-            T P[16];
-            deficient = !inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+        {
+            // (lane-dense, see ARB_DENSE: every lane inverts a block -- lanes without a constraint that of constraint 0 --,
+            // the active constraints' lanes store)
+            const bool mine = lane < nc && CD[(lane < nc ? lane : 0) * CD_STRIDE + CD_ACTIVE] != T(0);
+            if (ARB_DENSE_INV ? (nc > 0) : mine) {
+                const int c = lane < nc ? lane : 0, ct = mp->ctype[c];
+                const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                T P[16];
+                const bool ok = inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+                if (ARB_DENSE_INV) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+                    for (int i = 0; i < 16; ++i) keep(P[i]);
+                }
+                if (mine) {
+                    deficient = !ok;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
+                }
+            }
         }
         unsigned long long todo = __ballot(deficient);
         while (todo != 0ull) {                           // wave-uniform, rare
@@ -1087,9 +1126,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             if (qi >= 0) qs[qi] += dt * vnew;                               // core.py:238-240
         }
         WAVE_SYNC();
-        if (lane < nb && mp->jtype[lane] == JT_FREE) {                        // joints.py:54-57
-            T *qp = qs + mp->q_off[lane];
-            const T *vp = dqs + mp->dof_off[lane];
+        // (lane-dense, see ARB_DENSE: a world has one FreeJoint or a few; every lane runs the exponential -- lanes of other
+        // joints on the first FreeJoint's state --, the FreeJoints' lanes store)
+        const bool isfree = lane < nb && mp->jtype[lane] == JT_FREE;
+        const unsigned long long freemask = __ballot(isfree);
+        if (freemask != 0ull && (ARB_DENSE_FJ || isfree)) {                      // joints.py:54-57
+            const int fb = isfree ? lane : __builtin_ctzll(freemask);
+            T *qp = qs + mp->q_off[fb];
+            const T *vp = dqs + mp->dof_off[fb];
             M3<T> R, Re; V3<T> p, pe;
             R.a[0] = qp[0]; R.a[1] = qp[1]; R.a[2] = qp[2]; p.x = qp[3];
             R.a[3] = qp[4]; R.a[4] = qp[5]; R.a[5] = qp[6]; p.y = qp[7];
@@ -1097,10 +1141,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             exp_twist<T>(dt * v3<T>(vp[0], vp[1], vp[2]), dt * v3<T>(vp[3], vp[4], vp[5]), Re, pe);
             const M3<T> Rn = mul(R, Re);
             const V3<T> pn = mv(R, pe) + p;
-            qp[0] = Rn.a[0]; qp[1] = Rn.a[1]; qp[2] = Rn.a[2]; qp[3] = pn.x;
-            qp[4] = Rn.a[3]; qp[5] = Rn.a[4]; qp[6] = Rn.a[5]; qp[7] = pn.y;
-            qp[8] = Rn.a[6]; qp[9] = Rn.a[7]; qp[10] = Rn.a[8]; qp[11] = pn.z;
-            qp[12] = T(0); qp[13] = T(0); qp[14] = T(0); qp[15] = T(1);
+            if (ARB_DENSE_FJ) { keep(Rn); keep(pn); }
+            if (isfree) {
+                qp[0] = Rn.a[0]; qp[1] = Rn.a[1]; qp[2] = Rn.a[2]; qp[3] = pn.x;
+                qp[4] = Rn.a[3]; qp[5] = Rn.a[4]; qp[6] = Rn.a[5]; qp[7] = pn.y;
+                qp[8] = Rn.a[6]; qp[9] = Rn.a[7]; qp[10] = Rn.a[8]; qp[11] = pn.z;
+                qp[12] = T(0); qp[13] = T(0); qp[14] = T(0); qp[15] = T(1);
+            }
         }
         WAVE_SYNC();
     };
@@ -1195,7 +1242,18 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 jt = mp->jtype[b]; par = mp->parent[b]; doff = mp->dof_off[b]; dep = mp->depth[b];
                 k = mp->jnd[b];
                 JointLocal<double> jld;
-                joint_local<double>(jt, qs + mp->q_off[b], dqs + doff, jld);
+                if (ARB_DENSE_SC) {
+                    // (lane-dense, see ARB_DENSE: the sin / cos of the joint's angles on every body lane, before the
+                    // joint-type switch, whose cases run with the 1-7 lanes of one joint type enabled; a FreeJoint's
+                    // "angles" are entries of its pose matrix, unused)
+                    const T *qj = qs + mp->q_off[b];
+                    double ps[3], pc[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) arb_sincos((double)qj[i], &ps[i], &pc[i]);
+                    joint_local<double>(jt, qj, (const T *)(dqs + doff), jld, ps, pc);
+                } else {
+                    joint_local<double>(jt, qs + mp->q_off[b], dqs + doff, jld);
+                }
                 JointLocal<T> jl;
                 jl.R = cvt_m3<T>(jld.R); jl.p = cvt_v3<T>(jld.p);
 #pragma unroll
@@ -1254,7 +1312,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 Tnv = cross(p_cn, Tnw) + mv(R_cn, jl.Tv);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    if (i < k) {
+                    // (lane-dense, see ARB_DENSE: column i exists on the lanes of joints with more than i dofs -- the one
+                    // FreeJoint for i >= 3 --; every body lane computes it when any has it, those lanes store)
+                    if (ARB_DENSE_COL ? (__ballot(i < k) != 0ull) : (i < k)) {
                         V3<T> cw = v3<T>(T(0), T(0), T(0)), cv = cw, dw = cw;
                         if (jt == JT_FREE) {
                             if (i < 3) cw = v3<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
@@ -1269,10 +1329,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         const V3<T> dow = mv(R_cn, dw);
                         const V3<T> dov = cross(p_cn, dow);
                         const int col = doff + i;
-                        SC[0 * RS + col] = ow.x; SC[1 * RS + col] = ow.y; SC[2 * RS + col] = ow.z;
-                        SC[3 * RS + col] = ov.x; SC[4 * RS + col] = ov.y; SC[5 * RS + col] = ov.z;
-                        SC[6 * RS + col] = dow.x; SC[7 * RS + col] = dow.y; SC[8 * RS + col] = dow.z;
-                        SC[9 * RS + col] = dov.x; SC[10 * RS + col] = dov.y; SC[11 * RS + col] = dov.z;
+                        if (ARB_DENSE_COL) { keep(ow); keep(ov); keep(dow); keep(dov); }
+                        if (i < k) {
+                            SC[0 * RS + col] = ow.x; SC[1 * RS + col] = ow.y; SC[2 * RS + col] = ow.z;
+                            SC[3 * RS + col] = ov.x; SC[4 * RS + col] = ov.y; SC[5 * RS + col] = ov.z;
+                            SC[6 * RS + col] = dow.x; SC[7 * RS + col] = dow.y; SC[8 * RS + col] = dow.z;
+                            SC[9 * RS + col] = dov.x; SC[10 * RS + col] = dov.y; SC[11 * RS + col] = dov.z;
+                        }
                     }
                 }
             }
@@ -1369,7 +1432,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // pose and twist down the tree, one depth level at a time
             if (!jumped)
             for (int lvl = 0; lvl <= mp->maxdepth; ++lvl) {
-                if (on && dep == lvl) {
+                // (lane-dense, see ARB_DENSE: every lane goes through the level's arithmetic -- a lane of another level on
+                // whatever its parent's block holds at the moment, a lane without a body on body 0 --, the bodies of this
+                // level store)
+                const bool mine = on && dep == lvl;
+                if (ARB_DENSE_LVL || mine) {
+                    const int bb = on ? b : 0;
                     M3<double> Rg = m3_identity<double>(); V3<double> pg = v3<double>(0., 0., 0.);
                     V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw;
                     if (par >= 0) {
@@ -1378,20 +1446,23 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
                         aw = ld_v3(pb + BD_AB); av = ld_v3(pb + BD_AB + 3);
                     }
-                    const M3<double> R_pc_d = ld_m3(PD + 12 * b);
-                    const V3<double> p_pc_d = ld_v3(PD + 12 * b + 9);
+                    const M3<double> R_pc_d = ld_m3(PD + 12 * bb);
+                    const V3<double> p_pc_d = ld_v3(PD + 12 * bb + 9);
                     const M3<double> Rc_d = mul(Rg, R_pc_d);         // child_pose  core.py:1299
                     const V3<double> pc_d = mv(Rg, p_pc_d) + pg;
-                    st_m3(PD + 12 * b, Rc_d); st_v3(PD + 12 * b + 9, pc_d);
                     const V3<T> cw = mv(R_cp, tw) + Tnw;             // child_twist core.py:1308
                     const V3<T> cv = cross(p_cp, mv(R_cp, tw)) + mv(R_cp, tv) + Tnv;
-                    T *bd = BD + b * BDS;
-                    st_v3(bd + BD_TW, cw); st_v3(bd + BD_TW + 3, cv);
                     // dJ_c gvel = dAd_cp T_p + Ad_cp (dJ_p gvel) + Ad_cn dJ_nr gvel_j   (core.py:1312-1313 times gvel)
                     const V3<T> raw = mv(R_cp, aw);
                     const V3<T> nbw = mv(dA_cp, tw) + raw + Bnw;
                     const V3<T> nbv = mv(dB_cp, tw) + mv(dA_cp, tv) + cross(p_cp, raw) + mv(R_cp, av) + Bnv;
-                    st_v3(bd + BD_AB, nbw); st_v3(bd + BD_AB + 3, nbv);
+                    if (ARB_DENSE_LVL) { keep(Rc_d); keep(pc_d); keep(cw); keep(cv); keep(nbw); keep(nbv); }
+                    if (mine) {
+                        T *bd = BD + b * BDS;
+                        st_m3(PD + 12 * b, Rc_d); st_v3(PD + 12 * b + 9, pc_d);
+                        st_v3(bd + BD_TW, cw); st_v3(bd + BD_TW + 3, cv);
+                        st_v3(bd + BD_AB, nbw); st_v3(bd + BD_AB + 3, nbv);
+                    }
                 }
                 WAVE_SYNC();
             }
@@ -1494,8 +1565,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         ARB_STAMP(1);
         // (RT -- the rhs and the rows of J' -- is zeroed in phase B, once the joints' own columns SC, which share its
         // space since round 3, have been consumed)
-        if (do_constraints && lane < nc) {
-            const int c = lane;
+        // (lane-dense, see ARB_DENSE: with four contacts four lanes would work; every lane runs the arithmetic -- lanes
+        // without a constraint on constraint 0 --, the constraints' own lanes store)
+        if (do_constraints && (ARB_DENSE_AP || lane < nc)) {
+            const bool mine = lane < nc;
+            const int c = mine ? lane : 0;
             T *cd = CD + c * CD_STRIDE;
             const int ct = mp->ctype[c];
             bool active = false;
@@ -1536,24 +1610,32 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const T vz0 = (mv(R0, bv0) + cross(P0, mv(R0, bw0))).z;
                     const T dsd = vz1 - vz0;
                     active = ((double)sd_d + (double)dsd * (double)dt < mp->cprox_d[c]);
-                    {   // phase B works on world-axes columns about the origin of a tree's root body: store world -> contact
-                        // frame 0 about the root of body 1's tree (the rows of another tree's dofs shift it, see there)
-                        const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
-                        st_m3(cd + CD_R1, cvt_m3<T>(transpose(Rc))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(Rc, gc0 - p0w)));
-                    }
-                    st_v3(cd + CD_GC0, cvt_v3<T>(gc0)); st_v3(cd + CD_GC1, cvt_v3<T>(gc1));
+                    // phase B works on world-axes columns about the origin of a tree's root body: store world -> contact
+                    // frame 0 about the root of body 1's tree (the rows of another tree's dofs shift it, see there)
+                    const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
+                    const M3<T> o_r1 = cvt_m3<T>(transpose(Rc));
+                    const V3<T> o_p1 = cvt_v3<T>(-mtv(Rc, gc0 - p0w)), o_g0 = cvt_v3<T>(gc0), o_g1 = cvt_v3<T>(gc1);
+                    if (ARB_DENSE_AP) { keep(o_r1); keep(o_p1); keep(o_g0); keep(o_g1); keep(sd); keep((int)active); }
+                    if (mine) {
+                        st_m3(cd + CD_R1, o_r1); st_v3(cd + CD_P1, o_p1);
+                        st_v3(cd + CD_GC0, o_g0); st_v3(cd + CD_GC1, o_g1);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
+                        for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
+                    }
                 } else if (ct == ARB_CT_JOINTLIMITS) {
                     const T p0 = qd[mp->cdof[c]];
-                    cd[CD_POS0] = p0;
                     const double lo_d = mp->cmin_d[c], hi_d = mp->cmax_d[c], px_d = mp->cprox_d[c];
                     active = ((double)p0 - lo_d < px_d) || (hi_d - (double)p0 < px_d);
                     // per-step constants of the solve, formed in float64: (min - pos0)/dt, (max - pos0)/dt
-                    cd[CD_POS0 + 1] = (T)((lo_d - (double)p0) / (double)dt);
-                    cd[CD_POS0 + 2] = (T)((hi_d - (double)p0) / (double)dt);
+                    const T glo = (T)((lo_d - (double)p0) / (double)dt), ghi = (T)((hi_d - (double)p0) / (double)dt);
+                    if (ARB_DENSE_AP) { keep(glo); keep(ghi); keep((int)active); }
+                    if (mine) {
+                        cd[CD_POS0] = p0;
+                        cd[CD_POS0 + 1] = glo;
+                        cd[CD_POS0 + 2] = ghi;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:58-60
+                        for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:58-60
+                    }
                     sd = p0;
                 } else {                                                // BallAndSocket
                     const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
@@ -1565,17 +1647,20 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const V3<double> pf0 = ld_v3(mp->cb0_d + 12 * c + 9), pf1 = ld_v3(mp->cb1_d + 12 * c + 9);
                     const M3<double> RP0 = mul(Rg0, Rf0); const V3<double> pP0 = mv(Rg0, pf0) + pg0;
                     const V3<double> pP1 = mv(Rg1, pf1) + pg1;
-                    st_v3(cd + CD_POS0, cvt_v3<T>(mtv(RP0, pP1 - pP0)));  // p_01  constraints.py:196-197
                     // body1 -> frame 0: Ad(inv(P0) H_gb1);  body0 -> frame 0: Ad(inv(bpose0))
-                    {
-                        const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
-                        st_m3(cd + CD_R1, cvt_m3<T>(transpose(RP0))); st_v3(cd + CD_P1, cvt_v3<T>(-mtv(RP0, pP0 - p0w)));
-                    }
+                    const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
+                    const V3<T> o_pos = cvt_v3<T>(mtv(RP0, pP1 - pP0));      // p_01  constraints.py:196-197
+                    const M3<T> o_r1 = cvt_m3<T>(transpose(RP0));
+                    const V3<T> o_p1 = cvt_v3<T>(-mtv(RP0, pP0 - p0w));
+                    if (ARB_DENSE_AP) { keep(o_pos); keep(o_r1); keep(o_p1); }
+                    if (mine) { st_v3(cd + CD_POS0, o_pos); st_m3(cd + CD_R1, o_r1); st_v3(cd + CD_P1, o_p1); }
                     active = true;
                 }
             }
-            cd[CD_SDIST] = sd;
-            cd[CD_ACTIVE] = active ? T(1) : T(0);
+            if (mine) {
+                cd[CD_SDIST] = sd;
+                cd[CD_ACTIVE] = active ? T(1) : T(0);
+            }
         }
         WAVE_SYNC();
         if (lane < ndol) FF0[lane] = FF[lane];
@@ -1685,14 +1770,17 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 }
                 if (!jumped)
                 for (int lvl = 1; lvl <= mp->maxdepth; ++lvl) {
-                    if (mydep == lvl) {
-                        T *bd = BD + lane * BDS;
-                        const T *pb = BD + par * BDS;
+                    const bool mine = mydep == lvl;          // (lane-dense, see ARB_DENSE)
+                    if (ARB_DENSE_LVL || mine) {
+                        T *bd = BD + (lane < nb ? lane : 0) * BDS;
+                        const T *pb = BD + (par >= 0 ? par : 0) * BDS;
                         const M3<T> R_cp = ld_m3(bd + BD_RCP);
                         const V3<T> p_cp = ld_v3(bd + BD_PCP);
                         const V3<T> rw = mv(R_cp, ld_v3(pb + BD_OM));
-                        st_v3(bd + BD_OM + 3, cross(p_cp, rw) + mv(R_cp, ld_v3(pb + BD_OM + 3)) + ld_v3(bd + BD_OM + 3));
-                        st_v3(bd + BD_OM, rw + ld_v3(bd + BD_OM));
+                        const V3<T> nv = cross(p_cp, rw) + mv(R_cp, ld_v3(pb + BD_OM + 3)) + ld_v3(bd + BD_OM + 3);
+                        const V3<T> nw = rw + ld_v3(bd + BD_OM);
+                        if (ARB_DENSE_LVL) { keep(nv); keep(nw); }
+                        if (mine) { st_v3(bd + BD_OM + 3, nv); st_v3(bd + BD_OM, nw); }
                     }
                     WAVE_SYNC();
                 }
@@ -2387,6 +2475,27 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // (dqs is zero beyond ndof; rows >= ndof of the columns are never used)
             typedef T V4 __attribute__((ext_vector_type(4)));
             const V4 *d4 = reinterpret_cast<const V4 *>(dqs);
+            // (lane-dense, see ARB_DENSE: one lane holds the column; every lane adds, the column's lane keeps the sum)
+            if (ARB_DENSE_GV) {
+                const bool mine = lane == rhs_lane;
+#pragma unroll
+                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                    const V4 v = d4[i4];
+                    const T s0 = Z[4 * i4] + v.x, s1 = Z[4 * i4 + 1] + v.y, s2 = Z[4 * i4 + 2] + v.z, s3 = Z[4 * i4 + 3] + v.w;
+                    Z[4 * i4] = mine ? s0 : Z[4 * i4]; Z[4 * i4 + 1] = mine ? s1 : Z[4 * i4 + 1];
+                    Z[4 * i4 + 2] = mine ? s2 : Z[4 * i4 + 2]; Z[4 * i4 + 3] = mine ? s3 : Z[4 * i4 + 3];
+                }
+                if (NSETS == 2) {
+                    const bool mine2 = WAVE + lane == n;
+#pragma unroll
+                    for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                        const V4 v = d4[i4];
+                        const T s0 = Z2[4 * i4] + v.x, s1 = Z2[4 * i4 + 1] + v.y, s2 = Z2[4 * i4 + 2] + v.z, s3 = Z2[4 * i4 + 3] + v.w;
+                        Z2[4 * i4] = mine2 ? s0 : Z2[4 * i4]; Z2[4 * i4 + 1] = mine2 ? s1 : Z2[4 * i4 + 1];
+                        Z2[4 * i4 + 2] = mine2 ? s2 : Z2[4 * i4 + 2]; Z2[4 * i4 + 3] = mine2 ? s3 : Z2[4 * i4 + 3];
+                    }
+                }
+            } else {
             if (lane == rhs_lane) {
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
@@ -2400,6 +2509,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     const V4 v = d4[i4];
                     Z2[4 * i4] += v.x; Z2[4 * i4 + 1] += v.y; Z2[4 * i4 + 2] += v.z; Z2[4 * i4 + 3] += v.w;
                 }
+            }
             }
         }
         // lanes >= n (and the second set) now hold Y rhs and Y J'^T columns

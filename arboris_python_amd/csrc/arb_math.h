@@ -264,9 +264,17 @@ template <typename T> struct JointLocal {
 };
 
 // q, dq point at the joint's own slice of the state.
+// pre_s / pre_c (optional): sin and cos of q[0], q[1], q[2], formed by the caller OUTSIDE the joint-type switch -- on the
+// device every case of the switch runs with the few lanes of that joint type enabled, and a wavefront with 8 or fewer
+// lanes enabled issues its vector instructions 3-4 times slower (tools/exec_mask_probe.hip); the angles' sin/cos are most
+// of the switch.  Same arb_sincos on the same arguments: the results do not change.
 template <typename T, typename QP>
-ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
+ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o, const T *pre_s = nullptr, const T *pre_c = nullptr) {
     const T Z = T(0), O = T(1);
+    auto arb_sincos = [&](T a, T *sn, T *cs, int i) {
+        if (pre_s != nullptr) { *sn = pre_s[i]; *cs = pre_c[i]; }
+        else ::arb_sincos(a, sn, cs);
+    };
     o.R = m3_identity<T>();
     o.p = v3<T>(Z, Z, Z);
     for (int i = 0; i < 3; ++i) { o.jw[i] = v3<T>(Z, Z, Z); o.djw[i] = v3<T>(Z, Z, Z); }
@@ -281,7 +289,7 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
     } break;
     case JT_RZRYRX: {                                 // joints.py:59-104, rotzyx :34-59
         T sz, cz, sy, cy, sx, cx;
-        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sy, &cy); arb_sincos(T(q[2]), &sx, &cx);
+        arb_sincos(T(q[0]), &sz, &cz, 0); arb_sincos(T(q[1]), &sy, &cy, 1); arb_sincos(T(q[2]), &sx, &cx, 2);
         o.R.a[0] = cz * cy; o.R.a[1] = cz * sy * sx - sz * cx; o.R.a[2] = cz * sy * cx + sz * sx;
         o.R.a[3] = sz * cy; o.R.a[4] = sz * sy * sx + cz * cx; o.R.a[5] = sz * sy * cx - cz * sx;
         o.R.a[6] = -sy;     o.R.a[7] = cy * sx;                o.R.a[8] = cy * cx;
@@ -295,7 +303,7 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
     } break;
     case JT_RZRY: {                                   // joints.py:107-146, rotzy :60-80
         T sz, cz, sy, cy;
-        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sy, &cy);
+        arb_sincos(T(q[0]), &sz, &cz, 0); arb_sincos(T(q[1]), &sy, &cy, 1);
         o.R.a[0] = cz * cy; o.R.a[1] = -sz; o.R.a[2] = cz * sy;
         o.R.a[3] = sz * cy; o.R.a[4] = cz;  o.R.a[5] = sz * sy;
         o.R.a[6] = -sy;     o.R.a[7] = Z;   o.R.a[8] = cy;
@@ -307,7 +315,7 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
     } break;
     case JT_RZRX: {                                   // joints.py:149-185, rotzx :82-102
         T sz, cz, sx, cx;
-        arb_sincos(T(q[0]), &sz, &cz); arb_sincos(T(q[1]), &sx, &cx);
+        arb_sincos(T(q[0]), &sz, &cz, 0); arb_sincos(T(q[1]), &sx, &cx, 1);
         o.R.a[0] = cz; o.R.a[1] = -sz * cx; o.R.a[2] = sz * sx;
         o.R.a[3] = sz; o.R.a[4] = cz * cx;  o.R.a[5] = -cz * sx;
         o.R.a[6] = Z;  o.R.a[7] = sx;       o.R.a[8] = cx;
@@ -319,7 +327,7 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
     } break;
     case JT_RYRX: {                                   // joints.py:188-224, rotyx :104-124
         T sy, cy, sx, cx;
-        arb_sincos(T(q[0]), &sy, &cy); arb_sincos(T(q[1]), &sx, &cx);
+        arb_sincos(T(q[0]), &sy, &cy, 0); arb_sincos(T(q[1]), &sx, &cx, 1);
         o.R.a[0] = cy;  o.R.a[1] = sy * sx; o.R.a[2] = sy * cx;
         o.R.a[3] = Z;   o.R.a[4] = cx;      o.R.a[5] = -sx;
         o.R.a[6] = -sy; o.R.a[7] = cy * sx; o.R.a[8] = cy * cx;
@@ -330,19 +338,19 @@ ARB_HD void joint_local(int jt, QP q, QP dq, JointLocal<T> &o) {
         o.Tw = T(dq[0]) * o.jw[0] + T(dq[1]) * o.jw[1];
     } break;
     case JT_RZ: {                                     // joints.py:227-303
-        T s, c; arb_sincos(T(q[0]), &s, &c);
+        T s, c; arb_sincos(T(q[0]), &s, &c, 0);
         o.R.a[0] = c; o.R.a[1] = -s; o.R.a[3] = s; o.R.a[4] = c;
         o.jw[0] = v3<T>(Z, Z, O);
         o.Tw = T(dq[0]) * o.jw[0];
     } break;
     case JT_RY: {                                     // joints.py:305-326
-        T s, c; arb_sincos(T(q[0]), &s, &c);
+        T s, c; arb_sincos(T(q[0]), &s, &c, 0);
         o.R.a[0] = c; o.R.a[2] = s; o.R.a[6] = -s; o.R.a[8] = c;
         o.jw[0] = v3<T>(Z, O, Z);
         o.Tw = T(dq[0]) * o.jw[0];
     } break;
     case JT_RX: {                                     // joints.py:328-349
-        T s, c; arb_sincos(T(q[0]), &s, &c);
+        T s, c; arb_sincos(T(q[0]), &s, &c, 0);
         o.R.a[4] = c; o.R.a[5] = -s; o.R.a[7] = s; o.R.a[8] = c;
         o.jw[0] = v3<T>(O, Z, Z);
         o.Tw = T(dq[0]) * o.jw[0];

@@ -48,6 +48,18 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
 if "SQ_THREAD_CYCLES_VALU" in lanes and lanes.get("SQ_ACTIVE_INST_VALU"):
     out["valu_lane_utilisation"] = lanes["SQ_THREAD_CYCLES_VALU"] / (64. * lanes["SQ_ACTIVE_INST_VALU"])
 out["pmc_per_launch"] = pmc
+# Dynamic instruction mix (round 4) and the pipe-weighted issue fraction: a wave64 float32 instruction holds a SIMD-32's
+# vector pipe for 2.4 cycles, a float64 one for 4.3 (tools/exec_mask_probe.hip / valu_issue_probe.hip, two to four
+# independent waves per SIMD, shader clock from s_memtime against s_memrealtime); everything the float classes leave --
+# moves, selects, compares, integer, lane exchanges -- is priced like float32 (DPP operands cost 4.2: a lower bound).
+f32 = ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32"]
+f64 = ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]
+if all(k in pmc for k in f32 + f64 + ["SQ_INSTS_VALU"]):
+    n32 = sum(pmc[k]["mean_per_launch"] for k in f32); n64 = sum(pmc[k]["mean_per_launch"] for k in f64)
+    tot = pmc["SQ_INSTS_VALU"]["mean_per_launch"]
+    out["valu_mix_per_launch"] = {"float32": n32, "float64": n64, "other": tot - n32 - n64, "total": tot,
+                                  "pipe_cycles": 2.4 * (tot - n64) + 4.3 * n64,
+                                  "pipe_cycles_note": "2.4 cycles per float32 / other instruction, 4.3 per float64 instruction"}
 out["notes"] = ("bench.py config 3: human36 + 4 contacts, 4096 worlds, f32, one 40-step episode per launch; kernel-trace pass: "
                 "--steps 40 --warmup 40 --min-seconds 1 (>= 50 timed episode launches + the one-launch-per-step leg); each --pmc "
                 "group in its own pass (--min-seconds 0.2 --no-per-step-leg), counters averaged over all episode launches. "
