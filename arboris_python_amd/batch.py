@@ -229,16 +229,18 @@ class BatchedWorlds(object):
         return out
 
     def plan(self, nworlds, nsteps=1, dtype=None, ext_gforce=False, other_inputs=False, waves=None, split=False,
-             static_worlds=False, one_world=False):
+             static_worlds=False, one_world=False, world_logs=False):
         """Which kernel build and launch shape ``step`` would use (``arb_step_plan``): a dict with ``waves_per_simd``,
-        ``worlds_per_wavefront`` (2 = the packed build; the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``."""
+        ``worlds_per_wavefront`` (2 = the packed build; the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``.
+        ``world_logs``: the launch is a rollout that logs per-world energies (or states of a batch that is not a multiple
+        of the forest's copies), which a small model runs one world per wavefront."""
         torch = _torch()
         code = _capi.ARB_F64 if dtype == torch.float64 else _capi.ARB_F32
         flags = self._waves_flag(waves) | self._split_flag(split) | (_capi.ARB_STEP_STATIC_WORLDS if static_worlds else 0)
         flags |= _capi.ARB_STEP_ONE_WORLD if one_world else 0
         p = _capi.StepPlan()
         _capi.check(self._lib.arb_step_plan(self._handle, code, int(nworlds), int(nsteps), flags,
-                                            3 if other_inputs else (1 if ext_gforce else 0), C.byref(p)))
+                                            (3 if other_inputs else (1 if ext_gforce else 0)) | (4 if world_logs else 0), C.byref(p)))
         return {k: getattr(p, k) for k, _ in _capi.StepPlan._fields_}
 
     def status(self):

@@ -66,6 +66,11 @@
 #ifndef ARB_GS_F64
 #define ARB_GS_F64 0            // 1: the Gauss-Seidel sweeps of float32 worlds in float64 arithmetic (measured, not the default: DESIGN.md 2)
 #endif
+#ifndef ARB_ELIM_F64
+#define ARB_ELIM_F64 0          // 1 (experiment, round 4): phases C and D of float32 worlds in float64 -- the register tile [Z | rhs | J'^T],
+                                // the elimination and the constraint-space products; the sweeps stay float32.  Settles where the float32
+                                // outliers are decided (profiles/r04_replay_stats.txt); not a production build (88 more registers)
+#endif
 #ifndef ARB_PACK_MIN_ROUNDS
 #define ARB_PACK_MIN_ROUNDS 4   // the packed build is picked from this many pairs of worlds per wave slot on (16384 worlds on an MI355X: measured +2 %; +0..2 % at 8192, -8 % at 4096, where the three-wave build wins)
 #endif
@@ -468,8 +473,13 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
         k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
         k_eps1 = k_act && k_ct == ARB_CT_SOFTFINGER && (k_e0 == G(1)) && (k_e1 == G(1)) && (k_e2 == G(1));
     }
-    const unsigned long long actmask = __ballot(k_act);
+    unsigned long long actmask = __ballot(k_act);
     const unsigned long long eps1mask = __ballot(k_eps1);
+    // forest worlds (several copies of a small model in this wavefront): a copy whose own rows a sweep left bit for bit
+    // unchanged is at ITS fixed point and takes no further part -- one world per wavefront stops sweeping there, and a
+    // float32 solve repeated beyond it is not exactly idempotent (the root finder's start depends on how far the root
+    // moved in the previous sweep), which used to leave the copies a few ulps from the one-world launch (round 4)
+    const int g_fk = mp->fk, g_fnc = mp->fnc;
     int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
     int tr_rel = 0, tr_sta = 0, tr_slow = 0;
     G vr_prev = vr, fr_prev = fr;
@@ -670,7 +680,15 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
         }
         // A sweep that leaves every velocity and force bit-for-bit unchanged is a fixed point
         // of the iteration: the remaining sweeps of core.py:929-935 would repeat it exactly.
-        if (__all(same_bits(vr, vr_prev) && same_bits(fr, fr_prev)) && !(MODE == 1 && (dbg.ablate & 8))) break;
+        const unsigned long long sameb = __ballot(same_bits(vr, vr_prev) && same_bits(fr, fr_prev));
+        if (sameb == ~0ull && !(MODE == 1 && (dbg.ablate & 8))) break;
+        if (g_fk > 1) {
+            const int rows = ARB_MAXDOL * g_fnc;              // constraint rows of one copy (g_fk * rows <= 64)
+            const unsigned long long rm = (rows >= 64) ? ~0ull : ((1ull << rows) - 1ull), cm = (1ull << g_fnc) - 1ull;
+            for (int j = 0; j < g_fk; ++j)
+                if (((sameb >> (j * rows)) & rm) == rm) actmask &= ~(cm << (j * g_fnc));
+            if (actmask == 0ull) break;
+        }
         vr_prev = vr; fr_prev = fr;
     }
 #if ARB_GS_PRIO
@@ -939,8 +957,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     // chunk-major, so the chunk an item waits for was drawn nworlds items earlier: it is finished, or it is running
     // on a resident wavefront that waits for nothing drawn later -- no circular wait.  The spin is capped all the same
     // (a producer stalled by a debugger or by serialised workgroups must not hang the device): a wavefront whose wait
-    // expires raises the handle's host-visible status word, poisons the world's flag so that its later chunks do not
-    // wait again, and goes on to the next item WITHOUT touching the world; the host reports ARB_ERR_STALLED.
+    // expires raises the handle's host-visible status word, poisons the world's flag -- for good: flags only grow -- so
+    // that its later chunks neither wait nor run, and goes on to the next item WITHOUT touching the world; the host
+    // reports ARB_ERR_STALLED on every call until arb_model_status has been read.
     // (the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs, faulted on
     // their first launch -- queue or not -- with the item loop around the body, ROCm 7.2: there every workgroup draws
     // ONE item and the grid is the number of items; the hardware dispatcher does the looping)
@@ -974,17 +993,23 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         }
         if (qitem_chunk > 0) {
             int spins = 0;      // (the cap, ~7 s of polling by default, guarantees that every wavefront leaves the kernel)
+            int flag = 0;
             bool ready = false;
             while (queue_spin_cap >= 0) {       // (a negative cap is the tests' fault injection: every wait "expires")
-                ready = __hip_atomic_load(queue + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= qitem_chunk;
+                flag = __hip_atomic_load(queue + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = flag >= qitem_chunk;
                 if (ready || spins >= queue_spin_cap) break;
                 __builtin_amdgcn_s_sleep(16);
                 ++spins;
             }
-            if (!ready) {
-                if (lane0 == 0) {
+            // A wait that expires POISONS the world's flag, and the poison sticks (both writers of the flag use an atomic
+            // max): no later chunk of the world waits again, none of them touches the world -- whose late producer may
+            // still be writing its state --, and the host reports ARB_ERR_STALLED until the caller acknowledges it.
+            constexpr int POISON = 0x7fffffff;
+            if (!ready || flag == POISON) {
+                if (!ready && lane0 == 0) {
                     __hip_atomic_store(mp->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(queue + 1 + w, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_max(queue + 1 + w, POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (!QUEUE_LOOP) return;
                 continue;
@@ -1187,7 +1212,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             for (int i = lane; i < ndol; i += WAVE) FF[i] = fff[i];
             WAVE_SYNC();
         }
-        const T ext_k = (PACK && isub == 1) ? ext_kB : ext_kA;
+        T ext_k = (PACK && isub == 1) ? ext_kB : ext_kA;
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
@@ -1201,6 +1226,16 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             for (int i = lane; i < nq; i += WAVE) if (!(fabs(qs[i]) <= lim)) bad |= 1u << (i / fnq);
             if (lane < n && !(fabs(dqs[lane]) <= lim)) bad |= 1u << (lane / fn);
             for (int i = lane; i < ndol; i += WAVE) if (!(fabs(FF[i]) <= lim)) bad |= 1u << (i / fnd);
+            // ... and the copy's per-world INPUTS (round 4): a NaN or Inf in one world's user torques or PD targets / gains
+            // would go through the shared elimination like a NaN in its state
+            if (lane < n) {
+                bool in_bad = !(fabs(ext_kA) <= lim);
+                if (FEAT_ALL && pwd.qdes != nullptr)
+                    in_bad = in_bad || !(fabs(pwd.qdes[w * n + lane]) <= lim) || !(fabs(pwd.dqdes[w * n + lane]) <= lim);
+                if (FEAT_ALL && pwd.kp != nullptr)
+                    in_bad = in_bad || !(fabs(pwd.kp[w * n + lane]) <= lim) || !(fabs(pwd.kd[w * n + lane]) <= lim);
+                if (in_bad) bad |= 1u << (lane / fn);
+            }
             unsigned long long some = __ballot(bad != 0u);
             while (some != 0ull) {                           // wave-uniform, rare
                 dead |= (unsigned)__builtin_amdgcn_readlane((int)bad, __builtin_ctzll(some));
@@ -1220,9 +1255,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     logo.dq[((long)step * nworlds + w) * n + lane] = ((dead >> (lane / fn)) & 1u) ? (T)NAN : dqs[lane];
             }
         }
+        bool lane_dead = false;     // this lane's dof belongs to a retired copy: its inputs are ignored from now on
         if (dead != 0u) {           // retired copies compute on a state of rest
             const int fn = ARB_UNI(mp->fn), fnq = ARB_UNI(mp->fnq), fnd = ARB_MAXDOL * ARB_UNI(mp->fnc);
             for (int i = lane; i < nq; i += WAVE) if ((dead >> (i / fnq)) & 1u) qs[i] = mp->qdef[i];
+            lane_dead = lane < n && ((dead >> (lane / fn)) & 1u);
+            if (lane_dead) ext_k = T(0);
             if (lane < n && ((dead >> (lane / fn)) & 1u)) dqs[lane] = T(0);
             for (int i = lane; i < ndol; i += WAVE) if ((dead >> (i / fnd)) & 1u) FF[i] = T(0);
             WAVE_SYNC();
@@ -1668,10 +1706,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         // ================= phase B: lane = dof column =======================
         ARB_OPAQUE_LANE();
         ARB_STAMP(2);
-        T Z[NMAX];
-        T Z2[NSETS == 2 ? NMAX : 1];
+        // (ZT: the arithmetic type of the register tile -- T, or float64 for float32 worlds in the ARB_ELIM_F64 experiment)
+        constexpr bool ELIM64 = (ARB_ELIM_F64 != 0) && std::is_same<T, float>::value && NMAX <= 48 && CM != 1;
+        using ZT = std::conditional_t<ELIM64, double, T>;
+        ZT Z[NMAX];
+        ZT Z2[NSETS == 2 ? NMAX : 1];
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) Z[i] = T(0);
+        for (int i = 0; i < NMAX; ++i) Z[i] = ZT(0);
         T rhsM = T(0), rhsG = T(0);
         // ---- composite assembly ---------------------------------------------------------------------
         // With X_k = Ad(g<-body(k)) S_k the column of dof k in WORLD axes (about the root body's
@@ -2155,10 +2196,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                                 td += pq.x * Xk[2 * j] + pq.y * Xk[2 * j + 1] + rq.x * dXk[2 * j] + rq.y * dXk[2 * j + 1];
                             }
                         }
-                        const T val = (T)((i <= e_k) ? tu : td);
-                        Z[i] = (((i < 32 ? rel_lo : rel_hi) >> (i & 31)) & 1u) ? val : T(0);
+                        const ZT val = (ZT)((i <= e_k) ? tu : td);
+                        Z[i] = (((i < 32 ? rel_lo : rel_hi) >> (i & 31)) & 1u) ? val : ZT(0);
                     } else {
-                        Z[i] = T(0);
+                        Z[i] = ZT(0);
                     }
                 }
             }
@@ -2231,7 +2272,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         T rhs = rhsM + ext_k;          // gforce - (N + B + Z_pd) gvel
         if (pwd.kp != nullptr) {
             // per-world diagonal gains and targets (arb_step_ex): tau0 = kp (qdes - q) + kd dqdes, Z += dt kp + kd
-            if (lane < n) {
+            if (lane < n && !lane_dead) {
                 const T kp = pwd.kp[w * n + lane], kd = pwd.kd[w * n + lane];
                 const T acc = kp * (pwd.qdes[w * n + lane] - qd[lane]) + kd * pwd.dqdes[w * n + lane];
                 const T zd = dt * kp + kd;
@@ -2242,13 +2283,16 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     for (int i = 0; i < NMAX; ++i) Z[i] += (i == lane) ? zd : T(0);
                 }
             }
-        } else if (mp->has_pd && lane < n) {
+        } else if (mp->has_pd && lane < n && !lane_dead) {
             // model gains (controllers.py:141-158); per-world targets replace the model's tau0 when given
             T acc = (pwd.qdes != nullptr) ? T(0) : mp->pd_tau0[lane], accv = T(0);
             for (int i = 0; i < n; ++i) {
                 const T kp = mp->pd_kp[lane * n + i], kd = mp->pd_kd[lane * n + i];
-                if (pwd.qdes != nullptr) acc += kp * (pwd.qdes[w * n + i] - qd[i]) + kd * pwd.dqdes[w * n + i];
-                else acc -= kp * qd[i];
+                if (pwd.qdes != nullptr) {
+                    // (block-diagonal gains: the targets of another copy meet exact zeros -- which a NaN target of a
+                    // retired copy would turn into NaN: kp = kd = 0 means no term)
+                    if (kp != T(0) || kd != T(0)) acc += kp * (pwd.qdes[w * n + i] - qd[i]) + kd * pwd.dqdes[w * n + i];
+                } else acc -= kp * qd[i];
                 accv += (dt * kp + kd) * dqs[i];
             }
             gf0 += acc;
@@ -2267,7 +2311,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         if (MODE == 1) {
             if (dbg.Zout != nullptr && lane < n) {
 #pragma unroll
-                for (int i = 0; i < NMAX; ++i) if (i < n) dbg.Zout[(w * n + i) * n + lane] = Z[i];
+                for (int i = 0; i < NMAX; ++i) if (i < n) dbg.Zout[(w * n + i) * n + lane] = (T)Z[i];
             }
             if (zmode != 0) return;
             if (dbg.gforce0 != nullptr && lane < n) dbg.gforce0[w * n + lane] = gf0;
@@ -2409,8 +2453,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         // is rotated one row per step so that the pivot row always sits in
         // Z[NMAX-1] and every index below is a compile-time constant.
         for (int j = n; j < NMAX; ++j) {           // bring row n-1 into Z[NMAX-1]
-            const T t = Z[NMAX - 1];
-            T t2 = T(0);
+            const ZT t = Z[NMAX - 1];
+            ZT t2 = ZT(0);
             if (NSETS == 2) t2 = Z2[NMAX - 1];
 #pragma unroll
             for (int r = NMAX - 1; r >= 1; --r) { Z[r] = Z[r - 1]; if (NSETS == 2) Z2[r] = Z2[r - 1]; }
@@ -2430,10 +2474,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             }
         }
         for (int j = n - 1; j >= 0; --j) {
-            const T piv = bcast(Z[NMAX - 1], j);
-            const T ip = arb_rcp(piv);
-            const T t = Z[NMAX - 1] * ip;
-            T t2 = T(0);
+            const ZT piv = bcast(Z[NMAX - 1], j);
+            const ZT ip = arb_rcp(piv);
+            const ZT t = Z[NMAX - 1] * ip;
+            ZT t2 = ZT(0);
             if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
             // multipliers in groups of 8 broadcasts: the v_readlane -> SGPR -> v_fma wait states of one row are
             // filled by the broadcasts of the next rows instead of s_nop
@@ -2443,7 +2487,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             constexpr int GB = ARB_PIVOT_GB;
 #pragma unroll
             for (int r0 = NMAX - 1; r0 >= 1; r0 -= GB) {
-                T f[GB];
+                ZT f[GB];
 #pragma unroll
                 for (int k = 0; k < GB; ++k) if (r0 - k >= 1) f[k] = bcast(Z[r0 - k - 1], j);
                 asm volatile("" ::: "memory");
@@ -2481,7 +2525,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     const V4 v = d4[i4];
-                    const T s0 = Z[4 * i4] + v.x, s1 = Z[4 * i4 + 1] + v.y, s2 = Z[4 * i4 + 2] + v.z, s3 = Z[4 * i4 + 3] + v.w;
+                    const ZT s0 = Z[4 * i4] + v.x, s1 = Z[4 * i4 + 1] + v.y, s2 = Z[4 * i4 + 2] + v.z, s3 = Z[4 * i4 + 3] + v.w;
                     Z[4 * i4] = mine ? s0 : Z[4 * i4]; Z[4 * i4 + 1] = mine ? s1 : Z[4 * i4 + 1];
                     Z[4 * i4 + 2] = mine ? s2 : Z[4 * i4 + 2]; Z[4 * i4 + 3] = mine ? s3 : Z[4 * i4 + 3];
                 }
@@ -2490,7 +2534,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
                     for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                         const V4 v = d4[i4];
-                        const T s0 = Z2[4 * i4] + v.x, s1 = Z2[4 * i4 + 1] + v.y, s2 = Z2[4 * i4 + 2] + v.z, s3 = Z2[4 * i4 + 3] + v.w;
+                        const ZT s0 = Z2[4 * i4] + v.x, s1 = Z2[4 * i4 + 1] + v.y, s2 = Z2[4 * i4 + 2] + v.z, s3 = Z2[4 * i4 + 3] + v.w;
                         Z2[4 * i4] = mine2 ? s0 : Z2[4 * i4]; Z2[4 * i4 + 1] = mine2 ? s1 : Z2[4 * i4 + 1];
                         Z2[4 * i4 + 2] = mine2 ? s2 : Z2[4 * i4 + 2]; Z2[4 * i4 + 3] = mine2 ? s3 : Z2[4 * i4 + 3];
                     }
@@ -2522,7 +2566,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // [v | Y'] = J' [Y rhs | Y J'^T]                                core.py:925-927
             typedef T V4 __attribute__((ext_vector_type(4)));
 #if ARB_PHASE_D_MFMA
-            if constexpr (std::is_same<T, float>::value) {
+            if constexpr (std::is_same<T, float>::value && !ELIM64) {
                 // On the matrix cores (float32): the four rows of one constraint are the four accumulator registers of
                 // a v_mfma_f32_4x4x1_16b_f32 slab, the 64 lanes its 64 columns (B operand = this lane's entry Z[r] of
                 // the solution column), and the A operand of step r carries J'[4c + lane%4][r] -- read straight from
@@ -2555,8 +2599,20 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                                 qd = __builtin_amdgcn_mfma_f32_4x4x1f32(jv.w, Z2[4 * i4 + 3], qd, 0, 0, 0);
                             }
                         }
-                        acc = (pa + pb) + (pc + pd);
-                        if (NSETS == 2) acc2 = (qa + qb) + (qc + qd);
+                        // (forest worlds: the dofs of copy j start at j * fn, so the partial sum that holds "r mod 4 = 0" of the
+                        // copy's own dofs is accumulator (j * fn) mod 4: added in the order of the copy alone, the sums are
+                        // bit for bit those of one world per wavefront for any fn; round 4)
+                        const int rot = (NMAX <= 32 && !PACK) ? (ARB_UNI(mp->fk) > 1 ? ((c / ARB_UNI(mp->fnc)) * ARB_UNI(mp->fn)) & 3 : 0) : 0;
+                        if (rot == 0) acc = (pa + pb) + (pc + pd);
+                        else if (rot == 1) acc = (pb + pc) + (pd + pa);
+                        else if (rot == 2) acc = (pc + pd) + (pa + pb);
+                        else acc = (pd + pa) + (pb + pc);
+                        if (NSETS == 2) {
+                            if (rot == 0) acc2 = (qa + qb) + (qc + qd);
+                            else if (rot == 1) acc2 = (qb + qc) + (qd + qa);
+                            else if (rot == 2) acc2 = (qc + qd) + (qa + qb);
+                            else acc2 = (qd + qa) + (qb + qc);
+                        }
                     }
                     const float out[4] = {acc.x, acc.y, acc.z, acc.w}, out2[4] = {acc2.x, acc2.y, acc2.z, acc2.w};
 #pragma unroll
@@ -2575,23 +2631,47 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             for (int idx = 0; idx < ndol; ++idx) {
                 // row idx of J' (zero beyond ndof), read as 16/32-byte LDS vectors (wave-uniform address)
                 const V4 *jr4 = reinterpret_cast<const V4 *>(RT + (1 + idx) * RS);
-                T acc = T(0), acc2 = T(0);
+                ZT acc = ZT(0), acc2 = ZT(0);
                 // the rows of a constraint outside the active set are zero (phase B): nothing to multiply
                 // (free fall: the whole loop collapses to the stores)
                 if (CD[(idx >> 2) * CD_STRIDE + CD_ACTIVE] != T(0)) {
+                    // (forest worlds: the groups of four start at the first dof of the constraint's copy, (j * fn) mod 4 = rot
+                    // elements into the row, as they do for the copy alone; what lies before belongs to other copies and is
+                    // exactly zero in this row.  Bit for bit the sums of one world per wavefront; round 4)
+                    const int rot = (NMAX <= 32 && !PACK) ? (ARB_UNI(mp->fk) > 1 ? (((idx >> 2) / ARB_UNI(mp->fnc)) * ARB_UNI(mp->fn)) & 3 : 0) : 0;
+                    if (rot == 0) {
 #pragma unroll
-                    for (int i4 = 0; i4 < NMAX / 4; ++i4) {
-                        const V4 jv = jr4[i4];
-                        acc += jv.x * Z[4 * i4] + jv.y * Z[4 * i4 + 1] + jv.z * Z[4 * i4 + 2] + jv.w * Z[4 * i4 + 3];
-                        if (NSETS == 2)
-                            acc2 += jv.x * Z2[4 * i4] + jv.y * Z2[4 * i4 + 1] + jv.z * Z2[4 * i4 + 2] + jv.w * Z2[4 * i4 + 3];
+                        for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                            const V4 jv = jr4[i4];
+                            acc += jv.x * Z[4 * i4] + jv.y * Z[4 * i4 + 1] + jv.z * Z[4 * i4 + 2] + jv.w * Z[4 * i4 + 3];
+                            if (NSETS == 2)
+                                acc2 += jv.x * Z2[4 * i4] + jv.y * Z2[4 * i4 + 1] + jv.z * Z2[4 * i4 + 2] + jv.w * Z2[4 * i4 + 3];
+                        }
+                    } else {
+                        const T *jr = RT + (1 + idx) * RS;
+                        static_for_asc(std::make_integer_sequence<int, 3>{}, [&](auto rc) {
+                            constexpr int R0 = decltype(rc)::value + 1;
+                            if (rot == R0) {
+#pragma unroll
+                                for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                                    constexpr int NM = NMAX;
+                                    const int r0 = 4 * i4 + R0;
+                                    // (elements past the tile are zero: a copy's dofs end before it)
+                                    const T jx = jr[r0], jy = (r0 + 1 < NM) ? jr[r0 + 1] : T(0), jz = (r0 + 2 < NM) ? jr[r0 + 2] : T(0),
+                                            jw = (r0 + 3 < NM) ? jr[r0 + 3] : T(0);
+                                    const int a = r0, b = (r0 + 1 < NM) ? r0 + 1 : r0, c2 = (r0 + 2 < NM) ? r0 + 2 : r0, d = (r0 + 3 < NM) ? r0 + 3 : r0;
+                                    acc += jx * Z[a] + jy * Z[b] + jz * Z[c2] + jw * Z[d];
+                                    if (NSETS == 2) acc2 += jx * Z2[a] + jy * Z2[b] + jz * Z2[c2] + jw * Z2[d];
+                                }
+                            }
+                        });
                     }
                 }
-                if (lane == n) VV[idx] = acc;
-                else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = acc;
+                if (lane == n) VV[idx] = (T)acc;
+                else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = (T)acc;
                 if (NSETS == 2) {
-                    if (WAVE + lane == n) VV[idx] = acc2;
-                    else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = acc2;
+                    if (WAVE + lane == n) VV[idx] = (T)acc2;
+                    else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = (T)acc2;
                 }
             }
             WAVE_SYNC();
@@ -2607,7 +2687,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     V4 v;
-                    v.x = Z[4 * i4]; v.y = Z[4 * i4 + 1]; v.z = Z[4 * i4 + 2]; v.w = Z[4 * i4 + 3];
+                    v.x = (T)Z[4 * i4]; v.y = (T)Z[4 * i4 + 1]; v.z = (T)Z[4 * i4 + 2]; v.w = (T)Z[4 * i4 + 3];
                     dst[i4] = v;
                 }
             }
@@ -2616,7 +2696,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 #pragma unroll
                 for (int i4 = 0; i4 < NMAX / 4; ++i4) {
                     V4 v;
-                    v.x = Z2[4 * i4]; v.y = Z2[4 * i4 + 1]; v.z = Z2[4 * i4 + 2]; v.w = Z2[4 * i4 + 3];
+                    v.x = (T)Z2[4 * i4]; v.y = (T)Z2[4 * i4 + 1]; v.z = (T)Z2[4 * i4 + 2]; v.w = (T)Z2[4 * i4 + 3];
                     dst[i4] = v;
                 }
             }
@@ -2731,7 +2811,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     // (LDS is reused by the next item: all lanes are past their last LDS access -- one wavefront, program order)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the coherent stores above are performed
     WAVE_SYNC();
-    if (lane0 == 0) __hip_atomic_store(queue + 1 + w, qitem_chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (an atomic max: a flag poisoned by a consumer that gave up waiting for THIS chunk stays poisoned)
+    if (lane0 == 0) (void)__hip_atomic_fetch_max(queue + 1 + w, qitem_chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!QUEUE_LOOP) break;
     }     // work items
 }
@@ -2907,17 +2988,36 @@ hipError_t arb_scratch_alloc(void **p, size_t bytes, hipStream_t st) {
 // development knobs read from the environment at every launch (cheap; they must be changeable between launches of
 // one process): ARB_LDS_PAD = bytes of dynamic LDS added to every step-kernel workgroup (occupancy experiments),
 // ARB_QUEUE_SPIN_CAP = polls after which a wavefront gives up waiting for a chunk (negative: every wait of a later chunk
-// expires at once -- the fault injection of the ARB_ERR_STALLED tests)
+// expires at once -- the fault injection of the ARB_ERR_STALLED tests).  A TEST knob: a small positive cap makes healthy
+// launches report stalls (and skip worlds) whenever a producer is merely slow.
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
-// Wave slots of the chip for a kernel (workgroups of one wavefront): CUs x resident workgroups per CU.
+// Wave slots of a device for one-wavefront workgroups of a kernel that runs `waves_per_simd` wavefronts per SIMD by its
+// registers and asks for `lds_bytes` of LDS: ONE model behind the launch (queue grid, "more units than slots?"), the choice
+// of the build (choose_build) and arb_step_plan.  The 160 KB of a CU are handed out in 128 granules of 1280 B
+// (tools/lds_granule_probe.hip): hipOccupancyMaxActiveBlocksPerMultiprocessor divides 160 KB by the request instead and
+// overestimates between the granule boundaries (twelve wavefronts per CU up to 12 800 B, not 13 653 B), which is why it is
+// not asked.
+static long slots_per_cu(int waves_per_simd, long lds_bytes) {
+    const long by_lds = 128l / std::max(1l, (lds_bytes + 1279) / 1280);
+    return std::max(1l, std::min((long)(4 * waves_per_simd), by_lds));
+}
+// wavefronts per SIMD a compiled kernel runs by its register allocation (512 registers per lane and SIMD, handed out in
+// blocks of eight; at most eight wavefronts)
+template <typename K>
+static int kernel_waves_per_simd(K kern) {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) != hipSuccess || fa.numRegs <= 0) { (void)hipGetLastError(); return 0; }
+    return std::min(8, 512 / (((int)fa.numRegs + 7) / 8 * 8));
+}
 template <typename K>
 static int wave_slots(K kern, size_t lds) {
-    int dev = 0, cus = 0, per_cu = 0;
+    int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WAVE, lds) != hipSuccess) return 0;
-    return cus * per_cu;
+    const int wps = kernel_waves_per_simd(kern);
+    if (wps <= 0) return 0;
+    return (int)(cus * slots_per_cu(wps, (long)lds));
 }
 
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
@@ -3069,11 +3169,16 @@ struct arb_model {
     int forest_k = 1;
 };
 
-// ARB_ERR_STALLED when an earlier launch of the handle raised the status word (host memory: no synchronisation)
-static int take_status(arb_model *M) {
+// ARB_ERR_STALLED when an earlier launch of the handle raised the status word (host memory: no synchronisation).
+// The word is STICKY: the stepping / inspecting entry points only look at it (`clear` false) and refuse to launch while
+// it is raised -- with asynchronous callers the first call to see it is not necessarily one whose status is checked --;
+// arb_model_status alone reads and clears it, which is the caller's acknowledgement.
+static int take_status(arb_model *M, bool clear) {
     if (M->status_host == nullptr) return ARB_OK;
-    int v = __atomic_exchange_n(M->status_host, 0, __ATOMIC_RELAXED);
-    if (M->forest && M->forest->status_host) v |= __atomic_exchange_n(M->forest->status_host, 0, __ATOMIC_RELAXED);
+    int v = clear ? __atomic_exchange_n(M->status_host, 0, __ATOMIC_RELAXED) : __atomic_load_n(M->status_host, __ATOMIC_RELAXED);
+    if (M->forest && M->forest->status_host)
+        v |= clear ? __atomic_exchange_n(M->forest->status_host, 0, __ATOMIC_RELAXED)
+                   : __atomic_load_n(M->forest->status_host, __ATOMIC_RELAXED);
     return v != 0 ? ARB_ERR_STALLED : ARB_OK;
 }
 
@@ -3579,7 +3684,7 @@ extern "C" int arb_model_destroy(arb_model *M) {
 
 extern "C" int arb_model_status(arb_model *M) {
     if (!M) return ARB_ERR_INVALID;
-    return take_status(M);
+    return take_status(M, true);
 }
 
 extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
@@ -3607,9 +3712,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
     const long pad = std::max(0, env_int("ARB_LDS_PAD", 0));
     const long lds2 = (long)M->lf.total * 4 + pad, lds3 = (long)M->lf3.total * 4 + pad;
-    // (wavefronts per CU by LDS: the 160 KB come in 128 granules of 1280 B, tools/lds_granule_probe.hip)
-    auto by_lds = [](long bytes) { return 128l / std::max(1l, (bytes + 1279) / 1280); };
-    const long s2 = (long)cus * std::min(8l, by_lds(lds2)), s3 = (long)cus * std::min(12l, by_lds(lds3));
+    const long s2 = (long)cus * slots_per_cu(2, lds2), s3 = (long)cus * slots_per_cu(3, lds3);
     bc.slots2 = s2; bc.slots3 = s3;
     // Two or three waves per SIMD?  Three when the batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3
     // pin the build; ARB_FORCE_WAVES=2|3 in the environment overrides both (development).
@@ -3634,7 +3737,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     // ARB_FORCE_PACK=0|1 in the environment overrides the batch-size rule (development).
     if (M->packable && noopt && M->lfp.lscan) {
         const long ldsp = (long)M->lfp.total * 4 + pad;
-        const long sp = (long)cus * std::min(8l, by_lds(ldsp));
+        const long sp = (long)cus * slots_per_cu(2, ldsp);
         bc.slotsp = sp;
         // (end of round 3: with its LDS trimmed to the 1280-byte allocation granule the three-wave build really has twelve
         // wavefronts per CU -- eleven until then, whatever the occupancy API said -- and beats the packed build at every
@@ -3818,7 +3921,7 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (nworlds == 0 || nsteps == 0) return ARB_OK;     // empty batch: nothing to do (pointers may be null)
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
-    if (int stalled = take_status(M)) return stalled;
+    if (int stalled = take_status(M, false)) return stalled;
     ARB_GUARD_DEVICE(M->device);
     if (use_forest(M, nworlds, flags, log)) {
         // small worlds share wavefronts: nworlds / k worlds of the forest on the same buffers, the rest one per wavefront
@@ -3857,7 +3960,9 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     if (!M || !out || nworlds < 0 || nsteps < 0 || (dtype != ARB_F32 && dtype != ARB_F64)) return ARB_ERR_INVALID;
     if (flags & ~ARB_STEP_KNOWN_FLAGS) return ARB_ERR_INVALID;
     ARB_GUARD_DEVICE(M->device);
-    if (optional_inputs <= 3 && use_forest(M, nworlds, flags, nullptr)) {
+    const bool world_logs = (optional_inputs & 4) != 0;      // per-world energies, or state logs of a ragged batch: no forest
+    optional_inputs &= 3;
+    if (!world_logs && use_forest(M, nworlds, flags, nullptr)) {
         const int rc = arb_step_plan(M->forest, dtype, nworlds / M->forest_k, nsteps, flags | ARB_STEP_ONE_WORLD, optional_inputs, out);
         if (rc == ARB_OK) out->worlds_per_wavefront = M->forest_k;
         return rc;
@@ -3876,8 +3981,7 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     out->lds_bytes = L.total * (dtype == ARB_F64 ? 8 : 4);
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device);
-    const long per_cu = std::min((long)(4 * out->waves_per_simd), 128l / std::max(1l, ((long)out->lds_bytes + 1279) / 1280));
-    out->wave_slots = (int32_t)(cus * per_cu);                    // (an estimate: the launch asks the occupancy API)
+    out->wave_slots = (int32_t)(cus * slots_per_cu(out->waves_per_simd, (long)out->lds_bytes + std::max(0, env_int("ARB_LDS_PAD", 0))));   // (the launch's own model: slots_per_cu)
     const long units = bc.pack ? (nworlds + 1) / 2 : nworlds;
     out->work_queue = (!split && nsteps >= 2 && !(flags & ARB_STEP_STATIC_WORLDS) && units > out->wave_slots &&
                        env_int("ARB_QUEUE_CHUNK", 4) > 0) ? 1 : 0;
@@ -3939,7 +4043,7 @@ extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *d
     if (nworlds == 0) return ARB_OK;
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
-    if (int stalled = take_status(M)) return stalled;
+    if (int stalled = take_status(M, false)) return stalled;
     ARB_GUARD_DEVICE(M->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32)

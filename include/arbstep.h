@@ -124,12 +124,14 @@ enum {
                                          wavefront) once nw exceeds twice the wave slots of the device (4096 on an MI355X).  The copies share nothing but
                                          ground, gravity and dt: the augmented system is block diagonal and products with the
                                          exact zeros between the blocks change nothing, every tree is assembled about its own
-                                         root -- results are bit-identical to one world per wavefront for models without constraints, and within a
-                                         few ulps with constraints (the constraint-space products sum the dofs in groups of four;
-                                         tests/test_gpu_forest.py, test_gpu_random_models.py).
-                                         A copy whose state is not finite, or beyond +-1e8 (float32) / 1e100, at the beginning
-                                         of a step is retired: NaN in its state, forces and logs from then on, its neighbours
-                                         untouched (a NaN in a user torque or PD input of one copy is NOT contained).  Launches
+                                         root, and the constraint-space products add a copy's dofs in the groups of four they
+                                         form in the copy alone (round 4) -- results are bit-identical to one world per
+                                         wavefront, with or without constraints, whatever the batch size and a world's place
+                                         in the batch (tests/test_gpu_forest.py, test_gpu_random_models.py).
+                                         The one difference: a copy whose state or per-world inputs (user torques, PD targets
+                                         and gains) are not finite, or beyond +-1e8 (float32) / 1e100, at the beginning of a
+                                         step is retired: NaN in its state, forces and logs from then on, its inputs ignored,
+                                         its neighbours untouched; one world per wavefront keeps stepping such a world.  Launches
                                          that log energies (per world) or that log states for a batch that is not a multiple of
                                          k run one world per wavefront. */
 #define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u)
@@ -254,7 +256,11 @@ int arb_model_get_info(const arb_model *m, arb_model_info *info);
  *   wave_slots is an estimate from the registers of the build and the 1280-byte granule in which a CU's 160 KB of LDS are
  *   handed out (hipOccupancyMaxActiveBlocksPerMultiprocessor divides 160 KB by the request and overestimates: twelve
  *   wavefronts per CU fit up to 12 800 B each, not 13 653 B).
- *   optional_inputs: 0 = none, 1 = ext_gforce only, 3 = per-world PD inputs / logs / dt_steps
+ *   optional_inputs: 0 = none, 1 = ext_gforce only, 3 = per-world PD inputs / logs / dt_steps; + 4 = the launch logs
+ *   per-world energies, or states for a batch that is not a multiple of the forest's copies (such launches of a small
+ *   model run one world per wavefront: without the bit the plan describes arb_step / arb_step_ex without those logs)
+ *   wave_slots comes from the model the launch itself uses (wavefronts per SIMD by the build's registers, LDS by the
+ *   1280-byte granule), so `work_queue` is what the launch does.
  */
 typedef struct arb_step_plan_info {
     int32_t waves_per_simd;        /* register budget the chosen build was compiled for: 1, 2 or 3 */
@@ -262,7 +268,7 @@ typedef struct arb_step_plan_info {
                                       then describe the launch of the forest) */
     int32_t feat;                  /* optional-input set of the kernel instantiation: 0, 1 or 3 */
     int32_t lds_bytes;             /* dynamic LDS per wavefront */
-    int32_t wave_slots;            /* resident wavefronts of that build on the device (estimate) */
+    int32_t wave_slots;            /* resident wavefronts of that build on the device */
     int32_t work_queue;            /* 1: the resident wavefronts draw (chunk of steps, world or pair) items from a device-side queue */
 } arb_step_plan_info;
 int arb_step_plan(arb_model *m, int dtype, int64_t nworlds, int32_t nsteps, uint32_t flags, int32_t optional_inputs,
@@ -272,10 +278,15 @@ int arb_step_plan(arb_model *m, int dtype, int64_t nworlds, int32_t nsteps, uint
  * Health of the handle's launches.  The device-side work queue of multi-step launches orders the chunks of a world
  * through a flag per world; a wavefront that waits for a flag longer than ~10 s (a stalled producer: a debugger, a
  * preempted queue, counter collection that serialises workgroups) gives up, does NOT advance or publish its item and
- * raises a status word in host-visible memory.  arb_model_status returns ARB_OK or ARB_ERR_STALLED and clears the
- * word; it reads host memory only (no synchronisation: call it after synchronising the stream to learn about the
- * launches queued so far).  Every arb_step / arb_step_ex / arb_rollout / arb_inspect call makes the same check on entry
- * and returns ARB_ERR_STALLED instead of launching when an earlier launch of the handle stalled.
+ * raises a status word in host-visible memory; the world's flag stays poisoned for the rest of that launch, so none of
+ * its later chunks runs (or waits) either.  arb_model_status returns ARB_OK or ARB_ERR_STALLED and CLEARS the word: it
+ * is the caller's acknowledgement, and the only call that clears.  It reads host memory only (no synchronisation: call
+ * it after synchronising the stream to learn about the launches queued so far).  Every arb_step / arb_step_ex /
+ * arb_rollout / arb_inspect call looks at the word on entry and returns ARB_ERR_STALLED instead of launching for as
+ * long as it is raised (sticky since round 4: with asynchronous callers the first call to notice a stall is not
+ * necessarily one whose status is checked; up to ABI 5.0 that call cleared the word and the next one ran on the invalid
+ * state with ARB_OK).  The states of the stalled launch are invalid: reload them before stepping on.
+ * (ARB_QUEUE_SPIN_CAP in the environment, the number of polls of that wait, is the tests' fault injection only.)
  */
 int arb_model_status(arb_model *m);
 

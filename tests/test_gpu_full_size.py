@@ -27,7 +27,7 @@ import pytest
 
 import arb_oracle as O
 from conftest import load_model, oracle_sensitivity
-from parity_tools import explain_outlier, ill_conditioned, world_err
+from parity_tools import check_replay, replay_errors, world_err
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -50,39 +50,9 @@ def bws():
         bw.close()
 
 
-def replay_errors(m, log_q, log_dq, steps, worlds, dt, with_index=False):
-    """Oracle step from the device's own logged state at `steps` for `worlds`; returns the per-world
-    errors of q and dq against the device's next logged state, stacked over the steps (and, with
-    `with_index`, the (step, world) pair of every entry)."""
-    eq, edq, idx = [], [], []
-    for k in steps:
-        q = log_q[k][worlds].double().cpu().numpy()
-        dq = log_dq[k][worlds].double().cpu().numpy()
-        oq, odq, _ = O.step(m, q, dq, dt)
-        eq.append(world_err(log_q[k + 1][worlds].cpu().numpy(), oq))
-        edq.append(world_err(log_dq[k + 1][worlds].cpu().numpy(), odq))
-        idx += [(k, int(w)) for w in worlds]
-    if with_index:
-        return np.concatenate(eq), np.concatenate(edq), idx
-    return np.concatenate(eq), np.concatenate(edq)
-
-
-def check_replay(bw, m, log, steps, worlds, dt, min_ok=0.995, max_outlier=1e-3):
-    eq, edq, idx = replay_errors(m, log["q"], log["dq"], steps, worlds, dt, with_index=True)
-    ok = (eq < F32_TOL) & (edq < F32_TOL)
-    assert ok.mean() >= min_ok, (ok.mean(), eq.max(), edq.max())
-    for i in np.flatnonzero(~ok):
-        k, w = idx[i]
-        qk, dqk = log["q"][k][w].cpu().numpy(), log["dq"][k][w].cpu().numpy()
-        why = explain_outlier(bw, m, qk, dqk, dt)
-        if why is None:
-            # same decisions everywhere: only acceptable when the step itself is that ill-conditioned -- the float64 oracle
-            # moves by at least the observed error under a one-ulp (float32) input change
-            why = ill_conditioned(m, qk, dqk, dt, eq[i], edq[i], cap=max_outlier)
-        assert why is not None, "unexplained outlier: step %d world %d, err q %.2e dq %.2e" % (k, w, eq[i], edq[i])
-        assert eq[i] < max_outlier and edq[i] < 10 * max_outlier, (k, w, eq[i], edq[i], why)
-        print("outlier step %d world %d: err q %.2e dq %.2e -- %s" % (k, w, eq[i], edq[i], why))
-    return ok.mean(), float(eq.max()), float(edq.max())
+def _report(tag, r):
+    print("%s replay: %d world-steps, ok %.4f, max err q %.2e dq %.2e, outliers by criterion %s, above the cap %d"
+          % (tag, r["n"], r["ok"], r["max_q"], r["max_dq"], r["criteria"], len(r["over_cap"])))
 
 
 # ---------------------------------------------------------------------------
@@ -127,7 +97,7 @@ def test_config3_falling_episode_4096(bws):
     assert float(cf[:, :, 3].max()) > 10.
     # replay of sampled (step, world) pairs through the oracle: free fall, first impacts, sliding
     worlds = np.arange(5, B, 64)                                    # 64 worlds x 13 steps = 832 world-steps
-    print("config 3 replay: ok %.4f, max err q %.2e dq %.2e" % check_replay(bw, m, log, range(0, 39, 3), worlds, dt))
+    _report("config 3", check_replay(bw, m, log, range(0, 39, 3), worlds, dt))
     # batch-position / batch-size independence over the whole episode, bitwise
     # (the library picks the float32 kernel build -- two or three waves per SIMD -- by batch size; the builds are
     # bit-identical, the pin below is belt and braces)
@@ -160,16 +130,16 @@ def test_config4_snake64_16384(bws):
     B, dt = 16384, 1e-3
     q, dq = synth.random_states(m, B, seed=0, angle=0.5, vel=1.0)
     tq, tdq = bw.to_device(q, dq, torch.float64)
-    log = bw.rollout(tq, tdq, dt, 3, log_energy=False)
+    log = bw.rollout(tq, tdq, dt, 4, log_energy=False)
     torch.cuda.synchronize()
     assert torch.isfinite(tq).all() and torch.isfinite(tdq).all()
-    worlds = np.arange(0, B, 2048)                                  # 8 worlds (the oracle inverts 64x64 matrices)
-    eq, edq = replay_errors(m, log["q"], log["dq"], (0, 1), worlds, dt)
+    worlds = np.arange(0, B, 256)                                   # 64 worlds x 3 steps (the oracle inverts 64x64 matrices)
+    eq, edq = replay_errors(m, log["q"], log["dq"], (0, 1, 2), worlds, dt)
     # cond(Z) ~ 3e8: the reference's explicit inverse is itself only good to ~3e-6
     assert eq.max() < F32_TOL and edq.max() < F32_TOL, (eq.max(), edq.max())
     sub = np.arange(1, B, 1111)
     sq, sdq = bw.to_device(q[sub], dq[sub], torch.float64)
-    bw.step(sq, sdq, dt, 3)
+    bw.step(sq, sdq, dt, 4)
     torch.cuda.synchronize()
     assert torch.equal(sq, tq[sub]) and torch.equal(sdq, tdq[sub])
 
@@ -190,14 +160,60 @@ def test_config5_65536_worlds_32_steps(bws, name):
     torch.cuda.synchronize()
     assert torch.isfinite(tq).all() and torch.isfinite(tdq).all() and torch.isfinite(cf).all()
     worlds = np.arange(17, B, 1024)                                 # 64 worlds x 6 steps = 384 world-steps
-    print("config 5 (%s) replay: ok %.4f, max err q %.2e dq %.2e"
-          % ((name,) + check_replay(bw, m, log, (0, 5, 9, 16, 24, 30), worlds, dt)))
+    _report("config 5 (%s)" % name, check_replay(bw, m, log, (0, 5, 9, 16, 24, 30), worlds, dt, de_cap=4e-3 if m.nc > 4 else None))
     # batch-position independence at this size, first step, bitwise
     sub = np.arange(11, B, 997)
     sq, sdq = bw.to_device(q[sub], dq[sub], torch.float32)
     bw.step(sq, sdq, dt, 1, cforce=bw.new_cforce(len(sub), torch.float32), waves=3)      # (ignored by the 8-contact model: one build)
     torch.cuda.synchronize()
     assert torch.equal(sq, log["q"][1][sub]) and torch.equal(sdq, log["dq"][1][sub])
+
+
+@pytest.mark.parametrize("name,stride", [("human36_c4", 16), ("human36_c8", 16)])
+def test_replay_10k_world_steps_every_outlier_adjudicated(bws, name, stride):
+    """The adjudication at scale, inside the suite the driver runs (round 4): every step of the 40-step episode x every
+    16th world of the 4096-world headline batch = 256 x 39 = 9984 world-steps, with the 4 contacts of the headline and
+    with the reference's own 8 (tests/test_human36_falling.py:32).  Measured (profiles/r04_replay_stats.txt): 99.9 % /
+    99.6 % within 1e-5; every world-step above is adjudicated by parity_tools.explain_outlier, none unexplained; the
+    world-steps above the cap (1e-3 in q, 1e-2 in dq) are decision differences that a criterion on the ORACLE's side
+    explains, printed one by one."""
+    from arboris_python_amd import synth
+    bw, m = bws(name)
+    B, T, dt = 4096, 40, 5e-3
+    q, dq = synth.standing_states(m, B, seed=1000, drop=0.03, vel=0.1)
+    tq, tdq = bw.to_device(q, dq, torch.float32)
+    log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False)
+    torch.cuda.synchronize()
+    worlds = np.arange(3, B, stride)
+    r = check_replay(bw, m, log, range(0, 39), worlds, dt, verbose=False, de_cap=4e-3 if m.nc > 4 else None)
+    _report("%s, %d world-steps" % (name, r["n"]), r)
+    assert r["n"] >= 9984
+
+
+def test_config5_mpc_shape_against_the_oracle(bws):
+    """The MPC shape against the ORACLE (round 4; until then the device was only compared with itself): 64 of the 2048
+    rollouts x the 32 steps of the horizon, per-rollout user torques, replayed step by step through
+    O.step(..., ext_gforce): >= 99.5 % of the 2048 world-steps within 1e-5, the others decision differences (below 1e-2;
+    the torques are small against the contact forces, so the statistics are those of config 3)."""
+    from arboris_python_amd import synth
+    bw, m = bws("human36_c4")
+    B, T, dt = 2048, 32, 5e-3
+    q, dq = synth.standing_states(m, B, seed=9, drop=0.03, vel=0.1)
+    rng = np.random.default_rng(9)
+    tau_h = rng.uniform(-0.05, 0.05, size=(B, m.ndof))
+    tau_h[:, :6] = 0.
+    tau = torch.as_tensor(tau_h, dtype=torch.float32, device=bw.device).contiguous()
+    tq, tdq = bw.to_device(q, dq, torch.float32)
+    log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), ext_gforce=tau, log_energy=False)
+    torch.cuda.synchronize()
+    worlds = np.arange(7, B, 32)
+    eq, edq = replay_errors(m, log["q"], log["dq"], range(0, T - 1), worlds, dt, ext=tau.double().cpu().numpy())
+    ok = (eq < F32_TOL) & (edq < F32_TOL)
+    print("MPC shape vs oracle: %d world-steps, ok %.4f, max err q %.2e dq %.2e" % (len(ok), ok.mean(), eq.max(), edq.max()))
+    assert ok.mean() >= 0.995 and eq.max() < 1e-2 and edq.max() < 1e-1
+    # the torques are in the oracle's step: without them it is 1e-4 off on the first step
+    eq0, edq0 = replay_errors(m, log["q"], log["dq"], (0,), worlds, dt)
+    assert edq0.max() > 10 * F32_TOL
 
 
 def test_config5_mpc_2048_rollouts_x_32_step_horizon(bws):

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import arb_oracle as O
+from parity_tools import explain_outlier, ill_conditioned
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -117,9 +118,25 @@ def test_random_model_single_steps(seed):
     e32 = np.maximum(np.abs(sq.cpu().numpy() - oq32).max(axis=1) / np.maximum(1., np.abs(oq32).max(axis=1)),
                      np.abs(sdq.cpu().numpy() - odq32).max(axis=1) / np.maximum(1., np.abs(odq32).max(axis=1)))
     assert np.isfinite(e32[ok32]).all() and e32[ok32].max() < 1e-3, (seed, e32[ok32])
+    # Every world over the 1e-5 gate is adjudicated (round 4; until then: "70 % of the calm worlds below 1e-5"): a decision
+    # of a SoftFingerContact solve that differs from the oracle's and is marginal for the oracle (parity_tools criteria
+    # a-e), or identical decisions in a step so ill-conditioned that the float64 oracle itself moves by at least the
+    # error under a one-ulp (float32) input change.  (BallAndSocket rows have no decision; the clamp decision of a
+    # JointLimits solve is not in the device's trace -- code 4 -- nor in the oracle's, so a world whose only difference
+    # is that clamp has to pass the conditioning test.)  Worlds torn towards a violated loop closure (|dq+| of 1e2 ... 1e3
+    # rad/s) are held to 1e-3 as before, the calm ones to 1e-4.
     calm = ok32 & (np.abs(odq32).max(axis=1) < 30.)       # worlds that are not being torn towards a violated loop closure
-    if calm.sum() >= 3:
-        assert e32[calm].max() < 1e-4 and (e32[calm] < 1e-5).mean() >= 0.7, (seed, e32[calm])
+    if calm.any():
+        assert e32[calm].max() < 1e-4, (seed, e32[calm])
+    eq32 = np.abs(sq.cpu().numpy() - oq32).max(axis=1) / np.maximum(1., np.abs(oq32).max(axis=1))
+    edq32 = np.abs(sdq.cpu().numpy() - odq32).max(axis=1) / np.maximum(1., np.abs(odq32).max(axis=1))
+    for wi in np.flatnonzero(calm & (e32 >= 1e-5)):
+        qw, dqw = np.asarray(q[wi], np.float32), np.asarray(dq[wi], np.float32)
+        why = explain_outlier(bw, m, qw, dqw, dt) if m.nc else None
+        if why is None:
+            why = ill_conditioned(m, qw, dqw, dt, eq32[wi], edq32[wi], cap=1e-4)
+        assert why is not None, "seed %d world %d: float32 error q %.2e dq %.2e unexplained" % (seed, wi, eq32[wi], edq32[wi])
+        print("seed %d world %d over the gate (q %.2e dq %.2e) [%s]: %s" % (seed, wi, eq32[wi], edq32[wi], why.criterion, why))
     # a multi-step launch of more worlds than wave slots goes through the work queue (whatever register tile the
     # model selects): bit-identical to one workgroup per world
     reps = -(-5000 // B)
@@ -150,14 +167,9 @@ def test_random_model_single_steps(seed):
             lim = 1e8 if dtype == torch.float32 else 1e100
             fin = np.all(np.abs(res[0][0]) < lim, axis=1) & np.all(np.abs(res[0][1]) < lim, axis=1) & np.all(np.abs(res[0][2]) < lim, axis=1)
             assert fin.sum() >= len(qb) // 6
-            # (bit for bit when the model has no constraints or ndof is a multiple of four; otherwise to a few ulps: the
-            # constraint-space products of phase D sum over the dof index in groups of four, and copy j's dofs start at
-            # j * ndof.  Forces are (mass / dt) x velocity differences: 1e3 x the tolerance)
+            # (bit for bit, with or without constraints: since round 4 the constraint-space products of phase D add a copy's
+            # dofs in the groups of four they form in the copy alone -- until then models with constraints and ndof % 4 != 0
+            # agreed to a few ulps only)
             for k, (a1, af) in enumerate(zip(res[0], res[1])):
-                if m.nc == 0 or m.ndof % 4 == 0:
-                    assert np.array_equal(a1[fin], af[fin]), (seed, dtype, bw.info["forest_copies"])
-                else:
-                    err = np.abs(a1[fin] - af[fin]).max(axis=1) / np.maximum(1., np.abs(a1[fin]).max(axis=1))
-                    tol = (2e-5 if dtype == torch.float32 else 1e-11) * (1e3 if k == 2 else 1.)
-                    assert err.max() < tol, (seed, dtype, bw.info["forest_copies"], k, err.max())
+                assert np.array_equal(a1[fin], af[fin]), (seed, dtype, bw.info["forest_copies"], k)
     bw.close()

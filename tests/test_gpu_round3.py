@@ -127,10 +127,16 @@ def test_queue_stall_is_reported(monkeypatch):
     torch.cuda.synchronize()
     monkeypatch.delenv("ARB_QUEUE_SPIN_CAP")
     before = sq.clone()
+    for _ in range(2):                                   # the word is sticky: EVERY call fails until it is acknowledged
+        with pytest.raises(_capi.ArbError):
+            bw.step(sq, sdq, dt, 1, cforce=scf)
+        torch.cuda.synchronize()
+        assert torch.equal(sq, before)
     with pytest.raises(_capi.ArbError):
-        bw.step(sq, sdq, dt, 1, cforce=scf)
-    torch.cuda.synchronize()
-    assert torch.equal(sq, before)
+        bw.inspect(sq[:4], sdq[:4], dt, ["q_next"], cforce=scf[:4])
+    with pytest.raises(_capi.ArbError):
+        bw.status()                                      # the acknowledgement (arb_model_status reads and clears)
+    bw.status()
     # and the handle works again afterwards, bit for bit
     rq, rdq = bw.to_device(q, dq, torch.float32)
     bw.step(rq, rdq, dt, T, cforce=bw.new_cforce(B, torch.float32))

@@ -2,16 +2,18 @@
 """Error distribution of the float32 fused kernel against the float64 oracle over many (world, step) pairs of
 the falling episode: every sampled state logged by the device is stepped once by the oracle, and every pair over the
 1e-5 gate goes through tests/parity_tools.explain_outlier (a decision difference only counts when the decision was
-marginal for the oracle itself) or the ill-conditioning rule of the tests: explained / unexplained counts are printed.
+marginal for the oracle itself) or the ill-conditioning rule of the tests.  Printed: the share within 1e-5 / 1e-4, the
+outliers PER CRITERION (active, a-e, ill; parity_tools), the share of world-steps explained by (d) / (e), the largest
+system errors (Y', v', the flipped solve's rows) among the cases that reached (d) / (e), the world-steps above the caps of
+the tests (1e-3 in q, 1e-2 in dq) one by one, and the unexplained ones.
 usage (GPU box): python tools/replay_stats.py [seed [world_stride [step_stride [contacts]]]]   (defaults 1000, 16, 3, 4)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT + "/oracle")
 import torch
-import arb_oracle as O
-from conftest import load_model, oracle_sensitivity
-from parity_tools import explain_outlier, ill_conditioned
+from conftest import load_model
+import parity_tools as P
 from arboris_python_amd import synth
 from arboris_python_amd.batch import BatchedWorlds
 arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
@@ -23,29 +25,33 @@ tq, tdq = bw.to_device(q, dq, torch.float32)
 log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False)
 torch.cuda.synchronize()
 worlds = np.arange(0, B, arg(2, 16))     # 256 worlds by default
-errs, reasons, unexplained = [], {}, []
+errs, crit, unexplained, over, diag = [], {}, [], [], dict(e_adm=0., e_vel=0., e_row=0.)
 for k in range(0, T - 1, arg(3, 3)):       # 13 steps by default
-    qk = log["q"][k][worlds].double().cpu().numpy(); dqk = log["dq"][k][worlds].double().cpu().numpy()
-    oq, odq, _ = O.step(m, qk, dqk, dt)
-    g = log["dq"][k + 1][worlds].double().cpu().numpy()
-    gq = log["q"][k + 1][worlds].double().cpu().numpy()
-    e = np.abs(g - odq).max(axis=1) / np.maximum(1., np.abs(odq).max(axis=1))
-    eq = np.abs(gq - oq).max(axis=1) / np.maximum(1., np.abs(oq).max(axis=1))
+    eq, e = P.replay_errors(m, log["q"], log["dq"], (k,), worlds, dt)
     errs.append(np.maximum(e, eq))
     for i in np.flatnonzero((e > 1e-5) | (eq > 1e-5)):
         w = int(worlds[i])
         qf, dqf = log["q"][k][w].cpu().numpy(), log["dq"][k][w].cpu().numpy()
-        why = explain_outlier(bw, m, qf, dqf, dt)
+        why = P.explain_outlier(bw, m, qf, dqf, dt)
+        if why is not None and why.criterion in ("d", "e"):
+            for key in diag:
+                diag[key] = max(diag[key], P.LAST_DIAG.get(key, 0.))
         if why is None:
-            why = ill_conditioned(m, qf, dqf, dt, eq[i], e[i])
-        tag = "UNEXPLAINED" if why is None else why.split(":")[0].split("(")[0].strip()
-        reasons[tag] = reasons.get(tag, 0) + 1
+            why = P.ill_conditioned(m, qf, dqf, dt, eq[i], e[i])
+        tag = "UNEXPLAINED" if why is None else why.criterion
+        crit[tag] = crit.get(tag, 0) + 1
         if why is None:
-            unexplained.append((k, w, float(eq[i]), float(e[i])))
-        print("  outlier step %2d world %4d: err q %.2e dq %.2e -- %s" % (k, w, eq[i], e[i], why))
-    print("step %2d: median %.1e  p99 %.1e  max %.1e  > 1e-5: %d of %d" % (k, np.median(e), np.quantile(e, 0.99), e.max(), int((e > 1e-5).sum()), len(e)))
+            unexplained.append((k, w, float(eq[i]), float(e[i]), dict(P.LAST_DIAG)))
+        if not (eq[i] < 1e-3 and e[i] < 1e-2):
+            over.append((k, w, float(eq[i]), float(e[i]), tag))
+            print("  ABOVE THE CAP step %2d world %4d: err q %.2e dq %.2e [%s] -- %s" % (k, w, eq[i], e[i], tag, why))
     sys.stdout.flush()
 e = np.concatenate(errs)
-print("all: %d pairs, within 1e-5: %.2f %%, within 1e-4: %.2f %%, max %.1e" % (len(e), 100 * (e <= 1e-5).mean(), 100 * (e <= 1e-4).mean(), e.max()))
-print("outliers: %d, by reason: %s" % (int((e > 1e-5).sum()), reasons))
+n = len(e)
+print("all: %d pairs, within 1e-5: %.2f %%, within 1e-4: %.2f %%, max %.1e" % (n, 100 * (e <= 1e-5).mean(), 100 * (e <= 1e-4).mean(), e.max()))
+print("outliers: %d, by criterion: %s" % (int((e > 1e-5).sum()), dict(sorted(crit.items()))))
+de = crit.get("d", 0) + crit.get("e", 0)
+print("criteria (d) + (e): %d = %.4f %% of the world-steps (cap %.2f %%); largest system errors among them: Y' %.1e, v' %.1e, solve rows %.1e"
+      % (de, 100. * de / n, 100 * (4e-3 if m.nc > 4 else P.DE_SHARE_CAP), diag["e_adm"], diag["e_vel"], diag["e_row"]))
+print("above the caps (q 1e-3, dq 1e-2): %d %s" % (len(over), over))
 print("unexplained: %d %s" % (len(unexplained), unexplained[:20]))
