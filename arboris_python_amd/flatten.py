@@ -158,8 +158,9 @@ def replicate_model(m, copies):
     ``k nb ..``, dofs ``k ndof ..``, position scalars ``k nq ..`` and constraints ``k nc ..``, so that a batch of states
     ``(B, nq)`` of ``m`` IS a batch ``(B / copies, copies nq)`` of the forest, without a copy.  The copies share ground,
     gravity and dt and nothing else: the impedance matrix is block diagonal, the Gauss-Seidel sweeps of one copy never
-    see another's forces.  This is how several small worlds share one wavefront (a 3-dof simplearm uses 3 of its 64
-    lanes, five of them 15), see ``BatchedWorlds(..., pack=)``."""
+    see another's forces.  The host-side statement of what the LIBRARY does by itself for small models (``arb_model_create``
+    builds the forest, ``BatchedWorlds.info["forest_copies"]`` says how many copies share a wavefront, ``step(..., one_world=True)``
+    opts out): used by the tests and probes that build a forest by hand."""
     K = int(copies)
     if K < 1:
         raise ValueError("copies must be >= 1")

@@ -119,6 +119,32 @@ print(time.perf_counter() - t0)
 """
 
 
+def usable_cores():
+    """Host cores this process may actually run on: the scheduler affinity mask, capped by the cgroup CPU quota when
+    there is one (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1).  os.cpu_count() reports the machine's
+    hardware threads (256 on the GPU box), of which a one-GPU lease gets a share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:                                   # pragma: no cover
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except Exception:
+        try:
+            qv = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pv = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if qv > 0:
+                quota = qv / pv
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(model, q, dq, dt, budget_s, episode):
     """The NumPy float64 oracle (a port of the reference algorithm) timed on the host:
     one core, then one single-threaded process per core over disjoint world shards
@@ -152,7 +178,8 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
     # all cores: child processes (they never touch the GPU), one BLAS thread each
     try:
         per = 32                                         # worlds per process (the oracle batches its NumPy calls over worlds)
-        ncores = min(os.cpu_count() or 1, 128, q.shape[0] // per)
+        usable, quota = usable_cores()
+        ncores = max(1, min(usable, 128, q.shape[0] // per))
         nsteps = max(2, min(episode, int(budget_s * out["value"] / per)))
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         with tempfile.TemporaryDirectory() as td:
@@ -161,9 +188,14 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
             procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, f, str(r), str(per), str(nsteps), repr(dt)],
                                       stdout=subprocess.PIPE, env=env) for r in range(ncores)]
             times = [float(p.communicate(timeout=600)[0].decode().strip().splitlines()[-1]) for p in procs]
+        rates = sorted(per * nsteps / t for t in times)
         out["all_cores"] = dict(value=per * ncores * nsteps / max(times), unit="world-steps/s", cores=ncores,
-                                sample="%d single-threaded processes x %d worlds x %d steps (stepping loops only, "
-                                       "slowest process)" % (ncores, per, nsteps))
+                                usable_cores=usable, cgroup_cpu_quota=quota, hardware_threads=os.cpu_count(),
+                                per_process_rate={"min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1]},
+                                per_core_vs_single=rates[len(rates) // 2] / out["value"],
+                                sample="%d single-threaded processes (one per usable core: scheduler affinity, capped by the "
+                                       "cgroup CPU quota) x %d worlds x %d steps (stepping loops only, slowest process); the "
+                                       "single-core figure runs 64 worlds per NumPy call, these 32" % (ncores, per, nsteps))
     except Exception as e:                              # pragma: no cover
         out["all_cores"] = dict(value=None, error=repr(e))
     return out
@@ -227,7 +259,7 @@ def make_states(cfg, model, lo, hi, seed):
         return synth.world_states(model, range(lo, hi), "random", seed, angle=0.5, vel=1.0)
     # config 2: random poses, hinge angles U(-0.7, 0.7) rad, velocities U(-1, 1).  (More energetic draws -- angle 1,
     # velocities 3, the generator's defaults -- send the reference's own time stepping beyond 100 rad/s within 40 steps
-    # for 80 % of the worlds, in the float64 oracle as on the device, tools/config2_finite.py: the step's cost does not
+    # for 80 % of the worlds, in the float64 oracle as on the device, tools/experiments/config2_finite.py: the step's cost does not
     # depend on the data, but a benchmark should not integrate garbage.)
     return synth.world_states(model, range(lo, hi), "random", seed, angle=0.7, vel=1.0)
 
@@ -287,6 +319,30 @@ def dry_run(args, cfg):
                           "config": args.config}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000):
+    """One more workload timed like the headline (whole episodes, one launch per episode, states resident in HBM, at least
+    `min_seconds` and 10 launches): world-steps/s, the launch durations from HIP events on the launch stream, the build."""
+    mdl = build_model(cfg)
+    b2 = BatchedWorlds(mdl, local_rank)
+    dt2 = torch.float32 if cfg["dtype"] == "f32" else torch.float64
+    qa, da = make_states(cfg, mdl, 0, cfg["batch"], seed=seed)
+    ta, tb = b2.to_device(qa, da, dt2)
+    ex2 = None
+    if cfg.get("torques"):
+        ex2 = torch.as_tensor(make_torques(mdl, 0, cfg["batch"], seed=2000), dtype=dt2, device=b2.device).contiguous()
+    run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, ext=ex2)
+    cal, _, _ = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, ext=ex2)
+    n_ep = max(10, int(np.ceil(min_seconds / max(cal / 2, 1e-6))))
+    wl, me, (qe, dqe) = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], n_ep, torch, ext=ex2)
+    out = {"workload": cfg["name"] + ", batch %d, %s" % (cfg["batch"], cfg["dtype"]),
+           "value": cfg["batch"] * n_ep * cfg["episode"] / wl, "unit": "world-steps/s",
+           "kernel_ms": float(np.mean(me)), "episodes": n_ep, "steps_per_launch": cfg["episode"], "timed_region_s": wl,
+           "finite": bool(torch.isfinite(qe).all() and torch.isfinite(dqe).all()),
+           "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")))}
+    b2.close()
+    return out
 
 
 def main():
@@ -459,10 +515,9 @@ def main():
                 if res["roofline"]["traffic"] > 20 * handover:
                     res["roofline"]["traffic_note"] += (
                         "  The rest is SCRATCH traffic: at this batch size the library runs the kernel build compiled for three "
-                        "waves per SIMD (168 VGPRs, ~500 spilled registers, none in a loop), whose spill stores and reloads go "
-                        "through the memory hierarchy (%.0f GB/s of the 8000 GB/s roof at this launch duration) -- the price of the "
-                        "third wave, which pays +5.5 %% end to end on this latency-bound kernel (DESIGN.md 3); the two-wave "
-                        "build (ARB_STEP_WAVES2) moves %.1f MB per launch"
+                        "waves per SIMD, which spills registers (tools/so_stats.sh prints the counts of the shipped library; "
+                        "DESIGN.md has the table), and the spill stores and reloads go through the memory hierarchy (%.0f GB/s of "
+                        "the 8000 GB/s roof at this launch duration); the two-wave build (ARB_STEP_WAVES2) moves %.1f MB per launch"
                         % (res["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9, (handover + bytes_per_world_step * B) / 1e6))
                 ws = float(B * EP)
                 simds, clk = 1024, 2.4e9                     # 256 CUs x 4 SIMD-32; peak shader clock
@@ -479,10 +534,23 @@ def main():
                     # sustains), so the issue roof is 1024 SIMDs x 2.4 GHz / 2 wave-instructions per second.
                     "valu_issue_frac": 2. * pm["SQ_INSTS_VALU"]["mean_per_launch"] / (kern_ms * 1e-3 * simds * clk),
                     "valu_issue_frac_note": "SQ_INSTS_VALU x 2 cycles (wave64 on SIMD-32) / (kernel time x 1024 SIMDs x 2.4 GHz): "
-                                            "the profiled launch's wave-instructions against THIS run's kernel time.  Round 2 "
-                                            "reported SQ_ACTIVE_INST_VALU x 4 cycles (0.80): that is the occupancy of a single "
-                                            "wave's issue slot, not of the SIMD's pipe",
+                                            "the profiled launch's wave-instructions against THIS run's kernel time -- every "
+                                            "instruction priced at the float32 datasheet rate; see valu_pipe_frac for the mix",
                     "note": "SQ counters of profiles/%s" % os.path.basename(prof)}
+                mix = pj.get("valu_mix_per_launch")
+                if mix:
+                    # Pipe-weighted (round 4): the dynamic instruction mix of the profiled launch (SQ_INSTS_VALU_{ADD,MUL,FMA,
+                    # TRANS}_F{32,64}) priced with the rates this machine sustains (tools/exec_mask_probe.hip: 2.4 cycles per
+                    # wave64 float32 instruction, 4.3 per float64 one, two or more independent waves per SIMD)
+                    valu["valu_mix_per_world_step"] = {k: mix[k] / ws for k in ("float32", "float64", "other", "total")}
+                    valu["valu_pipe_frac"] = mix["pipe_cycles"] / (kern_ms * 1e-3 * simds * clk)
+                    valu["valu_pipe_frac_note"] = ("(2.4 x (float32 + other) + 4.3 x float64 instructions) / (kernel time x 1024 SIMDs x "
+                                                   "2.4 GHz): the share of the vector pipes' time the launch's instructions occupy. "
+                                                   "'other' = moves, selects, compares, integer, lane exchanges, priced like float32 "
+                                                   "(DPP operands cost 4.2: a lower bound); the shader clock under this load is below "
+                                                   "2.4 GHz (2.0-2.2 measured), so the pipes are busier than the figure says.  The "
+                                                   "rest of the time every resident wave of a SIMD waits: one wave alone issues an "
+                                                   "instruction every 4.7 cycles at best, a dependent one every 8")
                 if "valu_lane_utilisation" in pj:
                     # active lanes per executed VALU instruction: thread-cycles over 64 x instruction-cycles, one pass
                     valu["valu_lane_utilisation"] = pj["valu_lane_utilisation"]
@@ -505,6 +573,25 @@ def main():
         w1, m1, _ = run_episodes(bw, q0, dq0, dt, EP, 5, torch, None, spl=1, split=args.split, ext=ext)
         res["per_step_launch"] = {"value": B * 5 * EP / w1, "unit": "world-steps/s", "kernel_ms": float(np.mean(m1)),
                                   "steps": 5 * EP}
+    if n_gpus == 1 and not args.no_per_step_leg and args.config == 3 and not args.split:
+        # (same switch as the one-launch-per-step leg: the profiling runs skip all of these)
+        # The path that meets 1e-5 on EVERY world-step: the float64 kernels on the headline workload (the float32 kernels
+        # meet it on 99.9 % of the world-steps, the others are decisions that are marginal for the reference itself or
+        # that the float32 elimination moves: profiles/r04_replay_stats.txt)
+        c64 = dict(cfg, dtype="f64")
+        res["strict_f64"] = timed_leg(BatchedWorlds, torch, np, local_rank, c64, 1.0)
+        res["strict_f64"]["tolerance"] = "1e-7 against the float64 reference on every world-step (tests: 1e-9 without contacts)"
+        # the reference's own falling scenario has 8 contact points (tests/test_human36_falling.py:32)
+        c8 = dict(cfg, contacts=8, name=cfg["name"].replace("4 floor", "8 floor") + " -- the reference's own 8 contact points")
+        res["contacts8"] = timed_leg(BatchedWorlds, torch, np, local_rank, c8, 1.0)
+        # The literal MPC shape of BASELINE config 5 -- 2048 rollouts x 32 in-kernel steps, per-rollout torques -- on ONE
+        # GPU: 2048 rollouts are fewer than the 3072 wave slots of one MI355X, every rollout has a wavefront to itself
+        # from the first to the last step, and the horizon costs the latency of one world's 32 steps.  Splitting the
+        # 2048 rollouts over 8 GPUs (256 each, `--config 5 --mpc`) takes just as long per horizon: the shape is latency
+        # bound, not throughput bound, and one GPU is the right place for it.
+        cm = dict(MPC, batch=2048, name=MPC["name"].replace("256 rollouts/GPU = 2048 on 8 GPUs", "all 2048 rollouts on ONE GPU"))
+        res["mpc_2048_rollouts_one_gpu"] = timed_leg(BatchedWorlds, torch, np, local_rank, cm, 0.5)
+        res["mpc_2048_rollouts_one_gpu"]["ms_per_horizon"] = res["mpc_2048_rollouts_one_gpu"]["kernel_ms"]
     if n_gpus == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(model, q, dq, dt, args.cpu_seconds, EP)
         res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
