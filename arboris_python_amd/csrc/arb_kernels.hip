@@ -1048,6 +1048,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     // size always exist, which folds their `i < n` predicates away
     constexpr int NLOW = NMAX == 16 ? 0 : NMAX == 32 ? 16 : NMAX == 44 ? 32 : NMAX == 48 ? 44 : 48;
     constexpr bool LSCAN_OK = NMAX <= 48;      // (the 64-row tiles are register-bound: only the DPP scan is compiled in)
+#ifndef ARB_MFMA_ROWS
+#define ARB_MFMA_ROWS 0          // measured round 4: 1 = rows of Z on the float64 matrix cores: -1.5 % (fewer instructions, more spill reloads and LDS round trips); kept as an experiment
+#endif
+    // the rows of Z as float64 matrix-core products (phase B; float32 worlds on the 44- and 48-row tiles, whose RT space
+    // holds the staging of a tile column; ARB_ELIM_F64 keeps the register tile in float64: the row loop)
+    constexpr bool MFMA_ROWS = (ARB_MFMA_ROWS != 0) && std::is_same<T, float>::value && (NMAX == 44 || NMAX == 48) && !(ARB_ELIM_F64 != 0);
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
     constexpr int BDS = (MODE == 1) ? BD_STRIDE_INSPECT : BD_STRIDE;      // per-body block (the gravity wrench slot: inspect only)
     T dt = dt_in, inv_dt = T(1) / dt_in;
@@ -1845,6 +1851,194 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             const bool use_table = lscan && TWO_PASS;
             WAVE_SYNC();
             // ---- lane = body: world-frame matrices of the body -----------------------------------
+#ifndef ARB_B_STREAM
+#define ARB_B_STREAM 1
+#endif
+            // Small trees (prefix table), round 4: the 36 entries of A_b are produced ROW BY ROW and every row goes straight
+            // into the body's table row -- the 36 float64 accumulators of A never sit in registers beside the 36 of Mg.  The
+            // kernels compiled for three waves per SIMD (168 registers) spent 57 k instead of 17 k cycles in this block and
+            // 35 k instead of 12 k in the dof products that follow (spilled registers reloaded from scratch memory, each
+            // reload waited for: tools/bstamp_probe.py on a -DARB_WAVES_PER_EU=3 build), more than all their other phases lost
+            // together.  With two table passes (those kernels) the block runs TWICE: before the M | rhs pass it forms Mg and
+            // the wrenches, stores them and forgets everything; before the A pass it forms Mg again -- ~250 float64
+            // instructions on the body lanes, against 36 accumulators held in (spilled) registers across the first pass.
+            // Element by element the additions are those of the accumulator version (below: large trees), in the same
+            // order: bit-identical.
+            constexpr int NMR = NACC - TB_PASS1;               // M (upper triangle, 21) | rhs wrench (6) [| gravity wrench (6)]
+            const bool bstream = (ARB_B_STREAM != 0) && lscan;
+            typedef double BD2 __attribute__((ext_vector_type(2)));
+            // Mg = Ad(b<-g)^T M_b Ad(b<-g) of body b (symmetric), 36 entries row-major
+            auto world_G = [&](const M3<double> &R, const V3<double> &p, const T *Mb, double (&G)[36]) {
+                auto blk = [](const T *m6, int r0, int c0) {
+                    M3<double> o;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) o.a[3 * i + j] = (double)m6[6 * (r0 + i) + c0 + j];
+                    return o;
+                };
+                auto rot = [&](const M3<double> &Xm) { return mul(R, mulBT(Xm, R)); };       // R X R^T
+                auto rowcross = [](const M3<double> &Xm, V3<double> v) {                      // X v^
+                    M3<double> o;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const V3<double> c = cross(v3<double>(Xm.a[3 * i], Xm.a[3 * i + 1], Xm.a[3 * i + 2]), v);
+                        o.a[3 * i] = c.x; o.a[3 * i + 1] = c.y; o.a[3 * i + 2] = c.z;
+                    }
+                    return o;
+                };
+                const M3<double> M11 = rot(blk(Mb, 0, 0)), M12 = rot(blk(Mb, 0, 3)), M22 = rot(blk(Mb, 3, 3));
+                const M3<double> G12 = add(M12, hatmul(p, M22));
+                const M3<double> G21 = transpose(G12);
+                const M3<double> G11 = add(sub(M11, rowcross(M12, p)), hatmul(p, G21));
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        G[6 * i + j] = G11.a[3 * i + j]; G[6 * i + 3 + j] = G12.a[3 * i + j];
+                        G[6 * (3 + i) + j] = G21.a[3 * i + j]; G[6 * (3 + i) + 3 + j] = M22.a[3 * i + j];
+                    }
+            };
+            // Bg = Ad^T B_b Ad (viscosity, rare: a general 6x6)
+            auto world_B = [&](const M3<double> &R, const V3<double> &p, const T *Vb, double (&Bv)[36]) {
+                auto blk = [](const T *m6, int r0, int c0) {
+                    M3<double> o;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) o.a[3 * i + j] = (double)m6[6 * (r0 + i) + c0 + j];
+                    return o;
+                };
+                auto rot = [&](const M3<double> &Xm) { return mul(R, mulBT(Xm, R)); };
+                auto rowcross = [](const M3<double> &Xm, V3<double> v) {
+                    M3<double> o;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const V3<double> c = cross(v3<double>(Xm.a[3 * i], Xm.a[3 * i + 1], Xm.a[3 * i + 2]), v);
+                        o.a[3 * i] = c.x; o.a[3 * i + 1] = c.y; o.a[3 * i + 2] = c.z;
+                    }
+                    return o;
+                };
+                const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
+                const M3<double> H12 = add(B12, hatmul(p, B22));
+                const M3<double> H21 = sub(B21, rowcross(B22, p));
+                const M3<double> H11 = add(sub(B11, rowcross(B12, p)), hatmul(p, H21));
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        Bv[6 * i + j] = H11.a[3 * i + j]; Bv[6 * i + 3 + j] = H12.a[3 * i + j];
+                        Bv[6 * (3 + i) + j] = H21.a[3 * i + j]; Bv[6 * (3 + i) + 3 + j] = B22.a[3 * i + j];
+                    }
+            };
+            // M (upper triangle) | rhs wrench [| gravity wrench] of body b into table positions OFFD .. (doubles)
+            auto store_MR = [&](auto offc, const M3<double> &R, const V3<double> &p, const double (&G)[36], BD2 *trow) {
+                constexpr int OFFD = decltype(offc)::value;
+                double wr[NACC - 57];              // world wrench of the increment rhs (6) [| gravity wrench (6), inspect]
+                {   // wrenches to world axes: Ad(b<-g)^T f = (R tau + p x R f, R f)
+                    const V3<double> f = mv(R, v3<double>((double)ptb[3], (double)ptb[4], (double)ptb[5]));
+                    const V3<double> tq = mv(R, v3<double>((double)ptb[0], (double)ptb[1], (double)ptb[2])) + cross(p, f);
+                    wr[0] = tq.x; wr[1] = tq.y; wr[2] = tq.z; wr[3] = f.x; wr[4] = f.y; wr[5] = f.z;
+                }
+                if (MODE == 1) {
+                    const V3<double> f = mv(R, v3<double>((double)pgb[3], (double)pgb[4], (double)pgb[5]));
+                    const V3<double> tq = mv(R, v3<double>((double)pgb[0], (double)pgb[1], (double)pgb[2])) + cross(p, f);
+                    wr[NACC - 63] = tq.x; wr[NACC - 62] = tq.y; wr[NACC - 61] = tq.z; wr[NACC - 60] = f.x; wr[NACC - 59] = f.y; wr[NACC - 58] = f.z;
+                }
+                auto mr_at = [&](int i) -> double {
+                    constexpr int RW[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+                    constexpr int CL[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+                    if (i < 21) return useN ? G[6 * RW[i] + CL[i]] : 0.;
+                    return i < NMR ? wr[i - 21] : 0.;
+                };
+#pragma unroll
+                for (int i2 = 0; i2 < (NMR + 1) / 2; ++i2) { BD2 v; v.x = mr_at(2 * i2); v.y = mr_at(2 * i2 + 1); trow[OFFD / 2 + i2] = v; }
+            };
+            // rows of A_b = Mg/dt - ad(T*)^T Mg + Mg ad(Om) + Bg into table positions 0 .. 35, one row at a time
+            auto store_A = [&](auto hvc, const double *Bv, const M3<double> &R, const V3<double> &p, const T *Mb, const double (&G)[36], BD2 *trow) {
+                constexpr bool HV = decltype(hvc)::value;
+                // T* = [w; c x w] (c = centre of mass, core.py:1276-1288) and Om, both in world axes
+                const V3<double> wb = v3<double>((double)twb[0], (double)twb[1], (double)twb[2]);
+                const double mm = (double)Mb[21];
+                V3<double> cm = v3<double>(0., 0., 0.);
+                if (!(mm <= 1e-10)) cm = (1. / mm) * v3<double>((double)Mb[6 * 2 + 4], (double)Mb[6 * 0 + 5], (double)Mb[6 * 1 + 3]);
+                const V3<double> Tw = mv(R, wb);
+                const V3<double> Tv = mv(R, cross(cm, wb)) + cross(p, Tw);
+                const V3<double> ow = mv(R, v3<double>((double)om_b[0], (double)om_b[1], (double)om_b[2]));
+                const V3<double> ov = mv(R, v3<double>((double)om_b[3], (double)om_b[4], (double)om_b[5])) + cross(p, ow);
+                static_for_asc(std::make_integer_sequence<int, 6>{}, [&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double a[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        a[j] = 0.;
+                        if constexpr (HV) a[j] += Bv[6 * r + j];
+                        a[j] += useM ? cM * G[6 * r + j] : 0.;
+                    }
+                    if (useN) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {                        // -ad(T*)^T Mg: component r of column j
+                            const V3<double> gt = v3<double>(G[j], G[6 + j], G[12 + j]), gb = v3<double>(G[18 + j], G[24 + j], G[30 + j]);
+                            if constexpr (r < 3) {
+                                const V3<double> t = cross(Tw, gt) + cross(Tv, gb);
+                                a[j] += (r == 0) ? t.x : (r == 1) ? t.y : t.z;
+                            } else {
+                                const V3<double> u = cross(Tw, gb);
+                                a[j] += (r == 3) ? u.x : (r == 4) ? u.y : u.z;
+                            }
+                        }
+                        {                                                    // Mg ad(Om): row r
+                            const V3<double> gl = v3<double>(G[6 * r], G[6 * r + 1], G[6 * r + 2]), gr = v3<double>(G[6 * r + 3], G[6 * r + 4], G[6 * r + 5]);
+                            const V3<double> t = cross(gl, ow) + cross(gr, ov), u = cross(gr, ow);
+                            a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += u.x; a[4] += u.y; a[5] += u.z;
+                        }
+                    }
+                    BD2 v0, v1, v2;
+                    v0.x = a[0]; v0.y = a[1]; v1.x = a[2]; v1.y = a[3]; v2.x = a[4]; v2.y = a[5];
+                    trow[3 * r] = v0; trow[3 * r + 1] = v1; trow[3 * r + 2] = v2;
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);               // (row by row: interleaved rows bring the 36 accumulators back)
+                });
+            };
+            // the A part of a body's table row (viscosity, rare, is a code path of its own: its 36 values cost the usual path
+            // no registers)
+            auto body_A = [&]() {
+                const int b = lane;
+                const M3<double> R = ld_m3(PD + 12 * b);
+                const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);      // about its tree's root
+                const T *Mb = mp->mass + 36 * b;
+                BD2 *trow = reinterpret_cast<BD2 *>(STG + TBS * b);
+                if (mp->has_visc && useB) {
+                    double Bv[36], G[36];
+                    world_B(R, p, mp->visc + 36 * b, Bv);
+                    world_G(R, p, Mb, G);
+                    store_A(std::true_type{}, Bv, R, p, Mb, G, trow);
+                } else {
+                    double G[36];
+                    world_G(R, p, Mb, G);
+                    store_A(std::false_type{}, nullptr, R, p, Mb, G, trow);
+                }
+            };
+            if (bstream) {
+                if (lane < nb) {
+                    const int b = lane;
+                    BD2 *trow = reinterpret_cast<BD2 *>(STG + TBS * b);
+                    {
+                        const M3<double> R = ld_m3(PD + 12 * b);
+                        const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);
+                        double G[36];
+                        world_G(R, p, mp->mass + 36 * b, G);
+                        // two passes: M | rhs is the first (positions 0 ..); one pass: behind the 36 entries of A
+                        if constexpr (TWO_PASS) store_MR(std::integral_constant<int, 0>{}, R, p, G, trow);
+                        else store_MR(std::integral_constant<int, TB_PASS1>{}, R, p, G, trow);
+                    }
+                    if constexpr (!TWO_PASS) {
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        body_A();
+                    }
+                }
+            } else
             if (lane < nb) {
                 const int b = lane;
                 const M3<double> R = ld_m3(PD + 12 * b);
@@ -2014,6 +2208,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                     // first pass: M | rhs, whose rows the body lanes have written already (the pass over the 36 entries of
                     // A, still in registers, runs inside the consumer below once the first has been consumed: the table is
                     // half as large that way, and the body block never holds more than A and Mg in registers)
+                    if (bstream) {
+                        // (round 4: the body lanes have written their table rows -- everything with one pass, M | rhs with two)
+                        if constexpr (TWO_PASS) tb_pass(std::integral_constant<int, TB_PASS1>{}, std::integral_constant<int, NACC - TB_PASS1>{}, true);
+                        else tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NACC>{}, true);
+                    } else
                     if constexpr (TWO_PASS) tb_pass(std::integral_constant<int, TB_PASS1>{}, std::integral_constant<int, NACC - TB_PASS1>{}, true);
                     else tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NACC>{}, false);
                     // (c) happens in the consumer below, which streams the two table rows of body(k) straight
@@ -2123,6 +2322,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                         if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
                     });
                     WAVE_SYNC();                   // every lane has consumed the first pass: the table is rewritten
+                    if (bstream) {
+                        if (lane < nb) body_A();   // (the rows of A straight into the table, Mg formed again: see the body block)
+                        WAVE_SYNC();
+                        tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, TB_PASS1>{}, true);
+                    } else
                     tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, TB_PASS1>{}, false);
                     static_for_asc(std::make_integer_sequence<int, TB_PASS1 / 2>{}, [&](auto i2c) {
                         constexpr int i2 = decltype(i2c)::value;
@@ -2141,7 +2345,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 WAVE_SYNC();                   // every lane is done with the staging area: it becomes XPR
                 // ... and with the joints' own columns SC: their space becomes RT = [rhs | rows of J'], zero before
                 // the constraint rows and the joint-limit selectors are written (entries >= ndof of a row stay zero)
-                for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0);
+                if constexpr (!MFMA_ROWS) { for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0); }
                 if (lane < n) {
                     double *o = STG + XPR_STRIDE * lane;
 #pragma unroll
@@ -2151,6 +2355,135 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             }
             // ---- lane = column k: rows of Z ----------------------------------------------------------
             ARB_BSTAMP(5);
+            if constexpr (MFMA_ROWS) {
+                // On the matrix cores, in float64 (round 4; float32 worlds on the 44- and 48-row tiles).  The rows of Z are two
+                // matrix products over the dof index pairs (i, k):  U[i][k] = X_i . G_k  (rows at or above the joint of k:
+                // i <= e_k)  and  L[i][k] = [P_i | R_i] . [X_k | dX'_k]  (rows below), 6 and 12 terms deep, 44 x 44 results.
+                // The vector-ALU version walks the 44 rows one after the other, every lane its own column: 9 broadcast LDS
+                // reads and 18 float64 multiply-adds per row, ~1850 instructions and 20 k cycles of a step in which nothing
+                // else of the wave can issue.  v_mfma_f64_16x16x4_f64 computes a 16 x 16 tile four terms deep per
+                // instruction (tools/mfma_f64_layout_probe.hip: A operand lane l = A[l % 16][l / 16], B operand lane l =
+                // B[l / 16][l % 16], result register v of lane l = D[l / 16 + 4 v][l % 16]; one issue per 16 cycles, 64
+                // cycles of latency): 9 tiles x (2 + 3) instructions.  The A side -- X | P | R of every dof -- is the XPR
+                // array as it stands; the B side -- G, X | dX' of the 16 dofs of a tile column -- and the results travel
+                // through the space of RT, which is not yet in use (its zeroing moves behind this block): tile column by
+                // tile column, so that 1536 bytes are enough whatever the model's number of constraints.  Same sums in a
+                // different order than the row loop: a float32 entry of Z may differ by an ulp from the round-3 kernels;
+                // every build of the step kernel (two / three waves, packed, inspect) runs this code, so they stay
+                // bit-identical to one another.
+                typedef double d4 __attribute__((ext_vector_type(4)));
+                typedef T V4 __attribute__((ext_vector_type(4)));
+                constexpr int NT = (NMAX + 15) / 16;
+                const int lj = lane & 15, lg = lane >> 4;
+                const unsigned long long rel = (lane < n) ? (mp->upmask[lane] | mp->descmask[lane]) : 0ull;
+                const int rel_lo = (int)(unsigned)rel, rel_hi = (int)(unsigned)(rel >> 32);
+                const int e_k = (lane < n) ? (mp->dof_off[bsrc] + mp->jnd[bsrc] - 1) : -1;
+                double *BS = reinterpret_cast<double *>(RT);        // B-side staging: [16 dofs][6 or 12]
+                T *OS = RT;                                         // result staging: [8 columns][16 NT positions]
+                static_for_asc(std::make_integer_sequence<int, NT>{}, [&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+                    const bool mycol = lg == K;                      // lanes 16 K .. 16 K + 15: the dofs of this tile column
+                    // what this lane's results belong to: column 16 K + lj
+                    const int src = 16 * K + lj;
+                    const int ecol = __shfl(e_k, src);
+                    const unsigned rlo = (unsigned)__shfl(rel_lo, src), rhi = (unsigned)__shfl(rel_hi, src);
+                    // Which products does tile (I, K) need?  Rows above the tile column's dofs (I < K) are all at or above the
+                    // joint: U only.  Two tiles below the diagonal and further (I > K + 1) every row lies below every
+                    // joint of the column (e_k <= k + 5): L only.  The diagonal tile and the one below it need both.
+                    d4 accU[NT], accL[NT];
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) { accU[I] = d4{0., 0., 0., 0.}; accL[I] = d4{0., 0., 0., 0.}; }
+                    // ---- U = X^T G: the column's G vectors to LDS, two instructions per tile (6 terms in 2 x 4)
+                    if (mycol) {
+                        double *o = BS + 6 * lj;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) o[i] = Gk[i];
+                    }
+                    WAVE_SYNC();
+                    {
+                        const double b0 = BS[6 * lj + lg], b1 = (lg < 2) ? BS[6 * lj + 4 + lg] : 0.;
+#pragma unroll
+                        for (int I = 0; I < NT; ++I) {
+                            if (I > K + 1) continue;
+                            const int irow = (16 * I + lj < RS) ? 16 * I + lj : RS - 1;        // (rows beyond the tile: masked below)
+                            const double *xa = STG + XPR_STRIDE * irow;
+                            const double a0 = xa[lg], a1 = (lg < 2) ? xa[4 + lg] : 0.;
+                            accU[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accU[I], 0, 0, 0);
+                            accU[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accU[I], 0, 0, 0);
+                        }
+                    }
+                    WAVE_SYNC();
+                    // ---- L = [P | R]^T [X | dX']: three instructions per tile (12 terms)
+                    if (mycol) {
+                        double *o = BS + 12 * lj;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) { o[i] = Xk[i]; o[6 + i] = dXk[i]; }
+                    }
+                    WAVE_SYNC();
+                    {
+                        const double b0 = BS[12 * lj + lg], b1 = BS[12 * lj + 4 + lg], b2 = BS[12 * lj + 8 + lg];
+#pragma unroll
+                        for (int I = 0; I < NT; ++I) {
+                            if (I < K) continue;
+                            const int irow = (16 * I + lj < RS) ? 16 * I + lj : RS - 1;
+                            const double *xa = STG + XPR_STRIDE * irow + 6;
+                            const double a0 = xa[lg], a1 = xa[4 + lg], a2 = xa[8 + lg];
+                            accL[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accL[I], 0, 0, 0);
+                            accL[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accL[I], 0, 0, 0);
+                            accL[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accL[I], 0, 0, 0);
+                        }
+                    }
+                    // ---- select by row (at or above the joint: U, below: L), mask the unrelated rows, round to T
+                    V4 res[NT];
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) {
+                        T r4[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int i = 16 * I + lg + 4 * v;                                  // the row this register holds
+                            T val;
+                            if (I < K) val = (T)accU[I][v];
+                            else if (I > K + 1) val = (T)accL[I][v];
+                            else val = (i <= ecol) ? (T)accU[I][v] : (T)accL[I][v];
+                            const bool on = (((16 * I + 4 * v < 32 ? rlo : rhi) >> ((16 * I + 4 * v + lg) & 31)) & 1u) != 0u;
+                            r4[v] = on ? val : T(0);
+                        }
+                        res[I] = V4{r4[0], r4[1], r4[2], r4[3]};
+                    }
+                    WAVE_SYNC();                    // (every lane has read its B operands: the staging space turns over)
+                    // ---- results to their column lanes, eight columns at a time: lane (lg, lj) stores the four rows
+                    // lg + 4 v of tile row I as ONE 16-byte vector at position 16 I + 4 lg of its column, the column's
+                    // lane reads vector 4 I + g back as rows 16 I + g + 4 v
+                    constexpr int OSS = 16 * NT;                     // positions per column
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if ((lj >> 3) == h) {
+                            V4 *o = reinterpret_cast<V4 *>(OS + (lj & 7) * OSS + 4 * lg);
+#pragma unroll
+                            for (int I = 0; I < NT; ++I) o[4 * I] = res[I];
+                        }
+                        WAVE_SYNC();
+                        if (mycol && (lj >> 3) == h) {
+                            const V4 *c4 = reinterpret_cast<const V4 *>(OS + (lj & 7) * OSS);
+#pragma unroll
+                            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    if (16 * I + g >= NMAX) continue;
+                                    const V4 r = c4[4 * I + g];
+                                    Z[16 * I + g] = r.x;
+                                    if (16 * I + g + 4 < NMAX) Z[16 * I + g + 4] = r.y;
+                                    if (16 * I + g + 8 < NMAX) Z[16 * I + g + 8] = r.z;
+                                    if (16 * I + g + 12 < NMAX) Z[16 * I + g + 12] = r.w;
+                                }
+                        }
+                        WAVE_SYNC();
+                    }
+                });
+                // RT = [rhs | rows of J'] starts from zero (see above)
+                for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0);
+                WAVE_SYNC();
+            } else
             {
                 typedef double D2 __attribute__((ext_vector_type(2)));
                 // DFS numbering: rows related to column k are ancestors' (or own) dofs up to the last own dof

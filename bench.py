@@ -573,7 +573,7 @@ def main():
         w1, m1, _ = run_episodes(bw, q0, dq0, dt, EP, 5, torch, None, spl=1, split=args.split, ext=ext)
         res["per_step_launch"] = {"value": B * 5 * EP / w1, "unit": "world-steps/s", "kernel_ms": float(np.mean(m1)),
                                   "steps": 5 * EP}
-    if n_gpus == 1 and not args.no_per_step_leg and args.config == 3 and not args.split:
+    if n_gpus == 1 and not args.no_per_step_leg and args.config == 3 and not args.split and os.environ.get("ARB_BENCH_LEGS") != "perstep":
         # (same switch as the one-launch-per-step leg: the profiling runs skip all of these)
         # The path that meets 1e-5 on EVERY world-step: the float64 kernels on the headline workload (the float32 kernels
         # meet it on 99.9 % of the world-steps, the others are decisions that are marginal for the reference itself or
