@@ -71,6 +71,9 @@
                                 // the elimination and the constraint-space products; the sweeps stay float32.  Settles where the float32
                                 // outliers are decided (profiles/r04_replay_stats.txt); not a production build (88 more registers)
 #endif
+#ifndef ARB_ROOT_QM
+#define ARB_ROOT_QM 1           // the sliding root finder decides from lane masks (arb_math.h: slide_leftmost_root_qm)
+#endif
 #ifndef ARB_PACK_MIN_ROUNDS
 #define ARB_PACK_MIN_ROUNDS 4   // the packed build is picked from this many pairs of worlds per wave slot on (16384 worlds on an MI355X: measured +2 %; +0..2 % at 8192, -8 % at 4096, where the three-wave build wins)
 #endif
@@ -593,6 +596,8 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #ifdef ARB_GSSTAMPS
                             int *const probe = (MODE == 1 && lane == base) ? gprobe : nullptr;
                             if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni, probe, woff)) {
+#elif ARB_ROOT_QM
+                            if (slide_leftmost_root_qm(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), base, woff)) {
 #else
                             if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni, nullptr, woff)) {
 #endif
@@ -713,23 +718,30 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 }
 
 // ===========================================================================
-// The Gauss-Seidel stage for TWO worlds held by one wavefront (round 3): world h on lanes 32 h .. 32 h + ndol - 1
-// (ndol <= 32: up to eight SoftFingerContacts with eps = (1,1,1), which the host checks).  The sweeps are one dependent
-// instruction chain in which one quad of lanes does useful work; here the quad of constraint c of BOTH worlds works at
-// once.  A stage of the local solve is executed when either world needs it and its results are taken lane by lane
-// under the conditions of gs_stage, whose arithmetic every lane repeats operation for operation: a world's forces and
-// velocities are bit-identical to gs_stage's.  A world that has reached its bit-exact fixed point (or has no partner:
-// `two` false) takes no further part -- its lanes keep their values, as gs_stage's break would.
-// LDS per world: AM = Y', CD, VV, FF as for gs_stage; WORK is shared scratch.
+// The Gauss-Seidel stage for NG = 2 or 4 worlds held by one wavefront (round 3: two; round 4: four): world g on lanes
+// GL g .. GL g + ndol - 1 with GL = 64 / NG (ndol <= GL: up to eight SoftFingerContacts for two worlds, four for four, all
+// with eps = (1,1,1), which the host checks).  The sweeps are one dependent instruction chain in which one quad of lanes
+// does useful work; here the quad of constraint c of EVERY world works at once.  A stage of the local solve is executed
+// when some world needs it and its results are taken lane by lane under the conditions of gs_stage, whose arithmetic every
+// lane repeats operation for operation: a world's forces and velocities are bit-identical to gs_stage's.  A world that has
+// reached its bit-exact fixed point (or a group without a world: g >= nvalid) takes no further part -- its lanes keep
+// their values, as gs_stage's break would.
+// LDS per world g: AMp[g] = Y', CDp[g], VVp[g], FFp[g] as for gs_stage; WORK is shared scratch.
 // ===========================================================================
-template <typename T>
-__device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt,
-                                          const T *AM0, T *CD0, T *VV0, T *FF0w, const T *AM1, T *CD1, T *VV1, T *FF1w,
-                                          T *WORK, const bool two) {
-    const int half = lane >> 5, hl = lane & 31;
-    const T *AM = half ? AM1 : AM0;
-    T *CD = half ? CD1 : CD0, *VV = half ? VV1 : VV0, *FF = half ? FF1w : FF0w;
-    const bool mine = (half == 0) || two;                 // this lane's world exists
+template <typename T, int NG>
+__device__ __forceinline__ void gs_stage_n(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt,
+                                           const T *const (&AMp)[NG], T *const (&CDp)[NG], T *const (&VVp)[NG], T *const (&FFp)[NG],
+                                           T *WORK, const int nvalid) {
+    static_assert(NG == 2 || NG == 4, "two or four worlds per wavefront");
+    constexpr int GL = WAVE / NG;
+    const int grp = lane / GL, hl = lane % GL;
+    const T *AM = AMp[0];
+    T *CD = CDp[0], *VV = VVp[0], *FF = FFp[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) {
+        AM = (grp == g) ? AMp[g] : AM; CD = (grp == g) ? CDp[g] : CD; VV = (grp == g) ? VVp[g] : VV; FF = (grp == g) ? FFp[g] : FF;
+    }
+    const bool mine = grp < nvalid;                       // this lane's world exists
     {
         bool deficient = false;
         if (mine && hl < nc && CD[hl * CD_STRIDE + CD_ACTIVE] != T(0)) {
@@ -783,23 +795,28 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
         }
     }
     if (mine && hl < nc) k_act = CD[hl * CD_STRIDE + CD_ACTIVE] != T(0);
-    const unsigned long long actmask = __ballot(k_act);          // bit c: world 0, bit 32 + c: world 1
-    bool done0 = false, done1 = !two;
+    const unsigned long long actmask = __ballot(k_act);          // bit GL g + c: constraint c of world g
+    constexpr unsigned ALLG = (1u << NG) - 1u;
+    constexpr unsigned long long GMASK = (GL >= 64) ? ~0ull : ((1ull << GL) - 1ull);
+    unsigned done = (ALLG << nvalid) & ALLG;                      // groups without a world take no part
     T vr_prev = vr, fr_prev = fr;
 #if ARB_GS_PRIO
     __builtin_amdgcn_s_setprio(ARB_GS_PRIO);
 #endif
     for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
-        if (done0 && done1) break;
+        if (done == ALLG) break;
         for (int c = 0; c < nc; ++c) {
-            const bool on0 = !done0 && ((actmask >> c) & 1ull), on1 = !done1 && ((actmask >> (32 + c)) & 1ull);
-            if (!on0 && !on1) continue;
+            // the worlds that take part in this solve: bit GL g + 4 c (the leading lane of the quad of c in group g)
             const int base = 4 * c;
-            const bool my_on = half ? on1 : on0;                 // this lane's world takes part in this solve
+            unsigned long long onl = 0ull;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                if (!((done >> g) & 1u) && ((actmask >> (GL * g + c)) & 1ull)) onl |= 1ull << (GL * g + base);
+            if (onl == 0ull) continue;
+            const int myq = GL * grp + base;                     // the leading lane of this lane's group's quad of c
+            const bool my_on = (onl >> myq) & 1ull;              // this lane's world takes part in this solve
             const int rq = hl - base;
             const bool inquad = rq >= 0 && rq < 4;
-            // bit masks of the quads' leading lanes (base, 32 + base) of the worlds taking part
-            const unsigned long long lead = (on0 ? (1ull << base) : 0ull) | (on1 ? (1ull << (32 + base)) : 0ull);
             T a4[4] = {T(0), T(0), T(0), T(0)};
             if (mine && hl < ndol) {
 #pragma unroll
@@ -815,16 +832,14 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
             const T fn0 = quad_bcast<0>(fnr), fn1 = quad_bcast<1>(fnr), fn2 = quad_bcast<2>(fnr), fn3 = quad_bcast<3>(fnr);
             const T lhs = fn0 * fn0 + fn1 * fn1 + fn2 * fn2;
             const T rhs = (fn3 * q_mu) * (fn3 * q_mu);
-            // the verdicts of the two quads of constraint c
+            // the verdicts of the quads of constraint c
             const unsigned long long relb = __ballot(q_sd + dt * v0n > T(0)), statb = __ballot(lhs <= rhs);
-            const bool rel0 = (relb >> base) & 1ull, rel1 = (relb >> (32 + base)) & 1ull;
-            const bool sta0 = (statb >> base) & 1ull, sta1 = (statb >> (32 + base)) & 1ull;
-            const bool release = half ? rel1 : rel0, stat = half ? sta1 : sta0;
-            const bool slide0 = on0 && !rel0 && !sta0, slide1 = on1 && !rel1 && !sta1;
-            const bool my_slide = half ? slide1 : slide0;
+            const bool release = (relb >> myq) & 1ull, stat = (statb >> myq) & 1ull;
+            const unsigned long long slm = onl & ~relb & ~statb;                 // leading lanes of the quads that slide
+            const bool my_slide = (slm >> myq) & 1ull;
+            (void)stat;
             T dfl = release ? -fr : dfr, fnl = release ? T(0) : fnr;             // release / static, row by row
-            if (slide0 || slide1) {                                              // sliding friction: either world
-                const unsigned long long slm = (slide0 ? (1ull << base) : 0ull) | (slide1 ? (1ull << (32 + base)) : 0ull);
+            if (slm != 0ull) {                                                   // sliding friction: some world
                 const auto anyq = [&](bool b) { return (bool)((__ballot(b) & slm) != 0ull); };
                 const bool want = my_slide && inquad;
                 T alpha[4], shift = T(0);
@@ -862,9 +877,9 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
                 const unsigned long long needfb = __ballot(want && !have) & slm;
                 if (needfb != 0ull) {
                     const T eps[3] = {T(1), T(1), T(1)};
-                    for (int h = 0; h < 2; ++h) {
-                        if (!((needfb >> (32 * h + base)) & 1ull)) continue;
-                        const bool hq = want && half == h;
+                    for (int h = 0; h < NG; ++h) {
+                        if (!((needfb >> (GL * h + base)) & 1ull)) continue;
+                        const bool hq = want && grp == h;
                         if (hq) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
                         WAVE_SYNC();
                         if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
@@ -881,22 +896,24 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
                 const T fns = (rq == 0) ? fnew[0] : (rq == 1) ? fnew[1] : (rq == 2) ? fnew[2] : fnew[3];
                 dfl = my_slide ? dfs : dfl; fnl = my_slide ? fns : fnl;
             }
-            // the force increments of this lane's world: from the quad of c in its own half
+            // the force increments of this lane's world: from the quad of c in its own group
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const T d0 = bcast(dfl, base + i), d1 = bcast(dfl, 32 + base + i);
-                df[i] = half ? d1 : d0;
+                T d = bcast(dfl, base + i);
+#pragma unroll
+                for (int g = 1; g < NG; ++g) { const T dg = bcast(dfl, GL * g + base + i); d = (grp == g) ? dg : d; }
+                df[i] = d;
             }
             if (my_on) {
                 fr = inquad ? fnl : fr;
                 vr += a4[0] * df[0] + a4[1] * df[1] + a4[2] * df[2] + a4[3] * df[3];      // core.py:935
             }
-            (void)lead;
         }
         // a sweep that leaves every velocity and force of a world bit for bit unchanged is its fixed point
         const unsigned long long sameb = __ballot(same_bits(vr, vr_prev) && same_bits(fr, fr_prev));
-        if (!done0 && (unsigned)(sameb & 0xffffffffull) == 0xffffffffu) done0 = true;
-        if (!done1 && (unsigned)(sameb >> 32) == 0xffffffffu) done1 = true;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (((sameb >> (GL * g)) & GMASK) == GMASK) done |= 1u << g;
         vr_prev = vr; fr_prev = fr;
     }
 #if ARB_GS_PRIO
@@ -905,6 +922,16 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
     WAVE_SYNC();
     if (mine && hl < ndol) { FF[hl] = fr; VV[hl] = vr; }
     WAVE_SYNC();
+}
+
+// two worlds per wavefront (the packed build of round 3 and its sweep kernel)
+template <typename T>
+__device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt,
+                                          const T *AM0, T *CD0, T *VV0, T *FF0w, const T *AM1, T *CD1, T *VV1, T *FF1w,
+                                          T *WORK, const bool two) {
+    const T *const AMp[2] = {AM0, AM1};
+    T *const CDp[2] = {CD0, CD1}, *const VVp[2] = {VV0, VV1}, *const FFp[2] = {FF0w, FF1w};
+    gs_stage_n<T, 2>(mp, lane, nc, ndol, dt, AMp, CDp, VVp, FFp, WORK, two ? 2 : 1);
 }
 
 // ===========================================================================
@@ -3189,32 +3216,38 @@ __global__ __launch_bounds__(WAVE, WV) void arb_gsw_kernel(
     if (lane < ndol) wsf[w * ndol + lane] = FF[lane];
 }
 
-// The same with TWO worlds per wavefront (gs_stage2): worlds 2 p and 2 p + 1 in workgroup p.  Development / test vehicle
-// of the packed sweeps (ARB_GSW_PACK=1 in the environment selects it for ARB_STEP_SPLIT_WAVE): bit-identical to
-// arb_gsw_kernel by construction, checked in tests/test_gpu_round3.py.
-template <typename T, int WV>
-__global__ __launch_bounds__(WAVE, WV) void arb_gsw2_kernel(
+// The same with NG = 2 or 4 worlds per wavefront (gs_stage_n): worlds NG p .. NG p + NG - 1 in workgroup p.  Development /
+// test vehicle of the packed sweeps (ARB_GSW_PACK=2|4 in the environment selects it for ARB_STEP_SPLIT_WAVE; 1 means 2):
+// bit-identical to arb_gsw_kernel by construction, checked in tests/test_gpu_round3.py.
+template <typename T, int WV, int NG>
+__global__ __launch_bounds__(WAVE, WV) void arb_gswn_kernel(
     const DevModel<T> *__restrict__ mp, const T *__restrict__ wsA, const T *__restrict__ wsv,
     T *__restrict__ wsf, const T *__restrict__ wsc, long nworlds, T dt_in, const double *__restrict__ dts)
 {
     const int lane = threadIdx.x;
-    const long w0 = 2l * blockIdx.x;
+    const long w0 = (long)NG * blockIdx.x;
     if (w0 >= nworlds) return;
-    const bool two = w0 + 1 < nworlds;
+    const int nvalid = (int)((nworlds - w0 < NG) ? nworlds - w0 : NG);
     const int nc = mp->nc, ndol = mp->ndol;
     const T dt = dts != nullptr ? (T)dts[0] : dt_in;
     T *lds = reinterpret_cast<T *>(arb_lds_raw);
     auto al = [](int x) { return (x + 3) & ~3; };
     const int per = al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol);
-    T *AMw[2], *CDw[2], *VVw[2], *FFw[2];
-    for (int h = 0; h < 2; ++h) {
-        AMw[h] = lds + h * per; CDw[h] = AMw[h] + al(ndol * ndol); VVw[h] = CDw[h] + al(nc * CD_STRIDE); FFw[h] = VVw[h] + al(ndol);
+    const T *AMw[NG];
+    T *CDw[NG], *VVw[NG], *FFw[NG];
+#pragma unroll
+    for (int h = 0; h < NG; ++h) {
+        T *b = lds + h * per;
+        AMw[h] = b; CDw[h] = b + al(ndol * ndol); VVw[h] = CDw[h] + al(nc * CD_STRIDE); FFw[h] = VVw[h] + al(ndol);
     }
-    T *WORK = lds + 2 * per;
+    T *WORK = lds + NG * per;
     const int nA = ndol * ndol;
-    for (int h = 0; h < (two ? 2 : 1); ++h) {
+#pragma unroll
+    for (int h = 0; h < NG; ++h) {
+        if (h >= nvalid) continue;
         const long w = w0 + h;
-        for (int i = lane; i < nA; i += WAVE) AMw[h][i] = wsA[w * nA + i];
+        T *am = lds + h * per;
+        for (int i = lane; i < nA; i += WAVE) am[i] = wsA[w * nA + i];
         if (lane < ndol) { VVw[h][lane] = wsv[w * ndol + lane]; FFw[h][lane] = wsf[w * ndol + lane]; }
         if (lane < nc) {
             const T *cs = wsc + (w * nc + lane) * 8;
@@ -3223,9 +3256,10 @@ __global__ __launch_bounds__(WAVE, WV) void arb_gsw2_kernel(
         }
     }
     WAVE_SYNC();
-    gs_stage2<T>(mp, lane, nc, ndol, dt, AMw[0], CDw[0], VVw[0], FFw[0], AMw[1], CDw[1], VVw[1], FFw[1], WORK, two);
-    for (int h = 0; h < (two ? 2 : 1); ++h)
-        if (lane < ndol) wsf[(w0 + h) * ndol + lane] = FFw[h][lane];
+    gs_stage_n<T, NG>(mp, lane, nc, ndol, dt, AMw, CDw, VVw, FFw, WORK, nvalid);
+#pragma unroll
+    for (int h = 0; h < NG; ++h)
+        if (h < nvalid && lane < ndol) wsf[(w0 + h) * ndol + lane] = FFw[h][lane];
 }
 
 // ===========================================================================
@@ -4154,17 +4188,29 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 }
 
 template <typename T>
-static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st, bool pack = false) {
+static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st, bool pack = false, bool pack4 = false) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int ndol = 4 * nc;
     const size_t lds = (size_t)(al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol) + 64) * sizeof(T);
     // waves per SIMD the sweep kernel is compiled for (development knob ARB_GSW_WAVES: 3 = no spills, 4 = 128 VGPRs)
-    static const int wv = [] { const char *e = getenv("ARB_GSW_WAVES"); return e ? atoi(e) : 3; }();
+    const int wv = env_int("ARB_GSW_WAVES", 3);
     if (lds > 64 * 1024) return ARB_ERR_UNSUPPORTED;
     if (pack) {
-        // (development: two worlds per wavefront; the caller has checked that the model qualifies)
-        const size_t lds2 = (size_t)(2 * (al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol)) + 64) * sizeof(T);
-        hipLaunchKernelGGL((arb_gsw2_kernel<T, 3>), dim3((unsigned)((nw + 1) / 2)), dim3(WAVE), lds2, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
+        // (development: two or four worlds per wavefront; the caller has checked that the model qualifies -- four need
+        // their 4 nc rows to fit a quarter of the wavefront)
+        const int ng = (pack4 && ndol <= 16) ? 4 : 2;
+        const size_t ldsn = (size_t)(ng * (al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol)) + 64) * sizeof(T);
+        const unsigned grid = (unsigned)((nw + ng - 1) / ng);
+        // (the packed sweeps keep every stage's results lane by lane: compiled for three waves per SIMD they spill ~50
+        // registers inside the solve -- ARB_GSW_WAVES=2 selects the 256-register build)
+        if (ng == 4 && wv == 2)
+            hipLaunchKernelGGL((arb_gswn_kernel<T, 2, 4>), dim3(grid), dim3(WAVE), ldsn, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
+        else if (ng == 4)
+            hipLaunchKernelGGL((arb_gswn_kernel<T, 3, 4>), dim3(grid), dim3(WAVE), ldsn, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
+        else if (wv == 2)
+            hipLaunchKernelGGL((arb_gswn_kernel<T, 2, 2>), dim3(grid), dim3(WAVE), ldsn, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
+        else
+            hipLaunchKernelGGL((arb_gswn_kernel<T, 3, 2>), dim3(grid), dim3(WAVE), ldsn, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
         HIP_TRY(hipGetLastError());
         return ARB_OK;
     }
@@ -4211,7 +4257,7 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
         sio.mode = 2 | (k > 0 ? 1 : 0);
         // (kernel k finishes step k-1 with dts[k-1], then builds step k with dts[k])
         rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, dts ? dts + k : nullptr, st);
-        if (rc == ARB_OK) rc = launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st, M->packable && env_int("ARB_GSW_PACK", 0) != 0);
+        if (rc == ARB_OK) rc = launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st, M->packable && env_int("ARB_GSW_PACK", 0) != 0, env_int("ARB_GSW_PACK", 0) == 4);
     }
     if (rc == ARB_OK) {
         sio.mode = 1;                                      // apply the last step's forces, write cforce

@@ -1050,6 +1050,104 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
 #undef U
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same again with the quad's verdicts formed from LANE MASKS (round 4).  A wave-uniform test of a compound condition,
+// `uni(a || b || c)`, cost a v_cndmask + v_cmp round trip through a vector register on the critical chain of the sweeps:
+// the compiler materialises the disjunction as a 0/1 value per lane before it can ballot it.  Here every single comparison
+// is balloted as it stands (the v_cmp result IS the mask), the masks are combined by scalar logic, and bit `qbase` -- the
+// leading lane of the quad that carries the live problem -- decides for the wave.  The lanes of that quad hold identical
+// data, so a selection under the quad's verdict gives them what the lane-wise selection of slide_leftmost_root_uni gives
+// them; operation for operation the same arithmetic: bit-identical roots.
+__device__ __forceinline__ bool slide_leftmost_root_qm(const SlidePre &k, double c1, double kappa, double warm, double *root,
+                                                       double step_tol, int qbase, double woff) {
+#define BM(c) __builtin_amdgcn_ballot_w64(c)
+#define QM(m) ((bool)(((m) >> qbase) & 1ull))
+    const double d2 = -kappa;
+    const double l1 = -(3. * k.tr - k.sQ);
+    const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
+    const double o[3] = {k.m2 + d2, -2. * k.tr, 3.};                          // O_chi
+    const double er[3] = {k.sA + 3. * d2, l1, 3.};                            // E_rho
+    const double orr[2] = {l1, 6.};                                           // O_rho
+    double pc[7];
+    pc[0] = e[0] * e[0] - d2 * (o[0] * o[0]);
+    pc[1] = 2. * e[0] * e[1] - d2 * (2. * o[0] * o[1]);
+    pc[2] = 2. * e[0] * e[2] + e[1] * e[1] - d2 * (2. * o[0] * o[2] + o[1] * o[1]);
+    pc[3] = 2. * (e[0] * e[3] + e[1] * e[2]) - d2 * (2. * o[1] * o[2]);
+    pc[4] = 2. * e[1] * e[3] + e[2] * e[2] - d2 * (o[2] * o[2]);
+    pc[5] = 2. * e[2] * e[3];
+    pc[6] = 1.;
+    pc[0] -= c1 * (er[0] * e[0] - d2 * (orr[0] * o[0]));
+    pc[1] -= c1 * (er[0] * e[1] + er[1] * e[0] - d2 * (orr[0] * o[1] + orr[1] * o[0]));
+    pc[2] -= c1 * (er[0] * e[2] + er[1] * e[1] + er[2] * e[0] - d2 * (orr[0] * o[2] + orr[1] * o[1]));
+    pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
+    pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
+    pc[5] -= c1 * (er[2] * e[3]);
+    double x = NAN;
+    double w0 = 0., w1 = 0., w2 = 0.;
+    bool from_shift = false;
+    if (QM(BM(warm == warm))) {
+        const double x0 = warm - (woff >= 0. ? woff : 1e-3 * fabs(warm)) - 1e-300;
+        double t[7];
+        for (int i = 0; i < 7; ++i) t[i] = pc[i];
+        for (int j = 0; j < 6; ++j)                 // Taylor shift: t[i] = p^(i)(x0) / i!
+            for (int i = 5; i >= j; --i) t[i] += x0 * t[i + 1];
+        const unsigned long long mc = BM(t[0] > 0.) & BM(t[1] < 0.) & BM(t[2] > 0.) & BM(t[3] < 0.) & BM(t[4] > 0.) & BM(t[5] < 0.);
+        if (QM(mc)) {
+            x = x0; w0 = t[0]; w1 = t[1]; w2 = 2. * t[2]; from_shift = true;
+        }
+    }
+    if (!from_shift) {
+        const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
+        if (QM(BM(!(rb > 0.)) | BM(!(rb < 1e300)))) return false;
+        x = -1.0001 * rb - 1e-300;
+    }
+    const double n = 6.;
+    for (int it = 0; it < 40; ++it) {
+        double p0, p1, p2;
+        unsigned long long m_zero = 0ull;
+        if (from_shift) {
+            p0 = w0; p1 = w1; p2 = w2;           // (p > 0 > p' certified: the rounding-level zero test is not needed here)
+            from_shift = false;
+        } else {
+            double ee = fabs(pc[6]);
+            p0 = pc[6]; p1 = 0.; p2 = 0.;
+            const double ax = fabs(x);
+            for (int i = 5; i >= 0; --i) {
+                p2 = p2 * x + p1; p1 = p1 * x + p0; p0 = p0 * x + pc[i];
+                ee = ee * ax + fabs(p0);                    // running Horner error bound
+            }
+            p2 *= 2.;
+            m_zero = BM(fabs(p0) <= 8.9e-16 * (2. * ee - fabs(p0)));      // p(x) = 0 to rounding
+        }
+        const double rad = (n - 1.) * ((n - 1.) * p1 * p1 - n * p0 * p2);
+        // anomalies: not left of all roots any more, or complex roots nearby
+        const unsigned long long m_bad = ~m_zero & (BM(!(p0 > 0.)) | BM(!(p1 < 0.)) | BM(!(rad >= 0.)));
+        const double den = p1 - arb_fast_sqrt(rad);   // both terms negative: no cancellation
+        const double dx = (n * (1. - 9.5367431640625e-07)) * p0 * arb_fast_rcp(den); // negative
+        const double xn = x - dx;
+        const unsigned long long m_stall = BM(!(xn > x));                 // no representable progress: converged
+        if (QM(m_zero | m_bad | m_stall | BM(fabs(dx) <= step_tol * fabs(xn)))) {
+            if (QM(m_bad)) return false;
+            *root = QM(m_zero | m_stall) ? x : xn;
+            return true;
+        }
+        if (QM(BM(fabs(dx) <= 1e-2 * fabs(xn)))) {
+            double q0 = pc[6];
+            for (int i = 5; i >= 0; --i) q0 = q0 * xn + pc[i];
+            if (QM(BM(fabs(q0) <= 0.25 * step_tol * fabs(xn) * (-p1)))) { *root = xn; return true; }
+        }
+        x = xn;
+    }
+    return false;
+#undef BM
+#undef QM
+}
+#elif defined(__HIPCC__)
+// (host pass of the kernel sources: declared, never called)
+__device__ bool slide_leftmost_root_qm(const SlidePre &k, double c1, double kappa, double warm, double *root,
+                                       double step_tol, int qbase, double woff);
+#endif
+
 // The same iteration for TWO worlds in one wavefront (round 3, packed sweeps): every lane carries its own problem --
 // the lanes of a quad identical copies of their constraint's --, `want` marks the lanes whose quad slides in this solve,
 // and `anyq(b)` tells whether b holds on some sliding quad: a stage is executed when some sliding quad needs it, its

@@ -330,15 +330,17 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
     q, dq = synth.world_states(m, range(B), "standing", 11, drop=0.03, vel=0.2)
     q[:, 7] -= 0.01
     res = {}
-    for mode in ("fused", "wave", "pack"):
-        monkeypatch.setenv("ARB_GSW_PACK", "1" if mode == "pack" else "0")
+    for mode in ("fused", "wave", "pack", "pack4"):
+        # (round 4: ARB_GSW_PACK=4 = FOUR worlds per wavefront for models of up to four contacts -- 16 constraint rows, a
+        # quarter of the wavefront each; with more it runs two, like ARB_GSW_PACK=1 / 2)
+        monkeypatch.setenv("ARB_GSW_PACK", {"pack": "1", "pack4": "4"}.get(mode, "0"))
         tq, tdq = bw.to_device(q, dq, dtype)
         cf = bw.new_cforce(B, dtype)
         bw.step(tq, tdq, 5e-3, 40, cforce=cf, split=("wave" if mode != "fused" else False))
         torch.cuda.synchronize()
         res[mode] = (tq, tdq, cf)
     assert float(res["fused"][2][:, :, 3].max()) > 100.                      # contacts engaged, sliding included
-    for mode in ("wave", "pack"):
+    for mode in ("wave", "pack", "pack4"):
         assert all(torch.equal(a, b) for a, b in zip(res["fused"], res[mode])), mode
     bw.close()
 
