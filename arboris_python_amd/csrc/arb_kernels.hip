@@ -1879,7 +1879,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             WAVE_SYNC();
             // ---- lane = body: world-frame matrices of the body -----------------------------------
 #ifndef ARB_B_STREAM
-#define ARB_B_STREAM 1
+#define ARB_B_STREAM 0          // measured round 4 (1: the block below): at the three-wave register budget the body block drops from
+                                // 57 k to 18 k cycles (tools/bstamp_probe.py, eight waves per CU), bit-identical -- and with twelve
+                                // waves per CU the launch takes as long as before (other waves cover the reloads), with 1 % more
+                                // instructions and 1.2 GB more fetched per launch: kept as an experiment, off
 #endif
             // Small trees (prefix table), round 4: the 36 entries of A_b are produced ROW BY ROW and every row goes straight
             // into the body's table row -- the 36 float64 accumulators of A never sit in registers beside the 36 of Mg.  The

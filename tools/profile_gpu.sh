@@ -10,7 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 40 --warmup 40 --min-seconds 1 --no-cpu-baseline"
 # PMC passes: episode launches only
 BENCH_S="python3 $R/bench.py --steps 40 --warmup 40 --min-seconds 0.2 --no-cpu-baseline --no-per-step-leg"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+# (ARB_BENCH_LEGS=perstep: the headline region + the one-launch-per-step leg, without the float64 / 8-contact / MPC legs the
+# default bench line also carries -- their kernels would mix into the per-kernel statistics)
+ARB_BENCH_LEGS=perstep rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH_S > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH_S > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq1 -- $BENCH_S > $OUT/pmc_sq1.log 2>&1
