@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libarbstep.so")
 if os.environ.get("ARBSTEP_LIB"):                 # development: load a differently built library
     LIB_PATH = os.environ["ARBSTEP_LIB"]
 
-ARB_ABI_VERSION = 5
+ARB_ABI_VERSION = 6
 ARB_OK = 0
 ARB_ERR_STALLED = 5
 ARB_F32, ARB_F64 = 0, 1

@@ -2752,7 +2752,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         // root): on these graded, nearly-SPD matrices that order halves the float32
         // error of pivot-free elimination (measured).
         ARB_CSTAMP(4);
-        if constexpr (CM == 1 && std::is_same<T, float>::value) {
+#ifndef ARB_ELIM_MFMA_ALL
+#define ARB_ELIM_MFMA_ALL 0     // experiment (round 4): 1 = EVERY float32 production kernel eliminates on the matrix cores (what CM = 1 selects)
+#endif
+        if constexpr ((CM == 1 || (ARB_ELIM_MFMA_ALL && MODE == 0 && NMAX < WAVE && !ELIM64)) && std::is_same<T, float>::value) {
             // ---- matrix-core elimination (float32): one pivot = one rank-1 update of the whole register tile,
             // issued as NMAX/4 v_mfma_f32_4x4x1_16b_f32: the 16 4x4 blocks of one instruction are the 64 columns
             // (lane = column, B operand = this lane's entry of the scaled pivot row) times four rows (the four

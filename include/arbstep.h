@@ -41,7 +41,10 @@
 extern "C" {
 #endif
 
-#define ARB_ABI_VERSION 5
+/* 6 (round 4): the stall status word is sticky (arb_model_status alone clears it), arb_step_plan's optional_inputs has a
+ * "per-world logs" bit, forest copies are bit-identical with constraints and their per-world inputs are screened.  No struct
+ * layout changed since 5. */
+#define ARB_ABI_VERSION 6
 
 /* status codes */
 enum {
