@@ -85,7 +85,7 @@ EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_
             "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_step_plan", "arb_step", "arb_step_ex", "arb_rollout",
             "arb_inspect"]
 # every symbol include/arbstep_hooks.h declares: host builds of the device math (unit tests, Constraint.solve)
-TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
+TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
               "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
 
 _lib = None
@@ -144,6 +144,8 @@ def load():
     lib.arb_host_softfinger_try.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, _PD]
     lib.arb_host_slide_root.restype = C.c_int
     lib.arb_host_slide_root.argtypes = [_PD, C.c_double, C.c_double, C.c_double, _PD]
+    lib.arb_dev_eig6_pair.restype = C.c_int
+    lib.arb_dev_eig6_pair.argtypes = [C.c_int, C.c_int, C.c_int, _PD, _PD]
     lib.arb_host_eig6.restype = C.c_int
     lib.arb_host_eig6.argtypes = [_PD, _PD, _PD]
     lib.arb_host_block_pinv.restype = C.c_int

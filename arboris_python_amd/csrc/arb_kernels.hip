@@ -55,7 +55,7 @@
 #ifdef ARB_WAVES_PER_EU
 #define ARB_WAVES(CM) ARB_WAVES_PER_EU
 #else
-#define ARB_WAVES(CM) ((CM) == 2 ? 3 : 2)      // (CM = 3, the packed build: two)
+#define ARB_WAVES(CM) (((CM) == 2 || (CM) == 4) ? 3 : 2)      // (CM = 3, the packed build: two; CM = 4, the rendezvous build: three)
 #endif
 #ifndef GS_SWEEPS
 #define GS_SWEEPS 20            // core.py:929-931 (overridable only for timing experiments: the reference's count is 20)
@@ -73,6 +73,21 @@
 #endif
 #ifndef ARB_ROOT_QM
 #define ARB_ROOT_QM 1           // the sliding root finder decides from lane masks (arb_math.h: slide_leftmost_root_qm)
+#endif
+#ifndef ARB_EIG_WAVE
+#define ARB_EIG_WAVE 1          // the generic 6x6 eigenvalue route of the sliding solve runs on the whole wavefront (eig6_wave); 0: one lane on LDS
+#endif
+// The rendezvous build (CM = 4, round 4): single steps as work items, the wavefronts of four worlds meet at the
+// Gauss-Seidel point -- three park their constraint-space system and what phase E needs in global memory and draw the
+// next item, the last to arrive sweeps all four systems (gs_stage_n<T, 4>) and integrates the four worlds.  Bit-identical
+// to the other builds; measured -1.2 % at 65 536 worlds, +0.5 % at 16 384, -9 % on config 5, -44 % at 4096 worlds (the
+// sliding root finder of four worlds costs what the slowest needs, single-step items cost 2.7 %, 28 KB of parked
+// state per world-step): compiled only with -DARB_WITH_RDV=1, selected only with ARB_FORCE_RDV=1 in the environment.
+#ifndef ARB_WITH_RDV
+#define ARB_WITH_RDV 0
+#endif
+#ifndef ARB_RDV_DEFAULT
+#define ARB_RDV_DEFAULT 0
 #endif
 #ifndef ARB_PACK_MIN_ROUNDS
 #define ARB_PACK_MIN_ROUNDS 4   // the packed build is picked from this many pairs of worlds per wave slot on (16384 worlds on an MI355X: measured +2 %; +0..2 % at 8192, -8 % at 4096, where the three-wave build wins)
@@ -610,12 +625,16 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                         }
                         if (!have) {
                             if (MODE == 1) { ++st_slow; --st_fast; }
-                            // rare: generic 6x6 eigenvalues (QR) on the LDS work array, one lane only
+                            // rare: generic 6x6 eigenvalues (QR) of the matrix in the LDS work array, by the whole wavefront
                             if (inquad) softfinger_sliding_shift<G>(Y, alpha, q_mu, eps, WORK, &shift, false);
                             WAVE_SYNC();
+#if ARB_EIG_WAVE
+                            shift = (G)slide_shift_from_eig_wave<T>(WORK, lane);
+#else
                             if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
                             WAVE_SYNC();
                             shift = WORK[40];
+#endif
                             WAVE_SYNC();
                             warm = NAN;
                             if (inquad) q_wmove = NAN;
@@ -882,9 +901,14 @@ __device__ __forceinline__ void gs_stage_n(const DevModel<T> *mp, const int lane
                         const bool hq = want && grp == h;
                         if (hq) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
                         WAVE_SYNC();
+#if ARB_EIG_WAVE
+                        const T sh_fb = slide_shift_from_eig_wave<T>(WORK, lane);
+#else
                         if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
                         WAVE_SYNC();
-                        if (hq) { shift = WORK[40]; warm = NAN; q_wmove = NAN; }
+                        const T sh_fb = WORK[40];
+#endif
+                        if (hq) { shift = sh_fb; warm = NAN; q_wmove = NAN; }
                         WAVE_SYNC();
                     }
                 }
@@ -956,13 +980,23 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
     T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
-    const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail, int queue_spin_cap)
+    const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail, int queue_spin_cap,
+    T *__restrict__ park_in)
 {
     static_assert(MODE == 0 || FEAT == 3, "the inspect kernels take every input");
     static_assert(CM != 1 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
     static_assert(CM != 2 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && std::is_same<T, float>::value), "three-wave build: float32, one column set");
     static_assert(CM != 3 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && FEAT <= 1 && std::is_same<T, float>::value), "packed build: float32, one column set, plain inputs");
+    static_assert(CM != 4 || (MODE == 0 && NSETS == 1 && NMAX >= 44 && NMAX <= 48 && FEAT <= 1 && std::is_same<T, float>::value), "rendezvous build: float32, one column set, plain inputs");
     constexpr bool PACK = (CM == 3);
+    // CM 4 = the RENDEZVOUS build (round 4): one world per wavefront through phases A-D, FOUR worlds per wavefront in the
+    // Gauss-Seidel sweeps.  Work items are (step, world); a wavefront that has built its world's constraint-space system
+    // parks it (Y', v', forces, the solution columns: ~4 KB) in global memory and counts itself in at its group of four
+    // worlds; the wavefront that arrives LAST fetches the three parked systems, runs the sweeps of all four worlds at once
+    // (gs_stage_n<T, 4>: bit-identical to gs_stage), finishes the step of each (phase E from the parked solution columns),
+    // and publishes the four worlds.  Nobody waits: the other three wavefronts have drawn their next items long before.
+    constexpr bool RDV = (CM == 4);
+    T *const park = RDV ? park_in : nullptr;
     constexpr bool FEAT_EXT = (FEAT & 1) != 0, FEAT_ALL = (FEAT & 2) != 0;
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
     const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
@@ -1037,6 +1071,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                 if (!ready && lane0 == 0) {
                     __hip_atomic_store(mp->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     (void)__hip_atomic_fetch_max(queue + 1 + w, POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (RDV) {        // (its group can never complete this step's rendezvous: nobody of it goes on)
+                        const long g0 = (w / 4) * 4;
+                        for (long wh = g0; wh < g0 + 4 && wh < nunits; ++wh)
+                            (void)__hip_atomic_fetch_max(queue + 1 + wh, POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 if (!QUEUE_LOOP) return;
                 continue;
@@ -1059,7 +1098,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 // (after the first global store the compiler no longer proves the model unclobbered and fetches it with vector
 // loads: readfirstlane puts the wave-uniform values back into SGPRs)
 #define ARB_UNI(x) __builtin_amdgcn_readfirstlane(x)
-#define ARB_LAY() ((CM == 3) ? mp->layp : (CM == 2) ? mp->lay3 : mp->lay)
+#define ARB_LAY() ((CM == 3) ? mp->layp : (CM == 2 || CM == 4) ? mp->lay3 : mp->lay)
 #define ARB_LDS_POINTERS() do { const Layout &lay_ = ARB_LAY();                                                              \
         qs = lds + ARB_UNI(lay_.q); dqs = lds + ARB_UNI(lay_.dq); qd = lds + ARB_UNI(lay_.qd); BD = lds + ARB_UNI(lay_.bd); SC = lds + ARB_UNI(lay_.sc);               \
         PD = reinterpret_cast<double *>(lds + ARB_UNI(lay_.pd)); CD = lds + ARB_UNI(lay_.cd); RT = lds + ARB_UNI(lay_.rt); AM = lds + ARB_UNI(lay_.am);       \
@@ -1170,12 +1209,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
 
     // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
     // columns in RT, then every joint integrates its position.
-    auto integrate_on = [&](const T *RT, const T *FF, const T *FF0, T *qs, T *dqs, bool with_forces) {
+    auto integrate_on = [&](const T *RT, const T *FF, const T *FF0, T *qs, T *dqs, bool with_forces, bool parked = false) {
         T vnew = T(0);
         if (lane < n) {
-            vnew = RT[lane];
+            // (parked: the solution columns wait in global memory, written by another wavefront -- coherent loads)
+            vnew = parked ? ldg(RT + lane) : RT[lane];
             if (with_forces)
-                for (int i = 0; i < ndol; ++i) vnew += RT[(1 + i) * RS + lane] * (FF[i] - FF0[i]);
+                for (int i = 0; i < ndol; ++i) vnew += (parked ? ldg(RT + (1 + i) * RS + lane) : RT[(1 + i) * RS + lane]) * (FF[i] - FF0[i]);
         }
         WAVE_SYNC();
         if (lane < n) {
@@ -1222,6 +1262,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
     }
     if (MODE == 0 && sio.mode != 0 && !(sio.mode & 2)) step_hi = step_lo;      // apply only
 
+    bool rdv_done = false;     // (rendezvous build: this item's step has been handed over / finished with its group)
     for (int step = step_lo; step < step_hi; ++step) {
         T gf0 = T(0);          // controllers' generalized force (inspect output)
         // Packed build: phases A-D for world A (isub 0), then for world B (isub 1), in the same working arrays; each
@@ -1872,7 +1913,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             // registers held across the first pass --, the two-wave kernels through a full table in one)
             // (measured on the 16- and 32-row tiles, whose register peak is the same phase A / B as the 44-row tile's: two passes
             // in their two-wave kernels cost 65 spilled VGPRs and 3-6 %, tools/experiments/forest_rate.py)
-            constexpr bool TWO_PASS = (CM == 2 || CM == 3 || MODE == 1);
+            constexpr bool TWO_PASS = (CM == 2 || CM == 3 || CM == 4 || MODE == 1);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
             const bool lscan = LSCAN_OK && mp->lay.lscan;
             const bool use_table = lscan && TWO_PASS;
@@ -3105,6 +3146,85 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
             break;
         }
 
+        if constexpr (RDV) {
+            ARB_OPAQUE_LANE();
+            auto al4 = [](int x) { return (x + 3) & ~3; };
+            const int nA = al4(ndol * ndol), nD = al4(ndol), nCDp = al4(2 * nc), nRT = (1 + ndol) * RS;
+            const int pVV = nA, pFF = pVV + nD, pFF0 = pFF + nD, pCD = pFF0 + nD, pRT = pCD + nCDp;
+            const long PST = pRT + nRT;                                   // parked floats per world
+            const int t = step;                                           // (one step per item)
+            // ---- park this world's system
+            {
+                T *pw = park + w * PST;
+                for (int i = lane; i < ndol * ndol; i += WAVE) stg(pw + i, AM[i]);
+                if (lane < ndol) { stg(pw + pVV + lane, VV[lane]); stg(pw + pFF + lane, FF[lane]); stg(pw + pFF0 + lane, FF0[lane]); }
+                if (lane < nc) { stg(pw + pCD + 2 * lane, CD[lane * CD_STRIDE + CD_ACTIVE]); stg(pw + pCD + 2 * lane + 1, CD[lane * CD_STRIDE + CD_SDIST]); }
+                for (int i = lane; i < nRT; i += WAVE) stg(pw + pRT + i, RT[i]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the coherent stores above are performed
+            WAVE_SYNC();
+            const long g = w / 4, g0 = 4 * g;
+            const int nv = (int)((nunits - g0 < 4) ? nunits - g0 : 4);    // worlds of this group
+            int old = 0;
+            if (lane0 == 0) old = __hip_atomic_fetch_add(queue + 1 + nunits + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            rdv_done = true;
+            if (old + 1 != nv * (t + 1)) break;                           // not the last of the group: on to the next item
+            asm volatile("" ::: "memory");
+            // ---- the last of its group: the other worlds' systems into LDS slots (two behind Y' in the per-body region,
+            // the third in the space of RT, whose columns are parked), the sweeps of all of them at once
+            const int SS = nA + al4(nc * CD_STRIDE) + 3 * nD;
+            const int myh = (int)(w - g0);
+            const T *AMp[4];
+            T *CDp[4], *VVp[4], *FFp[4], *F0p[4];
+            {
+                int slot = 0;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    if (h == myh || h >= nv) { AMp[h] = AM; CDp[h] = CD; VVp[h] = VV; FFp[h] = FF; F0p[h] = FF0; continue; }
+                    T *b = (slot < 2) ? (AM + nA + slot * SS) : RT;
+                    ++slot;
+                    AMp[h] = b; CDp[h] = b + nA; VVp[h] = CDp[h] + al4(nc * CD_STRIDE); FFp[h] = VVp[h] + nD; F0p[h] = FFp[h] + nD;
+                    const T *ph = park + (g0 + h) * PST;
+                    for (int i = lane; i < ndol * ndol; i += WAVE) b[i] = ldg(ph + i);
+                    if (lane < ndol) { VVp[h][lane] = ldg(ph + pVV + lane); FFp[h][lane] = ldg(ph + pFF + lane); F0p[h][lane] = ldg(ph + pFF0 + lane); }
+                    if (lane < nc) { CDp[h][lane * CD_STRIDE + CD_ACTIVE] = ldg(ph + pCD + 2 * lane); CDp[h][lane * CD_STRIDE + CD_SDIST] = ldg(ph + pCD + 2 * lane + 1); }
+                }
+            }
+            WAVE_SYNC();
+            {
+                const T *const AMc[4] = {AMp[0], AMp[1], AMp[2], AMp[3]};
+                T *const CDc[4] = {CDp[0], CDp[1], CDp[2], CDp[3]}, *const VVc[4] = {VVp[0], VVp[1], VVp[2], VVp[3]},
+                  *const FFc[4] = {FFp[0], FFp[1], FFp[2], FFp[3]};
+                gs_stage_n<T, 4>(mp, lane, nc, ndol, dt, AMc, CDc, VVc, FFc, WORK, nv);
+            }
+            // ---- phase E of every world of the group from its parked solution columns (this wavefront's own world first:
+            // its state is in LDS), the new states and forces to global memory, the four worlds published
+            ARB_OPAQUE_LANE();
+            for (int k = 0; k < nv; ++k) {
+                const int h = (k == 0) ? myh : (k <= myh ? k - 1 : k);
+                const long wh = g0 + h;
+                if (h != myh) {
+                    for (int i = lane; i < nq; i += WAVE) qs[i] = ldg(gq + wh * nq + i);
+                    dqs[lane] = (lane < n) ? ldg(gdq + wh * n + lane) : T(0);
+                    WAVE_SYNC();
+                }
+                const T *fh = (h == 0) ? FFp[0] : (h == 1) ? FFp[1] : (h == 2) ? FFp[2] : FFp[3];
+                const T *f0h = (h == 0) ? F0p[0] : (h == 1) ? F0p[1] : (h == 2) ? F0p[2] : F0p[3];
+                integrate_on(park + wh * PST + pRT, fh, f0h, qs, dqs, true, true);
+                for (int i = lane; i < nq; i += WAVE) stg(gq + wh * nq + i, qs[i]);
+                if (lane < n) stg(gdq + wh * n + lane, dqs[lane]);
+                if (gcforce != nullptr) for (int i = lane; i < ndol; i += WAVE) stg(gcforce + wh * ndol + i, fh[i]);
+                WAVE_SYNC();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WAVE_SYNC();
+            if (lane0 == 0)
+                for (int h = 0; h < nv; ++h)
+                    (void)__hip_atomic_fetch_max(queue + 1 + g0 + h, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+
         if (do_constraints) {
             ARB_STAMP(5);
             ARB_CSTAMP(7);
@@ -3143,6 +3263,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
         }
     }
 
+    if (RDV && rdv_done) {         // (states stored and worlds published by the last wavefront of the group)
+        if (!QUEUE_LOOP) break;
+        continue;
+    }
     // ---- store state -------------------------------------------------------
     ARB_OPAQUE_LANE();
     ARB_STAMP(7);
@@ -3294,6 +3418,38 @@ __global__ __launch_bounds__(WAVE) void arb_softfinger_test_kernel(const double 
     o[8] = (double)br;
 }
 
+// Device unit test of the wavefront's eig6 (test hook arb_dev_eig6_pair): one wavefront per 6x6 matrix, the one-lane
+// routine and the wavefront routine side by side.  out: [n][28] = shift, nfound, wr 6, wi 6 of eig6 | the same of eig6_wave
+template <typename T>
+__global__ __launch_bounds__(WAVE) void arb_eig6_test_kernel(const double *__restrict__ in, double *__restrict__ out, int n)
+{
+    T *lds = reinterpret_cast<T *>(arb_lds_raw);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    T *w0 = lds, *w1 = lds + 48;
+    if (lane < 36) { w0[lane] = (T)in[(size_t)i * 36 + lane]; w1[lane] = w0[lane]; }
+    WAVE_SYNC();
+    double *o = out + (size_t)i * 28;
+    const T sw = slide_shift_from_eig_wave<T>(w1, lane);
+    {
+        T wr[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, wi[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        const int nf = eig6_wave<T>(lane < 36 ? w1[lane] : T(0), lane, wr, wi);
+        if (lane == 5) {
+            o[14] = (double)sw; o[15] = (double)nf;
+            for (int k = 0; k < 6; ++k) { o[16 + k] = (double)wr[k]; o[22 + k] = (double)wi[k]; }
+        }
+    }
+    WAVE_SYNC();
+    if (lane == 0) {
+        T wr[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, wi[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        const int nf = eig6<T>(w0, wr, wi);
+        for (int k = 0; k < 36; ++k) w0[k] = (T)in[(size_t)i * 36 + k];
+        o[0] = (double)slide_shift_from_eig<T>(w0); o[1] = (double)nf;
+        for (int k = 0; k < 6; ++k) { o[2 + k] = (double)wr[k]; o[8 + k] = (double)wi[k]; }
+    }
+}
+
 // ===========================================================================
 // Host side: model upload, launch dispatch, C ABI
 // ===========================================================================
@@ -3405,13 +3561,32 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     // Work queue (see the kernel): multi-step launches of more worlds than the chip has wave slots.  Constraint forces
     // that persist from step to step travel between chunks through `cf`, so it must be there when the model has
     // constraints.  ARB_STEP_STATIC_WORLDS (or ARB_QUEUE_CHUNK=0 in the environment) keeps one workgroup per world.
-    const int chunk = env_int("ARB_QUEUE_CHUNK", 4);
-    const int tail = std::max(0, std::min(env_int("ARB_QUEUE_TAIL", 4), nsteps - 1));
+    // (the rendezvous build, CM = 4: items are single steps, always through the queue)
+    const int chunk = (CM == 4) ? 1 : env_int("ARB_QUEUE_CHUNK", 4);
+    const int tail = (CM == 4) ? 0 : std::max(0, std::min(env_int("ARB_QUEUE_TAIL", 4), nsteps - 1));
     const int spin_cap = env_int("ARB_QUEUE_SPIN_CAP", 1 << 24);
     int *queue = nullptr;
+    T *park = nullptr;
     const long units = (CM == 3) ? (nw + 1) / 2 : nw;        // work units: worlds, or pairs of worlds (packed build)
     unsigned grid = (unsigned)units;
     constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);     // (see the kernel)
+    if constexpr (CM == 4) {
+        if (cf == nullptr || sio.mode != 0 || nw * (long)nsteps >= (1l << 30)) return ARB_ERR_INVALID;     // (launch() checks before it picks this build)
+        auto al4 = [](long x) { return (x + 3) & ~3l; };
+        const long ndol = L.ndol, pst = al4(ndol * ndol) + 3 * al4(ndol) + al4(2 * (ndol / ARB_MAXDOL)) + (1 + ndol) * NMAX;
+        const size_t qbytes = (size_t)(1 + units + (units + 3) / 4) * sizeof(int), pbytes = (size_t)units * pst * sizeof(T);
+        void *blob = nullptr;
+        HIP_TRY(arb_scratch_alloc(&blob, qbytes + 256 + pbytes, st));
+        queue = static_cast<int *>(blob);
+        park = reinterpret_cast<T *>(static_cast<char *>(blob) + ((qbytes + 255) / 256) * 256);
+        if (hipMemsetAsync(queue, 0, qbytes, st) != hipSuccess) { g_hip_err = "hipMemsetAsync(queue)"; (void)hipFreeAsync(blob, st); return ARB_ERR_HIP; }
+        static thread_local size_t slots_lds = ~(size_t)0;
+        static thread_local int slots_dev = -1, slots = 0;
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (slots_lds != lds || slots_dev != dev) { slots = wave_slots(kern, lds); slots_lds = lds; slots_dev = dev; }
+        grid = (unsigned)std::max(1l, std::min((long)(slots > 0 ? slots : 1024), units * (long)nsteps));
+    } else
     if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 &&
         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
         // wave slots of this kernel on the current device, cached per thread for the last (device, LDS size) asked
@@ -3438,7 +3613,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio, dts,
-                       queue, chunk > 0 ? chunk : 1, tail, spin_cap);
+                       queue, chunk > 0 ? chunk : 1, tail, spin_cap, park);
     const hipError_t le = hipGetLastError();
     if (queue != nullptr) {
         const hipError_t fe = hipFreeAsync(queue, st);         // (also after a failed launch: nothing leaks)
@@ -3472,6 +3647,10 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 2>(ARB_LAUNCH_ONE_AR
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#if ARB_WITH_RDV
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 4>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 4>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#endif
 #endif
 #endif
 #else
@@ -3496,8 +3675,15 @@ ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_
     extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<float, NM, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<float, NM, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));
-ARB_EXTERN_TILE_W3(16) ARB_EXTERN_TILE_W3(32) ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
+ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
 #undef ARB_EXTERN_TILE_W3
+#if ARB_WITH_RDV
+#define ARB_EXTERN_TILE_RDV(NM)                                                         \
+    extern template int launch_one<float, NM, 1, 0, 0, 4>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 1, 4>(ARB_LAUNCH_ONE_ARGS(float));
+ARB_EXTERN_TILE_RDV(44) ARB_EXTERN_TILE_RDV(48)
+#undef ARB_EXTERN_TILE_RDV
+#endif
 ARB_EXTERN_TILE(float, 16) ARB_EXTERN_TILE(float, 32) ARB_EXTERN_TILE(float, 44) ARB_EXTERN_TILE(float, 48) ARB_EXTERN_TILE(float, 64)
 ARB_EXTERN_TILE(double, 16) ARB_EXTERN_TILE(double, 32) ARB_EXTERN_TILE(double, 44) ARB_EXTERN_TILE(double, 48) ARB_EXTERN_TILE(double, 64)
 #undef ARB_EXTERN_TILE
@@ -3533,6 +3719,7 @@ struct arb_model {
     DevModel<float> *df_dev;
     DevModel<double> *dd_dev;
     bool packable = false;         // every constraint a SoftFingerContact with eps = (1,1,1), at most eight: two worlds per wavefront in the sweeps
+    bool rdv_ok = false;           // ... at most FOUR, and the three-wave layout holds three more systems: the rendezvous build (CM = 4)
     int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
     Layout lf, lf3, lfp, ld;       // LDS layouts: float32 two-wave kernels, three-wave kernels, packed kernels; float64
     // Small worlds: `forest_k` independent copies of the model as ONE model (copy k owns bodies k nb.., dofs k n.., position
@@ -3948,6 +4135,14 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
     M->lf3 = M->df.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true);
     M->lfp = M->df.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true, true);
+    {
+        // the rendezvous build keeps three more constraint-space systems in the three-wave layout: two behind Y' in the
+        // per-body region, one in the space of RT
+        auto al4 = [](int x) { return (x + 3) & ~3; };
+        const int nA = al4(ndol * ndol), SS = nA + al4(nc * CD_STRIDE) + 3 * al4(ndol);
+        const int bdr = bd_region_elems(nb, M->nmax, ndol, 2, true), rtr = std::max(1 + ndol, 12) * M->nmax;
+        M->rdv_ok = M->packable && nc <= 4 && M->nsets == 1 && M->nmax >= 44 && M->nmax <= 48 && nA + 2 * SS <= bdr && SS <= rtr;
+    }
     M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     {
@@ -4074,7 +4269,7 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 // Which build of the float32 production kernel runs a launch (models with one column set and a tile of up to 48 rows;
 // every other model has the two-wave build only)?  The builds are bit-identical (-ffp-contract=on): a pure performance
 // decision, also reported by arb_step_plan.
-struct BuildChoice { bool w3 = false, pack = false; long slots2 = 0, slots3 = 0, slotsp = 0; };
+struct BuildChoice { bool w3 = false, pack = false, rdv = false; long slots2 = 0, slots3 = 0, slotsp = 0; };
 static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nsteps, unsigned flags) {
     BuildChoice bc;
     // (tiles of 44 and 48 rows.  The 16- and 32-row kernels use ~100 VGPRs less: their two-wave build has no spills and
@@ -4103,6 +4298,14 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     const int force = env_int("ARB_FORCE_WAVES", 0);
     if (force == 2) bc.w3 = false;
     if (force == 3) bc.w3 = true;
+    // Rendezvous build (four worlds per wavefront in the sweeps, CM = 4): multi-step launches of models that qualify.
+    // ARB_FORCE_RDV=0|1 in the environment overrides (development).
+    if (ARB_WITH_RDV && M->rdv_ok && noopt && nsteps >= 2 && !(flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3 | ARB_STEP_STATIC_WORLDS))) {
+        bc.rdv = ARB_RDV_DEFAULT != 0 && 10 * nw >= 11 * s3;
+        const int fr = env_int("ARB_FORCE_RDV", -1);
+        if (fr == 0) bc.rdv = false;
+        if (fr == 1) bc.rdv = true;
+    }
     // Two worlds per wavefront (the packed build: the sweeps of both worlds in one instruction stream): models whose
     // constraints are all SoftFingerContacts with eps = (1,1,1), plain inputs or user torques, a stash that still leaves
     // eight wavefronts per CU, and a batch large enough that pairs of worlds fill and balance the wave slots (measured,
@@ -4138,8 +4341,13 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
     const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma) ? choose_build(M, noopt, nw, nsteps, flags) : BuildChoice();
-    const bool w3 = bc.w3, pack = bc.pack;
-#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : (CMV) == 2 ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
+    const bool w3 = bc.w3, pack = bc.pack, rdv = bc.rdv && cf != nullptr && nw * (long)nsteps < (1l << 30);
+#if ARB_WITH_RDV
+#define ARB_RDV_CASE(NM) if (rdv) return plain ? ONE_(NM, 1, 0, 4) : ONE_(NM, 1, 1, 4);
+#else
+#define ARB_RDV_CASE(NM) (void)rdv;
+#endif
+#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
@@ -4147,6 +4355,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     if constexpr (std::is_same<T, float>::value) {
         if (M->nmax == 44 && M->nsets == 1) {
             if constexpr (MODE == 0) {
+                ARB_RDV_CASE(44)
                 if (pack) return plain ? ONE_(44, 1, 0, 3) : ONE_(44, 1, 1, 3);
                 if (w3 && plain) return ONE_(44, 1, 0, 2);
                 if (w3 && noopt) return ONE_(44, 1, 1, 2);
@@ -4175,6 +4384,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
             if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 3, 1) : ONE_(NM, 1, 3, 1);                  \
         }                                                                                              \
         if constexpr (MODE == 0 && std::is_same<T, float>::value && NM >= 44 && NM <= 48) {            \
+            ARB_RDV_CASE(NM)                                                                           \
             if (pack) return plain ? ONE_(NM, 1, 0, 3) : ONE_(NM, 1, 1, 3);                            \
             if (w3) return plain ? ONE_(NM, 1, 0, 2) : noopt ? ONE_(NM, 1, 1, 2) : ONE_(NM, 1, 3, 2);  \
         }                                                                                              \
@@ -4483,6 +4693,25 @@ extern "C" int arb_dev_softfinger_solve(int dtype, int device, int n, const doub
         hipLaunchKernelGGL(arb_softfinger_test_kernel<float>, dim3(grid), dim3(WAVE), WAVE * 41 * sizeof(float), 0, din, dout, n, use_fast);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(dout);
+    return ARB_OK;
+}
+
+// eig6 (one lane, matrix in LDS) and eig6_wave (the whole wavefront) on the same matrices, see arb_eig6_test_kernel
+extern "C" int arb_dev_eig6_pair(int dtype, int device, int n, const double *A /*[n][36]*/, double *out /*[n][28]*/) {
+    if (!A || !out || n <= 0 || (dtype != ARB_F32 && dtype != ARB_F64)) return ARB_ERR_INVALID;
+    ARB_GUARD_DEVICE(device);
+    double *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&din, sizeof(double) * 36 * (size_t)n));
+    HIP_TRY(hipMalloc(&dout, sizeof(double) * 28 * (size_t)n));
+    HIP_TRY(hipMemcpy(din, A, sizeof(double) * 36 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dout, 0, sizeof(double) * 28 * (size_t)n));
+    if (dtype == ARB_F64)
+        hipLaunchKernelGGL(arb_eig6_test_kernel<double>, dim3((unsigned)n), dim3(WAVE), 96 * sizeof(double), 0, din, dout, n);
+    else
+        hipLaunchKernelGGL(arb_eig6_test_kernel<float>, dim3((unsigned)n), dim3(WAVE), 96 * sizeof(float), 0, din, dout, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 28 * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(din); (void)hipFree(dout);
     return ARB_OK;
 }

@@ -795,6 +795,265 @@ ARB_HD int eig6(AP a, T wr[6], T wi[6]) {
     return found;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---------------------------------------------------------------------------
+// eig6 by a whole WAVEFRONT (round 4).  The generic route is rare (9-20 of 270 k sliding solves of a step) but one lane
+// working on a matrix in LDS pays an LDS round trip for every operand the next operation waits for: ~180 k cycles per
+// matrix, and the world that needs it holds up a one-step launch (and is the critical path of a short episode).  Here
+// lane 6 i + j holds E(i, j) in a register; the scalars of the iteration (shifts, the reflector) are formed by every
+// lane alike from v_readlane broadcasts, its decisions go through the scalar unit (v_readfirstlane), and the row /
+// column operations run on the lanes that own the elements, their operands gathered with ds_bpermute (the LDS
+// crossbar without a memory access).  Element by element and scalar by scalar the operations -- and the expressions
+// they are written as -- are those of eig6 above: bit-identical eigenvalues (tests/test_gpu_device_solve.py compares
+// the two on the device).  All 64 lanes must be active.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wv_lane(T v, int src /* wave-uniform */) {
+    if constexpr (sizeof(T) == 4) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+    } else {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+}
+template <typename T>
+__device__ __forceinline__ T wv_gather(T v, int src /* per lane */) {
+    if constexpr (sizeof(T) == 4) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+    } else {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)(b & 0xffffffffll));
+        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+}
+
+// `a`: this lane's element (lanes 36..63: anything).  Eigenvalues in wr / wi (every lane the same values).
+template <typename T>
+__device__ __forceinline__ int eig6_wave(T a, int lane, T wr[6], T wi[6]) {
+#define EL(i, j) wv_lane<T>(a, 6 * (i) + (j))
+#define UNI(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
+#define WSTORE(idx, re, im)                                                                         \
+    do {                                                                                            \
+        _Pragma("unroll") for (int e_ = 0; e_ < 6; ++e_)                                            \
+            if (e_ == (idx)) { wr[e_] = (re); wi[e_] = (im); }                                      \
+    } while (0)
+    const bool in = lane < 36;
+    const int ri = in ? lane / 6 : 8, cj = in ? lane - 6 * (lane / 6) : 8;      // (8: matches no row / column)
+    if (__builtin_amdgcn_ballot_w64(in && !(a - a == T(0))) != 0ull) return 0;
+    // --- balance ---
+    {
+        const T RADIX = T(2), sqrdx = T(4);
+        bool last = false;
+        int guard = 0;
+        while (!last && guard++ < 64) {
+            last = true;
+            for (int i = 0; i < 6; ++i) {
+                T r = T(0), c = T(0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const T ec = arb_abs(EL(j, i)), er = arb_abs(EL(i, j));
+                    if (j != i) { c += ec; r += er; }
+                }
+                if (UNI(c != T(0) && r != T(0))) {
+                    T g = r / RADIX, f = T(1), s = c + r;
+                    for (int cap = 0; UNI(c < g) && cap < 1100; ++cap) { f *= RADIX; c *= sqrdx; }
+                    g = r * RADIX;
+                    for (int cap = 0; UNI(c > g) && cap < 1100; ++cap) { f /= RADIX; c /= sqrdx; }
+                    if (UNI((c + r) / f < T(0.95) * s)) {
+                        last = false;
+                        g = T(1) / f;
+                        if (ri == i) a *= g;
+                        if (cj == i) a *= f;
+                    }
+                }
+            }
+        }
+    }
+    // --- Hessenberg form ---
+    for (int m = 1; m < 5; ++m) {
+        T x = T(0);
+        int iv = m;
+#pragma unroll
+        for (int j = 1; j < 6; ++j) {
+            const T e = EL(j < m ? m : j, m - 1);
+            if (j >= m && arb_abs(e) > arb_abs(x)) { x = e; iv = j; }
+        }
+        const int i = __builtin_amdgcn_readfirstlane(iv);
+        if (i != m) {
+            {
+                const int sr = (ri == i) ? m : (ri == m) ? i : ri;
+                const T g = wv_gather<T>(a, sr * 6 + cj);
+                if ((ri == i || ri == m) && cj >= m - 1 && cj < 6) a = g;
+            }
+            {
+                const int sc = (cj == i) ? m : (cj == m) ? i : cj;
+                const T g = wv_gather<T>(a, ri * 6 + sc);
+                if (in && (cj == i || cj == m)) a = g;
+            }
+        }
+        if (UNI(x != T(0))) {
+            for (int i2 = m + 1; i2 < 6; ++i2) {
+                T y = EL(i2, m - 1);
+                if (UNI(y != T(0))) {
+                    y /= x;
+                    if (lane == 6 * i2 + m - 1) a = y;
+                    const T em = wv_gather<T>(a, 6 * m + cj);
+                    if (ri == i2 && cj >= m && cj < 6) a = a - y * em;
+                    const T ei = wv_gather<T>(a, 6 * ri + i2);
+                    if (cj == m && ri < 6) a = a + y * ei;
+                }
+            }
+        }
+    }
+    if (in && ri >= 2 && cj < ri - 1) a = T(0);
+    // --- shifted QR ---
+    T anorm = T(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = (i > 0 ? i - 1 : 0); j < 6; ++j) anorm += arb_abs(EL(i, j));
+    int nn = 5, found = 0;
+    T t = T(0);
+    T p = T(0), q = T(0), r = T(0);
+    int total_its = 0;
+    while (nn >= 0) {
+        int its = 0, l;
+        do {
+            if (++total_its > 600) return found;
+            for (l = nn; l >= 1; --l) {
+                T s = arb_abs(EL(l - 1, l - 1)) + arb_abs(EL(l, l));
+                if (s == T(0)) s = anorm;
+                if (UNI((T)(arb_abs(EL(l, l - 1)) + s) == s)) { if (lane == 6 * l + l - 1) a = T(0); break; }
+            }
+            T x = EL(nn, nn);
+            if (l == nn) {
+                WSTORE(nn, x + t, T(0)); --nn; ++found;
+            } else {
+                T y = EL(nn - 1, nn - 1);
+                T w = EL(nn, nn - 1) * EL(nn - 1, nn);
+                if (l == nn - 1) {
+                    p = T(0.5) * (y - x);
+                    q = p * p + w;
+                    T z = arb_sqrt(arb_abs(q));
+                    x += t;
+                    if (UNI(q >= T(0))) {
+                        z = p + (p >= T(0) ? arb_abs(z) : -arb_abs(z));
+                        T w0 = x + z, w1 = x + z;
+                        if (UNI(z != T(0))) w1 = x - w / z;
+                        WSTORE(nn - 1, w0, T(0)); WSTORE(nn, w1, T(0));
+                    } else {
+                        WSTORE(nn - 1, x + p, -z); WSTORE(nn, x + p, z);
+                    }
+                    nn -= 2; found += 2;
+                } else {
+                    if (its >= 60) return found;
+                    if (its == 10 || its == 20) {
+                        t += x;
+                        if (in && ri == cj && ri <= nn) a -= x;
+                        T s = arb_abs(EL(nn, nn - 1)) + arb_abs(EL(nn - 1, nn - 2));
+                        y = x = T(0.75) * s;
+                        w = T(-0.4375) * s * s;
+                    }
+                    ++its;
+                    int m;
+                    T z;
+                    for (m = nn - 2; m >= l; --m) {
+                        z = EL(m, m);
+                        r = x - z;
+                        T s = y - z;
+                        p = (r * s - w) / EL(m + 1, m) + EL(m, m + 1);
+                        q = EL(m + 1, m + 1) - z - r - s;
+                        r = EL(m + 2, m + 1);
+                        s = arb_abs(p) + arb_abs(q) + arb_abs(r);
+                        p /= s; q /= s; r /= s;
+                        if (m == l) break;
+                        T u = arb_abs(EL(m, m - 1)) * (arb_abs(q) + arb_abs(r));
+                        T v = arb_abs(p) * (arb_abs(EL(m - 1, m - 1)) + arb_abs(z) + arb_abs(EL(m + 1, m + 1)));
+                        if (UNI((T)(u + v) == v)) break;
+                    }
+                    if (in && ri >= m + 2 && ri <= nn && (cj == ri - 2 || (ri != m + 2 && cj == ri - 3))) a = T(0);
+                    for (int k = m; k <= nn - 1; ++k) {
+                        if (k != m) {
+                            p = EL(k, k - 1);
+                            q = EL(k + 1, k - 1);
+                            r = T(0);
+                            if (k != nn - 1) r = EL(k + 2, k - 1);
+                            x = arb_abs(p) + arb_abs(q) + arb_abs(r);
+                            if (UNI(x != T(0))) { p /= x; q /= x; r /= x; }
+                        }
+                        T s = arb_sqrt(p * p + q * q + r * r);
+                        if (p < T(0)) s = -s;
+                        if (UNI(s != T(0))) {
+                            if (k == m) {
+                                if (l != m && lane == 6 * k + k - 1) a = -a;
+                            } else {
+                                if (lane == 6 * k + k - 1) a = -s * x;
+                            }
+                            p += s;
+                            x = p / s; y = q / s; z = r / s;
+                            q /= p; r /= p;
+                            const bool three = k != nn - 1;
+                            const int k2 = three ? k + 2 : k + 1;
+                            {
+                                const T e0 = wv_gather<T>(a, 6 * k + cj), e1 = wv_gather<T>(a, 6 * (k + 1) + cj),
+                                        e2 = wv_gather<T>(a, 6 * k2 + cj);
+                                if (cj >= k && cj <= nn) {
+                                    T pp = e0 + q * e1;
+                                    if (three) pp += r * e2;
+                                    if (three && ri == k2) a = e2 - pp * z;
+                                    if (ri == k + 1) a = e1 - pp * y;
+                                    if (ri == k) a = e0 - pp * x;
+                                }
+                            }
+                            const int mmin = nn < k + 3 ? nn : k + 3;
+                            {
+                                const T c0 = wv_gather<T>(a, 6 * ri + k), c1 = wv_gather<T>(a, 6 * ri + k + 1),
+                                        c2 = wv_gather<T>(a, 6 * ri + k2);
+                                if (ri >= l && ri <= mmin) {
+                                    T pp = x * c0 + y * c1;
+                                    if (three) pp += z * c2;
+                                    if (three && cj == k2) a = c2 - pp * r;
+                                    if (cj == k + 1) a = c1 - pp * q;
+                                    if (cj == k) a = c0 - pp;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } while (l < nn - 1);
+    }
+#undef EL
+#undef UNI
+#undef WSTORE
+    return found;
+}
+
+// slide_shift_from_eig (below) with the wavefront's eig6: `work` holds the 6x6 matrix (LDS, written and synchronised
+// by the caller); every lane returns the shift.
+template <typename T, typename AP>
+__device__ __forceinline__ T slide_shift_from_eig_wave(AP work, int lane) {
+    T wr[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, wi[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    const T a = lane < 36 ? work[lane] : T(0);
+    const int nf = eig6_wave<T>(a, lane, wr, wi);
+    bool any = false;
+    T smin = T(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        bool ok = (i >= 6 - nf) && (wi[i] == T(0)) && (wr[i] <= T(0));
+        if (ok) { smin = any ? (wr[i] < smin ? wr[i] : smin) : wr[i]; any = true; }
+    }
+    return any ? (smin > T(-1e10) ? smin : T(-1e10)) : T(-1e10);   // constraints.py:827-830
+}
+#elif defined(__HIPCC__)
+// (host pass of the kernel sources: declared, never called)
+template <typename T> __device__ int eig6_wave(T a, int lane, T wr[6], T wi[6]);
+template <typename T, typename AP> __device__ T slide_shift_from_eig_wave(AP work, int lane);
+#endif
+
 // ---------------------------------------------------------------------------
 // Sliding-friction shift `s` of SoftFingerContact.solve (constraints.py:803-830):
 // the smallest real non-positive eigenvalue of the 6x6 matrix

@@ -38,6 +38,10 @@ int arb_host_softfinger_solve(int dtype, const double *vel, const double *adm, d
 /* The same solve executed ON THE DEVICE, one lane per tuple (needs a GPU): in [n][27] = vel 4 | adm 16 | force 4 |
  * sdist, dt, mu;  out [n][9] = force 4 | dforce 4 | branch.  Returns an ARB_* status. */
 int arb_dev_softfinger_solve(int dtype, int device, int n, const double *in, double *out);
+/* The generic 6x6 eigenvalue route of the sliding solve on the device, n matrices [n][36] row-major: the one-lane routine
+ * and the wavefront routine (arb_math.h: eig6, eig6_wave) side by side; out [n][28] = shift, number found, wr[6], wi[6]
+ * of the first, then of the second.  The kernels run the second; the two must agree bit for bit. */
+int arb_dev_eig6_pair(int dtype, int device, int n, const double *A, double *out);
 
 /* Raw branch code of the first stage of the solve: 0, 1, 2 as above, 3 = sliding but the register-only shift
  * declined and the 6x6 eigenvalue fallback is needed. */

@@ -161,3 +161,66 @@ def test_device_solve_on_1e5_harvested_tuples_f32(harvested):
     assert (np.minimum(dev[sub, 8], 2) == np.minimum(host[:, 8], 2)).mean() > 0.999
     eq = np.minimum(dev[sub, 8], 2) == np.minimum(host[:, 8], 2)
     assert (np.abs(dev[sub, :8] - host[:, :8]).max(axis=1) / hs)[eq].max() < 1e-3
+
+
+def _eig_matrices(canary_tuples, n_random=3000):
+    """6x6 matrices for the generic eigenvalue route: the sliding solves' own B (constraints.py:818-824) of the canary
+    trace, random dense matrices over twelve decades, matrices with repeated / complex / zero eigenvalues, a non-finite one."""
+    rng = np.random.default_rng(77)
+    mats = []
+    tuples, _ = canary_tuples
+    for t in tuples:
+        Y = t[4:20].reshape(4, 4)
+        alpha = t[0:4] - Y @ t[20:24]
+        alpha[3] += t[24] / t[25]
+        mu, yn, Yc = t[26], Y[3, 3], Y[:3, 3]
+        a = mu / yn * alpha[3]
+        if a == 0.:
+            continue
+        beta, b = alpha[:3] - alpha[3] / yn * Yc, mu / yn * Yc
+        Yh = Y[:3, :3] - (Yc @ Yc) / yn
+        B = np.zeros((6, 6))
+        B[:3, :3] = Yh + 2. / a * (beta @ b)
+        B[3:, 3:] = Yh
+        B[:3, 3:] = -np.eye(3) * (beta @ beta) / a ** 2
+        B[3:, :3] = np.eye(3) * ((b @ b) - 1.)
+        mats.append(B)
+    for k in range(n_random):
+        A = rng.normal(size=(6, 6)) * 10. ** rng.uniform(-6, 6, size=(6, 1 if k % 3 else 6))
+        if k % 7 == 0:
+            A = A + A.T                                   # real spectrum
+        if k % 11 == 0:
+            A[rng.integers(6)] = 0.                       # a zero row: the balance step's c, r == 0 cases
+        if k % 13 == 0:
+            A = np.triu(A)                                # nothing to iterate on
+        if k % 17 == 0:
+            Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+            A = Q @ np.diag([1., 1., 1., -2., -2., 3.]) @ Q.T     # repeated eigenvalues
+        mats.append(A)
+    mats.append(np.zeros((6, 6)))
+    mats.append(np.eye(6))
+    bad = rng.normal(size=(6, 6)); bad[2, 3] = np.inf
+    mats.append(bad)
+    return np.ascontiguousarray(np.array(mats))
+
+
+@pytest.mark.parametrize("dtype", [_capi.ARB_F32, _capi.ARB_F64])
+def test_wavefront_eig6_is_the_one_lane_eig6_bit_for_bit(canary_tuples, dtype):
+    """The kernels run the generic 6x6 eigenvalue route on the whole wavefront (arb_math.h: eig6_wave, round 4); the
+    one-lane routine is the host-tested restatement of the EISPACK sequence (tests/test_capi_cpu.py against numpy)."""
+    assert torch.cuda.is_available()
+    lib = _capi.load()
+    A = _eig_matrices(canary_tuples)
+    out = np.full((len(A), 28), np.nan)
+    _capi.check(lib.arb_dev_eig6_pair(dtype, 0, len(A), _capi._dp(A), _capi._dp(out)))
+    one, wave = out[:, :14], out[:, 14:]
+    assert np.array_equal(one[:, 1], wave[:, 1])                         # eigenvalues found
+    assert (one[:-1, 1] == 6).mean() > 0.99 and one[-1, 1] == 0          # (the non-finite matrix: none)
+    same = (one.view(np.uint64) == wave.view(np.uint64)).all(axis=1)
+    assert same.all(), (int((~same).sum()), one[~same][:2], wave[~same][:2])
+    # and it IS an eigenvalue routine: float64 against numpy on the well-conditioned symmetric cases
+    if dtype == _capi.ARB_F64:
+        for k in range(len(A) - 3):
+            if np.allclose(A[k], A[k].T) and np.isfinite(A[k]).all() and np.abs(A[k]).max() > 0:
+                ref = np.sort(np.linalg.eigvalsh(A[k]))
+                assert np.abs(np.sort(wave[k, 2:8]) - ref).max() <= 1e-9 * np.abs(ref).max()
