@@ -85,22 +85,38 @@ EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_
             "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_step_plan", "arb_step", "arb_step_ex", "arb_rollout",
             "arb_inspect"]
 # every symbol include/arbstep_hooks.h declares: host builds of the device math (unit tests, Constraint.solve)
-TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
+TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_build_variants", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
               "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
 
 _lib = None
+_variants = None
+VARIANTS_PATH = os.path.join(_HERE, "libarbstep_variants.so")
 
 
 def load():
     """Load libarbstep.so once; raise RuntimeError if it has not been built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+def load_variants():
+    """The library of the build variants no launch of libarbstep.so selects (packed pairs, the rendezvous build;
+    `make -C arboris_python_amd/csrc variants`, float32 / 44-row kernels only): loaded by the tests that hold those
+    builds bit-identical to the shipped ones (``BatchedWorlds(model, lib=_capi.load_variants())``)."""
+    global _variants
+    if _variants is None:
+        _variants = _open(VARIANTS_PATH)
+    return _variants
+
+
+def _open(path):
+    if not os.path.exists(path):
         raise RuntimeError(
-            "libarbstep.so is not built (%s missing). Build it with "
-            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C arboris_python_amd/csrc`. "
-            "There is no CPU fallback for the step." % LIB_PATH)
+            "%s is not built (%s missing). Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C arboris_python_amd/csrc [variants]`. "
+            "There is no CPU fallback for the step." % (os.path.basename(path), path))
     # The state lives in torch tensors, so the process must run on ONE HIP runtime: torch's wheel bundles its
     # own libamdhip64.so.7, and libarbstep.so needs that soname too.  Whichever is loaded first serves both;
     # if libarbstep.so came first it would pull /opt/rocm's copy, torch would then load a second runtime and
@@ -109,7 +125,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:                                # pragma: no cover - symbol checks still work without torch
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.arb_abi_version.restype = C.c_int
     lib.arb_strerror.restype = C.c_char_p
     lib.arb_strerror.argtypes = [C.c_int]
@@ -144,6 +160,8 @@ def load():
     lib.arb_host_softfinger_try.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, _PD]
     lib.arb_host_slide_root.restype = C.c_int
     lib.arb_host_slide_root.argtypes = [_PD, C.c_double, C.c_double, C.c_double, _PD]
+    lib.arb_build_variants.restype = C.c_int
+    lib.arb_build_variants.argtypes = []
     lib.arb_dev_eig6_pair.restype = C.c_int
     lib.arb_dev_eig6_pair.argtypes = [C.c_int, C.c_int, C.c_int, _PD, _PD]
     lib.arb_host_eig6.restype = C.c_int
@@ -159,8 +177,7 @@ def load():
     lib.arb_host_narrow_phase.restype = C.c_double
     lib.arb_host_narrow_phase.argtypes = [C.c_int, _PD, _PD, C.c_double, C.c_double, _PD, _PD, _PD, _PD, _PD]
     if lib.arb_abi_version() != ARB_ABI_VERSION:
-        raise RuntimeError("libarbstep.so ABI version mismatch")
-    _lib = lib
+        raise RuntimeError("%s: ABI version mismatch" % os.path.basename(path))
     return lib
 
 

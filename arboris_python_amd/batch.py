@@ -24,7 +24,7 @@ class BatchedWorlds(object):
     ``model`` is a ``FlatModel`` or an initialised ``core.World``.
     """
 
-    def __init__(self, model, device=0):
+    def __init__(self, model, device=0, lib=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedWorlds needs a HIP device (torch.cuda.is_available() is False); "
@@ -34,7 +34,7 @@ class BatchedWorlds(object):
         self.model = model
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
-        self._lib = _capi.load()
+        self._lib = lib if lib is not None else _capi.load()      # (lib: another build of the library, tests)
         desc, keep = _capi.make_desc(model)
         handle = C.c_void_p()
         _capi.check(self._lib.arb_model_create(C.byref(desc), self.device_index, C.byref(handle)))

@@ -83,8 +83,14 @@
 // to the other builds; measured -1.2 % at 65 536 worlds, +0.5 % at 16 384, -9 % on config 5, -44 % at 4096 worlds (the
 // sliding root finder of four worlds costs what the slowest needs, single-step items cost 2.7 %, 28 KB of parked
 // state per world-step): compiled only with -DARB_WITH_RDV=1, selected only with ARB_FORCE_RDV=1 in the environment.
+// ARB_ALL_VARIANTS (make variants -> libarbstep_variants.so): the two build variants no launch of the shipped library
+// selects -- packed pairs (CM = 3, ARB_FORCE_PACK=1) and the rendezvous build -- compiled for the tests that hold them
+// bit-identical to the shipped builds (tests/test_gpu_round3.py); the default library carries neither.
+#ifndef ARB_ALL_VARIANTS
+#define ARB_ALL_VARIANTS 0
+#endif
 #ifndef ARB_WITH_RDV
-#define ARB_WITH_RDV 0
+#define ARB_WITH_RDV ARB_ALL_VARIANTS
 #endif
 #ifndef ARB_RDV_DEFAULT
 #define ARB_RDV_DEFAULT 0
@@ -3645,8 +3651,10 @@ template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 3, 1>(ARB_LAUNCH_ONE_AR
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#if ARB_ALL_VARIANTS
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
+#endif
 #if ARB_WITH_RDV
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 4>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 4>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
@@ -3672,11 +3680,16 @@ ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_
 #define ARB_EXTERN_TILE_W3(NM)                                                          \
     extern template int launch_one<float, NM, 1, 0, 0, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<float, NM, 1, 0, 1, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
-    extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
-    extern template int launch_one<float, NM, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
-    extern template int launch_one<float, NM, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));
+    extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));
 ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
 #undef ARB_EXTERN_TILE_W3
+#if ARB_ALL_VARIANTS
+#define ARB_EXTERN_TILE_PK(NM)                                                          \
+    extern template int launch_one<float, NM, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));
+ARB_EXTERN_TILE_PK(44) ARB_EXTERN_TILE_PK(48)
+#undef ARB_EXTERN_TILE_PK
+#endif
 #if ARB_WITH_RDV
 #define ARB_EXTERN_TILE_RDV(NM)                                                         \
     extern template int launch_one<float, NM, 1, 0, 0, 4>(ARB_LAUNCH_ONE_ARGS(float));  \
@@ -4311,7 +4324,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     // eight wavefronts per CU, and a batch large enough that pairs of worlds fill and balance the wave slots (measured,
     // three-wave / packed: 4096 worlds 18.2 / 16.8, 8192: 19.3 / 19.4, 16384: 19.6 / 20.0, 65536: 20.0 / 20.4).
     // ARB_FORCE_PACK=0|1 in the environment overrides the batch-size rule (development).
-    if (M->packable && noopt && M->lfp.lscan) {
+    if (ARB_ALL_VARIANTS && M->packable && noopt && M->lfp.lscan) {
         const long ldsp = (long)M->lfp.total * 4 + pad;
         const long sp = (long)cus * slots_per_cu(2, ldsp);
         bc.slotsp = sp;
@@ -4347,6 +4360,11 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #else
 #define ARB_RDV_CASE(NM) (void)rdv;
 #endif
+#if ARB_ALL_VARIANTS
+#define ARB_PACK_CASE(NM) if (pack) return plain ? ONE_(NM, 1, 0, 3) : ONE_(NM, 1, 1, 3);
+#else
+#define ARB_PACK_CASE(NM) (void)pack;
+#endif
 #define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
@@ -4356,7 +4374,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         if (M->nmax == 44 && M->nsets == 1) {
             if constexpr (MODE == 0) {
                 ARB_RDV_CASE(44)
-                if (pack) return plain ? ONE_(44, 1, 0, 3) : ONE_(44, 1, 1, 3);
+                ARB_PACK_CASE(44)
                 if (w3 && plain) return ONE_(44, 1, 0, 2);
                 if (w3 && noopt) return ONE_(44, 1, 1, 2);
                 if (plain) return ONE(44, 1, 0);
@@ -4385,7 +4403,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         }                                                                                              \
         if constexpr (MODE == 0 && std::is_same<T, float>::value && NM >= 44 && NM <= 48) {            \
             ARB_RDV_CASE(NM)                                                                           \
-            if (pack) return plain ? ONE_(NM, 1, 0, 3) : ONE_(NM, 1, 1, 3);                            \
+            ARB_PACK_CASE(NM)                                                                          \
             if (w3) return plain ? ONE_(NM, 1, 0, 2) : noopt ? ONE_(NM, 1, 1, 2) : ONE_(NM, 1, 3, 2);  \
         }                                                                                              \
         if constexpr (MODE == 0) {                                                                     \
@@ -4696,6 +4714,9 @@ extern "C" int arb_dev_softfinger_solve(int dtype, int device, int n, const doub
     (void)hipFree(din); (void)hipFree(dout);
     return ARB_OK;
 }
+
+// build variants compiled into this library: bit 0 packed pairs (ARB_FORCE_PACK=1), bit 1 the rendezvous build (ARB_FORCE_RDV=1)
+extern "C" int arb_build_variants(void) { return (ARB_ALL_VARIANTS ? 1 : 0) | (ARB_WITH_RDV ? 2 : 0); }
 
 // eig6 (one lane, matrix in LDS) and eig6_wave (the whole wavefront) on the same matrices, see arb_eig6_test_kernel
 extern "C" int arb_dev_eig6_pair(int dtype, int device, int n, const double *A /*[n][36]*/, double *out /*[n][28]*/) {

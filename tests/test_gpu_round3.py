@@ -25,6 +25,7 @@ import pytest
 
 import arb_oracle as O
 from conftest import load_model, ROOT
+from arboris_python_amd import _capi
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -348,25 +349,29 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
 @pytest.mark.parametrize("name,cases", [
     ("human36_c4", ((701, 40, False, False), (5001, 24, False, False), (2, 12, False, True), (1, 12, False, False),
                     (333, 12, True, True), (9001, 13, False, True))),
-    ("human36_c8", ((257, 24, False, False),)),           # 32 constraint rows: each world fills its half of the wavefront
-])
+])   # (8 contacts: two column sets, no packed step kernel -- its packed SWEEPS are test_packed_sweeps_equal_unpacked_bitwise)
 def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, cases):
     """The packed build of the step kernel (two worlds per wavefront: phases A-D world after world, the Gauss-Seidel
-    sweeps of both at once, ARB_FORCE_PACK=1) against the one-world builds (ARB_FORCE_PACK=0): states and forces bit
-    for bit -- one workgroup per pair and the work queue over pairs, odd batch sizes, a lone world, user torques (the
-    FEAT 1 kernel), one launch per step."""
+    sweeps of both at once; libarbstep_variants.so with ARB_FORCE_PACK=1) against the one-world builds of the shipped
+    library: states and forces bit for bit -- one workgroup per pair and the work queue over pairs, odd batch sizes, a
+    lone world, user torques (the FEAT 1 kernel), one launch per step."""
     from arboris_python_amd import synth
     from arboris_python_amd.batch import BatchedWorlds
     m, _, _ = load_model(name)
-    bw = BatchedWorlds(m)
+    variants = _capi.load_variants()
+    assert variants.arb_build_variants() & 1 and _capi.load().arb_build_variants() == 0
+    bws = {"0": BatchedWorlds(m), "1": BatchedWorlds(m, lib=variants)}
     for B, T, per_step, ext in cases:
         q, dq = synth.world_states(m, range(B), "standing", 31, drop=0.03, vel=0.2)
         q[:, 7] -= 0.012
-        tau = torch.as_tensor(np.random.default_rng(5).uniform(-0.05, 0.05, size=(B, m.ndof)), dtype=torch.float32, device=bw.device)
+        tau = torch.as_tensor(np.random.default_rng(5).uniform(-0.05, 0.05, size=(B, m.ndof)), dtype=torch.float32, device=bws["0"].device)
         tau[:, :6] = 0.
         res = {}
         for mode in ("0", "1"):
             monkeypatch.setenv("ARB_FORCE_PACK", mode)
+            bw = bws[mode]
+            if mode == "1":
+                assert bw.plan(B, T if not per_step else 1, ext_gforce=ext)["worlds_per_wavefront"] == 2
             tq, tdq = bw.to_device(q, dq, torch.float32)
             cf = bw.new_cforce(B, torch.float32)
             kw = dict(ext_gforce=tau.contiguous()) if ext else {}
@@ -380,7 +385,43 @@ def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, 
             res[mode] = (tq, tdq, cf)
         assert float(res["1"][2][:, :, 3].max()) > 10.
         assert all(torch.equal(a, b) for a, b in zip(res["0"], res["1"])), (B, T, per_step, ext)
-    bw.close()
+    for bw in bws.values():
+        bw.close()
+
+
+def test_rendezvous_build_equals_the_shipped_kernels_bitwise(monkeypatch):
+    """The rendezvous build (round 4; libarbstep_variants.so with ARB_FORCE_RDV=1): work items are single steps, the
+    wavefronts of worlds 4g .. 4g+3 meet at the Gauss-Seidel point -- three park their constraint-space system and draw the
+    next item, the last to arrive sweeps the four systems at once (gs_stage_n<T, 4>) and integrates the four worlds.  Against
+    the shipped library: states and forces bit for bit, batch sizes that leave one, two and three worlds in the last group,
+    a lone world, user torques (the FEAT 1 kernel).  (Measured slower than the shipped builds at every batch size,
+    DESIGN.md section 6: compiled for this test only.)"""
+    from arboris_python_amd import synth
+    from arboris_python_amd.batch import BatchedWorlds
+    m, _, _ = load_model("human36_c4")
+    variants = _capi.load_variants()
+    assert variants.arb_build_variants() & 2
+    bws = {"0": BatchedWorlds(m), "1": BatchedWorlds(m, lib=variants)}
+    monkeypatch.delenv("ARB_FORCE_PACK", raising=False)
+    for B, T, ext in ((700, 40, False), (5001, 24, False), (2, 12, True), (1, 12, False), (9003, 13, True)):
+        q, dq = synth.world_states(m, range(B), "standing", 31, drop=0.03, vel=0.2)
+        q[:, 7] -= 0.012
+        tau = torch.as_tensor(np.random.default_rng(5).uniform(-0.05, 0.05, size=(B, m.ndof)), dtype=torch.float32, device=bws["0"].device)
+        tau[:, :6] = 0.
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("ARB_FORCE_RDV", mode)
+            bw = bws[mode]
+            tq, tdq = bw.to_device(q, dq, torch.float32)
+            cf = bw.new_cforce(B, torch.float32)
+            bw.step(tq, tdq, 5e-3, T, cforce=cf, **(dict(ext_gforce=tau.contiguous()) if ext else {}))
+            torch.cuda.synchronize()
+            bw.status()
+            res[mode] = (tq, tdq, cf)
+        assert float(res["1"][2][:, :, 3].max()) > 10.
+        assert all(torch.equal(a, b) for a, b in zip(res["0"], res["1"])), (B, T, ext)
+    for bw in bws.values():
+        bw.close()
 
 
 # ---------------------------------------------------------------------------
@@ -414,18 +455,23 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     assert build(bw.plan(64 * cus, 40, waves=3)) == (3, 1)
     assert build(bw.plan(64 * cus, 40, dtype=torch.float64)) == (2, 1)
     assert bw.plan(64 * cus, 40, static_worlds=True)["work_queue"] == 0
+    # the packed build is compiled into libarbstep_variants.so only
+    variants = _capi.load_variants()
+    bwv = BatchedWorlds(m, lib=variants)
     monkeypatch.setenv("ARB_FORCE_PACK", "1")
-    assert build(bw.plan(100, 40)) == (2, 2)
+    assert build(bw.plan(100, 40)) == (2, 1) and build(bwv.plan(100, 40)) == (2, 2)
     monkeypatch.setenv("ARB_FORCE_PACK", "0")
-    assert build(bw.plan(64 * cus, 40)) == (3, 1)
-    bw.close()
+    assert build(bw.plan(64 * cus, 40)) == (3, 1) and build(bwv.plan(64 * cus, 40)) == (3, 1)
+    bw.close(); bwv.close()
     # a model with a kinematic constraint (not only SoftFingerContacts) has no packed build
     m, _, _ = load_model("ballsocket")
     bw = BatchedWorlds(m)
+    bwv = BatchedWorlds(m, lib=variants)
     monkeypatch.delenv("ARB_FORCE_PACK", raising=False)
     assert bw.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
     monkeypatch.setenv("ARB_FORCE_PACK", "1")
-    assert bw.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
+    assert bwv.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
+    bwv.close()
     # (by default its worlds share wavefronts another way: a forest of 5 copies, tests/test_gpu_forest.py)
     assert bw.plan(64 * cus, 40)["worlds_per_wavefront"] == bw.info["forest_copies"] == 5
     bw.close()
