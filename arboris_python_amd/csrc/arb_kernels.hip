@@ -74,6 +74,9 @@
 #ifndef ARB_ROOT_QM
 #define ARB_ROOT_QM 1           // the sliding root finder decides from lane masks (arb_math.h: slide_leftmost_root_qm)
 #endif
+#ifndef ARB_GS_FAST
+#define ARB_GS_FAST 1           // the sweeps of SoftFingerContact-only worlds run a variant without the rare routes (see gs_stage); 0: one variant
+#endif
 #ifndef ARB_EIG_WAVE
 #define ARB_EIG_WAVE 1          // the generic 6x6 eigenvalue route of the sliding solve runs on the whole wavefront (eig6_wave); 0: one lane on LDS
 #endif
@@ -520,10 +523,16 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     // whose bulk phases have independent instructions to fill the gaps
     __builtin_amdgcn_s_setprio(ARB_GS_PRIO);
 #endif
-    for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
-        if (MODE == 1) ++st_sweeps;
-        for (int c = 0; c < nc; ++c) {
-            if (!((actmask >> c) & 1ull)) continue;
+    // One local solve (constraint c of the current sweep).  FAST: the variant for worlds whose active constraints are all
+    // SoftFingerContacts with eps = (1,1,1) -- no other constraint type, no division by eps, and NONE of the rare routes (the
+    // 6x6 eigenvalue routine, row exchanges in the 4x4 solve): when a solve needs one, it returns false with the state as it
+    // found it and the complete variant below redoes that solve and finishes the step.  Same expressions, same operations:
+    // bit-identical results.  (Round 4: the rare routes' registers were paid for by every solve -- the eigenvalue routine
+    // alone 95 spilled SGPRs; without them the launch is 3 % faster.)
+    const auto solve_one = [&](auto fast_tag, const int sweep, const int c) -> bool {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        (void)sweep;
+        {
             const int base = 4 * c;
             ARB_GST(gt0);
             // column block Y'[:, 4c..4c+3] of this lane's row (issued early, used last)
@@ -532,7 +541,8 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a4[i] = AM[lane * ndol + base + i];
             }
-            const int ct = __builtin_amdgcn_readlane(k_ct, c);
+            // (the fast variant runs only when every active constraint is a SoftFingerContact with eps = (1,1,1))
+            const int ct = FAST ? (int)ARB_CT_SOFTFINGER : __builtin_amdgcn_readlane(k_ct, c);
             G vc[4], fc[4], df[4], fnew[4];
             // A constraint's four rows are one quad of lanes: what its local solve needs from its own
             // rows comes as DPP quad_perm operands (every quad evaluates ITS constraint; only the quad of
@@ -549,7 +559,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             if (ct == ARB_CT_SOFTFINGER) {                   // constraints.py:780-836
                 // The release test and the static-friction candidate are evaluated side by side
                 // (two independent dependent chains that overlap in the pipeline), inside the quad.
-                const bool eps1 = (eps1mask >> c) & 1ull;          // eps = (1,1,1): x/eps = x exactly
+                const bool eps1 = FAST ? true : (bool)((eps1mask >> c) & 1ull);          // eps = (1,1,1): x/eps = x exactly
                 const G vq0 = quad_bcast<0>(vr), vq1 = quad_bcast<1>(vr), vq2 = quad_bcast<2>(vr), vq3 = quad_bcast<3>(vr);
                 const G dfr = -(Prow[0] * vq0 + Prow[1] * vq1 + Prow[2] * vq2 + Prow[3] * (vq3 + q_sdt));
                 const G fnr = fr + dfr;
@@ -598,6 +608,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                         }
                         if (MODE == 1) ++st_fast;
                         double warm = q_warm;
+                        const double q_wmove_old = q_wmove;
                         bool have = false;
                         if (eps1) {
                             const G yc[3] = {q_yc0, q_yc1, q_yc2};
@@ -629,6 +640,9 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                                 have = true;
                             }
                         }
+                        if constexpr (FAST) {
+                            if (!have) return false;        // (rare: the complete variant takes over at this solve)
+                        }
                         if (!have) {
                             if (MODE == 1) { ++st_slow; --st_fast; }
                             // rare: generic 6x6 eigenvalues (QR) of the matrix in the LDS work array, by the whole wavefront
@@ -645,6 +659,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                             warm = NAN;
                             if (inquad) q_wmove = NAN;
                         }
+                        const double q_warm_old = q_warm;
                         if (inquad) q_warm = warm;          // next sweep restarts next to this root
                         ARB_GST(gt3);
                         fnew[0] = fq0; fnew[1] = fq1; fnew[2] = fq2; fnew[3] = fq3;
@@ -653,7 +668,14 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #pragma unroll
                             for (int i = 0; i < 3; ++i) sie2[i] = shift / (eps[i] * eps[i]);
                         }
-                        softfinger_slide_finish_scaled<G>(Y, alpha, sie2, fnew, df, uni);
+                        if constexpr (FAST) {
+                            if (!softfinger_slide_finish_noex<G>(Y, alpha, sie2, fnew, df, uni)) {      // (rare: row exchanges)
+                                q_warm = q_warm_old; q_wmove = q_wmove_old;                            // (the solve is redone)
+                                return false;
+                            }
+                        } else {
+                            softfinger_slide_finish_scaled<G>(Y, alpha, sie2, fnew, df, uni);
+                        }
                         ARB_GST(gt4);
 #ifdef ARB_GSSTAMPS
                         gslid = true;
@@ -708,18 +730,47 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             }
 #endif
         }
+        return true;
+    };
+    const auto end_of_sweep = [&]() -> bool {          // true: the sweeps are over
         // A sweep that leaves every velocity and force bit-for-bit unchanged is a fixed point
         // of the iteration: the remaining sweeps of core.py:929-935 would repeat it exactly.
         const unsigned long long sameb = __ballot(same_bits(vr, vr_prev) && same_bits(fr, fr_prev));
-        if (sameb == ~0ull && !(MODE == 1 && (dbg.ablate & 8))) break;
+        if (sameb == ~0ull && !(MODE == 1 && (dbg.ablate & 8))) return true;
         if (g_fk > 1) {
             const int rows = ARB_MAXDOL * g_fnc;              // constraint rows of one copy (g_fk * rows <= 64)
             const unsigned long long rm = (rows >= 64) ? ~0ull : ((1ull << rows) - 1ull), cm = (1ull << g_fnc) - 1ull;
             for (int j = 0; j < g_fk; ++j)
                 if (((sameb >> (j * rows)) & rm) == rm) actmask &= ~(cm << (j * g_fnc));
-            if (actmask == 0ull) break;
+            if (actmask == 0ull) return true;
         }
         vr_prev = vr; fr_prev = fr;
+        return false;
+    };
+    int sweep = 0, c0 = 0;
+    bool over = false;
+    // (inspect kernels, forests and the float64-sweeps experiment take the complete variant throughout)
+    bool fast = ARB_GS_FAST && MODE == 0 && SAME && g_fk == 1 && (actmask & ~eps1mask) == 0ull;
+    if (fast) {
+        for (; sweep < GS_SWEEPS && fast; ++sweep) {
+            for (int c = 0; c < nc; ++c) {
+                if (!((actmask >> c) & 1ull)) continue;
+                if (!solve_one(std::true_type{}, sweep, c)) { fast = false; c0 = c; break; }
+            }
+            if (!fast) break;
+            if (end_of_sweep()) { over = true; break; }
+        }
+    }
+    if (!over) {
+        for (; sweep < GS_SWEEPS; ++sweep) {
+            if (MODE == 1) ++st_sweeps;
+            for (int c = c0; c < nc; ++c) {
+                if (!((actmask >> c) & 1ull)) continue;
+                (void)solve_one(std::false_type{}, sweep, c);
+            }
+            c0 = 0;
+            if (end_of_sweep()) break;
+        }
     }
 #if ARB_GS_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -4715,8 +4766,9 @@ extern "C" int arb_dev_softfinger_solve(int dtype, int device, int n, const doub
     return ARB_OK;
 }
 
-// build variants compiled into this library: bit 0 packed pairs (ARB_FORCE_PACK=1), bit 1 the rendezvous build (ARB_FORCE_RDV=1)
-extern "C" int arb_build_variants(void) { return (ARB_ALL_VARIANTS ? 1 : 0) | (ARB_WITH_RDV ? 2 : 0); }
+// build variants compiled into this library: bit 0 packed pairs (ARB_FORCE_PACK=1), bit 1 the rendezvous build (ARB_FORCE_RDV=1),
+// bit 2 sweeps without the fast variant of the local solve (-DARB_GS_FAST=0)
+extern "C" int arb_build_variants(void) { return (ARB_ALL_VARIANTS ? 1 : 0) | (ARB_WITH_RDV ? 2 : 0) | (ARB_GS_FAST ? 0 : 4); }
 
 // eig6 (one lane, matrix in LDS) and eig6_wave (the whole wavefront) on the same matrices, see arb_eig6_test_kernel
 extern "C" int arb_dev_eig6_pair(int dtype, int device, int n, const double *A /*[n][36]*/, double *out /*[n][28]*/) {

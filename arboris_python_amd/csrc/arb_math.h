@@ -1694,6 +1694,25 @@ ARB_HD void softfinger_slide_finish_scaled(const T Y[16], const T alpha[4], cons
     for (int i = 0; i < 4; ++i) { df[i] = x[i] - f[i]; f[i] = x[i]; }
 }
 
+// the fast variant of the sweeps: the exchange-free elimination or nothing -- false (f, df untouched) when the quad's
+// verdict is that partial pivoting would exchange rows
+template <typename T, typename UNI>
+ARB_HD bool softfinger_slide_finish_noex(const T Y[16], const T alpha[4], const T sie2[3], T f[4], T df[4], UNI uni) {
+    T A[4][4], b[4], x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[i][j] = Y[4 * i + j];
+        b[i] = -alpha[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) A[i][i] -= sie2[i];                // s * diag(eps**-2)
+    if (!uni(solve4_no_exchange<T>(A, b, x))) return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { df[i] = x[i] - f[i]; f[i] = x[i]; }
+    return true;
+}
+
 // packed sweeps: the exchange-free elimination for every lane; partial pivoting as well when some sliding quad needs it
 template <typename T, typename ANYQ>
 ARB_HD void softfinger_slide_finish_pk(const T Y[16], const T alpha[4], const T sie2[3], T f[4], T df[4], bool want, ANYQ anyq) {

@@ -389,6 +389,46 @@ def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, 
         bw.close()
 
 
+def test_fast_sweeps_hand_over_to_the_complete_variant_bitwise(monkeypatch):
+    """Round 4: worlds whose active constraints are all SoftFingerContacts with eps = (1,1,1) run their sweeps through a
+    variant of the local solve without the rare routes (the 6x6 eigenvalue routine, row exchanges in the 4x4 solve); a
+    solve that needs one hands the step over to the complete variant (gs_stage, arb_kernels.hip).  libarbstep_variants.so
+    is compiled without the fast variant: whole falling episodes of 4096 worlds -- late steps have 2-6 worlds with such
+    solves, counted here with the inspect kernel -- must agree bit for bit, in every build (two waves, three waves, one
+    launch per step)."""
+    from arboris_python_amd import synth
+    from arboris_python_amd.batch import BatchedWorlds
+    m, _, _ = load_model("human36_c4")
+    variants = _capi.load_variants()
+    assert variants.arb_build_variants() & 4 and _capi.load().arb_build_variants() == 0
+    for v in ("ARB_FORCE_PACK", "ARB_FORCE_RDV", "ARB_FORCE_WAVES"):
+        monkeypatch.delenv(v, raising=False)
+    bws = {"fast": BatchedWorlds(m), "complete": BatchedWorlds(m, lib=variants)}
+    B, T = 4096, 40
+    q, dq = synth.standing_states(m, B, seed=1000, drop=0.03, vel=0.1)
+    handed_over = 0
+    for mode, kw in (("episode", {}), ("two_waves", dict(waves=2)), ("per_step", {})):
+        res = {}
+        for key, bw in bws.items():
+            tq, tdq = bw.to_device(q, dq, torch.float32)
+            cf = bw.new_cforce(B, torch.float32)
+            if mode == "per_step":
+                for k in range(T):
+                    if key == "fast" and k >= 30:
+                        st = bw.inspect(tq, tdq, 5e-3, ["gs_stats"], cforce=cf.clone())["gs_stats"]
+                        handed_over += int((st[:, 3] > 0).sum())
+                    bw.step(tq, tdq, 5e-3, 1, cforce=cf)
+            else:
+                bw.step(tq, tdq, 5e-3, T, cforce=cf, **kw)
+            torch.cuda.synchronize()
+            bw.status()
+            res[key] = (tq, tdq, cf)
+        assert all(torch.equal(a, b) for a, b in zip(res["fast"], res["complete"])), mode
+    assert handed_over >= 5, handed_over            # (worlds whose sweeps met the eigenvalue route in the last ten steps)
+    for bw in bws.values():
+        bw.close()
+
+
 def test_rendezvous_build_equals_the_shipped_kernels_bitwise(monkeypatch):
     """The rendezvous build (round 4; libarbstep_variants.so with ARB_FORCE_RDV=1): work items are single steps, the
     wavefronts of worlds 4g .. 4g+3 meet at the Gauss-Seidel point -- three park their constraint-space system and draw the
