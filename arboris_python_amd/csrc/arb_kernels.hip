@@ -80,6 +80,9 @@
 #ifndef ARB_EIG_WAVE
 #define ARB_EIG_WAVE 1          // the generic 6x6 eigenvalue route of the sliding solve runs on the whole wavefront (eig6_wave); 0: one lane on LDS
 #endif
+// (float32 worlds only: in float64 every scalar of the QR iteration is two SGPRs, and inlined in the sweeps they took the
+// float64 kernels from ~30 to ~550 spilled SGPRs -- nine VGPRs of spill lanes, the snake-64 kernel over 256 registers)
+#define ARB_EIG_WAVE_FOR(T) (ARB_EIG_WAVE != 0 && sizeof(T) == 4)
 // The rendezvous build (CM = 4, round 4): single steps as work items, the wavefronts of four worlds meet at the
 // Gauss-Seidel point -- three park their constraint-space system and what phase E needs in global memory and draw the
 // next item, the last to arrive sweeps all four systems (gs_stage_n<T, 4>) and integrates the four worlds.  Bit-identical
@@ -385,7 +388,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 // ===========================================================================
 // G = the arithmetic type of the sweeps (round 3 experiment, -DARB_GS_F64: float32 worlds whose sweeps -- velocities, forces,
 // the two decision inequalities, the (pseudo-)inverse blocks -- run in float64 on the float32 system Y', v'; G = T otherwise)
-template <typename T, int MODE, typename G = T>
+template <typename T, int MODE, typename G = T, bool ALLOW_FAST = true>
 __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt_t,
                                          const T inv_dt_t, const T *AM, T *CD, T *VV, T *FF, T *WORK,
                                          const DebugOut<T> &dbg, const long w) {
@@ -648,13 +651,13 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                             // rare: generic 6x6 eigenvalues (QR) of the matrix in the LDS work array, by the whole wavefront
                             if (inquad) softfinger_sliding_shift<G>(Y, alpha, q_mu, eps, WORK, &shift, false);
                             WAVE_SYNC();
-#if ARB_EIG_WAVE
-                            shift = (G)slide_shift_from_eig_wave<T>(WORK, lane);
-#else
-                            if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
-                            WAVE_SYNC();
-                            shift = WORK[40];
-#endif
+                            if constexpr (ARB_EIG_WAVE_FOR(T)) {
+                                shift = (G)slide_shift_from_eig_wave<T>(WORK, lane);
+                            } else {
+                                if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
+                                WAVE_SYNC();
+                                shift = WORK[40];
+                            }
                             WAVE_SYNC();
                             warm = NAN;
                             if (inquad) q_wmove = NAN;
@@ -750,8 +753,9 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     int sweep = 0, c0 = 0;
     bool over = false;
     // (inspect kernels, forests and the float64-sweeps experiment take the complete variant throughout)
-    bool fast = ARB_GS_FAST && MODE == 0 && SAME && g_fk == 1 && (actmask & ~eps1mask) == 0ull;
-    if (fast) {
+    // (ALLOW_FAST: not in the float64 64-row kernels, which are register-bound: a second copy of the solve is nine spilled VGPRs)
+    if constexpr (ARB_GS_FAST && ALLOW_FAST && MODE == 0 && SAME) {
+        bool fast = g_fk == 1 && (actmask & ~eps1mask) == 0ull;
         for (; sweep < GS_SWEEPS && fast; ++sweep) {
             for (int c = 0; c < nc; ++c) {
                 if (!((actmask >> c) & 1ull)) continue;
@@ -958,13 +962,14 @@ __device__ __forceinline__ void gs_stage_n(const DevModel<T> *mp, const int lane
                         const bool hq = want && grp == h;
                         if (hq) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
                         WAVE_SYNC();
-#if ARB_EIG_WAVE
-                        const T sh_fb = slide_shift_from_eig_wave<T>(WORK, lane);
-#else
-                        if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
-                        WAVE_SYNC();
-                        const T sh_fb = WORK[40];
-#endif
+                        T sh_fb;
+                        if constexpr (ARB_EIG_WAVE_FOR(T)) {
+                            sh_fb = slide_shift_from_eig_wave<T>(WORK, lane);
+                        } else {
+                            if (lane == 0) WORK[40] = slide_shift_from_eig<T>(WORK);
+                            WAVE_SYNC();
+                            sh_fb = WORK[40];
+                        }
                         if (hq) { shift = sh_fb; warm = NAN; q_wmove = NAN; }
                         WAVE_SYNC();
                     }
@@ -1033,7 +1038,10 @@ __device__ __forceinline__ void gs_stage2(const DevModel<T> *mp, const int lane,
 // (float64 worlds on the 64-row tile -- snake-64 -- need 36 KB of LDS per wave: four waves per CU, one per SIMD, so
 // their kernels may take the whole 512-entry register file of a SIMD instead of spilling at 256)
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
-__global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVES(CM)) void arb_step_kernel(
+// (float64 / 64 rows: two column sets need the whole register file of a SIMD; one column set fits 256 registers and must
+// stay there -- two wavefronts per SIMD, five per CU with snake-64's LDS -- whatever else is compiled into the kernel: at
+// 258 registers config 4 ran at 12.2 instead of 13.1 M world-steps/s)
+__global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1 && MODE == 0 && FEAT <= 1) ? 2 : 1) : ARB_WAVES(CM)) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
     T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
@@ -3291,7 +3299,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? 1 : ARB_WAVE
                              lds + ARB_UNI(lp.sa_ff), AM, CD, VV, FF, WORK, two);
             } else {
                 using GSG = std::conditional_t<(ARB_GS_F64 != 0) && std::is_same<T, float>::value, double, T>;
-                gs_stage<T, MODE, GSG>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
+                gs_stage<T, MODE, GSG, !(sizeof(T) == 8 && NMAX == 64)>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
             }
         }
 
