@@ -1089,10 +1089,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     // (the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs, faulted on
     // their first launch -- queue or not -- with the item loop around the body, ROCm 7.2: there every workgroup draws
     // ONE item and the grid is the number of items; the hardware dispatcher does the looping)
+    // (reproducer: tools/experiments/f64_64_item_loop_repro.sh builds with -DARB_QUEUE_LOOP_ALL=1, which puts the loop back)
 #ifndef ARB_QUEUE_LOOP
 #define ARB_QUEUE_LOOP 1
 #endif
-    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);
+#ifndef ARB_QUEUE_LOOP_ALL
+#define ARB_QUEUE_LOOP_ALL 0
+#endif
+    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && (ARB_QUEUE_LOOP_ALL || !(sizeof(T) == 8 && NMAX == 64));
     int *const queue = (MODE == 0) ? queue_in : nullptr;
     T *gq = gq_in, *gdq = gdq_in, *gcforce = gcforce_in;
     long w = blockIdx.x;
@@ -3634,7 +3638,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     T *park = nullptr;
     const long units = (CM == 3) ? (nw + 1) / 2 : nw;        // work units: worlds, or pairs of worlds (packed build)
     unsigned grid = (unsigned)units;
-    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && !(sizeof(T) == 8 && NMAX == 64);     // (see the kernel)
+    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && (ARB_QUEUE_LOOP_ALL || !(sizeof(T) == 8 && NMAX == 64));     // (see the kernel)
     if constexpr (CM == 4) {
         if (cf == nullptr || sio.mode != 0 || nw * (long)nsteps >= (1l << 30)) return ARB_ERR_INVALID;     // (launch() checks before it picks this build)
         auto al4 = [](long x) { return (x + 3) & ~3l; };
