@@ -32,8 +32,8 @@ for nc in (4, 8):
         torch.cuda.synchronize()
         bits = lambda t: t.contiguous().view(torch.int32)            # (bit patterns: NaN == NaN)
         same = bool(torch.equal(bits(sq), bits(tq[sub])) and torch.equal(bits(sdq), bits(tdq[sub])))
-        # the whole batch again through the plain step (no logs): from 16384 worlds on the library picks the PACKED build
-        # (two worlds per wavefront) for the 4-contact model -- bit patterns must equal the rollout's (three-wave build)
+        # the whole batch again through the plain step (no logs: the FEAT 0 kernel with the work queue; the rollout above
+        # is the FEAT 3 kernel) -- bit patterns must be equal
         pq, pdq = bw.to_device(q, dq, torch.float32)
         pcf = bw.new_cforce(B, torch.float32)
         bw.step(pq, pdq, dt, T, cforce=pcf)
@@ -47,7 +47,7 @@ for nc in (4, 8):
                            np.abs(log["dq"][k + 1][ws].cpu().numpy() - odq).max(1) / np.maximum(1, np.abs(odq).max(1)))
             ok.append(e < 1e-5)
         ok = np.concatenate(ok)
-        print("nc %d seed %d: %.1f M world-steps/s (with logs), finite %s, wave-split and plain-step (packed build) bitwise %s, within 1e-5: %d/%d, max |dq| %.0f, max force %.0f"
+        print("nc %d seed %d: %.1f M world-steps/s (with logs), finite %s, wave-split and plain-step bitwise %s, within 1e-5: %d/%d, max |dq| %.0f, max force %.0f"
               % (nc, seed, B * T / el / 1e6, fin, same, ok.sum(), len(ok), float(tdq.abs().max()), float(cf.abs().max())), flush=True)
         if not fin:
             # an exploding world is acceptable only if the float64 reference algorithm explodes on it too
