@@ -74,6 +74,9 @@
 #ifndef ARB_ROOT_QM
 #define ARB_ROOT_QM 1           // the sliding root finder decides from lane masks (arb_math.h: slide_leftmost_root_qm)
 #endif
+#ifndef ARB_POLY_LANES
+#define ARB_POLY_LANES 1        // sliding solve: the quad's lanes evaluate different coefficients of the sextic (see gs_stage); 0: every lane all of them
+#endif
 #ifndef ARB_GS_FAST
 #define ARB_GS_FAST 1           // the sweeps of SoftFingerContact-only worlds run a variant without the rare routes (see gs_stage); 0: one variant
 #endif
@@ -453,6 +456,11 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     G q_sd = G(0), q_sdt = G(0), q_mu = G(0);
     G q_iyn = G(0), q_muyn = G(0), q_yc0 = G(0), q_yc1 = G(0), q_yc2 = G(0), q_bsq = G(0);
     SlidePre q_sp = {0., 0., 0., 0., 0., 0.};
+    // ARB_POLY_LANES: lane r of a quad keeps the per-step constants of the sextic's coefficients r and r + 4 (arb_math.h:
+    // SlideCoef) and evaluates those two in every sliding solve; the quad exchanges the six values by DPP -- 12 fused
+    // multiply-adds and 12 DPP moves instead of the 36 of slide_poly (47 operations before round 4's expansion)
+    SlideCoef q_ka = {0., 0., 0., 0., 0., 0., 0.}, q_kb = {0., 0., 0., 0., 0., 0., 0.};
+    double q_nq = 0.;
     double q_warm = NAN;                    // root found for this constraint in the previous sweep
     double q_wmove = NAN;                   // how far that root had moved from the sweep before
     if (lane < ndol) {
@@ -489,6 +497,20 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * ndol + 4 * cc + j];
             q_sp = slide_precompute<G>(Yc4);
+            if (ARB_POLY_LANES) {
+                SlideCoef all[6];
+                slide_coefs_all(q_sp, all);
+                const auto pick = [&](double x0, double x1, double x2, double x3) { return rr == 0 ? x0 : rr == 1 ? x1 : rr == 2 ? x2 : x3; };
+                q_ka.a0 = pick(all[0].a0, all[1].a0, all[2].a0, all[3].a0); q_ka.a1 = pick(all[0].a1, all[1].a1, all[2].a1, all[3].a1);
+                q_ka.a2 = pick(all[0].a2, all[1].a2, all[2].a2, all[3].a2); q_ka.a3 = pick(all[0].a3, all[1].a3, all[2].a3, all[3].a3);
+                q_ka.b0 = pick(all[0].b0, all[1].b0, all[2].b0, all[3].b0); q_ka.b1 = pick(all[0].b1, all[1].b1, all[2].b1, all[3].b1);
+                q_ka.b2 = pick(all[0].b2, all[1].b2, all[2].b2, all[3].b2);
+                q_kb.a0 = pick(all[4].a0, all[5].a0, 0., 0.); q_kb.a1 = pick(all[4].a1, all[5].a1, 0., 0.);
+                q_kb.a2 = pick(all[4].a2, all[5].a2, 0., 0.); q_kb.a3 = pick(all[4].a3, all[5].a3, 0., 0.);
+                q_kb.b0 = pick(all[4].b0, all[5].b0, 0., 0.); q_kb.b1 = pick(all[4].b1, all[5].b1, 0., 0.);
+                q_kb.b2 = pick(all[4].b2, all[5].b2, 0., 0.);
+                q_nq = q_sp.nq;
+            }
             q_iyn = G(1) / Yc4[15]; q_muyn = q_mu / Yc4[15];
             q_yc0 = Yc4[3]; q_yc1 = Yc4[7]; q_yc2 = Yc4[11];
             const G bq0 = q_muyn * q_yc0, bq1 = q_muyn * q_yc1, bq2 = q_muyn * q_yc2;
@@ -631,6 +653,11 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #ifdef ARB_GSSTAMPS
                             int *const probe = (MODE == 1 && lane == base) ? gprobe : nullptr;
                             if (slide_leftmost_root_uni(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), uni, probe, woff)) {
+#elif ARB_ROOT_QM && ARB_POLY_LANES
+                            const double pxa = slide_coef_eval(q_ka, -kappa, c1), pxb = slide_coef_eval(q_kb, -kappa, c1);
+                            const double pcq[7] = {quad_bcast<0>(pxa), quad_bcast<1>(pxa), quad_bcast<2>(pxa), quad_bcast<3>(pxa),
+                                                   quad_bcast<0>(pxb), quad_bcast<1>(pxb), 1.};
+                            if (slide_leftmost_root_qm_pc(pcq, q_nq, c1, kappa, warm, &root, slide_step_tol<T>(), base, woff)) {
 #elif ARB_ROOT_QM
                             if (slide_leftmost_root_qm(q_sp, c1, kappa, warm, &root, slide_step_tol<T>(), base, woff)) {
 #else

@@ -1119,6 +1119,55 @@ ARB_HD SlidePre slide_precompute(const T Y[16]) {
     return k;
 }
 
+// The sextic's coefficients as polynomials in the two sweep-dependent scalars (round 4): with d = -kappa, expanding
+//   det(B - sI) = E_chi^2 - d O_chi^2 - c1 (E_rho E_chi - d O_rho O_chi)      (see above)
+// in powers of s gives  pc_i = A_i(d) - c1 B_i(d),  A_i of degree <= 3 and B_i of degree <= 2 in d with coefficients that
+// depend on the admittance block only -- 21 numbers per constraint and step instead of 47 float64 operations per solve:
+//   i   A_i                                                   B_i
+//   0   det^2 + (2 det tr - m2^2) d + (tr^2 - 2 m2) d^2 - d^3  -sA det - (sA tr + 3 det + l1 m2) d - (3 tr + l1) d^2
+//   1   -2 det m2 + (2 tr m2 - 6 det) d - 2 tr d^2             sA m2 - l1 det + (3 sA - 3 m2 + l1 tr) d + 3 d^2
+//   2   2 det tr + m2^2 - 2 tr^2 d + 3 d^2                     -sA tr + l1 m2 - 3 det + 6 tr d
+//   3   -2 (det + tr m2) + 4 tr d                              sA - l1 tr + 3 m2 - 6 d
+//   4   2 m2 + tr^2 - 3 d                                      l1 - 3 tr
+//   5   -2 tr                                                  3                       (l1 = sQ - 3 tr; pc_6 = 1)
+// Every coefficient is evaluated by the SAME seven-constant Horner form (zeros on top), so that the fused kernel -- where
+// the four lanes of a constraint's quad evaluate different coefficients at once and exchange them by DPP -- and the scalar
+// callers below execute the same operations: bit-identical coefficients.
+struct SlideCoef { double a0, a1, a2, a3, b0, b1, b2; };
+
+ARB_HD double slide_coef_eval(const SlideCoef &c, double d, double c1) {
+    const double A = ((c.a3 * d + c.a2) * d + c.a1) * d + c.a0;
+    const double B = (c.b2 * d + c.b1) * d + c.b0;
+    return A - c1 * B;
+}
+
+ARB_HD void slide_coefs_all(const SlidePre &k, SlideCoef c[6]) {
+    const double tr = k.tr, m2 = k.m2, det = k.det, sA = k.sA;
+    const double l1 = -(3. * tr - k.sQ);
+    c[0].a0 = det * det;               c[0].a1 = 2. * det * tr - m2 * m2;   c[0].a2 = tr * tr - 2. * m2;  c[0].a3 = -1.;
+    c[0].b0 = -(sA * det);             c[0].b1 = -(sA * tr + 3. * det + l1 * m2);   c[0].b2 = -(3. * tr + l1);
+    c[1].a0 = -2. * det * m2;          c[1].a1 = 2. * tr * m2 - 6. * det;   c[1].a2 = -2. * tr;           c[1].a3 = 0.;
+    c[1].b0 = sA * m2 - l1 * det;      c[1].b1 = 3. * sA - 3. * m2 + l1 * tr;       c[1].b2 = 3.;
+    c[2].a0 = 2. * det * tr + m2 * m2; c[2].a1 = -2. * tr * tr;             c[2].a2 = 3.;                 c[2].a3 = 0.;
+    c[2].b0 = -(sA * tr) + l1 * m2 - 3. * det;   c[2].b1 = 6. * tr;         c[2].b2 = 0.;
+    c[3].a0 = -2. * (det + tr * m2);   c[3].a1 = 4. * tr;                   c[3].a2 = 0.;                 c[3].a3 = 0.;
+    c[3].b0 = sA - l1 * tr + 3. * m2;  c[3].b1 = -6.;                       c[3].b2 = 0.;
+    c[4].a0 = 2. * m2 + tr * tr;       c[4].a1 = -3.;                       c[4].a2 = 0.;                 c[4].a3 = 0.;
+    c[4].b0 = l1 - 3. * tr;            c[4].b1 = 0.;                        c[4].b2 = 0.;
+    c[5].a0 = -2. * tr;                c[5].a1 = 0.;                        c[5].a2 = 0.;                 c[5].a3 = 0.;
+    c[5].b0 = 3.;                      c[5].b1 = 0.;                        c[5].b2 = 0.;
+}
+
+// the seven coefficients, constant term first
+ARB_HD void slide_poly(const SlidePre &k, double c1, double kappa, double pc[7]) {
+    SlideCoef c[6];
+    slide_coefs_all(k, c);
+    const double d2 = -kappa;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pc[i] = slide_coef_eval(c[i], d2, c1);
+    pc[6] = 1.;
+}
+
 // Leftmost real root of det(B - sI).  `warm` (NaN = none) is the root found for the same
 // constraint in the previous sweep: the iteration restarts just left of it when a
 // Budan-Fourier certificate (all Taylor coefficients at the start point alternate in sign,
@@ -1128,28 +1177,8 @@ ARB_HD SlidePre slide_precompute(const T Y[16]) {
 // least geometrically from the left, so the remaining distance is below the last step).
 ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, double warm, double *root,
                                 double step_tol = 4e-16) {
-    const double d2 = -kappa;
-    const double l1 = -(3. * k.tr - k.sQ);
-    const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
-    const double o[3] = {k.m2 + d2, -2. * k.tr, 3.};                          // O_chi
-    const double er[3] = {k.sA + 3. * d2, l1, 3.};                            // E_rho
-    const double orr[2] = {l1, 6.};                                           // O_rho
     double pc[7];
-    // E_chi^2 - d2 O_chi^2
-    pc[0] = e[0] * e[0] - d2 * (o[0] * o[0]);
-    pc[1] = 2. * e[0] * e[1] - d2 * (2. * o[0] * o[1]);
-    pc[2] = 2. * e[0] * e[2] + e[1] * e[1] - d2 * (2. * o[0] * o[2] + o[1] * o[1]);
-    pc[3] = 2. * (e[0] * e[3] + e[1] * e[2]) - d2 * (2. * o[1] * o[2]);
-    pc[4] = 2. * e[1] * e[3] + e[2] * e[2] - d2 * (o[2] * o[2]);
-    pc[5] = 2. * e[2] * e[3];
-    pc[6] = 1.;
-    // - c1 (E_rho E_chi - d2 O_rho O_chi)
-    pc[0] -= c1 * (er[0] * e[0] - d2 * (orr[0] * o[0]));
-    pc[1] -= c1 * (er[0] * e[1] + er[1] * e[0] - d2 * (orr[0] * o[1] + orr[1] * o[0]));
-    pc[2] -= c1 * (er[0] * e[2] + er[1] * e[1] + er[2] * e[0] - d2 * (orr[0] * o[2] + orr[1] * o[1]));
-    pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
-    pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
-    pc[5] -= c1 * (er[2] * e[3]);
+    slide_poly(k, c1, kappa, pc);
     double x = NAN;
     if (warm == warm) {
         const double x0 = warm - 1e-3 * fabs(warm) - 1e-300;
@@ -1209,28 +1238,8 @@ template <typename UNI>
 ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, double warm, double *root,
                                     double step_tol, UNI uni, int *probe = nullptr, double woff = -1.) {
 #define U(x) uni(x)
-    const double d2 = -kappa;
-    const double l1 = -(3. * k.tr - k.sQ);
-    const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
-    const double o[3] = {k.m2 + d2, -2. * k.tr, 3.};                          // O_chi
-    const double er[3] = {k.sA + 3. * d2, l1, 3.};                            // E_rho
-    const double orr[2] = {l1, 6.};                                           // O_rho
     double pc[7];
-    // E_chi^2 - d2 O_chi^2
-    pc[0] = e[0] * e[0] - d2 * (o[0] * o[0]);
-    pc[1] = 2. * e[0] * e[1] - d2 * (2. * o[0] * o[1]);
-    pc[2] = 2. * e[0] * e[2] + e[1] * e[1] - d2 * (2. * o[0] * o[2] + o[1] * o[1]);
-    pc[3] = 2. * (e[0] * e[3] + e[1] * e[2]) - d2 * (2. * o[1] * o[2]);
-    pc[4] = 2. * e[1] * e[3] + e[2] * e[2] - d2 * (o[2] * o[2]);
-    pc[5] = 2. * e[2] * e[3];
-    pc[6] = 1.;
-    // - c1 (E_rho E_chi - d2 O_rho O_chi)
-    pc[0] -= c1 * (er[0] * e[0] - d2 * (orr[0] * o[0]));
-    pc[1] -= c1 * (er[0] * e[1] + er[1] * e[0] - d2 * (orr[0] * o[1] + orr[1] * o[0]));
-    pc[2] -= c1 * (er[0] * e[2] + er[1] * e[1] + er[2] * e[0] - d2 * (orr[0] * o[2] + orr[1] * o[1]));
-    pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
-    pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
-    pc[5] -= c1 * (er[2] * e[3]);
+    slide_poly(k, c1, kappa, pc);
     // Every data-dependent branch of this variant costs a compare, a ballot and a scalar test on the critical
     // path of the sweeps: the exits of an iteration are evaluated arithmetically and tested once (measured:
     // +2.5 %; going further -- start point by selection, the short-step residual on every pass -- costs more
@@ -1317,30 +1326,12 @@ ARB_HD bool slide_leftmost_root_uni(const SlidePre &k, double c1, double kappa, 
 // leading lane of the quad that carries the live problem -- decides for the wave.  The lanes of that quad hold identical
 // data, so a selection under the quad's verdict gives them what the lane-wise selection of slide_leftmost_root_uni gives
 // them; operation for operation the same arithmetic: bit-identical roots.
-__device__ __forceinline__ bool slide_leftmost_root_qm(const SlidePre &k, double c1, double kappa, double warm, double *root,
-                                                       double step_tol, int qbase, double woff) {
+// (`pc`: the sextic's coefficients, formed by the caller -- the fused kernel spreads them over the quad's lanes, see
+// gs_stage --; `nq`: SlidePre::nq, for the spectrum bound of a cold start)
+__device__ __forceinline__ bool slide_leftmost_root_qm_pc(const double pc[7], double nq, double c1, double kappa, double warm,
+                                                          double *root, double step_tol, int qbase, double woff) {
 #define BM(c) __builtin_amdgcn_ballot_w64(c)
 #define QM(m) ((bool)(((m) >> qbase) & 1ull))
-    const double d2 = -kappa;
-    const double l1 = -(3. * k.tr - k.sQ);
-    const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
-    const double o[3] = {k.m2 + d2, -2. * k.tr, 3.};                          // O_chi
-    const double er[3] = {k.sA + 3. * d2, l1, 3.};                            // E_rho
-    const double orr[2] = {l1, 6.};                                           // O_rho
-    double pc[7];
-    pc[0] = e[0] * e[0] - d2 * (o[0] * o[0]);
-    pc[1] = 2. * e[0] * e[1] - d2 * (2. * o[0] * o[1]);
-    pc[2] = 2. * e[0] * e[2] + e[1] * e[1] - d2 * (2. * o[0] * o[2] + o[1] * o[1]);
-    pc[3] = 2. * (e[0] * e[3] + e[1] * e[2]) - d2 * (2. * o[1] * o[2]);
-    pc[4] = 2. * e[1] * e[3] + e[2] * e[2] - d2 * (o[2] * o[2]);
-    pc[5] = 2. * e[2] * e[3];
-    pc[6] = 1.;
-    pc[0] -= c1 * (er[0] * e[0] - d2 * (orr[0] * o[0]));
-    pc[1] -= c1 * (er[0] * e[1] + er[1] * e[0] - d2 * (orr[0] * o[1] + orr[1] * o[0]));
-    pc[2] -= c1 * (er[0] * e[2] + er[1] * e[1] + er[2] * e[0] - d2 * (orr[0] * o[2] + orr[1] * o[1]));
-    pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
-    pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
-    pc[5] -= c1 * (er[2] * e[3]);
     double x = NAN;
     double w0 = 0., w1 = 0., w2 = 0.;
     bool from_shift = false;
@@ -1356,7 +1347,7 @@ __device__ __forceinline__ bool slide_leftmost_root_qm(const SlidePre &k, double
         }
     }
     if (!from_shift) {
-        const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
+        const double rb = nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
         if (QM(BM(!(rb > 0.)) | BM(!(rb < 1e300)))) return false;
         x = -1.0001 * rb - 1e-300;
     }
@@ -1401,10 +1392,18 @@ __device__ __forceinline__ bool slide_leftmost_root_qm(const SlidePre &k, double
 #undef BM
 #undef QM
 }
+__device__ __forceinline__ bool slide_leftmost_root_qm(const SlidePre &k, double c1, double kappa, double warm, double *root,
+                                                       double step_tol, int qbase, double woff) {
+    double pc[7];
+    slide_poly(k, c1, kappa, pc);
+    return slide_leftmost_root_qm_pc(pc, k.nq, c1, kappa, warm, root, step_tol, qbase, woff);
+}
 #elif defined(__HIPCC__)
 // (host pass of the kernel sources: declared, never called)
 __device__ bool slide_leftmost_root_qm(const SlidePre &k, double c1, double kappa, double warm, double *root,
                                        double step_tol, int qbase, double woff);
+__device__ bool slide_leftmost_root_qm_pc(const double pc[7], double nq, double c1, double kappa, double warm,
+                                          double *root, double step_tol, int qbase, double woff);
 #endif
 
 // The same iteration for TWO worlds in one wavefront (round 3, packed sweeps): every lane carries its own problem --
@@ -1415,26 +1414,8 @@ __device__ bool slide_leftmost_root_qm(const SlidePre &k, double c1, double kapp
 template <typename ANYQ>
 ARB_HD void slide_leftmost_root_pk(const SlidePre &k, double c1, double kappa, double warm, double step_tol, double woff,
                                    bool want, ANYQ anyq, double *root_out, bool *ok_out) {
-    const double d2 = -kappa;
-    const double l1 = -(3. * k.tr - k.sQ);
-    const double e[4] = {-k.det - d2 * k.tr, k.m2 + 3. * d2, -k.tr, 1.};      // E_chi
-    const double o[3] = {k.m2 + d2, -2. * k.tr, 3.};                          // O_chi
-    const double er[3] = {k.sA + 3. * d2, l1, 3.};                            // E_rho
-    const double orr[2] = {l1, 6.};                                           // O_rho
     double pc[7];
-    pc[0] = e[0] * e[0] - d2 * (o[0] * o[0]);
-    pc[1] = 2. * e[0] * e[1] - d2 * (2. * o[0] * o[1]);
-    pc[2] = 2. * e[0] * e[2] + e[1] * e[1] - d2 * (2. * o[0] * o[2] + o[1] * o[1]);
-    pc[3] = 2. * (e[0] * e[3] + e[1] * e[2]) - d2 * (2. * o[1] * o[2]);
-    pc[4] = 2. * e[1] * e[3] + e[2] * e[2] - d2 * (o[2] * o[2]);
-    pc[5] = 2. * e[2] * e[3];
-    pc[6] = 1.;
-    pc[0] -= c1 * (er[0] * e[0] - d2 * (orr[0] * o[0]));
-    pc[1] -= c1 * (er[0] * e[1] + er[1] * e[0] - d2 * (orr[0] * o[1] + orr[1] * o[0]));
-    pc[2] -= c1 * (er[0] * e[2] + er[1] * e[1] + er[2] * e[0] - d2 * (orr[0] * o[2] + orr[1] * o[1]));
-    pc[3] -= c1 * (er[0] * e[3] + er[1] * e[2] + er[2] * e[1] - d2 * (orr[1] * o[2]));
-    pc[4] -= c1 * (er[1] * e[3] + er[2] * e[2]);
-    pc[5] -= c1 * (er[2] * e[3]);
+    slide_poly(k, c1, kappa, pc);
     double x = NAN, w0 = 0., w1 = 0., w2 = 0.;
     bool from_shift = false;
     const bool hasw = want && (warm == warm);
