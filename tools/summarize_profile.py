@@ -9,13 +9,13 @@ import csv, glob, json, os, shutil, sys
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"launch_shape": {"config": 3, "batch": 4096, "dtype": "f32", "contacts": 4, "steps_per_launch": 40, "split": False}}
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]
 if stats:
     shutil.copy(stats[0], os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats[0])))
     out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
                            for r in rows[:4]]
-trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+trace = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)[-1:]
 if trace:
     d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace[0]))
          if "arb_step_kernel" in r["Kernel_Name"]]
@@ -33,7 +33,17 @@ if trace:
                                   single_step_ms_first_episode=[round(x, 3) for x in one[:40]])
 pmc = {}
 lanes = {}
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+def newest_per_pass(pattern):
+    """gpurun merges every call's files into the same local directory: keep the newest file of each pass"""
+    best = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+for f in newest_per_pass(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
     acc = {}
     rows = [r for r in csv.DictReader(open(f)) if "arb_step_kernel" in r["Kernel_Name"]]
     for r in rows:                      # every dispatch of these passes is a whole-episode launch (--no-per-step-leg)
