@@ -80,9 +80,6 @@
 #ifndef ARB_ELIM_UNROLL
 #define ARB_ELIM_UNROLL 1       // phase C expanded per pivot with structural-zero skipping (tiles <= 48 rows, step kernels); 0: the rolled loop everywhere
 #endif
-#ifndef ARB_PIVOT_SKIP
-#define ARB_PIVOT_SKIP 0        // phase C skips the groups of rows that the pivot's dof is not related to (structural zeros of Z); 0: every row
-#endif
 #ifndef ARB_POLY_LANES
 #define ARB_POLY_LANES 1        // sliding solve: the quad's lanes evaluate different coefficients of the sextic (see gs_stage); 0: every lane all of them
 #endif
@@ -2963,7 +2960,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // ---- vector-ALU elimination expanded at template level (round 4): every pivot's code exists once, its row
             // indices are constants (no rotation of the register tile), and the groups of rows that dof j is NOT related to
             // -- structural zeros of Z: other branches of the tree, other copies of a forest, the padding rows -- are
-            // skipped outright.  Same operations on the same values as the rolled loop below: bit-identical.
+            // skipped outright: for human36 (two legs, two arms, trunk and head) 60 % of the row updates.  Same operations on
+            // the same values as the rolled loop below (a skipped update is `Z[r] - 0 t`): bit-identical.  Dense impedances
+            // (PD controllers: Z_a couples any pair of dofs) switch the skipping off.  (Skipping inside the ROLLED loop was
+            // measured too: the rotation of the register tile turns a skipped update into a move, the per-group branches
+            // break the interleaving of the broadcasts: -4.5 %.)
             const bool z_dense = mp->has_pd || (FEAT_ALL && pwd.kp != nullptr);
             const unsigned long long relv = (lane < n && !z_dense) ? (mp->upmask[lane] | mp->descmask[lane]) : ~0ull;
             const unsigned rel_lo = (unsigned)relv, rel_hi = (unsigned)(relv >> 32);
@@ -3022,36 +3023,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 for (int r = 0; r < NMAX; ++r) WORK[r] = Z[r];
             }
         }
-        // Structural zeros (round 4).  Z couples dof j only with the dofs of its own chain -- ancestors and descendants
-        // (`upmask | descmask`, the masks phase B assembles Z from) --, and pivoting from the extremities to the root
-        // fills nothing in outside that pattern: in the step of pivot j the rows of every other branch (and the padding
-        // rows n .. NMAX-1) have the multiplier 0 exactly, their update `Z[r] - 0 t` is the row itself.  A group of eight
-        // rows without a related row skips its eight broadcasts and fused multiply-adds and only moves with the
-        // rotation of the register tile: for human36 (two legs, two arms, trunk and head) 60 % of the row updates, for a
-        // forest every other copy's rows.  Bit-identical.  Dense impedances (PD controllers: Z_a couples any pair) switch it off.
-        const bool z_dense = !ARB_PIVOT_SKIP || mp->has_pd || (FEAT_ALL && pwd.kp != nullptr);
-        unsigned rel_lo = 0u, rel_hi = 0u;
-        if (!z_dense) {
-            const unsigned long long rel = (lane < n) ? (mp->upmask[lane] | mp->descmask[lane]) : 0ull;
-            rel_lo = (unsigned)rel; rel_hi = (unsigned)(rel >> 32);
-        }
-        const int zpad = NMAX - n;
         for (int j = n - 1; j >= 0; --j) {
             const ZT piv = bcast(Z[NMAX - 1], j);
             const ZT ip = arb_rcp(piv);
             const ZT t = Z[NMAX - 1] * ip;
             ZT t2 = ZT(0);
             if (NSETS == 2) t2 = Z2[NMAX - 1] * ip;
-            // related rows in REGISTER coordinates: before this step register s < d = n-1-j holds the pivoted row j+1+s,
-            // the next NMAX-n registers the padding rows, register s >= d + NMAX-n the row s - d - (NMAX-n) < j
-            unsigned long long pm = ~0ull;
-            if (!z_dense) {
-                const unsigned long long rel = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rel_hi, j) << 32)
-                                             | (unsigned)__builtin_amdgcn_readlane((int)rel_lo, j);
-                const int d = n - 1 - j;
-                const unsigned long long above = (j + 1 < 64) ? (rel >> (j + 1)) : 0ull;
-                pm = (above & ((1ull << d) - 1ull)) | ((rel & ((1ull << j) - 1ull)) << (d + zpad));
-            }
             // multipliers in groups of 8 broadcasts: the v_readlane -> SGPR -> v_fma wait states of one row are
             // filled by the broadcasts of the next rows instead of s_nop
 #ifndef ARB_PIVOT_GB
@@ -3060,18 +3037,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             constexpr int GB = ARB_PIVOT_GB;
 #pragma unroll
             for (int r0 = NMAX - 1; r0 >= 1; r0 -= GB) {
-                // source registers of this group: r0-1 down to max(r0-GB, 0)
-                const int glo = r0 - GB > 0 ? r0 - GB : 0;
-                const unsigned long long gbits = (pm >> glo) & ((1ull << (r0 - glo)) - 1ull);
-                if (gbits == 0ull) {
-#pragma unroll
-                    for (int k = 0; k < GB; ++k) if (r0 - k >= 1) {
-                        const int r = r0 - k;
-                        Z[r] = Z[r - 1];
-                        if (NSETS == 2) Z2[r] = Z2[r - 1];
-                    }
-                    continue;
-                }
                 ZT f[GB];
 #pragma unroll
                 for (int k = 0; k < GB; ++k) if (r0 - k >= 1) f[k] = bcast(Z[r0 - k - 1], j);
