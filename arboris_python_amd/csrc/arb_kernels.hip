@@ -107,6 +107,9 @@
 #ifndef ARB_WITH_RDV
 #define ARB_WITH_RDV ARB_ALL_VARIANTS
 #endif
+#ifndef ARB_WITH_SPEC
+#define ARB_WITH_SPEC (!ARB_ALL_VARIANTS)      // the kernels specialised for four plane / sphere SoftFingerContacts (FEAT bit 4): in the shipped library, not in
+#endif                                         // libarbstep_variants.so, whose general kernels hold them bit-identical (ARB_FORCE_SPEC=0 in the environment: development)
 #ifndef ARB_RDV_DEFAULT
 #define ARB_RDV_DEFAULT 0
 #endif
@@ -397,7 +400,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 // ===========================================================================
 // G = the arithmetic type of the sweeps (round 3 experiment, -DARB_GS_F64: float32 worlds whose sweeps -- velocities, forces,
 // the two decision inequalities, the (pseudo-)inverse blocks -- run in float64 on the float32 system Y', v'; G = T otherwise)
-template <typename T, int MODE, typename G = T, bool ALLOW_FAST = true>
+// SPECK: every constraint is an enabled SoftFingerContact (the specialised step kernels, FEAT bit 4): its type is a constant
+template <typename T, int MODE, typename G = T, bool ALLOW_FAST = true, bool SPECK = false>
 __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt_t,
                                          const T inv_dt_t, const T *AM, T *CD, T *VV, T *FF, T *WORK,
                                          const DebugOut<T> &dbg, const long w) {
@@ -413,7 +417,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             // the active constraints' lanes store)
             const bool mine = lane < nc && CD[(lane < nc ? lane : 0) * CD_STRIDE + CD_ACTIVE] != T(0);
             if (ARB_DENSE_INV ? (nc > 0) : mine) {
-                const int c = lane < nc ? lane : 0, ct = mp->ctype[c];
+                const int c = lane < nc ? lane : 0, ct = SPECK ? (int)ARB_CT_SOFTFINGER : mp->ctype[c];
                 const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 T P[16];
                 const bool ok = inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
@@ -433,7 +437,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             const int c = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             if (lane == c) {
-                const int ct = mp->ctype[c];
+                const int ct = SPECK ? (int)ARB_CT_SOFTFINGER : mp->ctype[c];
                 const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 T P[16];
                 pinv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
@@ -494,7 +498,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             }
         }
         q_sd = CD[cc * CD_STRIDE + CD_SDIST]; q_sdt = q_sd / dt; q_mu = mp->cmu[cc];
-        if (CD[cc * CD_STRIDE + CD_ACTIVE] != G(0) && mp->ctype[cc] == ARB_CT_SOFTFINGER) {
+        if (CD[cc * CD_STRIDE + CD_ACTIVE] != G(0) && (SPECK || mp->ctype[cc] == ARB_CT_SOFTFINGER)) {
             // admittance-only part of the sliding-branch polynomial and the other per-step constants of
             // SoftFingerContact.solve (constraints.py:795, 808-812), once per step
             G Yc4[16];
@@ -527,7 +531,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
         const T *cd = CD + lane * CD_STRIDE;
         k_act = cd[CD_ACTIVE] != G(0);
         k_sd = cd[CD_SDIST]; k_p0 = cd[CD_POS0]; k_p1 = cd[CD_POS0 + 1]; k_p2 = cd[CD_POS0 + 2];
-        k_ct = mp->ctype[lane]; k_mu = mp->cmu[lane];
+        k_ct = SPECK ? (int)ARB_CT_SOFTFINGER : mp->ctype[lane]; k_mu = mp->cmu[lane];
         k_e0 = mp->ceps[3 * lane]; k_e1 = mp->ceps[3 * lane + 1]; k_e2 = mp->ceps[3 * lane + 2];
         k_eps1 = k_act && k_ct == ARB_CT_SOFTFINGER && (k_e0 == G(1)) && (k_e1 == G(1)) && (k_e2 == G(1));
     }
@@ -537,7 +541,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     // unchanged is at ITS fixed point and takes no further part -- one world per wavefront stops sweeping there, and a
     // float32 solve repeated beyond it is not exactly idempotent (the root finder's start depends on how far the root
     // moved in the previous sweep), which used to leave the copies a few ulps from the one-world launch (round 4)
-    const int g_fk = mp->fk, g_fnc = mp->fnc;
+    const int g_fk = SPECK ? 1 : mp->fk, g_fnc = mp->fnc;
     int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
     int tr_rel = 0, tr_sta = 0, tr_slow = 0;
     G vr_prev = vr, fr_prev = fr;
@@ -573,7 +577,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                 for (int i = 0; i < 4; ++i) a4[i] = AM[lane * ndol + base + i];
             }
             // (the fast variant runs only when every active constraint is a SoftFingerContact with eps = (1,1,1))
-            const int ct = FAST ? (int)ARB_CT_SOFTFINGER : __builtin_amdgcn_readlane(k_ct, c);
+            const int ct = (FAST || SPECK) ? (int)ARB_CT_SOFTFINGER : __builtin_amdgcn_readlane(k_ct, c);
             G vc[4], fc[4], df[4], fnew[4];
             // A constraint's four rows are one quad of lanes: what its local solve needs from its own
             // rows comes as DPP quad_perm operands (every quad evaluates ITS constraint; only the quad of
@@ -1096,6 +1100,16 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     constexpr bool RDV = (CM == 4);
     T *const park = RDV ? park_in : nullptr;
     constexpr bool FEAT_EXT = (FEAT & 1) != 0, FEAT_ALL = (FEAT & 2) != 0;
+    // FEAT bit 4 (round 4): the kernel specialised for the model class of the headline workload -- exactly four constraints (eight
+    // for a model with two column sets: human36 with the reference's eight contact points), every one an enabled
+    // SoftFingerContact of a plane / sphere (or point) pair, and neither a PD controller nor joint viscosity in the model
+    // (arb_model::spec_ok, checked by the host): the constraint type, the shape pair, nc and ndol are compile-time constants
+    // and the code of the absent features is not compiled in.  Same expressions: bit-identical results.  (Measured, float32,
+    // 4096 worlds: constants +3 %, without the PD / viscosity code +8 % -- code that is never executed still costs the
+    // phases around it registers.)
+    constexpr bool SPEC = (FEAT & 4) != 0;
+    constexpr int SPEC_NC = 4 * NSETS;
+    static_assert(!SPEC || (!FEAT_ALL && MODE == 0 && (CM == 0 || CM == 2)), "specialised kernels: plain inputs / user torques");
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
     const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
     const LogOut<T> logo = FEAT_ALL ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
@@ -1210,7 +1224,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     // (the sizes are re-laundered at every phase boundary, ARB_OPAQUE_LANE: left to itself the compiler hoists
     // the ~90 wave-uniform predicates `i < n` of the unrolled row loops out of the step loop as 64-bit lane masks
     // and then spills them -- 284 SGPR spills in round 1)
-    int n = mp->n, nb = mp->nb, nc = mp->nc, ndol = mp->ndol;
+    int n = mp->n, nb = mp->nb, nc = SPEC ? SPEC_NC : mp->nc, ndol = SPEC ? SPEC_NC * ARB_MAXDOL : mp->ndol;
     const int nq = mp->nq;
     // the host picks the smallest register tile that holds ndof (kNmaxChoices): rows below the previous tile
     // size always exist, which folds their `i < n` predicates away
@@ -1306,8 +1320,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #define ARB_ASTAMP(k) do { } while (0)
 #endif
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); \
-                              n = ARB_UNI(mp->n); nb = ARB_UNI(mp->nb); nc = ARB_UNI(mp->nc); ndol = ARB_UNI(mp->ndol); \
-                              asm volatile("" : "+s"(n), "+s"(nb), "+s"(nc), "+s"(ndol)); ARB_LDS_POINTERS(); } while (0)
+                              n = ARB_UNI(mp->n); nb = ARB_UNI(mp->nb); asm volatile("" : "+s"(n), "+s"(nb));                \
+                              if (!SPEC) { nc = ARB_UNI(mp->nc); ndol = ARB_UNI(mp->ndol); asm volatile("" : "+s"(nc), "+s"(ndol)); } \
+                              ARB_LDS_POINTERS(); } while (0)
 
     // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
     // columns in RT, then every joint integrates its position.
@@ -1719,7 +1734,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 const V3<T> nbot = cross(wv, mtb);
                 T pt[6] = {mg[0] - ma[0] - ntop.x, mg[1] - ma[1] - ntop.y, mg[2] - ma[2] - ntop.z,
                            mg[3] - ma[3] - nbot.x, mg[4] - ma[4] - nbot.y, mg[5] - ma[5] - nbot.z};
-                if (mp->has_visc) {
+                if (!SPEC && mp->has_visc) {
                     T vt[6];
                     mat6_vec<T>(mp->visc + 36 * b, tw, vt);
 #pragma unroll
@@ -1785,10 +1800,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             const bool mine = lane < nc;
             const int c = mine ? lane : 0;
             T *cd = CD + c * CD_STRIDE;
-            const int ct = mp->ctype[c];
+            const int ct = SPEC ? (int)ARB_CT_SOFTFINGER : mp->ctype[c];
             bool active = false;
             T sd = T(0);
-            if (mp->cen[c]) {
+            if (SPEC || mp->cen[c]) {
                 if (ct == ARB_CT_SOFTFINGER) {
                     // Narrow phase in float64: the gap is a difference of O(1) positions.
                     const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
@@ -1808,7 +1823,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     const V3<double> ps0 = mv(Rg0, ld_v3(mp->cb0_d + 12 * c + 9)) + pg0;
                     const V3<double> p_g1 = mv(Rg1, ld_v3(mp->clocal_d + 3 * c)) + pg1;
                     const double rad = mp->cradius_d[c];
-                    const int geom = mp->cgeom[c];
+                    const int geom = SPEC ? (int)ARB_CG_PLANE_SPHERE : mp->cgeom[c];
                     V3<double> gc0, gc1;
                     M3<double> Rc;
                     const double sd_d = narrow_phase(geom, Rs0, ps0, p_g1, rad, mp->cradius0_d[c], ld_v3(mp->chalf_d + 3 * c),
@@ -2017,7 +2032,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // in their two-wave kernels cost 65 spilled VGPRs and 3-6 %, tools/experiments/forest_rate.py)
             constexpr bool TWO_PASS = (CM == 2 || CM == 3 || CM == 4 || MODE == 1);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
-            const bool lscan = LSCAN_OK && mp->lay.lscan;
+#ifndef ARB_SPEC_LSCAN
+#define ARB_SPEC_LSCAN 0        // 1: the specialised three-wave kernels compile the prefix-table path of phase B only (spec_ok asks for a small tree):
+                                // 341 -> 184 spilled registers and 3 % SLOWER (22.6 against 23.3 M world-steps/s, same box): off
+#endif
+            const bool lscan = (SPEC && CM == 2 && ARB_SPEC_LSCAN != 0) ? true : (LSCAN_OK && mp->lay.lscan);
             const bool use_table = lscan && TWO_PASS;
             WAVE_SYNC();
             // ---- lane = body: world-frame matrices of the body -----------------------------------
@@ -2181,7 +2200,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);      // about its tree's root
                 const T *Mb = mp->mass + 36 * b;
                 BD2 *trow = reinterpret_cast<BD2 *>(STG + TBS * b);
-                if (mp->has_visc && useB) {
+                if (!SPEC && mp->has_visc && useB) {
                     double Bv[36], G[36];
                     world_B(R, p, mp->visc + 36 * b, Bv);
                     world_G(R, p, Mb, G);
@@ -2236,7 +2255,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     return o;
                 };
                 // (first, while nothing else is live: this rarely taken block needs ~70 registers of its own)
-                if (mp->has_visc && useB) {                              // Bg = Ad^T B_b Ad (general 6x6)
+                if (!SPEC && mp->has_visc && useB) {                              // Bg = Ad^T B_b Ad (general 6x6)
                     const T *Vb = mp->visc + 36 * b;
                     const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
                     const M3<double> H12 = add(B12, hatmul(p, B22));
@@ -2714,7 +2733,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             if (do_constraints) {
                 for (int c = 0; c < nc; ++c) {
                     const int *ci = CI + CI_STRIDE * c;
-                    const int ct = ci[0];
+                    const int ct = SPEC ? (int)ARB_CT_SOFTFINGER : ci[0];
                     if (ct == ARB_CT_JOINTLIMITS) continue;
                     const T *cd = CD + c * CD_STRIDE;
                     if (cd[CD_ACTIVE] == T(0)) {            // not in the active set: zero rows (core.py:913-918)
@@ -2768,7 +2787,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             }
         }
         // joint-limit rows are dof selectors                              constraints.py:46-48
-        if (do_constraints) {
+        if (!SPEC && do_constraints) {
             for (int c = 0; c < nc; ++c)
                 if (CI[CI_STRIDE * c] == ARB_CT_JOINTLIMITS && lane == CI[CI_STRIDE * c + 5])
                     RT[(1 + 4 * c) * RS + lane] = CD[c * CD_STRIDE + CD_ACTIVE];
@@ -2789,7 +2808,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     for (int i = 0; i < NMAX; ++i) Z[i] += (i == lane) ? zd : T(0);
                 }
             }
-        } else if (mp->has_pd && lane < n && !lane_dead) {
+        } else if (!SPEC && mp->has_pd && lane < n && !lane_dead) {
             // model gains (controllers.py:141-158); per-world targets replace the model's tau0 when given
             T acc = (pwd.qdes != nullptr) ? T(0) : mp->pd_tau0[lane], accv = T(0);
             for (int i = 0; i < n; ++i) {
@@ -2846,7 +2865,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             }
         }
         // warm-started constraint forces enter the right-hand side          core.py:921-924
-        if (do_constraints && mp->has_warm && lane < n) {
+        if (!SPEC && do_constraints && mp->has_warm && lane < n) {
             for (int i = 0; i < ndol; ++i) rhs += RT[(1 + i) * RS + lane] * FF[i];
         }
         // ================= phase C: augmented Gauss-Jordan ===================
@@ -2965,7 +2984,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // (PD controllers: Z_a couples any pair of dofs) switch the skipping off.  (Skipping inside the ROLLED loop was
             // measured too: the rotation of the register tile turns a skipped update into a move, the per-group branches
             // break the interleaving of the broadcasts: -4.5 %.)
-            const bool z_dense = mp->has_pd || (FEAT_ALL && pwd.kp != nullptr);
+            const bool z_dense = (!SPEC && mp->has_pd) || (FEAT_ALL && pwd.kp != nullptr);
             const unsigned long long relv = (lane < n && !z_dense) ? (mp->upmask[lane] | mp->descmask[lane]) : ~0ull;
             const unsigned rel_lo = (unsigned)relv, rel_hi = (unsigned)(relv >> 32);
             static_for_desc(std::make_integer_sequence<int, NMAX>{}, [&](auto jc) {
@@ -3377,7 +3396,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                              lds + ARB_UNI(lp.sa_ff), AM, CD, VV, FF, WORK, two);
             } else {
                 using GSG = std::conditional_t<(ARB_GS_F64 != 0) && std::is_same<T, float>::value, double, T>;
-                gs_stage<T, MODE, GSG, !(sizeof(T) == 8 && NMAX == 64)>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
+                gs_stage<T, MODE, GSG, !(sizeof(T) == 8 && NMAX == 64), SPEC>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
             }
         }
 
@@ -3772,7 +3791,20 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
 #define ARB_LAUNCH_ONE_ARGS(T)                                                                                             \
     const DevModel<T> *, const Layout &, T *, T *, T *, const T *, const PerWorldPD<T> &, long, double, int, unsigned,   \
     const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, const double *, hipStream_t
-#ifdef ARB_PART
+#if defined(ARB_PART) && defined(ARB_PART_SPEC)      /* (translation units of their own: the specialised kernels, tiles 44 / 48) */
+#if ARB_PART_SPEC == 1         /* float32, one column set: two and three waves */
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 4, 2>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 5, 2>(ARB_LAUNCH_ONE_ARGS(float));
+#elif ARB_PART_SPEC == 2       /* float32, two column sets (eight contacts) */
+template int launch_one<float, ARB_PART_NMAX, 2, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 2, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));
+#else                          /* float64, one column set */
+template int launch_one<double, ARB_PART_NMAX, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(double));
+template int launch_one<double, ARB_PART_NMAX, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(double));
+#endif
+#elif defined(ARB_PART)
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 1, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
@@ -3820,6 +3852,19 @@ ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_
     extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));
 ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
 #undef ARB_EXTERN_TILE_W3
+#if ARB_WITH_SPEC
+#define ARB_EXTERN_TILE_SPEC(NM)                                                        \
+    extern template int launch_one<float, NM, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 4, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 5, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 2, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 2, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<double, NM, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
+    extern template int launch_one<double, NM, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(double));
+ARB_EXTERN_TILE_SPEC(44) ARB_EXTERN_TILE_SPEC(48)
+#undef ARB_EXTERN_TILE_SPEC
+#endif
 #if ARB_ALL_VARIANTS
 #define ARB_EXTERN_TILE_PK(NM)                                                          \
     extern template int launch_one<float, NM, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
@@ -3869,6 +3914,8 @@ struct arb_model {
     DevModel<float> *df_dev;
     DevModel<double> *dd_dev;
     bool packable = false;         // every constraint a SoftFingerContact with eps = (1,1,1), at most eight: two worlds per wavefront in the sweeps
+    bool spec_ok = false;          // four constraints per column set, all enabled SoftFingerContacts of plane / sphere pairs, no PD controller, no viscosity,
+                                   // one world per wavefront, tiles 44 / 48: the specialised kernels (FEAT bit 4)
     bool rdv_ok = false;           // ... at most FOUR, and the three-wave layout holds three more systems: the rendezvous build (CM = 4)
     int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
     Layout lf, lf3, lfp, ld;       // LDS layouts: float32 two-wave kernels, three-wave kernels, packed kernels; float64
@@ -4260,6 +4307,12 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     M->packable = nc >= 1 && nc <= 8 && fk == 1;      // (a forest's copies are retired one by one, which the packed build does not do)
     for (int c = 0; c < nc; ++c)
         M->packable = M->packable && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_eps[3 * c] == 1. && d->c_eps[3 * c + 1] == 1. && d->c_eps[3 * c + 2] == 1.;
+    M->spec_ok = ARB_WITH_SPEC && nc == 4 * M->nsets && fk == 1 && M->nmax >= 44 && M->nmax <= 48;
+    for (int c = 0; c < nc; ++c)
+        M->spec_ok = M->spec_ok && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_enabled[c] != 0 && d->c_geom[c] == ARB_CG_PLANE_SPHERE;
+    M->spec_ok = M->spec_ok && lds_scan(nb, M->nmax);                                         // (a small tree: phase B on the prefix table,
+    M->spec_ok = M->spec_ok && d->pd_kp == nullptr;                                           // (no PD controller in the model,
+    for (int i = 0; i < 36 * nb && M->spec_ok; ++i) M->spec_ok = d->visc[i] == 0.0;           //  no joint viscosity)
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) {
         g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err);
@@ -4492,6 +4545,24 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
     const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma) ? choose_build(M, noopt, nw, nsteps, flags) : BuildChoice();
     const bool w3 = bc.w3, pack = bc.pack, rdv = bc.rdv && cf != nullptr && nw * (long)nsteps < (1l << 30);
+    // the kernels specialised for the model class "four plane / sphere SoftFingerContacts" (FEAT bit 4): bit-identical to the
+    // general ones; ARB_FORCE_SPEC=0 in the environment runs the general kernels (development, tests)
+    // (float32 with one or two column sets, float64 with one)
+    const bool spec = ARB_WITH_SPEC && M->spec_ok && noopt && MODE == 0 && !mfma && !pack && !rdv &&
+                      (std::is_same<T, float>::value || M->nsets == 1) && env_int("ARB_FORCE_SPEC", 1) != 0;
+#if ARB_WITH_SPEC
+#define ARB_SPEC_CASE(NM) if (spec && M->nsets == 1) return w3 ? (plain ? ONE_(NM, 1, 4, 2) : ONE_(NM, 1, 5, 2)) : (plain ? ONE_(NM, 1, 4, 0) : ONE_(NM, 1, 5, 0));
+#define ARB_SPEC_CASE2(NM)                                                                                             \
+        if constexpr (MODE == 0 && NM >= 44 && NM <= 48) {                                                             \
+            if (spec && M->nsets == 1 && !std::is_same<T, float>::value) return plain ? ONE(NM, 1, 4) : ONE(NM, 1, 5); \
+            if constexpr (std::is_same<T, float>::value) {                                                             \
+                if (spec && M->nsets == 2) return plain ? ONE(NM, 2, 4) : ONE(NM, 2, 5);                               \
+            }                                                                                                          \
+        }
+#else
+#define ARB_SPEC_CASE(NM) (void)spec;
+#define ARB_SPEC_CASE2(NM)
+#endif
 #if ARB_WITH_RDV
 #define ARB_RDV_CASE(NM) if (rdv) return plain ? ONE_(NM, 1, 0, 4) : ONE_(NM, 1, 1, 4);
 #else
@@ -4512,6 +4583,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
             if constexpr (MODE == 0) {
                 ARB_RDV_CASE(44)
                 ARB_PACK_CASE(44)
+                ARB_SPEC_CASE(44)
                 if (w3 && plain) return ONE_(44, 1, 0, 2);
                 if (w3 && noopt) return ONE_(44, 1, 1, 2);
                 if (plain) return ONE(44, 1, 0);
@@ -4526,6 +4598,9 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         }
 #if ARB_QUICK >= 2
         if (M->nmax == 44 && M->nsets == 2) {
+#if ARB_WITH_SPEC
+            if constexpr (MODE == 0) { if (spec) return plain ? ONE(44, 2, 4) : ONE(44, 2, 5); }
+#endif
             if constexpr (MODE == 0) return plain ? ONE(44, 2, 0) : noopt ? ONE(44, 2, 1) : ONE(44, 2, 3);
             else return ONE(44, 2, 3);
         }
@@ -4541,8 +4616,10 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         if constexpr (MODE == 0 && std::is_same<T, float>::value && NM >= 44 && NM <= 48) {            \
             ARB_RDV_CASE(NM)                                                                           \
             ARB_PACK_CASE(NM)                                                                          \
+            ARB_SPEC_CASE(NM)                                                                          \
             if (w3) return plain ? ONE_(NM, 1, 0, 2) : noopt ? ONE_(NM, 1, 1, 2) : ONE_(NM, 1, 3, 2);  \
         }                                                                                              \
+        ARB_SPEC_CASE2(NM)                                                                             \
         if constexpr (MODE == 0) {                                                                     \
             if (plain) return (M->nsets == 2) ? ONE(NM, 2, 0) : ONE(NM, 1, 0);                         \
             if (noopt) return (M->nsets == 2) ? ONE(NM, 2, 1) : ONE(NM, 1, 1);                         \
@@ -4737,6 +4814,8 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
                        env_int("ARB_QUEUE_CHUNK", 4) > 0) ? 1 : 0;
     out->feat = optional_inputs <= 0 ? 0 : optional_inputs == 1 ? 1 : 3;
     if (!noopt) out->feat = 3;
+    // (the specialised kernels, see launch(): plain inputs or user torques of a model of their class, float32)
+    if (ARB_WITH_SPEC && M->spec_ok && noopt && (dtype == ARB_F32 || M->nsets == 1) && !mfma && !bc.pack && !bc.rdv && env_int("ARB_FORCE_SPEC", 1) != 0) out->feat |= 4;
     return ARB_OK;
 }
 
@@ -4854,7 +4933,7 @@ extern "C" int arb_dev_softfinger_solve(int dtype, int device, int n, const doub
 
 // build variants compiled into this library: bit 0 packed pairs (ARB_FORCE_PACK=1), bit 1 the rendezvous build (ARB_FORCE_RDV=1),
 // bit 2 sweeps without the fast variant of the local solve (-DARB_GS_FAST=0)
-extern "C" int arb_build_variants(void) { return (ARB_ALL_VARIANTS ? 1 : 0) | (ARB_WITH_RDV ? 2 : 0) | (ARB_GS_FAST ? 0 : 4); }
+extern "C" int arb_build_variants(void) { return (ARB_ALL_VARIANTS ? 1 : 0) | (ARB_WITH_RDV ? 2 : 0) | (ARB_GS_FAST ? 0 : 4) | (ARB_WITH_SPEC ? 0 : 8); }
 
 // eig6 (one lane, matrix in LDS) and eig6_wave (the whole wavefront) on the same matrices, see arb_eig6_test_kernel
 extern "C" int arb_dev_eig6_pair(int dtype, int device, int n, const double *A /*[n][36]*/, double *out /*[n][28]*/) {

@@ -44,8 +44,9 @@ int arb_dev_softfinger_solve(int dtype, int device, int n, const double *in, dou
 int arb_dev_eig6_pair(int dtype, int device, int n, const double *A, double *out);
 /* Build variants compiled into the loaded library: bit 0 packed pairs (two worlds per wavefront, ARB_FORCE_PACK=1 in the
  * environment), bit 1 the rendezvous build (ARB_FORCE_RDV=1), bit 2 Gauss-Seidel sweeps that run the complete variant of
- * the local solve throughout (no fast variant).  0 for libarbstep.so; 7 for libarbstep_variants.so (make variants), which
- * the bit-identity tests of those builds load. */
+ * the local solve throughout (no fast variant), bit 3 no specialised kernels (the general kernels also for models with four
+ * plane / sphere SoftFingerContacts).  0 for libarbstep.so; 15 for libarbstep_variants.so (make variants), which the
+ * bit-identity tests of those builds load. */
 int arb_build_variants(void);
 
 /* Raw branch code of the first stage of the solve: 0, 1, 2 as above, 3 = sliding but the register-only shift

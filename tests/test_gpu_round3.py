@@ -481,7 +481,8 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
     build = lambda p: (p["waves_per_simd"], p["worlds_per_wavefront"])
     p = bw.plan(4 * cus, 40)
-    assert build(p) == (2, 1) and p["work_queue"] == 0 and p["feat"] == 0 and p["wave_slots"] == 8 * cus
+    # (feat 4 / 5: the kernels specialised for four plane / sphere SoftFingerContacts, round 4 -- tests/test_gpu_round4.py)
+    assert build(p) == (2, 1) and p["work_queue"] == 0 and p["feat"] == 4 and p["wave_slots"] == 8 * cus
     p = bw.plan(16 * cus, 40)
     assert build(p) == (3, 1) and p["work_queue"] == 1 and p["wave_slots"] == 12 * cus
     assert p["lds_bytes"] * 12 <= 160 * 1024
@@ -489,7 +490,7 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     assert build(bw.plan(16 * cus, 40, waves=2)) == (2, 1)
     assert build(bw.plan(4 * cus, 40, waves=3)) == (3, 1)
     p = bw.plan(64 * cus, 40, ext_gforce=True)
-    assert build(p) == (3, 1) and p["feat"] == 1 and p["work_queue"] == 1
+    assert build(p) == (3, 1) and p["feat"] == 5 and p["work_queue"] == 1
     assert p["lds_bytes"] <= 10 * 1280                       # twelve wavefronts per CU at the 1280-byte LDS granule
     assert build(bw.plan(64 * cus, 40, other_inputs=True)) == (3, 1) and bw.plan(64 * cus, 40, other_inputs=True)["feat"] == 3
     assert build(bw.plan(64 * cus, 40, waves=3)) == (3, 1)

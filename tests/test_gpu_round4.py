@@ -1,0 +1,89 @@
+"""Round-4 GPU tests (through the C ABI): the kernels specialised for a model class.
+
+`arb_step_kernel`'s FEAT bit 4 (csrc/arb_kernels.hip): for models with exactly four enabled plane / sphere SoftFingerContacts
+(eight when the model has two column sets), no PD controller and no joint viscosity -- human36 on the floor, BASELINE
+configs 3 and 5 and the reference's own eight-contact scenario -- the constraint type, the shape pair, nc and ndol are
+compile-time constants and the code of the absent model features is not compiled in (+8 % on the headline workload).  Same expressions on the same values: the results must equal the general kernels' bit for bit, which
+`ARB_FORCE_SPEC=0` in the environment selects in the same library.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_model
+from arboris_python_amd import _capi
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def test_plan_reports_the_specialised_kernels(monkeypatch):
+    from arboris_python_amd.batch import BatchedWorlds
+    for v in ("ARB_FORCE_SPEC", "ARB_FORCE_WAVES"):
+        monkeypatch.delenv(v, raising=False)
+    assert _capi.load().arb_build_variants() == 0
+    # model: (float32, float64)
+    want = {"human36_c4": (True, True),          # four plane / sphere SoftFingerContacts
+            "human36_c8": (True, False),         # eight, two column sets: float32 only
+            "human36_g": (False, False),         # no constraints
+            "human36_c4_pdw": (False, False),    # a PD controller in the model: a dense impedance, outside the class
+            "simplearm": (False, False)}
+    for name, (spec32, spec64) in want.items():
+        m, _, _ = load_model(name)
+        bw = BatchedWorlds(m)
+        for B, T in ((512, 1), (8192, 40)):
+            assert bool(bw.plan(B, T)["feat"] & 4) == spec32, (name, B, T)
+            assert bool(bw.plan(B, T, ext_gforce=True)["feat"] & 4) == spec32, (name, B, T)
+            assert bw.plan(B, T, other_inputs=True)["feat"] == 3, (name, B, T)       # every optional input: the general kernel
+            assert bool(bw.plan(B, T, dtype=torch.float64)["feat"] & 4) == spec64, (name, B, T)
+        if spec32:
+            monkeypatch.setenv("ARB_FORCE_SPEC", "0")
+            assert bw.plan(8192, 40)["feat"] == 0
+            monkeypatch.delenv("ARB_FORCE_SPEC")
+        bw.close()
+
+
+@pytest.mark.parametrize("torques", [False, True])
+@pytest.mark.parametrize("model,dtype", [("human36_c4", "float32"), ("human36_c4", "float64"), ("human36_c8", "float32")])
+def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, dtype, torques):
+    """Whole falling episodes (free fall, impact, sliding, the rare routes of the local solve late in the episode), two- and
+    three-wave builds, the work queue, one launch per step; plain inputs (FEAT 4 against 0) and user torques (5 against 1);
+    float32 with four and with eight contacts (two column sets), float64 with four."""
+    from arboris_python_amd import synth
+    from arboris_python_amd.batch import BatchedWorlds
+    for v in ("ARB_FORCE_SPEC", "ARB_FORCE_WAVES", "ARB_FORCE_PACK", "ARB_FORCE_RDV"):
+        monkeypatch.delenv(v, raising=False)
+    m, _, _ = load_model(model)
+    dt_ = getattr(torch, dtype)
+    bw = BatchedWorlds(m)
+    T = 40
+    cases = [(4096, "episode", {}), (700, "episode", {}), (1500, "per_step", {})]
+    if model == "human36_c4" and dtype == "float32":
+        cases.insert(1, (4096, "episode", dict(waves=2)))
+    for B, mode, kw in cases:
+        q, dq = synth.standing_states(m, B, seed=4000 + B, drop=0.03, vel=0.1)
+        ext = None
+        if torques:
+            rng = np.random.default_rng(B)
+            ext = torch.as_tensor(rng.normal(0., 0.5, (B, m.ndof)), dtype=dt_, device="cuda")
+        assert bw.plan(B, 1 if mode == "per_step" else T, dtype=dt_, ext_gforce=torques, **kw)["feat"] == (5 if torques else 4)
+        res = {}
+        for key in ("spec", "general"):
+            if key == "general":
+                monkeypatch.setenv("ARB_FORCE_SPEC", "0")
+            tq, tdq = bw.to_device(q, dq, dt_)
+            cf = bw.new_cforce(B, dt_)
+            if mode == "per_step":
+                for _ in range(T):
+                    bw.step(tq, tdq, 5e-3, 1, cforce=cf, ext_gforce=ext)
+            else:
+                bw.step(tq, tdq, 5e-3, T, cforce=cf, ext_gforce=ext, **kw)
+            torch.cuda.synchronize()
+            bw.status()
+            monkeypatch.delenv("ARB_FORCE_SPEC", raising=False)
+            res[key] = (tq, tdq, cf)
+        if not torques:
+            assert bool(torch.isfinite(res["spec"][0]).all())
+        assert float(torch.nan_to_num(res["spec"][2]).abs().max()) > 0.            # (the contacts did act)
+        bits = torch.int32 if dtype == "float32" else torch.int64                   # (bit patterns: a diverged world's NaN included)
+        assert all(torch.equal(a.view(bits), b.view(bits)) for a, b in zip(res["spec"], res["general"])), (B, mode, kw)
+    bw.close()
