@@ -1105,8 +1105,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     // SoftFingerContact of a plane / sphere (or point) pair, and neither a PD controller nor joint viscosity in the model
     // (arb_model::spec_ok, checked by the host): the constraint type, the shape pair, nc and ndol are compile-time constants
     // and the code of the absent features is not compiled in.  Same expressions: bit-identical results.  (Measured, float32,
-    // 4096 worlds: constants +3 %, without the PD / viscosity code +8 % -- code that is never executed still costs the
-    // phases around it registers.)
+    // 4096 worlds: constants +3 %, without the viscosity / PD / warm-start code +8 %.  One by one in the general kernel:
+    // viscosity +3 % -- its block was the FIRST term of phase B's accumulators, see there --, PD -1 %, warm start 0 %.)
     constexpr bool SPEC = (FEAT & 4) != 0;
     constexpr int SPEC_NC = 4 * NSETS;
     static_assert(!SPEC || (!FEAT_ALL && MODE == 0 && (CM == 0 || CM == 2)), "specialised kernels: plain inputs / user torques");
@@ -2254,21 +2254,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     }
                     return o;
                 };
-                // (first, while nothing else is live: this rarely taken block needs ~70 registers of its own)
-                if (!SPEC && mp->has_visc && useB) {                              // Bg = Ad^T B_b Ad (general 6x6)
-                    const T *Vb = mp->visc + 36 * b;
-                    const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
-                    const M3<double> H12 = add(B12, hatmul(p, B22));
-                    const M3<double> H21 = sub(B21, rowcross(B22, p));
-                    const M3<double> H11 = add(sub(B11, rowcross(B12, p)), hatmul(p, H21));
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            Acc[6 * i + j] += H11.a[3 * i + j]; Acc[6 * i + 3 + j] += H12.a[3 * i + j];
-                            Acc[6 * (3 + i) + j] += H21.a[3 * i + j]; Acc[6 * (3 + i) + 3 + j] += B22.a[3 * i + j];
-                        }
-                }
                 // (before the 3x3 blocks, so that R and p die with them) wrenches to world axes: Ad(b<-g)^T f = (R tau + p x R f, R f)
                 double wr[NACC - 57];              // world wrench of the increment rhs (6) [| gravity wrench (6), inspect]
                 {
@@ -2336,6 +2321,26 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                         Acc[6 * r] += t.x; Acc[6 * r + 1] += t.y; Acc[6 * r + 2] += t.z;
                         Acc[6 * r + 3] += u.x; Acc[6 * r + 4] += u.y; Acc[6 * r + 5] += u.z;
                     }
+                }
+                // Viscosity (rare): Bg = Ad^T B_b Ad, a general 6x6, added LAST, from the pose read again -- as the first term of the
+                // sums (until round 4) it made every accumulator a value that is live from its zero on, through this never
+                // taken branch, to its first real term: 3 % of the launch for every model without viscosity.
+                if (!SPEC && mp->has_visc && useB) {
+                    const M3<double> Rv = ld_m3(PD + 12 * b);
+                    const V3<double> pv = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);
+                    auto rotv = [&](const M3<double> &Xm) { return mul(Rv, mulBT(Xm, Rv)); };
+                    const T *Vb = mp->visc + 36 * b;
+                    const M3<double> B11 = rotv(blk(Vb, 0, 0)), B12 = rotv(blk(Vb, 0, 3)), B21 = rotv(blk(Vb, 3, 0)), B22 = rotv(blk(Vb, 3, 3));
+                    const M3<double> H12 = add(B12, hatmul(pv, B22));
+                    const M3<double> H21 = sub(B21, rowcross(B22, pv));
+                    const M3<double> H11 = add(sub(B11, rowcross(B12, pv)), hatmul(pv, H21));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            Acc[6 * i + j] += H11.a[3 * i + j]; Acc[6 * i + 3 + j] += H12.a[3 * i + j];
+                            Acc[6 * (3 + i) + j] += H21.a[3 * i + j]; Acc[6 * (3 + i) + 3 + j] += B22.a[3 * i + j];
+                        }
                 }
                 if (!use_table) {
 #pragma unroll
