@@ -26,7 +26,7 @@ for k in range(36):
         fa, fb = tq.clone(), tdq.clone(); fc = bw.new_cforce(B, torch.float32)
         sa, sb = tq.clone(), tdq.clone(); sc = bw.new_cforce(B, torch.float32)
         bw.step(fa, fb, dt, 1, cforce=fc, fused=True)
-        bw.step(sa, sb, dt, 1, cforce=sc, split=True)
+        bw.step(sa, sb, dt, 1, cforce=sc, split="wave")
         torch.cuda.synchronize()
         e = np.maximum(werr(fa, sa), werr(fb, sb))
         bad = np.nonzero(~(e < 1e-4))[0]
