@@ -12,9 +12,10 @@ Hdf5Logger :133-289).  Two levels:
   layout as ``Hdf5Logger``: ``timeline (nsteps,)``, ``gpositions/<joint>``,
   ``gvelocities/<joint>``, ``transforms/<name> (nsteps,4,4)``.
 
-``Hdf5Logger`` has the reference's constructor and dataset layout.  h5py is not a dependency: files are
-written as HDF5 when h5py is importable and the name ends in .h5/.hdf5, else as ``.npz`` archives whose keys
-are the dataset paths.
+``Hdf5Logger`` has the reference's constructor and dataset layout.  Names that end in .h5/.hdf5 give real HDF5
+files -- through h5py when it is importable, else through the package's own minimal writer (``h5min``: the plain
+groups-of-float64-datasets subset the reference uses, readable by the HDF5 library and by h5py) --; any other
+name gives an ``.npz`` archive whose keys are the dataset paths.
 """
 import time
 
@@ -95,15 +96,32 @@ class PerfMonitor(Observer):
                 .format(d.sum(), d.min(), d.mean(), d.max()))
 
 
+def _write_hdf5(filename, data, mode="w"):
+    """``{dataset path: array}`` into an HDF5 file: h5py when importable, else ``h5min`` (mode 'a': the datasets already
+    in the file are kept, those of the same path replaced -- ``h5min`` rewrites the file)."""
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(filename, mode) as f:
+            for k, v in data.items():
+                if k in f:
+                    del f[k]
+                f[k] = v
+        return
+    import os
+    from . import h5min
+    merged = {}
+    if mode == "a" and os.path.exists(filename):
+        merged.update(h5min.read(filename))
+    merged.update(data)
+    h5min.write(filename, merged)
+
+
 def _save_datasets(filename, data):
     if filename.endswith((".h5", ".hdf5")):
-        try:
-            import h5py
-        except ImportError:
-            raise RuntimeError("h5py is not installed; use a .npz file name")
-        with h5py.File(filename, "w") as f:
-            for k, v in data.items():
-                f[k] = v
+        _write_hdf5(filename, data)
     else:
         np.savez_compressed(filename, **data)
 
@@ -171,8 +189,8 @@ class Hdf5Logger(TrajectoryLogger):
     ``transforms`` holds one entry per body (``flat=True``, ``Body.pose``) or per joint (``flat=False``,
     ``Joint.pose`` under the name of the joint's second frame), plus the world's moving sub-frames (the contact
     frames).  ``root`` is ``group`` inside the file (default "/").  The file is written by ``finish()``: HDF5
-    through ``h5py`` when the name ends in .h5/.hdf5 -- h5py is not a dependency of this package, a clear error
-    is raised at construction when it is missing -- or a ``.npz`` archive whose keys are the dataset paths.
+    when the name ends in .h5/.hdf5 (h5py when importable, else the package's own ``h5min`` writer: the same
+    groups and float64 datasets, readable by the HDF5 library) or a ``.npz`` archive whose keys are the dataset paths.
     (The reference stores the ``model`` datasets in the ``transforms`` group and reads a ``World.admittance``
     attribute that does not exist; this class follows its documented layout.)
     """
@@ -186,12 +204,6 @@ class Hdf5Logger(TrajectoryLogger):
         self._group = "/".join(g for g in group.split("/") if g)
         self._save_model = save_model
         self._hdf5 = filename.endswith((".h5", ".hdf5"))
-        if self._hdf5:
-            try:
-                import h5py  # noqa: F401
-            except ImportError:
-                raise RuntimeError("Hdf5Logger(%r): h5py is not installed; give a .npz file name to get the same "
-                                   "datasets in a NumPy archive" % filename)
 
     @property
     def root(self):
@@ -225,13 +237,7 @@ class Hdf5Logger(TrajectoryLogger):
     def finish(self):
         prefix = self._group + "/" if self._group else ""
         if self._hdf5:
-            import h5py
-            with h5py.File(self._filename, self._mode) as f:
-                for key, v in self.data.items():
-                    path = prefix + key
-                    if path in f:
-                        del f[path]
-                    f[path] = v
+            _write_hdf5(self._filename, {prefix + key: v for key, v in self.data.items()}, self._mode)
             return
         data = {}
         import os

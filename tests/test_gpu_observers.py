@@ -137,10 +137,16 @@ def test_object_api_observers(tmp_path):
     assert "mean computation time" in perf.get_summary()
 
 
-def test_hdf5logger_layout_and_values(tmp_path):
+@pytest.mark.parametrize("ext", ["npz", "h5"])
+def test_hdf5logger_layout_and_values(tmp_path, ext):
     """Hdf5Logger through simulate(): the reference's dataset layout (observers.py:155-192), values against
-    the reference's simplearm run (tests/golden/g1_simplearm.npz = the payload of simplearm_flat.h5)."""
+    the reference's simplearm run (tests/golden/g1_simplearm.npz = the payload of simplearm_flat.h5).  As an .npz
+    archive and as a real HDF5 file (h5py when installed, else the package's own writer, arboris_python_amd/h5min.py --
+    read back here with h5min's reader, by the HDF5 library itself in tests/test_h5min.py)."""
     from conftest import load_golden
+    from arboris_python_amd import h5min
+    load = (lambda fn: np.load(fn)) if ext == "npz" else h5min.read
+    files = (lambda d: d.files) if ext == "npz" else (lambda d: list(d))
     from arboris_python_amd import scenes
     from arboris_python_amd.core import simulate
     from arboris_python_amd.observers import Hdf5Logger
@@ -148,9 +154,9 @@ def test_hdf5logger_layout_and_values(tmp_path):
     w = scenes.simplearm_world()
     w.getjoints()['Shoulder'].gpos[0] = 3.14 / 4
     timeline = np.arange(0, 1, .01)
-    f = str(tmp_path / "run.npz")
+    f = str(tmp_path / ("run." + ext))
     simulate(w, timeline, [Hdf5Logger(f, group="sim", mode='w', save_state=True, flat=True, save_model=True)])
-    d = np.load(f)
+    d = load(f)
     n = len(timeline) - 1
     assert d["sim/timeline"].shape == (n,) and np.allclose(d["sim/timeline"], timeline[:-1])
     for j in ("Shoulder", "Elbow", "Wrist"):
@@ -168,8 +174,9 @@ def test_hdf5logger_layout_and_values(tmp_path):
     assert np.abs(Z @ d["sim/model/admittance"][k] - np.eye(3)).max() < 1e-8
     # append mode keeps what is in the file
     simulate(w, timeline[:5], [Hdf5Logger(f, group="again", mode='a', save_transforms=False, save_state=True)])
-    d = np.load(f)
-    assert "sim/timeline" in d.files and d["again/gvelocities/Elbow"].shape == (4, 1)
+    d = load(f)
+    assert "sim/timeline" in files(d) and d["again/gvelocities/Elbow"].shape == (4, 1)
+    assert d["sim/transforms/Arm"].shape == (n, 4, 4)
 
 
 @pytest.mark.parametrize("name", ["simplearm", "snake9_free"])
