@@ -2036,7 +2036,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #define ARB_SPEC_LSCAN 0        // 1: the specialised three-wave kernels compile the prefix-table path of phase B only (spec_ok asks for a small tree):
                                 // 341 -> 184 spilled registers and 3 % SLOWER (22.6 against 23.3 M world-steps/s, same box): off
 #endif
-            const bool lscan = (SPEC && CM == 2 && ARB_SPEC_LSCAN != 0) ? true : (LSCAN_OK && mp->lay.lscan);
+            const bool lscan = (SPEC && ((CM == 2 && (ARB_SPEC_LSCAN & 1)) || (CM == 0 && (ARB_SPEC_LSCAN & 2)))) ? true : (LSCAN_OK && mp->lay.lscan);
             const bool use_table = lscan && TWO_PASS;
             WAVE_SYNC();
             // ---- lane = body: world-frame matrices of the body -----------------------------------
