@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             bool jumped = false;
             if constexpr (sizeof(T) == 8) {
                 const int maxdep = ARB_UNI(mp->maxdepth);
-                if (maxdep >= ARB_JUMP_DEPTH) {
+                if (!SPEC && maxdep >= ARB_JUMP_DEPTH) {          // (the specialised kernels' class: shallow trees)
                     jumped = true;
                     int rounds = 0;
                     while ((1 << rounds) < maxdep + 1) ++rounds;
@@ -1960,7 +1960,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 bool jumped = false;
                 if constexpr (sizeof(T) == 8) {
                     const int maxdep = ARB_UNI(mp->maxdepth);
-                    if (maxdep >= ARB_JUMP_DEPTH) {
+                    if (!SPEC && maxdep >= ARB_JUMP_DEPTH) {
                         jumped = true;
                         int rounds = 0;
                         while ((1 << rounds) < maxdep + 1) ++rounds;
@@ -4315,7 +4315,8 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     M->spec_ok = ARB_WITH_SPEC && nc == 4 * M->nsets && fk == 1 && M->nmax >= 44 && M->nmax <= 48;
     for (int c = 0; c < nc; ++c)
         M->spec_ok = M->spec_ok && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_enabled[c] != 0 && d->c_geom[c] == ARB_CG_PLANE_SPHERE;
-    M->spec_ok = M->spec_ok && lds_scan(nb, M->nmax);                                         // (a small tree: phase B on the prefix table,
+    M->spec_ok = M->spec_ok && maxdepth < ARB_JUMP_DEPTH;                                     // (a shallow tree: no log-depth chains in float64)
+    M->spec_ok = M->spec_ok && lds_scan(nb, M->nmax);                                         // (a small tree: phase B on the prefix table)
     M->spec_ok = M->spec_ok && d->pd_kp == nullptr;                                           // (no PD controller in the model,
     for (int i = 0; i < 36 * nb && M->spec_ok; ++i) M->spec_ok = d->visc[i] == 0.0;           //  no joint viscosity)
     DeviceGuard guard_(device);
@@ -4578,7 +4579,9 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #else
 #define ARB_PACK_CASE(NM) (void)pack;
 #endif
-#define ONE_(NM, NS, FT, CMV) launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st)
+// (the instantiation must fit the model: a kernel with the wrong tile, column sets or model class computes on, silently wrong --
+// round 4's first launch table sent an 8-contact model to the one-set specialised kernel; checked at every launch since)
+#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS)))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st))
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
