@@ -85,7 +85,7 @@ EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_
             "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_step_plan", "arb_step", "arb_step_ex", "arb_rollout",
             "arb_inspect"]
 # every symbol include/arbstep_hooks.h declares: host builds of the device math (unit tests, Constraint.solve)
-TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_build_variants", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
+TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_build_variants", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_real_root_cascade", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
               "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
 
 _lib = None
@@ -160,6 +160,8 @@ def _open(path):
     lib.arb_host_softfinger_try.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double, C.c_double, _PD]
     lib.arb_host_slide_root.restype = C.c_int
     lib.arb_host_slide_root.argtypes = [_PD, C.c_double, C.c_double, C.c_double, _PD]
+    lib.arb_host_real_root_cascade.restype = C.c_int
+    lib.arb_host_real_root_cascade.argtypes = [_PD, C.c_double, _PD]
     lib.arb_build_variants.restype = C.c_int
     lib.arb_build_variants.argtypes = []
     lib.arb_dev_eig6_pair.restype = C.c_int

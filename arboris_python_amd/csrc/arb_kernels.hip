@@ -679,6 +679,28 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                                 shift = (root <= 0.) ? (G)(root > -1e10 ? root : -1e10) : G(-1e10);
                                 have = true;
                             }
+#if ARB_ROOT_CASCADE && ARB_ROOT_QM && ARB_POLY_LANES && !defined(ARB_GSSTAMPS)
+                            if constexpr (!FAST) {
+                                if (!have) {
+                                    // (rare) the iteration declined -- complex roots in its way --: the derivative cascade decides
+                                    // in float64 (arb_math.h: slide_real_root_cascade), every lane on the sextic of c's quad
+                                    double pb[7];
+#pragma unroll
+                                    for (int i = 0; i < 6; ++i) pb[i] = bcast(pcq[i], base);
+                                    pb[6] = 1.;
+                                    const double rbq = bcast(q_nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa)), base);
+                                    int rc = -1;
+                                    if (rbq > 0. && rbq < 1e300) rc = slide_real_root_cascade(pb, -1.0001 * rbq - 1e-300, &root, reinterpret_cast<double *>(WORK));
+                                    if (rc >= 0) {
+                                        if (MODE == 1) { ++st_slow; --st_fast; }
+                                        shift = (rc == 1) ? (G)(root > -1e10 ? root : -1e10) : G(-1e10);
+                                        have = true;
+                                        warm = NAN;
+                                        if (inquad) q_wmove = NAN;
+                                    }
+                                }
+                            }
+#endif
                         }
                         if constexpr (FAST) {
                             if (!have) return false;        // (rare: the complete variant takes over at this solve)
@@ -973,10 +995,11 @@ __device__ __forceinline__ void gs_stage_n(const DevModel<T> *mp, const int lane
                 }
                 double warm = q_warm;
                 bool have = false;
+                double c1 = 0., kappa = 0.;
                 {
                     const T yc[3] = {q_yc0, q_yc1, q_yc2};
                     const T bq[3] = {q_muyn * yc[0], q_muyn * yc[1], q_muyn * yc[2]};
-                    double c1, kappa, root;
+                    double root;
                     slide_c1_kappa<T>(alpha, yc, q_iyn, q_muyn, bq, q_bsq, &c1, &kappa);
                     double woff = -1.;
                     if (sizeof(T) == 4 && q_wmove == q_wmove)
@@ -997,6 +1020,23 @@ __device__ __forceinline__ void gs_stage_n(const DevModel<T> *mp, const int lane
                     for (int h = 0; h < NG; ++h) {
                         if (!((needfb >> (GL * h + base)) & 1ull)) continue;
                         const bool hq = want && grp == h;
+#if ARB_ROOT_CASCADE
+                        {   // (as gs_stage: the derivative cascade first, every lane on the sextic of this world's quad)
+                            double pq[7], pb[7], croot = 0.;
+                            slide_poly(q_sp, c1, kappa, pq);
+                            const int src = GL * h + base;
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) pb[i] = bcast(pq[i], src);
+                            pb[6] = 1.;
+                            const double rbq = bcast(q_sp.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa)), src);
+                            int rc = -1;
+                            if (rbq > 0. && rbq < 1e300) rc = slide_real_root_cascade(pb, -1.0001 * rbq - 1e-300, &croot, reinterpret_cast<double *>(WORK));
+                            if (rc >= 0) {
+                                if (hq) { shift = (rc == 1) ? (T)(croot > -1e10 ? croot : -1e10) : T(-1e10); warm = NAN; q_wmove = NAN; }
+                                continue;
+                            }
+                        }
+#endif
                         if (hq) softfinger_sliding_shift<T>(Y, alpha, q_mu, eps, WORK, &shift, false);
                         WAVE_SYNC();
                         T sh_fb;
@@ -4984,6 +5024,13 @@ extern "C" int arb_host_softfinger_try(int dtype, const double *vel, const doubl
 extern "C" int arb_host_slide_root(const double *Y, double c1, double kappa, double warm, double *root) {
     const SlidePre k = slide_precompute<double>(Y);
     return slide_leftmost_root(k, c1, kappa, warm, root) ? 1 : 0;
+}
+
+// the derivative cascade on a sextic given by its seven coefficients (constant term first): the leftmost real root in
+// [lo, 0]; returns 1 with *root, 0 when there is none, -1 for non-finite input
+extern "C" int arb_host_real_root_cascade(const double *pc, double lo, double *root) {
+    if (!pc || !root) return -1;
+    return slide_real_root_cascade(pc, lo, root);
 }
 
 // (pseudo-)inverse of an nd x nd block as the kernels form it: returns 1 when the pivoted elimination was kept,

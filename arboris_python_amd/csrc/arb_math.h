@@ -1091,6 +1091,9 @@ ARB_HD double arb_fast_sqrt(double x) {
 // where E/O are the parts of chi(s +- d), rho(s +- d) even/odd in d (all real whatever the
 // sign of d2):  E_chi = chi(s) + d2 (3s - tr),  O_chi = chi'(s) + d2,  E_rho = rho(s) + 3 d2,
 // O_rho = rho'(s).  (Matrix determinant lemma on (Q - s + c1 11^T)(Q - s) + kappa I.)
+#ifndef ARB_ROOT_CASCADE
+#define ARB_ROOT_CASCADE 1      // the sliding solve's fallback decides by the derivative cascade (slide_real_root_cascade) before the 6x6 eigenvalue routine is asked
+#endif
 struct SlidePre { double tr, m2, det, sQ, sA, nq; };
 
 template <typename T>
@@ -1228,6 +1231,108 @@ ARB_HD bool slide_leftmost_root(const SlidePre &k, double c1, double kappa, doub
         x = xn;
     }
     return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The leftmost real root of the sextic in [lo, 0] when the iteration above declines (a complex pair leftmost, or nearly
+// so): the DERIVATIVE CASCADE.  The real roots of p^(j+1) cut [lo, 0] into pieces on which p^(j) is monotone; a piece
+// holds a real root of p^(j) exactly when p^(j) changes sign over it, and a bracketed Newton iteration finds it.  From
+// the linear p^(5) down to p itself, whose first root is the answer (constraints.py:826-830: the smallest real
+// eigenvalue <= 0).  Float64 throughout: the decision "real or complex" is taken by the sign of p at a stationary
+// point, i.e. to the rounding of a float64 Horner value -- the reference's float64 eigvals decides the same cases,
+// the float32 QR sequence this route runs before (eig6) decided them in float32.  Round 4: ~100 k cycles per
+// fallback for the QR sequence on the whole wavefront; this route is plain scalar arithmetic, the same for host and
+// device.  Returns 1 with *root, 0 when p has no real root in [lo, 0], -1 when the input is not finite.
+// ---------------------------------------------------------------------------------------------------------------
+// (one instance of the level code and of the bracketed iteration serves the six levels -- the polynomial of a level is the
+// degree-6 form with zeros on top --, and the coefficients and the two root lists live in `buf`, 19 doubles: in the kernels
+// the LDS scratch array, every lane writing the same values; the route costs the sweeps' loop neither code nor registers)
+ARB_HD void cascade_horner(const double c[7], double x, double &f, double &df) {
+    f = c[6]; df = 0.;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) { df = df * x + f; f = f * x + c[i]; }
+}
+
+// root of the polynomial c between a and b, where it is monotone and f(a) = fa, f(b) differ in sign
+ARB_HD double cascade_solve(const double c[7], double a, double fa, double b) {
+    double xl = (fa < 0.) ? a : b, xh = (fa < 0.) ? b : a;          // f(xl) < 0 < f(xh)
+    double x = 0.5 * (a + b), dxold = fabs(b - a), dx = dxold, f, df;
+    cascade_horner(c, x, f, df);
+    for (int it = 0; it < 200; ++it) {
+        if (f == 0.) return x;
+        if (f < 0.) xl = x; else xh = x;
+        const bool outside = ((x - xh) * df - f) * ((x - xl) * df - f) > 0.;
+        const bool slow = fabs(2. * f) > fabs(dxold * df);
+        dxold = dx;
+        double xn;
+        if (outside || slow || !(df != 0.)) { dx = 0.5 * (xh - xl); xn = xl + dx; }      // bisection
+        else { dx = f / df; xn = x - dx; }                                                 // Newton
+        if (xn == x) return x;
+        x = xn;
+        if (fabs(dx) <= 2.3e-16 * fabs(x)) return x;
+        cascade_horner(c, x, f, df);
+    }
+    return x;
+}
+
+ARB_HD int slide_real_root_cascade(const double pc[7], double lo, double *root, double *buf /* [19] */) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) if (!(fabs(pc[i]) < 1e300)) return -1;
+    if (!(lo < 0.) || !(lo > -1e300)) return -1;
+    // C(i + J, J): p^(J)(x) / J! = sum_i C(i + J, J) pc[i + J] x^i
+    const double BINOM[6][7] = {{1., 1., 1., 1., 1., 1., 1.}, {1., 2., 3., 4., 5., 6., 0.}, {1., 3., 6., 10., 15., 0., 0.},
+                                {1., 4., 10., 20., 0., 0., 0.}, {1., 5., 15., 0., 0., 0., 0.}, {1., 6., 0., 0., 0., 0., 0.}};
+    double *pcs = buf + 12;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pcs[i] = pc[i];
+    int nprev = 0, off_prev = 0;                        // roots of the level above: buf[off_prev .. off_prev + nprev)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int J = 5; J >= 0; --J) {
+        double c[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) c[i] = (i + J <= 6) ? BINOM[J][i] * pcs[(i + J <= 6) ? i + J : 6] : 0.;
+        const double *prev = buf + off_prev;
+        double *cur = buf + (6 - off_prev);
+        int n = 0;
+        double last = lo - 1.;
+        double a = lo, fa, fb, d_;
+        cascade_horner(c, a, fa, d_);
+        bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+        for (int k = 0; k <= nprev && !done; ++k) {
+            const double b = (k < nprev) ? prev[k] : 0.;
+            cascade_horner(c, b, fb, d_);
+            double r = 0.;
+            bool got = false;
+            if (fa == 0.) { r = a; got = true; }
+            else if (fb != 0. && ((fa < 0.) != (fb < 0.))) { r = cascade_solve(c, a, fa, b); got = true; }
+            if (got && n < 6 && (n == 0 || r > last)) {
+                cur[n] = r; last = r; ++n;
+                done = (J == 0);                         // of p itself only the first root is asked for
+            }
+            a = b; fa = fb;
+        }
+        if (!done && fa == 0. && n < 6 && (n == 0 || 0. > last)) { cur[n] = 0.; ++n; }      // a root at 0 itself
+        nprev = n; off_prev = 6 - off_prev;
+    }
+    if (nprev > 0) { *root = buf[off_prev]; return 1; }
+    return 0;
+}
+ARB_HD int slide_real_root_cascade(const double pc[7], double lo, double *root) {
+    double buf[19];
+    return slide_real_root_cascade(pc, lo, root, buf);
+}
+// the cascade from the per-step constants of a contact (what the register-only iteration starts from)
+ARB_HD int slide_real_root_cascade_from(const SlidePre &k, double c1, double kappa, double *root) {
+    double pc[7];
+    slide_poly(k, c1, kappa, pc);
+    const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));     // (the spectrum bound of slide_leftmost_root)
+    if (!(rb > 0.) || !(rb < 1e300)) return -1;
+    return slide_real_root_cascade(pc, -1.0001 * rb - 1e-300, root);
 }
 
 // The same iteration for the fused kernel, where the four lanes of a constraint's quad carry the live
@@ -1532,6 +1637,15 @@ ARB_HD bool softfinger_sliding_shift(const T Y[16], const T alpha[4], T mu, cons
             *shift = (root <= 0.) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
             return true;
         }
+#if ARB_ROOT_CASCADE
+        // the iteration declined (complex roots in its way): the derivative cascade decides in float64
+        const int rc = slide_real_root_cascade_from(kk, c1, kappa, &root);
+        if (rc >= 0) {
+            if (warm) *warm = NAN;
+            *shift = (rc == 1) ? (T)(root > -1e10 ? root : -1e10) : T(-1e10);
+            return true;
+        }
+#endif
     }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {

@@ -59,6 +59,13 @@ int arb_host_softfinger_try(int dtype, const double *vel, const double *adm, con
  * Returns 1 and *root on success, 0 when the caller must fall back to eig6. */
 int arb_host_slide_root(const double *Y, double c1, double kappa, double warm, double *root);
 
+/* What decides when that iteration declines (a complex pair of roots leftmost, or nearly so), before the 6x6 eigenvalue
+ * routine is asked: the derivative cascade (arb_math.h: slide_real_root_cascade) on a sextic given by its seven
+ * coefficients pc (constant term first) -- the leftmost real root in [lo, 0], which is the smallest real eigenvalue <= 0 of
+ * constraints.py:826-830 when lo is left of the spectrum.  Returns 1 with *root, 0 when there is no real root in [lo, 0],
+ * -1 for non-finite input. */
+int arb_host_real_root_cascade(const double *pc, double lo, double *root);
+
 /* (Pseudo-)inverse of an nd x nd constraint block as the kernels form it (numpy.linalg.pinv at
  * constraints.py:79, 83, 235, 795): returns 1 when pivoted elimination was kept, 0 when the block was found rank
  * deficient and the Jacobi-SVD route was taken, -1 on a bad argument. */

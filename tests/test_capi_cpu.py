@@ -200,6 +200,64 @@ def test_sliding_root_formula_and_warm_start():
 
 
 @needs_lib
+def test_real_root_cascade_against_numpy_roots():
+    """The derivative cascade (arb_math.h: slide_real_root_cascade; what decides the sliding shift when the warm-started
+    iteration declines) finds the leftmost real root <= 0 of a sextic, or reports that there is none: against
+    numpy.roots on sextics built from prescribed roots -- all real, real roots behind a complex pair (the case the iteration
+    declines), complex only, clusters over ten decades, a root at zero, roots right of zero only."""
+    lib = _capi.load()
+    rng = np.random.default_rng(5)
+    checked = {"real": 0, "none": 0}
+    for trial in range(4000):
+        kind = trial % 6
+        scale = 10. ** rng.uniform(-4, 4)
+        if kind == 0:                                   # six real roots, any sign
+            roots = list(rng.normal(0., 1., 6) * scale)
+        elif kind == 1:                                 # a complex pair LEFT of the real roots
+            re = -abs(rng.normal(3., 1.)) * scale
+            roots = [complex(re, abs(rng.normal()) * scale + 1e-3 * scale), None] + list(-np.abs(rng.normal(0., 1., 4)) * scale * 0.5)
+        elif kind == 2:                                 # complex pairs only
+            roots = []
+            for _ in range(3):
+                roots += [complex(rng.normal() * scale, abs(rng.normal()) * scale + 1e-2 * scale), None]
+        elif kind == 3:                                 # two complex pairs and two real roots
+            roots = [complex(rng.normal() * scale, abs(rng.normal()) * scale + 1e-2 * scale), None,
+                     complex(-abs(rng.normal()) * scale, abs(rng.normal()) * scale + 1e-2 * scale), None] + list(rng.normal(0., 1., 2) * scale)
+        elif kind == 4:                                 # roots spread over many decades, all negative
+            roots = list(-10. ** rng.uniform(-6, 3, 6))
+        else:                                           # positive real roots only (none admissible) or one at zero
+            roots = list(np.abs(rng.normal(0., 1., 6)) * scale + 1e-3 * scale)
+            if trial % 12 == 5:
+                roots[0] = 0.
+        full = []
+        for r in roots:
+            if r is None:
+                full.append(np.conj(full[-1]))
+            else:
+                full.append(r)
+        pc = np.real(np.poly(full))[::-1].copy()        # constant term first, monic
+        assert pc.shape == (7,) and pc[6] == 1.
+        lo = -1.0001 * (1. + np.abs(pc[:6]).max())      # Cauchy bound: left of every root
+        real = sorted(float(np.real(r)) for r in full if np.imag(r) == 0. and np.real(r) <= 0.)
+        root = np.zeros(1)
+        rc = lib.arb_host_real_root_cascade(_capi._dp(np.ascontiguousarray(pc)), float(lo), _capi._dp(root))
+        # (the prescribed roots are the reference; multiplying them out conditions the leftmost real one at about
+        # 1e-16 * |largest root|^6 / |p'|, so compare through the polynomial's own residual)
+        if real:
+            assert rc == 1, (trial, kind, rc, real[0])
+            want = real[0]
+            dp = abs(np.polyval(np.polyder(pc[::-1]), want))
+            bound = 1e-12 * max(abs(want), 1e-300) + 1e-13 * np.sum(np.abs(pc) * np.abs(want) ** np.arange(7)) / max(dp, 1e-300)
+            assert abs(root[0] - want) <= bound, (trial, kind, root[0], want, bound)
+            checked["real"] += 1
+        else:
+            assert rc == 0, (trial, kind, rc, root[0])
+            checked["none"] += 1
+    assert checked["real"] > 1500 and checked["none"] > 600, checked
+    assert lib.arb_host_real_root_cascade(_capi._dp(np.array([1., np.nan, 0., 0., 0., 0., 1.])), -5., _capi._dp(np.zeros(1))) == -1
+
+
+@needs_lib
 def test_device_softfinger_solve_float32_on_host():
     lib = _capi.load()
     g = load_golden("g3_contacts.npz")
