@@ -224,3 +224,77 @@ def test_wavefront_eig6_is_the_one_lane_eig6_bit_for_bit(canary_tuples, dtype):
             if np.allclose(A[k], A[k].T) and np.isfinite(A[k]).all() and np.abs(A[k]).max() > 0:
                 ref = np.sort(np.linalg.eigvalsh(A[k]))
                 assert np.abs(np.sort(wave[k, 2:8]) - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------------------
+# The derivative cascade (round 4): sliding solves whose 6x6 matrix has a COMPLEX pair leftmost -- the case in which the
+# warm-started iteration declines -- are decided by slide_real_root_cascade in float64, on the device as on the host,
+# and agree with the reference's eigvals-based shift.
+# ---------------------------------------------------------------------------
+def _complex_leftmost_tuples(n_want=300, seed=11):
+    rng = np.random.default_rng(seed)
+    tuples, results, kinds = [], [], {"real_behind": 0, "none": 0}
+    eps = np.ones(3)
+    for _ in range(60000):
+        A = rng.normal(size=(4, 4))
+        adm = (A @ A.T + np.diag(rng.uniform(0.2, 2., 4))) * 10. ** rng.uniform(-2, 0)
+        force = rng.normal(size=4) * 50.; force[3] = abs(force[3]) + 5.
+        vel = rng.normal(size=4)
+        sd, dt, mu = -abs(rng.normal()) * 1e-3, 5e-3, rng.uniform(0.3, 1.2)
+        alpha = vel - adm @ force
+        alpha[3] += sd / dt
+        if sd + dt * (vel - adm @ force)[3] > 0:
+            continue
+        Yc, yn = adm[0:3, 3], adm[3, 3]
+        beta = alpha[0:3] - alpha[3] / yn * Yc
+        a = mu / yn * alpha[3]
+        b = mu / yn * Yc
+        Bm = np.zeros((6, 6))
+        Yh = adm[0:3, 0:3] - np.dot(Yc, Yc.T) / yn
+        Bm[3:, 3:] = Yh
+        Bm[:3, :3] = Yh + 2 / a * np.dot(beta, b.T)
+        Bm[:3, 3:] = -np.eye(3) * (np.dot(beta, beta.T) / a ** 2)
+        Bm[3:, :3] = np.eye(3) * (np.dot(b, b.T) - 1.)
+        S = np.linalg.eigvals(Bm)
+        left = S[np.argmin(S.real)]
+        scale = np.abs(S).max()
+        if abs(left.imag) < 1e-3 * scale:                  # the leftmost eigenvalue must be clearly complex ...
+            continue
+        if np.any((S.imag != 0) & (np.abs(S.imag) < 1e-6 * scale)):      # ... and no other pair nearly real
+            continue
+        dforce, newf, br = O._softfinger_solve_one(vel, adm, force.copy(), sd, mu, eps, dt)
+        if br != 2:
+            continue
+        real_neg = S[(S.imag == 0) & (S.real <= 0)]
+        kind = "real_behind" if len(real_neg) else "none"
+        kinds[kind] += 1
+        tuples.append(np.concatenate([vel, adm.ravel(), force, [sd, dt, mu]]))
+        results.append(np.concatenate([newf, dforce, [2]]))
+        if len(tuples) >= n_want:
+            break
+    return np.array(tuples), np.array(results), kinds
+
+
+def test_cascade_decides_the_solves_the_iteration_declines():
+    lib = _capi.load()
+    tuples, ref, kinds = _complex_leftmost_tuples()
+    # (random admittance blocks give spectra WITHOUT a real eigenvalue <= 0 behind the complex pair -- the answer is "none",
+    # the shift -1e10 of constraints.py:827-828; the nearly-real pairs with real eigenvalues behind them that falling robots
+    # produce are the canary's, above, and the harvested tuples')
+    assert len(tuples) >= 200, (len(tuples), kinds)
+    scale = np.maximum(1., np.abs(ref[:, :4]).max(axis=1))
+    for dtype, tol in ((_capi.ARB_F64, 1e-8), (_capi.ARB_F32, 5e-4)):
+        dev = device_solve(lib, dtype, tuples)
+        host = np.array([host_solve(lib, dtype, t) for t in tuples])
+        assert np.isfinite(dev).all()
+        # branch 2 = sliding and the shift decided without the 6x6 eigenvalue routine (3 = that routine was needed:
+        # every one of these tuples before the cascade existed)
+        assert (dev[:, 8] == 2).all() and (host[:, 8] == 2).all(), np.bincount(dev[:, 8].astype(int))
+        err = np.abs(dev[:, :8] - ref[:, :8]).max(axis=1) / scale
+        errh = np.abs(dev[:, :8] - host[:, :8]).max(axis=1) / scale
+        print("cascade, dtype %d: max rel err vs oracle %.2e, device vs host %.2e" % (dtype, err.max(), errh.max()))
+        assert err.max() < tol and errh.max() < tol, (err.max(), errh.max())
+    # the eigenvalue routine, forced, on the same tuples: the same answers
+    dev6 = device_solve(lib, _capi.ARB_F64 | 0x100, tuples)
+    assert (np.minimum(dev6[:, 8], 2) == 2).all()
+    assert (np.abs(dev6[:, :8] - ref[:, :8]).max(axis=1) / scale).max() < 1e-6
