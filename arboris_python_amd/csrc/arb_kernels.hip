@@ -1147,9 +1147,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     // and the code of the absent features is not compiled in.  Same expressions: bit-identical results.  (Measured, float32,
     // 4096 worlds: constants +3 %, without the viscosity / PD / warm-start code +8 %.  One by one in the general kernel:
     // viscosity +3 % -- its block was the FIRST term of phase B's accumulators, see there --, PD -1 %, warm start 0 %.)
-    constexpr bool SPEC = (FEAT & 4) != 0;
-    constexpr int SPEC_NC = 4 * NSETS;
+    // FEAT bit 8: the same for models WITHOUT constraints (BASELINE config 2: human36 in free motion) -- nc = 0 is a constant,
+    // phases A', D, the sweeps and the constraint columns of phase C are not compiled in.
+    constexpr bool SPEC = (FEAT & 12) != 0;
+    constexpr int SPEC_NC = (FEAT & 8) ? 0 : 4 * NSETS;
     static_assert(!SPEC || (!FEAT_ALL && MODE == 0 && (CM == 0 || CM == 2)), "specialised kernels: plain inputs / user torques");
+    static_assert((FEAT & 12) != 12 && (!(FEAT & 8) || NSETS == 1), "specialised kernels: one model class at a time");
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
     const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
     const LogOut<T> logo = FEAT_ALL ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
@@ -3845,9 +3848,14 @@ template int launch_one<float, ARB_PART_NMAX, 1, 0, 5, 2>(ARB_LAUNCH_ONE_ARGS(fl
 #elif ARB_PART_SPEC == 2       /* float32, two column sets (eight contacts) */
 template int launch_one<float, ARB_PART_NMAX, 2, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 2, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));
-#else                          /* float64, one column set */
+#elif ARB_PART_SPEC == 3       /* float64, one column set */
 template int launch_one<double, ARB_PART_NMAX, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(double));
 template int launch_one<double, ARB_PART_NMAX, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(double));
+#else                          /* float32, no constraints (FEAT bit 8): two and three waves */
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 8, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 9, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 8, 2>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 9, 2>(ARB_LAUNCH_ONE_ARGS(float));
 #endif
 #elif defined(ARB_PART)
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
@@ -3906,7 +3914,11 @@ ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
     extern template int launch_one<float, NM, 2, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<float, NM, 2, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<double, NM, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
-    extern template int launch_one<double, NM, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(double));
+    extern template int launch_one<double, NM, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
+    extern template int launch_one<float, NM, 1, 0, 8, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 9, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 8, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 9, 2>(ARB_LAUNCH_ONE_ARGS(float));
 ARB_EXTERN_TILE_SPEC(44) ARB_EXTERN_TILE_SPEC(48)
 #undef ARB_EXTERN_TILE_SPEC
 #endif
@@ -3961,6 +3973,7 @@ struct arb_model {
     bool packable = false;         // every constraint a SoftFingerContact with eps = (1,1,1), at most eight: two worlds per wavefront in the sweeps
     bool spec_ok = false;          // four constraints per column set, all enabled SoftFingerContacts of plane / sphere pairs, no PD controller, no viscosity,
                                    // one world per wavefront, tiles 44 / 48: the specialised kernels (FEAT bit 4)
+    bool spec0_ok = false;         // no constraints, otherwise the same class: the specialised kernels of FEAT bit 8
     bool rdv_ok = false;           // ... at most FOUR, and the three-wave layout holds three more systems: the rendezvous build (CM = 4)
     int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
     Layout lf, lf3, lfp, ld;       // LDS layouts: float32 two-wave kernels, three-wave kernels, packed kernels; float64
@@ -4355,6 +4368,9 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     M->spec_ok = ARB_WITH_SPEC && nc == 4 * M->nsets && fk == 1 && M->nmax >= 44 && M->nmax <= 48;
     for (int c = 0; c < nc; ++c)
         M->spec_ok = M->spec_ok && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_enabled[c] != 0 && d->c_geom[c] == ARB_CG_PLANE_SPHERE;
+    M->spec0_ok = ARB_WITH_SPEC && nc == 0 && fk == 1 && M->nsets == 1 && M->nmax >= 44 && M->nmax <= 48 &&
+                  maxdepth < ARB_JUMP_DEPTH && lds_scan(nb, M->nmax) && d->pd_kp == nullptr;
+    for (int i = 0; i < 36 * nb && M->spec0_ok; ++i) M->spec0_ok = d->visc[i] == 0.0;
     M->spec_ok = M->spec_ok && maxdepth < ARB_JUMP_DEPTH;                                     // (a shallow tree: no log-depth chains in float64)
     M->spec_ok = M->spec_ok && lds_scan(nb, M->nmax);                                         // (a small tree: phase B on the prefix table)
     M->spec_ok = M->spec_ok && d->pd_kp == nullptr;                                           // (no PD controller in the model,
@@ -4596,8 +4612,11 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // (float32 with one or two column sets, float64 with one)
     const bool spec = ARB_WITH_SPEC && M->spec_ok && noopt && MODE == 0 && !mfma && !pack && !rdv &&
                       (std::is_same<T, float>::value || M->nsets == 1) && env_int("ARB_FORCE_SPEC", 1) != 0;
+    const bool spec0 = ARB_WITH_SPEC && M->spec0_ok && noopt && MODE == 0 && std::is_same<T, float>::value && !mfma && !pack && !rdv &&
+                       env_int("ARB_FORCE_SPEC", 1) != 0;
 #if ARB_WITH_SPEC
-#define ARB_SPEC_CASE(NM) if (spec && M->nsets == 1) return w3 ? (plain ? ONE_(NM, 1, 4, 2) : ONE_(NM, 1, 5, 2)) : (plain ? ONE_(NM, 1, 4, 0) : ONE_(NM, 1, 5, 0));
+#define ARB_SPEC0_CASE(NM) if (spec0) return w3 ? (plain ? ONE_(NM, 1, 8, 2) : ONE_(NM, 1, 9, 2)) : (plain ? ONE_(NM, 1, 8, 0) : ONE_(NM, 1, 9, 0));
+#define ARB_SPEC_CASE(NM) ARB_SPEC0_CASE(NM) if (spec && M->nsets == 1) return w3 ? (plain ? ONE_(NM, 1, 4, 2) : ONE_(NM, 1, 5, 2)) : (plain ? ONE_(NM, 1, 4, 0) : ONE_(NM, 1, 5, 0));
 #define ARB_SPEC_CASE2(NM)                                                                                             \
         if constexpr (MODE == 0 && NM >= 44 && NM <= 48) {                                                             \
             if (spec && M->nsets == 1 && !std::is_same<T, float>::value) return plain ? ONE(NM, 1, 4) : ONE(NM, 1, 5); \
@@ -4606,7 +4625,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
             }                                                                                                          \
         }
 #else
-#define ARB_SPEC_CASE(NM) (void)spec;
+#define ARB_SPEC_CASE(NM) (void)spec; (void)spec0;
 #define ARB_SPEC_CASE2(NM)
 #endif
 #if ARB_WITH_RDV
@@ -4621,7 +4640,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #endif
 // (the instantiation must fit the model: a kernel with the wrong tile, column sets or model class computes on, silently wrong --
 // round 4's first launch table sent an 8-contact model to the one-set specialised kernel; checked at every launch since)
-#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS)))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st))
+#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS))) && (!((FT) & 8) || (M->spec0_ok && M->nc == 0))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st))
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
@@ -4864,6 +4883,7 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     if (!noopt) out->feat = 3;
     // (the specialised kernels, see launch(): plain inputs or user torques of a model of their class, float32)
     if (ARB_WITH_SPEC && M->spec_ok && noopt && (dtype == ARB_F32 || M->nsets == 1) && !mfma && !bc.pack && !bc.rdv && env_int("ARB_FORCE_SPEC", 1) != 0) out->feat |= 4;
+    if (ARB_WITH_SPEC && M->spec0_ok && noopt && dtype == ARB_F32 && !mfma && !bc.pack && !bc.rdv && env_int("ARB_FORCE_SPEC", 1) != 0) out->feat |= 8;
     return ARB_OK;
 }
 

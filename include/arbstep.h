@@ -270,8 +270,10 @@ typedef struct arb_step_plan_info {
     int32_t worlds_per_wavefront;  /* 1, 2 (the packed build), or the copies of a small model's forest (the other fields
                                       then describe the launch of the forest) */
     int32_t feat;                  /* optional-input set of the kernel instantiation: 0, 1 or 3; + 4: the kernel specialised for
-                                      models with exactly four enabled plane / sphere SoftFingerContacts, no PD controller
-                                      and no joint viscosity (float32, plain inputs or user torques; bit-identical results) */
+                                      models with exactly four (eight: two column sets) enabled plane / sphere
+                                      SoftFingerContacts, + 8: for models without constraints -- in both classes no PD
+                                      controller, no joint viscosity, a small shallow tree; plain inputs or user torques;
+                                      results bit-identical to the general kernels' */
     int32_t lds_bytes;             /* dynamic LDS per wavefront */
     int32_t wave_slots;            /* resident wavefronts of that build on the device */
     int32_t work_queue;            /* 1: the resident wavefronts draw (chunk of steps, world or pair) items from a device-side queue */

@@ -21,20 +21,21 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
     for v in ("ARB_FORCE_SPEC", "ARB_FORCE_WAVES"):
         monkeypatch.delenv(v, raising=False)
     assert _capi.load().arb_build_variants() == 0
-    # model: (float32, float64)
-    want = {"human36_c4": (True, True),          # four plane / sphere SoftFingerContacts
-            "human36_c8": (True, False),         # eight, two column sets: float32 only
-            "human36_g": (False, False),         # no constraints
-            "human36_c4_pdw": (False, False),    # a PD controller in the model: a dense impedance, outside the class
-            "simplearm": (False, False)}
+    # model: class bit in float32 (4: contacts, 8: no constraints, 0: the general kernels), in float64
+    want = {"human36_c4": (4, 4),                # four plane / sphere SoftFingerContacts
+            "human36_c8": (4, 0),                # eight, two column sets: float32 only
+            "human36_g": (8, 0),                 # no constraints (BASELINE config 2): float32 only
+            "human36_visc": (0, 0),              # joint viscosity: outside the classes
+            "human36_c4_pdw": (0, 0),            # a PD controller in the model: a dense impedance, outside the classes
+            "simplearm": (0, 0)}
     for name, (spec32, spec64) in want.items():
         m, _, _ = load_model(name)
         bw = BatchedWorlds(m)
         for B, T in ((512, 1), (8192, 40)):
-            assert bool(bw.plan(B, T)["feat"] & 4) == spec32, (name, B, T)
-            assert bool(bw.plan(B, T, ext_gforce=True)["feat"] & 4) == spec32, (name, B, T)
+            assert bw.plan(B, T)["feat"] == spec32, (name, B, T)
+            assert bw.plan(B, T, ext_gforce=True)["feat"] == (spec32 | 1), (name, B, T)
             assert bw.plan(B, T, other_inputs=True)["feat"] == 3, (name, B, T)       # every optional input: the general kernel
-            assert bool(bw.plan(B, T, dtype=torch.float64)["feat"] & 4) == spec64, (name, B, T)
+            assert bw.plan(B, T, dtype=torch.float64)["feat"] == spec64, (name, B, T)
         if spec32:
             monkeypatch.setenv("ARB_FORCE_SPEC", "0")
             assert bw.plan(8192, 40)["feat"] == 0
@@ -43,11 +44,13 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
 
 
 @pytest.mark.parametrize("torques", [False, True])
-@pytest.mark.parametrize("model,dtype", [("human36_c4", "float32"), ("human36_c4", "float64"), ("human36_c8", "float32")])
+@pytest.mark.parametrize("model,dtype", [("human36_c4", "float32"), ("human36_c4", "float64"), ("human36_c8", "float32"),
+                                         ("human36_g", "float32")])
 def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, dtype, torques):
     """Whole falling episodes (free fall, impact, sliding, the rare routes of the local solve late in the episode), two- and
     three-wave builds, the work queue, one launch per step; plain inputs (FEAT 4 against 0) and user torques (5 against 1);
-    float32 with four and with eight contacts (two column sets), float64 with four."""
+    float32 with four and with eight contacts (two column sets), float64 with four; the class without constraints
+    (FEAT 8 / 9: human36 in free motion, BASELINE config 2)."""
     from arboris_python_amd import synth
     from arboris_python_amd.batch import BatchedWorlds
     for v in ("ARB_FORCE_SPEC", "ARB_FORCE_WAVES", "ARB_FORCE_PACK", "ARB_FORCE_RDV"):
@@ -65,13 +68,14 @@ def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, 
         if torques:
             rng = np.random.default_rng(B)
             ext = torch.as_tensor(rng.normal(0., 0.5, (B, m.ndof)), dtype=dt_, device="cuda")
-        assert bw.plan(B, 1 if mode == "per_step" else T, dtype=dt_, ext_gforce=torques, **kw)["feat"] == (5 if torques else 4)
+        cls = 8 if m.nc == 0 else 4
+        assert bw.plan(B, 1 if mode == "per_step" else T, dtype=dt_, ext_gforce=torques, **kw)["feat"] == (cls | (1 if torques else 0))
         res = {}
         for key in ("spec", "general"):
             if key == "general":
                 monkeypatch.setenv("ARB_FORCE_SPEC", "0")
             tq, tdq = bw.to_device(q, dq, dt_)
-            cf = bw.new_cforce(B, dt_)
+            cf = bw.new_cforce(B, dt_) if m.nc else None
             if mode == "per_step":
                 for _ in range(T):
                     bw.step(tq, tdq, 5e-3, 1, cforce=cf, ext_gforce=ext)
@@ -80,10 +84,11 @@ def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, 
             torch.cuda.synchronize()
             bw.status()
             monkeypatch.delenv("ARB_FORCE_SPEC", raising=False)
-            res[key] = (tq, tdq, cf)
+            res[key] = (tq, tdq) if cf is None else (tq, tdq, cf)
         if not torques:
             assert bool(torch.isfinite(res["spec"][0]).all())
-        assert float(torch.nan_to_num(res["spec"][2]).abs().max()) > 0.            # (the contacts did act)
+        if m.nc:
+            assert float(torch.nan_to_num(res["spec"][2]).abs().max()) > 0.        # (the contacts did act)
         bits = torch.int32 if dtype == "float32" else torch.int64                   # (bit patterns: a diverged world's NaN included)
         assert all(torch.equal(a.view(bits), b.view(bits)) for a, b in zip(res["spec"], res["general"])), (B, mode, kw)
     bw.close()
