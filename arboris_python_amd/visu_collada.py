@@ -255,17 +255,35 @@ def write_collada_scene(world, dae_filename, flat=False, scale=1.):
     return drv
 
 
-def write_collada_animation(collada_animation, collada_scene, trajectory, prefix="transforms/"):
+def _read_hdf5(filename):
+    try:
+        import h5py
+    except ImportError:
+        from . import h5min
+        return h5min.read(filename)
+    out = {}
+    with h5py.File(filename, "r") as f:
+        f.visititems(lambda n, o: out.__setitem__(n, o[()]) if isinstance(o, h5py.Dataset) else None)
+    return out
+
+
+def write_collada_animation(collada_animation, collada_scene, trajectory, hdf5_group="/", prefix="transforms/"):
     """Add one ``<animation>`` per ``transforms/<name>`` dataset of ``trajectory`` to the scene file
     ``collada_scene`` and write the result to ``collada_animation``.
 
-    ``trajectory``: mapping with ``timeline`` (nsteps,) and ``transforms/<name>`` (nsteps, 4, 4)
-    (``TrajectoryLogger.data``, ``batched_trajectory(...)`` or an ``.npz`` written by
-    ``observers.save_trajectory``).  ``<name>`` must be the id of a node of the scene; whether the
+    ``trajectory``: the path of an HDF5 file written by ``Hdf5Logger`` -- the reference's signature
+    ``(collada_animation, collada_scene, hdf5_file, hdf5_group="/")``, visu_collada.py:343-364, which hands the job to the
+    external ``h5toanim`` program; read here with h5py or the package's own reader --, or a mapping with ``timeline``
+    (nsteps,) and ``transforms/<name>`` (nsteps, 4, 4) (``TrajectoryLogger.data``, ``batched_trajectory(...)``), or
+    the path of an ``.npz`` written by ``observers.save_trajectory``.  ``hdf5_group``: the group of the file (or the
+    key prefix of the archive) the logger wrote to.  ``<name>`` must be the id of a node of the scene; whether the
     matrices are absolute poses or joint poses must match the ``flat`` flag the scene was written with.
     """
     if isinstance(trajectory, str):
-        trajectory = dict(np.load(trajectory))
+        trajectory = _read_hdf5(trajectory) if trajectory.endswith((".h5", ".hdf5")) else dict(np.load(trajectory))
+        group = "/".join(g for g in hdf5_group.split("/") if g)
+        if group:
+            trajectory = {k[len(group) + 1:]: v for k, v in trajectory.items() if k.startswith(group + "/")}
     ET.register_namespace("", NS)
     tree = ET.parse(collada_scene)
     root = tree.getroot()

@@ -114,6 +114,31 @@ def test_animation_from_reference_trajectories(tmp_path, flat):
         assert np.allclose(matrix_of(nodes[name]), traj["transforms/" + name][0], atol=1e-12)
 
 
+def test_animation_from_an_hdf5_file_and_group(tmp_path):
+    """The reference's call, write_collada_animation(anim, scene, hdf5_file, hdf5_group) (visu_collada.py:343-364): the
+    trajectory comes from an HDF5 file as Hdf5Logger writes it (here through the package's own writer), inside a group."""
+    from arboris_python_amd.observers import _write_hdf5
+    g = load_golden("g1_simplearm.npz")
+    data = {"sim/run/timeline": g["h5_flat_timeline"]}
+    for name, H in zip(ORDER, g["h5_flat_HandArmForearm"]):
+        data["sim/run/transforms/" + name] = H
+    data["other/timeline"] = np.zeros(3)
+    h5 = str(tmp_path / "log.h5")
+    _write_hdf5(h5, data, "w")
+    w = make_world()
+    for b in w.iterbodies():
+        if b.name in ORDER:
+            b._pose = data["sim/run/transforms/" + b.name][0]
+    scene, anim = str(tmp_path / "s.dae"), str(tmp_path / "a.dae")
+    write_collada_scene(w, scene, flat=True)
+    assert write_collada_animation(anim, scene, h5, "/sim/run") == 3
+    root = ET.parse(anim).getroot()
+    a = {x.get("id"): x for x in root.find(Q("library_animations")).findall(Q("animation"))}["Arm.anim"]
+    arrays = {s_.get("id"): s_ for s_ in a.findall(Q("source"))}
+    H = np.array([float(x) for x in arrays["Arm.anim.output"].find(Q("float_array")).text.split()])
+    assert np.array_equal(H.reshape(-1, 4, 4), data["sim/run/transforms/Arm"])
+
+
 def test_animation_rejects_unknown_nodes(tmp_path):
     w = make_world()
     scene = str(tmp_path / "s.dae")
