@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libarbstep.so")
 if os.environ.get("ARBSTEP_LIB"):                 # development: load a differently built library
     LIB_PATH = os.environ["ARBSTEP_LIB"]
 
-ARB_ABI_VERSION = 6
+ARB_ABI_VERSION = 7
 ARB_OK = 0
 ARB_ERR_STALLED = 5
 ARB_F32, ARB_F64 = 0, 1
@@ -27,6 +27,9 @@ ARB_STEP_STATIC_WORLDS = 32
 ARB_STEP_WAVES2 = 64
 ARB_STEP_WAVES3 = 128
 ARB_STEP_ONE_WORLD = 256
+ARB_STEP_GENERAL_KERNELS = 512
+ARB_WARN_ILLCOND = 1
+ARB_ILLCOND_GROWTH = 2048.0
 
 _PD = C.POINTER(C.c_double)
 _PI = C.POINTER(C.c_int32)
@@ -57,7 +60,7 @@ class ModelInfo(C.Structure):
 
 
 INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
-                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps", "gs_trace", "c_adm", "c_vel"]
+                  "c_sdist", "c_active", "c_jac", "c_force", "c_frame", "gforce", "q_next", "dq_next", "gs_stats", "energy", "stamps", "gs_trace", "c_adm", "c_vel", "pivot_growth"]
 
 
 class StepPlan(C.Structure):
@@ -69,11 +72,17 @@ class RolloutLog(C.Structure):
     _fields_ = [("q_log", C.c_void_p), ("dq_log", C.c_void_p), ("energy_log", C.c_void_p)]
 
 
+class StepCost(C.Structure):
+    _fields_ = [("cost_out", C.c_void_p), ("w_q", C.c_void_p), ("w_dq", C.c_void_p), ("w_tau", C.c_void_p), ("q_ref", C.c_void_p)]
+
+
 class StepArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("dq", C.c_void_p), ("cforce", C.c_void_p), ("ext_gforce", C.c_void_p),
                 ("pd_qdes", C.c_void_p), ("pd_dqdes", C.c_void_p), ("pd_kp", C.c_void_p), ("pd_kd", C.c_void_p),
                 ("nworlds", C.c_int64), ("dt", C.c_double), ("nsteps", C.c_int32), ("flags", C.c_uint32),
-                ("log", C.POINTER(RolloutLog)), ("dt_steps", C.c_void_p)]
+                ("log", C.POINTER(RolloutLog)), ("dt_steps", C.c_void_p),
+                ("ext_gforce_steps", C.c_void_p), ("pd_qdes_steps", C.c_void_p), ("pd_dqdes_steps", C.c_void_p),
+                ("cost", C.POINTER(StepCost))]
 
 
 class InspectOut(C.Structure):
@@ -82,10 +91,10 @@ class InspectOut(C.Structure):
 
 # every symbol include/arbstep.h declares (tests check they are all exported)
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
-            "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_step_plan", "arb_step", "arb_step_ex", "arb_rollout",
+            "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_model_warnings", "arb_step_plan", "arb_step", "arb_step_ex", "arb_rollout",
             "arb_inspect"]
 # every symbol include/arbstep_hooks.h declares: host builds of the device math (unit tests, Constraint.solve)
-TEST_HOOKS = ["arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_build_variants", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_real_root_cascade", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
+TEST_HOOKS = ["arb_hook_set_knob", "arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_build_variants", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_real_root_cascade", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
               "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
 
 _lib = None
@@ -138,6 +147,10 @@ def _open(path):
     lib.arb_model_get_info.argtypes = [C.c_void_p, C.POINTER(ModelInfo)]
     lib.arb_model_status.restype = C.c_int
     lib.arb_model_status.argtypes = [C.c_void_p]
+    lib.arb_model_warnings.restype = C.c_int
+    lib.arb_model_warnings.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.arb_hook_set_knob.restype = C.c_int
+    lib.arb_hook_set_knob.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.arb_step_plan.restype = C.c_int
     lib.arb_step_plan.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int32, C.c_uint32, C.c_int32, C.POINTER(StepPlan)]
     lib.arb_step.restype = C.c_int

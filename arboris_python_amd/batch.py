@@ -64,12 +64,15 @@ class BatchedWorlds(object):
             return _capi.ARB_F64
         raise TypeError("state tensors must be float32 or float64")
 
-    def _check_state(self, q, dq, cforce=None, ext=None):
+    def _check_state(self, q, dq, cforce=None, ext=None, nsteps=None):
         m = self.model
         B = q.shape[0]
+        ext_shape = (B, m.ndof)
+        if ext is not None and ext.dim() == 3:          # a torque SEQUENCE: one row per step (arb_step_args.ext_gforce_steps)
+            ext_shape = (int(nsteps), B, m.ndof)
         for name, t, shape in (("q", q, (B, m.nq)), ("dq", dq, (B, m.ndof)),
                                ("cforce", cforce, (B, m.nc, _capi.ARB_MAXDOL)),
-                               ("ext_gforce", ext, (B, m.ndof))):
+                               ("ext_gforce", ext, ext_shape)):
             if t is None:
                 continue
             if tuple(t.shape) != shape:
@@ -126,9 +129,22 @@ class BatchedWorlds(object):
             return _capi.ARB_STEP_WAVES2 if waves == 2 else _capi.ARB_STEP_WAVES3
         raise ValueError("waves must be None (the library picks by batch size), 2 or 3")
 
+    def set_knob(self, name, value):
+        """A development / test knob of this handle (``arb_hook_set_knob``, include/arbstep_hooks.h): the library reads
+        no environment variable."""
+        _capi.check(self._lib.arb_hook_set_knob(self._handle, name.encode(), int(value)))
+
+    def warnings(self):
+        """Warning bits the handle's launches raised so far (``arb_model_warnings``; cleared by the call):
+        ``_capi.ARB_WARN_ILLCOND`` = a float32 launch met a world whose impedance matrix float32 cannot eliminate to 1e-5
+        (long serial chains): step such a model in float64."""
+        w = C.c_uint32(0)
+        _capi.check(self._lib.arb_model_warnings(self._handle, C.byref(w)))
+        return int(w.value)
+
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
              stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False,
-             waves=None, one_world=False):
+             waves=None, one_world=False, cost=None, general_kernels=False, _log=None):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
@@ -144,12 +160,18 @@ class BatchedWorlds(object):
         ``one_world=True``: one world per wavefront even for a small model (ARB_STEP_ONE_WORLD).  By default the worlds
         of a model of at most 16 dofs share wavefronts once the batch exceeds twice the device's wave slots: the library
         steps ``B // k`` worlds of a forest of ``k = self.info["forest_copies"]`` copies of the model on the same buffers.
-        ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller).
-        ``pd_targets=(qdes, dqdes)`` (B,ndof) each: one ProportionalDerivativeController target
-        per world (controllers.py:63-158), with the model's gains, or with the per-world DIAGONAL
-        gains ``pd_gains=(kp, kd)`` (B,ndof) each."""
+        ``ext_gforce`` (B,ndof): user torques, one row per world (a zero-impedance Controller), constant over the
+        launch; ``ext_gforce`` (nsteps,B,ndof): a torque SEQUENCE, step t of the launch applies row t (the reference polls
+        its controllers every step, core.py:811-817: an MPC horizon in one launch).
+        ``pd_targets=(qdes, dqdes)`` (B,ndof) each -- or (nsteps,B,ndof) each: a target sequence --: one
+        ProportionalDerivativeController target per world (controllers.py:63-158), with the model's gains, or with the
+        per-world DIAGONAL gains ``pd_gains=(kp, kd)`` (B,ndof) each.
+        ``cost=dict(out=(B,), w_q=(ndof,), w_dq=(ndof,), w_tau=(ndof,), q_ref=(ndof,))`` (``out`` required, the others
+        optional): the running cost of the rollout, ``out[w] += sum_t sum_i w_q (q_i - q_ref_i)^2 + w_dq dq_i^2 +
+        w_tau tau_t,i^2`` on the state after every step (``arb_step_cost``, include/arbstep.h), summed on chip.
+        ``general_kernels=True``: the general kernels also for a model of a specialised class (ARB_STEP_GENERAL_KERNELS)."""
         torch = _torch()
-        B = self._check_state(q, dq, cforce, ext_gforce)
+        B = self._check_state(q, dq, cforce, ext_gforce, nsteps)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
@@ -162,8 +184,11 @@ class BatchedWorlds(object):
         flags |= self._waves_flag(waves)
         if one_world:
             flags |= _capi.ARB_STEP_ONE_WORLD
+        if general_kernels:
+            flags |= _capi.ARB_STEP_GENERAL_KERNELS
         dts = self._dt_steps(dt, nsteps, st)
-        if pd_targets is None and pd_gains is None and dts is None:
+        ext_seq = ext_gforce is not None and ext_gforce.dim() == 3
+        if pd_targets is None and pd_gains is None and dts is None and not ext_seq and cost is None and _log is None:
             _capi.check(self._lib.arb_step(
                 self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
                 None if cforce is None else cforce.data_ptr(),
@@ -173,16 +198,36 @@ class BatchedWorlds(object):
         a = _capi.StepArgs()
         a.q, a.dq = q.data_ptr(), dq.data_ptr()
         a.cforce = None if cforce is None else cforce.data_ptr()
-        a.ext_gforce = None if ext_gforce is None else ext_gforce.data_ptr()
+        if ext_seq:
+            a.ext_gforce_steps = ext_gforce.data_ptr()
+        else:
+            a.ext_gforce = None if ext_gforce is None else ext_gforce.data_ptr()
         for names, pair in ((("pd_qdes", "pd_dqdes"), pd_targets), (("pd_kp", "pd_kd"), pd_gains)):
             if pair is None:
                 continue
+            seq = names[0] == "pd_qdes" and pair[0].dim() == 3
+            want = (int(nsteps), B, self.model.ndof) if seq else (B, self.model.ndof)
             for name, t in zip(names, pair):
-                if tuple(t.shape) != (B, self.model.ndof) or not t.is_contiguous() or t.dtype != q.dtype \
-                        or t.device != self.device:
-                    raise ValueError("%s must be a contiguous (B, ndof) %s tensor on %s" % (name, q.dtype, self.device))
-                setattr(a, name, t.data_ptr())
+                if tuple(t.shape) != want or not t.is_contiguous() or t.dtype != q.dtype or t.device != self.device:
+                    raise ValueError("%s must be a contiguous %s %s tensor on %s" % (name, want, q.dtype, self.device))
+                setattr(a, name + "_steps" if seq else name, t.data_ptr())
+        keep = None
+        if cost is not None:
+            keep = _capi.StepCost()
+            for key, field, shape in (("out", "cost_out", (B,)), ("w_q", "w_q", (self.model.ndof,)), ("w_dq", "w_dq", (self.model.ndof,)),
+                                      ("w_tau", "w_tau", (self.model.ndof,)), ("q_ref", "q_ref", (self.model.ndof,))):
+                t = cost.get(key)
+                if t is None:
+                    if key == "out":
+                        raise ValueError("cost needs the accumulator tensor cost['out'] of shape (B,)")
+                    continue
+                if tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != q.dtype or t.device != self.device:
+                    raise ValueError("cost[%r] must be a contiguous %s %s tensor on %s" % (key, shape, q.dtype, self.device))
+                setattr(keep, field, t.data_ptr())
+            a.cost = C.pointer(keep)
         a.nworlds, a.nsteps, a.flags = B, int(nsteps), flags
+        if _log is not None:
+            a.log = C.pointer(_log)
         if dts is None:
             a.dt = float(dt)
         else:
@@ -190,18 +235,14 @@ class BatchedWorlds(object):
         _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
 
     def rollout(self, q, dq, dt, nsteps, cforce=None, ext_gforce=None, log_state=True, log_energy=True,
-                skip_constraints=False, stream=None, fused=False, split=False, waves=None, one_world=False):
+                skip_constraints=False, stream=None, fused=False, split=False, waves=None, one_world=False, **step_kw):
         """Advance ``nsteps`` steps in ONE launch and return the per-step logs an Observer
         would have recorded (state and energies at the beginning of every step):
-        ``{"q": (nsteps,B,nq), "dq": (nsteps,B,ndof), "energy": (nsteps,B,2)}``."""
+        ``{"q": (nsteps,B,nq), "dq": (nsteps,B,ndof), "energy": (nsteps,B,2)}``.  Other keywords (``pd_targets``,
+        ``pd_gains``, ``cost``, a torque sequence as ``ext_gforce`` ...) as for ``step``."""
         torch = _torch()
-        B = self._check_state(q, dq, cforce, ext_gforce)
+        B = self._check_state(q, dq, cforce, ext_gforce, nsteps)
         m = self.model
-        st = torch.cuda.current_stream(self.device) if stream is None else stream
-        flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
-        if fused:
-            flags |= _capi.ARB_STEP_FUSED
-        flags |= self._split_flag(split) | self._waves_flag(waves) | (_capi.ARB_STEP_ONE_WORLD if one_world else 0)
         out = {}
         log = _capi.RolloutLog()
         if log_state:
@@ -211,25 +252,26 @@ class BatchedWorlds(object):
         if log_energy:
             out["energy"] = torch.empty((nsteps, B, 2), dtype=q.dtype, device=self.device)
             log.energy_log = out["energy"].data_ptr()
-        dts = self._dt_steps(dt, nsteps, st)
-        if dts is None:
+        scalar_dt = np.ndim(dt.detach().cpu() if hasattr(dt, "detach") else dt) == 0
+        if scalar_dt and not step_kw and not (ext_gforce is not None and ext_gforce.dim() == 3):
+            # (the plain entry point: arb_rollout)
+            st = torch.cuda.current_stream(self.device) if stream is None else stream
+            flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
+            if fused:
+                flags |= _capi.ARB_STEP_FUSED
+            flags |= self._split_flag(split) | self._waves_flag(waves) | (_capi.ARB_STEP_ONE_WORLD if one_world else 0)
             _capi.check(self._lib.arb_rollout(
                 self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
                 None if cforce is None else cforce.data_ptr(),
                 None if ext_gforce is None else ext_gforce.data_ptr(),
                 B, float(dt), int(nsteps), flags, C.byref(log), C.c_void_p(st.cuda_stream)))
             return out
-        a = _capi.StepArgs()
-        a.q, a.dq = q.data_ptr(), dq.data_ptr()
-        a.cforce = None if cforce is None else cforce.data_ptr()
-        a.ext_gforce = None if ext_gforce is None else ext_gforce.data_ptr()
-        a.nworlds, a.nsteps, a.flags, a.dt, a.dt_steps = B, int(nsteps), flags, 0., dts.data_ptr()
-        a.log = C.pointer(log)
-        _capi.check(self._lib.arb_step_ex(self._handle, self._dtype_code(q), C.byref(a), C.c_void_p(st.cuda_stream)))
+        self.step(q, dq, dt, nsteps, cforce=cforce, ext_gforce=ext_gforce, skip_constraints=skip_constraints, stream=stream,
+                  fused=fused, split=split, waves=waves, one_world=one_world, _log=log, **step_kw)
         return out
 
     def plan(self, nworlds, nsteps=1, dtype=None, ext_gforce=False, other_inputs=False, waves=None, split=False,
-             static_worlds=False, one_world=False, world_logs=False):
+             static_worlds=False, one_world=False, world_logs=False, general_kernels=False):
         """Which kernel build and launch shape ``step`` would use (``arb_step_plan``): a dict with ``waves_per_simd``,
         ``worlds_per_wavefront`` (2 = the packed build; the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``.
         ``world_logs``: the launch is a rollout that logs per-world energies (or states of a batch that is not a multiple
@@ -238,6 +280,7 @@ class BatchedWorlds(object):
         code = _capi.ARB_F64 if dtype == torch.float64 else _capi.ARB_F32
         flags = self._waves_flag(waves) | self._split_flag(split) | (_capi.ARB_STEP_STATIC_WORLDS if static_worlds else 0)
         flags |= _capi.ARB_STEP_ONE_WORLD if one_world else 0
+        flags |= _capi.ARB_STEP_GENERAL_KERNELS if general_kernels else 0
         p = _capi.StepPlan()
         _capi.check(self._lib.arb_step_plan(self._handle, code, int(nworlds), int(nsteps), flags,
                                             (3 if other_inputs else (1 if ext_gforce else 0)) | (4 if world_logs else 0), C.byref(p)))
@@ -246,8 +289,19 @@ class BatchedWorlds(object):
     def status(self):
         """Health of this handle's launches so far (``arb_model_status``): raises ``ArbError`` (ARB_ERR_STALLED) when a
         launch gave up waiting inside its device-side work queue -- its results are invalid.  Reads host memory only;
-        synchronise the stream first to learn about launches that are still queued."""
+        synchronise the stream first to learn about launches that are still queued.
+
+        The stall word is STICKY: once a launch has stalled, every ``step`` / ``rollout`` / ``inspect`` call on this
+        handle raises ARB_ERR_STALLED without launching until THIS method has been called -- it is the acknowledgement.
+        The protocol after catching the error: synchronise, call ``status()`` (it raises once more and clears the word),
+        RELOAD the states (the stalled launch left them half-advanced), then step again.  Retrying ``step`` without
+        calling ``status()`` raises forever."""
         _capi.check(self._lib.arb_model_status(self._handle))
+
+    def acknowledge_stall(self):
+        """``status()`` without the exception: clears a raised stall word and returns True when one had been recorded
+        (the states of the stalled launch are invalid: reload them before stepping on)."""
+        return self._lib.arb_model_status(self._handle) == _capi.ARB_ERR_STALLED
 
     def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False):
         """Evaluate one step without touching ``q``/``dq``; returns a dict of the
@@ -261,7 +315,7 @@ class BatchedWorlds(object):
                       vel_free=(B, n), c_sdist=(B, nc), c_active=(B, nc), c_jac=(B, nc, 4, n),
                       c_force=(B, nc, 4), c_frame=(B, nc, 2, 4, 4), gforce=(B, n),
                       q_next=(B, nq), dq_next=(B, n), gs_stats=(B, 5), stamps=(B, 8), energy=(B, 2),
-                      gs_trace=(B, 20, nc), c_adm=(B, 4 * nc, 4 * nc), c_vel=(B, 4 * nc))
+                      gs_trace=(B, 20, nc), c_adm=(B, 4 * nc, 4 * nc), c_vel=(B, 4 * nc), pivot_growth=(B,))
         want = list(want)
         if "gforce" in want and nc and "c_jac" not in want:
             want.append("c_jac")

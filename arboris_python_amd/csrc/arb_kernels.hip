@@ -36,6 +36,7 @@
 #include <type_traits>
 #include <utility>
 #include <mutex>
+#include <cctype>
 
 #include "arbstep.h"
 #include "arbstep_hooks.h"
@@ -190,6 +191,7 @@ struct DevModel {
     int nb, n, nq, nc, ndol, ncols, maxdepth;
     int has_visc, has_pd, has_warm, has_grav;
     int *status;     // host-visible word (mapped pinned memory) that a launch raises when it gives up waiting in the work queue
+    int *warn;       // host-visible warning bits (ARB_WARN_*), raised by the float32 kernels: see the growth check of phase C
     Layout lay;      // LDS offsets of this precision's kernels: re-read per phase instead of held in SGPRs for the whole launch
     Layout lay3;     // ... of the three-wave kernels (two-pass prefix table: a smaller bd region)
     Layout layp;     // ... of the packed kernels (two worlds per wavefront: the two-pass layout + the stash)
@@ -244,6 +246,10 @@ struct SplitIO {
 template <typename T>
 struct PerWorldPD { const T *qdes, *dqdes, *kp, *kd; };
 
+// Running cost of a rollout (arb_step_cost, ABI 7): a diagonal quadratic form of (q, dq, tau) per step, summed on chip
+template <typename T>
+struct CostIO { T *out; const T *wq, *wdq, *wtau, *qref; };
+
 // Optional per-step logs of arb_rollout (state and energies as observers see them: before the step)
 template <typename T>
 struct LogOut {
@@ -260,6 +266,7 @@ struct DebugOut {
     int ablate;         // diagnostic (env ARB_ABLATE, inspect only): bit 3 (8) = run all 20 Gauss-Seidel sweeps, no fixed-point exit
     int *gs_stats;      // [nw][5]: release, static, sliding (fast shift), sliding (eig6 fallback) solve counts, sweeps
     T *c_adm, *c_vel;   // [nw][ndol][ndol], [nw][ndol]: the constraint-space system Y' = J' Y J'^T, v' the sweeps start from
+    T *pivot_growth;    // [nw]: max_j |Z_jj| / |pivot_j| of the elimination (see ARB_WARN_ILLCOND)
     int *gs_trace;      // [nw][GS_SWEEPS][nc]: decision of every solve (0 release, 1 static, 2 sliding fast shift,
                         // 3 sliding eig6, 4 other constraint types); entries of solves not executed are left alone
 };
@@ -1123,7 +1130,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,
     const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail, int queue_spin_cap,
-    T *__restrict__ park_in)
+    T *__restrict__ park_in, const long ext_stride_in, const long pd_stride_in, const CostIO<T> cost_in)
 {
     static_assert(MODE == 0 || FEAT == 3, "the inspect kernels take every input");
     static_assert(CM != 1 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
@@ -1154,6 +1161,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     static_assert(!SPEC || (!FEAT_ALL && MODE == 0 && (CM == 0 || CM == 2)), "specialised kernels: plain inputs / user torques");
     static_assert((FEAT & 12) != 12 && (!(FEAT & 8) || NSETS == 1), "specialised kernels: one model class at a time");
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
+    // ABI 7: control inputs that change along the horizon -- step t reads row t of [nsteps][nworlds][ndof] arrays (stride 0:
+    // one row for the whole launch) -- and the running cost of the rollout; both travel with the user torques (FEAT bit 0),
+    // the per-step PD targets with the other optional inputs (bit 1)
+    const long ext_stride = FEAT_EXT ? ext_stride_in : 0l, pd_stride = FEAT_ALL ? pd_stride_in : 0l;
+    const CostIO<T> cost = (FEAT_EXT && CM != 3 && CM != 4) ? cost_in : CostIO<T>{nullptr, nullptr, nullptr, nullptr, nullptr};
     const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
     const LogOut<T> logo = FEAT_ALL ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
     const SplitIO<T> sio = FEAT_ALL ? sio_in : SplitIO<T>{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1326,6 +1338,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     unsigned dead = 0u;
     const T ext_kA = (gext != nullptr && lane < n) ? gext[w0 * n + lane] : T(0);
     const T ext_kB = (PACK && two && gext != nullptr && lane < n) ? gext[(w0 + 1) * n + lane] : T(0);
+    // running cost of the rollout (arb_step_cost): read here, one addition per step in step order, written back with the
+    // state -- a horizon cut into work items or launches adds up bit for bit like one launch
+    T cost_acc = T(0);
+    if constexpr (FEAT_EXT) { if (cost.out != nullptr) cost_acc = ldg(cost.out + w0); }
+    bool warn_illcond = false;     // (float32: some pivot of this item's eliminations cancelled more digits than float32 can spare)
     if (lane < nc) {
         const int b1 = mp->cbody[lane], b0 = mp->cbody0[lane];
         const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
@@ -1425,6 +1442,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     bool rdv_done = false;     // (rendezvous build: this item's step has been handed over / finished with its group)
     for (int step = step_lo; step < step_hi; ++step) {
         T gf0 = T(0);          // controllers' generalized force (inspect output)
+        T ext_cost = T(0);     // this step's user torque of the lane's dof (the running cost's tau)
         // Packed build: phases A-D for world A (isub 0), then for world B (isub 1), in the same working arrays; each
         // world's state is copied in before (world B's is parked meanwhile), world A's results are stashed after.
         const int nsub = (PACK && two) ? 2 : 1;
@@ -1447,6 +1465,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             WAVE_SYNC();
         }
         T ext_k = (PACK && isub == 1) ? ext_kB : ext_kA;
+        if constexpr (FEAT_EXT) {
+            // a torque SEQUENCE (arb_step_args.ext_gforce_steps): this step's row
+            if (ext_stride != 0l && gext != nullptr)
+                ext_k = (lane0 < ARB_UNI(mp->n)) ? gext[(long)step * ext_stride + (w0 + ((PACK && isub == 1) ? 1 : 0)) * ARB_UNI(mp->n) + lane0] : T(0);
+            ext_cost = ext_k;
+        }
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
@@ -1463,9 +1487,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // ... and the copy's per-world INPUTS (round 4): a NaN or Inf in one world's user torques or PD targets / gains
             // would go through the shared elimination like a NaN in its state
             if (lane < n) {
-                bool in_bad = !(fabs(ext_kA) <= lim);
+                bool in_bad = !(fabs(ext_k) <= lim);
                 if (FEAT_ALL && pwd.qdes != nullptr)
-                    in_bad = in_bad || !(fabs(pwd.qdes[w * n + lane]) <= lim) || !(fabs(pwd.dqdes[w * n + lane]) <= lim);
+                    in_bad = in_bad || !(fabs(pwd.qdes[(long)step * pd_stride + w * n + lane]) <= lim) || !(fabs(pwd.dqdes[(long)step * pd_stride + w * n + lane]) <= lim);
                 if (FEAT_ALL && pwd.kp != nullptr)
                     in_bad = in_bad || !(fabs(pwd.kp[w * n + lane]) <= lim) || !(fabs(pwd.kd[w * n + lane]) <= lim);
                 if (in_bad) bad |= 1u << (lane / fn);
@@ -1948,6 +1972,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) Z[i] = ZT(0);
         T rhsM = T(0), rhsG = T(0);
+        // |Z_kk| as assembled (float32 worlds; inspect): the elimination of phase C compares every pivot with it, see there
+        constexpr bool TRACK_GROWTH = (sizeof(T) == 4 && MODE == 0) || MODE == 1;
+        float zdiag = 0.f;
         // ---- composite assembly ---------------------------------------------------------------------
         // With X_k = Ad(g<-body(k)) S_k the column of dof k in WORLD axes (about the root body's
         // origin; the same vector for every body below the joint), the reference's sums over bodies
@@ -2580,6 +2607,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 }
 #pragma unroll
                 for (int r = 0; r < 6; ++r) Gk[r] += Mdk[r];
+                if constexpr (TRACK_GROWTH) {
+                    double zd = 0.;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) zd += Xk[r] * Gk[r];          // Z[k][k] = X_k . G_k
+                    zdiag = (float)zd;
+                }
                 rhsM = (lane < n) ? (T)rm : T(0);
                 rhsG = (MODE == 1 && lane < n) ? (T)rg : T(0);
                 WAVE_SYNC();                   // every lane is done with the staging area: it becomes XPR
@@ -2847,7 +2880,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // per-world diagonal gains and targets (arb_step_ex): tau0 = kp (qdes - q) + kd dqdes, Z += dt kp + kd
             if (lane < n && !lane_dead) {
                 const T kp = pwd.kp[w * n + lane], kd = pwd.kd[w * n + lane];
-                const T acc = kp * (pwd.qdes[w * n + lane] - qd[lane]) + kd * pwd.dqdes[w * n + lane];
+                const long pdo = (long)step * pd_stride + w * n;      // (this step's targets: arb_step_args.pd_qdes_steps)
+                const T acc = kp * (pwd.qdes[pdo + lane] - qd[lane]) + kd * pwd.dqdes[pdo + lane];
                 const T zd = dt * kp + kd;
                 gf0 += acc;
                 rhs += acc - zd * dqs[lane];
@@ -2864,7 +2898,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 if (pwd.qdes != nullptr) {
                     // (block-diagonal gains: the targets of another copy meet exact zeros -- which a NaN target of a
                     // retired copy would turn into NaN: kp = kd = 0 means no term)
-                    if (kp != T(0) || kd != T(0)) acc += kp * (pwd.qdes[w * n + i] - qd[i]) + kd * pwd.dqdes[w * n + i];
+                    if (kp != T(0) || kd != T(0)) acc += kp * (pwd.qdes[(long)step * pd_stride + w * n + i] - qd[i]) + kd * pwd.dqdes[(long)step * pd_stride + w * n + i];
                 } else acc -= kp * qd[i];
                 accv += (dt * kp + kd) * dqs[i];
             }
@@ -2962,6 +2996,19 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         // root): on these graded, nearly-SPD matrices that order halves the float32
         // error of pivot-free elimination (measured).
         ARB_CSTAMP(4);
+        // Growth check (ABI 7, ARB_WARN_ILLCOND).  Pivot-free elimination leaves, for dof j, the pivot Z_jj - (what the dofs
+        // eliminated before j take away); when that difference is 2^11 times smaller than Z_jj itself, eleven of float32's 24
+        // bits are cancelled in that subtraction alone and the step's velocities cannot hold 1e-5 (a 64-link chain: 2^17; human36:
+        // 2^6).  Both magnitudes are wave-uniform (v_readlane): the comparison runs on the SCALAR unit, as a difference of
+        // the floats' bit patterns (2^23 log2 of the ratio to 6 %), one extra v_readlane per pivot.
+        int growth_bits = -(1 << 30);
+        auto track_growth = [&](auto pivv, int j) {
+            if constexpr (TRACK_GROWTH) {
+                const int zb = __builtin_amdgcn_readlane(__float_as_int(zdiag), j) & 0x7fffffff;
+                const int pb = __builtin_amdgcn_readfirstlane(__float_as_int((float)pivv)) & 0x7fffffff;
+                growth_bits = (zb - pb > growth_bits) ? zb - pb : growth_bits;
+            }
+        };
 #ifndef ARB_ELIM_MFMA_ALL
 #define ARB_ELIM_MFMA_ALL 0     // experiment (round 4): 1 = EVERY float32 production kernel eliminates on the matrix cores (what CM = 1 selects)
 #endif
@@ -2988,6 +3035,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 constexpr int j = decltype(jc)::value;
                 if (j < n) {
                     const float piv = bcast(Z[j], j);
+                    track_growth(piv, j);
                     const float nip = -arb_rcp(piv);
                     const float tn = Z[j] * nip;                  // minus this lane's entry of the scaled pivot row
                     float tn2 = 0.f;
@@ -3039,6 +3087,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 constexpr int j = decltype(jc)::value;
                 if (j < n) {
                     const ZT piv = bcast(Z[j], j);
+                    track_growth(piv, j);
                     const ZT ip = arb_rcp(piv);
                     const ZT t = Z[j] * ip;
                     ZT t2 = ZT(0);
@@ -3092,6 +3141,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         }
         for (int j = n - 1; j >= 0; --j) {
             const ZT piv = bcast(Z[NMAX - 1], j);
+            track_growth(piv, j);
             const ZT ip = arb_rcp(piv);
             const ZT t = Z[NMAX - 1] * ip;
             ZT t2 = ZT(0);
@@ -3131,6 +3181,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         }
         }
         ARB_CSTAMP(5);
+        if constexpr (TRACK_GROWTH) {
+            if (sizeof(T) == 4 && MODE == 0) warn_illcond = warn_illcond || (growth_bits > (11 << 23));      // ARB_ILLCOND_GROWTH = 2^11
+            if (MODE == 1 && dbg.pivot_growth != nullptr && lane == 0)
+                dbg.pivot_growth[w] = (T)__int_as_float((growth_bits > 0 ? growth_bits : 0) + 0x3f800000);
+        }
         // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
         {
             // (dqs is zero beyond ndof; rows >= ndof of the columns are never used)
@@ -3471,6 +3526,24 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         } else {
             integrate_from_rt(do_constraints);
         }
+        if constexpr (FEAT_EXT && !PACK && !RDV) {
+            // running cost (arb_step_cost): the state after this step, this step's torques; lane = dof, wave sum, one addition
+            if (cost.out != nullptr) {
+                T c = T(0);
+                if (lane < n) {
+                    const int qi = mp->dof2q[lane];
+                    const T dd = (qi >= 0 ? qs[qi] : T(0)) - (cost.qref != nullptr ? cost.qref[lane] : T(0));
+                    const T vv = dqs[lane];
+                    const T cq = (cost.wq != nullptr ? cost.wq[lane] : T(0)) * dd * dd;
+                    const T cv = (cost.wdq != nullptr ? cost.wdq[lane] : T(0)) * vv * vv;
+                    const T cu = (cost.wtau != nullptr ? cost.wtau[lane] : T(0)) * ext_cost * ext_cost;
+                    c = (cq + cv) + cu;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+                cost_acc += c;
+            }
+        }
     }
 
     if (RDV && rdv_done) {         // (states stored and worlds published by the last wavefront of the group)
@@ -3502,6 +3575,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             if (gcforce != nullptr && !(sio.mode & 2))
                 for (int i = lane; i < ndol; i += WAVE) stg(gcforce + wm * ndol + i, FF[i]);
         }
+        if constexpr (FEAT_EXT) { if (cost.out != nullptr && lane0 == 0) stg(cost.out + w0, cost_acc); }
+        if (sizeof(T) == 4 && warn_illcond && lane0 == 0)
+            (void)__hip_atomic_fetch_or(mp->warn, (int)ARB_WARN_ILLCOND, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
         if (dbg.q_next != nullptr) for (int i = lane; i < nq; i += WAVE) dbg.q_next[w * nq + i] = qs[i];
         if (dbg.dq_next != nullptr && lane < n) dbg.dq_next[w * n + lane] = dqs[lane];
@@ -3724,12 +3800,14 @@ hipError_t arb_scratch_alloc(void **p, size_t bytes, hipStream_t st) {
 }
 #endif
 
-// development knobs read from the environment at every launch (cheap; they must be changeable between launches of
-// one process): ARB_LDS_PAD = bytes of dynamic LDS added to every step-kernel workgroup (occupancy experiments),
-// ARB_QUEUE_SPIN_CAP = polls after which a wavefront gives up waiting for a chunk (negative: every wait of a later chunk
-// expires at once -- the fault injection of the ARB_ERR_STALLED tests).  A TEST knob: a small positive cap makes healthy
-// launches report stalls (and skip worlds) whenever a producer is merely slow.
-static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+// Development / test knobs of a handle (include/arbstep_hooks.h: arb_hook_set_knob).  The library reads NO environment
+// variable (ABI 7); a build with -DARB_DEVELOPMENT (tools/quick_build.sh) fills them from ARB_<NAME> once, at
+// arb_model_create.  queue_spin_cap: a TEST knob -- a small positive cap makes healthy launches report stalls (and skip
+// worlds) whenever a producer is merely slow.
+struct Knobs {
+    int lds_pad = 0, queue_chunk = 4, queue_tail = 4, queue_spin_cap = 1 << 24;
+    int force_waves = 0, force_pack = -1, force_rdv = -1, gsw_waves = 3, gsw_pack = 0, ablate = 0;
+};
 
 // Wave slots of a device for one-wavefront workgroups of a kernel that runs `waves_per_simd` wavefronts per SIMD by its
 // registers and asks for `lds_bytes` of LDS: ONE model behind the launch (queue grid, "more units than slots?"), the choice
@@ -3762,9 +3840,10 @@ static int wave_slots(K kern, size_t lds) {
 template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
 int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw, double dt,
                       int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
-                      const SplitIO<T> &sio, const double *dts, hipStream_t st) {
+                      const SplitIO<T> &sio, const double *dts, hipStream_t st, const Knobs &kn, long ext_stride, long pd_stride,
+                      const CostIO<T> &cost) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE, FEAT, CM>;
-    const size_t lds = (size_t)(MODE == 1 ? L.total_inspect : L.total) * sizeof(T) + (size_t)std::max(0, env_int("ARB_LDS_PAD", 0));
+    const size_t lds = (size_t)(MODE == 1 ? L.total_inspect : L.total) * sizeof(T) + (size_t)std::max(0, kn.lds_pad);
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -3772,9 +3851,9 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     // that persist from step to step travel between chunks through `cf`, so it must be there when the model has
     // constraints.  ARB_STEP_STATIC_WORLDS (or ARB_QUEUE_CHUNK=0 in the environment) keeps one workgroup per world.
     // (the rendezvous build, CM = 4: items are single steps, always through the queue)
-    const int chunk = (CM == 4) ? 1 : env_int("ARB_QUEUE_CHUNK", 4);
-    const int tail = (CM == 4) ? 0 : std::max(0, std::min(env_int("ARB_QUEUE_TAIL", 4), nsteps - 1));
-    const int spin_cap = env_int("ARB_QUEUE_SPIN_CAP", 1 << 24);
+    const int chunk = (CM == 4) ? 1 : kn.queue_chunk;
+    const int tail = (CM == 4) ? 0 : std::max(0, std::min(kn.queue_tail, nsteps - 1));
+    const int spin_cap = kn.queue_spin_cap;
     int *queue = nullptr;
     T *park = nullptr;
     const long units = (CM == 3) ? (nw + 1) / 2 : nw;        // work units: worlds, or pairs of worlds (packed build)
@@ -3823,7 +3902,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, dm, L, q, dq, cf, ext, pwd, nw, (T)dt, nsteps, flags, dbg, zmode, logo, sio, dts,
-                       queue, chunk > 0 ? chunk : 1, tail, spin_cap, park);
+                       queue, chunk > 0 ? chunk : 1, tail, spin_cap, park, ext_stride, pd_stride, cost);
     const hipError_t le = hipGetLastError();
     if (queue != nullptr) {
         const hipError_t fe = hipFreeAsync(queue, st);         // (also after a failed launch: nothing leaks)
@@ -3838,7 +3917,8 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
 #endif
 #define ARB_LAUNCH_ONE_ARGS(T)                                                                                             \
     const DevModel<T> *, const Layout &, T *, T *, T *, const T *, const PerWorldPD<T> &, long, double, int, unsigned,   \
-    const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, const double *, hipStream_t
+    const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, const double *, hipStream_t, const Knobs &, long, long, \
+    const CostIO<T> &
 #if defined(ARB_PART) && defined(ARB_PART_SPEC)      /* (translation units of their own: the specialised kernels, tiles 44 / 48) */
 #if ARB_PART_SPEC == 1         /* float32, one column set: two and three waves */
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));
@@ -3975,7 +4055,8 @@ struct arb_model {
                                    // one world per wavefront, tiles 44 / 48: the specialised kernels (FEAT bit 4)
     bool spec0_ok = false;         // no constraints, otherwise the same class: the specialised kernels of FEAT bit 8
     bool rdv_ok = false;           // ... at most FOUR, and the three-wave layout holds three more systems: the rendezvous build (CM = 4)
-    int *status_host = nullptr;    // mapped pinned word the kernels raise when a work-queue wait expires (ARB_ERR_STALLED)
+    int *status_host = nullptr;    // mapped pinned words the kernels raise: [0] a work-queue wait expired (ARB_ERR_STALLED), [1] ARB_WARN_* bits
+    Knobs kn;                      // development / test knobs (arb_hook_set_knob)
     Layout lf, lf3, lfp, ld;       // LDS layouts: float32 two-wave kernels, three-wave kernels, packed kernels; float64
     // Small worlds: `forest_k` independent copies of the model as ONE model (copy k owns bodies k nb.., dofs k n.., position
     // scalars k nq.., constraints k nc..), so that a batch of states [nw][nq] of this model IS a batch [nw / k][k nq] of
@@ -4247,7 +4328,11 @@ static int forest_create(const arb_model_desc *d, int K, int device, arb_model *
 // prefix table whose restart at every root keeps the copies apart.  ARB_FOREST=0 in the environment turns the forest
 // off, ARB_FOREST=k asks for k copies (development).
 static int forest_copies(int nb, int n, int nc) {
-    const int want = env_int("ARB_FOREST", -1);
+#ifdef ARB_DEVELOPMENT
+    const int want = getenv("ARB_FOREST") ? atoi(getenv("ARB_FOREST")) : -1;
+#else
+    const int want = -1;
+#endif
     if (want == 0 || want == 1) return 1;
     int K = 1;
     for (int k = 2; k <= WAVE; ++k) {
@@ -4387,14 +4472,15 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     {
         void *hp = nullptr, *dp = nullptr;
-        hipError_t e = hipHostMalloc(&hp, sizeof(int), hipHostMallocMapped);
-        if (e == hipSuccess) { M->status_host = static_cast<int *>(hp); *M->status_host = 0; e = hipHostGetDevicePointer(&dp, hp, 0); }
+        hipError_t e = hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped);
+        if (e == hipSuccess) { M->status_host = static_cast<int *>(hp); M->status_host[0] = M->status_host[1] = 0; e = hipHostGetDevicePointer(&dp, hp, 0); }
         if (e != hipSuccess) {
             g_hip_err = std::string("status word: ") + hipGetErrorString(e);
             arb_model_destroy(M);
             return ARB_ERR_HIP;
         }
         M->df.status = M->dd.status = static_cast<int *>(dp);
+        M->df.warn = M->dd.warn = static_cast<int *>(dp) + 1;
     }
     int tot;
     M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
@@ -4426,6 +4512,16 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
         }
         M->df_dev = static_cast<DevModel<float> *>(pf); M->dd_dev = static_cast<DevModel<double> *>(pd);
     }
+#ifdef ARB_DEVELOPMENT
+    {   // development builds: the knobs from the environment, once
+        const char *names[] = {"lds_pad", "queue_chunk", "queue_tail", "queue_spin_cap", "force_waves", "force_pack", "force_rdv", "gsw_waves", "gsw_pack", "ablate"};
+        for (const char *nm : names) {
+            std::string e = std::string("ARB_") + nm;
+            for (auto &ch : e) ch = (char)toupper((unsigned char)ch);
+            if (const char *v = getenv(e.c_str())) (void)arb_hook_set_knob(M, nm, atoi(v));
+        }
+    }
+#endif
     if (with_forest) {
         const int K = forest_copies(nb, n, nc);
         if (K > 1) {
@@ -4520,6 +4616,29 @@ extern "C" int arb_model_status(arb_model *M) {
     return take_status(M, true);
 }
 
+extern "C" int arb_model_warnings(arb_model *M, uint32_t *warnings) {
+    if (!M || !warnings) return ARB_ERR_INVALID;
+    unsigned v = M->status_host ? (unsigned)__atomic_exchange_n(M->status_host + 1, 0, __ATOMIC_RELAXED) : 0u;
+    if (M->forest && M->forest->status_host) v |= (unsigned)__atomic_exchange_n(M->forest->status_host + 1, 0, __ATOMIC_RELAXED);
+    *warnings = v;
+    return ARB_OK;
+}
+
+extern "C" int arb_hook_set_knob(arb_model *M, const char *name, int value) {
+    if (!M || !name) return ARB_ERR_INVALID;
+    struct { const char *n; int Knobs::*f; } tab[] = {
+        {"lds_pad", &Knobs::lds_pad}, {"queue_chunk", &Knobs::queue_chunk}, {"queue_tail", &Knobs::queue_tail},
+        {"queue_spin_cap", &Knobs::queue_spin_cap}, {"force_waves", &Knobs::force_waves}, {"force_pack", &Knobs::force_pack},
+        {"force_rdv", &Knobs::force_rdv}, {"gsw_waves", &Knobs::gsw_waves}, {"gsw_pack", &Knobs::gsw_pack}, {"ablate", &Knobs::ablate}};
+    for (auto &t : tab)
+        if (strcmp(t.n, name) == 0) {
+            M->kn.*(t.f) = value;
+            if (M->forest) M->forest->kn.*(t.f) = value;
+            return ARB_OK;
+        }
+    return ARB_ERR_INVALID;
+}
+
 extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
     if (!M || !info) return ARB_ERR_INVALID;
     info->nb = M->nb; info->ndof = M->n; info->nq = M->nq; info->nc = M->nc;
@@ -4543,12 +4662,12 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     if (!(M->nsets == 1 && M->nmax >= 44 && M->nmax <= 48)) return bc;
     static thread_local int cus_dev = -1, cus = 0;
     if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
-    const long pad = std::max(0, env_int("ARB_LDS_PAD", 0));
+    const long pad = std::max(0, M->kn.lds_pad);
     const long lds2 = (long)M->lf.total * 4 + pad, lds3 = (long)M->lf3.total * 4 + pad;
     const long s2 = (long)cus * slots_per_cu(2, lds2), s3 = (long)cus * slots_per_cu(3, lds3);
     bc.slots2 = s2; bc.slots3 = s3;
     // Two or three waves per SIMD?  Three when the batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3
-    // pin the build; ARB_FORCE_WAVES=2|3 in the environment overrides both (development).
+    // pin the build; the knob "force_waves" = 2|3 overrides both (development).
     if (s3 > s2 && s2 > 0) {
         // measured (human36 + 4 contacts, M world-steps/s, two / three waves; end of round 3, twelve wavefronts per CU
         // for real): 2048 worlds 14.6 / 13.5, 2560: 16.7 / 13.9, 3072: 17.1 / 16.2, 3584: 16.8 / 18.0, 4096: 16.6 / 18.7,
@@ -4560,14 +4679,14 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
         if (flags & ARB_STEP_WAVES2) bc.w3 = false;
         if (flags & ARB_STEP_WAVES3) bc.w3 = true;
     }
-    const int force = env_int("ARB_FORCE_WAVES", 0);
+    const int force = M->kn.force_waves;
     if (force == 2) bc.w3 = false;
     if (force == 3) bc.w3 = true;
     // Rendezvous build (four worlds per wavefront in the sweeps, CM = 4): multi-step launches of models that qualify.
-    // ARB_FORCE_RDV=0|1 in the environment overrides (development).
+    // The knob "force_rdv" = 0|1 overrides (development).
     if (ARB_WITH_RDV && M->rdv_ok && noopt && nsteps >= 2 && !(flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3 | ARB_STEP_STATIC_WORLDS))) {
         bc.rdv = ARB_RDV_DEFAULT != 0 && 10 * nw >= 11 * s3;
-        const int fr = env_int("ARB_FORCE_RDV", -1);
+        const int fr = M->kn.force_rdv;
         if (fr == 0) bc.rdv = false;
         if (fr == 1) bc.rdv = true;
     }
@@ -4575,7 +4694,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     // constraints are all SoftFingerContacts with eps = (1,1,1), plain inputs or user torques, a stash that still leaves
     // eight wavefronts per CU, and a batch large enough that pairs of worlds fill and balance the wave slots (measured,
     // three-wave / packed: 4096 worlds 18.2 / 16.8, 8192: 19.3 / 19.4, 16384: 19.6 / 20.0, 65536: 20.0 / 20.4).
-    // ARB_FORCE_PACK=0|1 in the environment overrides the batch-size rule (development).
+    // The knob "force_pack" = 0|1 overrides the batch-size rule (development).
     if (ARB_ALL_VARIANTS && M->packable && noopt && M->lfp.lscan) {
         const long ldsp = (long)M->lfp.total * 4 + pad;
         const long sp = (long)cus * slots_per_cu(2, ldsp);
@@ -4586,7 +4705,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
         // build stays in the library, bit-identical and tested, behind ARB_FORCE_PACK=1.)
         bc.pack = false;
         (void)ARB_PACK_MIN_ROUNDS;
-        const int fp = env_int("ARB_FORCE_PACK", -1);
+        const int fp = M->kn.force_pack;
         if (fp == 0) bc.pack = false;
         if (fp == 1) bc.pack = true;
         if (flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3)) bc.pack = false;      // (a pinned build is a pinned build)
@@ -4597,23 +4716,27 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
 template <typename T, int MODE>
 static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext, const PerWorldPD<T> &pwd, long nw,
                   double dt, int nsteps, unsigned flags, const DebugOut<T> &dbg, int zmode, const LogOut<T> &logo,
-                  const SplitIO<T> &sio, const double *dts, hipStream_t st) {
+                  const SplitIO<T> &sio, const double *dts, hipStream_t st, long ext_stride = 0, long pd_stride = 0,
+                  const CostIO<T> &cost = CostIO<T>{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     // the plain step (FEAT 0): nothing but the state and the constraint forces; FEAT 1: + user torques (MPC rollouts)
     const bool noopt = MODE == 0 && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
                        logo.dq == nullptr && logo.energy == nullptr && sio.mode == 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS) && dts == nullptr;
     // (the kernels only look at ARB_STEP_SKIP_CONSTRAINTS; the other flags are for the host)
-    const bool plain = noopt && ext == nullptr;
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
     const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma) ? choose_build(M, noopt, nw, nsteps, flags) : BuildChoice();
-    const bool w3 = bc.w3, pack = bc.pack, rdv = bc.rdv && cf != nullptr && nw * (long)nsteps < (1l << 30);
+    // (the packed and rendezvous builds -- libarbstep_variants.so -- know neither torque sequences nor the running cost)
+    const bool seq = ext_stride != 0 || cost.out != nullptr;
+    const bool w3 = bc.w3, pack = bc.pack && !seq, rdv = bc.rdv && !seq && cf != nullptr && nw * (long)nsteps < (1l << 30);
     // the kernels specialised for the model class "four plane / sphere SoftFingerContacts" (FEAT bit 4): bit-identical to the
-    // general ones; ARB_FORCE_SPEC=0 in the environment runs the general kernels (development, tests)
+    // general ones, which ARB_STEP_GENERAL_KERNELS selects
     // (float32 with one or two column sets, float64 with one)
     const bool spec = ARB_WITH_SPEC && M->spec_ok && noopt && MODE == 0 && !mfma && !pack && !rdv &&
-                      (std::is_same<T, float>::value || M->nsets == 1) && env_int("ARB_FORCE_SPEC", 1) != 0;
+                      (std::is_same<T, float>::value || M->nsets == 1) && !(flags & ARB_STEP_GENERAL_KERNELS);
     const bool spec0 = ARB_WITH_SPEC && M->spec0_ok && noopt && MODE == 0 && std::is_same<T, float>::value && !mfma && !pack && !rdv &&
-                       env_int("ARB_FORCE_SPEC", 1) != 0;
+                       !(flags & ARB_STEP_GENERAL_KERNELS);
+    // (the running cost travels with the user torques: FEAT bit 0)
+    const bool plain = noopt && ext == nullptr && cost.out == nullptr;
 #if ARB_WITH_SPEC
 #define ARB_SPEC0_CASE(NM) if (spec0) return w3 ? (plain ? ONE_(NM, 1, 8, 2) : ONE_(NM, 1, 9, 2)) : (plain ? ONE_(NM, 1, 8, 0) : ONE_(NM, 1, 9, 0));
 #define ARB_SPEC_CASE(NM) ARB_SPEC0_CASE(NM) if (spec && M->nsets == 1) return w3 ? (plain ? ONE_(NM, 1, 4, 2) : ONE_(NM, 1, 5, 2)) : (plain ? ONE_(NM, 1, 4, 0) : ONE_(NM, 1, 5, 0));
@@ -4640,7 +4763,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #endif
 // (the instantiation must fit the model: a kernel with the wrong tile, column sets or model class computes on, silently wrong --
 // round 4's first launch table sent an 8-contact model to the one-set specialised kernel; checked at every launch since)
-#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS))) && (!((FT) & 8) || (M->spec0_ok && M->nc == 0))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st))
+#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS))) && (!((FT) & 8) || (M->spec0_ok && M->nc == 0))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st, M->kn, ext_stride, pd_stride, cost))
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
@@ -4703,12 +4826,11 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 }
 
 template <typename T>
-static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st, bool pack = false, bool pack4 = false) {
+static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long nw, double dt, const double *dts, hipStream_t st, int wv, bool pack = false, bool pack4 = false) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int ndol = 4 * nc;
     const size_t lds = (size_t)(al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol) + 64) * sizeof(T);
-    // waves per SIMD the sweep kernel is compiled for (development knob ARB_GSW_WAVES: 3 = no spills, 4 = 128 VGPRs)
-    const int wv = env_int("ARB_GSW_WAVES", 3);
+    // wv: waves per SIMD the sweep kernel is compiled for (knob "gsw_waves": 3 = no spills, 4 = 128 VGPRs)
     if (lds > 64 * 1024) return ARB_ERR_UNSUPPORTED;
     if (pack) {
         // (development: two or four worlds per wavefront; the caller has checked that the model qualifies -- four need
@@ -4717,7 +4839,7 @@ static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long
         const size_t ldsn = (size_t)(ng * (al(ndol * ndol) + al(nc * CD_STRIDE) + 2 * al(ndol)) + 64) * sizeof(T);
         const unsigned grid = (unsigned)((nw + ng - 1) / ng);
         // (the packed sweeps keep every stage's results lane by lane: compiled for three waves per SIMD they spill ~50
-        // registers inside the solve -- ARB_GSW_WAVES=2 selects the 256-register build)
+        // registers inside the solve -- gsw_waves = 2 selects the 256-register build)
         if (ng == 4 && wv == 2)
             hipLaunchKernelGGL((arb_gswn_kernel<T, 2, 4>), dim3(grid), dim3(WAVE), ldsn, st, dm, sio.A, sio.v, sio.f, sio.c, nw, (T)dt, dts);
         else if (ng == 4)
@@ -4740,7 +4862,7 @@ static int launch_gsw(const DevModel<T> *dm, int nc, const SplitIO<T> &sio, long
 template <typename T>
 static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const T *ext,
                       const PerWorldPD<T> &pwd, long nw, double dt, const double *dts, int nsteps, unsigned flags,
-                      const arb_rollout_log *log, hipStream_t st) {
+                      const arb_rollout_log *log, hipStream_t st, long ext_stride, long pd_stride, const CostIO<T> &cost) {
     DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
     LogOut<T> lo; memset(&lo, 0, sizeof(lo));
     if (log) { lo.q = (T *)log->q_log; lo.dq = (T *)log->dq_log; lo.energy = (T *)log->energy_log; }
@@ -4748,7 +4870,8 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
     const int nc = M->nc, ndol = M->ndol, n = M->n;
     const bool split = nc > 0 && (flags & ARB_STEP_SPLIT_WAVE) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
     if (!split)
-        return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, dts, st);
+        return launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, 0, lo, sio, dts, st, ext_stride, pd_stride, cost);
+    if (cost.out != nullptr) return ARB_ERR_INVALID;        // (the split execution integrates a step in the NEXT launch: no running cost)
     // ---- split execution (opt-in): step kernel (dynamics + system) / Gauss-Seidel kernel (one wavefront per world) ----
     // The hand-over buffers are allocated per call in stream order and freed in stream order after the last launch:
     // no per-handle state, so a handle may run split steps on several streams at once.
@@ -4770,9 +4893,11 @@ static int step_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q
         if (lk.dq) lk.dq += (size_t)k * nw * n;
         if (lk.energy) lk.energy += (size_t)k * nw * 2;
         sio.mode = 2 | (k > 0 ? 1 : 0);
-        // (kernel k finishes step k-1 with dts[k-1], then builds step k with dts[k])
-        rc = launch<T, 0>(M, dm, L, q, dq, cf, ext, pwd, nw, dt, 1, flags, dbg, 0, lk, sio, dts ? dts + k : nullptr, st);
-        if (rc == ARB_OK) rc = launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st, M->packable && env_int("ARB_GSW_PACK", 0) != 0, env_int("ARB_GSW_PACK", 0) == 4);
+        // (kernel k finishes step k-1 with dts[k-1], then builds step k with dts[k]; a control sequence: row k)
+        PerWorldPD<T> pk = pwd;
+        if (pk.qdes != nullptr) { pk.qdes += (size_t)k * pd_stride; pk.dqdes += (size_t)k * pd_stride; }
+        rc = launch<T, 0>(M, dm, L, q, dq, cf, ext ? ext + (size_t)k * ext_stride : nullptr, pk, nw, dt, 1, flags, dbg, 0, lk, sio, dts ? dts + k : nullptr, st);
+        if (rc == ARB_OK) rc = launch_gsw<T>(dm, nc, sio, nw, dt, dts ? dts + k : nullptr, st, M->kn.gsw_waves, M->packable && M->kn.gsw_pack != 0, M->kn.gsw_pack == 4);
     }
     if (rc == ARB_OK) {
         sio.mode = 1;                                      // apply the last step's forces, write cforce
@@ -4792,16 +4917,19 @@ static int device_cus(int device) {
     if (cus_dev != device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device); cus_dev = device; }
     return cus;
 }
-static bool use_forest(const arb_model *M, int64_t nworlds, uint32_t flags, const arb_rollout_log *log) {
+static bool use_forest(const arb_model *M, int64_t nworlds, uint32_t flags, const arb_rollout_log *log, bool per_world_out = false) {
     if (!M->forest || (flags & (ARB_STEP_ONE_WORLD | ARB_STEP_SPLIT_WAVE | ARB_STEP_MFMA_ELIM))) return false;
+    if (per_world_out) return false;                   // (a running cost is per world, like the energies)
     if (log && (log->energy_log || ((log->q_log || log->dq_log) && nworlds % M->forest_k != 0))) return false;
     return nworlds > 16l * device_cus(M->device);      // (measured, simplearm: 4096 worlds 98 alone / 91 M as a forest, 8192: 100 / 181)
 }
 
+// ext_stride / pd_stride: elements between the rows of consecutive steps of a control sequence (0: one row for the launch)
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                      const void *pd_qdes, const void *pd_dqdes, const void *pd_kp, const void *pd_kd,
                      int64_t nworlds, double dt, const double *dt_steps, int32_t nsteps, uint32_t flags,
-                     const arb_rollout_log *log, void *stream) {
+                     const arb_rollout_log *log, void *stream, long ext_stride = 0, long pd_stride = 0,
+                     const arb_step_cost *cost = nullptr) {
     if (!M || nworlds < 0 || nsteps < 0) return ARB_ERR_INVALID;
     if (dt_steps == nullptr && !(dt > 0.0)) return ARB_ERR_INVALID;
     if (dt_steps != nullptr) dt = 1.0;                  // unused: every step reads its own dt
@@ -4812,35 +4940,41 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if ((pd_qdes == nullptr) != (pd_dqdes == nullptr) || (pd_kp == nullptr) != (pd_kd == nullptr)) return ARB_ERR_INVALID;
     if (pd_kp != nullptr && pd_qdes == nullptr) return ARB_ERR_INVALID;
     if (pd_qdes != nullptr && pd_kp == nullptr && !M->df.has_pd) return ARB_ERR_INVALID;
+    if (cost != nullptr && cost->cost_out == nullptr) return ARB_ERR_INVALID;
     if (nworlds == 0 || nsteps == 0) return ARB_OK;     // empty batch: nothing to do (pointers may be null)
     if (!q || !dq) return ARB_ERR_INVALID;
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     if (int stalled = take_status(M, false)) return stalled;
     ARB_GUARD_DEVICE(M->device);
-    if (use_forest(M, nworlds, flags, log)) {
+    if (use_forest(M, nworlds, flags, log, cost != nullptr)) {
         // small worlds share wavefronts: nworlds / k worlds of the forest on the same buffers, the rest one per wavefront
+        // (a control sequence keeps its row stride: the rows of a step are the whole batch's)
         const int K = M->forest_k;
         const int64_t nf = nworlds / K, done = nf * K;
         const size_t es = dtype == ARB_F32 ? sizeof(float) : sizeof(double);
         int rc = step_impl(M->forest, dtype, q, dq, cforce, ext_gforce, pd_qdes, pd_dqdes, pd_kp, pd_kd, nf, dt, dt_steps, nsteps,
-                           flags | ARB_STEP_ONE_WORLD, log, stream);
+                           flags | ARB_STEP_ONE_WORLD, log, stream, ext_stride, pd_stride);
         if (rc != ARB_OK || done == nworlds) return rc;
         auto at = [&](const void *p, size_t per_world) -> void * {
             return p ? (void *)((const char *)p + (size_t)done * per_world * es) : nullptr;
         };
         return step_impl(M, dtype, at(q, M->nq), at(dq, M->n), at(cforce, (size_t)M->nc * ARB_MAXDOL), at(ext_gforce, M->n),
                          at(pd_qdes, M->n), at(pd_dqdes, M->n), at(pd_kp, M->n), at(pd_kd, M->n), nworlds - done, dt, dt_steps,
-                         nsteps, flags | ARB_STEP_ONE_WORLD, nullptr, stream);
+                         nsteps, flags | ARB_STEP_ONE_WORLD, nullptr, stream, ext_stride, pd_stride);
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32) {
         const PerWorldPD<float> pwd = {(const float *)pd_qdes, (const float *)pd_dqdes, (const float *)pd_kp, (const float *)pd_kd};
+        CostIO<float> ci = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (cost) ci = CostIO<float>{(float *)cost->cost_out, (const float *)cost->w_q, (const float *)cost->w_dq, (const float *)cost->w_tau, (const float *)cost->q_ref};
         return step_typed<float>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce,
-                                 (const float *)ext_gforce, pwd, (long)nworlds, dt, dt_steps, nsteps, flags, log, st);
+                                 (const float *)ext_gforce, pwd, (long)nworlds, dt, dt_steps, nsteps, flags, log, st, ext_stride, pd_stride, ci);
     }
     const PerWorldPD<double> pwd = {(const double *)pd_qdes, (const double *)pd_dqdes, (const double *)pd_kp, (const double *)pd_kd};
+    CostIO<double> ci = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (cost) ci = CostIO<double>{(double *)cost->cost_out, (const double *)cost->w_q, (const double *)cost->w_dq, (const double *)cost->w_tau, (const double *)cost->q_ref};
     return step_typed<double>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce,
-                              (const double *)ext_gforce, pwd, (long)nworlds, dt, dt_steps, nsteps, flags, log, st);
+                              (const double *)ext_gforce, pwd, (long)nworlds, dt, dt_steps, nsteps, flags, log, st, ext_stride, pd_stride, ci);
 }
 
 extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
@@ -4854,7 +4988,8 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     if (!M || !out || nworlds < 0 || nsteps < 0 || (dtype != ARB_F32 && dtype != ARB_F64)) return ARB_ERR_INVALID;
     if (flags & ~ARB_STEP_KNOWN_FLAGS) return ARB_ERR_INVALID;
     ARB_GUARD_DEVICE(M->device);
-    const bool world_logs = (optional_inputs & 4) != 0;      // per-world energies, or state logs of a ragged batch: no forest
+    if (optional_inputs < 0 || optional_inputs > 7 || (optional_inputs & 3) == 2) return ARB_ERR_INVALID;
+    const bool world_logs = (optional_inputs & 4) != 0;      // per-world energies / costs, or state logs of a ragged batch: no forest
     optional_inputs &= 3;
     if (!world_logs && use_forest(M, nworlds, flags, nullptr)) {
         const int rc = arb_step_plan(M->forest, dtype, nworlds / M->forest_k, nsteps, flags | ARB_STEP_ONE_WORLD, optional_inputs, out);
@@ -4875,22 +5010,31 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     out->lds_bytes = L.total * (dtype == ARB_F64 ? 8 : 4);
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device);
-    out->wave_slots = (int32_t)(cus * slots_per_cu(out->waves_per_simd, (long)out->lds_bytes + std::max(0, env_int("ARB_LDS_PAD", 0))));   // (the launch's own model: slots_per_cu)
+    out->wave_slots = (int32_t)(cus * slots_per_cu(out->waves_per_simd, (long)out->lds_bytes + std::max(0, M->kn.lds_pad)));   // (the launch's own model: slots_per_cu)
     const long units = bc.pack ? (nworlds + 1) / 2 : nworlds;
     out->work_queue = (!split && nsteps >= 2 && !(flags & ARB_STEP_STATIC_WORLDS) && units > out->wave_slots &&
-                       env_int("ARB_QUEUE_CHUNK", 4) > 0) ? 1 : 0;
+                       M->kn.queue_chunk > 0) ? 1 : 0;
     out->feat = optional_inputs <= 0 ? 0 : optional_inputs == 1 ? 1 : 3;
     if (!noopt) out->feat = 3;
     // (the specialised kernels, see launch(): plain inputs or user torques of a model of their class, float32)
-    if (ARB_WITH_SPEC && M->spec_ok && noopt && (dtype == ARB_F32 || M->nsets == 1) && !mfma && !bc.pack && !bc.rdv && env_int("ARB_FORCE_SPEC", 1) != 0) out->feat |= 4;
-    if (ARB_WITH_SPEC && M->spec0_ok && noopt && dtype == ARB_F32 && !mfma && !bc.pack && !bc.rdv && env_int("ARB_FORCE_SPEC", 1) != 0) out->feat |= 8;
+    if (ARB_WITH_SPEC && M->spec_ok && noopt && (dtype == ARB_F32 || M->nsets == 1) && !mfma && !bc.pack && !bc.rdv && !(flags & ARB_STEP_GENERAL_KERNELS)) out->feat |= 4;
+    if (ARB_WITH_SPEC && M->spec0_ok && noopt && dtype == ARB_F32 && !mfma && !bc.pack && !bc.rdv && !(flags & ARB_STEP_GENERAL_KERNELS)) out->feat |= 8;
     return ARB_OK;
 }
 
 extern "C" int arb_step_ex(arb_model *M, int dtype, const arb_step_args *a, void *stream) {
-    if (!a) return ARB_ERR_INVALID;
-    return step_impl(M, dtype, a->q, a->dq, a->cforce, a->ext_gforce, a->pd_qdes, a->pd_dqdes, a->pd_kp, a->pd_kd,
-                     a->nworlds, a->dt, a->dt_steps, a->nsteps, a->flags, a->log, stream);
+    if (!a || !M) return ARB_ERR_INVALID;
+    // control sequences (ABI 7): [nsteps][nworlds][ndof] arrays, one row per step
+    if (a->ext_gforce_steps != nullptr && a->ext_gforce != nullptr) return ARB_ERR_INVALID;
+    if ((a->pd_qdes_steps == nullptr) != (a->pd_dqdes_steps == nullptr)) return ARB_ERR_INVALID;
+    if (a->pd_qdes_steps != nullptr && a->pd_qdes != nullptr) return ARB_ERR_INVALID;
+    if (a->nworlds < 0) return ARB_ERR_INVALID;
+    const long row = (long)a->nworlds * M->n;
+    const void *ext = a->ext_gforce_steps ? a->ext_gforce_steps : a->ext_gforce;
+    const void *qdes = a->pd_qdes_steps ? a->pd_qdes_steps : a->pd_qdes, *dqdes = a->pd_dqdes_steps ? a->pd_dqdes_steps : a->pd_dqdes;
+    return step_impl(M, dtype, a->q, a->dq, a->cforce, ext, qdes, dqdes, a->pd_kp, a->pd_kd,
+                     a->nworlds, a->dt, a->dt_steps, a->nsteps, a->flags, a->log, stream,
+                     a->ext_gforce_steps ? row : 0l, a->pd_qdes_steps ? row : 0l, a->cost);
 }
 
 extern "C" int arb_rollout(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
@@ -4925,7 +5069,7 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
     dbg.c_force = (T *)o->c_force; dbg.c_frame = (T *)o->c_frame; dbg.gforce = (T *)o->gforce;
     dbg.q_next = (T *)o->q_next; dbg.dq_next = (T *)o->dq_next; dbg.gs_stats = (int *)o->gs_stats; dbg.gs_trace = (int *)o->gs_trace; dbg.stamps = (long long *)o->stamps; dbg.energy = (T *)o->energy;
     dbg.c_adm = (T *)o->c_adm; dbg.c_vel = (T *)o->c_vel;
-    { const char *ab = getenv("ARB_ABLATE"); dbg.ablate = ab ? atoi(ab) : 0; }
+    dbg.ablate = M->kn.ablate; dbg.pivot_growth = (T *)o->pivot_growth;
     LogOut<T> nolog; memset(&nolog, 0, sizeof(nolog));
     SplitIO<T> nosplit; memset(&nosplit, 0, sizeof(nosplit));
     return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, nosplit, nullptr, st);
@@ -5007,19 +5151,26 @@ extern "C" int arb_build_variants(void) { return (ARB_ALL_VARIANTS ? 1 : 0) | (A
 extern "C" int arb_dev_eig6_pair(int dtype, int device, int n, const double *A /*[n][36]*/, double *out /*[n][28]*/) {
     if (!A || !out || n <= 0 || (dtype != ARB_F32 && dtype != ARB_F64)) return ARB_ERR_INVALID;
     ARB_GUARD_DEVICE(device);
+    if (n > (1 << 20)) return ARB_ERR_INVALID;          // (a test hook: one workgroup per matrix)
     double *din = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&din, sizeof(double) * 36 * (size_t)n));
-    HIP_TRY(hipMalloc(&dout, sizeof(double) * 28 * (size_t)n));
-    HIP_TRY(hipMemcpy(din, A, sizeof(double) * 36 * (size_t)n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dout, 0, sizeof(double) * 28 * (size_t)n));
-    if (dtype == ARB_F64)
-        hipLaunchKernelGGL(arb_eig6_test_kernel<double>, dim3((unsigned)n), dim3(WAVE), 96 * sizeof(double), 0, din, dout, n);
-    else
-        hipLaunchKernelGGL(arb_eig6_test_kernel<float>, dim3((unsigned)n), dim3(WAVE), 96 * sizeof(float), 0, din, dout, n);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 28 * (size_t)n, hipMemcpyDeviceToHost));
-    (void)hipFree(din); (void)hipFree(dout);
-    return ARB_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&din, sizeof(double) * 36 * (size_t)n));
+        HIP_TRY(hipMalloc(&dout, sizeof(double) * 28 * (size_t)n));
+        HIP_TRY(hipMemcpy(din, A, sizeof(double) * 36 * (size_t)n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(dout, 0, sizeof(double) * 28 * (size_t)n));
+        if (dtype == ARB_F64)
+            hipLaunchKernelGGL(arb_eig6_test_kernel<double>, dim3((unsigned)n), dim3(WAVE), 96 * sizeof(double), 0, din, dout, n);
+        else
+            hipLaunchKernelGGL(arb_eig6_test_kernel<float>, dim3((unsigned)n), dim3(WAVE), 96 * sizeof(float), 0, din, dout, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());                 // (the kernel's own execution status, before the buffers go)
+        HIP_TRY(hipMemcpy(out, dout, sizeof(double) * 28 * (size_t)n, hipMemcpyDeviceToHost));
+        return ARB_OK;
+    };
+    const int rc = body();
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    return rc;
 }
 
 // raw branch code of softfinger_try (3 = the fast sliding-shift path declined and eig6 is needed)

@@ -53,7 +53,7 @@ CONFIGS = {
 # the literal MPC shape of config 5 (secondary run): 2048 rollouts x 32 in-kernel steps over 8 GPUs = 256
 # rollouts per GPU, every rollout with its own user torques (arb_step's ext_gforce, controllers.py:63-158's hook);
 # one launch per horizon, only the final state is written.  The latency regime: one world per wave slot at most.
-MPC = dict(model="human36", contacts=4, batch=256, dtype="f32", dt=5e-3, episode=32, states="standing", torques=True,
+MPC = dict(model="human36", contacts=4, batch=256, dtype="f32", dt=5e-3, episode=32, states="standing", torques="sequence",
            name="human36 + 4 contacts, MPC shape: 32-step horizon resident in one launch, per-rollout torques, "
                 "256 rollouts/GPU = 2048 on 8 GPUs (BASELINE config #5, literal shape)")
 
@@ -201,7 +201,8 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
     return out
 
 
-def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True, ext=None):
+def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True, ext=None,
+                 general=False, cost=None):
     """Run `n_episodes` whole episodes: restore the pristine states, advance `episode` steps (one arb_step
     launch per `spl` steps; default the whole episode in one launch).  Returns wall seconds between the
     two barrier + synchronize brackets, the launch durations in ms (HIP events on the launch stream =
@@ -221,15 +222,25 @@ def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=Non
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    kw = {}
+    if general:
+        kw["general_kernels"] = True
+    if cost is not None:
+        kw["cost"] = cost
+    seq = ext is not None and ext.dim() == 3         # a torque SEQUENCE (one row per step): chunked launches take their rows
     for _ in range(n_episodes):
         q.copy_(q0); dq.copy_(dq0)
         if cf is not None:
             cf.zero_()
+        if cost is not None:
+            cost["out"].zero_()
+        k0 = 0
         for c in chunks:
             if timed:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            bw.step(q, dq, dt, c, cforce=cf, split=split or False, ext_gforce=ext)
+            bw.step(q, dq, dt, c, cforce=cf, split=split or False, ext_gforce=(ext[k0:k0 + c] if seq else ext), **kw)
+            k0 += c
             if timed:
                 b.record()
                 ev.append((a, b))
@@ -264,12 +275,23 @@ def make_states(cfg, model, lo, hi, seed):
     return synth.world_states(model, range(lo, hi), "random", seed, angle=0.7, vel=1.0)
 
 
-def make_torques(model, lo, hi, seed):
+def make_torques(model, lo, hi, seed, steps=None):
     """Per-rollout user torques of the MPC shape for rollouts [lo, hi): U(-0.05, 0.05) N m on every joint dof, none on
-    the floating base (the distal bodies of human36 are light); rollout w draws from its own stream (seed, w)."""
+    the floating base (the distal bodies of human36 are light); rollout w draws from its own stream (seed, w).
+    `steps`: a torque SEQUENCE (steps, rollouts, ndof) -- a control input per step of the horizon, as an MPC rollout has
+    (the reference polls its controllers every step, core.py:811-817): amplitude, frequency and phase per rollout and dof."""
     import numpy as np
-    tau = np.stack([np.random.default_rng([seed, w]).uniform(-0.05, 0.05, size=model.ndof) for w in range(lo, hi)])
-    tau[:, :6] = 0.
+    if steps is None:
+        tau = np.stack([np.random.default_rng([seed, w]).uniform(-0.05, 0.05, size=model.ndof) for w in range(lo, hi)])
+        tau[:, :6] = 0.
+        return tau
+    seqs = []
+    for w in range(lo, hi):
+        rng = np.random.default_rng([seed, w])
+        a, om, ph = rng.uniform(-0.05, 0.05, model.ndof), rng.uniform(0.2, 1.0, model.ndof), rng.uniform(0., 6.283, model.ndof)
+        seqs.append(a * np.sin(om * np.arange(steps)[:, None] + ph))
+    tau = np.stack(seqs, axis=1)
+    tau[:, :, :6] = 0.
     return tau
 
 
@@ -321,26 +343,36 @@ def dry_run(args, cfg):
         dist.destroy_process_group()
 
 
-def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000):
+def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000, general=False, min_launches=10):
     """One more workload timed like the headline (whole episodes, one launch per episode, states resident in HBM, at least
-    `min_seconds` and 10 launches): world-steps/s, the launch durations from HIP events on the launch stream, the build."""
+    `min_seconds` and `min_launches` launches): world-steps/s, the launch durations from HIP events on the launch stream,
+    the build.  cfg["torques"]: True = one torque row per rollout, "sequence" = a torque row per step and rollout
+    (arb_step_args.ext_gforce_steps) plus the per-rollout running cost (arb_step_cost), as an MPC horizon has."""
     mdl = build_model(cfg)
     b2 = BatchedWorlds(mdl, local_rank)
     dt2 = torch.float32 if cfg["dtype"] == "f32" else torch.float64
     qa, da = make_states(cfg, mdl, 0, cfg["batch"], seed=seed)
     ta, tb = b2.to_device(qa, da, dt2)
-    ex2 = None
-    if cfg.get("torques"):
+    ex2, cost = None, None
+    if cfg.get("torques") == "sequence":
+        ex2 = torch.as_tensor(make_torques(mdl, 0, cfg["batch"], seed=2000, steps=cfg["episode"]), dtype=dt2, device=b2.device).contiguous()
+        ones = torch.ones(mdl.ndof, dtype=dt2, device=b2.device)
+        cost = dict(out=torch.zeros(cfg["batch"], dtype=dt2, device=b2.device), w_q=ones, w_dq=0.01 * ones, w_tau=ones.clone())
+    elif cfg.get("torques"):
         ex2 = torch.as_tensor(make_torques(mdl, 0, cfg["batch"], seed=2000), dtype=dt2, device=b2.device).contiguous()
-    run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, ext=ex2)
-    cal, _, _ = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, ext=ex2)
-    n_ep = max(10, int(np.ceil(min_seconds / max(cal / 2, 1e-6))))
-    wl, me, (qe, dqe) = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], n_ep, torch, ext=ex2)
+    kw = dict(ext=ex2, general=general, cost=cost)
+    run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
+    cal, _, _ = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
+    n_ep = max(min_launches, int(np.ceil(min_seconds / max(cal / 2, 1e-6))))
+    wl, me, (qe, dqe) = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], n_ep, torch, **kw)
     out = {"workload": cfg["name"] + ", batch %d, %s" % (cfg["batch"], cfg["dtype"]),
            "value": cfg["batch"] * n_ep * cfg["episode"] / wl, "unit": "world-steps/s",
            "kernel_ms": float(np.mean(me)), "episodes": n_ep, "steps_per_launch": cfg["episode"], "timed_region_s": wl,
            "finite": bool(torch.isfinite(qe).all() and torch.isfinite(dqe).all()),
-           "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")))}
+           "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")), general_kernels=general)}
+    if cost is not None:
+        out["cost_finite"] = bool(torch.isfinite(cost["out"]).all())
+        out["mean_cost_per_rollout"] = float(cost["out"].double().mean())
     b2.close()
     return out
 
@@ -397,7 +429,8 @@ def main():
     dt, EP = cfg["dt"], cfg["episode"]
     ext = None
     if cfg.get("torques"):
-        ext = torch.as_tensor(make_torques(model, lo, hi, seed=2000), dtype=dtype, device=bw.device).contiguous()
+        ext = torch.as_tensor(make_torques(model, lo, hi, seed=2000, steps=EP if cfg["torques"] == "sequence" else None),
+                              dtype=dtype, device=bw.device).contiguous()
 
     # ---- warmup: W steps rounded up to whole episodes (untimed), then one calibration episode -------------
     warm_eps = max(1, -(-args.warmup // EP))
@@ -443,7 +476,7 @@ def main():
     if model.nc:
         bytes_per_world_step += 2 * model.nc * 4 * elem                  # cforce in + out
     if ext is not None:
-        bytes_per_world_step += model.ndof * elem                        # the rollout's torques, read once per launch
+        bytes_per_world_step += model.ndof * elem * (EP if ext.dim() == 3 else 1)   # the rollout's torques: one row per launch, or per step
     value = n_gpus * B * steps_timed / wall
     kern_ms = float(np.mean(ep_ms))
     # one launch reads and writes the state once, whatever the number of steps it advances on chip
@@ -504,7 +537,7 @@ def main():
                 res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
                 # hand-overs of a world's state between wavefronts in the work queue (csrc launch_one: ARB_QUEUE_CHUNK /
                 # ARB_QUEUE_TAIL defaults 4 / 4): chunks of 4 steps, then the last 4 steps one by one
-                chunk_, tail_ = int(os.environ.get("ARB_QUEUE_CHUNK", "4")), min(int(os.environ.get("ARB_QUEUE_TAIL", "4")), EP - 1)
+                chunk_, tail_ = 4, min(4, EP - 1)          # (the library's work-item sizes: csrc Knobs)
                 items_ = (-(-(EP - tail_) // chunk_) + tail_) if chunk_ > 0 else 1
                 handover = items_ * bytes_per_world_step * B
                 res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
@@ -589,9 +622,28 @@ def main():
         # from the first to the last step, and the horizon costs the latency of one world's 32 steps.  Splitting the
         # 2048 rollouts over 8 GPUs (256 each, `--config 5 --mpc`) takes just as long per horizon: the shape is latency
         # bound, not throughput bound, and one GPU is the right place for it.
-        cm = dict(MPC, batch=2048, name=MPC["name"].replace("256 rollouts/GPU = 2048 on 8 GPUs", "all 2048 rollouts on ONE GPU"))
+        # Round 5: every rollout applies a torque SEQUENCE -- one row per step, read inside the launch
+        # (arb_step_args.ext_gforce_steps; the reference polls its controllers every step, core.py:811-817) -- and returns
+        # its running cost (arb_step_cost): what an MPC horizon is.  (Until round 4 the leg held one torque per rollout.)
+        cm = dict(MPC, batch=2048, torques="sequence",
+                  name=MPC["name"].replace("256 rollouts/GPU = 2048 on 8 GPUs", "all 2048 rollouts on ONE GPU")
+                                  .replace("per-rollout torques", "a torque sequence per rollout (one row per step) + per-rollout cost"))
         res["mpc_2048_rollouts_one_gpu"] = timed_leg(BatchedWorlds, torch, np, local_rank, cm, 0.5)
-        res["mpc_2048_rollouts_one_gpu"]["ms_per_horizon"] = res["mpc_2048_rollouts_one_gpu"]["kernel_ms"]
+        mp_ = res["mpc_2048_rollouts_one_gpu"]
+        mp_["ms_per_horizon"] = mp_["kernel_ms"]
+        mp_["algorithmic_bytes_per_world_step"] = (2 * (model.nq + model.ndof) * 4 + 2 * model.nc * 4 * 4 + 4) / 32. + model.ndof * 4
+        mp_["algorithmic_bytes_note"] = ("state + contact forces in and out and the cost once per horizon, plus this step's "
+                                         "torque row: %d B per world-step" % (model.ndof * 4))
+        # the general kernels on the headline workload (the headline runs the kernels specialised for its model class:
+        # four plane / sphere SoftFingerContacts, no PD controller, no viscosity; a human36 outside the class gets these)
+        res["general_kernel"] = timed_leg(BatchedWorlds, torch, np, local_rank, cfg, 0.7, general=True)
+        # the other BASELINE configs and the throughput regime, under the same driver clock (short legs)
+        cfgs = {}
+        for key, c_ in (("config2", CONFIGS[2]), ("config4", CONFIGS[4]), ("config5", CONFIGS[5]),
+                        ("batch65536", dict(cfg, batch=65536, name=cfg["name"] + " -- 65 536 worlds on ONE GPU (the throughput regime)"))):
+            cfgs[key] = timed_leg(BatchedWorlds, torch, np, local_rank, dict(c_), 0.5, seed=1000 if key == "batch65536" else 0,
+                                  min_launches=5 if key == "batch65536" else 10)
+        res["configs"] = cfgs
     if n_gpus == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(model, q, dq, dt, args.cpu_seconds, EP)
         res["cpu_baseline"]["host_cores_available"] = os.cpu_count()
@@ -606,7 +658,8 @@ def main():
             ta, tb = b2.to_device(qa, da, dt2)
             ex2 = None
             if c2.get("torques"):
-                ex2 = torch.as_tensor(make_torques(mdl, 0, c2["batch"], seed=2000), dtype=dt2, device=b2.device).contiguous()
+                ex2 = torch.as_tensor(make_torques(mdl, 0, c2["batch"], seed=2000, steps=c2["episode"] if c2["torques"] == "sequence" else None),
+                                      dtype=dt2, device=b2.device).contiguous()
             run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 2, torch, timed=False, ext=ex2)
             wl, me, (qe, _) = run_episodes(b2, ta, tb, c2["dt"], c2["episode"], 20, torch, ext=ex2)
             extra["config%s" % cid] = {"workload": c2["name"], "world_steps_per_s": c2["batch"] * 20 * c2["episode"] / wl,

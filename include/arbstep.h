@@ -44,7 +44,11 @@ extern "C" {
 /* 6 (round 4): the stall status word is sticky (arb_model_status alone clears it), arb_step_plan's optional_inputs has a
  * "per-world logs" bit, forest copies are bit-identical with constraints and their per-world inputs are screened.  No struct
  * layout changed since 5. */
-#define ARB_ABI_VERSION 6
+/* 7 (round 5): arb_step_args carries per-step control schedules (ext_gforce_steps, pd_qdes_steps / pd_dqdes_steps: the
+ * reference polls its controllers EVERY step, core.py:811-817) and a per-world running cost (arb_step_cost); arb_inspect_out
+ * ends with pivot_growth; arb_model_warnings / ARB_WARN_ILLCOND; ARB_STEP_GENERAL_KERNELS.  The library reads NO environment
+ * variable any more (development builds, -DARB_DEVELOPMENT, still do: once, at arb_model_create). */
+#define ARB_ABI_VERSION 7
 
 /* status codes */
 enum {
@@ -111,7 +115,7 @@ enum {
                                          them).  Default: the library picks by batch size and launch shape (three waves from
                                          ~3400 worlds on an MI355X; a third build that holds TWO worlds per wavefront is in the
                                          library, bit-identical, but loses to three waves since their LDS fits twelve wavefronts
-                                         per CU: ARB_FORCE_PACK=1 in the environment selects it), for models that have those builds: float32, 33 .. 48 dofs (the 44- and 48-row
+                                         per CU: the knob "force_pack" of arbstep_hooks.h selects it in libarbstep_variants.so), for models that have those builds: float32, 33 .. 48 dofs (the 44- and 48-row
                                          register tiles; smaller models run faster on two waves at every batch size), ndof + 1 +
                                          4 nc <= 64.  All builds execute the same float operations in the same order per world --
                                          the library is compiled with -ffp-contract=on, so no fused multiply-add depends on how
@@ -137,7 +141,10 @@ enum {
                                          its neighbours untouched; one world per wavefront keeps stepping such a world.  Launches
                                          that log energies (per world) or that log states for a batch that is not a multiple of
                                          k run one world per wavefront. */
-#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u)
+#define ARB_STEP_GENERAL_KERNELS 512u   /* run the general kernels also for a model of one of the specialised classes (arb_step_plan_info.feat
+                                         bits 4 / 8): bit-identical results, ~8 % slower -- for callers (and tests) that want to
+                                         see the difference */
+#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u | 512u)
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the
@@ -237,6 +244,9 @@ typedef struct arb_inspect_out {
     void *c_adm;     /* [nw][4 nc][4 nc]  the constraint-space admittance Y' = J' Y J'^T the sweeps run on (core.py:927);
                         rows / columns of inactive constraints are zero */
     void *c_vel;     /* [nw][4 nc]        v' = J' Y (M gvel/dt + gforce') before the sweeps (core.py:925-926) */
+    void *pivot_growth; /* [nw]  (ABI 7) max over the dofs j of |Z_jj| / |pivot_j| in the pivot-free elimination of the
+                        impedance (core.py:818): how many digits the subtraction that leaves pivot j cancels.  The float32
+                        kernels raise ARB_WARN_ILLCOND from it (see arb_model_warnings). */
 } arb_inspect_out;
 
 int arb_abi_version(void);
@@ -254,7 +264,7 @@ int arb_model_get_info(const arb_model *m, arb_model_info *info);
  * the tests check the batch-size rules).  The float32 step kernel of a model with 33 <= ndof <= 48 and ndof + 1 + 4 nc
  * <= 64 exists in three bit-identical builds -- two waves per SIMD (no register spills), three waves per SIMD (more waves
  * in flight), and two WORLDS per wavefront (their Gauss-Seidel sweeps in one instruction stream; contact-only models; on
- * request only: ARB_FORCE_PACK=1 in the environment) -- picked by batch size and launch shape; ARB_STEP_WAVES2 /
+ * request only: libarbstep_variants.so, knob "force_pack" of arbstep_hooks.h) -- picked by batch size and launch shape; ARB_STEP_WAVES2 /
  * ARB_STEP_WAVES3 pin one.  Models of at most 16 dofs: see ARB_STEP_ONE_WORLD.
  *   wave_slots is an estimate from the registers of the build and the 1280-byte granule in which a CU's 160 KB of LDS are
  *   handed out (hipOccupancyMaxActiveBlocksPerMultiprocessor divides 160 KB by the request and overestimates: twelve
@@ -293,9 +303,25 @@ int arb_step_plan(arb_model *m, int dtype, int64_t nworlds, int32_t nsteps, uint
  * long as it is raised (sticky since round 4: with asynchronous callers the first call to notice a stall is not
  * necessarily one whose status is checked; up to ABI 5.0 that call cleared the word and the next one ran on the invalid
  * state with ARB_OK).  The states of the stalled launch are invalid: reload them before stepping on.
- * (ARB_QUEUE_SPIN_CAP in the environment, the number of polls of that wait, is the tests' fault injection only.)
+ * (The knob "queue_spin_cap" of arbstep_hooks.h, the number of polls of that wait, is the tests' fault injection only.)
  */
 int arb_model_status(arb_model *m);
+
+/*
+ * Warnings of the handle's launches so far (ABI 7): a bit mask, returned in *warnings and CLEARED.  Like arb_model_status
+ * it reads host memory only.
+ *   ARB_WARN_ILLCOND   a float32 launch met a world whose impedance matrix Z = M/dt + B + N (core.py:813-818) loses more
+ *                      digits in the elimination than float32 can spare: for some dof j the pivot that is left,
+ *                      Z_jj - (what the dofs eliminated before j take away), is smaller than Z_jj / ARB_ILLCOND_GROWTH --
+ *                      the subtraction cancels log10 of that ratio digits of float32's seven, and the velocities
+ *                      the step returns are accurate to what is left at best.  Long serial chains do this (snake-64:
+ *                      growth ~1e5, velocity error 0.25 in float32), branched bodies of the size of human36 do not
+ *                      (growth < 100).  The reference computes in float64 throughout (core.py:818): step such a
+ *                      model with ARB_F64.  The results are still written; the warning does not stop anything.
+ */
+#define ARB_WARN_ILLCOND 1u
+#define ARB_ILLCOND_GROWTH 2048.0   /* 2^11: the float32 kernels compare exponents */
+int arb_model_warnings(arb_model *m, uint32_t *warnings);
 
 /*
  * Advance `nworlds` independent worlds by `nsteps` steps of `dt`, in place.
@@ -344,8 +370,29 @@ int arb_rollout(arb_model *m, int dtype, void *q, void *dq, void *cforce, const 
  *            model's gain matrices altogether and need pd_qdes/pd_dqdes.
  *   log      NULL (arb_step) or the per-step logs (arb_rollout)
  *   dt_steps one dt per step (device, float64) instead of the uniform `dt`
- * Other fields as in arb_step.  ext_gforce is the hook for user torques (MPC inputs).
+ * Other fields as in arb_step.  ext_gforce is the hook for user torques (MPC inputs), constant over the call;
+ * ext_gforce_steps is a torque SEQUENCE (one row per step and world), read step by step inside the launch.
+ * Zero-initialise the struct (memset): fields added by later ABI versions then mean "absent".
  */
+/*
+ * Running cost of a rollout (ABI 7; SURVEY 8d config 5: an MPC horizon returns a cost per rollout, 8e: the costs are what
+ * the ranks exchange).  With u_t the user torques of step t and x_{t+1} = (q, dq) the state AFTER step t,
+ *     cost_out[w] += sum over the launch's steps t of
+ *                    sum_i  w_q[i] (qj_i - q_ref[i])^2 + w_dq[i] dq_i^2 + w_tau[i] u_t,i^2
+ * where qj is the dof-indexed vector of the linear joint positions (0 for the dofs of a FreeJoint, whose position is a
+ * pose) -- a diagonal quadratic form of (q, dq, tau), evaluated on chip at the end of every step; only the sum leaves
+ * the chip.  All pointers are DEVICE pointers of the state's dtype; a NULL weight or reference is zero.  cost_out is
+ * read and written (initialise it; a horizon cut into several launches accumulates: the additions are made one step
+ * at a time in step order, so the sum is bit for bit the same however the horizon is cut).
+ */
+typedef struct arb_step_cost {
+    void *cost_out;            /* [nworlds] */
+    const void *w_q;           /* [ndof] or NULL */
+    const void *w_dq;          /* [ndof] or NULL */
+    const void *w_tau;         /* [ndof] or NULL */
+    const void *q_ref;         /* [ndof] or NULL */
+} arb_step_cost;
+
 typedef struct arb_step_args {
     void *q, *dq, *cforce;
     const void *ext_gforce;
@@ -359,6 +406,13 @@ typedef struct arb_step_args {
     const double *dt_steps;   /* DEVICE pointer [nsteps] (always float64) or NULL: the dt of every step, for a
                                  non-uniform timeline inside one launch (core.py:1357: dt = next_time - current_time);
                                  when given, `dt` is ignored */
+    /* ---- ABI 7: control inputs that change along the horizon (the reference polls every controller every step,
+       core.py:811-817, controllers.py:141-158) -- one launch simulates a control SEQUENCE ---- */
+    const void *ext_gforce_steps;   /* DEVICE [nsteps][nworlds][ndof] or NULL: the user torques of every step; replaces
+                                       ext_gforce (giving both is ARB_ERR_INVALID) */
+    const void *pd_qdes_steps;      /* DEVICE [nsteps][nworlds][ndof] or both NULL: the PD targets of every step; replace */
+    const void *pd_dqdes_steps;     /* pd_qdes / pd_dqdes (same rules for the gains) */
+    const arb_step_cost *cost;      /* NULL or the running cost (not with ARB_STEP_SPLIT_WAVE: ARB_ERR_INVALID) */
 } arb_step_args;
 
 int arb_step_ex(arb_model *m, int dtype, const arb_step_args *args, void *stream);

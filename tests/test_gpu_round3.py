@@ -111,22 +111,22 @@ def test_queue_stall_is_reported(monkeypatch):
     bw.status()                                          # healthy launch: nothing raised
     good_q = tq.clone()
     # fault injection: every wait for an earlier chunk "expires" (a negative cap)
-    monkeypatch.setenv("ARB_QUEUE_SPIN_CAP", "-1")
+    bw.set_knob("queue_spin_cap", -1)                    # (arbstep_hooks.h: the library reads no environment variable)
     sq, sdq = bw.to_device(q, dq, torch.float32)
     scf = bw.new_cforce(B, torch.float32)
     bw.step(sq, sdq, dt, T, cforce=scf)
     torch.cuda.synchronize()
-    monkeypatch.delenv("ARB_QUEUE_SPIN_CAP")
+    bw.set_knob("queue_spin_cap", 1 << 24)
     with pytest.raises(_capi.ArbError) as ei:
         bw.status()
     assert "status %d" % _capi.ARB_ERR_STALLED in str(ei.value)
     bw.status()                                          # reading the word cleared it
     # a stall is also reported by the next step call on the handle, which then does nothing
-    monkeypatch.setenv("ARB_QUEUE_SPIN_CAP", "-1")
+    bw.set_knob("queue_spin_cap", -1)
     sq, sdq = bw.to_device(q, dq, torch.float32)
     bw.step(sq, sdq, dt, T, cforce=bw.new_cforce(B, torch.float32))
     torch.cuda.synchronize()
-    monkeypatch.delenv("ARB_QUEUE_SPIN_CAP")
+    bw.set_knob("queue_spin_cap", 1 << 24)
     before = sq.clone()
     for _ in range(2):                                   # the word is sticky: EVERY call fails until it is acknowledged
         with pytest.raises(_capi.ArbError):
@@ -320,7 +320,7 @@ def test_bench_mpc_shape():
 @pytest.mark.parametrize("name,B", [("human36_c4", 1001), ("human36_c8", 301)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
-    """The packed sweep kernel of the split execution (ARB_GSW_PACK=1: worlds 2p and 2p+1 share a wavefront, a stage of
+    """The packed sweep kernel of the split execution (knob gsw_pack = 1: worlds 2p and 2p+1 share a wavefront, a stage of
     the local solve runs when either world needs it, results are taken lane by lane) against the one-world sweep kernel
     and against the fused kernel: same forces, velocities and positions bit for bit over a whole falling episode, odd
     batch sizes included (the last wavefront holds one world)."""
@@ -332,9 +332,9 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
     q[:, 7] -= 0.01
     res = {}
     for mode in ("fused", "wave", "pack", "pack4"):
-        # (round 4: ARB_GSW_PACK=4 = FOUR worlds per wavefront for models of up to four contacts -- 16 constraint rows, a
-        # quarter of the wavefront each; with more it runs two, like ARB_GSW_PACK=1 / 2)
-        monkeypatch.setenv("ARB_GSW_PACK", {"pack": "1", "pack4": "4"}.get(mode, "0"))
+        # (round 4: gsw_pack = 4 = FOUR worlds per wavefront for models of up to four contacts -- 16 constraint rows, a
+        # quarter of the wavefront each; with more it runs two, like knob gsw_pack = 1 / 2)
+        bw.set_knob("gsw_pack", {"pack": 1, "pack4": 4}.get(mode, 0))
         tq, tdq = bw.to_device(q, dq, dtype)
         cf = bw.new_cforce(B, dtype)
         bw.step(tq, tdq, 5e-3, 40, cforce=cf, split=("wave" if mode != "fused" else False))
@@ -352,7 +352,7 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
 ])   # (8 contacts: two column sets, no packed step kernel -- its packed SWEEPS are test_packed_sweeps_equal_unpacked_bitwise)
 def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, cases):
     """The packed build of the step kernel (two worlds per wavefront: phases A-D world after world, the Gauss-Seidel
-    sweeps of both at once; libarbstep_variants.so with ARB_FORCE_PACK=1) against the one-world builds of the shipped
+    sweeps of both at once; libarbstep_variants.so with knob force_pack = 1) against the one-world builds of the shipped
     library: states and forces bit for bit -- one workgroup per pair and the work queue over pairs, odd batch sizes, a
     lone world, user torques (the FEAT 1 kernel), one launch per step."""
     from arboris_python_amd import synth
@@ -368,8 +368,8 @@ def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, 
         tau[:, :6] = 0.
         res = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("ARB_FORCE_PACK", mode)
             bw = bws[mode]
+            bw.set_knob("force_pack", int(mode))
             if mode == "1":
                 assert bw.plan(B, T if not per_step else 1, ext_gforce=ext)["worlds_per_wavefront"] == 2
             tq, tdq = bw.to_device(q, dq, torch.float32)
@@ -401,8 +401,6 @@ def test_fast_sweeps_hand_over_to_the_complete_variant_bitwise(monkeypatch):
     m, _, _ = load_model("human36_c4")
     variants = _capi.load_variants()
     assert variants.arb_build_variants() & 4 and _capi.load().arb_build_variants() == 0
-    for v in ("ARB_FORCE_PACK", "ARB_FORCE_RDV", "ARB_FORCE_WAVES"):
-        monkeypatch.delenv(v, raising=False)
     bws = {"fast": BatchedWorlds(m), "complete": BatchedWorlds(m, lib=variants)}
     B, T = 4096, 40
     q, dq = synth.standing_states(m, B, seed=1000, drop=0.03, vel=0.1)
@@ -430,7 +428,7 @@ def test_fast_sweeps_hand_over_to_the_complete_variant_bitwise(monkeypatch):
 
 
 def test_rendezvous_build_equals_the_shipped_kernels_bitwise(monkeypatch):
-    """The rendezvous build (round 4; libarbstep_variants.so with ARB_FORCE_RDV=1): work items are single steps, the
+    """The rendezvous build (round 4; libarbstep_variants.so with knob force_rdv = 1): work items are single steps, the
     wavefronts of worlds 4g .. 4g+3 meet at the Gauss-Seidel point -- three park their constraint-space system and draw the
     next item, the last to arrive sweeps the four systems at once (gs_stage_n<T, 4>) and integrates the four worlds.  Against
     the shipped library: states and forces bit for bit, batch sizes that leave one, two and three worlds in the last group,
@@ -442,7 +440,6 @@ def test_rendezvous_build_equals_the_shipped_kernels_bitwise(monkeypatch):
     variants = _capi.load_variants()
     assert variants.arb_build_variants() & 2
     bws = {"0": BatchedWorlds(m), "1": BatchedWorlds(m, lib=variants)}
-    monkeypatch.delenv("ARB_FORCE_PACK", raising=False)
     for B, T, ext in ((700, 40, False), (5001, 24, False), (2, 12, True), (1, 12, False), (9003, 13, True)):
         q, dq = synth.world_states(m, range(B), "standing", 31, drop=0.03, vel=0.2)
         q[:, 7] -= 0.012
@@ -450,8 +447,8 @@ def test_rendezvous_build_equals_the_shipped_kernels_bitwise(monkeypatch):
         tau[:, :6] = 0.
         res = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("ARB_FORCE_RDV", mode)
             bw = bws[mode]
+            bw.set_knob("force_rdv", int(mode))
             tq, tdq = bw.to_device(q, dq, torch.float32)
             cf = bw.new_cforce(B, torch.float32)
             bw.step(tq, tdq, 5e-3, T, cforce=cf, **(dict(ext_gforce=tau.contiguous()) if ext else {}))
@@ -471,11 +468,9 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     """The float32 step kernel of a human36-sized model exists as a two-wave, a three-wave and a packed (two worlds
     per wavefront) build; arb_step_plan reports which one a launch shape gets.  On an MI355X (256 CUs): two waves for
     small batches and one-step launches, three from ~4100 worlds of a multi-step launch; the packed build only on request
-    (ARB_FORCE_PACK=1: the three-wave build, whose LDS fits the 1280-byte allocation granule twelve times per CU, beats it at
+    (knob force_pack = 1: the three-wave build, whose LDS fits the 1280-byte allocation granule twelve times per CU, beats it at
     every batch size); float64 and models with two column sets have the two-wave build only."""
     from arboris_python_amd.batch import BatchedWorlds
-    monkeypatch.delenv("ARB_FORCE_WAVES", raising=False)
-    monkeypatch.delenv("ARB_FORCE_PACK", raising=False)
     m, _, _ = load_model("human36_c4")
     bw = BatchedWorlds(m)
     cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
@@ -499,18 +494,17 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     # the packed build is compiled into libarbstep_variants.so only
     variants = _capi.load_variants()
     bwv = BatchedWorlds(m, lib=variants)
-    monkeypatch.setenv("ARB_FORCE_PACK", "1")
+    bw.set_knob("force_pack", 1); bwv.set_knob("force_pack", 1)
     assert build(bw.plan(100, 40)) == (2, 1) and build(bwv.plan(100, 40)) == (2, 2)
-    monkeypatch.setenv("ARB_FORCE_PACK", "0")
+    bw.set_knob("force_pack", 0); bwv.set_knob("force_pack", 0)
     assert build(bw.plan(64 * cus, 40)) == (3, 1) and build(bwv.plan(64 * cus, 40)) == (3, 1)
     bw.close(); bwv.close()
     # a model with a kinematic constraint (not only SoftFingerContacts) has no packed build
     m, _, _ = load_model("ballsocket")
     bw = BatchedWorlds(m)
     bwv = BatchedWorlds(m, lib=variants)
-    monkeypatch.delenv("ARB_FORCE_PACK", raising=False)
     assert bw.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
-    monkeypatch.setenv("ARB_FORCE_PACK", "1")
+    bwv.set_knob("force_pack", 1)
     assert bwv.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
     bwv.close()
     # (by default its worlds share wavefronts another way: a forest of 5 copies, tests/test_gpu_forest.py)

@@ -4,7 +4,7 @@
 (eight when the model has two column sets), no PD controller and no joint viscosity -- human36 on the floor, BASELINE
 configs 3 and 5 and the reference's own eight-contact scenario -- the constraint type, the shape pair, nc and ndol are
 compile-time constants and the code of the absent model features is not compiled in (+8 % on the headline workload).  Same expressions on the same values: the results must equal the general kernels' bit for bit, which
-`ARB_FORCE_SPEC=0` in the environment selects in the same library.
+the flag ARB_STEP_GENERAL_KERNELS selects in the same library.
 """
 import numpy as np
 import pytest
@@ -18,8 +18,6 @@ pytestmark = pytest.mark.gpu
 
 def test_plan_reports_the_specialised_kernels(monkeypatch):
     from arboris_python_amd.batch import BatchedWorlds
-    for v in ("ARB_FORCE_SPEC", "ARB_FORCE_WAVES"):
-        monkeypatch.delenv(v, raising=False)
     assert _capi.load().arb_build_variants() == 0
     # model: class bit in float32 (4: contacts, 8: no constraints, 0: the general kernels), in float64
     want = {"human36_c4": (4, 4),                # four plane / sphere SoftFingerContacts
@@ -37,9 +35,7 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
             assert bw.plan(B, T, other_inputs=True)["feat"] == 3, (name, B, T)       # every optional input: the general kernel
             assert bw.plan(B, T, dtype=torch.float64)["feat"] == spec64, (name, B, T)
         if spec32:
-            monkeypatch.setenv("ARB_FORCE_SPEC", "0")
-            assert bw.plan(8192, 40)["feat"] == 0
-            monkeypatch.delenv("ARB_FORCE_SPEC")
+            assert bw.plan(8192, 40, general_kernels=True)["feat"] == 0
         bw.close()
 
 
@@ -53,8 +49,6 @@ def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, 
     (FEAT 8 / 9: human36 in free motion, BASELINE config 2)."""
     from arboris_python_amd import synth
     from arboris_python_amd.batch import BatchedWorlds
-    for v in ("ARB_FORCE_SPEC", "ARB_FORCE_WAVES", "ARB_FORCE_PACK", "ARB_FORCE_RDV"):
-        monkeypatch.delenv(v, raising=False)
     m, _, _ = load_model(model)
     dt_ = getattr(torch, dtype)
     bw = BatchedWorlds(m)
@@ -72,18 +66,16 @@ def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, 
         assert bw.plan(B, 1 if mode == "per_step" else T, dtype=dt_, ext_gforce=torques, **kw)["feat"] == (cls | (1 if torques else 0))
         res = {}
         for key in ("spec", "general"):
-            if key == "general":
-                monkeypatch.setenv("ARB_FORCE_SPEC", "0")
+            gk = dict(general_kernels=(key == "general"))
             tq, tdq = bw.to_device(q, dq, dt_)
             cf = bw.new_cforce(B, dt_) if m.nc else None
             if mode == "per_step":
                 for _ in range(T):
-                    bw.step(tq, tdq, 5e-3, 1, cforce=cf, ext_gforce=ext)
+                    bw.step(tq, tdq, 5e-3, 1, cforce=cf, ext_gforce=ext, **gk)
             else:
-                bw.step(tq, tdq, 5e-3, T, cforce=cf, ext_gforce=ext, **kw)
+                bw.step(tq, tdq, 5e-3, T, cforce=cf, ext_gforce=ext, **kw, **gk)
             torch.cuda.synchronize()
             bw.status()
-            monkeypatch.delenv("ARB_FORCE_SPEC", raising=False)
             res[key] = (tq, tdq) if cf is None else (tq, tdq, cf)
         if not torques:
             assert bool(torch.isfinite(res["spec"][0]).all())

@@ -5,5 +5,5 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/build/ab
 n=$1; shift
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=on -std=c++17 -fPIC -I $R/include -DARB_QUICK=${ARB_QUICK:-1} "$@" -shared -o $R/build/ab/$n.so $R/arboris_python_amd/csrc/arb_kernels.hip 2>&1 | grep -i -A5 "error" | head -20
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=on -std=c++17 -fPIC -I $R/include -DARB_QUICK=${ARB_QUICK:-1} -DARB_DEVELOPMENT "$@" -shared -o $R/build/ab/$n.so $R/arboris_python_amd/csrc/arb_kernels.hip 2>&1 | grep -i -A5 "error" | head -20
 ls -la $R/build/ab/$n.so
