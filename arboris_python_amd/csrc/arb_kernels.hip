@@ -552,7 +552,9 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
     int st_rel = 0, st_sta = 0, st_fast = 0, st_slow = 0, st_sweeps = 0;
     int tr_rel = 0, tr_sta = 0, tr_slow = 0;
     G vr_prev = vr, fr_prev = fr;
-#ifdef ARB_GSSTAMPS   /* development: cycles of the segments of a sliding solve, summed over the step's sliding solves */
+#ifdef ARB_MARKS       /* development (tools/isa_phase_mix.py): comment markers in the compiler's assembly output at the segment boundaries */
+#define ARB_GST(v) asm volatile("; ARB_MARK GS_" #v)
+#elif defined(ARB_GSSTAMPS)   /* development: cycles of the segments of a sliding solve, summed over the step's sliding solves */
     long long gst[6] = {0, 0, 0, 0, 0, 0}, gt0 = 0, gt1 = 0, gt2 = 0, gt3 = 0, gt4 = 0;
     int gprobe[2] = {0, 0};
     bool gslid = false;
@@ -1355,7 +1357,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     }
     WAVE_SYNC();
 
-#ifdef ARB_GSSTAMPS
+#ifdef ARB_MARKS
+#define ARB_STAMP(k) asm volatile("; ARB_MARK P" #k)
+#define ARB_BSTAMP(k) asm volatile("; ARB_MARK B" #k)
+#define ARB_CSTAMP(k) asm volatile("; ARB_MARK C" #k)
+#define ARB_ASTAMP(k) asm volatile("; ARB_MARK A" #k)
+#elif defined(ARB_GSSTAMPS)
 #define ARB_STAMP(k) do { } while (0)
 #define ARB_BSTAMP(k) do { } while (0)
 #elif defined(ARB_ASTAMPS)   /* development: slots 1..6 = inside phase A (joint kinematics + H_pc, block algebra, own columns, level loop, body wrenches, end) */
@@ -4768,6 +4775,12 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
     // two column sets, the inspect kernel and the optional inputs)
+#if ARB_QUICK == 3      /* the headline kernels only: the specialised float32 kernels, plain inputs, two and three waves (~1 min) */
+    if constexpr (std::is_same<T, float>::value && MODE == 0) {
+        if (M->nmax == 44 && M->nsets == 1 && spec && plain) return w3 ? ONE_(44, 1, 4, 2) : ONE_(44, 1, 4, 0);
+    }
+    return ARB_ERR_UNSUPPORTED;
+#else
     if constexpr (std::is_same<T, float>::value) {
         if (M->nmax == 44 && M->nsets == 1) {
             if constexpr (MODE == 0) {
@@ -4797,6 +4810,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #endif
     }
     return ARB_ERR_UNSUPPORTED;
+#endif
 #else
 #define CASE(NM)                                                                                       \
     case NM:                                                                                           \
