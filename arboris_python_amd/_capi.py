@@ -28,6 +28,7 @@ ARB_STEP_WAVES2 = 64
 ARB_STEP_WAVES3 = 128
 ARB_STEP_ONE_WORLD = 256
 ARB_STEP_GENERAL_KERNELS = 512
+ARB_STEP_BODY_COLUMNS = 1024
 ARB_WARN_ILLCOND = 1
 ARB_ILLCOND_GROWTH = 2048.0
 

@@ -144,7 +144,7 @@ class BatchedWorlds(object):
 
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
              stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False,
-             waves=None, one_world=False, cost=None, general_kernels=False, _log=None):
+             waves=None, one_world=False, cost=None, general_kernels=False, body_columns=False, _log=None):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
@@ -169,7 +169,10 @@ class BatchedWorlds(object):
         ``cost=dict(out=(B,), w_q=(ndof,), w_dq=(ndof,), w_tau=(ndof,), q_ref=(ndof,))`` (``out`` required, the others
         optional): the running cost of the rollout, ``out[w] += sum_t sum_i w_q (q_i - q_ref_i)^2 + w_dq dq_i^2 +
         w_tau tau_t,i^2`` on the state after every step (``arb_step_cost``, include/arbstep.h), summed on chip.
-        ``general_kernels=True``: the general kernels also for a model of a specialised class (ARB_STEP_GENERAL_KERNELS)."""
+        ``general_kernels=True``: the general kernels also for a model of a specialised class (ARB_STEP_GENERAL_KERNELS).
+        ``body_columns=True``: constraint columns in body space wherever the model qualifies (ARB_STEP_BODY_COLUMNS: the
+        default where it saves the second column set -- human36 with eight contacts --; with four contacts 2 % slower and
+        half as many float32 outliers)."""
         torch = _torch()
         B = self._check_state(q, dq, cforce, ext_gforce, nsteps)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
@@ -186,6 +189,8 @@ class BatchedWorlds(object):
             flags |= _capi.ARB_STEP_ONE_WORLD
         if general_kernels:
             flags |= _capi.ARB_STEP_GENERAL_KERNELS
+        if body_columns:
+            flags |= _capi.ARB_STEP_BODY_COLUMNS
         dts = self._dt_steps(dt, nsteps, st)
         ext_seq = ext_gforce is not None and ext_gforce.dim() == 3
         if pd_targets is None and pd_gains is None and dts is None and not ext_seq and cost is None and _log is None:
@@ -271,7 +276,7 @@ class BatchedWorlds(object):
         return out
 
     def plan(self, nworlds, nsteps=1, dtype=None, ext_gforce=False, other_inputs=False, waves=None, split=False,
-             static_worlds=False, one_world=False, world_logs=False, general_kernels=False):
+             static_worlds=False, one_world=False, world_logs=False, general_kernels=False, body_columns=False):
         """Which kernel build and launch shape ``step`` would use (``arb_step_plan``): a dict with ``waves_per_simd``,
         ``worlds_per_wavefront`` (2 = the packed build; the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``.
         ``world_logs``: the launch is a rollout that logs per-world energies (or states of a batch that is not a multiple
@@ -281,6 +286,7 @@ class BatchedWorlds(object):
         flags = self._waves_flag(waves) | self._split_flag(split) | (_capi.ARB_STEP_STATIC_WORLDS if static_worlds else 0)
         flags |= _capi.ARB_STEP_ONE_WORLD if one_world else 0
         flags |= _capi.ARB_STEP_GENERAL_KERNELS if general_kernels else 0
+        flags |= _capi.ARB_STEP_BODY_COLUMNS if body_columns else 0
         p = _capi.StepPlan()
         _capi.check(self._lib.arb_step_plan(self._handle, code, int(nworlds), int(nsteps), flags,
                                             (3 if other_inputs else (1 if ext_gforce else 0)) | (4 if world_logs else 0), C.byref(p)))
@@ -303,9 +309,11 @@ class BatchedWorlds(object):
         (the states of the stalled launch are invalid: reload them before stepping on)."""
         return self._lib.arb_model_status(self._handle) == _capi.ARB_ERR_STALLED
 
-    def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False):
+    def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False, general_kernels=False,
+                body_columns=False):
         """Evaluate one step without touching ``q``/``dq``; returns a dict of the
-        requested intermediate results (names of ``arb_inspect_out``)."""
+        requested intermediate results (names of ``arb_inspect_out``).  ``general_kernels`` / ``body_columns``: the
+        arithmetic of ``step`` with the same flag (the inspect kernel forms the constraint-space system the same way)."""
         torch = _torch()
         m = self.model
         B = self._check_state(q, dq, cforce, ext_gforce)
@@ -330,6 +338,8 @@ class BatchedWorlds(object):
             setattr(out, name, t.data_ptr())
         st = torch.cuda.current_stream(self.device)
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
+        flags |= _capi.ARB_STEP_GENERAL_KERNELS if general_kernels else 0
+        flags |= _capi.ARB_STEP_BODY_COLUMNS if body_columns else 0
         _capi.check(self._lib.arb_inspect(
             self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
             None if cforce is None else cforce.data_ptr(),

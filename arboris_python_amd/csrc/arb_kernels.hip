@@ -150,9 +150,8 @@
 #define CD_ACTIVE 25
 #define CD_POS0 26   // (3) BallAndSocket p_01 / JointLimits pos0
 #define CD_PINV 32   // (16) inverse of the constraint's admittance block
-#define CD_GC0 48    // (3) origin of contact frame 0
-#define CD_GC1 51    // (3) origin of contact frame 1
-#define CD_STRIDE 56
+#define CD_STRIDE 48 // (round 5: the origins of the two contact frames, six more elements, were kept for the inspect kernels'
+                     //  c_frame output only: written from phase A' now -- 32 B x nc of every wavefront's LDS)
 
 struct Layout {      // offsets in elements of T inside the wave's LDS block
     int q, dq, qd, bd, pd, sc, cd, rt, am, vv, ff, ff0, work, ci, total;
@@ -162,6 +161,9 @@ struct Layout {      // offsets in elements of T inside the wave's LDS block
     int sa_q, sa_dq, sa_am, sa_cd, sa_vv, sa_ff, sa_ff0, sa_rt, sb_q, sb_dq, sb_ff;
     int lscan;       // phase B forms the subtree sums from a prefix table in LDS (small trees) instead of a DPP scan
     int ndol;        // rows of the stacked constraint system (host side: does the model carry constraint forces?)
+    // body-space constraint columns (BODYCOL kernels, round 5): behind Y' in the per-body region -- the body-space admittance
+    // YB ((6 nbp)^2), the body-space free velocity VB (6 nbp; phase E: the body-space force), the half product W (6 nbp x ndol)
+    int yb, vb, wst;
 };
 // per-constraint integer constants staged in LDS once per launch (int32 words): type, dof masks of the ancestors of
 // body 1 and of body 0 (lo, hi each), constrained dof -- the constraint-row loops of phase B read them with
@@ -186,9 +188,19 @@ __device__ __forceinline__ bool same_bits(double a, double b) { return __double_
 // compile-time offset, so the kernels hold one pointer pair in SGPRs instead of ~45 (round 1 spilled 284
 // SGPRs to VGPR lanes, most of them table pointers).
 #define ARB_CAP 64
+#define ARB_MAXPAIR 4     // body-space constraint columns: at most this many (body 0, body 1) pairs, six columns each
 template <typename T>
 struct DevModel {
     int nb, n, nq, nc, ndol, ncols, maxdepth;
+    // Body-space constraint columns (round 5, the BODYCOL kernels): the 4 nc rows of J' of a model whose constraints are all
+    // SoftFingerContacts are T_c J_p -- J_p the six rows of the relative Jacobian of the contact's pair of bodies p (world
+    // axes, about the origin of `pair_ref`), T_c the contact's 4 x 6 frame transform (constraints.py:429-433: Ad(H_01) of
+    // one body Jacobian for every contact of the body) -- so the augmented system carries 6 nbp columns Y J_p^T instead of
+    // 4 nc, and human36 with the reference's eight contact points (two feet: 12 instead of 32 columns) fits ONE column set.
+    int nbp, ncols_b;
+    int pair_ref[ARB_MAXPAIR], cpair[ARB_CAP];
+    unsigned long long pair_a1[ARB_MAXPAIR], pair_a0[ARB_MAXPAIR], pair_cmask[ARB_MAXPAIR];
+    Layout layb, layb3;      // LDS layouts of the BODYCOL kernels (two-wave / three-wave)
     int has_visc, has_pd, has_warm, has_grav;
     int *status;     // host-visible word (mapped pinned memory) that a launch raises when it gives up waiting in the work queue
     int *warn;       // host-visible warning bits (ARB_WARN_*), raised by the float32 kernels: see the growth check of phase C
@@ -1134,7 +1146,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     const double *__restrict__ dts_in, int *__restrict__ queue_in, int queue_chunk, int queue_tail, int queue_spin_cap,
     T *__restrict__ park_in, const long ext_stride_in, const long pd_stride_in, const CostIO<T> cost_in)
 {
-    static_assert(MODE == 0 || FEAT == 3, "the inspect kernels take every input");
+    static_assert(MODE == 0 || FEAT == 3 || FEAT == 19, "the inspect kernels take every input");
     static_assert(CM != 1 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
     static_assert(CM != 2 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && std::is_same<T, float>::value), "three-wave build: float32, one column set");
     static_assert(CM != 3 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && FEAT <= 1 && std::is_same<T, float>::value), "packed build: float32, one column set, plain inputs");
@@ -1158,9 +1170,22 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     // viscosity +3 % -- its block was the FIRST term of phase B's accumulators, see there --, PD -1 %, warm start 0 %.)
     // FEAT bit 8: the same for models WITHOUT constraints (BASELINE config 2: human36 in free motion) -- nc = 0 is a constant,
     // phases A', D, the sweeps and the constraint columns of phase C are not compiled in.
-    constexpr bool SPEC = (FEAT & 12) != 0;
-    constexpr int SPEC_NC = (FEAT & 8) ? 0 : 4 * NSETS;
-    static_assert(!SPEC || (!FEAT_ALL && MODE == 0 && (CM == 0 || CM == 2)), "specialised kernels: plain inputs / user torques");
+    // FEAT bit 16 (round 5): BODY-SPACE constraint columns -- the same model class as bit 4 with ANY number of contacts on up
+    // to ARB_MAXPAIR pairs of bodies (human36 with the reference's eight contact points, tests/test_human36_falling.py:32: two
+    // feet): the augmented system carries the six columns Y J_p^T of every pair instead of the 4 nc columns Y J'^T (see
+    // DevModel::nbp), so the model fits ONE column set; Y' = T (J_p Y J_p^T) T^T and v' = T J_p Y rhs are formed from the
+    // 6 nbp x 6 nbp body-space admittance after phase D, phase E applies Y J_p^T (sum of T_c^T f_c).  nc is a run-time value
+    // here.  Inspect kernels of such a model (MODE 1, FEAT 19) run the same arithmetic.
+    constexpr bool BODYCOL = (FEAT & 16) != 0;
+    constexpr bool SPEC = (FEAT & 12) != 0 || BODYCOL;
+#ifndef ARB_BC_NC
+#define ARB_BC_NC 0           // development: the BODYCOL kernels compiled for this number of contacts (0: a run-time value)
+#endif
+    constexpr bool NC_CONST = ((FEAT & 12) != 0 && !BODYCOL) || (BODYCOL && ARB_BC_NC > 0 && MODE == 0);       // nc, ndol compile-time constants
+    constexpr int SPEC_NC = BODYCOL ? ARB_BC_NC : (FEAT & 8) ? 0 : 4 * NSETS;
+    static_assert(!NC_CONST || (!FEAT_ALL && MODE == 0 && (CM == 0 || CM == 2)), "specialised kernels: plain inputs / user torques");
+    static_assert(!BODYCOL || (NSETS == 1 && (CM == 0 || CM == 2) && (FEAT == 20 || FEAT == 21 || FEAT == 19)),
+                  "body-space columns: one column set; plain inputs (20), user torques (21), every optional input / inspect (19)");
     static_assert((FEAT & 12) != 12 && (!(FEAT & 8) || NSETS == 1), "specialised kernels: one model class at a time");
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
     // ABI 7: control inputs that change along the horizon -- step t reads row t of [nsteps][nworlds][ndof] arrays (stride 0:
@@ -1271,7 +1296,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 // (after the first global store the compiler no longer proves the model unclobbered and fetches it with vector
 // loads: readfirstlane puts the wave-uniform values back into SGPRs)
 #define ARB_UNI(x) __builtin_amdgcn_readfirstlane(x)
-#define ARB_LAY() ((CM == 3) ? mp->layp : (CM == 2 || CM == 4) ? mp->lay3 : mp->lay)
+#define ARB_LAY() ((CM == 3) ? mp->layp : (CM == 2 || CM == 4) ? (BODYCOL ? mp->layb3 : mp->lay3) : (BODYCOL ? mp->layb : mp->lay))
 #define ARB_LDS_POINTERS() do { const Layout &lay_ = ARB_LAY();                                                              \
         qs = lds + ARB_UNI(lay_.q); dqs = lds + ARB_UNI(lay_.dq); qd = lds + ARB_UNI(lay_.qd); BD = lds + ARB_UNI(lay_.bd); SC = lds + ARB_UNI(lay_.sc);               \
         PD = reinterpret_cast<double *>(lds + ARB_UNI(lay_.pd)); CD = lds + ARB_UNI(lay_.cd); RT = lds + ARB_UNI(lay_.rt); AM = lds + ARB_UNI(lay_.am);       \
@@ -1281,7 +1306,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     // (the sizes are re-laundered at every phase boundary, ARB_OPAQUE_LANE: left to itself the compiler hoists
     // the ~90 wave-uniform predicates `i < n` of the unrolled row loops out of the step loop as 64-bit lane masks
     // and then spills them -- 284 SGPR spills in round 1)
-    int n = mp->n, nb = mp->nb, nc = SPEC ? SPEC_NC : mp->nc, ndol = SPEC ? SPEC_NC * ARB_MAXDOL : mp->ndol;
+    int n = mp->n, nb = mp->nb, nc = NC_CONST ? SPEC_NC : mp->nc, ndol = NC_CONST ? SPEC_NC * ARB_MAXDOL : mp->ndol;
     const int nq = mp->nq;
     // the host picks the smallest register tile that holds ndof (kNmaxChoices): rows below the previous tile
     // size always exist, which folds their `i < n` predicates away
@@ -1316,7 +1341,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     {
         T *q_to = PACK ? SAq : qs, *dq_to = PACK ? SAdq : dqs, *ff_to = PACK ? SAff : FF;
         for (int i = lane; i < nq; i += WAVE) q_to[i] = ldg(gq + w0 * nq + i);
-        dq_to[lane] = (lane < n) ? ldg(gdq + w0 * n + lane) : T(0);
+        if (lane < RS) dq_to[lane] = (lane < n) ? ldg(gdq + w0 * n + lane) : T(0);      // (the velocity array has one element per tile row)
         for (int i = lane; i < ndol; i += WAVE) {
             T f = T(0);
             if (gcforce != nullptr) f = ldg(gcforce + w0 * ndol + i);
@@ -1325,7 +1350,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     }
     if (PACK && two) {
         for (int i = lane; i < nq; i += WAVE) qs[i] = ldg(gq + (w0 + 1) * nq + i);
-        dqs[lane] = (lane < n) ? ldg(gdq + (w0 + 1) * n + lane) : T(0);
+        if (lane < RS) dqs[lane] = (lane < n) ? ldg(gdq + (w0 + 1) * n + lane) : T(0);
         for (int i = lane; i < ndol; i += WAVE) {
             T f = T(0);
             if (gcforce != nullptr) f = ldg(gcforce + (w0 + 1) * ndol + i);
@@ -1345,7 +1370,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     T cost_acc = T(0);
     if constexpr (FEAT_EXT) { if (cost.out != nullptr) cost_acc = ldg(cost.out + w0); }
     bool warn_illcond = false;     // (float32: some pivot of this item's eliminations cancelled more digits than float32 can spare)
-    if (lane < nc) {
+    if (!BODYCOL && lane < nc) {     // (body-space columns: the pairs' masks come from the model, the class has one tree)
         const int b1 = mp->cbody[lane], b0 = mp->cbody0[lane];
         const unsigned long long a1 = b1 >= 0 ? mp->anc[b1] : 0ull, a0 = b0 >= 0 ? mp->anc[b0] : 0ull;
         int *ci = CI + CI_STRIDE * lane;
@@ -1388,13 +1413,36 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #endif
 #define ARB_OPAQUE_LANE() do { lane = lane0; asm volatile("" : "+v"(lane)); mp = mp_in; asm volatile("" : "+s"(mp)); \
                               n = ARB_UNI(mp->n); nb = ARB_UNI(mp->nb); asm volatile("" : "+s"(n), "+s"(nb));                \
-                              if (!SPEC) { nc = ARB_UNI(mp->nc); ndol = ARB_UNI(mp->ndol); asm volatile("" : "+s"(nc), "+s"(ndol)); } \
+                              if (!NC_CONST) { nc = ARB_UNI(mp->nc); ndol = ARB_UNI(mp->ndol); asm volatile("" : "+s"(nc), "+s"(ndol)); } \
                               ARB_LDS_POINTERS(); } while (0)
 
     // World.integrate, core.py:974-980: gvel <- Y rhs + Y J'^T (f - f0) from the solution
     // columns in RT, then every joint integrates its position.
     auto integrate_on = [&](const T *RT, const T *FF, const T *FF0, T *qs, T *dqs, bool with_forces, bool parked = false) {
         T vnew = T(0);
+        if constexpr (BODYCOL) {
+            // body-space columns: gvel+ = Y rhs + (Y J_p^T) g with the body-space force g = sum over the pair's contacts of
+            // T_c^T (f_c - f0_c): lane j < 6 nbp forms g_j, then every dof lane takes its 6 nbp terms
+            const int nb6 = 6 * ARB_UNI(mp->nbp);
+            T *const GB = lds + ARB_UNI(ARB_LAY().vb);
+            if (with_forces && lane < nb6) {
+                const int p = lane / 6, j = lane - 6 * p;
+                double g = 0.;
+                for (int c = 0; c < nc; ++c) {
+                    if (mp->cpair[c] != p) continue;
+                    const T *tc = CD + c * CD_STRIDE + j;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g += (double)tc[6 * r] * (double)(FF[4 * c + r] - FF0[4 * c + r]);
+                }
+                GB[lane] = (T)g;
+            }
+            WAVE_SYNC();
+            if (lane < n) {
+                vnew = RT[lane];
+                if (with_forces)
+                    for (int i = 0; i < nb6; ++i) vnew += RT[(1 + i) * RS + lane] * GB[i];
+            }
+        } else
         if (lane < n) {
             // (parked: the solution columns wait in global memory, written by another wavefront -- coherent loads)
             vnew = parked ? ldg(RT + lane) : RT[lane];
@@ -1461,13 +1509,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             T *Sq = lds + ARB_UNI(lp.sa_q), *Sdq = lds + ARB_UNI(lp.sa_dq), *Sff = lds + ARB_UNI(lp.sa_ff);
             if (isub == 0 && two) {        // park world B's state
                 for (int i = lane; i < nq; i += WAVE) SBq[i] = qs[i];
-                SBdq[lane] = dqs[lane];
+                if (lane < RS) SBdq[lane] = dqs[lane];
                 for (int i = lane; i < ndol; i += WAVE) SBff[i] = FF[i];
             }
             WAVE_SYNC();
             const T *fq = isub == 0 ? Sq : SBq, *fdq = isub == 0 ? Sdq : SBdq, *fff = isub == 0 ? Sff : SBff;
             for (int i = lane; i < nq; i += WAVE) qs[i] = fq[i];
-            dqs[lane] = fdq[lane];
+            if (lane < RS) dqs[lane] = fdq[lane];
             for (int i = lane; i < ndol; i += WAVE) FF[i] = fff[i];
             WAVE_SYNC();
         }
@@ -1915,15 +1963,51 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     active = ((double)sd_d + (double)dsd * (double)dt < mp->cprox_d[c]);
                     // phase B works on world-axes columns about the origin of a tree's root body: store world -> contact
                     // frame 0 about the root of body 1's tree (the rows of another tree's dofs shift it, see there)
+                    if constexpr (BODYCOL) {
+                        // T_c, the contact's rows (w_z, v_x, v_y, v_z) of Ad(c0 <- world axes at o) -- o the origin of the pair's
+                        // reference body, a few centimetres from the contact point: [[Rx, 0], [px^ Rx, Rx]] with Rx = Rc^T,
+                        // px = -Rx (gc0 - o) -- as 4 x 6 in the block's first 24 slots; ZERO for a contact outside the active set,
+                        // whose rows and columns of Y' and entry of v' then come out zero by themselves (core.py:913-918)
+                        const V3<double> o = ld_v3(PD + 12 * mp->pair_ref[mp->cpair[c]] + 9);
+                        const M3<double> Rx = transpose(Rc);
+                        const M3<double> PR = hatmul(-mtv(Rc, gc0 - o), Rx);
+                        const double am = active ? 1. : 0.;
+                        T t24[24];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            t24[j] = (T)(am * Rx.a[6 + j]); t24[3 + j] = T(0);
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) { t24[6 * (1 + a) + j] = (T)(am * PR.a[3 * a + j]); t24[6 * (1 + a) + 3 + j] = (T)(am * Rx.a[3 * a + j]); }
+                        }
+                        if (ARB_DENSE_AP) { for (int i = 0; i < 24; ++i) keep(t24[i]); keep(sd); keep((int)active); }
+                        if (mine) {
+#pragma unroll
+                            for (int i = 0; i < 24; ++i) cd[i] = t24[i];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
+                        }
+                    } else {
                     const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
                     const M3<T> o_r1 = cvt_m3<T>(transpose(Rc));
-                    const V3<T> o_p1 = cvt_v3<T>(-mtv(Rc, gc0 - p0w)), o_g0 = cvt_v3<T>(gc0), o_g1 = cvt_v3<T>(gc1);
-                    if (ARB_DENSE_AP) { keep(o_r1); keep(o_p1); keep(o_g0); keep(o_g1); keep(sd); keep((int)active); }
+                    const V3<T> o_p1 = cvt_v3<T>(-mtv(Rc, gc0 - p0w));
+                    if (ARB_DENSE_AP) { keep(o_r1); keep(o_p1); keep(sd); keep((int)active); }
                     if (mine) {
                         st_m3(cd + CD_R1, o_r1); st_v3(cd + CD_P1, o_p1);
-                        st_v3(cd + CD_GC0, o_g0); st_v3(cd + CD_GC1, o_g1);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
+                    }
+                    }
+                    // inspect: the poses of the two contact frames H_gc0, H_gc1 (constraints.py:284-288), straight from here
+                    if (MODE == 1 && mine && step == 0 && dbg.c_frame != nullptr) {
+                        for (int f = 0; f < 2; ++f) {
+                            T *of = dbg.c_frame + ((w * nc + c) * 2 + f) * 16;
+                            const V3<double> gf = f ? gc1 : gc0;
+                            for (int i = 0; i < 3; ++i) {
+                                for (int j = 0; j < 3; ++j) of[4 * i + j] = (T)Rc.a[3 * i + j];
+                                of[4 * i + 3] = (T)(i == 0 ? gf.x : i == 1 ? gf.y : gf.z);
+                            }
+                            of[12] = of[13] = of[14] = T(0); of[15] = T(1);
+                        }
                     }
                 } else if (ct == ARB_CT_JOINTLIMITS) {
                     const T p0 = qd[mp->cdof[c]];
@@ -2625,7 +2709,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 WAVE_SYNC();                   // every lane is done with the staging area: it becomes XPR
                 // ... and with the joints' own columns SC: their space becomes RT = [rhs | rows of J'], zero before
                 // the constraint rows and the joint-limit selectors are written (entries >= ndof of a row stay zero)
-                if constexpr (!MFMA_ROWS) { for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0); }
+                // (body-space columns: six rows per pair of bodies, padded to whole slabs of four for phase D)
+                const int rt_rows = BODYCOL ? 4 * ((6 * ARB_UNI(mp->nbp) + 3) / 4) : ndol;
+                if constexpr (!MFMA_ROWS) { for (int i = lane; i < (1 + rt_rows) * RS; i += WAVE) RT[i] = T(0); }
                 if (lane < n) {
                     double *o = STG + XPR_STRIDE * lane;
 #pragma unroll
@@ -2795,19 +2881,28 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #pragma unroll
                             for (int j = 0; j < 9; ++j) x9[j] = xi[j];
                             asm volatile("" : "+v"(x9[0]), "+v"(x9[1]), "+v"(x9[2]), "+v"(x9[3]), "+v"(x9[4]), "+v"(x9[5]), "+v"(x9[6]), "+v"(x9[7]), "+v"(x9[8]));
+                            // (round 5: three chains of six fused multiply-adds and one addition per row -- 19 float64
+                            // instructions; written as sums of products, `tu += a.x * G0 + a.y * G1`, the front end's contraction
+                            // rule made 24 of them: a multiply, a fused multiply-add and an addition per pair)
+                            double tp = 0.;
 #pragma unroll
                             for (int j = 0; j < 3; ++j) {
                                 const D2 a = x9[j], pq = x9[3 + j], rq = x9[6 + j];
-                                tu += a.x * Gk[2 * j] + a.y * Gk[2 * j + 1];
-                                td += pq.x * Xk[2 * j] + pq.y * Xk[2 * j + 1] + rq.x * dXk[2 * j] + rq.y * dXk[2 * j + 1];
+                                tu = fma(a.x, Gk[2 * j], tu); tu = fma(a.y, Gk[2 * j + 1], tu);
+                                tp = fma(pq.x, Xk[2 * j], tp); tp = fma(pq.y, Xk[2 * j + 1], tp);
+                                td = fma(rq.x, dXk[2 * j], td); td = fma(rq.y, dXk[2 * j + 1], td);
                             }
+                            td += tp;
                         } else {          // (float64 kernels: their tile takes two registers per row, no room for nine reads in flight)
+                            double tp = 0.;
 #pragma unroll
                             for (int j = 0; j < 3; ++j) {
                                 const D2 a = xi[j], pq = xi[3 + j], rq = xi[6 + j];
-                                tu += a.x * Gk[2 * j] + a.y * Gk[2 * j + 1];
-                                td += pq.x * Xk[2 * j] + pq.y * Xk[2 * j + 1] + rq.x * dXk[2 * j] + rq.y * dXk[2 * j + 1];
+                                tu = fma(a.x, Gk[2 * j], tu); tu = fma(a.y, Gk[2 * j + 1], tu);
+                                tp = fma(pq.x, Xk[2 * j], tp); tp = fma(pq.y, Xk[2 * j + 1], tp);
+                                td = fma(rq.x, dXk[2 * j], td); td = fma(rq.y, dXk[2 * j + 1], td);
                             }
+                            td += tp;
                         }
                         const ZT val = (ZT)((i <= e_k) ? tu : td);
                         Z[i] = (((i < 32 ? rel_lo : rel_hi) >> (i & 31)) & 1u) ? val : ZT(0);
@@ -2818,6 +2913,24 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             }
             // ---- constraint rows: s_k [Ad(c0<-g) X_k] with s_k = [k above body 1] - [k above body 0] --
             ARB_BSTAMP(6);
+            if constexpr (BODYCOL) { if (do_constraints) {
+                // ---- the six rows of every pair's relative Jacobian J_p = s_k [X_k moved to the pair's reference point]:
+                // world axes about the origin o of the pair's reference body (the class has one tree: p0k is its root)
+                const unsigned long long actm = __ballot(lane < nc && CD[(lane < nc ? lane : 0) * CD_STRIDE + CD_ACTIVE] != T(0));
+                const int nbp = ARB_UNI(mp->nbp);
+                for (int p = 0; p < nbp; ++p) {
+                    if ((actm & mp->pair_cmask[p]) == 0ull) continue;      // no contact of the pair is active: the rows stay zero
+                    const double sgn = (double)((mp->pair_a1[p] >> lane) & 1ull) - (double)((mp->pair_a0[p] >> lane) & 1ull);
+                    const V3<double> o = ld_v3(PD + 12 * mp->pair_ref[p] + 9) - p0k;
+                    const V3<double> xw = v3<double>(Xk[0], Xk[1], Xk[2]);
+                    const V3<double> jv = v3<double>(Xk[3], Xk[4], Xk[5]) + cross(xw, o);       // velocity of the point o
+                    if (lane < n) {
+                        T *row = RT + (1 + 6 * p) * RS + lane;
+                        row[0] = (T)(sgn * xw.x); row[RS] = (T)(sgn * xw.y); row[2 * RS] = (T)(sgn * xw.z);
+                        row[3 * RS] = (T)(sgn * jv.x); row[4 * RS] = (T)(sgn * jv.y); row[5 * RS] = (T)(sgn * jv.z);
+                    }
+                }
+            } } else
             if (do_constraints) {
                 for (int c = 0; c < nc; ++c) {
                     const int *ci = CI + CI_STRIDE * c;
@@ -2929,28 +3042,21 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             }
             if (zmode != 0) return;
             if (dbg.gforce0 != nullptr && lane < n) dbg.gforce0[w * n + lane] = gf0;
+            if (BODYCOL && dbg.c_jac != nullptr && lane < n) {
+                // (body-space columns: J'_c = T_c J_p, formed here for the output only)
+                for (int i = 0; i < ndol; ++i) {
+                    const int c = i >> 2, pp = mp->cpair[c];
+                    T acc = T(0);
+                    for (int j = 0; j < 6; ++j) acc += CD[c * CD_STRIDE + 6 * (i & 3) + j] * RT[(1 + 6 * pp + j) * RS + lane];
+                    dbg.c_jac[(w * ndol + i) * n + lane] = do_constraints ? acc : T(0);
+                }
+            } else
             if (dbg.c_jac != nullptr && lane < n)
                 for (int i = 0; i < ndol; ++i) dbg.c_jac[(w * ndol + i) * n + lane] = do_constraints ? RT[(1 + i) * RS + lane] : T(0);
             if (lane < nc) {
                 const T *cd = CD + lane * CD_STRIDE;
                 if (dbg.c_sdist != nullptr) dbg.c_sdist[w * nc + lane] = do_constraints ? cd[CD_SDIST] : T(0);
                 if (dbg.c_active != nullptr) dbg.c_active[w * nc + lane] = (do_constraints && cd[CD_ACTIVE] != T(0)) ? 1 : 0;
-                if (dbg.c_frame != nullptr && do_constraints && mp->ctype[lane] == ARB_CT_SOFTFINGER) {
-                    for (int f = 0; f < 2; ++f) {
-                        T *o = dbg.c_frame + ((w * nc + lane) * 2 + f) * 16;
-                        // rotation of both frames: Rc = R_g1 R1^T (R1 = Rc^T R_g1; ground: R1 = Rc^T)
-                        const int b1 = mp->cbody[lane];
-                        for (int i = 0; i < 3; ++i) {
-                            for (int j = 0; j < 3; ++j) {
-                                double acc = 0.;
-                                acc = (double)cd[CD_R1 + 3 * j + i];          // CD_R1 holds Rc^T
-                                o[4 * i + j] = (T)acc;
-                            }
-                            o[4 * i + 3] = cd[(f ? CD_GC1 : CD_GC0) + i];
-                        }
-                        o[12] = o[13] = o[14] = T(0); o[15] = T(1);
-                    }
-                }
             }
         }
         // warm-started constraint forces enter the right-hand side          core.py:921-924
@@ -2963,7 +3069,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         ARB_STAMP(3);
         if (lane < RS) RT[lane] = (lane < n) ? rhs : T(0);
         WAVE_SYNC();
-        const int ncols = do_constraints ? mp->ncols : n + 1;
+        const int ncols = do_constraints ? (BODYCOL ? mp->ncols_b : mp->ncols) : n + 1;
         // Late rhs: 64 dofs, no constraints, one register set (the host's choice for that case): every lane holds a
         // column of Z, the rhs column waits in LDS (row 0 of RT) until the first pivot (dof n-1) has been taken;
         // lane n-1 -- whose own column is finished by that pivot -- applies the pivot to the rhs instead and carries
@@ -3243,7 +3349,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         ARB_CSTAMP(6);
         if (do_constraints) {
             // [v | Y'] = J' [Y rhs | Y J'^T]                                core.py:925-927
+            // (body-space columns: [v_b | Y_b] = J_p [Y rhs | Y J_p^T], 6 nbp rows in slabs of four; Y' and v' follow below)
             typedef T V4 __attribute__((ext_vector_type(4)));
+            const int nb6 = BODYCOL ? 6 * ARB_UNI(mp->nbp) : 0;
+            const int nslab = BODYCOL ? (nb6 + 3) / 4 : nc;
+            T *const OV = BODYCOL ? lds + ARB_UNI(ARB_LAY().vb) : VV, *const OA = BODYCOL ? lds + ARB_UNI(ARB_LAY().yb) : AM;
+            const int ost = BODYCOL ? nb6 : ndol;
+            bool anyact = false;
+            if constexpr (BODYCOL) anyact = __ballot(lane < nc && CD[(lane < nc ? lane : 0) * CD_STRIDE + CD_ACTIVE] != T(0)) != 0ull;
 #if ARB_PHASE_D_MFMA
             if constexpr (std::is_same<T, float>::value && !ELIM64) {
                 // On the matrix cores (float32): the four rows of one constraint are the four accumulator registers of
@@ -3254,10 +3367,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 // back to back (NMAX x 8 cycles per active constraint instead of 4 x (NMAX/2 v_pk_fma + NMAX/4 reads)).
                 typedef float F4 __attribute__((ext_vector_type(4)));
                 const int lq = lane & 3;
-                for (int c = 0; c < nc; ++c) {
+                for (int c = 0; c < nslab; ++c) {
                     F4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
                     // the rows of a constraint outside the active set are zero (phase B): nothing to multiply
-                    if (CD[c * CD_STRIDE + CD_ACTIVE] != T(0)) {
+                    if (BODYCOL ? anyact : (CD[c * CD_STRIDE + CD_ACTIVE] != T(0))) {
                         const F4 *jr4 = reinterpret_cast<const F4 *>(RT + (1 + 4 * c + lq) * RS);
                         // four partial sums (r mod 4), added pairwise at the end: four independent accumulator chains in
                         // the matrix pipe, and the rounding of a 44-term float32 dot product stays where the vector-ALU
@@ -3297,8 +3410,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int idx = 4 * c + i;
-                        if (lane == n) VV[idx] = out[i];
-                        else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = out[i];
+                        if (BODYCOL && idx >= ost) continue;
+                        if (lane == n) OV[idx] = out[i];
+                        else if (lane > n && lane < ncols) OA[idx * ost + (lane - n - 1)] = out[i];
                         if (NSETS == 2) {
                             if (WAVE + lane == n) VV[idx] = out2[i];
                             else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = out2[i];
@@ -3307,13 +3421,13 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 }
             } else
 #endif
-            for (int idx = 0; idx < ndol; ++idx) {
+            for (int idx = 0; idx < ost; ++idx) {
                 // row idx of J' (zero beyond ndof), read as 16/32-byte LDS vectors (wave-uniform address)
                 const V4 *jr4 = reinterpret_cast<const V4 *>(RT + (1 + idx) * RS);
                 ZT acc = ZT(0), acc2 = ZT(0);
                 // the rows of a constraint outside the active set are zero (phase B): nothing to multiply
                 // (free fall: the whole loop collapses to the stores)
-                if (CD[(idx >> 2) * CD_STRIDE + CD_ACTIVE] != T(0)) {
+                if (BODYCOL ? anyact : (CD[(idx >> 2) * CD_STRIDE + CD_ACTIVE] != T(0))) {
                     // (forest worlds: the groups of four start at the first dof of the constraint's copy, (j * fn) mod 4 = rot
                     // elements into the row, as they do for the copy alone; what lies before belongs to other copies and is
                     // exactly zero in this row.  Bit for bit the sums of one world per wavefront; round 4)
@@ -3346,14 +3460,56 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                         });
                     }
                 }
-                if (lane == n) VV[idx] = (T)acc;
-                else if (lane > n && lane < ncols) AM[idx * ndol + (lane - n - 1)] = (T)acc;
+                if (lane == n) OV[idx] = (T)acc;
+                else if (lane > n && lane < ncols) OA[idx * ost + (lane - n - 1)] = (T)acc;
                 if (NSETS == 2) {
                     if (WAVE + lane == n) VV[idx] = (T)acc2;
                     else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = (T)acc2;
                 }
             }
             WAVE_SYNC();
+            if constexpr (BODYCOL) {
+                // ---- constraint space from body space: Y' = T Y_b T^T, v' = T v_b with T = blockdiag-by-pair of the contacts'
+                // 4 x 6 transforms (zero for contacts outside the active set).  Two passes through LDS:
+                //   W[i][col] = sum_j Y_b[i][6 p(col) + j] T_c(col)[col % 4][j]           6 nbp x ndol entries, 6 terms each
+                //   Y'[row][col] = sum_i T_c(row)[row % 4][i] W[6 p(row) + i][col]       ndol x ndol entries, 6 terms each
+                // (human36 with eight contacts: 6 + 16 entries per lane instead of 20 more matrix-core slabs and a second
+                // column set in phase C)
+                T *const WS = lds + ARB_UNI(ARB_LAY().wst);
+                for (int e = lane; e < nb6 * ndol; e += WAVE) {
+                    const int i = e / ndol, col = e - i * ndol, c2 = col >> 2, p2 = mp->cpair[c2];
+                    const T *tr = CD + c2 * CD_STRIDE + 6 * (col & 3), *yb = OA + i * nb6 + 6 * p2;
+                    // (float64 sums: the products of two float32 numbers are exact there, each entry is rounded once)
+                    double acc = 0.;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc += (double)yb[j] * (double)tr[j];
+                    WS[e] = (T)acc;
+                }
+                if (lane < ndol) {
+                    const int c2 = lane >> 2, p2 = mp->cpair[c2];
+                    const T *tr = CD + c2 * CD_STRIDE + 6 * (lane & 3);
+                    double acc = 0.;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc += (double)tr[j] * (double)OV[6 * p2 + j];
+                    VV[lane] = (T)acc;
+                }
+                WAVE_SYNC();
+                const int nd4 = ndol >> 2;          // (ndol = 4 nc)
+                for (int e = lane; e < ndol * nd4; e += WAVE) {
+                    const int row = e / nd4, c4 = e - row * nd4, c2 = row >> 2, p2 = mp->cpair[c2];
+                    const T *tr = CD + c2 * CD_STRIDE + 6 * (row & 3);
+                    double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const V4 w4 = *reinterpret_cast<const V4 *>(WS + (6 * p2 + i) * ndol + 4 * c4);
+                        const double t = (double)tr[i];
+                        a0 += t * (double)w4.x; a1 += t * (double)w4.y; a2 += t * (double)w4.z; a3 += t * (double)w4.w;
+                    }
+                    const V4 acc = {(T)a0, (T)a1, (T)a2, (T)a3};
+                    *reinterpret_cast<V4 *>(AM + row * ndol + 4 * c4) = acc;
+                }
+                WAVE_SYNC();
+            }
         }
         // solution columns -> LDS (row r of RT := column r of [Y rhs | Y J'^T])
         WAVE_SYNC();
@@ -3478,7 +3634,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 const long wh = g0 + h;
                 if (h != myh) {
                     for (int i = lane; i < nq; i += WAVE) qs[i] = ldg(gq + wh * nq + i);
-                    dqs[lane] = (lane < n) ? ldg(gdq + wh * n + lane) : T(0);
+                    if (lane < RS) dqs[lane] = (lane < n) ? ldg(gdq + wh * n + lane) : T(0);
                     WAVE_SYNC();
                 }
                 const T *fh = (h == 0) ? FFp[0] : (h == 1) ? FFp[1] : (h == 2) ? FFp[2] : FFp[3];
@@ -3932,9 +4088,20 @@ template int launch_one<float, ARB_PART_NMAX, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(fl
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 4, 2>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 5, 2>(ARB_LAUNCH_ONE_ARGS(float));
-#elif ARB_PART_SPEC == 2       /* float32, two column sets (eight contacts) */
-template int launch_one<float, ARB_PART_NMAX, 2, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));
-template int launch_one<float, ARB_PART_NMAX, 2, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));
+#elif ARB_PART_SPEC == 5       /* float32, body-space constraint columns (FEAT bit 16): plain / torques / every input, two and three waves; inspect */
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 20, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 21, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 20, 2>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 21, 2>(ARB_LAUNCH_ONE_ARGS(float));
+#elif ARB_PART_SPEC == 6
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 19, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 19, 2>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 1, 19, 0>(ARB_LAUNCH_ONE_ARGS(float));
+#elif ARB_PART_SPEC == 7       /* float64, body-space constraint columns */
+template int launch_one<double, ARB_PART_NMAX, 1, 0, 20, 0>(ARB_LAUNCH_ONE_ARGS(double));
+template int launch_one<double, ARB_PART_NMAX, 1, 0, 21, 0>(ARB_LAUNCH_ONE_ARGS(double));
+template int launch_one<double, ARB_PART_NMAX, 1, 0, 19, 0>(ARB_LAUNCH_ONE_ARGS(double));
+template int launch_one<double, ARB_PART_NMAX, 1, 1, 19, 0>(ARB_LAUNCH_ONE_ARGS(double));
 #elif ARB_PART_SPEC == 3       /* float64, one column set */
 template int launch_one<double, ARB_PART_NMAX, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(double));
 template int launch_one<double, ARB_PART_NMAX, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(double));
@@ -3998,8 +4165,17 @@ ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
     extern template int launch_one<float, NM, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<float, NM, 1, 0, 4, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
     extern template int launch_one<float, NM, 1, 0, 5, 2>(ARB_LAUNCH_ONE_ARGS(float));  \
-    extern template int launch_one<float, NM, 2, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
-    extern template int launch_one<float, NM, 2, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 20, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 21, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 20, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 21, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 19, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 19, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 1, 19, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<double, NM, 1, 0, 20, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
+    extern template int launch_one<double, NM, 1, 0, 21, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
+    extern template int launch_one<double, NM, 1, 0, 19, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
+    extern template int launch_one<double, NM, 1, 1, 19, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
     extern template int launch_one<double, NM, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
     extern template int launch_one<double, NM, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(double)); \
     extern template int launch_one<float, NM, 1, 0, 8, 0>(ARB_LAUNCH_ONE_ARGS(float));  \
@@ -4061,6 +4237,10 @@ struct arb_model {
     bool spec_ok = false;          // four constraints per column set, all enabled SoftFingerContacts of plane / sphere pairs, no PD controller, no viscosity,
                                    // one world per wavefront, tiles 44 / 48: the specialised kernels (FEAT bit 4)
     bool spec0_ok = false;         // no constraints, otherwise the same class: the specialised kernels of FEAT bit 8
+    bool bodycols = false;         // the same class with more contacts than one column set holds, on few pairs of bodies: body-space
+                                   // constraint columns (FEAT bit 16), ONE column set -- human36 with the reference's eight contact points
+    bool bodycols_default = false; // ... chosen without being asked (ARB_STEP_BODY_COLUMNS): when they save the second column set
+    Layout lfb, lfb3, ldb;         // ... and their LDS layouts: float32 two-wave / three-wave, float64
     bool rdv_ok = false;           // ... at most FOUR, and the three-wave layout holds three more systems: the rendezvous build (CM = 4)
     int *status_host = nullptr;    // mapped pinned words the kernels raise: [0] a work-queue wait expired (ARB_ERR_STALLED), [1] ARB_WARN_* bits
     Knobs kn;                      // development / test knobs (arb_hook_set_knob)
@@ -4124,21 +4304,23 @@ static std::vector<double> h12(const double *H16, int count) {
 // (the table restarts at every root, which keeps the trees of a wavefront -- the copies of a forest -- apart; the DPP
 // scan of the larger trees runs across all bodies of the wavefront)
 static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
-static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass, int bd_stride = BD_STRIDE) {
+// (nbp > 0: the layout of the BODYCOL kernels -- behind Y' the body-space admittance, velocity and the half product W)
+static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass, int bd_stride = BD_STRIDE, int nbp = 0) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int tb = lds_scan(nb, rs) ? al(nb * (two_pass ? TB_STRIDE : TB_STRIDE1) * elems_per_double) : 0;
-    return std::max(std::max(std::max(al(nb * bd_stride), al(XPR_STRIDE * rs * elems_per_double)), tb), al(std::max(ndol * ndol, 4)));
+    const int am = al(std::max(ndol * ndol, 4)) + (nbp > 0 ? al(36 * nbp * nbp) + al(6 * nbp) + al(6 * nbp * ndol) : 0);
+    return std::max(std::max(std::max(al(nb * bd_stride), al(XPR_STRIDE * rs * elems_per_double)), tb), am);
 }
 
 static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems, bool two_pass = false,
-                          bool pack = false) {
+                          bool pack = false, int nbp = 0) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
     L.q = o; o += al(nq);
-    L.dq = o; o += WAVE;
+    L.dq = o; o += al(rs);                           // (one element per tile row; 64 until round 5)
     L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
-    L.rt = o; L.sc = o; o += std::max(1 + ndol, 12) * rs;
+    L.rt = o; L.sc = o; o += std::max(1 + (nbp > 0 ? 4 * ((6 * nbp + 3) / 4) : ndol), 12) * rs;
     L.cd = o; o += al(nc * CD_STRIDE);               // (nothing without constraints: every access is inside a loop over them)
     L.vv = o; o += al(std::max(ndol, 4));
     L.ff = o; o += al(std::max(ndol, 4));
@@ -4151,15 +4333,16 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     // contacts layout is 12 800 B with this line, 12 880 B with 64 elements here)
     L.work = o; L.qd = o; o += std::max(44, al(rs));
     {
-        const int words = CI_STRIDE * std::max(nc, 1);                      // int32 words, see CI_STRIDE
+        const int words = CI_STRIDE * (nbp > 0 ? 1 : std::max(nc, 1));      // int32 words, see CI_STRIDE (BODYCOL kernels: unused)
         L.ci = o; o += al(elems_per_double == 2 ? words : (words + 1) / 2);     // (float: one word per element; double: two)
     }
     // the per-body blocks (and what takes their place) come last: the inspect kernels' larger blocks (BD_STRIDE_INSPECT:
     // the gravity wrench, 6 elements per body more -- 3 KB for a float64 snake-64, the difference between four and five
     // wavefronts per CU for the step kernels) then only lengthen the allocation, every other offset is shared
     L.bd = o; L.am = o;
-    const int bd_step = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass);
-    const int bd_insp = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE_INSPECT);
+    const int bd_step = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE, nbp);
+    const int bd_insp = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE_INSPECT, nbp);
+    L.yb = L.am + al(std::max(ndol * ndol, 4)); L.vb = L.yb + al(36 * nbp * nbp); L.wst = L.vb + al(6 * nbp);
     L.total_inspect = o + bd_insp;
     o += bd_step;
     L.sa_q = L.sa_dq = L.sa_am = L.sa_cd = L.sa_vv = L.sa_ff = L.sa_ff0 = L.sa_rt = L.sb_q = L.sb_dq = L.sb_ff = 0;
@@ -4171,9 +4354,9 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
         L.sa_ff = o; o += al(std::max(ndol, 4));
         L.sa_ff0 = o; o += al(std::max(ndol, 4));
         L.sa_q = o; o += al(nq);
-        L.sa_dq = o; o += WAVE;
+        L.sa_dq = o; o += al(rs);
         L.sb_q = o; o += al(nq);
-        L.sb_dq = o; o += WAVE;
+        L.sb_dq = o; o += al(rs);
         L.sb_ff = o; o += al(std::max(ndol, 4));
     }
     L.total = o;
@@ -4457,7 +4640,7 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     M->packable = nc >= 1 && nc <= 8 && fk == 1;      // (a forest's copies are retired one by one, which the packed build does not do)
     for (int c = 0; c < nc; ++c)
         M->packable = M->packable && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_eps[3 * c] == 1. && d->c_eps[3 * c + 1] == 1. && d->c_eps[3 * c + 2] == 1.;
-    M->spec_ok = ARB_WITH_SPEC && nc == 4 * M->nsets && fk == 1 && M->nmax >= 44 && M->nmax <= 48;
+    M->spec_ok = ARB_WITH_SPEC && nc == 4 && M->nsets == 1 && fk == 1 && M->nmax >= 44 && M->nmax <= 48;
     for (int c = 0; c < nc; ++c)
         M->spec_ok = M->spec_ok && d->ctype[c] == ARB_CT_SOFTFINGER && d->c_enabled[c] != 0 && d->c_geom[c] == ARB_CG_PLANE_SPHERE;
     M->spec0_ok = ARB_WITH_SPEC && nc == 0 && fk == 1 && M->nsets == 1 && M->nmax >= 44 && M->nmax <= 48 &&
@@ -4467,6 +4650,36 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     M->spec_ok = M->spec_ok && lds_scan(nb, M->nmax);                                         // (a small tree: phase B on the prefix table)
     M->spec_ok = M->spec_ok && d->pd_kp == nullptr;                                           // (no PD controller in the model,
     for (int i = 0; i < 36 * nb && M->spec_ok; ++i) M->spec_ok = d->visc[i] == 0.0;           //  no joint viscosity)
+    // Body-space constraint columns (FEAT bit 16): the same class -- enabled plane / sphere SoftFingerContacts only, no PD
+    // controller, no viscosity, one small shallow tree -- with more contacts than one column set holds (ndof + 1 + 4 nc > 64) on
+    // so few pairs of bodies that six columns per pair fit (ndof + 1 + 6 nbp <= 64)
+    int bc_nbp = 0, bc_b1[ARB_MAXPAIR], bc_b0[ARB_MAXPAIR];
+    std::vector<int> bc_cpair(std::max(nc, 1), 0);
+    {
+        bool ok = ARB_WITH_SPEC && fk == 1 && nc > 0 && M->nmax >= 44 && M->nmax <= 48 && maxdepth < ARB_JUMP_DEPTH &&
+                  lds_scan(nb, M->nmax) && d->pd_kp == nullptr;
+        for (int i = 0; i < 36 * nb && ok; ++i) ok = d->visc[i] == 0.0;
+        int nroots = 0;
+        for (int b = 0; b < nb; ++b) nroots += d->parent[b] < 0;
+        ok = ok && nroots == 1;
+        for (int c = 0; c < nc && ok; ++c) {
+            ok = d->ctype[c] == ARB_CT_SOFTFINGER && d->c_enabled[c] != 0 && d->c_geom[c] == ARB_CG_PLANE_SPHERE &&
+                 (d->c_body[c] >= 0 || d->c_body0[c] >= 0);
+            int p = 0;
+            while (p < bc_nbp && !(bc_b1[p] == d->c_body[c] && bc_b0[p] == d->c_body0[c])) ++p;
+            if (p == bc_nbp) {
+                if (bc_nbp == ARB_MAXPAIR) { ok = false; break; }
+                bc_b1[p] = d->c_body[c]; bc_b0[p] = d->c_body0[c]; ++bc_nbp;
+            }
+            bc_cpair[c] = p;
+        }
+        M->bodycols = ok && n + 1 + 6 * bc_nbp <= WAVE;
+        // by default where they save the second column set; ARB_STEP_BODY_COLUMNS asks for them wherever the model qualifies
+        M->bodycols_default = M->bodycols && M->nsets == 2;
+#ifdef ARB_DEVELOPMENT
+        if (getenv("ARB_BODYCOL_ALL")) M->bodycols_default = M->bodycols;
+#endif
+    }
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) {
         g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err);
@@ -4503,6 +4716,23 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     }
     M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
+    if (M->bodycols) {
+        int tb;
+        M->lfb = M->df.layb = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tb, false, false, bc_nbp);
+        M->lfb3 = M->df.layb3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tb, true, false, bc_nbp);
+        M->ldb = M->dd.layb = M->dd.layb3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tb, false, false, bc_nbp);
+        auto fillp = [&](auto &dm) {
+            dm.nbp = bc_nbp; dm.ncols_b = n + 1 + 6 * bc_nbp;
+            for (int p = 0; p < bc_nbp; ++p) {
+                dm.pair_ref[p] = bc_b1[p] >= 0 ? bc_b1[p] : bc_b0[p];
+                dm.pair_a1[p] = bc_b1[p] >= 0 ? anc[bc_b1[p]] : 0ull;
+                dm.pair_a0[p] = bc_b0[p] >= 0 ? anc[bc_b0[p]] : 0ull;
+                dm.pair_cmask[p] = 0ull;
+            }
+            for (int c = 0; c < nc; ++c) { dm.cpair[c] = bc_cpair[c]; dm.pair_cmask[bc_cpair[c]] |= 1ull << c; }
+        };
+        fillp(M->df); fillp(M->dd);
+    }
     {
         // one blob per precision
         void *pf = nullptr, *pd = nullptr;
@@ -4661,16 +4891,16 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
 // every other model has the two-wave build only)?  The builds are bit-identical (-ffp-contract=on): a pure performance
 // decision, also reported by arb_step_plan.
 struct BuildChoice { bool w3 = false, pack = false, rdv = false; long slots2 = 0, slots3 = 0, slotsp = 0; };
-static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nsteps, unsigned flags) {
+static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nsteps, unsigned flags, bool bodyc = false) {
     BuildChoice bc;
     // (tiles of 44 and 48 rows.  The 16- and 32-row kernels use ~100 VGPRs less: their two-wave build has no spills and
     // measured faster than a three-wave build at every batch size -- simplearm, one world per wavefront: 101 against
     // 60 M world-steps/s; its forest of 10: 494 against 389 M at 65 536 worlds --, so they have no other)
-    if (!(M->nsets == 1 && M->nmax >= 44 && M->nmax <= 48)) return bc;
+    if (!((M->nsets == 1 || bodyc) && M->nmax >= 44 && M->nmax <= 48)) return bc;
     static thread_local int cus_dev = -1, cus = 0;
     if (cus_dev != M->device) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device); cus_dev = M->device; }
     const long pad = std::max(0, M->kn.lds_pad);
-    const long lds2 = (long)M->lf.total * 4 + pad, lds3 = (long)M->lf3.total * 4 + pad;
+    const long lds2 = (long)(bodyc ? M->lfb : M->lf).total * 4 + pad, lds3 = (long)(bodyc ? M->lfb3 : M->lf3).total * 4 + pad;
     const long s2 = (long)cus * slots_per_cu(2, lds2), s3 = (long)cus * slots_per_cu(3, lds3);
     bc.slots2 = s2; bc.slots3 = s3;
     // Two or three waves per SIMD?  Three when the batch fills the extra wave slots.  ARB_STEP_WAVES2 / ARB_STEP_WAVES3
@@ -4691,7 +4921,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     if (force == 3) bc.w3 = true;
     // Rendezvous build (four worlds per wavefront in the sweeps, CM = 4): multi-step launches of models that qualify.
     // The knob "force_rdv" = 0|1 overrides (development).
-    if (ARB_WITH_RDV && M->rdv_ok && noopt && nsteps >= 2 && !(flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3 | ARB_STEP_STATIC_WORLDS))) {
+    if (ARB_WITH_RDV && M->rdv_ok && !bodyc && noopt && nsteps >= 2 && !(flags & (ARB_STEP_WAVES2 | ARB_STEP_WAVES3 | ARB_STEP_STATIC_WORLDS))) {
         bc.rdv = ARB_RDV_DEFAULT != 0 && 10 * nw >= 11 * s3;
         const int fr = M->kn.force_rdv;
         if (fr == 0) bc.rdv = false;
@@ -4702,7 +4932,7 @@ static BuildChoice choose_build(const arb_model *M, bool noopt, long nw, int nst
     // eight wavefronts per CU, and a batch large enough that pairs of worlds fill and balance the wave slots (measured,
     // three-wave / packed: 4096 worlds 18.2 / 16.8, 8192: 19.3 / 19.4, 16384: 19.6 / 20.0, 65536: 20.0 / 20.4).
     // The knob "force_pack" = 0|1 overrides the batch-size rule (development).
-    if (ARB_ALL_VARIANTS && M->packable && noopt && M->lfp.lscan) {
+    if (ARB_ALL_VARIANTS && M->packable && !bodyc && noopt && M->lfp.lscan) {
         const long ldsp = (long)M->lfp.total * 4 + pad;
         const long sp = (long)cus * slots_per_cu(2, ldsp);
         bc.slotsp = sp;
@@ -4731,7 +4961,12 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // (the kernels only look at ARB_STEP_SKIP_CONSTRAINTS; the other flags are for the host)
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
                       !(M->n == WAVE && M->nc == 0);          // (the late-rhs case is handled by the vector-ALU elimination)
-    const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma) ? choose_build(M, noopt, nw, nsteps, flags) : BuildChoice();
+    // body-space constraint columns (FEAT bit 16): every launch of a model of that class -- step, rollout, inspect -- except the split
+    // execution, the matrix-core elimination and ARB_STEP_GENERAL_KERNELS, which run the general kernels on two column sets
+    // (equal to rounding, not bit for bit: Y' is formed as T (J_p Y J_p^T) T^T instead of J' Y J'^T)
+    const bool bodyc = ARB_WITH_SPEC && M->bodycols && (M->bodycols_default || (flags & ARB_STEP_BODY_COLUMNS)) && !mfma && sio.mode == 0 &&
+                       !(flags & (ARB_STEP_GENERAL_KERNELS | ARB_STEP_SKIP_CONSTRAINTS));
+    const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma) ? choose_build(M, noopt, nw, nsteps, flags, bodyc) : BuildChoice();
     // (the packed and rendezvous builds -- libarbstep_variants.so -- know neither torque sequences nor the running cost)
     const bool seq = ext_stride != 0 || cost.out != nullptr;
     const bool w3 = bc.w3, pack = bc.pack && !seq, rdv = bc.rdv && !seq && cf != nullptr && nw * (long)nsteps < (1l << 30);
@@ -4750,13 +4985,21 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #define ARB_SPEC_CASE2(NM)                                                                                             \
         if constexpr (MODE == 0 && NM >= 44 && NM <= 48) {                                                             \
             if (spec && M->nsets == 1 && !std::is_same<T, float>::value) return plain ? ONE(NM, 1, 4) : ONE(NM, 1, 5); \
-            if constexpr (std::is_same<T, float>::value) {                                                             \
-                if (spec && M->nsets == 2) return plain ? ONE(NM, 2, 4) : ONE(NM, 2, 5);                               \
+        }
+#define ARB_BODYC_CASE(NM)                                                                                             \
+        if constexpr (NM >= 44 && NM <= 48) {                                                                          \
+            if (bodyc) {                                                                                               \
+                if constexpr (MODE == 1) return ONE(NM, 1, 19);                                                        \
+                else if constexpr (std::is_same<T, float>::value) {                                                    \
+                    if (w3) return plain ? ONE_(NM, 1, 20, 2) : noopt ? ONE_(NM, 1, 21, 2) : ONE_(NM, 1, 19, 2);       \
+                    return plain ? ONE(NM, 1, 20) : noopt ? ONE(NM, 1, 21) : ONE(NM, 1, 19);                           \
+                } else return plain ? ONE(NM, 1, 20) : noopt ? ONE(NM, 1, 21) : ONE(NM, 1, 19);                        \
             }                                                                                                          \
         }
 #else
 #define ARB_SPEC_CASE(NM) (void)spec; (void)spec0;
 #define ARB_SPEC_CASE2(NM)
+#define ARB_BODYC_CASE(NM) (void)bodyc;
 #endif
 #if ARB_WITH_RDV
 #define ARB_RDV_CASE(NM) if (rdv) return plain ? ONE_(NM, 1, 0, 4) : ONE_(NM, 1, 1, 4);
@@ -4770,12 +5013,20 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #endif
 // (the instantiation must fit the model: a kernel with the wrong tile, column sets or model class computes on, silently wrong --
 // round 4's first launch table sent an 8-contact model to the one-set specialised kernel; checked at every launch since)
-#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS))) && (!((FT) & 8) || (M->spec0_ok && M->nc == 0))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st, M->kn, ext_stride, pd_stride, cost))
+#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && (((FT) & 16) ? (M->bodycols && (NS) == 1) : (M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS))))) && (!((FT) & 8) || (M->spec0_ok && M->nc == 0))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, ((FT) & 16) ? ((CMV) == 2 ? M->lfb3 : (std::is_same<T, float>::value ? M->lfb : M->ldb)) : (CMV) == 3 ? M->lfp : ((CMV) == 2 || (CMV) == 4) ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st, M->kn, ext_stride, pd_stride, cost))
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also
     // two column sets, the inspect kernel and the optional inputs)
-#if ARB_QUICK == 3      /* the headline kernels only: the specialised float32 kernels, plain inputs, two and three waves (~1 min) */
+#if ARB_QUICK == 4      /* development: the body-space-column kernels of the 44-row tile (float32 two / three waves + inspect, float64) */
+    if (M->nmax == 44 && bodyc) {
+        if constexpr (MODE == 1) { if constexpr (std::is_same<T, float>::value) return ONE(44, 1, 19); else return ARB_ERR_UNSUPPORTED; }
+        else if constexpr (std::is_same<T, float>::value) { if (plain) return w3 ? ONE_(44, 1, 20, 2) : ONE(44, 1, 20); }
+        else { if (plain) return ONE(44, 1, 20); }
+    }
+    (void)spec; (void)spec0;
+    return ARB_ERR_UNSUPPORTED;
+#elif ARB_QUICK == 3      /* the headline kernels only: the specialised float32 kernels, plain inputs, two and three waves (~1 min) */
     if constexpr (std::is_same<T, float>::value && MODE == 0) {
         if (M->nmax == 44 && M->nsets == 1 && spec && plain) return w3 ? ONE_(44, 1, 4, 2) : ONE_(44, 1, 4, 0);
     }
@@ -4817,6 +5068,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
         if constexpr (MODE == 0 && std::is_same<T, float>::value) {                                    \
             if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 3, 1) : ONE_(NM, 1, 3, 1);                  \
         }                                                                                              \
+        ARB_BODYC_CASE(NM)                                                                             \
         if constexpr (MODE == 0 && std::is_same<T, float>::value && NM >= 44 && NM <= 48) {            \
             ARB_RDV_CASE(NM)                                                                           \
             ARB_PACK_CASE(NM)                                                                          \
@@ -5015,12 +5267,14 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     const bool noopt = optional_inputs <= 1 && !split && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
     const bool mfma = dtype == ARB_F32 && (flags & ARB_STEP_MFMA_ELIM) && !(M->n == WAVE && M->nc == 0);
     BuildChoice bc;
-    if (dtype == ARB_F32 && !mfma) bc = choose_build(M, noopt, (long)nworlds, split ? 1 : nsteps, flags);
+    const bool bodyc = ARB_WITH_SPEC && M->bodycols && (M->bodycols_default || (flags & ARB_STEP_BODY_COLUMNS)) && !mfma && !split &&
+                       !(flags & (ARB_STEP_GENERAL_KERNELS | ARB_STEP_SKIP_CONSTRAINTS));
+    if (dtype == ARB_F32 && !mfma) bc = choose_build(M, noopt, (long)nworlds, split ? 1 : nsteps, flags, bodyc);
     out->worlds_per_wavefront = bc.pack ? 2 : 1;
     // (the float64 64-row kernels may use the whole register file of a SIMD: those with two column sets do -- one
     // wavefront per SIMD --, those with one fit 256 registers)
-    out->waves_per_simd = (dtype == ARB_F64 && M->nmax == 64 && M->nsets == 2) ? 1 : (bc.w3 && !bc.pack) ? 3 : 2;
-    const Layout &L = dtype == ARB_F64 ? M->ld : bc.pack ? M->lfp : bc.w3 ? M->lf3 : M->lf;
+    out->waves_per_simd = (dtype == ARB_F64 && M->nmax == 64 && M->nsets == 2 && !bodyc) ? 1 : (bc.w3 && !bc.pack) ? 3 : 2;
+    const Layout &L = bodyc ? (dtype == ARB_F64 ? M->ldb : bc.w3 ? M->lfb3 : M->lfb) : dtype == ARB_F64 ? M->ld : bc.pack ? M->lfp : bc.w3 ? M->lf3 : M->lf;
     out->lds_bytes = L.total * (dtype == ARB_F64 ? 8 : 4);
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device);
@@ -5030,6 +5284,7 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
                        M->kn.queue_chunk > 0) ? 1 : 0;
     out->feat = optional_inputs <= 0 ? 0 : optional_inputs == 1 ? 1 : 3;
     if (!noopt) out->feat = 3;
+    if (bodyc) out->feat |= noopt ? 20 : 16;       // (4 | 16: the specialised kernels with body-space columns; 19: every optional input)
     // (the specialised kernels, see launch(): plain inputs or user torques of a model of their class, float32)
     if (ARB_WITH_SPEC && M->spec_ok && noopt && (dtype == ARB_F32 || M->nsets == 1) && !mfma && !bc.pack && !bc.rdv && !(flags & ARB_STEP_GENERAL_KERNELS)) out->feat |= 4;
     if (ARB_WITH_SPEC && M->spec0_ok && noopt && dtype == ARB_F32 && !mfma && !bc.pack && !bc.rdv && !(flags & ARB_STEP_GENERAL_KERNELS)) out->feat |= 8;

@@ -210,8 +210,14 @@ template <unsigned LO, unsigned HI>
 ARB_HD double arb_pinned_bits() {
 #if defined(__HIP_DEVICE_COMPILE__)
     int lo, hi;
+#ifndef ARB_PINNED_VGPR      /* round 5: in SCALAR registers (s_mov_b32: the scalar unit has room, the vector pipes do not -- 144 v_mov per step
+                                in the sin / cos of phase A); -DARB_PINNED_VGPR=1: the round-2 form */
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"(LO));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"(HI));
+#else
     asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "n"(LO));
     asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "n"(HI));
+#endif
     return __hiloint2double(hi, lo);
 #else
     const unsigned long long b = ((unsigned long long)HI << 32) | LO;

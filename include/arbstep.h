@@ -144,7 +144,20 @@ enum {
 #define ARB_STEP_GENERAL_KERNELS 512u   /* run the general kernels also for a model of one of the specialised classes (arb_step_plan_info.feat
                                          bits 4 / 8): bit-identical results, ~8 % slower -- for callers (and tests) that want to
                                          see the difference */
-#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u | 512u)
+#define ARB_STEP_BODY_COLUMNS 1024u     /* constraint columns in BODY space wherever the model qualifies.  For a model whose constraints are all
+                                         enabled plane / sphere SoftFingerContacts (no PD controller, no joint viscosity, one small tree) the
+                                         4 nc rows of the constraint Jacobian are T_c J_p: J_p the six rows of the relative Jacobian of the
+                                         contact's pair of bodies, T_c a 4 x 6 frame transform (constraints.py:429-433).  The augmented
+                                         system then carries six columns Y J_p^T per PAIR instead of four per contact, and Y' = T (J_p Y
+                                         J_p^T) T^T, v' = T J_p Y rhs are formed afterwards (float64 sums).  The library does this BY DEFAULT
+                                         where it saves the second column set (human36 with the reference's eight contact points: 55
+                                         columns instead of 75, +16 % world-steps/s); the flag asks for it also where one column set
+                                         would do (four contacts: 2 % slower, half as many float32 world-steps beyond 1e-5 of the
+                                         float64 reference -- fewer float32 columns go through the elimination).  Equal to
+                                         the classical columns to rounding, not bit for bit; ignored for models outside the class, with
+                                         ARB_STEP_SPLIT_WAVE, ARB_STEP_MFMA_ELIM and ARB_STEP_GENERAL_KERNELS.  arb_step_plan_info.feat
+                                         reports bit 16. */
+#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u | 512u | 1024u)
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the

@@ -55,6 +55,8 @@ F32_TOL = 1e-5
 
 
 LAST_DIAG = {}        # what the last explain_outlier call measured (printed by check_replay when no criterion holds)
+KERNEL_KW = {}        # kernel-selection keywords of BatchedWorlds.step / inspect (body_columns, general_kernels) of the rollout
+                      # under adjudication: the inspect kernel must form the constraint-space system as the step kernel did
 
 
 class Reason(str):
@@ -152,7 +154,8 @@ def explain_outlier(bw, m, q, dq, dt, samples=8, seed=0, solve_samples=64):
     import torch
     tq = torch.as_tensor(q[None], dtype=torch.float32, device=bw.device).contiguous()
     tdq = torch.as_tensor(dq[None], dtype=torch.float32, device=bw.device).contiguous()
-    r = bw.inspect(tq, tdq, dt, ["gs_stats", "gs_trace", "c_active", "c_adm", "c_vel", "c_sdist"], cforce=bw.new_cforce(1, torch.float32))
+    r = bw.inspect(tq, tdq, dt, ["gs_stats", "gs_trace", "c_active", "c_adm", "c_vel", "c_sdist"], cforce=bw.new_cforce(1, torch.float32),
+                   **KERNEL_KW)
     st = r["gs_stats"].cpu().numpy()[0]                    # release, static, fast slide, eig6 slide, sweeps
     dtr = r["gs_trace"].cpu().numpy()[0]                   # (20, nc): decision of every executed solve, -1 = not run
     dact = r["c_active"].cpu().numpy()[0].astype(bool)

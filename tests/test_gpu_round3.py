@@ -155,7 +155,7 @@ def test_unknown_flags_are_refused():
     q, dq = synth.standing_states(m, 4, seed=2)
     tq, tdq = bw.to_device(q, dq, torch.float32)
     before = tq.clone()
-    for bad in (4, 1024, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel)
+    for bad in (4, 2048, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel)
         rc = bw._lib.arb_step(bw._handle, _capi.ARB_F32, tq.data_ptr(), tdq.data_ptr(), None, None, 4, 5e-3, 1, bad, None)
         assert rc == 1
     with pytest.raises(ValueError):
@@ -337,7 +337,9 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
         bw.set_knob("gsw_pack", {"pack": 1, "pack4": 4}.get(mode, 0))
         tq, tdq = bw.to_device(q, dq, dtype)
         cf = bw.new_cforce(B, dtype)
-        bw.step(tq, tdq, 5e-3, 40, cforce=cf, split=("wave" if mode != "fused" else False))
+        # (general_kernels: the split execution runs the general kernels; the fused reference must too -- the eight-contact
+        # model's default are the body-space-column kernels of round 5, equal to rounding only)
+        bw.step(tq, tdq, 5e-3, 40, cforce=cf, split=("wave" if mode != "fused" else False), general_kernels=(mode == "fused"))
         torch.cuda.synchronize()
         res[mode] = (tq, tdq, cf)
     assert float(res["fused"][2][:, :, 3].max()) > 100.                      # contacts engaged, sliding included

@@ -19,9 +19,10 @@ pytestmark = pytest.mark.gpu
 def test_plan_reports_the_specialised_kernels(monkeypatch):
     from arboris_python_amd.batch import BatchedWorlds
     assert _capi.load().arb_build_variants() == 0
-    # model: class bit in float32 (4: contacts, 8: no constraints, 0: the general kernels), in float64
+    # model: class bits in float32 (4: contacts, 8: no constraints, 4 | 16: contacts with body-space columns, 0: the general
+    # kernels), in float64
     want = {"human36_c4": (4, 4),                # four plane / sphere SoftFingerContacts
-            "human36_c8": (4, 0),                # eight, two column sets: float32 only
+            "human36_c8": (20, 20),              # eight on two feet: body-space constraint columns, ONE column set (round 5)
             "human36_g": (8, 0),                 # no constraints (BASELINE config 2): float32 only
             "human36_visc": (0, 0),              # joint viscosity: outside the classes
             "human36_c4_pdw": (0, 0),            # a PD controller in the model: a dense impedance, outside the classes
@@ -32,7 +33,8 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
         for B, T in ((512, 1), (8192, 40)):
             assert bw.plan(B, T)["feat"] == spec32, (name, B, T)
             assert bw.plan(B, T, ext_gforce=True)["feat"] == (spec32 | 1), (name, B, T)
-            assert bw.plan(B, T, other_inputs=True)["feat"] == 3, (name, B, T)       # every optional input: the general kernel
+            # every optional input: the general kernel (with body-space columns when the model has them)
+            assert bw.plan(B, T, other_inputs=True)["feat"] == (19 if spec32 & 16 else 3), (name, B, T)
             assert bw.plan(B, T, dtype=torch.float64)["feat"] == spec64, (name, B, T)
         if spec32:
             assert bw.plan(8192, 40, general_kernels=True)["feat"] == 0
@@ -40,13 +42,13 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
 
 
 @pytest.mark.parametrize("torques", [False, True])
-@pytest.mark.parametrize("model,dtype", [("human36_c4", "float32"), ("human36_c4", "float64"), ("human36_c8", "float32"),
-                                         ("human36_g", "float32")])
+@pytest.mark.parametrize("model,dtype", [("human36_c4", "float32"), ("human36_c4", "float64"), ("human36_g", "float32")])
 def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, dtype, torques):
     """Whole falling episodes (free fall, impact, sliding, the rare routes of the local solve late in the episode), two- and
     three-wave builds, the work queue, one launch per step; plain inputs (FEAT 4 against 0) and user torques (5 against 1);
-    float32 with four and with eight contacts (two column sets), float64 with four; the class without constraints
-    (FEAT 8 / 9: human36 in free motion, BASELINE config 2)."""
+    float32 and float64 with four contacts; the class without constraints (FEAT 8 / 9: human36 in free motion, BASELINE
+    config 2).  (Eight contacts: the body-space-column kernels of round 5 equal the general two-column-set kernels to
+    rounding, not bit for bit -- tests/test_gpu_round5.py.)"""
     from arboris_python_amd import synth
     from arboris_python_amd.batch import BatchedWorlds
     m, _, _ = load_model(model)

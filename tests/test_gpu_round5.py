@@ -260,3 +260,147 @@ def test_float32_on_an_ill_conditioned_model_raises_a_warning():
         torch.cuda.synchronize()
         assert bw.warnings() == 0, name
         bw.close()
+
+
+# ---------------------------------------------------------------------------
+# body-space constraint columns (FEAT bit 16): the reference's own eight-contact scenario in ONE column set
+# ---------------------------------------------------------------------------
+def _contact_subset(m, keep):
+    """The flattened model with the contacts `keep` only (a copy)."""
+    import copy
+    m2 = copy.deepcopy(m)
+    keep = np.asarray(keep)
+    for k, v in vars(m).items():
+        if k == "c_names":
+            m2.c_names = [m.c_names[i] for i in keep]
+        elif (k.startswith("c_") or k == "ctype") and isinstance(v, np.ndarray) and len(v) == m.nc:
+            setattr(m2, k, v[keep].copy())
+    return m2
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_body_space_columns_against_the_oracle_and_the_two_set_kernels(dtype):
+    """human36 with the reference's eight contact points (tests/test_human36_falling.py:32): all contacts of a foot are
+    T_c J_foot (constraints.py:429-433), so the augmented system carries 6 columns per foot (12) instead of 4 per contact (32)
+    and fits one column set; Y' = T (J Y J^T) T^T is formed after phase D.  One step from the reference's own drop trajectory
+    and from random contact states, against the oracle (float64: 1e-8; float32: the 1e-5 gate with the usual adjudication of
+    ill-conditioned steps) and against the general kernels on two column sets (ARB_STEP_GENERAL_KERNELS); the inspect
+    kernel's Y', v', J' against the oracle's; a six-contact model (three per foot: 67 columns the classical way) likewise."""
+    from conftest import assert_f32_parity
+    from arboris_python_amd.batch import BatchedWorlds
+    g = load_golden("g3_contacts.npz")
+    m8, _, _ = load_model("human36_c8")
+    dt_ = getattr(torch, dtype)
+    npt = np.float64 if dtype == "float64" else np.float32
+    Q = np.concatenate([g["drop8_q"][:39], g["rand8_q"]]); DQ = np.concatenate([g["drop8_dq"][:39], g["rand8_dq"]])
+    for m, tag in ((m8, "eight"), (_contact_subset(m8, [0, 1, 2, 4, 5, 7]), "six")):
+        bw = BatchedWorlds(m)
+        p = bw.plan(8192, 40, dtype=dt_)
+        assert p["feat"] == 20 and p["waves_per_simd"] == (3 if dtype == "float32" else 2), p
+        assert bw.plan(8192, 40, dtype=dt_, general_kernels=True)["feat"] == 0
+        if dtype == "float32" and tag == "eight":
+            assert p["lds_bytes"] <= 10 * 1280 and p["wave_slots"] == 12 * torch.cuda.get_device_properties(0).multi_processor_count
+        qi, dqi = Q.astype(npt).astype(np.float64), DQ.astype(npt).astype(np.float64)
+        oq, odq, ocf, dbg = O.step(m, qi, dqi, 5e-3, debug=True)
+        res = {}
+        for gk in (False, True):
+            tq, tdq = bw.to_device(Q, DQ, dt_)
+            cf = bw.new_cforce(len(Q), dt_)
+            bw.step(tq, tdq, 5e-3, 1, cforce=cf, general_kernels=gk)
+            torch.cuda.synchronize()
+            res[gk] = (tq.double().cpu().numpy(), tdq.double().cpu().numpy(), cf.double().cpu().numpy())
+            if dtype == "float64":
+                assert _rel(res[gk][0], oq).max() < 1e-8 and _rel(res[gk][1], odq).max() < 1e-8, (tag, gk)
+                assert np.abs(res[gk][2] - ocf).max() < 1e-7 * max(1., np.abs(ocf).max())
+            else:
+                assert_f32_parity(m, Q, DQ, 5e-3, res[gk][0], res[gk][1], oq, odq, 1e-5)
+        d = np.maximum(_rel(res[False][0], res[True][0]), _rel(res[False][1], res[True][1]))
+        print("%s contacts, %s: body-space vs two column sets: max %.2e, share > 1e-5: %.4f" % (tag, dtype, d.max(), (d > 1e-5).mean()))
+        # (float32: two roundings of the same step, each within ~5e-6 of the reference: a few pairs differ by just over 1e-5)
+        assert d.max() < (1e-9 if dtype == "float64" else 1e-3) and (d > 3e-5).mean() <= (0. if dtype == "float64" else 0.03)
+        assert float(np.abs(ocf).max()) > 100.                                   # (the contacts act)
+        # the constraint-space system of the inspect kernel (the same body-space arithmetic)
+        tq, tdq = bw.to_device(Q, DQ, dt_)
+        r = bw.inspect(tq, tdq, 5e-3, ["c_adm", "c_vel", "c_jac", "c_active", "c_frame", "dq_next"], cforce=bw.new_cforce(len(Q), dt_))
+        torch.cuda.synchronize()
+        tol = 1e-9 if dtype == "float64" else 2e-6
+        act = np.asarray(dbg["active"]).astype(bool)
+        assert np.array_equal(r["c_active"].cpu().numpy().astype(bool), act)
+        for key, ok in (("c_adm", "adm"), ("c_vel", "vel0")):
+            a = r[key].double().cpu().numpy().reshape(len(Q), -1); b = np.asarray(dbg[ok]).reshape(len(Q), -1)
+            assert np.abs(a - b).max() < tol * np.abs(b).max(), (tag, key, np.abs(a - b).max() / np.abs(b).max())
+        assert _rel(r["dq_next"].double().cpu().numpy(), res[False][1]).max() == 0.            # inspect == step, bit for bit
+        bw.close()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_body_space_columns_on_request_for_the_four_contact_model(dtype):
+    """ARB_STEP_BODY_COLUMNS: a model that fits one column set anyway (human36 with four contacts, the headline workload) steps
+    through the body-space kernels when asked -- against the oracle like the default path, and against the default path."""
+    from conftest import assert_f32_parity
+    from arboris_python_amd.batch import BatchedWorlds
+    g = load_golden("g3_contacts.npz")
+    m, _, _ = load_model("human36_c4")
+    dt_ = getattr(torch, dtype)
+    npt = np.float64 if dtype == "float64" else np.float32
+    Q = np.concatenate([g["drop4_q"][:39], g["rand4_q"]]); DQ = np.concatenate([g["drop4_dq"][:39], g["rand4_dq"]])
+    bw = BatchedWorlds(m)
+    assert bw.plan(8192, 40, dtype=dt_)["feat"] == 4 and bw.plan(8192, 40, dtype=dt_, body_columns=True)["feat"] == 20
+    assert bw.plan(8192, 40, dtype=dt_, body_columns=True, general_kernels=True)["feat"] == 0
+    oq, odq, ocf = O.step(m, Q.astype(npt).astype(np.float64), DQ.astype(npt).astype(np.float64), 5e-3)
+    res = {}
+    for bc in (False, True):
+        tq, tdq = bw.to_device(Q, DQ, dt_)
+        cf = bw.new_cforce(len(Q), dt_)
+        bw.step(tq, tdq, 5e-3, 1, cforce=cf, body_columns=bc)
+        torch.cuda.synchronize()
+        res[bc] = (tq.double().cpu().numpy(), tdq.double().cpu().numpy())
+        if dtype == "float64":
+            assert _rel(res[bc][0], oq).max() < 1e-8 and _rel(res[bc][1], odq).max() < 1e-8
+        else:
+            assert_f32_parity(m, Q, DQ, 5e-3, res[bc][0], res[bc][1], oq, odq, 1e-5)
+    d = np.maximum(_rel(res[False][0], res[True][0]), _rel(res[False][1], res[True][1]))
+    assert d.max() > 0. and d.max() < (1e-9 if dtype == "float64" else 1e-3)
+    r = bw.inspect(*bw.to_device(Q, DQ, dt_), 5e-3, ["dq_next"], cforce=bw.new_cforce(len(Q), dt_), body_columns=True)
+    assert _rel(r["dq_next"].double().cpu().numpy(), res[True][1]).max() == 0.
+    bw.close()
+
+
+def test_body_space_columns_whole_episodes_and_torque_sequences():
+    """Whole falling episodes of the eight-contact model on the body-space kernels: two- and three-wave builds, the work
+    queue, one launch per step and user torques give the same bits (they are builds of one source), the states stay finite,
+    and the float64 kernels stay within 1e-6 of the general float64 kernels over the 16 steps around the impact."""
+    from arboris_python_amd import synth
+    from arboris_python_amd.batch import BatchedWorlds
+    m, _, _ = load_model("human36_c8")
+    bw = BatchedWorlds(m)
+    B, T = 5000, 40
+    q, dq = synth.standing_states(m, B, seed=12, drop=0.03, vel=0.1)
+    tau = torch.as_tensor(_torque_sequence(m, T, B, seed=3), dtype=torch.float32, device=bw.device).contiguous()
+    res = {}
+    for mode, kw in (("episode", {}), ("two_waves", dict(waves=2)), ("per_step", {}), ("static", dict(static_worlds=True))):
+        tq, tdq = bw.to_device(q, dq, torch.float32)
+        cf = bw.new_cforce(B, torch.float32)
+        if mode == "per_step":
+            for t in range(T):
+                bw.step(tq, tdq, 5e-3, 1, cforce=cf, ext_gforce=tau[t].contiguous())
+        else:
+            bw.step(tq, tdq, 5e-3, T, cforce=cf, ext_gforce=tau, **kw)
+        torch.cuda.synchronize()
+        bw.status()
+        res[mode] = (tq, tdq, cf)
+    assert bool(torch.isfinite(res["episode"][0]).all()) and float(res["episode"][2][:, :, 3].max()) > 100.
+    for mode in ("two_waves", "per_step", "static"):
+        assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(res["episode"], res[mode])), mode
+    q[:, 7] -= 0.01
+    fin = {}
+    for gk in (False, True):
+        tq, tdq = bw.to_device(q[:600], dq[:600], torch.float64)
+        cf = bw.new_cforce(600, torch.float64)
+        bw.step(tq, tdq, 5e-3, 16, cforce=cf, general_kernels=gk)
+        torch.cuda.synchronize()
+        fin[gk] = (tq.cpu().numpy(), tdq.cpu().numpy())
+    d = np.maximum(_rel(fin[False][0], fin[True][0]), _rel(fin[False][1], fin[True][1]))
+    print("float64, 16 steps: body-space vs two column sets: max %.2e, median %.2e" % (d.max(), np.median(d)))
+    assert np.median(d) < 1e-9 and (d > 1e-6).mean() < 0.02
+    bw.close()

@@ -6,7 +6,8 @@ marginal for the oracle itself) or the ill-conditioning rule of the tests.  Prin
 outliers PER CRITERION (active, a-e, ill; parity_tools), the share of world-steps explained by (d) / (e), the largest
 system errors (Y', v', the flipped solve's rows) among the cases that reached (d) / (e), the world-steps above the caps of
 the tests (1e-3 in q, 1e-2 in dq) one by one, and the unexplained ones.
-usage (GPU box): python tools/replay_stats.py [seed [world_stride [step_stride [contacts]]]]   (defaults 1000, 16, 3, 4)"""
+usage (GPU box): python tools/replay_stats.py [seed [world_stride [step_stride [contacts [kernels]]]]]   (defaults 1000, 16, 3, 4;
+kernels: "body" = ARB_STEP_BODY_COLUMNS, "general" = ARB_STEP_GENERAL_KERNELS, default: what the library picks)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +23,10 @@ bw = BatchedWorlds(m)
 B, T, dt = 4096, 40, 5e-3
 q, dq = synth.standing_states(m, B, seed=arg(1, 1000), drop=0.03, vel=0.1)
 tq, tdq = bw.to_device(q, dq, torch.float32)
-log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False)
+if len(sys.argv) > 5 and sys.argv[5] in ("body", "general"):
+    P.KERNEL_KW.update({"body_columns" if sys.argv[5] == "body" else "general_kernels": True})
+print("kernels:", P.KERNEL_KW or "default", bw.plan(B, T, other_inputs=True, **P.KERNEL_KW))
+log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False, **P.KERNEL_KW)
 torch.cuda.synchronize()
 worlds = np.arange(0, B, arg(2, 16))     # 256 worlds by default
 errs, crit, unexplained, over, diag = [], {}, [], [], dict(e_adm=0., e_vel=0., e_row=0.)
