@@ -132,14 +132,26 @@
 #define BD_TW 18     // body twist (6)
 #define BD_AB 24     // bias acceleration dJ_b * gvel (6): phase A, until the rhs wrench is formed from it ...
 #define BD_PT 24     // ... M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b (6): rhs of the increment form, in the same slot
-#define BD_STRIDE 30         // the step kernels
+// (round 5, LDS bank conflicts: ODD strides -- with 30 elements per body neighbouring bodies' 16-byte accesses overlapped by two
+// banks and bodies b, b + 16 met on one; measured with SQ_LDS_BANK_CONFLICT, tools/pmc_lds.sh: 30 -> 31 takes 27 M of the
+// 166 M conflict cycles per launch that were left once the rows of Y' were padded, see gs_stage; 34: none; 36: +47 M)
+#ifndef BD_STRIDE
+#define BD_STRIDE 31         // the step kernels
+#endif
 #define BD_PG 30     // M_b g_b (6): the inspect kernels only (World._gforce of the controllers alone), hence last
-#define BD_STRIDE_INSPECT 36
+#define BD_STRIDE_INSPECT 37
 // (the world pose H_gb of a body lives in PD, in float64, only: a copy in T here cost 12 elements per body -- 6 KB of the
 // 43 KB of a float64 snake-64 wavefront, which kept its kernels at three wavefronts per CU instead of four)
 // Composite assembly of Z (phase B): per-body accumulators travelling up the tree, in float64:
 // A (36) | M upper triangle (21) | wrench of the increment rhs (6) | gravity wrench (6, inspect only)
 #define XPR_STRIDE 18     // float64 per dof: X (6) | P = A^T X (6) | R = M X (6)
+// float64 per body in the pose table PD: R (9) | p (3) + one of padding (round 5): rows of 12 doubles = 24 banks put bodies b and
+// b + 8 on the same banks -- every level of the pose chain reads a parent's pose and its own with 16-byte accesses --: 99 M of
+// the remaining 139 M conflict cycles per launch; rows of 13 doubles are read with 8-byte accesses, all 17 bodies of human36
+// on disjoint banks (14 would keep the 16-byte accesses and cost the twelfth wavefront per CU: 12 864 B)
+#ifndef PDS
+#define PDS 13
+#endif
 
 // per-constraint block in LDS (elements)
 #define CD_R1 0      // transform body1 -> constraint frame: R (9), p (3)
@@ -421,7 +433,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char arb_lds_raw[];
 // the two decision inequalities, the (pseudo-)inverse blocks -- run in float64 on the float32 system Y', v'; G = T otherwise)
 // SPECK: every constraint is an enabled SoftFingerContact (the specialised step kernels, FEAT bit 4): its type is a constant
 template <typename T, int MODE, typename G = T, bool ALLOW_FAST = true, bool SPECK = false>
-__device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const T dt_t,
+// lda: row stride of Y' in LDS.  The step kernels pad the rows by four elements (round 5): with the dense stride 4 nc -- 16
+// floats for four contacts -- the 16 row lanes' reads of their column block Y'[:, 4c..4c+3], four per local solve, fell on TWO of
+// the 32 banks: eight-way conflicts, 28 extra LDS cycles per solve, 80 solves per step -- 370 M of the 438 M conflict cycles per
+// launch that SQ_LDS_BANK_CONFLICT had counted since round 3 (28 % of the LDS-active cycles).  With rows of 4 nc + 4 floats
+// read as ONE 16-byte vector the 16 / 32 rows lie in distinct 16-byte slots of the 256-byte bank row: conflict-free.
+__device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const int lda, const T dt_t,
                                          const T inv_dt_t, const T *AM, T *CD, T *VV, T *FF, T *WORK,
                                          const DebugOut<T> &dbg, const long w) {
     constexpr bool SAME = std::is_same<T, G>::value;
@@ -439,7 +456,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                 const int c = lane < nc ? lane : 0, ct = SPECK ? (int)ARB_CT_SOFTFINGER : mp->ctype[c];
                 const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 T P[16];
-                const bool ok = inv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+                const bool ok = inv_block<T>(AM + (4 * c) * lda + 4 * c, lda, nd, P);
                 if (ARB_DENSE_INV) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) keep(P[i]);
@@ -459,7 +476,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                 const int ct = SPECK ? (int)ARB_CT_SOFTFINGER : mp->ctype[c];
                 const int nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 T P[16];
-                pinv_block<T>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+                pinv_block<T>(AM + (4 * c) * lda + 4 * c, lda, nd, P);
                 for (int i = 0; i < 16; ++i) CD[c * CD_STRIDE + CD_PINV + i] = P[i];
             }
         }
@@ -497,7 +514,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
         vr = VV[lane]; fr = FF[lane];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            Yrow[i] = AM[lane * ndol + 4 * cc + i];
+            Yrow[i] = AM[lane * lda + 4 * cc + i];
             if constexpr (SAME) Prow[i] = CD[cc * CD_STRIDE + CD_PINV + 4 * rr + i];
         }
         if constexpr (!SAME) {
@@ -510,7 +527,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Yb[4 * i + j] = (G)AM[(4 * cc + i) * ndol + 4 * cc + j];
+                    for (int j = 0; j < 4; ++j) Yb[4 * i + j] = (G)AM[(4 * cc + i) * lda + 4 * cc + j];
                 if (!inv_block<G, T>(Yb, 4, nd, P)) pinv_block<G, T>(Yb, 4, nd, P);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) Prow[i] = (rr == 0) ? P[i] : (rr == 1) ? P[4 + i] : (rr == 2) ? P[8 + i] : P[12 + i];
@@ -524,7 +541,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * ndol + 4 * cc + j];
+                for (int j = 0; j < 4; ++j) Yc4[4 * i + j] = AM[(4 * cc + i) * lda + 4 * cc + j];
             q_sp = slide_precompute<G>(Yc4);
             if (ARB_POLY_LANES) {
                 SlideCoef all[6];
@@ -594,8 +611,9 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             // column block Y'[:, 4c..4c+3] of this lane's row (issued early, used last)
             G a4[4] = {G(0), G(0), G(0), G(0)};
             if (lane < ndol) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a4[i] = AM[lane * ndol + base + i];
+                typedef T A4 __attribute__((ext_vector_type(4)));      // (one 16-byte read: rows are 16-byte aligned, see lda)
+                const A4 av = *reinterpret_cast<const A4 *>(AM + lane * lda + base);
+                a4[0] = av.x; a4[1] = av.y; a4[2] = av.z; a4[3] = av.w;
             }
             // (the fast variant runs only when every active constraint is a SoftFingerContact with eps = (1,1,1))
             const int ct = (FAST || SPECK) ? (int)ARB_CT_SOFTFINGER : __builtin_amdgcn_readlane(k_ct, c);
@@ -658,7 +676,7 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
                             typedef T Y4 __attribute__((ext_vector_type(4)));      // (storage type)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const Y4 y4 = *reinterpret_cast<const Y4 *>(AM + (base + r) * ndol + base);
+                                const Y4 y4 = *reinterpret_cast<const Y4 *>(AM + (base + r) * lda + base);
                                 Y[4 * r] = y4.x; Y[4 * r + 1] = y4.y; Y[4 * r + 2] = y4.z; Y[4 * r + 3] = y4.w;
                             }
                         }
@@ -1312,15 +1330,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     // size always exist, which folds their `i < n` predicates away
     constexpr int NLOW = NMAX == 16 ? 0 : NMAX == 32 ? 16 : NMAX == 44 ? 32 : NMAX == 48 ? 44 : 48;
     constexpr bool LSCAN_OK = NMAX <= 48;      // (the 64-row tiles are register-bound: only the DPP scan is compiled in)
-#ifndef ARB_MFMA_ROWS
-#define ARB_MFMA_ROWS 0          // measured round 4: 1 = rows of Z on the float64 matrix cores: -1.5 % (fewer instructions, more spill reloads and LDS round trips); kept as an experiment
-#endif
-    // the rows of Z as float64 matrix-core products (phase B; float32 worlds on the 44- and 48-row tiles, whose RT space
-    // holds the staging of a tile column; ARB_ELIM_F64 keeps the register tile in float64: the row loop)
-    constexpr bool MFMA_ROWS = (ARB_MFMA_ROWS != 0) && std::is_same<T, float>::value && (NMAX == 44 || NMAX == 48) && !(ARB_ELIM_F64 != 0);
     constexpr int RS = NMAX;          // row stride of the per-dof LDS arrays (columns >= ndof stay zero)
     constexpr int BDS = (MODE == 1) ? BD_STRIDE_INSPECT : BD_STRIDE;      // per-body block (the gravity wrench slot: inspect only)
     T dt = dt_in, inv_dt = T(1) / dt_in;
+    // row stride of Y' in LDS: four elements of padding (bank conflicts of the sweeps' column reads, see gs_stage); the packed and
+    // rendezvous builds (libarbstep_variants.so) keep the dense rows their stash copies assume
+#define lda ((PACK || RDV) ? ndol : ndol + 4)
     // (evaluated where it is used, from the laundered nc: as one hoisted flag it lives in spilled lane masks)
 #define do_constraints ((nc > 0) && !(flags & ARB_STEP_SKIP_CONSTRAINTS))
 
@@ -1624,7 +1639,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     const V3<double> p_pc_d = mv(Rpr, p_rc) + ppr;
                     // parked in the body's own pose slot until its depth level comes (24 registers less across
                     // the level loop: phase A is the register-pressure peak of the kernel)
-                    st_m3(PD + 12 * b, R_pc_d); st_v3(PD + 12 * b + 9, p_pc_d);
+                    st_m3(PD + PDS * b, R_pc_d); st_v3(PD + PDS * b + 9, p_pc_d);
                     R_pc = cvt_m3<T>(R_pc_d);
                     p_pc = cvt_v3<T>(p_pc_d);
                 }
@@ -1740,12 +1755,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                         const int a = on ? (int)WORK[b] : -1;
                         M3<double> Ra = m3_identity<double>(); V3<double> pa = v3<double>(0., 0., 0.);
                         T na = T(-1);
-                        if (a >= 0) { Ra = ld_m3(PD + 12 * a); pa = ld_v3(PD + 12 * a + 9); na = WORK[a]; }
+                        if (a >= 0) { Ra = ld_m3(PD + PDS * a); pa = ld_v3(PD + PDS * a + 9); na = WORK[a]; }
                         WAVE_SYNC();
                         if (a >= 0) {
-                            const M3<double> Rb = ld_m3(PD + 12 * b);
-                            const V3<double> pb2 = ld_v3(PD + 12 * b + 9);
-                            st_m3(PD + 12 * b, mul(Ra, Rb)); st_v3(PD + 12 * b + 9, mv(Ra, pb2) + pa);
+                            const M3<double> Rb = ld_m3(PD + PDS * b);
+                            const V3<double> pb2 = ld_v3(PD + PDS * b + 9);
+                            st_m3(PD + PDS * b, mul(Ra, Rb)); st_v3(PD + PDS * b + 9, mv(Ra, pb2) + pa);
                             WORK[b] = na;
                         }
                         WAVE_SYNC();
@@ -1753,7 +1768,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     // (2) twists
                     M3<double> Rgb = m3_identity<double>(); V3<double> pgb = v3<double>(0., 0., 0.);
                     if (on) {
-                        Rgb = ld_m3(PD + 12 * b); pgb = ld_v3(PD + 12 * b + 9);
+                        Rgb = ld_m3(PD + PDS * b); pgb = ld_v3(PD + PDS * b + 9);
                         const V3<double> ww = mv(Rgb, Tnw);
                         st_v3(bdl + BD_TW, ww); st_v3(bdl + BD_TW + 3, cross(pgb, ww) + mv(Rgb, Tnv));
                     }
@@ -1793,12 +1808,12 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     V3<T> tw = v3<T>(T(0), T(0), T(0)), tv = tw, aw = tw, av = tw;
                     if (par >= 0) {
                         const T *pb = BD + par * BDS;
-                        Rg = ld_m3(PD + 12 * par); pg = ld_v3(PD + 12 * par + 9);
+                        Rg = ld_m3(PD + PDS * par); pg = ld_v3(PD + PDS * par + 9);
                         tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3);
                         aw = ld_v3(pb + BD_AB); av = ld_v3(pb + BD_AB + 3);
                     }
-                    const M3<double> R_pc_d = ld_m3(PD + 12 * bb);
-                    const V3<double> p_pc_d = ld_v3(PD + 12 * bb + 9);
+                    const M3<double> R_pc_d = ld_m3(PD + PDS * bb);
+                    const V3<double> p_pc_d = ld_v3(PD + PDS * bb + 9);
                     const M3<double> Rc_d = mul(Rg, R_pc_d);         // child_pose  core.py:1299
                     const V3<double> pc_d = mv(Rg, p_pc_d) + pg;
                     const V3<T> cw = mv(R_cp, tw) + Tnw;             // child_twist core.py:1308
@@ -1810,7 +1825,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     if (ARB_DENSE_LVL) { keep(Rc_d); keep(pc_d); keep(cw); keep(cv); keep(nbw); keep(nbv); }
                     if (mine) {
                         T *bd = BD + b * BDS;
-                        st_m3(PD + 12 * b, Rc_d); st_v3(PD + 12 * b + 9, pc_d);
+                        st_m3(PD + PDS * b, Rc_d); st_v3(PD + PDS * b + 9, pc_d);
                         st_v3(bd + BD_TW, cw); st_v3(bd + BD_TW + 3, cv);
                         st_v3(bd + BD_AB, nbw); st_v3(bd + BD_AB + 3, nbv);
                     }
@@ -1829,7 +1844,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 // gravity in the body frame: Ad(inv(H_gb)) [0; g up]   controllers.py:56-58
                 T g6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
                 if (mp->has_grav && mp->weighted[b]) {
-                    const M3<T> Rg = cvt_m3<T>(ld_m3(PD + 12 * b));
+                    const M3<T> Rg = cvt_m3<T>(ld_m3(PD + PDS * b));
                     const V3<T> gl = mtv(Rg, v3<T>(mp->grav[0], mp->grav[1], mp->grav[2]));
                     g6[3] = gl.x; g6[4] = gl.y; g6[5] = gl.z;
                 }
@@ -1872,7 +1887,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         }
         if (MODE == 1 && step == 0) {
             if (dbg.pose != nullptr && lane < nb) {
-                const double *pw = PD + 12 * lane;
+                const double *pw = PD + PDS * lane;
                 T *o = dbg.pose + (w * nb + lane) * 16;
                 for (int i = 0; i < 3; ++i) {
                     for (int j = 0; j < 3; ++j) o[4 * i + j] = (T)pw[3 * i + j];
@@ -1898,7 +1913,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #pragma unroll
                 for (int i = 0; i < 6; ++i) ke += 0.5 * (double)tw[i] * (double)mt[i];
                 const double *cm = mp->com_d + 4 * lane;
-                const M3<double> Rg = ld_m3(PD + 12 * lane); const V3<double> pg = ld_v3(PD + 12 * lane + 9);
+                const M3<double> Rg = ld_m3(PD + PDS * lane); const V3<double> pg = ld_v3(PD + PDS * lane + 9);
                 const V3<double> cg = mv(Rg, v3<double>(cm[0], cm[1], cm[2])) + pg;
                 pe = 9.81 * cm[3] * (mp->up[0] * cg.x + mp->up[1] * cg.y + mp->up[2] * cg.z);
             }
@@ -1933,11 +1948,11 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     V3<double> pg0 = v3<double>(0., 0., 0.), pg1 = pg0;
                     V3<T> bw0 = v3<T>(T(0), T(0), T(0)), bv0 = bw0, bw1 = bw0, bv1 = bw0;
                     if (b0 >= 0) {
-                        Rg0 = ld_m3(PD + 12 * b0); pg0 = ld_v3(PD + 12 * b0 + 9);
+                        Rg0 = ld_m3(PD + PDS * b0); pg0 = ld_v3(PD + PDS * b0 + 9);
                         bw0 = ld_v3(BD + b0 * BDS + BD_TW); bv0 = ld_v3(BD + b0 * BDS + BD_TW + 3);
                     }
                     if (b1 >= 0) {
-                        Rg1 = ld_m3(PD + 12 * b1); pg1 = ld_v3(PD + 12 * b1 + 9);
+                        Rg1 = ld_m3(PD + PDS * b1); pg1 = ld_v3(PD + PDS * b1 + 9);
                         bw1 = ld_v3(BD + b1 * BDS + BD_TW); bv1 = ld_v3(BD + b1 * BDS + BD_TW + 3);
                     }
                     // pose of shape 0's frame and centre of shape 1 (a Sphere or a Point)
@@ -1968,7 +1983,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                         // reference body, a few centimetres from the contact point: [[Rx, 0], [px^ Rx, Rx]] with Rx = Rc^T,
                         // px = -Rx (gc0 - o) -- as 4 x 6 in the block's first 24 slots; ZERO for a contact outside the active set,
                         // whose rows and columns of Y' and entry of v' then come out zero by themselves (core.py:913-918)
-                        const V3<double> o = ld_v3(PD + 12 * mp->pair_ref[mp->cpair[c]] + 9);
+                        const V3<double> o = ld_v3(PD + PDS * mp->pair_ref[mp->cpair[c]] + 9);
                         const M3<double> Rx = transpose(Rc);
                         const M3<double> PR = hatmul(-mtv(Rc, gc0 - o), Rx);
                         const double am = active ? 1. : 0.;
@@ -1987,7 +2002,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                             for (int i = 0; i < 4; ++i) FF[4 * c + i] = T(0);   // constraints.py:294
                         }
                     } else {
-                    const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
+                    const V3<double> p0w = ld_v3(PD + PDS * CI[CI_STRIDE * c + 6] + 9);
                     const M3<T> o_r1 = cvt_m3<T>(transpose(Rc));
                     const V3<T> o_p1 = cvt_v3<T>(-mtv(Rc, gc0 - p0w));
                     if (ARB_DENSE_AP) { keep(o_r1); keep(o_p1); keep(sd); keep((int)active); }
@@ -2028,14 +2043,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     const int b0 = mp->cbody0[c], b1 = mp->cbody[c];
                     M3<double> Rg0 = m3_identity<double>(), Rg1 = Rg0;
                     V3<double> pg0 = v3<double>(0., 0., 0.), pg1 = pg0;
-                    if (b0 >= 0) { Rg0 = ld_m3(PD + 12 * b0); pg0 = ld_v3(PD + 12 * b0 + 9); }
-                    if (b1 >= 0) { Rg1 = ld_m3(PD + 12 * b1); pg1 = ld_v3(PD + 12 * b1 + 9); }
+                    if (b0 >= 0) { Rg0 = ld_m3(PD + PDS * b0); pg0 = ld_v3(PD + PDS * b0 + 9); }
+                    if (b1 >= 0) { Rg1 = ld_m3(PD + PDS * b1); pg1 = ld_v3(PD + PDS * b1 + 9); }
                     const M3<double> Rf0 = ld_m3(mp->cb0_d + 12 * c);
                     const V3<double> pf0 = ld_v3(mp->cb0_d + 12 * c + 9), pf1 = ld_v3(mp->cb1_d + 12 * c + 9);
                     const M3<double> RP0 = mul(Rg0, Rf0); const V3<double> pP0 = mv(Rg0, pf0) + pg0;
                     const V3<double> pP1 = mv(Rg1, pf1) + pg1;
                     // body1 -> frame 0: Ad(inv(P0) H_gb1);  body0 -> frame 0: Ad(inv(bpose0))
-                    const V3<double> p0w = ld_v3(PD + 12 * CI[CI_STRIDE * c + 6] + 9);
+                    const V3<double> p0w = ld_v3(PD + PDS * CI[CI_STRIDE * c + 6] + 9);
                     const V3<T> o_pos = cvt_v3<T>(mtv(RP0, pP1 - pP0));      // p_01  constraints.py:196-197
                     const M3<T> o_r1 = cvt_m3<T>(transpose(RP0));
                     const V3<T> o_p1 = cvt_v3<T>(-mtv(RP0, pP0 - p0w));
@@ -2129,7 +2144,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                         T *const bdl = BD + (onb ? lane : 0) * BDS;
                         M3<double> Rgb = m3_identity<double>(); V3<double> pgb2 = v3<double>(0., 0., 0.);
                         if (onb) {
-                            Rgb = ld_m3(PD + 12 * lane); pgb2 = ld_v3(PD + 12 * lane + 9);
+                            Rgb = ld_m3(PD + PDS * lane); pgb2 = ld_v3(PD + PDS * lane + 9);
                             const V3<double> ww = mv(Rgb, ld_v3(bdl + BD_OM));
                             const V3<double> wv = cross(pgb2, ww) + mv(Rgb, ld_v3(bdl + BD_OM + 3));
                             st_v3(bdl + BD_OM, ww); st_v3(bdl + BD_OM + 3, wv);
@@ -2193,209 +2208,14 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // in their two-wave kernels cost 65 spilled VGPRs and 3-6 %, tools/experiments/forest_rate.py)
             constexpr bool TWO_PASS = (CM == 2 || CM == 3 || CM == 4 || MODE == 1);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
-#ifndef ARB_SPEC_LSCAN
-#define ARB_SPEC_LSCAN 0        // 1: the specialised three-wave kernels compile the prefix-table path of phase B only (spec_ok asks for a small tree):
-                                // 341 -> 184 spilled registers and 3 % SLOWER (22.6 against 23.3 M world-steps/s, same box): off
-#endif
-            const bool lscan = (SPEC && ((CM == 2 && (ARB_SPEC_LSCAN & 1)) || (CM == 0 && (ARB_SPEC_LSCAN & 2)))) ? true : (LSCAN_OK && mp->lay.lscan);
+            const bool lscan = LSCAN_OK && mp->lay.lscan;
             const bool use_table = lscan && TWO_PASS;
             WAVE_SYNC();
             // ---- lane = body: world-frame matrices of the body -----------------------------------
-#ifndef ARB_B_STREAM
-#define ARB_B_STREAM 0          // measured round 4 (1: the block below): at the three-wave register budget the body block drops from
-                                // 57 k to 18 k cycles (tools/bstamp_probe.py, eight waves per CU), bit-identical -- and with twelve
-                                // waves per CU the launch takes as long as before (other waves cover the reloads), with 1 % more
-                                // instructions and 1.2 GB more fetched per launch: kept as an experiment, off
-#endif
-            // Small trees (prefix table), round 4: the 36 entries of A_b are produced ROW BY ROW and every row goes straight
-            // into the body's table row -- the 36 float64 accumulators of A never sit in registers beside the 36 of Mg.  The
-            // kernels compiled for three waves per SIMD (168 registers) spent 57 k instead of 17 k cycles in this block and
-            // 35 k instead of 12 k in the dof products that follow (spilled registers reloaded from scratch memory, each
-            // reload waited for: tools/bstamp_probe.py on a -DARB_WAVES_PER_EU=3 build), more than all their other phases lost
-            // together.  With two table passes (those kernels) the block runs TWICE: before the M | rhs pass it forms Mg and
-            // the wrenches, stores them and forgets everything; before the A pass it forms Mg again -- ~250 float64
-            // instructions on the body lanes, against 36 accumulators held in (spilled) registers across the first pass.
-            // Element by element the additions are those of the accumulator version (below: large trees), in the same
-            // order: bit-identical.
-            constexpr int NMR = NACC - TB_PASS1;               // M (upper triangle, 21) | rhs wrench (6) [| gravity wrench (6)]
-            const bool bstream = (ARB_B_STREAM != 0) && lscan;
-            typedef double BD2 __attribute__((ext_vector_type(2)));
-            // Mg = Ad(b<-g)^T M_b Ad(b<-g) of body b (symmetric), 36 entries row-major
-            auto world_G = [&](const M3<double> &R, const V3<double> &p, const T *Mb, double (&G)[36]) {
-                auto blk = [](const T *m6, int r0, int c0) {
-                    M3<double> o;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) o.a[3 * i + j] = (double)m6[6 * (r0 + i) + c0 + j];
-                    return o;
-                };
-                auto rot = [&](const M3<double> &Xm) { return mul(R, mulBT(Xm, R)); };       // R X R^T
-                auto rowcross = [](const M3<double> &Xm, V3<double> v) {                      // X v^
-                    M3<double> o;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const V3<double> c = cross(v3<double>(Xm.a[3 * i], Xm.a[3 * i + 1], Xm.a[3 * i + 2]), v);
-                        o.a[3 * i] = c.x; o.a[3 * i + 1] = c.y; o.a[3 * i + 2] = c.z;
-                    }
-                    return o;
-                };
-                const M3<double> M11 = rot(blk(Mb, 0, 0)), M12 = rot(blk(Mb, 0, 3)), M22 = rot(blk(Mb, 3, 3));
-                const M3<double> G12 = add(M12, hatmul(p, M22));
-                const M3<double> G21 = transpose(G12);
-                const M3<double> G11 = add(sub(M11, rowcross(M12, p)), hatmul(p, G21));
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        G[6 * i + j] = G11.a[3 * i + j]; G[6 * i + 3 + j] = G12.a[3 * i + j];
-                        G[6 * (3 + i) + j] = G21.a[3 * i + j]; G[6 * (3 + i) + 3 + j] = M22.a[3 * i + j];
-                    }
-            };
-            // Bg = Ad^T B_b Ad (viscosity, rare: a general 6x6)
-            auto world_B = [&](const M3<double> &R, const V3<double> &p, const T *Vb, double (&Bv)[36]) {
-                auto blk = [](const T *m6, int r0, int c0) {
-                    M3<double> o;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) o.a[3 * i + j] = (double)m6[6 * (r0 + i) + c0 + j];
-                    return o;
-                };
-                auto rot = [&](const M3<double> &Xm) { return mul(R, mulBT(Xm, R)); };
-                auto rowcross = [](const M3<double> &Xm, V3<double> v) {
-                    M3<double> o;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const V3<double> c = cross(v3<double>(Xm.a[3 * i], Xm.a[3 * i + 1], Xm.a[3 * i + 2]), v);
-                        o.a[3 * i] = c.x; o.a[3 * i + 1] = c.y; o.a[3 * i + 2] = c.z;
-                    }
-                    return o;
-                };
-                const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
-                const M3<double> H12 = add(B12, hatmul(p, B22));
-                const M3<double> H21 = sub(B21, rowcross(B22, p));
-                const M3<double> H11 = add(sub(B11, rowcross(B12, p)), hatmul(p, H21));
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        Bv[6 * i + j] = H11.a[3 * i + j]; Bv[6 * i + 3 + j] = H12.a[3 * i + j];
-                        Bv[6 * (3 + i) + j] = H21.a[3 * i + j]; Bv[6 * (3 + i) + 3 + j] = B22.a[3 * i + j];
-                    }
-            };
-            // M (upper triangle) | rhs wrench [| gravity wrench] of body b into table positions OFFD .. (doubles)
-            auto store_MR = [&](auto offc, const M3<double> &R, const V3<double> &p, const double (&G)[36], BD2 *trow) {
-                constexpr int OFFD = decltype(offc)::value;
-                double wr[NACC - 57];              // world wrench of the increment rhs (6) [| gravity wrench (6), inspect]
-                {   // wrenches to world axes: Ad(b<-g)^T f = (R tau + p x R f, R f)
-                    const V3<double> f = mv(R, v3<double>((double)ptb[3], (double)ptb[4], (double)ptb[5]));
-                    const V3<double> tq = mv(R, v3<double>((double)ptb[0], (double)ptb[1], (double)ptb[2])) + cross(p, f);
-                    wr[0] = tq.x; wr[1] = tq.y; wr[2] = tq.z; wr[3] = f.x; wr[4] = f.y; wr[5] = f.z;
-                }
-                if (MODE == 1) {
-                    const V3<double> f = mv(R, v3<double>((double)pgb[3], (double)pgb[4], (double)pgb[5]));
-                    const V3<double> tq = mv(R, v3<double>((double)pgb[0], (double)pgb[1], (double)pgb[2])) + cross(p, f);
-                    wr[NACC - 63] = tq.x; wr[NACC - 62] = tq.y; wr[NACC - 61] = tq.z; wr[NACC - 60] = f.x; wr[NACC - 59] = f.y; wr[NACC - 58] = f.z;
-                }
-                auto mr_at = [&](int i) -> double {
-                    constexpr int RW[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
-                    constexpr int CL[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-                    if (i < 21) return useN ? G[6 * RW[i] + CL[i]] : 0.;
-                    return i < NMR ? wr[i - 21] : 0.;
-                };
-#pragma unroll
-                for (int i2 = 0; i2 < (NMR + 1) / 2; ++i2) { BD2 v; v.x = mr_at(2 * i2); v.y = mr_at(2 * i2 + 1); trow[OFFD / 2 + i2] = v; }
-            };
-            // rows of A_b = Mg/dt - ad(T*)^T Mg + Mg ad(Om) + Bg into table positions 0 .. 35, one row at a time
-            auto store_A = [&](auto hvc, const double *Bv, const M3<double> &R, const V3<double> &p, const T *Mb, const double (&G)[36], BD2 *trow) {
-                constexpr bool HV = decltype(hvc)::value;
-                // T* = [w; c x w] (c = centre of mass, core.py:1276-1288) and Om, both in world axes
-                const V3<double> wb = v3<double>((double)twb[0], (double)twb[1], (double)twb[2]);
-                const double mm = (double)Mb[21];
-                V3<double> cm = v3<double>(0., 0., 0.);
-                if (!(mm <= 1e-10)) cm = (1. / mm) * v3<double>((double)Mb[6 * 2 + 4], (double)Mb[6 * 0 + 5], (double)Mb[6 * 1 + 3]);
-                const V3<double> Tw = mv(R, wb);
-                const V3<double> Tv = mv(R, cross(cm, wb)) + cross(p, Tw);
-                const V3<double> ow = mv(R, v3<double>((double)om_b[0], (double)om_b[1], (double)om_b[2]));
-                const V3<double> ov = mv(R, v3<double>((double)om_b[3], (double)om_b[4], (double)om_b[5])) + cross(p, ow);
-                static_for_asc(std::make_integer_sequence<int, 6>{}, [&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    double a[6];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        a[j] = 0.;
-                        if constexpr (HV) a[j] += Bv[6 * r + j];
-                        a[j] += useM ? cM * G[6 * r + j] : 0.;
-                    }
-                    if (useN) {
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {                        // -ad(T*)^T Mg: component r of column j
-                            const V3<double> gt = v3<double>(G[j], G[6 + j], G[12 + j]), gb = v3<double>(G[18 + j], G[24 + j], G[30 + j]);
-                            if constexpr (r < 3) {
-                                const V3<double> t = cross(Tw, gt) + cross(Tv, gb);
-                                a[j] += (r == 0) ? t.x : (r == 1) ? t.y : t.z;
-                            } else {
-                                const V3<double> u = cross(Tw, gb);
-                                a[j] += (r == 3) ? u.x : (r == 4) ? u.y : u.z;
-                            }
-                        }
-                        {                                                    // Mg ad(Om): row r
-                            const V3<double> gl = v3<double>(G[6 * r], G[6 * r + 1], G[6 * r + 2]), gr = v3<double>(G[6 * r + 3], G[6 * r + 4], G[6 * r + 5]);
-                            const V3<double> t = cross(gl, ow) + cross(gr, ov), u = cross(gr, ow);
-                            a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += u.x; a[4] += u.y; a[5] += u.z;
-                        }
-                    }
-                    BD2 v0, v1, v2;
-                    v0.x = a[0]; v0.y = a[1]; v1.x = a[2]; v1.y = a[3]; v2.x = a[4]; v2.y = a[5];
-                    trow[3 * r] = v0; trow[3 * r + 1] = v1; trow[3 * r + 2] = v2;
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);               // (row by row: interleaved rows bring the 36 accumulators back)
-                });
-            };
-            // the A part of a body's table row (viscosity, rare, is a code path of its own: its 36 values cost the usual path
-            // no registers)
-            auto body_A = [&]() {
-                const int b = lane;
-                const M3<double> R = ld_m3(PD + 12 * b);
-                const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);      // about its tree's root
-                const T *Mb = mp->mass + 36 * b;
-                BD2 *trow = reinterpret_cast<BD2 *>(STG + TBS * b);
-                if (!SPEC && mp->has_visc && useB) {
-                    double Bv[36], G[36];
-                    world_B(R, p, mp->visc + 36 * b, Bv);
-                    world_G(R, p, Mb, G);
-                    store_A(std::true_type{}, Bv, R, p, Mb, G, trow);
-                } else {
-                    double G[36];
-                    world_G(R, p, Mb, G);
-                    store_A(std::false_type{}, nullptr, R, p, Mb, G, trow);
-                }
-            };
-            if (bstream) {
-                if (lane < nb) {
-                    const int b = lane;
-                    BD2 *trow = reinterpret_cast<BD2 *>(STG + TBS * b);
-                    {
-                        const M3<double> R = ld_m3(PD + 12 * b);
-                        const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);
-                        double G[36];
-                        world_G(R, p, mp->mass + 36 * b, G);
-                        // two passes: M | rhs is the first (positions 0 ..); one pass: behind the 36 entries of A
-                        if constexpr (TWO_PASS) store_MR(std::integral_constant<int, 0>{}, R, p, G, trow);
-                        else store_MR(std::integral_constant<int, TB_PASS1>{}, R, p, G, trow);
-                    }
-                    if constexpr (!TWO_PASS) {
-                        asm volatile("" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                        body_A();
-                    }
-                }
-            } else
             if (lane < nb) {
                 const int b = lane;
-                const M3<double> R = ld_m3(PD + 12 * b);
-                const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);      // about its tree's root
+                const M3<double> R = ld_m3(PD + PDS * b);
+                const V3<double> p = ld_v3(PD + PDS * b + 9) - ld_v3(PD + PDS * mp->root[b] + 9);      // about its tree's root
                 const T *Mb = mp->mass + 36 * b;
                 auto blk = [](const T *m6, int r0, int c0) {
                     M3<double> o;
@@ -2487,8 +2307,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 // sums (until round 4) it made every accumulator a value that is live from its zero on, through this never
                 // taken branch, to its first real term: 3 % of the launch for every model without viscosity.
                 if (!SPEC && mp->has_visc && useB) {
-                    const M3<double> Rv = ld_m3(PD + 12 * b);
-                    const V3<double> pv = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);
+                    const M3<double> Rv = ld_m3(PD + PDS * b);
+                    const V3<double> pv = ld_v3(PD + PDS * b + 9) - ld_v3(PD + PDS * mp->root[b] + 9);
                     auto rotv = [&](const M3<double> &Xm) { return mul(Rv, mulBT(Xm, Rv)); };
                     const T *Vb = mp->visc + 36 * b;
                     const M3<double> B11 = rotv(blk(Vb, 0, 0)), B12 = rotv(blk(Vb, 0, 3)), B21 = rotv(blk(Vb, 3, 0)), B22 = rotv(blk(Vb, 3, 3));
@@ -2566,11 +2386,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     // first pass: M | rhs, whose rows the body lanes have written already (the pass over the 36 entries of
                     // A, still in registers, runs inside the consumer below once the first has been consumed: the table is
                     // half as large that way, and the body block never holds more than A and Mg in registers)
-                    if (bstream) {
-                        // (round 4: the body lanes have written their table rows -- everything with one pass, M | rhs with two)
-                        if constexpr (TWO_PASS) tb_pass(std::integral_constant<int, TB_PASS1>{}, std::integral_constant<int, NACC - TB_PASS1>{}, true);
-                        else tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NACC>{}, true);
-                    } else
                     if constexpr (TWO_PASS) tb_pass(std::integral_constant<int, TB_PASS1>{}, std::integral_constant<int, NACC - TB_PASS1>{}, true);
                     else tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NACC>{}, false);
                     // (c) happens in the consumer below, which streams the two table rows of body(k) straight
@@ -2600,9 +2415,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 T omk[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) omk[i] = __shfl(om_b[i], bsrc);
-                const M3<double> R = ld_m3(PD + 12 * bsrc);
-                p0k = ld_v3(PD + 12 * mp->root[bsrc] + 9);
-                const V3<double> p = ld_v3(PD + 12 * bsrc + 9) - p0k;
+                const M3<double> R = ld_m3(PD + PDS * bsrc);
+                p0k = ld_v3(PD + PDS * mp->root[bsrc] + 9);
+                const V3<double> p = ld_v3(PD + PDS * bsrc + 9) - p0k;
                 const int kc = lane < RS ? lane : 0;
                 const V3<double> sw = v3<double>((double)SC[0 * RS + kc], (double)SC[1 * RS + kc], (double)SC[2 * RS + kc]);
                 const V3<double> sv = v3<double>((double)SC[3 * RS + kc], (double)SC[4 * RS + kc], (double)SC[5 * RS + kc]);
@@ -2680,11 +2495,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                         if constexpr ((i2 & 3) == 3) asm volatile("" ::: "memory");   // four row pairs in flight
                     });
                     WAVE_SYNC();                   // every lane has consumed the first pass: the table is rewritten
-                    if (bstream) {
-                        if (lane < nb) body_A();   // (the rows of A straight into the table, Mg formed again: see the body block)
-                        WAVE_SYNC();
-                        tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, TB_PASS1>{}, true);
-                    } else
                     tb_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, TB_PASS1>{}, false);
                     static_for_asc(std::make_integer_sequence<int, TB_PASS1 / 2>{}, [&](auto i2c) {
                         constexpr int i2 = decltype(i2c)::value;
@@ -2711,7 +2521,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 // the constraint rows and the joint-limit selectors are written (entries >= ndof of a row stay zero)
                 // (body-space columns: six rows per pair of bodies, padded to whole slabs of four for phase D)
                 const int rt_rows = BODYCOL ? 4 * ((6 * ARB_UNI(mp->nbp) + 3) / 4) : ndol;
-                if constexpr (!MFMA_ROWS) { for (int i = lane; i < (1 + rt_rows) * RS; i += WAVE) RT[i] = T(0); }
+                for (int i = lane; i < (1 + rt_rows) * RS; i += WAVE) RT[i] = T(0);
                 if (lane < n) {
                     double *o = STG + XPR_STRIDE * lane;
 #pragma unroll
@@ -2721,135 +2531,6 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             }
             // ---- lane = column k: rows of Z ----------------------------------------------------------
             ARB_BSTAMP(5);
-            if constexpr (MFMA_ROWS) {
-                // On the matrix cores, in float64 (round 4; float32 worlds on the 44- and 48-row tiles).  The rows of Z are two
-                // matrix products over the dof index pairs (i, k):  U[i][k] = X_i . G_k  (rows at or above the joint of k:
-                // i <= e_k)  and  L[i][k] = [P_i | R_i] . [X_k | dX'_k]  (rows below), 6 and 12 terms deep, 44 x 44 results.
-                // The vector-ALU version walks the 44 rows one after the other, every lane its own column: 9 broadcast LDS
-                // reads and 18 float64 multiply-adds per row, ~1850 instructions and 20 k cycles of a step in which nothing
-                // else of the wave can issue.  v_mfma_f64_16x16x4_f64 computes a 16 x 16 tile four terms deep per
-                // instruction (tools/mfma_f64_layout_probe.hip: A operand lane l = A[l % 16][l / 16], B operand lane l =
-                // B[l / 16][l % 16], result register v of lane l = D[l / 16 + 4 v][l % 16]; one issue per 16 cycles, 64
-                // cycles of latency): 9 tiles x (2 + 3) instructions.  The A side -- X | P | R of every dof -- is the XPR
-                // array as it stands; the B side -- G, X | dX' of the 16 dofs of a tile column -- and the results travel
-                // through the space of RT, which is not yet in use (its zeroing moves behind this block): tile column by
-                // tile column, so that 1536 bytes are enough whatever the model's number of constraints.  Same sums in a
-                // different order than the row loop: a float32 entry of Z may differ by an ulp from the round-3 kernels;
-                // every build of the step kernel (two / three waves, packed, inspect) runs this code, so they stay
-                // bit-identical to one another.
-                typedef double d4 __attribute__((ext_vector_type(4)));
-                typedef T V4 __attribute__((ext_vector_type(4)));
-                constexpr int NT = (NMAX + 15) / 16;
-                const int lj = lane & 15, lg = lane >> 4;
-                const unsigned long long rel = (lane < n) ? (mp->upmask[lane] | mp->descmask[lane]) : 0ull;
-                const int rel_lo = (int)(unsigned)rel, rel_hi = (int)(unsigned)(rel >> 32);
-                const int e_k = (lane < n) ? (mp->dof_off[bsrc] + mp->jnd[bsrc] - 1) : -1;
-                double *BS = reinterpret_cast<double *>(RT);        // B-side staging: [16 dofs][6 or 12]
-                T *OS = RT;                                         // result staging: [8 columns][16 NT positions]
-                static_for_asc(std::make_integer_sequence<int, NT>{}, [&](auto kc) {
-                    constexpr int K = decltype(kc)::value;
-                    const bool mycol = lg == K;                      // lanes 16 K .. 16 K + 15: the dofs of this tile column
-                    // what this lane's results belong to: column 16 K + lj
-                    const int src = 16 * K + lj;
-                    const int ecol = __shfl(e_k, src);
-                    const unsigned rlo = (unsigned)__shfl(rel_lo, src), rhi = (unsigned)__shfl(rel_hi, src);
-                    // Which products does tile (I, K) need?  Rows above the tile column's dofs (I < K) are all at or above the
-                    // joint: U only.  Two tiles below the diagonal and further (I > K + 1) every row lies below every
-                    // joint of the column (e_k <= k + 5): L only.  The diagonal tile and the one below it need both.
-                    d4 accU[NT], accL[NT];
-#pragma unroll
-                    for (int I = 0; I < NT; ++I) { accU[I] = d4{0., 0., 0., 0.}; accL[I] = d4{0., 0., 0., 0.}; }
-                    // ---- U = X^T G: the column's G vectors to LDS, two instructions per tile (6 terms in 2 x 4)
-                    if (mycol) {
-                        double *o = BS + 6 * lj;
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) o[i] = Gk[i];
-                    }
-                    WAVE_SYNC();
-                    {
-                        const double b0 = BS[6 * lj + lg], b1 = (lg < 2) ? BS[6 * lj + 4 + lg] : 0.;
-#pragma unroll
-                        for (int I = 0; I < NT; ++I) {
-                            if (I > K + 1) continue;
-                            const int irow = (16 * I + lj < RS) ? 16 * I + lj : RS - 1;        // (rows beyond the tile: masked below)
-                            const double *xa = STG + XPR_STRIDE * irow;
-                            const double a0 = xa[lg], a1 = (lg < 2) ? xa[4 + lg] : 0.;
-                            accU[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accU[I], 0, 0, 0);
-                            accU[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accU[I], 0, 0, 0);
-                        }
-                    }
-                    WAVE_SYNC();
-                    // ---- L = [P | R]^T [X | dX']: three instructions per tile (12 terms)
-                    if (mycol) {
-                        double *o = BS + 12 * lj;
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) { o[i] = Xk[i]; o[6 + i] = dXk[i]; }
-                    }
-                    WAVE_SYNC();
-                    {
-                        const double b0 = BS[12 * lj + lg], b1 = BS[12 * lj + 4 + lg], b2 = BS[12 * lj + 8 + lg];
-#pragma unroll
-                        for (int I = 0; I < NT; ++I) {
-                            if (I < K) continue;
-                            const int irow = (16 * I + lj < RS) ? 16 * I + lj : RS - 1;
-                            const double *xa = STG + XPR_STRIDE * irow + 6;
-                            const double a0 = xa[lg], a1 = xa[4 + lg], a2 = xa[8 + lg];
-                            accL[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accL[I], 0, 0, 0);
-                            accL[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accL[I], 0, 0, 0);
-                            accL[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accL[I], 0, 0, 0);
-                        }
-                    }
-                    // ---- select by row (at or above the joint: U, below: L), mask the unrelated rows, round to T
-                    V4 res[NT];
-#pragma unroll
-                    for (int I = 0; I < NT; ++I) {
-                        T r4[4];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int i = 16 * I + lg + 4 * v;                                  // the row this register holds
-                            T val;
-                            if (I < K) val = (T)accU[I][v];
-                            else if (I > K + 1) val = (T)accL[I][v];
-                            else val = (i <= ecol) ? (T)accU[I][v] : (T)accL[I][v];
-                            const bool on = (((16 * I + 4 * v < 32 ? rlo : rhi) >> ((16 * I + 4 * v + lg) & 31)) & 1u) != 0u;
-                            r4[v] = on ? val : T(0);
-                        }
-                        res[I] = V4{r4[0], r4[1], r4[2], r4[3]};
-                    }
-                    WAVE_SYNC();                    // (every lane has read its B operands: the staging space turns over)
-                    // ---- results to their column lanes, eight columns at a time: lane (lg, lj) stores the four rows
-                    // lg + 4 v of tile row I as ONE 16-byte vector at position 16 I + 4 lg of its column, the column's
-                    // lane reads vector 4 I + g back as rows 16 I + g + 4 v
-                    constexpr int OSS = 16 * NT;                     // positions per column
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if ((lj >> 3) == h) {
-                            V4 *o = reinterpret_cast<V4 *>(OS + (lj & 7) * OSS + 4 * lg);
-#pragma unroll
-                            for (int I = 0; I < NT; ++I) o[4 * I] = res[I];
-                        }
-                        WAVE_SYNC();
-                        if (mycol && (lj >> 3) == h) {
-                            const V4 *c4 = reinterpret_cast<const V4 *>(OS + (lj & 7) * OSS);
-#pragma unroll
-                            for (int I = 0; I < NT; ++I)
-#pragma unroll
-                                for (int g = 0; g < 4; ++g) {
-                                    if (16 * I + g >= NMAX) continue;
-                                    const V4 r = c4[4 * I + g];
-                                    Z[16 * I + g] = r.x;
-                                    if (16 * I + g + 4 < NMAX) Z[16 * I + g + 4] = r.y;
-                                    if (16 * I + g + 8 < NMAX) Z[16 * I + g + 8] = r.z;
-                                    if (16 * I + g + 12 < NMAX) Z[16 * I + g + 12] = r.w;
-                                }
-                        }
-                        WAVE_SYNC();
-                    }
-                });
-                // RT = [rhs | rows of J'] starts from zero (see above)
-                for (int i = lane; i < (1 + ndol) * RS; i += WAVE) RT[i] = T(0);
-                WAVE_SYNC();
-            } else
             {
                 typedef double D2 __attribute__((ext_vector_type(2)));
                 // DFS numbering: rows related to column k are ancestors' (or own) dofs up to the last own dof
@@ -2921,7 +2602,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 for (int p = 0; p < nbp; ++p) {
                     if ((actm & mp->pair_cmask[p]) == 0ull) continue;      // no contact of the pair is active: the rows stay zero
                     const double sgn = (double)((mp->pair_a1[p] >> lane) & 1ull) - (double)((mp->pair_a0[p] >> lane) & 1ull);
-                    const V3<double> o = ld_v3(PD + 12 * mp->pair_ref[p] + 9) - p0k;
+                    const V3<double> o = ld_v3(PD + PDS * mp->pair_ref[p] + 9) - p0k;
                     const V3<double> xw = v3<double>(Xk[0], Xk[1], Xk[2]);
                     const V3<double> jv = v3<double>(Xk[3], Xk[4], Xk[5]) + cross(xw, o);       // velocity of the point o
                     if (lane < n) {
@@ -2951,7 +2632,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                     const M3<double> Rx = ld_m3_as<double>(cd + CD_R1);
                     // (the frame was stored about the root of body 1's tree; the columns of a dof of another tree are about
                     // that tree's root: shift by the difference -- exactly zero inside the frame's own tree)
-                    const V3<double> px = cvt_v3<double>(ld_v3(cd + CD_P1)) + mv(Rx, p0k - ld_v3(PD + 12 * ci[6] + 9));
+                    const V3<double> px = cvt_v3<double>(ld_v3(cd + CD_P1)) + mv(Rx, p0k - ld_v3(PD + PDS * ci[6] + 9));
                     const V3<double> cw = mv(Rx, v3<double>(Xk[0], Xk[1], Xk[2]));
                     const V3<double> cv = mv(Rx, v3<double>(Xk[3], Xk[4], Xk[5])) + cross(px, cw);
                     if (lane < n) {
@@ -2967,8 +2648,8 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // ---- inspect: body Jacobians J_b = Ad(b<-g) X, dJ_b = Ad(b<-g) dX' + ad(Om_b) J_b -----------
             if (MODE == 1 && step == 0 && (dbg.jac != nullptr || dbg.djac != nullptr)) {
                 for (int b = 0; b < nb; ++b) {
-                    const M3<double> R = ld_m3(PD + 12 * b);
-                    const V3<double> p = ld_v3(PD + 12 * b + 9) - ld_v3(PD + 12 * mp->root[b] + 9);
+                    const M3<double> R = ld_m3(PD + PDS * b);
+                    const V3<double> p = ld_v3(PD + PDS * b + 9) - ld_v3(PD + PDS * mp->root[b] + 9);
                     const V3<double> obw = v3<double>((double)bcast(om_b[0], b), (double)bcast(om_b[1], b), (double)bcast(om_b[2], b));
                     const V3<double> obv = v3<double>((double)bcast(om_b[3], b), (double)bcast(om_b[4], b), (double)bcast(om_b[5], b));
                     const bool mine = (lane < n) && ((mp->anc[b] >> lane) & 1ull);
@@ -3122,10 +2803,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 growth_bits = (zb - pb > growth_bits) ? zb - pb : growth_bits;
             }
         };
-#ifndef ARB_ELIM_MFMA_ALL
-#define ARB_ELIM_MFMA_ALL 0     // experiment (round 4): 1 = EVERY float32 production kernel eliminates on the matrix cores (what CM = 1 selects)
-#endif
-        if constexpr ((CM == 1 || (ARB_ELIM_MFMA_ALL && MODE == 0 && NMAX < WAVE && !ELIM64)) && std::is_same<T, float>::value) {
+        if constexpr (CM == 1 && std::is_same<T, float>::value) {
             // ---- matrix-core elimination (float32): one pivot = one rank-1 update of the whole register tile,
             // issued as NMAX/4 v_mfma_f32_4x4x1_16b_f32: the 16 4x4 blocks of one instruction are the 64 columns
             // (lane = column, B operand = this lane's entry of the scaled pivot row) times four rows (the four
@@ -3354,7 +3032,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             const int nb6 = BODYCOL ? 6 * ARB_UNI(mp->nbp) : 0;
             const int nslab = BODYCOL ? (nb6 + 3) / 4 : nc;
             T *const OV = BODYCOL ? lds + ARB_UNI(ARB_LAY().vb) : VV, *const OA = BODYCOL ? lds + ARB_UNI(ARB_LAY().yb) : AM;
-            const int ost = BODYCOL ? nb6 : ndol;
+            const int ost = BODYCOL ? nb6 : lda, orows = BODYCOL ? nb6 : ndol;
             bool anyact = false;
             if constexpr (BODYCOL) anyact = __ballot(lane < nc && CD[(lane < nc ? lane : 0) * CD_STRIDE + CD_ACTIVE] != T(0)) != 0ull;
 #if ARB_PHASE_D_MFMA
@@ -3410,18 +3088,18 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int idx = 4 * c + i;
-                        if (BODYCOL && idx >= ost) continue;
+                        if (BODYCOL && idx >= orows) continue;
                         if (lane == n) OV[idx] = out[i];
                         else if (lane > n && lane < ncols) OA[idx * ost + (lane - n - 1)] = out[i];
                         if (NSETS == 2) {
                             if (WAVE + lane == n) VV[idx] = out2[i];
-                            else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = out2[i];
+                            else if ((WAVE + lane) < ncols) AM[idx * lda + (WAVE + lane - n - 1)] = out2[i];
                         }
                     }
                 }
             } else
 #endif
-            for (int idx = 0; idx < ost; ++idx) {
+            for (int idx = 0; idx < orows; ++idx) {
                 // row idx of J' (zero beyond ndof), read as 16/32-byte LDS vectors (wave-uniform address)
                 const V4 *jr4 = reinterpret_cast<const V4 *>(RT + (1 + idx) * RS);
                 ZT acc = ZT(0), acc2 = ZT(0);
@@ -3464,7 +3142,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                 else if (lane > n && lane < ncols) OA[idx * ost + (lane - n - 1)] = (T)acc;
                 if (NSETS == 2) {
                     if (WAVE + lane == n) VV[idx] = (T)acc2;
-                    else if ((WAVE + lane) < ncols) AM[idx * ndol + (WAVE + lane - n - 1)] = (T)acc2;
+                    else if ((WAVE + lane) < ncols) AM[idx * lda + (WAVE + lane - n - 1)] = (T)acc2;
                 }
             }
             WAVE_SYNC();
@@ -3506,7 +3184,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                         a0 += t * (double)w4.x; a1 += t * (double)w4.y; a2 += t * (double)w4.z; a3 += t * (double)w4.w;
                     }
                     const V4 acc = {(T)a0, (T)a1, (T)a2, (T)a3};
-                    *reinterpret_cast<V4 *>(AM + row * ndol + 4 * c4) = acc;
+                    *reinterpret_cast<V4 *>(AM + row * lda + 4 * c4) = acc;
                 }
                 WAVE_SYNC();
             }
@@ -3539,7 +3217,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         WAVE_SYNC();
         if (MODE == 1 && dbg.vel_free != nullptr && lane < n) dbg.vel_free[w * n + lane] = RT[lane];
         if (MODE == 1 && do_constraints) {
-            if (dbg.c_adm != nullptr) for (int i = lane; i < ndol * ndol; i += WAVE) dbg.c_adm[(long)w * ndol * ndol + i] = AM[i];
+            if (dbg.c_adm != nullptr) for (int i = lane; i < ndol * ndol; i += WAVE) dbg.c_adm[(long)w * ndol * ndol + i] = AM[(i / ndol) * lda + i % ndol];
             if (dbg.c_vel != nullptr) for (int i = lane; i < ndol; i += WAVE) dbg.c_vel[(long)w * ndol + i] = VV[i];
         }
 
@@ -3562,7 +3240,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // the next launch applies the forces (integrate_from_rt above)
             const int ncol_s = 1 + ndol;
             for (int i = lane; i < ncol_s * n; i += WAVE) sio.sol[(long)w * ncol_s * n + i] = RT[(i / n) * RS + (i % n)];
-            for (int i = lane; i < ndol * ndol; i += WAVE) sio.A[(long)w * ndol * ndol + i] = AM[i];
+            for (int i = lane; i < ndol * ndol; i += WAVE) sio.A[(long)w * ndol * ndol + i] = AM[(i / ndol) * lda + i % ndol];
             for (int i = lane; i < ndol; i += WAVE) {
                 sio.v[w * ndol + i] = VV[i]; sio.f[w * ndol + i] = FF[i]; sio.f0[w * ndol + i] = FF0[i];
             }
@@ -3662,7 +3340,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
                              lds + ARB_UNI(lp.sa_ff), AM, CD, VV, FF, WORK, two);
             } else {
                 using GSG = std::conditional_t<(ARB_GS_F64 != 0) && std::is_same<T, float>::value, double, T>;
-                gs_stage<T, MODE, GSG, !(sizeof(T) == 8 && NMAX == 64), SPEC>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
+                gs_stage<T, MODE, GSG, !(sizeof(T) == 8 && NMAX == 64), SPEC>(mp, lane, nc, ndol, lda, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
             }
         }
 
@@ -3756,6 +3434,7 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
     }     // work items
 }
 #undef do_constraints
+#undef lda
 #undef ARB_LDS_POINTERS
 #undef ARB_UNI
 
@@ -3791,7 +3470,7 @@ __global__ __launch_bounds__(WAVE, WV) void arb_gsw_kernel(
     WAVE_SYNC();
     DebugOut<T> nodbg;
     nodbg.gs_stats = nullptr; nodbg.gs_trace = nullptr; nodbg.ablate = 0;
-    gs_stage<T, 0>(mp, lane, nc, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, nodbg, w);
+    gs_stage<T, 0>(mp, lane, nc, ndol, ndol, dt, inv_dt, AM, CD, VV, FF, WORK, nodbg, w);
     if (lane < ndol) wsf[w * ndol + lane] = FF[lane];
 }
 
@@ -4305,22 +3984,28 @@ static std::vector<double> h12(const double *H16, int count) {
 // scan of the larger trees runs across all bodies of the wavefront)
 static bool lds_scan(int nb, int rs) { return nb <= 24 && rs <= 48; }
 // (nbp > 0: the layout of the BODYCOL kernels -- behind Y' the body-space admittance, velocity and the half product W)
-static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass, int bd_stride = BD_STRIDE, int nbp = 0) {
+static int rt_rows_of(int nbp, int ndol) { return std::max(1 + (nbp > 0 ? 4 * ((6 * nbp + 3) / 4) : ndol), 12); }
+// W (6 nbp x ndol) is live between the matrix-core products of phase D, which are the last to read the rows of J in RT, and the
+// solution columns' write-back into RT: it borrows that space when it fits
+static bool bc_w_in_rt(int nbp, int ndol, int rs) { return 6 * nbp * ndol <= rt_rows_of(nbp, ndol) * rs; }
+static int bd_region_elems(int nb, int rs, int ndol, int elems_per_double, bool two_pass, int bd_stride = BD_STRIDE, int nbp = 0, int ndof = 0) {
     auto al = [](int x) { return (x + 3) & ~3; };
     const int tb = lds_scan(nb, rs) ? al(nb * (two_pass ? TB_STRIDE : TB_STRIDE1) * elems_per_double) : 0;
-    const int am = al(std::max(ndol * ndol, 4)) + (nbp > 0 ? al(36 * nbp * nbp) + al(6 * nbp) + al(6 * nbp * ndol) : 0);
-    return std::max(std::max(std::max(al(nb * bd_stride), al(XPR_STRIDE * rs * elems_per_double)), tb), am);
+    // (Y' with rows of ndol + 4 elements: see gs_stage; the half product W of the BODYCOL kernels lives in RT's space when it fits)
+    const int am = al(std::max(ndol * (ndol + 4), 4)) + (nbp > 0 ? al(36 * nbp * nbp) + al(6 * nbp) + (bc_w_in_rt(nbp, ndol, rs) ? 0 : al(6 * nbp * ndol)) : 0);
+    // (the X | P | R vectors: one row per DOF -- rows n .. rs - 1 of the tile are never read; 0: callers that only know the tile)
+    return std::max(std::max(std::max(al(nb * bd_stride), al(XPR_STRIDE * (ndof > 0 ? ndof : rs) * elems_per_double)), tb), am);
 }
 
 static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_per_double, int *total_elems, bool two_pass = false,
-                          bool pack = false, int nbp = 0) {
+                          bool pack = false, int nbp = 0, int ndof = 0) {
     auto al = [](int x) { return (x + 3) & ~3; };
     Layout L;
     int o = 0;
     L.q = o; o += al(nq);
     L.dq = o; o += al(rs);                           // (one element per tile row; 64 until round 5)
-    L.pd = o; o += al(nb * 12 * elems_per_double);   // body poses kept in float64 (see phase A)
-    L.rt = o; L.sc = o; o += std::max(1 + (nbp > 0 ? 4 * ((6 * nbp + 3) / 4) : ndol), 12) * rs;
+    L.pd = o; o += al(nb * PDS * elems_per_double);  // body poses kept in float64 (see phase A)
+    L.rt = o; L.sc = o; o += rt_rows_of(nbp, ndol) * rs;
     L.cd = o; o += al(nc * CD_STRIDE);               // (nothing without constraints: every access is inside a loop over them)
     L.vv = o; o += al(std::max(ndol, 4));
     L.ff = o; o += al(std::max(ndol, 4));
@@ -4340,9 +4025,10 @@ static Layout make_layout(int nb, int nq, int nc, int ndol, int rs, int elems_pe
     // the gravity wrench, 6 elements per body more -- 3 KB for a float64 snake-64, the difference between four and five
     // wavefronts per CU for the step kernels) then only lengthen the allocation, every other offset is shared
     L.bd = o; L.am = o;
-    const int bd_step = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE, nbp);
-    const int bd_insp = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE_INSPECT, nbp);
-    L.yb = L.am + al(std::max(ndol * ndol, 4)); L.vb = L.yb + al(36 * nbp * nbp); L.wst = L.vb + al(6 * nbp);
+    const int bd_step = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE, nbp, ndof);
+    const int bd_insp = bd_region_elems(nb, rs, ndol, elems_per_double, two_pass, BD_STRIDE_INSPECT, nbp, ndof);
+    L.yb = L.am + al(std::max(ndol * (ndol + 4), 4)); L.vb = L.yb + al(36 * nbp * nbp);
+    L.wst = (nbp > 0 && bc_w_in_rt(nbp, ndol, rs)) ? L.rt : L.vb + al(6 * nbp);
     L.total_inspect = o + bd_insp;
     o += bd_step;
     L.sa_q = L.sa_dq = L.sa_am = L.sa_cd = L.sa_vv = L.sa_ff = L.sa_ff0 = L.sa_rt = L.sb_q = L.sb_dq = L.sb_ff = 0;
@@ -4703,24 +4389,24 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
         M->df.warn = M->dd.warn = static_cast<int *>(dp) + 1;
     }
     int tot;
-    M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot);
-    M->lf3 = M->df.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true);
-    M->lfp = M->df.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true, true);
+    M->lf = M->df.lay = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, false, false, 0, n);
+    M->lf3 = M->df.lay3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true, false, 0, n);
+    M->lfp = M->df.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tot, true, true, 0, n);
     {
         // the rendezvous build keeps three more constraint-space systems in the three-wave layout: two behind Y' in the
         // per-body region, one in the space of RT
         auto al4 = [](int x) { return (x + 3) & ~3; };
         const int nA = al4(ndol * ndol), SS = nA + al4(nc * CD_STRIDE) + 3 * al4(ndol);
-        const int bdr = bd_region_elems(nb, M->nmax, ndol, 2, true), rtr = std::max(1 + ndol, 12) * M->nmax;
+        const int bdr = bd_region_elems(nb, M->nmax, ndol, 2, true, BD_STRIDE, 0, n), rtr = std::max(1 + ndol, 12) * M->nmax;
         M->rdv_ok = M->packable && nc <= 4 && M->nsets == 1 && M->nmax >= 44 && M->nmax <= 48 && nA + 2 * SS <= bdr && SS <= rtr;
     }
-    M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot);
+    M->ld = M->dd.lay = M->dd.lay3 = M->dd.layp = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tot, false, false, 0, n);
     if ((size_t)tot * sizeof(double) > 160 * 1024) { arb_model_destroy(M); return ARB_ERR_UNSUPPORTED; }
     if (M->bodycols) {
         int tb;
-        M->lfb = M->df.layb = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tb, false, false, bc_nbp);
-        M->lfb3 = M->df.layb3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tb, true, false, bc_nbp);
-        M->ldb = M->dd.layb = M->dd.layb3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tb, false, false, bc_nbp);
+        M->lfb = M->df.layb = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tb, false, false, bc_nbp, n);
+        M->lfb3 = M->df.layb3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 2, &tb, true, false, bc_nbp, n);
+        M->ldb = M->dd.layb = M->dd.layb3 = make_layout(nb, d->nq, nc, ndol, M->nmax, 1, &tb, false, false, bc_nbp, n);
         auto fillp = [&](auto &dm) {
             dm.nbp = bc_nbp; dm.ncols_b = n + 1 + 6 * bc_nbp;
             for (int p = 0; p < bc_nbp; ++p) {
