@@ -114,9 +114,32 @@ def _write_hdf5(filename, data, mode="w"):
     from . import h5min
     merged = {}
     if mode == "a" and os.path.exists(filename):
-        merged.update(h5min.read(filename))
+        merged.update(h5min.read(filename))          # (datasets only: attributes of the old file are NOT carried over)
     merged.update(data)
-    h5min.write(filename, merged)
+    # the rewrite goes to a temporary file first: a failure midway leaves the old file as it was
+    tmp = filename + ".tmp"
+    h5min.write(tmp, merged)
+    os.replace(tmp, filename)
+
+
+def _probe_appendable(filename):
+    """Can ``_write_hdf5(filename, ..., mode='a')`` keep what the file already holds?  Called when the logger is BUILT, so that an
+    existing file the package's own reader cannot parse (chunked or compressed datasets, version-2 object headers) is
+    refused before the simulation runs instead of in ``finish()``, after it.  (With h5py there is nothing to probe.)"""
+    import os
+    try:
+        import h5py  # noqa: F401
+        return
+    except ImportError:
+        pass
+    if os.path.exists(filename):
+        from . import h5min
+        try:
+            h5min.read(filename)
+        except Exception as e:
+            raise ValueError("%s exists and cannot be appended to without h5py (%s): use mode='w', another file, or install "
+                             "h5py.  (Appending through the built-in writer rewrites the file and drops its attributes.)"
+                             % (filename, e))
 
 
 def _save_datasets(filename, data):
@@ -204,6 +227,8 @@ class Hdf5Logger(TrajectoryLogger):
         self._group = "/".join(g for g in group.split("/") if g)
         self._save_model = save_model
         self._hdf5 = filename.endswith((".h5", ".hdf5"))
+        if self._hdf5 and mode == 'a':
+            _probe_appendable(filename)
 
     @property
     def root(self):

@@ -267,7 +267,7 @@ def _read_hdf5(filename):
     return out
 
 
-def write_collada_animation(collada_animation, collada_scene, trajectory, hdf5_group="/", prefix="transforms/"):
+def write_collada_animation(collada_animation, collada_scene, trajectory, hdf5_group="/", *, prefix="transforms/"):
     """Add one ``<animation>`` per ``transforms/<name>`` dataset of ``trajectory`` to the scene file
     ``collada_scene`` and write the result to ``collada_animation``.
 
@@ -276,14 +276,20 @@ def write_collada_animation(collada_animation, collada_scene, trajectory, hdf5_g
     external ``h5toanim`` program; read here with h5py or the package's own reader --, or a mapping with ``timeline``
     (nsteps,) and ``transforms/<name>`` (nsteps, 4, 4) (``TrajectoryLogger.data``, ``batched_trajectory(...)``), or
     the path of an ``.npz`` written by ``observers.save_trajectory``.  ``hdf5_group``: the group of the file (or the
-    key prefix of the archive) the logger wrote to.  ``<name>`` must be the id of a node of the scene; whether the
+    key prefix of the archive, or of the mapping) the logger wrote to.  ``prefix`` is keyword-only: the fourth positional
+    argument is the reference's ``hdf5_group``.  ``<name>`` must be the id of a node of the scene; whether the
     matrices are absolute poses or joint poses must match the ``flat`` flag the scene was written with.
     """
     if isinstance(trajectory, str):
-        trajectory = _read_hdf5(trajectory) if trajectory.endswith((".h5", ".hdf5")) else dict(np.load(trajectory))
-        group = "/".join(g for g in hdf5_group.split("/") if g)
-        if group:
-            trajectory = {k[len(group) + 1:]: v for k, v in trajectory.items() if k.startswith(group + "/")}
+        if trajectory.endswith((".h5", ".hdf5")):
+            trajectory = _read_hdf5(trajectory)
+        elif trajectory.endswith(".npz"):
+            trajectory = dict(np.load(trajectory))
+        else:
+            raise ValueError("trajectory file %r: expected .h5 / .hdf5 (Hdf5Logger) or .npz (observers.save_trajectory)" % trajectory)
+    group = "/".join(g for g in hdf5_group.split("/") if g)
+    if group:                                      # (files, archives and mappings alike)
+        trajectory = {k[len(group) + 1:]: v for k, v in trajectory.items() if k.startswith(group + "/")}
     ET.register_namespace("", NS)
     tree = ET.parse(collada_scene)
     root = tree.getroot()

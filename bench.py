@@ -546,12 +546,25 @@ def main():
                                                    "%d-step episode (%d x %d B x worlds = %.1f MB of the figure)."
                                                    % (os.path.basename(prof), items_, EP, items_, bytes_per_world_step, handover / 1e6))
                 if res["roofline"]["traffic"] > 20 * handover:
-                    res["roofline"]["traffic_note"] += (
-                        "  The rest is SCRATCH traffic: at this batch size the library runs the kernel build compiled for three "
-                        "waves per SIMD, which spills registers (tools/so_stats.sh prints the counts of the shipped library; "
-                        "DESIGN.md has the table), and the spill stores and reloads go through the memory hierarchy (%.0f GB/s of "
-                        "the 8000 GB/s roof at this launch duration); the two-wave build (ARB_STEP_WAVES2) moves %.1f MB per launch"
-                        % (res["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9, (handover + bytes_per_world_step * B) / 1e6))
+                    # where the bytes go (round 5): the scratch instructions of the profiled launch, 256 B per wave-instruction
+                    note = ("  The rest is SCRATCH traffic of the kernel build compiled for three waves per SIMD (168 VGPRs; the "
+                            "register table of DESIGN.md 3 is generated from the shipped library)")
+                    if "SQ_INSTS_VMEM_WR" in pm and "SQ_INSTS_VMEM_RD" in pm:
+                        wr, rd = pm["SQ_INSTS_VMEM_WR"]["mean_per_launch"], pm["SQ_INSTS_VMEM_RD"]["mean_per_launch"]
+                        note += (": %.0f spill stores and %.0f reloads per world-step (vector-memory wave-instructions of 256 B; the "
+                                 "state's own loads and stores are 10 of them) = %.1f GB stored, %.1f GB loaded per launch at the "
+                                 "L1; WRITE_SIZE counts %.1f GB (stores are written through), FETCH_SIZE %.1f GB (%.0f %% of the "
+                                 "reloads are served by the L2)"
+                                 % (wr / (B * EP), rd / (B * EP), wr * 256 / 1e9, rd * 256 / 1e9, pm["WRITE_SIZE"]["mean_per_launch"] * 1024 / 1e9,
+                                    pm["FETCH_SIZE"]["mean_per_launch"] * 1024 / 1e9, 100. * (1. - pm["FETCH_SIZE"]["mean_per_launch"] * 1024 / max(rd * 256., 1.))))
+                    note += (".  FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: they include Infinity-Cache hits "
+                             "(MI355X_MICROARCH.md), and the spill footprint of the whole chip -- 3072 wavefronts x 64 lanes x 512 B = "
+                             "100 MB -- fits the 256 MiB Infinity Cache, so how much of the %.0f GB/s reaches HBM is NOT known from these "
+                             "counters (no HBM-side counter is exposed to rocprofv3 on this pool); at most %.0f %% of the 8 TB/s roof "
+                             "either way.  The two-wave build (ARB_STEP_WAVES2, no spills) moves %.1f MB per launch."
+                             % (res["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9, 100. * res["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                (handover + bytes_per_world_step * B) / 1e6))
+                    res["roofline"]["traffic_note"] += note
                 ws = float(B * EP)
                 simds, clk = 1024, 2.4e9                     # 256 CUs x 4 SIMD-32; peak shader clock
                 valu = {

@@ -116,3 +116,29 @@ def test_logger_file_modes(tmp_path):
     assert np.array_equal(back["sim/timeline"], np.arange(4.) + 1) and back["sim/transforms/Arm"].shape == (4, 4, 4)
     _write_hdf5(fn, {"only": np.zeros(3)}, "w")
     assert set(h5min.read(fn)) == {"only"}
+
+
+def test_hdf5logger_append_probes_the_existing_file_early_and_rewrites_atomically(tmp_path, monkeypatch):
+    """Hdf5Logger(mode='a') without h5py: an existing file the built-in reader cannot parse is refused when the logger is
+    BUILT (not in finish(), after the simulation has run); a readable one is kept and extended, through a temporary file."""
+    import builtins
+    from arboris_python_amd import observers, h5min
+    real_import = builtins.__import__
+
+    def no_h5py(name, *a, **kw):
+        if name == "h5py":
+            raise ImportError("h5py hidden for this test")
+        return real_import(name, *a, **kw)
+    monkeypatch.setattr(builtins, "__import__", no_h5py)
+    bad = tmp_path / "bad.h5"
+    bad.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\x02" * 200)              # a superblock version the reader does not know
+    with pytest.raises(ValueError, match="cannot be appended"):
+        observers.Hdf5Logger(str(bad), mode='a')
+    observers.Hdf5Logger(str(bad), mode='w')                            # overwriting is fine
+    good = tmp_path / "good.h5"
+    h5min.write(str(good), {"old/x": np.arange(3.)})
+    observers.Hdf5Logger(str(good), mode='a')                           # readable: accepted
+    observers._write_hdf5(str(good), {"new/y": np.ones((2, 2))}, mode="a")
+    back = h5min.read(str(good))
+    assert np.array_equal(back["old/x"], np.arange(3.)) and np.array_equal(back["new/y"], np.ones((2, 2)))
+    assert not (tmp_path / "good.h5.tmp").exists()

@@ -29,7 +29,7 @@ print("kernels:", P.KERNEL_KW or "default", bw.plan(B, T, other_inputs=True, **P
 log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False, **P.KERNEL_KW)
 torch.cuda.synchronize()
 worlds = np.arange(0, B, arg(2, 16))     # 256 worlds by default
-errs, crit, unexplained, over, diag = [], {}, [], [], dict(e_adm=0., e_vel=0., e_row=0.)
+errs, crit, unexplained, over, diag = [], {}, [], [], dict(e_adm=0., e_vel=0., e_row=0., apriori_adm=0., apriori_vel=0.)
 for k in range(0, T - 1, arg(3, 3)):       # 13 steps by default
     eq, e = P.replay_errors(m, log["q"], log["dq"], (k,), worlds, dt)
     errs.append(np.maximum(e, eq))
@@ -56,6 +56,7 @@ print("all: %d pairs, within 1e-5: %.2f %%, within 1e-4: %.2f %%, max %.1e" % (n
 print("outliers: %d, by criterion: %s" % (int((e > 1e-5).sum()), dict(sorted(crit.items()))))
 de = crit.get("d", 0) + crit.get("e", 0)
 print("criteria (d) + (e): %d = %.4f %% of the world-steps (cap %.2f %%); largest system errors among them: Y' %.1e, v' %.1e, solve rows %.1e"
-      % (de, 100. * de / n, 100 * (4e-3 if m.nc > 4 else P.DE_SHARE_CAP), diag["e_adm"], diag["e_vel"], diag["e_row"]))
+      "; the a-priori float32 bounds they had to stay inside (parity_tools.APRIORI_K): Y' %.1e, v' %.1e of the largest entry"
+      % (de, 100. * de / n, 100 * (4e-3 if m.nc > 4 else P.DE_SHARE_CAP), diag["e_adm"], diag["e_vel"], diag["e_row"], diag["apriori_adm"], diag["apriori_vel"]))
 print("above the caps (q 1e-3, dq 1e-2): %d %s" % (len(over), over))
 print("unexplained: %d %s" % (len(unexplained), unexplained[:20]))
