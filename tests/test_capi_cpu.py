@@ -423,3 +423,14 @@ def test_block_pinv_matches_numpy_pinv(dtype, tol):
     # the blocks of the reference-generated singular scenarios (tests/golden/g12_singular.npz)
     g = load_golden("g12_singular.npz")
     assert g["loop_block_singular_values"][-1] < 1e-12 and g["contact_static_block_singular_values"][-1] < 1e-12
+
+
+def test_design_register_table_is_generated_from_the_shipped_library():
+    """DESIGN.md section 3 prints the registers / spills of the shipped kernels: the block is written by
+    tools/gen_register_table.py from the library's code-object metadata (round 4's hand-written table had gone stale)."""
+    import subprocess, sys
+    tool = os.path.join(ROOT, "tools", "gen_register_table.py")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm tools not installed")
+    r = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
