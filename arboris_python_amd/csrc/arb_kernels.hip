@@ -628,6 +628,9 @@ __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, 
             // c is used).  Values go through SGPRs (v_readlane) only where the whole wave needs them.
             const G fq0 = quad_bcast<0>(fr), fq1 = quad_bcast<1>(fr), fq2 = quad_bcast<2>(fr), fq3 = quad_bcast<3>(fr);
             // own-row products (meaningful on lanes base..base+3)
+            // (measured round 5: the three four-term sums of a solve as two two-term chains joined by an addition -- two dependent
+            // operations less each --: -0.5 %.  With three waves per SIMD the sweeps are bound by the NUMBER of instructions a
+            // wave issues, not by the depth of its chain)
             const G v0r = vr - (Yrow[0] * fq0 + Yrow[1] * fq1 + Yrow[2] * fq2 + Yrow[3] * fq3);
             bool quad_done = false;      // softfinger release / static: per-lane results, see below
             G dfl = G(0), fnl = G(0);
@@ -2804,8 +2807,10 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
         int growth_bits = -(1 << 30);
         auto track_growth = [&](auto pivv, int j) {
             if constexpr (TRACK_GROWTH) {
-                const int zb = __builtin_amdgcn_readlane(__float_as_int(zdiag), j) & 0x7fffffff;
-                const int pb = __builtin_amdgcn_readfirstlane(__float_as_int((float)pivv)) & 0x7fffffff;
+                // (no masking of the sign bits: Z_jj and a healthy pivot are positive; a pivot <= 0 -- a negative integer -- makes the
+                // difference huge, and the warning is right to come)
+                const int zb = __builtin_amdgcn_readlane(__float_as_int(zdiag), j);
+                const int pb = __builtin_amdgcn_readfirstlane(__float_as_int((float)pivv));
                 growth_bits = (zb - pb > growth_bits) ? zb - pb : growth_bits;
             }
         };
@@ -2878,6 +2883,9 @@ __global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1
             // measured too: the rotation of the register tile turns a skipped update into a move, the per-group branches
             // break the interleaving of the broadcasts: -4.5 %.)
             const bool z_dense = (!SPEC && mp->has_pd) || (FEAT_ALL && pwd.kp != nullptr);
+            // (measured round 5: the groups of rows a pivot touches as a model constant -- one scalar load per pivot and a bit test
+            // per group: -3 % (the load's latency is on the pivot's path); the whole pattern in twelve scalar registers: -1 %
+            // (spilled scalar registers).  The two v_readlane per pivot of the lanes' own masks stay.)
             const unsigned long long relv = (lane < n && !z_dense) ? (mp->upmask[lane] | mp->descmask[lane]) : ~0ull;
             const unsigned rel_lo = (unsigned)relv, rel_hi = (unsigned)(relv >> 32);
             static_for_desc(std::make_integer_sequence<int, NMAX>{}, [&](auto jc) {
@@ -4111,6 +4119,7 @@ static int build_dev(arb_model *M, const arb_model_desc *d, const std::vector<in
         if (d->parent[b] < 0) m.rootmask |= 1ull << b;
     }
     fill(m.upmask, tt.upmask.data(), n); fill(m.descmask, tt.descmask.data(), n); fill(m.anc, anc.data(), nb);
+
     const std::vector<double> hpr = h12(d->H_pr, nb), hcn = h12(d->H_cn, nb);
     fill(m.Hpr, hpr.data(), 12 * nb); fill(m.Hcn, hcn.data(), 12 * nb);
     fill(m.Hpr_d, hpr.data(), 12 * nb); fill(m.Hcn_d, hcn.data(), 12 * nb);
