@@ -112,9 +112,9 @@ def load():
 
 
 def load_variants():
-    """The library of the build variants no launch of libarbstep.so selects (packed pairs, the rendezvous build;
-    `make -C arboris_python_amd/csrc variants`, float32 / 44-row kernels only): loaded by the tests that hold those
-    builds bit-identical to the shipped ones (``BatchedWorlds(model, lib=_capi.load_variants())``)."""
+    """The test library (`make -C arboris_python_amd/csrc variants`: float32 / 44-row GENERAL kernels only, sweeps that run
+    the complete local solve throughout): loaded by the tests that hold the specialised kernels and the fast sweeps of
+    the shipped library bit-identical (``BatchedWorlds(model, lib=_capi.load_variants())``)."""
     global _variants
     if _variants is None:
         _variants = _open(VARIANTS_PATH)

@@ -278,7 +278,7 @@ class BatchedWorlds(object):
     def plan(self, nworlds, nsteps=1, dtype=None, ext_gforce=False, other_inputs=False, waves=None, split=False,
              static_worlds=False, one_world=False, world_logs=False, general_kernels=False, body_columns=False):
         """Which kernel build and launch shape ``step`` would use (``arb_step_plan``): a dict with ``waves_per_simd``,
-        ``worlds_per_wavefront`` (2 = the packed build; the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``.
+        ``worlds_per_wavefront`` (the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``.
         ``world_logs``: the launch is a rollout that logs per-world energies (or states of a batch that is not a multiple
         of the forest's copies), which a small model runs one world per wavefront."""
         torch = _torch()

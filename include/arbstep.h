@@ -113,9 +113,7 @@ enum {
 #define ARB_STEP_WAVES2 64u            /* pin the float32 step kernel build: compiled for two waves per SIMD (no register spills: */
 #define ARB_STEP_WAVES3 128u           /* the faster wave) or for three (more waves in flight: the faster chip once the batch fills
                                          them).  Default: the library picks by batch size and launch shape (three waves from
-                                         ~3400 worlds on an MI355X; a third build that holds TWO worlds per wavefront is in the
-                                         library, bit-identical, but loses to three waves since their LDS fits twelve wavefronts
-                                         per CU: the knob "force_pack" of arbstep_hooks.h selects it in libarbstep_variants.so), for models that have those builds: float32, 33 .. 48 dofs (the 44- and 48-row
+                                         ~3400 worlds on an MI355X), for models that have both builds: float32, 33 .. 48 dofs (the 44- and 48-row
                                          register tiles; smaller models run faster on two waves at every batch size), ndof + 1 +
                                          4 nc <= 64.  All builds execute the same float operations in the same order per world --
                                          the library is compiled with -ffp-contract=on, so no fused multiply-add depends on how
@@ -275,10 +273,8 @@ int arb_model_get_info(const arb_model *m, arb_model_info *info);
 /*
  * Which kernel build and launch shape arb_step / arb_step_ex would use for a batch (diagnostics: the benchmark records it,
  * the tests check the batch-size rules).  The float32 step kernel of a model with 33 <= ndof <= 48 and ndof + 1 + 4 nc
- * <= 64 exists in three bit-identical builds -- two waves per SIMD (no register spills), three waves per SIMD (more waves
- * in flight), and two WORLDS per wavefront (their Gauss-Seidel sweeps in one instruction stream; contact-only models; on
- * request only: libarbstep_variants.so, knob "force_pack" of arbstep_hooks.h) -- picked by batch size and launch shape; ARB_STEP_WAVES2 /
- * ARB_STEP_WAVES3 pin one.  Models of at most 16 dofs: see ARB_STEP_ONE_WORLD.
+ * <= 64 exists in two bit-identical builds -- two waves per SIMD (no register spills) and three waves per SIMD (more waves
+ * in flight) -- picked by batch size and launch shape; ARB_STEP_WAVES2 / ARB_STEP_WAVES3 pin one.  Models of at most 16 dofs: see ARB_STEP_ONE_WORLD.
  *   wave_slots is an estimate from the registers of the build and the 1280-byte granule in which a CU's 160 KB of LDS are
  *   handed out (hipOccupancyMaxActiveBlocksPerMultiprocessor divides 160 KB by the request and overestimates: twelve
  *   wavefronts per CU fit up to 12 800 B each, not 13 653 B).
@@ -290,7 +286,7 @@ int arb_model_get_info(const arb_model *m, arb_model_info *info);
  */
 typedef struct arb_step_plan_info {
     int32_t waves_per_simd;        /* register budget the chosen build was compiled for: 1, 2 or 3 */
-    int32_t worlds_per_wavefront;  /* 1, 2 (the packed build), or the copies of a small model's forest (the other fields
+    int32_t worlds_per_wavefront;  /* 1, or the copies of a small model's forest (the other fields
                                       then describe the launch of the forest) */
     int32_t feat;                  /* optional-input set of the kernel instantiation: 0, 1 or 3; + 4: the kernel specialised for
                                       models with exactly four (eight: two column sets) enabled plane / sphere

@@ -42,11 +42,11 @@ int arb_dev_softfinger_solve(int dtype, int device, int n, const double *in, dou
  * and the wavefront routine (arb_math.h: eig6, eig6_wave) side by side; out [n][28] = shift, number found, wr[6], wi[6]
  * of the first, then of the second.  The kernels run the second; the two must agree bit for bit. */
 int arb_dev_eig6_pair(int dtype, int device, int n, const double *A, double *out);
-/* Build variants compiled into the loaded library: bit 0 packed pairs (two worlds per wavefront, knob "force_pack"),
- * bit 1 the rendezvous build (knob "force_rdv"), bit 2 Gauss-Seidel sweeps that run the complete variant of
- * the local solve throughout (no fast variant), bit 3 no specialised kernels (the general kernels also for models with four
- * plane / sphere SoftFingerContacts).  0 for libarbstep.so; 15 for libarbstep_variants.so (make variants), which the
- * bit-identity tests of those builds load. */
+/* Build variants compiled into the loaded library: bit 2 Gauss-Seidel sweeps that run the complete variant of the local solve
+ * throughout (no fast variant), bit 3 no specialised kernels (the general kernels also for models with four plane / sphere
+ * SoftFingerContacts).  0 for libarbstep.so; 12 for libarbstep_variants.so (make variants), which the bit-identity tests of the
+ * fast sweeps and of the specialised kernels load.  (Bits 0 and 1 were the packed and rendezvous builds of rounds 3 and 4:
+ * bit-identical, measured slower at every batch size, removed in round 5.) */
 int arb_build_variants(void);
 
 /* Development / test knobs of ONE handle (ABI 7: the library itself reads no environment variable; a build with
@@ -56,8 +56,7 @@ int arb_build_variants(void);
  *   "queue_chunk" (4), "queue_tail" (4)  steps per work item, single-step items at the end of an episode (0 chunk: no queue)
  *   "lds_pad" (0)               bytes of dynamic LDS added to every step-kernel workgroup (occupancy experiments)
  *   "force_waves" (0)           2 | 3: pin the float32 build whatever the flags say
- *   "force_pack" (-1), "force_rdv" (-1)   0 | 1: the packed / rendezvous build (libarbstep_variants.so only)
- *   "gsw_waves" (3), "gsw_pack" (0)       the split execution's sweep kernel: waves per SIMD; 2 | 4 worlds per wavefront
+ *   "gsw_waves" (3)             the split execution's sweep kernel: 3 | 4 waves per SIMD
  *   "ablate" (0)                inspect kernels: bit 3 = run all 20 Gauss-Seidel sweeps (no fixed-point exit)
  * Returns ARB_OK, or ARB_ERR_INVALID for an unknown name.  Applies to the handle's forest as well. */
 int arb_hook_set_knob(arb_model *m, const char *name, int value);

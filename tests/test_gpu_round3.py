@@ -315,15 +315,15 @@ def test_bench_mpc_shape():
 
 
 # ---------------------------------------------------------------------------
-# two worlds per wavefront in the Gauss-Seidel sweeps (gs_stage2) == one world per wavefront, bit for bit
+# the sweep kernel of the split execution == the fused kernel, bit for bit
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B", [("human36_c4", 1001), ("human36_c8", 301)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
-    """The packed sweep kernel of the split execution (knob gsw_pack = 1: worlds 2p and 2p+1 share a wavefront, a stage of
-    the local solve runs when either world needs it, results are taken lane by lane) against the one-world sweep kernel
-    and against the fused kernel: same forces, velocities and positions bit for bit over a whole falling episode, odd
-    batch sizes included (the last wavefront holds one world)."""
+def test_split_sweeps_equal_fused_bitwise(monkeypatch, name, B, dtype):
+    """The one-wavefront-per-world sweep kernel of the split execution (arb_gsw_kernel, three or four waves per SIMD) against
+    the fused kernel: same forces, velocities and positions bit for bit over a whole falling episode.  (Rounds 3 and 4 also
+    carried sweep kernels with two and four worlds per wavefront and the packed / rendezvous builds of the step kernel:
+    bit-identical, measured slower at every batch size -- DESIGN.md section 6 --, removed in round 5.)"""
     from arboris_python_amd import synth
     from arboris_python_amd.batch import BatchedWorlds
     m, _, _ = load_model(name)
@@ -331,10 +331,8 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
     q, dq = synth.world_states(m, range(B), "standing", 11, drop=0.03, vel=0.2)
     q[:, 7] -= 0.01
     res = {}
-    for mode in ("fused", "wave", "pack", "pack4"):
-        # (round 4: gsw_pack = 4 = FOUR worlds per wavefront for models of up to four contacts -- 16 constraint rows, a
-        # quarter of the wavefront each; with more it runs two, like knob gsw_pack = 1 / 2)
-        bw.set_knob("gsw_pack", {"pack": 1, "pack4": 4}.get(mode, 0))
+    for mode in ("fused", "wave3", "wave4"):
+        bw.set_knob("gsw_waves", 4 if mode == "wave4" else 3)
         tq, tdq = bw.to_device(q, dq, dtype)
         cf = bw.new_cforce(B, dtype)
         # (general_kernels: the split execution runs the general kernels; the fused reference must too -- the eight-contact
@@ -343,52 +341,9 @@ def test_packed_sweeps_equal_unpacked_bitwise(monkeypatch, name, B, dtype):
         torch.cuda.synchronize()
         res[mode] = (tq, tdq, cf)
     assert float(res["fused"][2][:, :, 3].max()) > 100.                      # contacts engaged, sliding included
-    for mode in ("wave", "pack", "pack4"):
+    for mode in ("wave3", "wave4"):
         assert all(torch.equal(a, b) for a, b in zip(res["fused"], res[mode])), mode
     bw.close()
-
-
-@pytest.mark.parametrize("name,cases", [
-    ("human36_c4", ((701, 40, False, False), (5001, 24, False, False), (2, 12, False, True), (1, 12, False, False),
-                    (333, 12, True, True), (9001, 13, False, True))),
-])   # (8 contacts: two column sets, no packed step kernel -- its packed SWEEPS are test_packed_sweeps_equal_unpacked_bitwise)
-def test_packed_step_kernel_equals_one_world_kernels_bitwise(monkeypatch, name, cases):
-    """The packed build of the step kernel (two worlds per wavefront: phases A-D world after world, the Gauss-Seidel
-    sweeps of both at once; libarbstep_variants.so with knob force_pack = 1) against the one-world builds of the shipped
-    library: states and forces bit for bit -- one workgroup per pair and the work queue over pairs, odd batch sizes, a
-    lone world, user torques (the FEAT 1 kernel), one launch per step."""
-    from arboris_python_amd import synth
-    from arboris_python_amd.batch import BatchedWorlds
-    m, _, _ = load_model(name)
-    variants = _capi.load_variants()
-    assert variants.arb_build_variants() & 1 and _capi.load().arb_build_variants() == 0
-    bws = {"0": BatchedWorlds(m), "1": BatchedWorlds(m, lib=variants)}
-    for B, T, per_step, ext in cases:
-        q, dq = synth.world_states(m, range(B), "standing", 31, drop=0.03, vel=0.2)
-        q[:, 7] -= 0.012
-        tau = torch.as_tensor(np.random.default_rng(5).uniform(-0.05, 0.05, size=(B, m.ndof)), dtype=torch.float32, device=bws["0"].device)
-        tau[:, :6] = 0.
-        res = {}
-        for mode in ("0", "1"):
-            bw = bws[mode]
-            bw.set_knob("force_pack", int(mode))
-            if mode == "1":
-                assert bw.plan(B, T if not per_step else 1, ext_gforce=ext)["worlds_per_wavefront"] == 2
-            tq, tdq = bw.to_device(q, dq, torch.float32)
-            cf = bw.new_cforce(B, torch.float32)
-            kw = dict(ext_gforce=tau.contiguous()) if ext else {}
-            if per_step:
-                for _ in range(T):
-                    bw.step(tq, tdq, 5e-3, 1, cforce=cf, **kw)
-            else:
-                bw.step(tq, tdq, 5e-3, T, cforce=cf, **kw)
-            torch.cuda.synchronize()
-            bw.status()
-            res[mode] = (tq, tdq, cf)
-        assert float(res["1"][2][:, :, 3].max()) > 10.
-        assert all(torch.equal(a, b) for a, b in zip(res["0"], res["1"])), (B, T, per_step, ext)
-    for bw in bws.values():
-        bw.close()
 
 
 def test_fast_sweeps_hand_over_to_the_complete_variant_bitwise(monkeypatch):
@@ -402,7 +357,7 @@ def test_fast_sweeps_hand_over_to_the_complete_variant_bitwise(monkeypatch):
     from arboris_python_amd.batch import BatchedWorlds
     m, _, _ = load_model("human36_c4")
     variants = _capi.load_variants()
-    assert variants.arb_build_variants() & 4 and _capi.load().arb_build_variants() == 0
+    assert variants.arb_build_variants() == 12 and _capi.load().arb_build_variants() == 0
     bws = {"fast": BatchedWorlds(m), "complete": BatchedWorlds(m, lib=variants)}
     B, T = 4096, 40
     q, dq = synth.standing_states(m, B, seed=1000, drop=0.03, vel=0.1)
@@ -429,49 +384,13 @@ def test_fast_sweeps_hand_over_to_the_complete_variant_bitwise(monkeypatch):
         bw.close()
 
 
-def test_rendezvous_build_equals_the_shipped_kernels_bitwise(monkeypatch):
-    """The rendezvous build (round 4; libarbstep_variants.so with knob force_rdv = 1): work items are single steps, the
-    wavefronts of worlds 4g .. 4g+3 meet at the Gauss-Seidel point -- three park their constraint-space system and draw the
-    next item, the last to arrive sweeps the four systems at once (gs_stage_n<T, 4>) and integrates the four worlds.  Against
-    the shipped library: states and forces bit for bit, batch sizes that leave one, two and three worlds in the last group,
-    a lone world, user torques (the FEAT 1 kernel).  (Measured slower than the shipped builds at every batch size,
-    DESIGN.md section 6: compiled for this test only.)"""
-    from arboris_python_amd import synth
-    from arboris_python_amd.batch import BatchedWorlds
-    m, _, _ = load_model("human36_c4")
-    variants = _capi.load_variants()
-    assert variants.arb_build_variants() & 2
-    bws = {"0": BatchedWorlds(m), "1": BatchedWorlds(m, lib=variants)}
-    for B, T, ext in ((700, 40, False), (5001, 24, False), (2, 12, True), (1, 12, False), (9003, 13, True)):
-        q, dq = synth.world_states(m, range(B), "standing", 31, drop=0.03, vel=0.2)
-        q[:, 7] -= 0.012
-        tau = torch.as_tensor(np.random.default_rng(5).uniform(-0.05, 0.05, size=(B, m.ndof)), dtype=torch.float32, device=bws["0"].device)
-        tau[:, :6] = 0.
-        res = {}
-        for mode in ("0", "1"):
-            bw = bws[mode]
-            bw.set_knob("force_rdv", int(mode))
-            tq, tdq = bw.to_device(q, dq, torch.float32)
-            cf = bw.new_cforce(B, torch.float32)
-            bw.step(tq, tdq, 5e-3, T, cforce=cf, **(dict(ext_gforce=tau.contiguous()) if ext else {}))
-            torch.cuda.synchronize()
-            bw.status()
-            res[mode] = (tq, tdq, cf)
-        assert float(res["1"][2][:, :, 3].max()) > 10.
-        assert all(torch.equal(a, b) for a, b in zip(res["0"], res["1"])), (B, T, ext)
-    for bw in bws.values():
-        bw.close()
-
-
 # ---------------------------------------------------------------------------
 # arb_step_plan: which build of the step kernel a launch gets
 # ---------------------------------------------------------------------------
 def test_step_plan_reports_the_batch_size_rules(monkeypatch):
-    """The float32 step kernel of a human36-sized model exists as a two-wave, a three-wave and a packed (two worlds
-    per wavefront) build; arb_step_plan reports which one a launch shape gets.  On an MI355X (256 CUs): two waves for
-    small batches and one-step launches, three from ~4100 worlds of a multi-step launch; the packed build only on request
-    (knob force_pack = 1: the three-wave build, whose LDS fits the 1280-byte allocation granule twelve times per CU, beats it at
-    every batch size); float64 and models with two column sets have the two-wave build only."""
+    """The float32 step kernel of a human36-sized model exists as a two-wave and a three-wave build; arb_step_plan reports
+    which one a launch shape gets.  On an MI355X (256 CUs): two waves for small batches and one-step launches, three from
+    ~3400 worlds of a multi-step launch; float64 and models with two column sets have the two-wave build only."""
     from arboris_python_amd.batch import BatchedWorlds
     m, _, _ = load_model("human36_c4")
     bw = BatchedWorlds(m)
@@ -493,22 +412,11 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     assert build(bw.plan(64 * cus, 40, waves=3)) == (3, 1)
     assert build(bw.plan(64 * cus, 40, dtype=torch.float64)) == (2, 1)
     assert bw.plan(64 * cus, 40, static_worlds=True)["work_queue"] == 0
-    # the packed build is compiled into libarbstep_variants.so only
-    variants = _capi.load_variants()
-    bwv = BatchedWorlds(m, lib=variants)
-    bw.set_knob("force_pack", 1); bwv.set_knob("force_pack", 1)
-    assert build(bw.plan(100, 40)) == (2, 1) and build(bwv.plan(100, 40)) == (2, 2)
-    bw.set_knob("force_pack", 0); bwv.set_knob("force_pack", 0)
-    assert build(bw.plan(64 * cus, 40)) == (3, 1) and build(bwv.plan(64 * cus, 40)) == (3, 1)
-    bw.close(); bwv.close()
-    # a model with a kinematic constraint (not only SoftFingerContacts) has no packed build
+    bw.close()
+    # a small model: one world per wavefront on request ...
     m, _, _ = load_model("ballsocket")
     bw = BatchedWorlds(m)
-    bwv = BatchedWorlds(m, lib=variants)
     assert bw.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
-    bwv.set_knob("force_pack", 1)
-    assert bwv.plan(64 * cus, 40, one_world=True)["worlds_per_wavefront"] == 1
-    bwv.close()
     # (by default its worlds share wavefronts another way: a forest of 5 copies, tests/test_gpu_forest.py)
     assert bw.plan(64 * cus, 40)["worlds_per_wavefront"] == bw.info["forest_copies"] == 5
     bw.close()
