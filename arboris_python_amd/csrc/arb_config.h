@@ -18,6 +18,8 @@
 #else
 #define ARB_WAVES(CM) ((CM) == 2 ? 3 : 2)
 #endif
+// (the float64 64-row kernels: see arb_step_kernel.h -- one wave per SIMD unless one column set and plain inputs)
+#define ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, CM) ((sizeof(T) == 8 && (NMAX) == 64) ? (((NSETS) == 1 && (MODE) == 0 && (FEAT) <= 1) ? 2 : 1) : ARB_WAVES(CM))
 #ifndef GS_SWEEPS
 #define GS_SWEEPS 20            // core.py:929-931 (overridable only for timing experiments: the reference's count is 20)
 #endif

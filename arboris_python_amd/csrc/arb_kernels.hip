@@ -1010,6 +1010,26 @@ extern "C" int arb_step(arb_model *M, int dtype, void *q, void *dq, void *cforce
                      flags, nullptr, stream);
 }
 
+// What would arb_step / arb_step_ex launch for this batch?  The same dispatch as step_typed with placeholder buffers (never
+// dereferenced: launch_one returns at its probe): optional_inputs 1 = user torques, 3 = every optional input.
+template <typename T>
+static int plan_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, long nw, int nsteps, unsigned flags, int optional_inputs,
+                      LaunchProbe *pr) {
+    DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
+    LogOut<T> lo; memset(&lo, 0, sizeof(lo));
+    SplitIO<T> sio; memset(&sio, 0, sizeof(sio));
+    PerWorldPD<T> pwd = {nullptr, nullptr, nullptr, nullptr};
+    T *const some = reinterpret_cast<T *>(static_cast<uintptr_t>(256));
+    if (optional_inputs == 3) lo.q = some;
+    const bool split = M->nc > 0 && (flags & ARB_STEP_SPLIT_WAVE) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
+    if (split) sio.mode = 2;          // (one launch per step: dynamics + system, then the sweep kernel)
+    g_probe = pr;
+    const int rc = launch<T, 0>(M, dm, L, some, some, M->nc > 0 ? some : nullptr, optional_inputs >= 1 ? some : nullptr, pwd, nw, 1e-3,
+                                split ? 1 : nsteps, flags, dbg, 0, lo, sio, nullptr, nullptr);
+    g_probe = nullptr;
+    return rc;
+}
+
 extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t nsteps, uint32_t flags, int32_t optional_inputs,
                              arb_step_plan_info *out) {
     if (!M || !out || nworlds < 0 || nsteps < 0 || (dtype != ARB_F32 && dtype != ARB_F64)) return ARB_ERR_INVALID;
@@ -1024,31 +1044,19 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
         return rc;
     }
     memset(out, 0, sizeof(*out));
-    const bool split = M->nc > 0 && (flags & ARB_STEP_SPLIT_WAVE) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
-    const bool noopt = optional_inputs <= 1 && !split && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
-    const bool mfma = dtype == ARB_F32 && (flags & ARB_STEP_MFMA_ELIM) && !(M->n == WAVE && M->nc == 0);
-    BuildChoice bc;
-    const bool bodyc = ARB_WITH_SPEC && M->bodycols && (M->bodycols_default || (flags & ARB_STEP_BODY_COLUMNS)) && !mfma && !split &&
-                       !(flags & (ARB_STEP_GENERAL_KERNELS | ARB_STEP_SKIP_CONSTRAINTS));
-    if (dtype == ARB_F32 && !mfma) bc = choose_build(M, (long)nworlds, split ? 1 : nsteps, flags, bodyc);
+    // the launch path itself answers (launch_one with a probe installed: nothing is allocated or launched), so the plan cannot
+    // drift from what a launch does -- the instantiation, its LDS, the wave slots from the kernel's own register count
+    LaunchProbe pr;
+    memset(&pr, 0, sizeof(pr));
+    const int rc = dtype == ARB_F32 ? plan_typed<float>(M, M->df_dev, M->lf, (long)nworlds, nsteps, flags, optional_inputs, &pr)
+                                    : plan_typed<double>(M, M->dd_dev, M->ld, (long)nworlds, nsteps, flags, optional_inputs, &pr);
+    if (rc != ARB_OK) return rc;
     out->worlds_per_wavefront = 1;
-    // (the float64 64-row kernels may use the whole register file of a SIMD: those with two column sets do -- one
-    // wavefront per SIMD --, those with one fit 256 registers)
-    out->waves_per_simd = (dtype == ARB_F64 && M->nmax == 64 && M->nsets == 2 && !bodyc) ? 1 : bc.w3 ? 3 : 2;
-    const Layout &L = bodyc ? (dtype == ARB_F64 ? M->ldb : bc.w3 ? M->lfb3 : M->lfb) : dtype == ARB_F64 ? M->ld : bc.w3 ? M->lf3 : M->lf;
-    out->lds_bytes = L.total * (dtype == ARB_F64 ? 8 : 4);
-    int cus = 0;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, M->device);
-    out->wave_slots = (int32_t)(cus * slots_per_cu(out->waves_per_simd, (long)out->lds_bytes + std::max(0, M->kn.lds_pad)));   // (the launch's own model: slots_per_cu)
-    const long units = nworlds;
-    out->work_queue = (!split && nsteps >= 2 && !(flags & ARB_STEP_STATIC_WORLDS) && units > out->wave_slots &&
-                       M->kn.queue_chunk > 0) ? 1 : 0;
-    out->feat = optional_inputs <= 0 ? 0 : optional_inputs == 1 ? 1 : 3;
-    if (!noopt) out->feat = 3;
-    if (bodyc) out->feat |= noopt ? 20 : 16;       // (4 | 16: the specialised kernels with body-space columns; 19: every optional input)
-    // (the specialised kernels, see launch(): plain inputs or user torques of a model of their class, float32)
-    if (ARB_WITH_SPEC && M->spec_ok && noopt && (dtype == ARB_F32 || M->nsets == 1) && !mfma && !(flags & ARB_STEP_GENERAL_KERNELS)) out->feat |= 4;
-    if (ARB_WITH_SPEC && M->spec0_ok && noopt && dtype == ARB_F32 && !mfma && !(flags & ARB_STEP_GENERAL_KERNELS)) out->feat |= 8;
+    out->waves_per_simd = pr.waves_compiled;
+    out->lds_bytes = (int32_t)(pr.lds_bytes - std::max(0, M->kn.lds_pad));
+    out->wave_slots = pr.wave_slots;
+    out->work_queue = pr.work_queue;
+    out->feat = pr.feat;
     return ARB_OK;
 }
 

@@ -5,10 +5,16 @@
 // ===========================================================================
 // Host side: model upload, launch dispatch, C ABI
 // ===========================================================================
+// arb_step_plan asks the launch path itself: with a probe installed (per thread) launch_one describes the launch it would make
+// -- instantiation, LDS, wave slots from the kernel's own register count, queue or not -- and returns before it allocates
+// or launches anything.
+struct LaunchProbe { int nmax, nsets, feat, cm, waves_compiled, waves_by_regs, wave_slots, work_queue; long lds_bytes; };
 #ifdef ARB_PART
 extern thread_local std::string g_hip_err;
+extern thread_local LaunchProbe *g_probe;
 #else
 thread_local std::string g_hip_err;
+thread_local LaunchProbe *g_probe = nullptr;
 #endif
 
 #define HIP_TRY(expr)                                                          \
@@ -110,6 +116,16 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
                       const CostIO<T> &cost) {
     auto kern = arb_step_kernel<T, NMAX, NSETS, MODE, FEAT, CM>;
     const size_t lds = (size_t)(MODE == 1 ? L.total_inspect : L.total) * sizeof(T) + (size_t)std::max(0, kn.lds_pad);
+    if (g_probe != nullptr) {
+        LaunchProbe &pr = *g_probe;
+        pr.nmax = NMAX; pr.nsets = NSETS; pr.feat = FEAT; pr.cm = CM; pr.lds_bytes = (long)lds;
+        pr.waves_compiled = ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, CM);
+        pr.waves_by_regs = kernel_waves_per_simd(kern);
+        pr.wave_slots = wave_slots(kern, lds);
+        pr.work_queue = (MODE == 0 && kn.queue_chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 &&
+                         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30) && pr.wave_slots > 0 && nw > pr.wave_slots) ? 1 : 0;
+        return ARB_OK;
+    }
     if (lds > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }

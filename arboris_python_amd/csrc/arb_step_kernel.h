@@ -19,7 +19,7 @@ template <typename T, int NMAX, int NSETS, int MODE, int FEAT, int CM>
 // (float64 / 64 rows: two column sets need the whole register file of a SIMD; one column set fits 256 registers and must
 // stay there -- two wavefronts per SIMD, five per CU with snake-64's LDS -- whatever else is compiled into the kernel: at
 // 258 registers config 4 ran at 12.2 instead of 13.1 M world-steps/s)
-__global__ __launch_bounds__(WAVE, (sizeof(T) == 8 && NMAX == 64) ? ((NSETS == 1 && MODE == 0 && FEAT <= 1) ? 2 : 1) : ARB_WAVES(CM)) void arb_step_kernel(
+__global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, CM)) void arb_step_kernel(
     const DevModel<T> *__restrict__ mp_in, const Layout L, T *__restrict__ gq_in, T *__restrict__ gdq_in,
     T *__restrict__ gcforce_in, const T *__restrict__ gext_in, const PerWorldPD<T> pwd_in, long nworlds, T dt_in, int nsteps,
     unsigned flags_in, const DebugOut<T> dbg, int zmode, const LogOut<T> logo_in, const SplitIO<T> sio_in,

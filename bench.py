@@ -202,7 +202,7 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
 
 
 def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True, ext=None,
-                 general=False, cost=None):
+                 general=False, cost=None, body_columns=False):
     """Run `n_episodes` whole episodes: restore the pristine states, advance `episode` steps (one arb_step
     launch per `spl` steps; default the whole episode in one launch).  Returns wall seconds between the
     two barrier + synchronize brackets, the launch durations in ms (HIP events on the launch stream =
@@ -225,6 +225,8 @@ def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=Non
     kw = {}
     if general:
         kw["general_kernels"] = True
+    if body_columns:
+        kw["body_columns"] = True
     if cost is not None:
         kw["cost"] = cost
     seq = ext is not None and ext.dim() == 3         # a torque SEQUENCE (one row per step): chunked launches take their rows
@@ -343,7 +345,7 @@ def dry_run(args, cfg):
         dist.destroy_process_group()
 
 
-def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000, general=False, min_launches=10):
+def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000, general=False, min_launches=10, body_columns=False):
     """One more workload timed like the headline (whole episodes, one launch per episode, states resident in HBM, at least
     `min_seconds` and `min_launches` launches): world-steps/s, the launch durations from HIP events on the launch stream,
     the build.  cfg["torques"]: True = one torque row per rollout, "sequence" = a torque row per step and rollout
@@ -360,7 +362,7 @@ def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000,
         cost = dict(out=torch.zeros(cfg["batch"], dtype=dt2, device=b2.device), w_q=ones, w_dq=0.01 * ones, w_tau=ones.clone())
     elif cfg.get("torques"):
         ex2 = torch.as_tensor(make_torques(mdl, 0, cfg["batch"], seed=2000), dtype=dt2, device=b2.device).contiguous()
-    kw = dict(ext=ex2, general=general, cost=cost)
+    kw = dict(ext=ex2, general=general, cost=cost, body_columns=body_columns)
     run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
     cal, _, _ = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
     n_ep = max(min_launches, int(np.ceil(min_seconds / max(cal / 2, 1e-6))))
@@ -369,7 +371,7 @@ def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000,
            "value": cfg["batch"] * n_ep * cfg["episode"] / wl, "unit": "world-steps/s",
            "kernel_ms": float(np.mean(me)), "episodes": n_ep, "steps_per_launch": cfg["episode"], "timed_region_s": wl,
            "finite": bool(torch.isfinite(qe).all() and torch.isfinite(dqe).all()),
-           "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")), general_kernels=general)}
+           "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")), general_kernels=general, body_columns=body_columns)}
     if cost is not None:
         out["cost_finite"] = bool(torch.isfinite(cost["out"]).all())
         out["mean_cost_per_rollout"] = float(cost["out"].double().mean())
@@ -650,6 +652,12 @@ def main():
         # the general kernels on the headline workload (the headline runs the kernels specialised for its model class:
         # four plane / sphere SoftFingerContacts, no PD controller, no viscosity; a human36 outside the class gets these)
         res["general_kernel"] = timed_leg(BatchedWorlds, torch, np, local_rank, cfg, 0.7, general=True)
+        # the more accurate float32 path on request (ARB_STEP_BODY_COLUMNS: the contacts' columns in body space, Y' formed
+        # with float64 sums): the headline workload; one-step errors beyond 1e-5 on 1548 states harvested from an episode
+        # 0.13 % against the default's 0.26 %, largest 2.7e-5 against 3.4e-4 (tools/experiments/step_err.py)
+        res["body_columns_f32"] = timed_leg(BatchedWorlds, torch, np, local_rank, cfg, 0.5, body_columns=True)
+        res["body_columns_f32"]["accuracy"] = ("one-step errors beyond 1e-5 on 1548 harvested states: 0.13 % (default float32 kernels "
+                                               "0.26 %), largest 2.7e-5 (3.4e-4); strict_f64: none")
         # the other BASELINE configs and the throughput regime, under the same driver clock (short legs)
         cfgs = {}
         for key, c_ in (("config2", CONFIGS[2]), ("config4", CONFIGS[4]), ("config5", CONFIGS[5]),
