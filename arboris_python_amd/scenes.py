@@ -38,18 +38,26 @@ def snake_world(nbody=64, gravity=True, is_fixed=True, **kw):
     return w
 
 
-def human36_world(contacts=0, gravity=True, friction_coeff=0.6):
-    """human36 (+ ground plane and 4 or 8 SoftFingerContacts)."""
-    assert contacts in (0, 4, 8)
+def human36_world(contacts=0, gravity=True, friction_coeff=0.6, pd=False):
+    """human36 (+ ground plane and 4, 6 or 8 SoftFingerContacts; 6 = three per foot, the reference's points 0 1 2 4 5 7).
+    ``pd``: a ProportionalDerivativeController on every hinge dof that holds the standing pose (kp 20 N m / rad, kd 2): a
+    human36 OUTSIDE the model class of the specialised kernels (bench.py's ``model_classes`` legs)."""
+    assert contacts in (0, 4, 6, 8)
     w = World()
     if contacts:
         add_groundplane(w)
     add_human36(w)
     if gravity:
         w.register(WeightController())
+    if pd:
+        from .controllers import ProportionalDerivativeController
+        from .joints import LinearConfigurationSpaceJoint
+        js = [j for j in w.getjoints() if isinstance(j, LinearConfigurationSpaceJoint)]
+        n = sum(j.ndof for j in js)
+        w.register(ProportionalDerivativeController(js, kp=20. * np.eye(n), kd=2. * np.eye(n)))
     if contacts:
-        for c in get_all_contacts(w, friction_coeff=friction_coeff):
-            if contacts == 8 or c._shapes[1].name in FOUR_CONTACTS:
+        for i, c in enumerate(get_all_contacts(w, friction_coeff=friction_coeff)):
+            if contacts == 8 or (contacts == 6 and i not in (3, 6)) or (contacts == 4 and c._shapes[1].name in FOUR_CONTACTS):
                 w.register(c)
     w.init()
     return w

@@ -259,7 +259,7 @@ def build_model(cfg):
     from arboris_python_amd import scenes
     if cfg["model"] == "snake64":
         return scenes.flat(scenes.snake_world(64))
-    return scenes.flat(scenes.human36_world(cfg["contacts"]))
+    return scenes.flat(scenes.human36_world(cfg["contacts"], pd=bool(cfg.get("pd"))))
 
 
 def make_states(cfg, model, lo, hi, seed):
@@ -665,6 +665,14 @@ def main():
             cfgs[key] = timed_leg(BatchedWorlds, torch, np, local_rank, dict(c_), 0.5, seed=1000 if key == "batch65536" else 0,
                                   min_launches=5 if key == "batch65536" else 10)
         res["configs"] = cfgs
+        # human36 OUTSIDE the model class of the specialised headline kernels (round 4 review: what does a caller get whose
+        # model differs slightly?): six floor contacts (three per foot: body-space columns, one column set), and the headline
+        # model with a PD controller on its 36 hinge dofs (the general kernels)
+        mc = {}
+        for key, c_ in (("contacts6", dict(cfg, contacts=6, name=cfg["name"].replace("4 floor", "6 floor"))),
+                        ("pd_controlled", dict(cfg, pd=True, name=cfg["name"] + " + a PD controller on the 36 hinge dofs"))):
+            mc[key] = timed_leg(BatchedWorlds, torch, np, local_rank, c_, 0.4)
+        res["model_classes"] = mc
     if n_gpus == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(model, q, dq, dt, args.cpu_seconds, EP)
         res["cpu_baseline"]["host_cores_available"] = os.cpu_count()

@@ -404,3 +404,57 @@ def test_body_space_columns_whole_episodes_and_torque_sequences():
     print("float64, 16 steps: body-space vs two column sets: max %.2e, median %.2e" % (d.max(), np.median(d)))
     assert np.median(d) < 1e-9 and (d > 1e-6).mean() < 0.02
     bw.close()
+
+
+# ---------------------------------------------------------------------------
+# a human36 outside the model class of the specialised kernels: with a PD controller (bench.py: model_classes)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_pd_controlled_human36_on_the_floor_against_the_oracle(dtype):
+    """human36 + 4 floor contacts + a ProportionalDerivativeController on its 36 hinge dofs (controllers.py:141-158: the
+    constant part into the generalized force, dt kp + kd into the impedance) runs the GENERAL kernels -- the model is outside
+    the class of the specialised ones.  States of the reference's own drop trajectory and random contact states: one step
+    against the oracle (float64 1e-8; float32 the 1e-5 gate), and a 24-step episode in one launch against 24 one-step
+    launches, bit for bit."""
+    from conftest import assert_f32_parity
+    from arboris_python_amd import scenes
+    from arboris_python_amd.batch import BatchedWorlds
+    m = scenes.flat(scenes.human36_world(contacts=4, pd=True))
+    assert m.has_pd and m.nc == 4
+    g = load_golden("g3_contacts.npz")
+    Q = np.concatenate([g["drop4_q"][:39], g["rand4_q"]]); DQ = np.concatenate([g["drop4_dq"][:39], g["rand4_dq"]])
+    dt_ = getattr(torch, dtype)
+    npt = np.float64 if dtype == "float64" else np.float32
+    bw = BatchedWorlds(m)
+    p = bw.plan(8192, 40, dtype=dt_)
+    assert p["feat"] == 0 and p["waves_per_simd"] == (3 if dtype == "float32" else 2), p
+    qi, dqi = Q.astype(npt).astype(np.float64), DQ.astype(npt).astype(np.float64)
+    oq, odq, ocf = O.step(m, qi, dqi, 5e-3)
+    tq, tdq = bw.to_device(Q, DQ, dt_)
+    cf = bw.new_cforce(len(Q), dt_)
+    bw.step(tq, tdq, 5e-3, 1, cforce=cf)
+    torch.cuda.synchronize()
+    gq, gdq = tq.double().cpu().numpy(), tdq.double().cpu().numpy()
+    if dtype == "float64":
+        assert _rel(gq, oq).max() < 1e-8 and _rel(gdq, odq).max() < 1e-8
+        assert np.abs(cf.cpu().numpy() - ocf).max() < 1e-7 * max(1., np.abs(ocf).max())
+    else:
+        assert_f32_parity(m, Q, DQ, 5e-3, gq, gdq, oq, odq, 1e-5)
+    # the PD torques matter: without the controller the step differs
+    m0 = scenes.flat(scenes.human36_world(contacts=4))
+    o0 = O.step(m0, qi, dqi, 5e-3)
+    assert _rel(o0[1], odq).max() > 1e-3
+    res = {}
+    for mode in ("episode", "per_step"):
+        tq, tdq = bw.to_device(Q, DQ, dt_)
+        cf = bw.new_cforce(len(Q), dt_)
+        if mode == "episode":
+            bw.step(tq, tdq, 5e-3, 24, cforce=cf)
+        else:
+            for _ in range(24):
+                bw.step(tq, tdq, 5e-3, 1, cforce=cf)
+        torch.cuda.synchronize()
+        res[mode] = (tq, tdq, cf)
+    assert all(torch.equal(a, b) for a, b in zip(res["episode"], res["per_step"]))
+    assert torch.isfinite(res["episode"][0]).all()
+    bw.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: many seeds of the falling-human workload at full size -- finiteness of every world, fused == wave-split
-(bitwise) on a subsample, and the fraction of sampled world-steps within 1e-5 of the oracle.
+(general kernels, bitwise) on a subsample, rollout == plain step (bitwise) on the whole batch, and the fraction of sampled world-steps within 1e-5 of the oracle.
 usage (GPU box): python tools/soak.py [nseeds]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,13 +25,18 @@ for nc in (4, 8):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         fin = bool(torch.isfinite(tq).all() and torch.isfinite(tdq).all() and torch.isfinite(cf).all())
+        # a subsample through the general kernels, fused and wave-split (the split execution runs the general kernels; the
+        # eight-contact model's default are the body-space-column kernels, equal to those to rounding only): bit patterns
         sub = np.arange(seed, B, 8)[:4096]
-        sq, sdq = bw.to_device(q[sub], dq[sub], torch.float32)
-        scf = bw.new_cforce(len(sub), torch.float32)
-        bw.step(sq, sdq, dt, T, cforce=scf, split="wave")
-        torch.cuda.synchronize()
         bits = lambda t: t.contiguous().view(torch.int32)            # (bit patterns: NaN == NaN)
-        same = bool(torch.equal(bits(sq), bits(tq[sub])) and torch.equal(bits(sdq), bits(tdq[sub])))
+        res = []
+        for split in (False, "wave"):
+            sq, sdq = bw.to_device(q[sub], dq[sub], torch.float32)
+            scf = bw.new_cforce(len(sub), torch.float32)
+            bw.step(sq, sdq, dt, T, cforce=scf, split=split, general_kernels=not split)
+            torch.cuda.synchronize()
+            res.append((sq, sdq, scf))
+        same = all(bool(torch.equal(bits(a_), bits(b_))) for a_, b_ in zip(*res))
         # the whole batch again through the plain step (no logs: the FEAT 0 kernel with the work queue; the rollout above
         # is the FEAT 3 kernel) -- bit patterns must be equal
         pq, pdq = bw.to_device(q, dq, torch.float32)
