@@ -1517,83 +1517,6 @@ __device__ bool slide_leftmost_root_qm_pc(const double pc[7], double nq, double 
                                           double *root, double step_tol, int qbase, double woff);
 #endif
 
-// The same iteration for TWO worlds in one wavefront (round 3, packed sweeps): every lane carries its own problem --
-// the lanes of a quad identical copies of their constraint's --, `want` marks the lanes whose quad slides in this solve,
-// and `anyq(b)` tells whether b holds on some sliding quad: a stage is executed when some sliding quad needs it, its
-// results are kept lane by lane under the conditions of the single-world version.  Operation for operation the
-// arithmetic of a lane is that of slide_leftmost_root_uni, so a world's root is bit-identical to the unpacked result.
-template <typename ANYQ>
-ARB_HD void slide_leftmost_root_pk(const SlidePre &k, double c1, double kappa, double warm, double step_tol, double woff,
-                                   bool want, ANYQ anyq, double *root_out, bool *ok_out) {
-    double pc[7];
-    slide_poly(k, c1, kappa, pc);
-    double x = NAN, w0 = 0., w1 = 0., w2 = 0.;
-    bool from_shift = false;
-    const bool hasw = want && (warm == warm);
-    if (anyq(hasw)) {
-        const double x0 = warm - (woff >= 0. ? woff : 1e-3 * fabs(warm)) - 1e-300;
-        double t[7];
-        for (int i = 0; i < 7; ++i) t[i] = pc[i];
-        for (int j = 0; j < 6; ++j)                 // Taylor shift: t[i] = p^(i)(x0) / i!
-            for (int i = 5; i >= j; --i) t[i] += x0 * t[i + 1];
-        const bool cert = hasw && (t[0] > 0. && t[1] < 0. && t[2] > 0. && t[3] < 0. && t[4] > 0. && t[5] < 0.);
-        x = cert ? x0 : x; w0 = cert ? t[0] : w0; w1 = cert ? t[1] : w1; w2 = cert ? 2. * t[2] : w2;
-        from_shift = cert;
-    }
-    bool fail = false;
-    if (anyq(want && !from_shift)) {
-        const double rb = k.nq + 3. * fabs(c1) + arb_fast_sqrt(fabs(kappa));
-        const bool badrb = !(rb > 0.) || !(rb < 1e300);
-        const bool mine = want && !from_shift;
-        fail = mine && badrb;
-        x = (mine && !badrb) ? (-1.0001 * rb - 1e-300) : x;
-    }
-    bool active = want && !fail, ok = false;
-    double root = 0.;
-    const double n = 6.;
-    for (int it = 0; it < 40; ++it) {
-        if (!anyq(active)) break;
-        double hp0 = 0., hp1 = 0., hp2 = 0.;
-        bool hzero = false;
-        if (anyq(active && !from_shift)) {
-            double ee = fabs(pc[6]);
-            hp0 = pc[6]; hp1 = 0.; hp2 = 0.;
-            const double ax = fabs(x);
-            for (int i = 5; i >= 0; --i) {
-                hp2 = hp2 * x + hp1; hp1 = hp1 * x + hp0; hp0 = hp0 * x + pc[i];
-                ee = ee * ax + fabs(hp0);                   // running Horner error bound
-            }
-            hp2 *= 2.;
-            hzero = fabs(hp0) <= 8.9e-16 * (2. * ee - fabs(hp0));      // p(x) = 0 to rounding
-        }
-        const double p0 = from_shift ? w0 : hp0, p1 = from_shift ? w1 : hp1, p2 = from_shift ? w2 : hp2;
-        const bool zero = from_shift ? false : hzero;
-        from_shift = false;
-        const double rad = (n - 1.) * ((n - 1.) * p1 * p1 - n * p0 * p2);
-        const bool bad = !zero && (!(p0 > 0.) || !(p1 < 0.) || !(rad >= 0.));
-        const double den = p1 - arb_fast_sqrt(rad);
-        const double dx = (n * (1. - 9.5367431640625e-07)) * p0 * arb_fast_rcp(den);
-        const double xn = x - dx;
-        const bool stall = !(xn > x);
-        const bool fin = active && (zero || bad || stall || fabs(dx) <= step_tol * fabs(xn));
-        ok = fin ? !bad : ok;
-        root = fin ? ((zero || stall) ? x : xn) : root;
-        active = active && !fin;
-        const bool shortstep = active && fabs(dx) <= 1e-2 * fabs(xn);
-        if (anyq(shortstep)) {
-            double q0 = pc[6];
-            for (int i = 5; i >= 0; --i) q0 = q0 * xn + pc[i];
-            const bool acc = shortstep && fabs(q0) <= 0.25 * step_tol * fabs(xn) * (-p1);
-            ok = acc ? true : ok;
-            root = acc ? xn : root;
-            active = active && !acc;
-        }
-        x = active ? xn : x;
-    }
-    *root_out = root;
-    *ok_out = ok && !active;
-}
-
 // The two sweep-dependent scalars of det(B - sI) from the constants of the constraint's own
 // admittance block: yc = Y_c, iyn = 1/y_n, muyn = mu/y_n, b = muyn Y_c, bsq = b.b   (constraints.py:808-812)
 template <typename T>
@@ -1812,31 +1735,6 @@ ARB_HD bool softfinger_slide_finish_noex(const T Y[16], const T alpha[4], const 
 #pragma unroll
     for (int i = 0; i < 4; ++i) { df[i] = x[i] - f[i]; f[i] = x[i]; }
     return true;
-}
-
-// packed sweeps: the exchange-free elimination for every lane; partial pivoting as well when some sliding quad needs it
-template <typename T, typename ANYQ>
-ARB_HD void softfinger_slide_finish_pk(const T Y[16], const T alpha[4], const T sie2[3], T f[4], T df[4], bool want, ANYQ anyq) {
-    T A[4][4], b[4], x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) A[i][j] = Y[4 * i + j];
-        b[i] = -alpha[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) A[i][i] -= sie2[i];                // s * diag(eps**-2)
-    const bool okx = solve4_no_exchange<T>(A, b, x);
-    if (anyq(want && !okx)) {
-        T Bv[4][1];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Bv[i][0] = b[i];
-        gepp4<T, 1>(A, Bv);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = okx ? x[i] : Bv[i][0];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { df[i] = x[i] - f[i]; f[i] = x[i]; }
 }
 
 template <typename T>
