@@ -53,6 +53,7 @@ def _cost_tensors(bw, m, dtype, B, seed=3):
     ("human36_c4", "float64", 300, 16, {}),
     ("human36_c8", "float32", 200, 16, {}),                              # two column sets
     ("simplearm", "float32", 5000, 16, {}),                              # a forest of 8 copies per wavefront (no cost there)
+    ("simplearm", "float32", 5003, 16, {}),                              # ... and three worlds left over, one per wavefront
 ])
 def test_torque_sequence_in_one_launch_equals_one_step_launches_bitwise(name, dtype, B, T, kw):
     """`O.step(..., ext_gforce=tau_t)` for t = 0 .. T-1 inside ONE launch (`ext_gforce` of rank 3) == T one-step launches fed
