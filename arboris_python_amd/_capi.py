@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libarbstep.so")
 if os.environ.get("ARBSTEP_LIB"):                 # development: load a differently built library
     LIB_PATH = os.environ["ARBSTEP_LIB"]
 
-ARB_ABI_VERSION = 7
+ARB_ABI_VERSION = 8
 ARB_OK = 0
 ARB_ERR_STALLED = 5
 ARB_F32, ARB_F64 = 0, 1
@@ -29,6 +29,9 @@ ARB_STEP_WAVES3 = 128
 ARB_STEP_ONE_WORLD = 256
 ARB_STEP_GENERAL_KERNELS = 512
 ARB_STEP_BODY_COLUMNS = 1024
+ARB_STEP_MIXED = 2048
+ARB_STEP_NO_MIXED = 4096
+ARB_WIDE_MAX = 256
 ARB_WARN_ILLCOND = 1
 ARB_ILLCOND_GROWTH = 2048.0
 
@@ -57,7 +60,8 @@ class ModelInfo(C.Structure):
     _fields_ = [("nb", C.c_int32), ("ndof", C.c_int32), ("nq", C.c_int32), ("nc", C.c_int32),
                 ("nmax", C.c_int32), ("ncols", C.c_int32), ("nsets", C.c_int32),
                 ("lds_bytes_f32", C.c_int32), ("lds_bytes_f64", C.c_int32), ("device", C.c_int32),
-                ("forest_copies", C.c_int32)]
+                ("forest_copies", C.c_int32), ("mixed_default", C.c_int32), ("wide", C.c_int32),
+                ("rest_pivot_growth", C.c_float)]
 
 
 INSPECT_FIELDS = ["pose", "twist", "jac", "djac", "M", "B", "N", "Z", "gforce0", "vel_free",
@@ -83,7 +87,7 @@ class StepArgs(C.Structure):
                 ("nworlds", C.c_int64), ("dt", C.c_double), ("nsteps", C.c_int32), ("flags", C.c_uint32),
                 ("log", C.POINTER(RolloutLog)), ("dt_steps", C.c_void_p),
                 ("ext_gforce_steps", C.c_void_p), ("pd_qdes_steps", C.c_void_p), ("pd_dqdes_steps", C.c_void_p),
-                ("cost", C.POINTER(StepCost))]
+                ("cost", C.POINTER(StepCost)), ("ext_impedance", C.c_void_p)]
 
 
 class InspectOut(C.Structure):
@@ -93,10 +97,10 @@ class InspectOut(C.Structure):
 # every symbol include/arbstep.h declares (tests check they are all exported)
 EXPORTED = ["arb_abi_version", "arb_strerror", "arb_last_hip_error", "arb_model_create",
             "arb_model_destroy", "arb_model_get_info", "arb_model_status", "arb_model_warnings", "arb_step_plan", "arb_step", "arb_step_ex", "arb_rollout",
-            "arb_inspect"]
+            "arb_inspect", "arb_inspect_ex"]
 # every symbol include/arbstep_hooks.h declares: host builds of the device math (unit tests, Constraint.solve)
 TEST_HOOKS = ["arb_hook_set_knob", "arb_dev_softfinger_solve", "arb_dev_eig6_pair", "arb_build_variants", "arb_host_softfinger_solve", "arb_host_softfinger_try", "arb_host_slide_root", "arb_host_real_root_cascade", "arb_host_eig6", "arb_host_block_pinv", "arb_host_joint_local",
-              "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase"]
+              "arb_host_exp_twist", "arb_host_zaligned", "arb_host_narrow_phase", "arb_host_growth_bits"]
 
 _lib = None
 _variants = None
@@ -165,6 +169,10 @@ def _open(path):
     lib.arb_inspect.restype = C.c_int
     lib.arb_inspect.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_double, C.c_uint32, C.POINTER(InspectOut), C.c_void_p]
+    lib.arb_inspect_ex.restype = C.c_int
+    lib.arb_inspect_ex.argtypes = [C.c_void_p, C.c_int, C.POINTER(StepArgs), C.POINTER(InspectOut), C.c_void_p]
+    lib.arb_host_growth_bits.restype = C.c_int
+    lib.arb_host_growth_bits.argtypes = [C.c_float, C.c_float]
     lib.arb_host_softfinger_solve.restype = C.c_int
     lib.arb_host_softfinger_solve.argtypes = [C.c_int, _PD, _PD, _PD, C.c_double, C.c_double,
                                               C.c_double, _PD, _PD]

@@ -2,8 +2,8 @@
 
 ``core.World.update_dynamic / update_controllers / update_constraints /
 integrate`` call ``SingleWorldEngine.run``: the world is flattened, evaluated on
-the GPU in float64 as a batch of one through ``arb_inspect`` / ``arb_step`` and the
-results are scattered back onto the objects exactly where the reference leaves
+the GPU in float64 as a batch of one through ``arb_inspect_ex`` / ``arb_step_ex`` and
+the results are scattered back onto the objects exactly where the reference leaves
 them (core.py:1272-1288 body attributes, :722-734 world matrices, :812-818
 impedance/admittance, :910-937 constraint state, :974-980 joint state).
 
@@ -11,6 +11,18 @@ Two attributes are derived on the host from device results because the device
 never forms them: ``Body.nleffects`` (from the device twist, core.py:1276-1288)
 and ``World._admittance`` (inverse of the device impedance; the kernels solve
 with Z instead of inverting it).
+
+User-defined ``Controller`` subclasses (the reference's plugin point, core.py:327-339)
+cannot be lowered to the kernels: ``update_controllers`` calls their ``update(dt)`` on
+the host, exactly where the reference does (core.py:814-817), and hands the sums of
+their ``(gforce, impedance)`` to the device as ``ext_gforce`` / ``ext_impedance``
+(ABI 8) for the rest of the step.
+
+Round 6: the flattened model is cached on a signature of everything ``flatten_world``
+reads except the state (tree, frames, masses, plugin parameters), so a ``simulate`` step
+flattens once instead of four times, and ``update_controllers`` fetches what
+``update_constraints`` will ask for in the same launch (three launches per step
+instead of four).
 """
 import numpy as np
 
@@ -20,17 +32,7 @@ from .flatten import (flatten_world, JT_FREE, CT_SOFTFINGER, CT_JOINTLIMITS,
                       CT_BALLSOCKET)
 
 _NDOL = {CT_SOFTFINGER: 4, CT_JOINTLIMITS: 1, CT_BALLSOCKET: 3}
-
-
-def _same_model(a, b):
-    da, db = a.to_npz_dict(), b.to_npz_dict()
-    if da.keys() != db.keys():
-        return False
-    for k in da:
-        x, y = da[k], db[k]
-        if x.shape != y.shape or not np.array_equal(x, y):
-            return False
-    return True
+_CONSTRAINT_OUTPUTS = ["pose", "c_sdist", "c_active", "c_force", "c_frame", "gforce"]
 
 
 def _hinv(H):
@@ -40,33 +42,98 @@ def _hinv(H):
     return out
 
 
+def _bytes(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64)).tobytes()
+
+
+def model_signature(world):
+    """Everything ``flatten_world`` reads from ``world`` EXCEPT the state (joint positions / velocities, constraint
+    forces): identity and type of every joint in dof order, the frames' offsets, the bodies' mass and viscosity
+    matrices, and the parameters of every plugin.  Two calls with equal signatures flatten to the same model."""
+    sig = [tuple(world.up)]
+    for j in world.iterjoints():
+        body = j._frame1.body
+        sig.append((id(j), type(j).__name__, _bytes(j._frame0.bpose), _bytes(j._frame1.bpose),
+                    _bytes(body.mass), _bytes(body.viscosity)))
+    for a in world._controllers:
+        entry = [id(a), type(a).__name__]
+        for name in ("gravity", "kp", "kd", "gpos_des", "gvel_des"):
+            if hasattr(a, name):
+                entry.append(_bytes(getattr(a, name)))
+        if hasattr(a, "joints"):
+            entry.append(tuple(id(j) for j in a.joints))
+        sig.append(tuple(entry))
+    for c in world._constraints:
+        entry = [id(c), type(c).__name__, bool(c.is_enabled())]
+        for name in ("_mu", "_proximity", "_eps", "_min", "_max"):
+            if hasattr(c, name):
+                entry.append(_bytes(getattr(c, name)))
+        for s in getattr(c, "_shapes", ()):
+            entry.append((type(s).__name__, id(s.frame.body), _bytes(s.frame.bpose)) +
+                         tuple(_bytes(getattr(s, k)) for k in ("radius", "half_extents", "coeffs") if hasattr(s, k)))
+        if type(c).__name__ == "BallAndSocketConstraint":
+            entry.extend((id(f.body), _bytes(f.bpose)) for f in c._frames)
+        sig.append(tuple(entry))
+    return tuple(sig)
+
+
 class SingleWorldEngine(object):
     def __init__(self, world, device=0):
         self._device = device
         self._bw = None
+        self._sig = None
+        self._host_controllers = []
         self._warm = None
+        self._ext = None                # (gforce (1,n) tensor, impedance (1,n,n) tensor) of the host controllers, this step
+        self._ahead = None              # (state key, dt, results): what update_controllers fetched for update_constraints
+        self.flatten_count = 0          # (diagnostic; tests/test_host_api.py)
 
+    # -- model and state -------------------------------------------------------
     def _prepare(self, world):
         import torch
-        m, q, dq = flatten_world(world)
-        if self._bw is None or not _same_model(self._bw.model, m):
+        sig = model_signature(world)
+        if self._bw is None or sig != self._sig:
+            host = []
+            m, q, dq = flatten_world(world, host_controllers=host)
+            self.flatten_count += 1
             if self._bw is not None:
                 self._bw.close()
             self._bw = BatchedWorlds(m, self._device)
+            self._sig, self._host_controllers = sig, host
+        else:
+            m = self._bw.model
+            q = np.concatenate([np.asarray(j.gpos, np.float64).ravel() for j in world.iterjoints()])
+            dq = np.concatenate([np.asarray(j.gvel, np.float64).ravel() for j in world.iterjoints()])
         bw = self._bw
         tq, tdq = bw.to_device(q[None], dq[None], torch.float64)
         cf = np.zeros((1, m.nc, _capi.ARB_MAXDOL))
         for c, con in enumerate(world._constraints):
             f = np.asarray(con._force, float).ravel()
             cf[0, c, :len(f)] = f
-        return m, bw, tq, tdq, cf
+        return m, bw, tq, tdq, cf, (q.tobytes(), dq.tobytes(), cf.tobytes())
+
+    def _poll_host_controllers(self, world, dt, bw):
+        """core.py:814-817 for the controllers the kernels do not know: ``gforce += gforce_a; impedance -= Z_a``."""
+        import torch
+        if not self._host_controllers:
+            self._ext = None
+            return
+        n = world.ndof
+        g, z = np.zeros(n), np.zeros((n, n))
+        for a in self._host_controllers:
+            (ga, za) = a.update(dt)
+            g += np.asarray(ga, float).reshape(n)
+            z += np.asarray(za, float).reshape(n, n)
+        self._ext = (torch.as_tensor(g[None], dtype=torch.float64, device=bw.device).contiguous(),
+                     torch.as_tensor(z[None], dtype=torch.float64, device=bw.device).contiguous())
 
     def run(self, world, stage, dt):
         import torch
-        m, bw, tq, tdq, cf = self._prepare(world)
+        m, bw, tq, tdq, cf, key = self._prepare(world)
         bodies = list(world.ground.iter_descendant_bodies())
         n = m.ndof
         tcf = torch.as_tensor(cf, dtype=torch.float64, device=bw.device).contiguous() if m.nc else None
+        ext_g, ext_z = self._ext if self._ext is not None else (None, None)
         if stage in ("geometric", "dynamic"):
             want = ["pose"] if stage == "geometric" else ["pose", "twist", "jac", "djac", "M", "B", "N"]
             r = bw.inspect(tq, tdq, 1.0, want, skip_constraints=True)
@@ -87,18 +154,29 @@ class SingleWorldEngine(object):
                 world._mass = r["M"].copy()
                 world._viscosity = r["B"].copy()
                 world._nleffects = r["N"].copy()
+                self._ext = None            # (the controllers have not been polled for this state yet)
             return
         if stage == "controllers":
-            r = bw.inspect(tq, tdq, dt, ["Z", "gforce0"], skip_constraints=True)
-            world._impedance = r["Z"].cpu().numpy()[0].copy()
-            world._gforce = r["gforce0"].cpu().numpy()[0].copy()
+            self._poll_host_controllers(world, dt, bw)
+            ext_g, ext_z = self._ext if self._ext is not None else (None, None)
+            # one launch serves this stage and the next: Z and the controllers' gforce now, the constraint outputs
+            # kept for update_constraints at the same state and dt
+            want = ["Z", "gforce0"] + (_CONSTRAINT_OUTPUTS if m.nc else [])
+            r = bw.inspect(tq, tdq, dt, want, cforce=tcf, ext_gforce=ext_g, ext_impedance=ext_z)
+            r = {k: v.cpu().numpy()[0] for k, v in r.items()}
+            world._impedance = r["Z"].copy()
+            world._gforce = r["gforce0"].copy()
             world._admittance = np.linalg.inv(world._impedance)
+            self._ahead = (key, float(dt), r) if m.nc else None
             return
         if stage == "constraints":
             self._warm = cf.copy()
-            r = bw.inspect(tq, tdq, dt, ["pose", "c_sdist", "c_active", "c_force", "c_frame", "gforce"],
-                           cforce=tcf)
-            r = {k: v.cpu().numpy()[0] for k, v in r.items()}
+            if self._ahead is not None and self._ahead[0] == key and self._ahead[1] == float(dt):
+                r = self._ahead[2]
+            else:
+                r = bw.inspect(tq, tdq, dt, _CONSTRAINT_OUTPUTS, cforce=tcf, ext_gforce=ext_g, ext_impedance=ext_z)
+                r = {k: v.cpu().numpy()[0] for k, v in r.items()}
+            self._ahead = None
             world._gforce = r["gforce"].copy()
             self._scatter_constraints(world, m, r, bodies)
             return
@@ -106,7 +184,8 @@ class SingleWorldEngine(object):
             skip = not world._constraints_done
             if m.nc and not skip and self._warm is not None:
                 tcf = torch.as_tensor(self._warm, dtype=torch.float64, device=bw.device).contiguous()
-            bw.step(tq, tdq, dt, 1, cforce=None if skip else tcf, skip_constraints=skip)
+            bw.step(tq, tdq, dt, 1, cforce=None if skip else tcf, skip_constraints=skip, ext_gforce=ext_g,
+                    ext_impedance=ext_z)
             torch.cuda.synchronize(bw.device)
             q = tq.cpu().numpy()[0]
             dq = tdq.cpu().numpy()[0]
@@ -119,6 +198,8 @@ class SingleWorldEngine(object):
                 else:
                     j.gpos[:] = q[qs]
             self._warm = None
+            self._ext = None
+            self._ahead = None
             return
         raise ValueError(stage)
 

@@ -64,15 +64,17 @@ class BatchedWorlds(object):
             return _capi.ARB_F64
         raise TypeError("state tensors must be float32 or float64")
 
-    def _check_state(self, q, dq, cforce=None, ext=None, nsteps=None):
+    def _check_state(self, q, dq, cforce=None, ext=None, nsteps=None, zimp=None):
         m = self.model
         B = q.shape[0]
         ext_shape = (B, m.ndof)
         if ext is not None and ext.dim() == 3:          # a torque SEQUENCE: one row per step (arb_step_args.ext_gforce_steps)
+            if nsteps is None:
+                raise ValueError("ext_gforce: a torque sequence (nsteps, B, ndof) is not accepted here; pass one row (B, ndof)")
             ext_shape = (int(nsteps), B, m.ndof)
         for name, t, shape in (("q", q, (B, m.nq)), ("dq", dq, (B, m.ndof)),
                                ("cforce", cforce, (B, m.nc, _capi.ARB_MAXDOL)),
-                               ("ext_gforce", ext, ext_shape)):
+                               ("ext_gforce", ext, ext_shape), ("ext_impedance", zimp, (B, m.ndof, m.ndof))):
             if t is None:
                 continue
             if tuple(t.shape) != shape:
@@ -144,7 +146,8 @@ class BatchedWorlds(object):
 
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
              stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False,
-             waves=None, one_world=False, cost=None, general_kernels=False, body_columns=False, _log=None):
+             waves=None, one_world=False, cost=None, general_kernels=False, body_columns=False, ext_impedance=None,
+             mixed=None, _log=None):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
@@ -172,9 +175,14 @@ class BatchedWorlds(object):
         ``general_kernels=True``: the general kernels also for a model of a specialised class (ARB_STEP_GENERAL_KERNELS).
         ``body_columns=True``: constraint columns in body space wherever the model qualifies (ARB_STEP_BODY_COLUMNS: the
         default where it saves the second column set -- human36 with eight contacts --; with four contacts 2 % slower and
-        half as many float32 outliers)."""
+        half as many float32 outliers).
+        ``ext_impedance`` (B,ndof,ndof): the summed impedance ``Z_a`` of user-defined controllers, ``Z -= ext_impedance``
+        (core.py:815-817), with their generalized force in ``ext_gforce``: the generic Controller plugin path (ABI 8).
+        ``mixed``: None = the library's choice (float32 buffers of a model float32 cannot eliminate -- ``self.info
+        ["mixed_default"]``: long serial chains -- run the build that eliminates in float64), True = ARB_STEP_MIXED for any
+        model, False = ARB_STEP_NO_MIXED (plain float32; ``warnings()`` reports ARB_WARN_ILLCOND)."""
         torch = _torch()
-        B = self._check_state(q, dq, cforce, ext_gforce, nsteps)
+        B = self._check_state(q, dq, cforce, ext_gforce, nsteps, ext_impedance)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         if fused:
@@ -191,9 +199,12 @@ class BatchedWorlds(object):
             flags |= _capi.ARB_STEP_GENERAL_KERNELS
         if body_columns:
             flags |= _capi.ARB_STEP_BODY_COLUMNS
+        if mixed is not None:
+            flags |= _capi.ARB_STEP_MIXED if mixed else _capi.ARB_STEP_NO_MIXED
         dts = self._dt_steps(dt, nsteps, st)
         ext_seq = ext_gforce is not None and ext_gforce.dim() == 3
-        if pd_targets is None and pd_gains is None and dts is None and not ext_seq and cost is None and _log is None:
+        if (pd_targets is None and pd_gains is None and dts is None and not ext_seq and cost is None and _log is None
+                and ext_impedance is None):
             _capi.check(self._lib.arb_step(
                 self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
                 None if cforce is None else cforce.data_ptr(),
@@ -231,6 +242,8 @@ class BatchedWorlds(object):
                 setattr(keep, field, t.data_ptr())
             a.cost = C.pointer(keep)
         a.nworlds, a.nsteps, a.flags = B, int(nsteps), flags
+        if ext_impedance is not None:
+            a.ext_impedance = ext_impedance.data_ptr()
         if _log is not None:
             a.log = C.pointer(_log)
         if dts is None:
@@ -276,17 +289,23 @@ class BatchedWorlds(object):
         return out
 
     def plan(self, nworlds, nsteps=1, dtype=None, ext_gforce=False, other_inputs=False, waves=None, split=False,
-             static_worlds=False, one_world=False, world_logs=False, general_kernels=False, body_columns=False):
+             static_worlds=False, one_world=False, world_logs=False, general_kernels=False, body_columns=False, cost=False,
+             mixed=None):
         """Which kernel build and launch shape ``step`` would use (``arb_step_plan``): a dict with ``waves_per_simd``,
         ``worlds_per_wavefront`` (the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``.
         ``world_logs``: the launch is a rollout that logs per-world energies (or states of a batch that is not a multiple
-        of the forest's copies), which a small model runs one world per wavefront."""
+        of the forest's copies), which a small model runs one world per wavefront.  ``cost``: the launch carries a running
+        cost (per world, like the energies: a small model runs one world per wavefront; it travels with the user torques)."""
         torch = _torch()
+        world_logs = world_logs or bool(cost)
+        ext_gforce = ext_gforce or bool(cost)
         code = _capi.ARB_F64 if dtype == torch.float64 else _capi.ARB_F32
         flags = self._waves_flag(waves) | self._split_flag(split) | (_capi.ARB_STEP_STATIC_WORLDS if static_worlds else 0)
         flags |= _capi.ARB_STEP_ONE_WORLD if one_world else 0
         flags |= _capi.ARB_STEP_GENERAL_KERNELS if general_kernels else 0
         flags |= _capi.ARB_STEP_BODY_COLUMNS if body_columns else 0
+        if mixed is not None:
+            flags |= _capi.ARB_STEP_MIXED if mixed else _capi.ARB_STEP_NO_MIXED
         p = _capi.StepPlan()
         _capi.check(self._lib.arb_step_plan(self._handle, code, int(nworlds), int(nsteps), flags,
                                             (3 if other_inputs else (1 if ext_gforce else 0)) | (4 if world_logs else 0), C.byref(p)))
@@ -310,13 +329,14 @@ class BatchedWorlds(object):
         return self._lib.arb_model_status(self._handle) == _capi.ARB_ERR_STALLED
 
     def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False, general_kernels=False,
-                body_columns=False):
+                body_columns=False, ext_impedance=None, pd_targets=None, pd_gains=None):
         """Evaluate one step without touching ``q``/``dq``; returns a dict of the
         requested intermediate results (names of ``arb_inspect_out``).  ``general_kernels`` / ``body_columns``: the
-        arithmetic of ``step`` with the same flag (the inspect kernel forms the constraint-space system the same way)."""
+        arithmetic of ``step`` with the same flag (the inspect kernel forms the constraint-space system the same way).
+        ``ext_impedance``, ``pd_targets``, ``pd_gains`` as for ``step`` (``arb_inspect_ex``, ABI 8)."""
         torch = _torch()
         m = self.model
-        B = self._check_state(q, dq, cforce, ext_gforce)
+        B = self._check_state(q, dq, cforce, ext_gforce, None, ext_impedance)
         n, nb, nc, nq = m.ndof, m.nb, m.nc, m.nq
         shapes = dict(pose=(B, nb, 4, 4), twist=(B, nb, 6), jac=(B, nb, 6, n), djac=(B, nb, 6, n),
                       M=(B, n, n), B=(B, n, n), N=(B, n, n), Z=(B, n, n), gforce0=(B, n),
@@ -340,9 +360,25 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         flags |= _capi.ARB_STEP_GENERAL_KERNELS if general_kernels else 0
         flags |= _capi.ARB_STEP_BODY_COLUMNS if body_columns else 0
-        _capi.check(self._lib.arb_inspect(
-            self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
-            None if cforce is None else cforce.data_ptr(),
-            None if ext_gforce is None else ext_gforce.data_ptr(),
-            B, float(dt), flags, C.byref(out), C.c_void_p(st.cuda_stream)))
+        if ext_impedance is None and pd_targets is None and pd_gains is None:
+            _capi.check(self._lib.arb_inspect(
+                self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),
+                None if cforce is None else cforce.data_ptr(),
+                None if ext_gforce is None else ext_gforce.data_ptr(),
+                B, float(dt), flags, C.byref(out), C.c_void_p(st.cuda_stream)))
+            return res
+        a = _capi.StepArgs()
+        a.q, a.dq = q.data_ptr(), dq.data_ptr()
+        a.cforce = None if cforce is None else cforce.data_ptr()
+        a.ext_gforce = None if ext_gforce is None else ext_gforce.data_ptr()
+        a.ext_impedance = None if ext_impedance is None else ext_impedance.data_ptr()
+        for names, pair in ((("pd_qdes", "pd_dqdes"), pd_targets), (("pd_kp", "pd_kd"), pd_gains)):
+            if pair is None:
+                continue
+            for name, t in zip(names, pair):
+                if tuple(t.shape) != (B, n) or not t.is_contiguous() or t.dtype != q.dtype or t.device != self.device:
+                    raise ValueError("%s must be a contiguous %s %s tensor on %s" % (name, (B, n), q.dtype, self.device))
+                setattr(a, name, t.data_ptr())
+        a.nworlds, a.nsteps, a.flags, a.dt = B, 1, flags, float(dt)
+        _capi.check(self._lib.arb_inspect_ex(self._handle, self._dtype_code(q), C.byref(a), C.byref(out), C.c_void_p(st.cuda_stream)))
         return res

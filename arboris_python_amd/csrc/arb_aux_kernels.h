@@ -39,6 +39,16 @@ __global__ __launch_bounds__(WAVE, WV) void arb_gsw_kernel(
 }
 
 // ===========================================================================
+// Element-wise conversion between float32 and float64 buffers (the promotion of float32 launches of models only float64
+// can carry, step_promoted in arb_kernels.hip): grid-stride, coalesced.
+// ===========================================================================
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void arb_cvt_kernel(const TI *__restrict__ in, TO *__restrict__ out, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) out[i] = (TO)in[i];
+}
+
+// ===========================================================================
 // Device unit test of the local solve (test hook arb_dev_softfinger_solve): one LANE per input tuple, the
 // same arb_math.h code the kernels run -- inverse of the 4x4 block, SoftFingerContact.solve with the fast
 // sliding shift or the eig6 fallback on a lane-private LDS work array.

@@ -19,7 +19,9 @@
 #define ARB_WAVES(CM) ((CM) == 2 ? 3 : 2)
 #endif
 // (the float64 64-row kernels: see arb_step_kernel.h -- one wave per SIMD unless one column set and plain inputs)
-#define ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, CM) ((sizeof(T) == 8 && (NMAX) == 64) ? (((NSETS) == 1 && (MODE) == 0 && (FEAT) <= 1) ? 2 : 1) : ARB_WAVES(CM))
+// (CM 3, round 6: the MIXED build -- float32 state and LDS, the register tile of phases C / D in float64: the registers of a
+//  float64 kernel, hence its rules)
+#define ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, CM) (((sizeof(T) == 8 || (CM) == 3) && (NMAX) == 64) ? (((NSETS) == 1 && (MODE) == 0 && (FEAT) <= 1) ? 2 : 1) : ARB_WAVES(CM))
 #ifndef GS_SWEEPS
 #define GS_SWEEPS 20            // core.py:929-931 (overridable only for timing experiments: the reference's count is 20)
 #endif
@@ -204,8 +206,10 @@ struct SplitIO {
 
 // Optional per-world PD inputs of arb_step_ex (all [nworlds][ndof], null = absent): desired
 // positions/velocities, and diagonal gains that replace the model's gain matrices.
+// (ABI 8) zimp [nworlds][ndof][ndof], null = absent: the summed impedance Z_a of the world's user-defined Controllers this step
+// (core.py:815-817: `self._impedance -= impedance`), their generalized force travels in ext_gforce
 template <typename T>
-struct PerWorldPD { const T *qdes, *dqdes, *kp, *kd; };
+struct PerWorldPD { const T *qdes, *dqdes, *kp, *kd, *zimp; };
 
 // Running cost of a rollout (arb_step_cost, ABI 7): a diagonal quadratic form of (q, dq, tau) per step, summed on chip
 template <typename T>

@@ -84,6 +84,13 @@ struct arb_model {
     bool bodycols = false;         // the same class with more contacts than one column set holds, on few pairs of bodies: body-space
                                    // constraint columns (FEAT bit 16), ONE column set -- human36 with the reference's eight contact points
     bool bodycols_default = false; // ... chosen without being asked (ARB_STEP_BODY_COLUMNS): when they save the second column set
+    // What float32 launches of this model run by default (arb_model_info.mixed_default), from the pivot growth of the float32
+    // elimination at the model's rest states (probed once at arb_model_create): 0 the float32 kernels; 1 (growth >
+    // ARB_ILLCOND_GROWTH / 8) the mixed build, CM 3: float64 elimination and right-hand side; 2 (growth > ARB_ILLCOND_GROWTH:
+    // ARB_WARN_ILLCOND territory) PROMOTION: the float64 kernels on converted copies of the buffers (step_promoted)
+    int f32_policy = 0;
+    bool mixed_default = false;    // (f32_policy >= 1: the dispatch of launch())
+    float rest_growth = 0.f;
     Layout lfb, lfb3, ldb;         // ... and their LDS layouts: float32 two-wave / three-wave, float64
     int *status_host = nullptr;    // mapped pinned words the kernels raise: [0] a work-queue wait expired (ARB_ERR_STALLED), [1] ARB_WARN_* bits
     Knobs kn;                      // development / test knobs (arb_hook_set_knob)
@@ -373,6 +380,11 @@ static int forest_copies(int nb, int n, int nc) {
 
 // fk = 1: the described world, plus its forest when it is small; fk > 1: `d` describes a forest of fk copies
 static int model_create(const arb_model_desc *d, int device, arb_model **out, int fk);
+static int probe_rest_growth(arb_model *M, const arb_model_desc *d, float *growth);
+template <typename T>
+static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const void *q, const void *dq,
+                     const void *cforce, const void *ext, long nw, double dt, unsigned flags,
+                     const arb_inspect_out *o, hipStream_t st, const arb_step_args *a = nullptr);
 
 extern "C" int arb_model_create(const arb_model_desc *d, int device, arb_model **out) {
     return model_create(d, device, out, 1);
@@ -573,16 +585,6 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
         }
         M->df_dev = static_cast<DevModel<float> *>(pf); M->dd_dev = static_cast<DevModel<double> *>(pd);
     }
-#ifdef ARB_DEVELOPMENT
-    {   // development builds: the knobs from the environment, once
-        const char *names[] = {"lds_pad", "queue_chunk", "queue_tail", "queue_spin_cap", "force_waves", "gsw_waves", "ablate"};
-        for (const char *nm : names) {
-            std::string e = std::string("ARB_") + nm;
-            for (auto &ch : e) ch = (char)toupper((unsigned char)ch);
-            if (const char *v = getenv(e.c_str())) (void)arb_hook_set_knob(M, nm, atoi(v));
-        }
-    }
-#endif
     if (with_forest) {
         const int K = forest_copies(nb, n, nc);
         if (K > 1) {
@@ -593,7 +595,67 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
             else if (frc == ARB_ERR_HIP || frc == ARB_ERR_NOMEM) { arb_model_destroy(M); return frc; }
         }
     }
+#ifdef ARB_DEVELOPMENT
+    {   // development builds: the knobs from the environment, once -- AFTER the forest exists (arb_hook_set_knob copies the
+        // knobs into the forest's handle: before round 6 the forest kept the defaults)
+        const char *names[] = {"lds_pad", "queue_chunk", "queue_tail", "queue_spin_cap", "force_waves", "gsw_waves", "ablate"};
+        for (const char *nm : names) {
+            std::string e = std::string("ARB_") + nm;
+            for (auto &ch : e) ch = (char)toupper((unsigned char)ch);
+            if (const char *v = getenv(e.c_str())) (void)arb_hook_set_knob(M, nm, atoi(v));
+        }
+    }
+#endif
+#ifndef ARB_QUICK
+    if (with_forest) {
+        // Can float32 eliminate this model's impedance matrix?  Asked once, of the float32 inspect kernel, at two states of
+        // rest (every angle 0 / every hinge angle 0.4 rad; FreeJoints at the identity), free motion, dt = 1 ms: the pivot growth
+        // max_j Z_jj / pivot_j is a property of the tree and the masses far more than of the state (snake-64: 6e4 .. 9e5
+        // whatever the pose; human36: 3 .. 81).  Above ARB_ILLCOND_GROWTH / 8 float32 launches run the mixed build by default.
+        const int prc = probe_rest_growth(M, d, &M->rest_growth);
+        if (prc != ARB_OK) { arb_model_destroy(M); return prc; }
+        M->f32_policy = M->rest_growth > (float)ARB_ILLCOND_GROWTH ? 2 : M->rest_growth > (float)(ARB_ILLCOND_GROWTH / 8.0) ? 1 : 0;
+        M->mixed_default = M->f32_policy >= 1;
+    }
+#endif
     *out = M;
+    return ARB_OK;
+}
+
+// Pivot growth of the float32 elimination at the model's states of rest (see model_create): two worlds through the
+// float32 inspect kernel, free motion.  Synchronous (part of arb_model_create).
+static int probe_rest_growth(arb_model *M, const arb_model_desc *d, float *growth) {
+    const int nq = d->nq, n = d->ndof, nb = d->nb;
+    std::vector<float> hq(2 * (size_t)nq, 0.f), hdq(2 * (size_t)n, 0.f);
+    for (int w = 0; w < 2; ++w)
+        for (int b = 0; b < nb; ++b) {
+            float *qb = hq.data() + (size_t)w * nq + d->q_off[b];
+            const int jt = d->jtype[b];
+            if (jt == ARB_JT_FREE) { qb[0] = qb[5] = qb[10] = qb[15] = 1.f; }
+            else if (jt != ARB_JT_TXTYTZ && w == 1) for (int i = 0; i < joint_ndof(jt); ++i) qb[i] = 0.4f;
+        }
+    float *dq_ = nullptr, *dv_ = nullptr, *dg_ = nullptr;
+    float hg[2] = {0.f, 0.f};
+    auto cleanup = [&]() { if (dq_) (void)hipFree(dq_); if (dv_) (void)hipFree(dv_); if (dg_) (void)hipFree(dg_); };
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dq_), hq.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dv_), hdq.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dg_), 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(dq_, hq.data(), hq.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dv_, hdq.data(), hdq.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { g_hip_err = std::string("rest-state probe: ") + hipGetErrorString(e); cleanup(); return ARB_ERR_HIP; }
+    arb_inspect_out o;
+    memset(&o, 0, sizeof(o));
+    o.pivot_growth = dg_;
+    const int rc = inspect_t<float>(M, M->df_dev, M->lf, dq_, dv_, nullptr, nullptr, 2l, 1e-3, ARB_STEP_SKIP_CONSTRAINTS, &o, nullptr);
+    if (rc == ARB_OK) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(hg, dg_, 2 * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { g_hip_err = std::string("rest-state probe: ") + hipGetErrorString(e); cleanup(); return ARB_ERR_HIP; }
+    }
+    cleanup();
+    if (rc != ARB_OK) return rc;
+    // (a NaN growth -- a non-finite pivot -- counts as unbounded)
+    *growth = (hg[0] == hg[0] && hg[1] == hg[1]) ? std::max(hg[0], hg[1]) : INFINITY;
     return ARB_OK;
 }
 
@@ -708,6 +770,9 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
     info->lds_bytes_f64 = M->ld.total * (int)sizeof(double);
     info->device = M->device;
     info->forest_copies = M->forest ? M->forest_k : 1;
+    info->mixed_default = M->f32_policy;
+    info->wide = 0;
+    info->rest_pivot_growth = M->rest_growth;
     return ARB_OK;
 }
 
@@ -752,7 +817,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
                   const SplitIO<T> &sio, const double *dts, hipStream_t st, long ext_stride = 0, long pd_stride = 0,
                   const CostIO<T> &cost = CostIO<T>{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     // the plain step (FEAT 0): nothing but the state and the constraint forces; FEAT 1: + user torques (MPC rollouts)
-    const bool noopt = MODE == 0 && pwd.qdes == nullptr && pwd.kp == nullptr && logo.q == nullptr &&
+    const bool noopt = MODE == 0 && pwd.qdes == nullptr && pwd.kp == nullptr && pwd.zimp == nullptr && logo.q == nullptr &&
                        logo.dq == nullptr && logo.energy == nullptr && sio.mode == 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS) && dts == nullptr;
     // (the kernels only look at ARB_STEP_SKIP_CONSTRAINTS; the other flags are for the host)
     const bool mfma = MODE == 0 && std::is_same<T, float>::value && (flags & ARB_STEP_MFMA_ELIM) &&
@@ -760,16 +825,24 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     // body-space constraint columns (FEAT bit 16): every launch of a model of that class -- step, rollout, inspect -- except the split
     // execution, the matrix-core elimination and ARB_STEP_GENERAL_KERNELS, which run the general kernels on two column sets
     // (equal to rounding, not bit for bit: Y' is formed as T (J_p Y J_p^T) T^T instead of J' Y J'^T)
+    // the mixed build (CM 3, ARB_STEP_MIXED): float32 buffers, float64 elimination -- the model's default when float32 cannot
+    // eliminate its impedance matrix (arb_model::mixed_default), or on request; general kernels, two waves
+#ifdef ARB_QUICK
+    const bool mixed = false;
+#else
+    const bool mixed = MODE == 0 && std::is_same<T, float>::value && !mfma && sio.mode == 0 && !(flags & ARB_STEP_NO_MIXED) &&
+                       ((flags & ARB_STEP_MIXED) || M->mixed_default);
+#endif
     const bool bodyc = ARB_WITH_SPEC && M->bodycols && (M->bodycols_default || (flags & ARB_STEP_BODY_COLUMNS)) && !mfma && sio.mode == 0 &&
-                       !(flags & (ARB_STEP_GENERAL_KERNELS | ARB_STEP_SKIP_CONSTRAINTS));
-    const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma) ? choose_build(M, nw, nsteps, flags, bodyc) : BuildChoice();
+                       !(flags & (ARB_STEP_GENERAL_KERNELS | ARB_STEP_SKIP_CONSTRAINTS)) && !mixed;
+    const BuildChoice bc = (MODE == 0 && std::is_same<T, float>::value && !mfma && !mixed) ? choose_build(M, nw, nsteps, flags, bodyc) : BuildChoice();
     const bool w3 = bc.w3;
     // the kernels specialised for the model class "four plane / sphere SoftFingerContacts" (FEAT bit 4): bit-identical to the
     // general ones, which ARB_STEP_GENERAL_KERNELS selects
     // (float32 with one or two column sets, float64 with one)
-    const bool spec = ARB_WITH_SPEC && M->spec_ok && noopt && MODE == 0 && !mfma &&
+    const bool spec = ARB_WITH_SPEC && M->spec_ok && noopt && MODE == 0 && !mfma && !mixed &&
                       (std::is_same<T, float>::value || M->nsets == 1) && !(flags & ARB_STEP_GENERAL_KERNELS);
-    const bool spec0 = ARB_WITH_SPEC && M->spec0_ok && noopt && MODE == 0 && std::is_same<T, float>::value && !mfma &&
+    const bool spec0 = ARB_WITH_SPEC && M->spec0_ok && noopt && MODE == 0 && std::is_same<T, float>::value && !mfma && !mixed &&
                        !(flags & ARB_STEP_GENERAL_KERNELS);
     // (the running cost travels with the user torques: FEAT bit 0)
     const bool plain = noopt && ext == nullptr && cost.out == nullptr;
@@ -849,6 +922,10 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
     case NM:                                                                                           \
         if constexpr (MODE == 0 && std::is_same<T, float>::value) {                                    \
             if (mfma) return (M->nsets == 2) ? ONE_(NM, 2, 3, 1) : ONE_(NM, 1, 3, 1);                  \
+            if (mixed) {                                                                               \
+                if (M->nsets == 2) return plain ? ONE_(NM, 2, 0, 3) : noopt ? ONE_(NM, 2, 1, 3) : ONE_(NM, 2, 3, 3); \
+                return plain ? ONE_(NM, 1, 0, 3) : noopt ? ONE_(NM, 1, 1, 3) : ONE_(NM, 1, 3, 3);      \
+            }                                                                                          \
         }                                                                                              \
         ARB_BODYC_CASE(NM)                                                                             \
         if constexpr (MODE == 0 && std::is_same<T, float>::value && NM >= 44 && NM <= 48) {            \
@@ -951,12 +1028,50 @@ static bool use_forest(const arb_model *M, int64_t nworlds, uint32_t flags, cons
     return nworlds > 16l * device_cus(M->device);      // (measured, simplearm: 4096 worlds 98 alone / 91 M as a forest, 8192: 100 / 181)
 }
 
+static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
+                     const void *pd_qdes, const void *pd_dqdes, const void *pd_kp, const void *pd_kd,
+                     int64_t nworlds, double dt, const double *dt_steps, int32_t nsteps, uint32_t flags,
+                     const arb_rollout_log *log, void *stream, long ext_stride, long pd_stride,
+                     const arb_step_cost *cost, const void *ext_imp);
+
+// PROMOTION (round 6): float32 buffers of a model that only float64 carries to 1e-5 (arb_model::f32_policy 2: a long serial
+// chain -- the smallest eigenvalue of snake-64's mass matrix is 3e-9 of the largest, so a float32 rounding ANYWHERE between the
+// state and the generalized forces, 6e-8 relative, comes back as a velocity error of 1e-4 .. 1; the mixed build, which keeps
+// twists and body wrenches in float32, measures 7e-5) are stepped by the FLOAT64 kernels on converted copies: state, constraint
+// forces, user torques and impedance go up, state and forces come down after the last step -- the float32 buffers hold
+// exactly what a float64 caller would have rounded.  Stream-ordered scratch, no synchronisation.
+static int step_promoted(arb_model *M, float *q, float *dq, float *cf, const float *ext, const float *zimp, int64_t nw, double dt,
+                         const double *dts, int nsteps, uint32_t flags, hipStream_t st, long ext_stride) {
+    const size_t nq = (size_t)M->nq * nw, nd = (size_t)M->n * nw, nf = cf ? (size_t)M->ndol * nw : 0;
+    const size_t ne = ext ? (ext_stride ? (size_t)ext_stride * nsteps : nd) : 0, nz = zimp ? (size_t)M->n * M->n * nw : 0;
+    void *ws = nullptr;
+    HIP_TRY(arb_scratch_alloc(&ws, (nq + nd + nf + ne + nz) * sizeof(double), st));
+    double *pq = (double *)ws, *pdq = pq + nq, *pf = pdq + nd, *pe = pf + nf, *pz = pe + ne;
+    auto up = [&](const float *src, double *dst, size_t cnt) {
+        if (cnt) hipLaunchKernelGGL((arb_cvt_kernel<float, double>), dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, st, src, dst, cnt);
+    };
+    auto down = [&](const double *src, float *dst, size_t cnt) {
+        if (cnt) hipLaunchKernelGGL((arb_cvt_kernel<double, float>), dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, st, src, dst, cnt);
+    };
+    up(q, pq, nq); up(dq, pdq, nd); up(cf, pf, nf); up(ext, pe, ne); up(zimp, pz, nz);
+    int rc = (hipGetLastError() == hipSuccess) ? ARB_OK : ARB_ERR_HIP;
+    if (rc == ARB_OK)
+        rc = step_impl(M, ARB_F64, pq, pdq, nf ? pf : nullptr, ne ? pe : nullptr, nullptr, nullptr, nullptr, nullptr, nw, dt, dts, nsteps,
+                       flags, nullptr, st, ext_stride, 0, nullptr, nz ? pz : nullptr);
+    if (rc == ARB_OK) {
+        down(pq, q, nq); down(pdq, dq, nd); down(pf, cf, nf);
+        if (hipGetLastError() != hipSuccess) rc = ARB_ERR_HIP;
+    }
+    (void)hipFreeAsync(ws, st);
+    return rc;
+}
+
 // ext_stride / pd_stride: elements between the rows of consecutive steps of a control sequence (0: one row for the launch)
 static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
                      const void *pd_qdes, const void *pd_dqdes, const void *pd_kp, const void *pd_kd,
                      int64_t nworlds, double dt, const double *dt_steps, int32_t nsteps, uint32_t flags,
                      const arb_rollout_log *log, void *stream, long ext_stride = 0, long pd_stride = 0,
-                     const arb_step_cost *cost = nullptr) {
+                     const arb_step_cost *cost = nullptr, const void *ext_imp = nullptr) {
     if (!M || nworlds < 0 || nsteps < 0) return ARB_ERR_INVALID;
     if (dt_steps == nullptr && !(dt > 0.0)) return ARB_ERR_INVALID;
     if (dt_steps != nullptr) dt = 1.0;                  // unused: every step reads its own dt
@@ -973,7 +1088,8 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     if (int stalled = take_status(M, false)) return stalled;
     ARB_GUARD_DEVICE(M->device);
-    if (use_forest(M, nworlds, flags, log, cost != nullptr)) {
+    // (a dense per-world impedance couples any pair of dofs: the copies of a forest would no longer be independent blocks)
+    if (use_forest(M, nworlds, flags, log, cost != nullptr || ext_imp != nullptr)) {
         // small worlds share wavefronts: nworlds / k worlds of the forest on the same buffers, the rest one per wavefront
         // (a control sequence keeps its row stride: the rows of a step are the whole batch's)
         const int K = M->forest_k;
@@ -990,14 +1106,20 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
                          nsteps, flags | ARB_STEP_ONE_WORLD, nullptr, stream, ext_stride, pd_stride);
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // float32 buffers of a model float32 cannot carry (see step_promoted): the float64 kernels, unless the caller pinned a
+    // build or uses inputs the promotion does not convert (per-world PD inputs, logs, costs: those run the mixed build)
+    if (dtype == ARB_F32 && M->f32_policy == 2 && pd_qdes == nullptr && pd_kp == nullptr && log == nullptr && cost == nullptr &&
+        !(flags & (ARB_STEP_MIXED | ARB_STEP_NO_MIXED | ARB_STEP_MFMA_ELIM | ARB_STEP_SPLIT_WAVE)))
+        return step_promoted(M, (float *)q, (float *)dq, (float *)cforce, (const float *)ext_gforce, (const float *)ext_imp, nworlds, dt,
+                             dt_steps, nsteps, flags, st, ext_stride);
     if (dtype == ARB_F32) {
-        const PerWorldPD<float> pwd = {(const float *)pd_qdes, (const float *)pd_dqdes, (const float *)pd_kp, (const float *)pd_kd};
+        const PerWorldPD<float> pwd = {(const float *)pd_qdes, (const float *)pd_dqdes, (const float *)pd_kp, (const float *)pd_kd, (const float *)ext_imp};
         CostIO<float> ci = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if (cost) ci = CostIO<float>{(float *)cost->cost_out, (const float *)cost->w_q, (const float *)cost->w_dq, (const float *)cost->w_tau, (const float *)cost->q_ref};
         return step_typed<float>(M, M->df_dev, M->lf, (float *)q, (float *)dq, (float *)cforce,
                                  (const float *)ext_gforce, pwd, (long)nworlds, dt, dt_steps, nsteps, flags, log, st, ext_stride, pd_stride, ci);
     }
-    const PerWorldPD<double> pwd = {(const double *)pd_qdes, (const double *)pd_dqdes, (const double *)pd_kp, (const double *)pd_kd};
+    const PerWorldPD<double> pwd = {(const double *)pd_qdes, (const double *)pd_dqdes, (const double *)pd_kp, (const double *)pd_kd, (const double *)ext_imp};
     CostIO<double> ci = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (cost) ci = CostIO<double>{(double *)cost->cost_out, (const double *)cost->w_q, (const double *)cost->w_dq, (const double *)cost->w_tau, (const double *)cost->q_ref};
     return step_typed<double>(M, M->dd_dev, M->ld, (double *)q, (double *)dq, (double *)cforce,
@@ -1018,7 +1140,7 @@ static int plan_typed(arb_model *M, const DevModel<T> *dm, const Layout &L, long
     DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
     LogOut<T> lo; memset(&lo, 0, sizeof(lo));
     SplitIO<T> sio; memset(&sio, 0, sizeof(sio));
-    PerWorldPD<T> pwd = {nullptr, nullptr, nullptr, nullptr};
+    PerWorldPD<T> pwd = {nullptr, nullptr, nullptr, nullptr, nullptr};
     T *const some = reinterpret_cast<T *>(static_cast<uintptr_t>(256));
     if (optional_inputs == 3) lo.q = some;
     const bool split = M->nc > 0 && (flags & ARB_STEP_SPLIT_WAVE) && !(flags & (ARB_STEP_SKIP_CONSTRAINTS | ARB_STEP_FUSED));
@@ -1038,6 +1160,10 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     if (optional_inputs < 0 || optional_inputs > 7 || (optional_inputs & 3) == 2) return ARB_ERR_INVALID;
     const bool world_logs = (optional_inputs & 4) != 0;      // per-world energies / costs, or state logs of a ragged batch: no forest
     optional_inputs &= 3;
+    // (float32 buffers of a model only float64 carries: the launch runs the float64 kernels, see step_promoted)
+    if (dtype == ARB_F32 && M->f32_policy == 2 && optional_inputs <= 1 && !world_logs &&
+        !(flags & (ARB_STEP_MIXED | ARB_STEP_NO_MIXED | ARB_STEP_MFMA_ELIM | ARB_STEP_SPLIT_WAVE)))
+        dtype = ARB_F64;
     if (!world_logs && use_forest(M, nworlds, flags, nullptr)) {
         const int rc = arb_step_plan(M->forest, dtype, nworlds / M->forest_k, nsteps, flags | ARB_STEP_ONE_WORLD, optional_inputs, out);
         if (rc == ARB_OK) out->worlds_per_wavefront = M->forest_k;
@@ -1072,7 +1198,7 @@ extern "C" int arb_step_ex(arb_model *M, int dtype, const arb_step_args *a, void
     const void *qdes = a->pd_qdes_steps ? a->pd_qdes_steps : a->pd_qdes, *dqdes = a->pd_dqdes_steps ? a->pd_dqdes_steps : a->pd_dqdes;
     return step_impl(M, dtype, a->q, a->dq, a->cforce, ext, qdes, dqdes, a->pd_kp, a->pd_kd,
                      a->nworlds, a->dt, a->dt_steps, a->nsteps, a->flags, a->log, stream,
-                     a->ext_gforce_steps ? row : 0l, a->pd_qdes_steps ? row : 0l, a->cost);
+                     a->ext_gforce_steps ? row : 0l, a->pd_qdes_steps ? row : 0l, a->cost, a->ext_impedance);
 }
 
 extern "C" int arb_rollout(arb_model *M, int dtype, void *q, void *dq, void *cforce, const void *ext_gforce,
@@ -1086,8 +1212,12 @@ extern "C" int arb_rollout(arb_model *M, int dtype, void *q, void *dq, void *cfo
 template <typename T>
 static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const void *q, const void *dq,
                      const void *cforce, const void *ext, long nw, double dt, unsigned flags,
-                     const arb_inspect_out *o, hipStream_t st) {
+                     const arb_inspect_out *o, hipStream_t st, const arb_step_args *a) {
     PerWorldPD<T> pwd; memset(&pwd, 0, sizeof(pwd));
+    if (a != nullptr) {        // arb_inspect_ex: the per-world controller inputs of arb_step_ex
+        pwd.qdes = (const T *)a->pd_qdes; pwd.dqdes = (const T *)a->pd_dqdes; pwd.kp = (const T *)a->pd_kp; pwd.kd = (const T *)a->pd_kd;
+        pwd.zimp = (const T *)a->ext_impedance;
+    }
     DebugOut<T> dbg; memset(&dbg, 0, sizeof(dbg));
     int rc;
     // the three world matrices need one pass each (they share the accumulator registers)
@@ -1113,9 +1243,9 @@ static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const
     return launch<T, 1>(M, dm, L, (T *)q, (T *)dq, (T *)cforce, (const T *)ext, pwd, nw, dt, 1, flags, dbg, 0, nolog, nosplit, nullptr, st);
 }
 
-extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,
-                           const void *ext_gforce, int64_t nworlds, double dt, uint32_t flags,
-                           const arb_inspect_out *out, void *stream) {
+static int inspect_impl(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,
+                        const void *ext_gforce, int64_t nworlds, double dt, uint32_t flags,
+                        const arb_inspect_out *out, void *stream, const arb_step_args *a) {
     if (!M || !out || nworlds < 0 || !(dt > 0.0)) return ARB_ERR_INVALID;
     if (dtype != ARB_F32 && dtype != ARB_F64) return ARB_ERR_INVALID;
     if (out->gforce != nullptr && M->nc > 0 && out->c_jac == nullptr) return ARB_ERR_INVALID;
@@ -1126,8 +1256,25 @@ extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *d
     ARB_GUARD_DEVICE(M->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == ARB_F32)
-        return inspect_t<float>(M, M->df_dev, M->lf, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
-    return inspect_t<double>(M, M->dd_dev, M->ld, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st);
+        return inspect_t<float>(M, M->df_dev, M->lf, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st, a);
+    return inspect_t<double>(M, M->dd_dev, M->ld, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st, a);
+}
+
+extern "C" int arb_inspect(arb_model *M, int dtype, const void *q, const void *dq, const void *cforce,
+                           const void *ext_gforce, int64_t nworlds, double dt, uint32_t flags,
+                           const arb_inspect_out *out, void *stream) {
+    return inspect_impl(M, dtype, q, dq, cforce, ext_gforce, nworlds, dt, flags, out, stream, nullptr);
+}
+
+// (ABI 8) arb_inspect with the inputs of arb_step_ex: one step of `args` evaluated without touching the state.  Control
+// sequences, per-step dt, logs and costs belong to multi-step launches: refused here.
+extern "C" int arb_inspect_ex(arb_model *M, int dtype, const arb_step_args *a, const arb_inspect_out *out, void *stream) {
+    if (!M || !a) return ARB_ERR_INVALID;
+    if (a->ext_gforce_steps || a->pd_qdes_steps || a->pd_dqdes_steps || a->cost || a->log || a->dt_steps) return ARB_ERR_INVALID;
+    if ((a->pd_qdes == nullptr) != (a->pd_dqdes == nullptr) || (a->pd_kp == nullptr) != (a->pd_kd == nullptr)) return ARB_ERR_INVALID;
+    if (a->pd_kp != nullptr && a->pd_qdes == nullptr) return ARB_ERR_INVALID;
+    if (a->pd_qdes != nullptr && a->pd_kp == nullptr && !M->df.has_pd) return ARB_ERR_INVALID;
+    return inspect_impl(M, dtype, a->q, a->dq, a->cforce, a->ext_gforce, a->nworlds, a->dt, a->flags, out, stream, a);
 }
 
 // ---------------------------------------------------------------------------
@@ -1279,6 +1426,12 @@ extern "C" int arb_host_joint_local(int jt, const double *q, const double *dq, d
     for (int i = 0; i < 3; ++i) { out[21 + 3 * i] = jl.djw[i].x; out[22 + 3 * i] = jl.djw[i].y; out[23 + 3 * i] = jl.djw[i].z; }
     out[30] = jl.Tw.x; out[31] = jl.Tw.y; out[32] = jl.Tw.z; out[33] = jl.Tv.x; out[34] = jl.Tv.y; out[35] = jl.Tv.z;
     return 0;
+}
+
+extern "C" int arb_host_growth_bits(float zjj, float pivot) {
+    int zb, pb;
+    memcpy(&zb, &zjj, 4); memcpy(&pb, &pivot, 4);
+    return arb_growth_bits(zb, pb);
 }
 
 extern "C" int arb_host_exp_twist(const double *tw, double *H /*16*/) {

@@ -138,7 +138,7 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     int *queue = nullptr;
     const long units = nw;                                   // work units: worlds
     unsigned grid = (unsigned)units;
-    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && (ARB_QUEUE_LOOP_ALL || !(sizeof(T) == 8 && NMAX == 64));     // (see the kernel)
+    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && (ARB_QUEUE_LOOP_ALL || !((sizeof(T) == 8 || CM == 3) && NMAX == 64));     // (see the kernel)
     if (MODE == 0 && chunk > 0 && sio.mode == 0 && !(flags & ARB_STEP_STATIC_WORLDS) && nsteps >= 2 &&
         (cf != nullptr || L.ndol == 0) && nw * (long)nsteps < (1l << 30)) {
         // wave slots of this kernel on the current device, cached per thread for the last (device, LDS size) asked
@@ -211,6 +211,13 @@ template int launch_one<float, ARB_PART_NMAX, 1, 0, 9, 0>(ARB_LAUNCH_ONE_ARGS(fl
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 8, 2>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 9, 2>(ARB_LAUNCH_ONE_ARGS(float));
 #endif
+#elif defined(ARB_PART) && defined(ARB_PART_MIXED)      /* (translation units of their own: the mixed-precision build, CM 3, every tile) */
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 2, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 2, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 3, 3>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 2, 0, 3, 3>(ARB_LAUNCH_ONE_ARGS(float));
 #elif defined(ARB_PART)
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 1, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
 template int launch_one<ARB_PART_T, ARB_PART_NMAX, 2, 0, 0, 0>(ARB_LAUNCH_ONE_ARGS(ARB_PART_T));
@@ -252,6 +259,15 @@ ARB_EXTERN_TILE_CM(16) ARB_EXTERN_TILE_CM(32) ARB_EXTERN_TILE_CM(44) ARB_EXTERN_
     extern template int launch_one<float, NM, 1, 0, 3, 2>(ARB_LAUNCH_ONE_ARGS(float));
 ARB_EXTERN_TILE_W3(44) ARB_EXTERN_TILE_W3(48)
 #undef ARB_EXTERN_TILE_W3
+#define ARB_EXTERN_TILE_MIXED(NM)                                                       \
+    extern template int launch_one<float, NM, 1, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 2, 0, 0, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 2, 0, 1, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 1, 0, 3, 3>(ARB_LAUNCH_ONE_ARGS(float));  \
+    extern template int launch_one<float, NM, 2, 0, 3, 3>(ARB_LAUNCH_ONE_ARGS(float));
+ARB_EXTERN_TILE_MIXED(16) ARB_EXTERN_TILE_MIXED(32) ARB_EXTERN_TILE_MIXED(44) ARB_EXTERN_TILE_MIXED(48) ARB_EXTERN_TILE_MIXED(64)
+#undef ARB_EXTERN_TILE_MIXED
 #if ARB_WITH_SPEC
 #define ARB_EXTERN_TILE_SPEC(NM)                                                        \
     extern template int launch_one<float, NM, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));  \

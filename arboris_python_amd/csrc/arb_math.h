@@ -414,6 +414,19 @@ ARB_HD double arb_rcp(double x) {
 #endif
 }
 
+// Growth of one pivot of the pivot-free elimination (phase C, ARB_WARN_ILLCOND) from the BIT PATTERNS of the float32
+// diagonal entry Z_jj as assembled (zb) and of the pivot that is left (pb): the difference of the patterns is
+// 2^23 log2(Z_jj / pivot) to 6 %.  Both are positive integers for a healthy system; a pivot <= 0 (sign bit set -- -0.0
+// included -- or +0.0), a NaN on either side or an infinite pivot saturates: the float32 elimination has gone
+// indefinite and the warning must come whatever Z_jj is.  A negative diagonal counts by its magnitude.
+// Scalar-unit arithmetic on the device; compiled for the host behind arb_host_growth_bits (tests/test_capi_cpu.py).
+ARB_HD int arb_growth_bits(int zb, int pb) {
+    if (pb <= 0 || pb >= 0x7f800000) return 0x7fffffff;
+    zb &= 0x7fffffff;
+    if (zb > 0x7f800000) return 0x7fffffff;
+    return zb - pb;
+}
+
 // ---------------------------------------------------------------------------
 // Small dense solvers (wave-uniform use in the Gauss-Seidel stage)
 // ---------------------------------------------------------------------------

@@ -177,7 +177,7 @@
             // with the parent's twist from (2).  World-frame sums carry lever arms of the size of the robot: float64 only
             // (the float32 kernels and shallow trees keep the level loop below, whose operation order they are tested with).
             bool jumped = false;
-            if constexpr (sizeof(T) == 8) {
+            if constexpr (sizeof(T) == 8 || CM == 3) {      // (CM 3: the mixed build, float32 sums of float64 terms)
                 const int maxdep = ARB_UNI(mp->maxdepth);
                 if (!SPEC && maxdep >= ARB_JUMP_DEPTH) {          // (the specialised kernels' class: shallow trees)
                     jumped = true;
@@ -228,28 +228,29 @@
                     M3<double> Rgb = m3_identity<double>(); V3<double> pgb = v3<double>(0., 0., 0.);
                     if (on) {
                         Rgb = ld_m3(PD + PDS * b); pgb = ld_v3(PD + PDS * b + 9);
-                        const V3<double> ww = mv(Rgb, Tnw);
-                        st_v3(bdl + BD_TW, ww); st_v3(bdl + BD_TW + 3, cross(pgb, ww) + mv(Rgb, Tnv));
+                        const V3<double> ww = mv(Rgb, cvt_v3<double>(Tnw));
+                        st_v3(bdl + BD_TW, cvt_v3<T>(ww)); st_v3(bdl + BD_TW + 3, cvt_v3<T>(cross(pgb, ww) + mv(Rgb, cvt_v3<double>(Tnv))));
                     }
                     jump_sum(BD_TW);
                     if (on) {
-                        const V3<double> ww = ld_v3(bdl + BD_TW), wv = ld_v3(bdl + BD_TW + 3);
-                        st_v3(bdl + BD_TW, mtv(Rgb, ww)); st_v3(bdl + BD_TW + 3, mtv(Rgb, wv - cross(pgb, ww)));
+                        const V3<double> ww = ld_v3_as<double>(bdl + BD_TW), wv = ld_v3_as<double>(bdl + BD_TW + 3);
+                        st_v3(bdl + BD_TW, cvt_v3<T>(mtv(Rgb, ww))); st_v3(bdl + BD_TW + 3, cvt_v3<T>(mtv(Rgb, wv - cross(pgb, ww))));
                     }
                     WAVE_SYNC();
                     // (3) bias accelerations: dAd_cp T_p + Bn_c in body axes, to world axes, summed, back
                     if (on) {
                         V3<double> tw = v3<double>(0., 0., 0.), tv = tw;
-                        if (par >= 0) { const T *pb = BD + par * BDS; tw = ld_v3(pb + BD_TW); tv = ld_v3(pb + BD_TW + 3); }
-                        const V3<double> lw = mv(dA_cp, tw) + Bnw;
-                        const V3<double> lv = mv(dB_cp, tw) + mv(dA_cp, tv) + Bnv;
+                        if (par >= 0) { const T *pb = BD + par * BDS; tw = ld_v3_as<double>(pb + BD_TW); tv = ld_v3_as<double>(pb + BD_TW + 3); }
+                        const M3<double> dAd = cvt_m3<double>(dA_cp), dBd = cvt_m3<double>(dB_cp);
+                        const V3<double> lw = mv(dAd, tw) + cvt_v3<double>(Bnw);
+                        const V3<double> lv = mv(dBd, tw) + mv(dAd, tv) + cvt_v3<double>(Bnv);
                         const V3<double> ww = mv(Rgb, lw);
-                        st_v3(bdl + BD_AB, ww); st_v3(bdl + BD_AB + 3, cross(pgb, ww) + mv(Rgb, lv));
+                        st_v3(bdl + BD_AB, cvt_v3<T>(ww)); st_v3(bdl + BD_AB + 3, cvt_v3<T>(cross(pgb, ww) + mv(Rgb, lv)));
                     }
                     jump_sum(BD_AB);
                     if (on) {
-                        const V3<double> ww = ld_v3(bdl + BD_AB), wv = ld_v3(bdl + BD_AB + 3);
-                        st_v3(bdl + BD_AB, mtv(Rgb, ww)); st_v3(bdl + BD_AB + 3, mtv(Rgb, wv - cross(pgb, ww)));
+                        const V3<double> ww = ld_v3_as<double>(bdl + BD_AB), wv = ld_v3_as<double>(bdl + BD_AB + 3);
+                        st_v3(bdl + BD_AB, cvt_v3<T>(mtv(Rgb, ww))); st_v3(bdl + BD_AB + 3, cvt_v3<T>(mtv(Rgb, wv - cross(pgb, ww))));
                     }
                     WAVE_SYNC();
                 }

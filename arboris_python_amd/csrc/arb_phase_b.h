@@ -4,15 +4,18 @@
         ARB_OPAQUE_LANE();
         ARB_STAMP(2);
         // (ZT: the arithmetic type of the register tile -- T, or float64 for float32 worlds in the ARB_ELIM_F64 experiment)
-        constexpr bool ELIM64 = (ARB_ELIM_F64 != 0) && std::is_same<T, float>::value && NMAX <= 48 && CM != 1;
+        // (CM 3: the mixed build of round 6 -- the same mechanism as a production kernel for every tile)
+        constexpr bool ELIM64 = CM == 3 || ((ARB_ELIM_F64 != 0) && std::is_same<T, float>::value && NMAX <= 48 && CM != 1);
         using ZT = std::conditional_t<ELIM64, double, T>;
         ZT Z[NMAX];
         ZT Z2[NSETS == 2 ? NMAX : 1];
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) Z[i] = ZT(0);
         T rhsM = T(0), rhsG = T(0);
+        double rhsM_d = 0.;       // (the mixed build carries the right-hand side in float64 up to the register tile)
         // |Z_kk| as assembled (float32 worlds; inspect): the elimination of phase C compares every pivot with it, see there
-        constexpr bool TRACK_GROWTH = (sizeof(T) == 4 && MODE == 0) || MODE == 1;
+        // (the mixed build eliminates in float64: nothing to warn about)
+        constexpr bool TRACK_GROWTH = (sizeof(T) == 4 && MODE == 0 && CM != 3) || MODE == 1;
         float zdiag = 0.f;
         // ---- composite assembly ---------------------------------------------------------------------
         // With X_k = Ad(g<-body(k)) S_k the column of dof k in WORLD axes (about the root body's
@@ -67,7 +70,7 @@
                 // Ad(H_gc) Om_c = Ad(H_gp) Om_p + Ad(H_gc) W_c is a prefix sum over the ancestors; the ancestor pointers
                 // travel in the rhs-wrench slot, whose value every lane has taken into registers above)
                 bool jumped = false;
-                if constexpr (sizeof(T) == 8) {
+                if constexpr (sizeof(T) == 8 || CM == 3) {
                     const int maxdep = ARB_UNI(mp->maxdepth);
                     if (!SPEC && maxdep >= ARB_JUMP_DEPTH) {
                         jumped = true;
@@ -78,9 +81,9 @@
                         M3<double> Rgb = m3_identity<double>(); V3<double> pgb2 = v3<double>(0., 0., 0.);
                         if (onb) {
                             Rgb = ld_m3(PD + PDS * lane); pgb2 = ld_v3(PD + PDS * lane + 9);
-                            const V3<double> ww = mv(Rgb, ld_v3(bdl + BD_OM));
-                            const V3<double> wv = cross(pgb2, ww) + mv(Rgb, ld_v3(bdl + BD_OM + 3));
-                            st_v3(bdl + BD_OM, ww); st_v3(bdl + BD_OM + 3, wv);
+                            const V3<double> ww = mv(Rgb, ld_v3_as<double>(bdl + BD_OM));
+                            const V3<double> wv = cross(pgb2, ww) + mv(Rgb, ld_v3_as<double>(bdl + BD_OM + 3));
+                            st_v3(bdl + BD_OM, cvt_v3<T>(ww)); st_v3(bdl + BD_OM + 3, cvt_v3<T>(wv));
                             bdl[BD_AB] = (T)par;
                         }
                         WAVE_SYNC();
@@ -103,8 +106,8 @@
                             WAVE_SYNC();
                         }
                         if (onb) {
-                            const V3<double> ww = ld_v3(bdl + BD_OM), wv = ld_v3(bdl + BD_OM + 3);
-                            st_v3(bdl + BD_OM, mtv(Rgb, ww)); st_v3(bdl + BD_OM + 3, mtv(Rgb, wv - cross(pgb2, ww)));
+                            const V3<double> ww = ld_v3_as<double>(bdl + BD_OM), wv = ld_v3_as<double>(bdl + BD_OM + 3);
+                            st_v3(bdl + BD_OM, cvt_v3<T>(mtv(Rgb, ww))); st_v3(bdl + BD_OM + 3, cvt_v3<T>(mtv(Rgb, wv - cross(pgb2, ww))));
                         }
                         WAVE_SYNC();
                     }
@@ -448,6 +451,7 @@
                     zdiag = (float)zd;
                 }
                 rhsM = (lane < n) ? (T)rm : T(0);
+                if constexpr (ELIM64) rhsM_d = (lane < n) ? rm : 0.;
                 rhsG = (MODE == 1 && lane < n) ? (T)rg : T(0);
                 WAVE_SYNC();                   // every lane is done with the staging area: it becomes XPR
                 // ... and with the joints' own columns SC: their space becomes RT = [rhs | rows of J'], zero before
@@ -609,7 +613,10 @@
         }
         // controllers: gravity is in rhsG; PD adds to both sides         controllers.py:141-158
         gf0 = rhsG + ext_k;
-        T rhs = rhsM + ext_k;          // gforce - (N + B + Z_pd) gvel
+        // (RH: float64 in the mixed build -- a serial chain answers a generalized-force error of 1e-7 of the gravity torques with a
+        // velocity error of 1e-3: the smallest eigenvalue of its mass matrix is 1e-8 of the largest)
+        using RH = std::conditional_t<ELIM64, double, T>;
+        RH rhs = (ELIM64 ? (RH)rhsM_d : (RH)rhsM) + ext_k;          // gforce - (N + B + Z_pd) gvel
         if (pwd.kp != nullptr) {
             // per-world diagonal gains and targets (arb_step_ex): tau0 = kp (qdes - q) + kd dqdes, Z += dt kp + kd
             if (lane < n && !lane_dead) {
@@ -646,6 +653,24 @@
 #pragma unroll
                 for (int i = 0; i < NMAX; ++i)
                     if (i < npd) Z[i] += dt * kpp[i * npd + lane] + kdp[i * npd + lane];
+            }
+        }
+        // (ABI 8) the impedance of user-defined Controllers, a dense matrix per world: Z -= Z_a (core.py:815-817); in the
+        // increment form Z (gvel+ - gvel) = gforce - (N + B - Z_a) gvel the right-hand side gains Z_a gvel.  Lane = column k
+        // reads row i of Z_a coalesced; lane = dof i sums its own row for the right-hand side.
+        if (FEAT_ALL && pwd.zimp != nullptr) {
+            int nz = ARB_UNI(mp->n);
+            asm volatile("" : "+s"(nz));          // (a size of its own, as for the PD gains above)
+            const T *za = pwd.zimp + (long)w * nz * nz;
+            if (lane < nz && !lane_dead) {
+                if (MODE == 0 || zmode == 0) {
+#pragma unroll
+                    for (int i = 0; i < NMAX; ++i)
+                        if (i < nz) Z[i] -= (ZT)za[i * nz + lane];
+                }
+                T accz = T(0);
+                for (int i = 0; i < nz; ++i) accz += za[lane * nz + i] * dqs[i];
+                rhs += accz;
             }
         }
         WAVE_SYNC();

@@ -4,9 +4,16 @@
         ARB_OPAQUE_LANE();
         ARB_BSTAMP(7);
         ARB_STAMP(3);
-        if (lane < RS) RT[lane] = (lane < n) ? rhs : T(0);
-        WAVE_SYNC();
         const int ncols = do_constraints ? (BODYCOL ? mp->ncols_b : mp->ncols) : n + 1;
+        // (the mixed build: the float64 right-hand side travels to its column as a float32 pair hi + lo -- lo in the scratch
+        // array, or in row 1 of RT for the late-rhs case, which has no constraint rows and needs the scratch array itself)
+        T *const RLO = (NSETS == 1 && n == WAVE && NMAX == WAVE) ? RT + RS : WORK;
+        if (lane < RS) {
+            const T hi = (lane < n) ? (T)rhs : T(0);
+            RT[lane] = hi;
+            if constexpr (ELIM64) RLO[lane] = (lane < n) ? (T)((double)rhs - (double)hi) : T(0);
+        }
+        WAVE_SYNC();
         // Late rhs: 64 dofs, no constraints, one register set (the host's choice for that case): every lane holds a
         // column of Z, the rhs column waits in LDS (row 0 of RT) until the first pivot (dof n-1) has been taken;
         // lane n-1 -- whose own column is finished by that pivot -- applies the pivot to the rhs instead and carries
@@ -27,6 +34,16 @@
                     Z[4 * i4 + 1] = have ? v.y : T(0);
                     Z[4 * i4 + 2] = have ? v.z : T(0);
                     Z[4 * i4 + 3] = have ? v.w : T(0);
+                }
+                if constexpr (ELIM64) {
+                    if (lane == n) {                    // the rhs column: + lo
+                        const V4 *lo4 = reinterpret_cast<const V4 *>(RLO);
+#pragma unroll
+                        for (int i4 = 0; i4 < NMAX / 4; ++i4) {
+                            const V4 v = lo4[i4];
+                            Z[4 * i4] += (ZT)v.x; Z[4 * i4 + 1] += (ZT)v.y; Z[4 * i4 + 2] += (ZT)v.z; Z[4 * i4 + 3] += (ZT)v.w;
+                        }
+                    }
                 }
             }
             if (NSETS == 2) {
@@ -54,11 +71,14 @@
         int growth_bits = -(1 << 30);
         auto track_growth = [&](auto pivv, int j) {
             if constexpr (TRACK_GROWTH) {
-                // (no masking of the sign bits: Z_jj and a healthy pivot are positive; a pivot <= 0 -- a negative integer -- makes the
-                // difference huge, and the warning is right to come)
+                // (Z_jj and a healthy pivot are positive floats: their bit patterns are positive integers and the difference cannot
+                // overflow.  A pivot <= 0 -- sign bit set, -0.0 included: a NEGATIVE integer -- or a NaN pivot / diagonal means the
+                // float32 elimination has gone indefinite: the growth saturates, the warning comes whatever Z_jj is.  Round 5
+                // subtracted the raw patterns, which wraps for pb < 0: Z_jj = 512, pivot = -1e-3 gave -1988301423 and no warning.)
                 const int zb = __builtin_amdgcn_readlane(__float_as_int(zdiag), j);
                 const int pb = __builtin_amdgcn_readfirstlane(__float_as_int((float)pivv));
-                growth_bits = (zb - pb > growth_bits) ? zb - pb : growth_bits;
+                const int gb = arb_growth_bits(zb, pb);
+                growth_bits = (gb > growth_bits) ? gb : growth_bits;
             }
         };
         if constexpr (CM == 1 && std::is_same<T, float>::value) {
@@ -129,7 +149,7 @@
             // (PD controllers: Z_a couples any pair of dofs) switch the skipping off.  (Skipping inside the ROLLED loop was
             // measured too: the rotation of the register tile turns a skipped update into a move, the per-group branches
             // break the interleaving of the broadcasts: -4.5 %.)
-            const bool z_dense = (!SPEC && mp->has_pd) || (FEAT_ALL && pwd.kp != nullptr);
+            const bool z_dense = (!SPEC && mp->has_pd) || (FEAT_ALL && (pwd.kp != nullptr || pwd.zimp != nullptr));
             // (measured round 5: the groups of rows a pivot touches as a model constant -- one scalar load per pivot and a bit test
             // per group: -3 % (the load's latency is on the pivot's path); the whole pattern in twelve scalar registers: -1 %
             // (spilled scalar registers).  The two v_readlane per pivot of the lanes' own masks stay.)
@@ -223,10 +243,17 @@
                 if (late_rhs && j == n - 1) {                  // (wave-uniform: once per step)
                     asm volatile("");
                     if (lane == j) {
+                        if constexpr (ELIM64) {          // (the mixed build: rhs = hi + lo, products in float64)
+                            const double tr = ((double)RT[NMAX - 1] + (double)RLO[NMAX - 1]) * arb_rcp((double)WORK[NMAX - 1]);
+#pragma unroll
+                            for (int r = NMAX - 1; r >= 1; --r) Z[r] = ((double)RT[r - 1] + (double)RLO[r - 1]) - (double)WORK[r - 1] * tr;
+                            Z[0] = tr;
+                        } else {
                         const T tr = RT[NMAX - 1] * arb_rcp(WORK[NMAX - 1]);
 #pragma unroll
                         for (int r = NMAX - 1; r >= 1; --r) Z[r] = RT[r - 1] - WORK[r - 1] * tr;
                         Z[0] = tr;
+                        }
                     }
                 }
             }
@@ -236,7 +263,8 @@
         if constexpr (TRACK_GROWTH) {
             if (sizeof(T) == 4 && MODE == 0) warn_illcond = warn_illcond || (growth_bits > (11 << 23));      // ARB_ILLCOND_GROWTH = 2^11
             if (MODE == 1 && dbg.pivot_growth != nullptr && lane == 0)
-                dbg.pivot_growth[w] = (T)__int_as_float((growth_bits > 0 ? growth_bits : 0) + 0x3f800000);
+                dbg.pivot_growth[w] = growth_bits >= 0x40000000 ? (T)INFINITY      // (saturated: a pivot <= 0 or not finite)
+                                                                : (T)__int_as_float((growth_bits > 0 ? growth_bits : 0) + 0x3f800000);
         }
         // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
         {

@@ -29,7 +29,14 @@ __global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, 
     static_assert(MODE == 0 || FEAT == 3 || FEAT == 19, "the inspect kernels take every input");
     static_assert(CM != 1 || (FEAT == 3 && MODE == 0 && std::is_same<T, float>::value), "matrix-core elimination: float32 step kernels");
     static_assert(CM != 2 || (MODE == 0 && NSETS == 1 && NMAX <= 48 && std::is_same<T, float>::value), "three-wave build: float32, one column set");
-    static_assert(CM >= 0 && CM <= 2, "builds: 0 two waves, 1 matrix-core elimination, 2 three waves");
+    // CM 3 (round 6, ARB_STEP_MIXED): float32 state buffers and LDS, the register tile [Z | rhs | J'^T] of phases C / D in float64
+    // (the assembly of Z is float64 in every kernel; here it is no longer rounded to float32 before it is eliminated).  The
+    // reference inverts Z in float64 (core.py:818); pivot-free float32 elimination loses log2(Z_jj / pivot) bits per pivot --
+    // 17-20 of 24 on a 64-link chain.  Deep trees chain poses, twists and accelerations in log2(depth) rounds like the
+    // float64 kernels (the level loop of a 64-link chain is a third of the step).
+    static_assert(CM != 3 || (MODE == 0 && std::is_same<T, float>::value && !(FEAT & 28)), "mixed build: float32 step kernels, general model");
+    static_assert(CM >= 0 && CM <= 3, "builds: 0 two waves, 1 matrix-core elimination, 2 three waves, 3 mixed precision");
+    constexpr bool WIDE_REGS = (sizeof(T) == 8 || CM == 3);     // the register tile is float64
     constexpr bool FEAT_EXT = (FEAT & 1) != 0, FEAT_ALL = (FEAT & 2) != 0;
     // FEAT bit 4 (round 4): the kernel specialised for the model class of the headline workload -- exactly four constraints (eight
     // for a model with two column sets: human36 with the reference's eight contact points), every one an enabled
@@ -62,8 +69,8 @@ __global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, 
     // one row for the whole launch) -- and the running cost of the rollout; both travel with the user torques (FEAT bit 0),
     // the per-step PD targets with the other optional inputs (bit 1)
     const long ext_stride = FEAT_EXT ? ext_stride_in : 0l, pd_stride = FEAT_ALL ? pd_stride_in : 0l;
-    const CostIO<T> cost = (FEAT_EXT && CM != 3 && CM != 4) ? cost_in : CostIO<T>{nullptr, nullptr, nullptr, nullptr, nullptr};
-    const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr};
+    const CostIO<T> cost = FEAT_EXT ? cost_in : CostIO<T>{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const PerWorldPD<T> pwd = FEAT_ALL ? pwd_in : PerWorldPD<T>{nullptr, nullptr, nullptr, nullptr, nullptr};
     const LogOut<T> logo = FEAT_ALL ? logo_in : LogOut<T>{nullptr, nullptr, nullptr};
     const SplitIO<T> sio = FEAT_ALL ? sio_in : SplitIO<T>{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const unsigned flags = FEAT_ALL ? flags_in : 0u;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, 
 #ifndef ARB_QUEUE_LOOP_ALL
 #define ARB_QUEUE_LOOP_ALL 0
 #endif
-    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && (ARB_QUEUE_LOOP_ALL || !(sizeof(T) == 8 && NMAX == 64));
+    constexpr bool QUEUE_LOOP = ARB_QUEUE_LOOP && (ARB_QUEUE_LOOP_ALL || !(WIDE_REGS && NMAX == 64));
     int *const queue = (MODE == 0) ? queue_in : nullptr;
     T *gq = gq_in, *gdq = gdq_in, *gcforce = gcforce_in;
     long w = blockIdx.x;
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, 
             ARB_STAMP(5);
             ARB_CSTAMP(7);
             using GSG = std::conditional_t<(ARB_GS_F64 != 0) && std::is_same<T, float>::value, double, T>;
-            gs_stage<T, MODE, GSG, !(sizeof(T) == 8 && NMAX == 64), SPEC>(mp, lane, nc, ndol, lda, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
+            gs_stage<T, MODE, GSG, !(WIDE_REGS && NMAX == 64), SPEC>(mp, lane, nc, ndol, lda, dt, inv_dt, AM, CD, VV, FF, WORK, dbg, w);
         }
 
         // ================= phase E: new velocity, integrate ==================

@@ -201,8 +201,13 @@ def _bpose(frame):
     return np.array(frame.bpose, dtype=np.float64).reshape(4, 4)
 
 
-def flatten_world(world, positions=True):
+def flatten_world(world, positions=True, host_controllers=None):
     """Walk ``world`` depth-first and return ``(FlatModel, q0, dq0)``.
+
+    ``host_controllers``: a list that receives the world's user-defined ``Controller`` objects (anything that is not one
+    of the built-in classes, which are lowered to kernel constants).  The caller polls their ``update(dt)`` every step on
+    the host and feeds the sums to the device as ``ext_gforce`` / ``ext_impedance`` (core.py:814-817; the object API does,
+    ``_engine.py``).  Without the list such a controller raises ``UnsupportedModelError``.
 
     ``q0`` is the concatenation, in DFS joint order, of each joint's ``gpos``
     (ravelled; a FreeJoint contributes its 4x4 pose = 16 scalars, as stored by
@@ -314,10 +319,13 @@ def flatten_world(world, positions=True):
             dqd[dmap] = a.gvel_des
             tau0 += kp_a @ qd + kd_a @ dqd
             pdmask[dmap] = 1
+        elif host_controllers is not None:
+            host_controllers.append(a)
         else:
             raise UnsupportedModelError(
-                "controller %r of type %s cannot be lowered to the device step"
-                % (getattr(a, "name", None), type(a).__name__))
+                "controller %r of type %s cannot be lowered to the device step: poll its update(dt) on the host and pass "
+                "the (gforce, impedance) it returns as ext_gforce / ext_impedance (BatchedWorlds.step), or step the world "
+                "through core.World / simulate, which does that" % (getattr(a, "name", None), type(a).__name__))
     if n_weight > 1:
         # each controller would add its own gravity; the sum is what we stored
         pass

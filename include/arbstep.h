@@ -48,13 +48,19 @@ extern "C" {
  * reference polls its controllers EVERY step, core.py:811-817) and a per-world running cost (arb_step_cost); arb_inspect_out
  * ends with pivot_growth; arb_model_warnings / ARB_WARN_ILLCOND; ARB_STEP_GENERAL_KERNELS.  The library reads NO environment
  * variable any more (development builds, -DARB_DEVELOPMENT, still do: once, at arb_model_create). */
-#define ARB_ABI_VERSION 7
+/* 8 (round 6): arb_step_args ends with ext_impedance -- the dense impedance Z_a of a world's user-defined Controllers
+ * (core.py:327-339, 815-817), with their generalized force in ext_gforce: the generic plugin path --; arb_inspect_ex = arb_inspect
+ * with the inputs of arb_step_ex; ARB_STEP_MIXED / ARB_STEP_NO_MIXED and arb_model_info.mixed_default: float32 state with the
+ * impedance eliminated in float64, chosen by the library for models float32 cannot eliminate (long serial chains) instead of
+ * a warning and wrong velocities; arb_model_info.wide: worlds of more than 64 dofs or bodies (up to ARB_WIDE_MAX) run on the
+ * workgroup-per-world kernels (float64 arithmetic).  Earlier struct fields keep their offsets. */
+#define ARB_ABI_VERSION 8
 
 /* status codes */
 enum {
     ARB_OK = 0,
     ARB_ERR_INVALID = 1,      /* bad argument (null pointer, negative size, bad enum) */
-    ARB_ERR_UNSUPPORTED = 2,  /* model outside what the kernels handle (ndof > 64 ...) */
+    ARB_ERR_UNSUPPORTED = 2,  /* model outside what the kernels handle (ndof > ARB_WIDE_MAX ...) */
     ARB_ERR_HIP = 3,          /* a HIP runtime call failed (see arb_last_hip_error) */
     ARB_ERR_NOMEM = 4,
     ARB_ERR_STALLED = 5       /* an EARLIER launch on this handle gave up waiting inside its device-side work queue (see
@@ -108,7 +114,13 @@ enum {
                                          chunk (same results bit for bit; the queue is a stream-ordered allocation, so a launch
                                          has no hidden synchronisation) */
 #define ARB_STEP_SPLIT_WAVE 8u        /* run the sweeps in a second kernel with one WAVEFRONT per world (the fused kernel's
-                                         quad-local sweeps, bit-identical results, compiled for more waves per SIMD).
+                                         quad-local sweeps, compiled for more waves per SIMD): bit-identical to the
+                                         GENERAL kernels (ARB_STEP_GENERAL_KERNELS).  For a model whose default is
+                                         body-space constraint columns (arb_step_plan_info.feat bit 16: human36 with the
+                                         reference's eight contact points) this flag, ARB_STEP_MFMA_ELIM and
+                                         ARB_STEP_GENERAL_KERNELS switch back to the classical columns on two column
+                                         sets: equal to the default to ROUNDING there, not bit for bit -- compare such
+                                         runs with each other, not with the default.
                                          Measured slower than the default at every batch size: opt-in */
 #define ARB_STEP_WAVES2 64u            /* pin the float32 step kernel build: compiled for two waves per SIMD (no register spills: */
 #define ARB_STEP_WAVES3 128u           /* the faster wave) or for three (more waves in flight: the faster chip once the batch fills
@@ -140,8 +152,9 @@ enum {
                                          that log energies (per world) or that log states for a batch that is not a multiple of
                                          k run one world per wavefront. */
 #define ARB_STEP_GENERAL_KERNELS 512u   /* run the general kernels also for a model of one of the specialised classes (arb_step_plan_info.feat
-                                         bits 4 / 8): bit-identical results, ~8 % slower -- for callers (and tests) that want to
-                                         see the difference */
+                                         bits 4 / 8): bit-identical results, ~1 % slower -- for callers (and tests) that want to
+                                         see the difference.  (feat bit 16, body-space columns by default: the general
+                                         kernels run the classical columns -- equal to rounding only, see ARB_STEP_SPLIT_WAVE.) */
 #define ARB_STEP_BODY_COLUMNS 1024u     /* constraint columns in BODY space wherever the model qualifies.  For a model whose constraints are all
                                          enabled plane / sphere SoftFingerContacts (no PD controller, no joint viscosity, one small tree) the
                                          4 nc rows of the constraint Jacobian are T_c J_p: J_p the six rows of the relative Jacobian of the
@@ -155,7 +168,30 @@ enum {
                                          the classical columns to rounding, not bit for bit; ignored for models outside the class, with
                                          ARB_STEP_SPLIT_WAVE, ARB_STEP_MFMA_ELIM and ARB_STEP_GENERAL_KERNELS.  arb_step_plan_info.feat
                                          reports bit 16. */
-#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u | 512u | 1024u)
+#define ARB_STEP_MIXED 2048u            /* float32 state buffers, float64 ELIMINATION: the register tile [Z | rhs | J'^T], the
+                                         right-hand side, the pivot-free elimination and the constraint-space products of
+                                         phases C / D run in float64 (the assembly of Z is float64 in every kernel); twists,
+                                         body wrenches and the LDS stay float32.  The reference inverts Z in float64
+                                         (core.py:818); a float32 elimination loses log2(Z_jj / pivot_j) bits per pivot, which
+                                         on long serial chains (snake-64: 17-20 of 24) leaves nothing: plain float32 is wrong
+                                         by 10 % .. 200 % there, this build measures 7e-5 (median 8e-6) at 1.28 x the
+                                         throughput of the float64 kernels -- NOT 1e-5: the smallest eigenvalue of that mass
+                                         matrix is 3e-9 of the largest, every float32 rounding between the state and the
+                                         generalized forces comes back amplified.
+                                         What float32 launches run BY DEFAULT is decided per model from the pivot growth g
+                                         at its rest states (arb_model_info.rest_pivot_growth, probed once by
+                                         arb_model_create with the float32 inspect kernel), arb_model_info.mixed_default:
+                                           0  g <= ARB_ILLCOND_GROWTH / 8: the float32 kernels (human36: g < 100);
+                                           1  g <= ARB_ILLCOND_GROWTH: this build;
+                                           2  above: PROMOTION -- the launch converts state, constraint forces, user torques
+                                              and impedance to float64 scratch copies (stream-ordered), runs the FLOAT64
+                                              kernels for all nsteps and converts state and forces back: 1e-5 parity through
+                                              float32 buffers at float64 throughput.  Launches with per-world PD inputs,
+                                              logs or a running cost are not promoted: they run this build.
+                                         The flag asks for this build for any model (and instead of the promotion).
+                                         Ignored for float64 buffers, with ARB_STEP_MFMA_ELIM and ARB_STEP_SPLIT_WAVE. */
+#define ARB_STEP_NO_MIXED 4096u         /* plain float32 kernels whatever the model (ARB_WARN_ILLCOND reports what that costs) */
+#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u | 512u | 1024u | 2048u | 4096u)
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the
@@ -216,6 +252,11 @@ typedef struct arb_model_info {
     int32_t lds_bytes_f64;
     int32_t device;
     int32_t forest_copies;    /* small models: worlds per wavefront of the forest build (ARB_STEP_ONE_WORLD), 1 = none */
+    int32_t mixed_default;    /* (ABI 8) what float32 launches of this model run by default: 0 the float32 kernels, 1 the mixed
+                                 build, 2 promotion to the float64 kernels (see ARB_STEP_MIXED) */
+    int32_t wide;             /* (ABI 8) 1: more than 64 dofs / bodies / 16 constraints: one WORKGROUP per world (the wide kernels,
+                                 float64 arithmetic whatever the buffers' type); nmax, nsets and the LDS sizes then describe them */
+    float rest_pivot_growth;  /* (ABI 8) pivot growth of the float32 elimination at the model's rest state (see ARB_WARN_ILLCOND) */
 } arb_model_info;
 
 /*
@@ -327,6 +368,8 @@ int arb_model_status(arb_model *m);
  *                      growth ~1e5, velocity error 0.25 in float32), branched bodies of the size of human36 do not
  *                      (growth < 100).  The reference computes in float64 throughout (core.py:818): step such a
  *                      model with ARB_F64.  The results are still written; the warning does not stop anything.
+ *                      (Since ABI 8 only launches pinned with ARB_STEP_NO_MIXED can raise it for such a model: by default its
+ *                      float32 launches are promoted to the float64 kernels, see ARB_STEP_MIXED.)
  */
 #define ARB_WARN_ILLCOND 1u
 #define ARB_ILLCOND_GROWTH 2048.0   /* 2^11: the float32 kernels compare exponents */
@@ -422,6 +465,13 @@ typedef struct arb_step_args {
     const void *pd_qdes_steps;      /* DEVICE [nsteps][nworlds][ndof] or both NULL: the PD targets of every step; replace */
     const void *pd_dqdes_steps;     /* pd_qdes / pd_dqdes (same rules for the gains) */
     const arb_step_cost *cost;      /* NULL or the running cost (not with ARB_STEP_SPLIT_WAVE: ARB_ERR_INVALID) */
+    /* ---- ABI 8: the generic Controller plugin path.  A reference Controller returns (gforce_a, Z_a) from update(dt)
+       (core.py:327-339) and World.update_controllers sums `gforce += gforce_a; impedance -= Z_a` (core.py:814-817).  The
+       built-in controllers are lowered to the kernels (gravity, PD); ANY other controller is expressed by the caller as the
+       sum of the gforce_a in ext_gforce and the sum of the Z_a here.  The object API (core.World.update_controllers) does
+       exactly that for user-defined Controller subclasses, once per step on the host. ---- */
+    const void *ext_impedance;      /* DEVICE [nworlds][ndof][ndof] row-major or NULL: Z -= ext_impedance, constant over the
+                                       call.  Worlds of a small model run one per wavefront when it is given. */
 } arb_step_args;
 
 int arb_step_ex(arb_model *m, int dtype, const arb_step_args *args, void *stream);
@@ -431,6 +481,12 @@ int arb_step_ex(arb_model *m, int dtype, const arb_step_args *args, void *stream
 int arb_inspect(arb_model *m, int dtype, const void *q, const void *dq,
                 const void *cforce, const void *ext_gforce, int64_t nworlds, double dt,
                 uint32_t flags, const arb_inspect_out *out, void *stream);
+
+/* (ABI 8) arb_inspect with the inputs of arb_step_ex (per-world PD inputs, ext_gforce, ext_impedance; q / dq are not
+ * modified; nsteps is ignored: one step).  Control sequences, dt_steps, log and cost are refused (ARB_ERR_INVALID). */
+int arb_inspect_ex(arb_model *m, int dtype, const arb_step_args *args, const arb_inspect_out *out, void *stream);
+
+#define ARB_WIDE_MAX 256   /* (ABI 8) largest ndof / nb of a world (the wide kernels: one workgroup of 256 lanes per world) */
 
 #ifdef __cplusplus
 }

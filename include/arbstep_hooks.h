@@ -91,6 +91,11 @@ int arb_host_eig6(const double *A, double *wr, double *wi);
  * their derivatives 9 | relative twist 6. */
 int arb_host_joint_local(int jt, const double *q, const double *dq, double *out);
 
+/* The pivot-growth measure of the float32 elimination (phase C; ARB_WARN_ILLCOND of arbstep.h) for one assembled diagonal
+ * entry and the pivot left of it, as the kernels compute it on the scalar unit from the floats' bit patterns: ~2^23 log2(zjj /
+ * pivot), INT32_MAX for a pivot <= 0 (or -0.0, NaN, inf): the warning fires above 11 << 23. */
+int arb_host_growth_bits(float zjj, float pivot);
+
 /* twistvector.exp, arboris/twistvector.py:35-70: tw[6] -> H[16]. */
 int arb_host_exp_twist(const double *tw, double *H);
 

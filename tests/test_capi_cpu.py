@@ -425,6 +425,25 @@ def test_block_pinv_matches_numpy_pinv(dtype, tol):
     assert g["loop_block_singular_values"][-1] < 1e-12 and g["contact_static_block_singular_values"][-1] < 1e-12
 
 
+@needs_lib
+def test_pivot_growth_measure_saturates_for_an_indefinite_pivot():
+    """`zb - pb` on raw float bit patterns wrapped for a pivot <= 0 (Z_jj = 512, pivot = -1e-3 gave
+    -1988301423: no warning exactly when the float32 elimination has gone indefinite).  arb_growth_bits (arb_math.h), the
+    function phase C runs on the scalar unit, compiled for the host."""
+    lib = _capi.load()
+    g = lib.arb_host_growth_bits
+    thr = 11 << 23                                  # the kernels warn above this
+    INT_MAX = 0x7fffffff
+    assert g(512., 512.) == 0
+    assert abs(g(512., 1.) - (9 << 23)) <= 1        # 2^9: nine exponent steps
+    assert g(512., 512. / 4096.) > thr > g(512., 512. / 1024.)
+    for piv in (-1e-3, -0.0, 0.0, -512., float("nan"), float("inf"), -float("inf")):
+        assert g(512., piv) == INT_MAX, piv         # pivot <= 0 or not finite: saturated, whatever Z_jj
+    assert g(float("nan"), 1.) == INT_MAX
+    assert g(-512., 1.) == g(512., 1.)              # a negative diagonal counts by its magnitude
+    assert g(1e-3, 512.) < 0                        # a pivot larger than the diagonal: no growth
+
+
 def test_design_register_table_is_generated_from_the_shipped_library():
     """DESIGN.md section 3 prints the registers / spills of the shipped kernels: the block is written by
     tools/gen_register_table.py from the library's code-object metadata (round 4's hand-written table had gone stale)."""

@@ -155,7 +155,7 @@ def test_unknown_flags_are_refused():
     q, dq = synth.standing_states(m, 4, seed=2)
     tq, tdq = bw.to_device(q, dq, torch.float32)
     before = tq.clone()
-    for bad in (4, 2048, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel)
+    for bad in (4, 8192, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel); 2048, 4096: ABI 8
         rc = bw._lib.arb_step(bw._handle, _capi.ARB_F32, tq.data_ptr(), tdq.data_ptr(), None, None, 4, 5e-3, 1, bad, None)
         assert rc == 1
     with pytest.raises(ValueError):

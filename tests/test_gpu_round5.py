@@ -212,38 +212,50 @@ def test_step_ex_sequence_argument_validation():
     bw.close()
 
 
-def test_float32_on_an_ill_conditioned_model_raises_a_warning():
-    """snake-64 (BASELINE config 4's model) in float32: the elimination of its impedance matrix cancels ~17 of float32's 24
-    bits (pivot growth ~1e5), the velocities are wrong by tens of per cent -- and `arb_model_warnings` says so
-    (ARB_WARN_ILLCOND); in float64 the same launch is exact to 1e-9 and raises nothing.  human36 (growth < 2^11) never
-    raises it, on the ground or in free motion, one step or whole episodes through the work queue (as long as the
-    world itself has not diverged)."""
+def test_float32_on_an_ill_conditioned_model_is_right_by_default_and_warns_when_pinned():
+    """snake-64 (BASELINE config 4's model) with float32 buffers.  Plain float32 elimination of its impedance matrix cancels
+    ~17 of float32's 24 bits (pivot growth ~1e5): the velocities are wrong by tens of per cent, and `arb_model_warnings`
+    says so (ARB_WARN_ILLCOND) -- that is `mixed=False` (ARB_STEP_NO_MIXED) since round 6.  BY DEFAULT the library now
+    PROMOTES such a launch to the float64 kernels (arb_model_info.mixed_default == 2, from the pivot growth at the rest
+    states, probed by arb_model_create; conversion kernels around the float64 launch): right to 1e-5, no warning.  The mixed
+    build on request (`mixed=True`: float32 state, float64 elimination and right-hand side) is right to 2e-4 -- the body
+    wrenches stay float32 and this model amplifies every rounding by up to 3e8.  In float64 the same launch is
+    exact to 1e-9.  human36 (growth < 2^11) stays on the float32 kernels and never warns, on the ground or in free motion, one step
+    or whole episodes through the work queue (as long as the world itself has not diverged)."""
     from arboris_python_amd import synth
     from arboris_python_amd.batch import BatchedWorlds
     g = load_golden("g4_snake64.npz")
     m, _, _ = load_model("snake64_g")
     bw = BatchedWorlds(m)
+    assert bw.info["mixed_default"] == 2 and bw.info["rest_pivot_growth"] > _capi.ARB_ILLCOND_GROWTH
     q, dq = g["q"], g["dq"]
     gro = {}
-    for dtype in (torch.float32, torch.float64):
+    for dtype, mixed in ((torch.float32, False), (torch.float32, True), (torch.float32, None), (torch.float64, None)):
         tq, tdq = bw.to_device(q, dq, dtype)
         gro[dtype] = bw.inspect(tq, tdq, 1e-3, ["pivot_growth"])["pivot_growth"].double().cpu().numpy()
         assert bw.warnings() == 0                                          # (inspecting raises nothing)
-        bw.step(tq, tdq, 1e-3, 1)
+        bw.step(tq, tdq, 1e-3, 1, mixed=mixed)
         torch.cuda.synchronize()
         w = bw.warnings()
         err = _rel(tdq.double().cpu().numpy(), g["dq_next"]).max()
-        print("snake-64 %s: pivot growth %.3g .. %.3g, dq+ error %.2e, warnings %d" % (dtype, gro[dtype].min(), gro[dtype].max(), err, w))
-        if dtype == torch.float32:
-            assert w == _capi.ARB_WARN_ILLCOND and gro[dtype].min() > _capi.ARB_ILLCOND_GROWTH
+        print("snake-64 %s mixed=%s: pivot growth %.3g .. %.3g, dq+ error %.2e, warnings %d" % (dtype, mixed, gro[dtype].min(), gro[dtype].max(), err, w))
+        if dtype == torch.float32 and mixed is False:
+            assert w == _capi.ARB_WARN_ILLCOND and gro[dtype].min() > _capi.ARB_ILLCOND_GROWTH and err > 1e-2
             assert bw.warnings() == 0                                      # reading cleared it
+        elif dtype == torch.float32 and mixed is True:
+            assert w == 0 and err < 2e-4
         else:
             assert w == 0 and err < 1e-5        # (the golden dq+ is the reference's explicit inverse: ~3e-6, tests/test_gpu_parity.py)
-    assert np.all(gro[torch.float32] > gro[torch.float64] / 8.) and np.all(gro[torch.float32] < gro[torch.float64] * 8.)
+    # the float32 measure tracks the float64 one -- or SATURATES: in two of these eight worlds a float32 pivot comes out <= 0 (the
+    # elimination has gone indefinite), which round 5's bit-pattern subtraction wrapped into "no growth" (ADVICE r5, arb_growth_bits)
+    fin = np.isfinite(gro[torch.float32])
+    assert np.isfinite(gro[torch.float64]).all() and fin.sum() >= 4
+    assert np.all(gro[torch.float32][fin] > gro[torch.float64][fin] / 8.) and np.all(gro[torch.float32][fin] < gro[torch.float64][fin] * 8.)
     bw.close()
     for name in ("human36_c4", "human36_g", "human36_c8"):
         m, _, _ = load_model(name)
         bw = BatchedWorlds(m)
+        assert bw.info["mixed_default"] == 0 and bw.info["rest_pivot_growth"] < _capi.ARB_ILLCOND_GROWTH / 8.
         B = 5000
         if m.nc:
             qh, dqh = synth.standing_states(m, B, seed=3, drop=0.03, vel=0.1)

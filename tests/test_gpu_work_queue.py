@@ -143,18 +143,21 @@ def test_queue_warm_started_forces(bws):
     np.testing.assert_allclose(out["queue"][1][ws].cpu().numpy(), odq, rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-def test_queue_snake64_64_row_kernels(bws, dtype):
-    """the 64-row kernels: float64 takes the queue without the in-kernel item loop (csrc comment: one workgroup per
-    item), float32 with it (float32 is not accurate on this model, cond(Z) ~ 3e8, but it is deterministic)"""
+@pytest.mark.parametrize("dtype,mixed", [(torch.float64, None), (torch.float32, False), (torch.float32, True)])
+def test_queue_snake64_64_row_kernels(bws, dtype, mixed):
+    """the 64-row kernels: float64 -- and the mixed build, whose register tile is float64 -- take the queue without the
+    in-kernel item loop (csrc comment: one workgroup per item), plain float32 with it (float32 is not accurate on this model,
+    cond(Z) ~ 3e8, but it is deterministic).  (float32 buffers are pinned to a build here: by default such a launch is
+    promoted to the float64 kernels, which keep the state in float64 BETWEEN the steps of one launch -- T steps in one launch
+    are then more accurate than T one-step launches, not bit-identical to them; tests/test_gpu_round6.py)"""
     bw, m, q0, dq0 = bws("snake64_g")
     B, T = 3000, 9
     rng = np.random.default_rng(2)
     q = rng.uniform(-1., 1., (B, m.nq)); dq = rng.uniform(-1., 1., (B, m.ndof))
     tq, tdq = bw.to_device(q, dq, dtype)
-    bw.step(tq, tdq, 1e-3, T)
+    bw.step(tq, tdq, 1e-3, T, mixed=mixed)
     sq, sdq = bw.to_device(q, dq, dtype)
     for _ in range(T):
-        bw.step(sq, sdq, 1e-3, 1)
+        bw.step(sq, sdq, 1e-3, 1, mixed=mixed)
     torch.cuda.synchronize()
     assert torch.equal(tq, sq) and torch.equal(tdq, sdq)

@@ -394,3 +394,25 @@ def test_energy_monitor_formula(name, model):
             c = np.array([rx[2, 1], rx[0, 2], rx[1, 0], 1.])
             pe += mass[3, 3] * (d["pose"][:, b] @ c)[:, 0:3] @ m.up
     close(ke, g[name + "_ke"], 1e-11); close(9.81 * pe, g[name + "_pe"], 1e-11)
+
+
+# -- G14 (round 6): a user-defined Controller with a dense impedance ---------
+def test_user_controller_impedance_against_the_reference():
+    """The reference's loop body with a user-defined Controller registered (core.py:327-339, 814-817) on human36 + four
+    floor contacts, 12 steps: the oracle fed the (gforce_a, Z_a) the controller returned reproduces the reference's
+    impedance, generalized forces, constraint forces and trajectory."""
+    from arboris_python_amd.flatten import FlatModel
+    g = load_golden("g14_user_controller.npz")
+    skip = ("q", "dq", "ctrl_gforce", "ctrl_impedance", "Z", "gforce0", "gforce", "cforce", "dt")
+    m = FlatModel.from_npz_dict({k: g[k] for k in g.files if k not in skip})
+    dt = float(g["dt"])
+    cf = np.zeros((1, m.nc, 4))
+    for k in range(len(g["ctrl_gforce"])):
+        q, dq = g["q"][k][None], g["dq"][k][None]
+        oq, odq, cf, d = O.step(m, q, dq, dt, cforce=cf, ext_gforce=g["ctrl_gforce"][k][None],
+                                ext_impedance=g["ctrl_impedance"][k][None], debug=True)
+        close(d["Z"][0], g["Z"][k]); close(d["gforce0"][0], g["gforce0"][k])
+        close(d["gforce"][0], g["gforce"][k], 1e-9); close(cf[0], g["cforce"][k], 1e-9)
+        close(oq[0], g["q"][k + 1], 1e-10); close(odq[0], g["dq"][k + 1], 1e-10)
+    assert np.abs(g["cforce"]).max() > 50.          # the feet do push on the floor
+    assert np.abs(g["ctrl_impedance"][0] - np.diag(np.diag(g["ctrl_impedance"][0]))).max() > 0.   # a dense impedance

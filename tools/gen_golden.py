@@ -850,10 +850,66 @@ def gen_energy_monitor():
     save("g13_energy_monitor.npz", **out)
 
 
+def gen_user_controller():
+    """g14 (round 6): a USER-DEFINED Controller with a dense impedance (tests/plugin_controllers.py, derived from the
+    reference's own Controller ABC) registered on human36 with the four floor contacts; the reference's loop body run for
+    12 steps from a state with the feet on the floor.  Recorded per step: the state, what the controller returned, the
+    world's impedance and generalized force after update_controllers / update_constraints."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from plugin_controllers import make_spring_damper
+    from arboris.core import Controller
+    SpringDamper = make_spring_damper(Controller)
+    w = World()
+    add_groundplane(w)
+    add_human36(w)
+    w.register(WeightController())
+    ctrl = SpringDamper()
+    w.register(ctrl)
+    for c in get_all_contacts(w, friction_coeff=.6):
+        if c._shapes[1].name in FOUR:
+            w.register(c)
+    w.init()
+    host = []
+    m, _, _ = flatten_world(w, host_controllers=host)
+    assert host == [ctrl]
+    d = m.to_npz_dict()
+    q, dq = synth.standing_states(m, 1, seed=21, drop=0.0, vel=0.1)
+    q[:, 7] += 0.001                     # feet 1 mm above the floor (proximity 2 cm): the contacts are active from the first step
+    rng = np.random.default_rng(22)
+    for b in range(m.nb):                # bend the hinges a little: the spring has something to pull on
+        if m.jtype[b] != JT_FREE:
+            q[0, int(m.q_off[b]):int(m.q_off[b] + m.jnq[b])] = rng.uniform(-0.06, 0.06, int(m.jnq[b]))
+    set_state(w, m, q[0], dq[0])
+    dt, nsteps = 5e-3, 12
+    qs, dqs, gfa, za, Z, gf0, gf1, frc = [], [], [], [], [], [], [], []
+    orig = ctrl.update
+
+    def spy(dt_):
+        g, z = orig(dt_)
+        gfa.append(np.array(g)); za.append(np.array(z))
+        return g, z
+    ctrl.update = spy
+    cons = list(w._constraints)
+    for k in range(nsteps):
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        w.update_dynamic()
+        w.update_controllers(dt)
+        Z.append(w._impedance.copy()); gf0.append(w._gforce.copy())
+        w.update_constraints(dt)
+        gf1.append(w._gforce.copy()); frc.append([c._force.copy() for c in cons])
+        w.integrate(dt)
+    a, b = get_state(w, m)
+    qs.append(a); dqs.append(b)
+    d.update(q=np.array(qs), dq=np.array(dqs), ctrl_gforce=np.array(gfa), ctrl_impedance=np.array(za),
+             Z=np.array(Z), gforce0=np.array(gf0), gforce=np.array(gf1), cforce=np.array(frc), dt=dt)
+    save("g14_user_controller.npz", **d)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz, g12=gen_singular_blocks, g13=gen_energy_monitor)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz, g12=gen_singular_blocks, g13=gen_energy_monitor, g14=gen_user_controller)
     for k in which:
         table[k]()
