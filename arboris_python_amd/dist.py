@@ -45,7 +45,10 @@ def gather_rows(local, n_worlds, dist=None):
         import torch.distributed as dist
     ws = dist.get_world_size()
     per = -(-n_worlds // ws)
-    flat = local.reshape(local.shape[0], -1)
+    width = 1
+    for d in local.shape[1:]:
+        width *= int(d)
+    flat = local.reshape(local.shape[0], width)      # (an empty shard: -1 would be ambiguous)
     if flat.shape[0] < per:
         flat = torch.cat([flat, torch.zeros((per - flat.shape[0], flat.shape[1]), dtype=flat.dtype, device=flat.device)], dim=0)
     flat = flat.contiguous()

@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--extra", action="store_true", help="also time the other BASELINE configs (N=1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher/sharding rehearsal on CPU: gloo backend, no GPU call, no stepping")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="--dry-run only: a global batch that need not be a multiple of the ranks (ragged last shard, "
+                         "empty shards); default ranks x the per-GPU batch")
     return ap.parse_args(argv)
 
 
@@ -326,20 +329,24 @@ def dry_run(args, cfg):
         dist.init_process_group("gloo")
     ws = dist.get_world_size() if world > 1 else 1
     B = cfg["batch"]
-    a, b = shard_bounds(ws * B, rank, ws)
+    G = args.global_batch if args.global_batch is not None else ws * B
+    a, b = shard_bounds(G, rank, ws)
     shards = [None] * ws
     if world > 1:
+        from arboris_python_amd.dist import gather_rows
         dist.all_gather_object(shards, (a, b))
         q_loc = torch.arange(a, b, dtype=torch.float64).reshape(-1, 1).repeat(1, 3)
         dq_loc = -torch.arange(a, b, dtype=torch.float64).reshape(-1, 1).repeat(1, 2)
-        q_all, dq_all = gather_state(q_loc, dq_loc, ws * B, dist)
-        ok = bool(torch.equal(q_all[:, 0], torch.arange(ws * B, dtype=torch.float64))
-                  and torch.equal(dq_all[:, 0], -torch.arange(ws * B, dtype=torch.float64)))
+        q_all, dq_all = gather_state(q_loc, dq_loc, G, dist)
+        cost = gather_rows(0.5 * torch.arange(a, b, dtype=torch.float64), G, dist)      # per-rollout costs: (shard,) -> (G,)
+        ok = bool(torch.equal(q_all[:, 0], torch.arange(G, dtype=torch.float64))
+                  and torch.equal(dq_all[:, 0], -torch.arange(G, dtype=torch.float64))
+                  and torch.equal(cost, 0.5 * torch.arange(G, dtype=torch.float64)))
     else:
         shards, ok = [(a, b)], True
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": ws, "requested_gpus": args.gpus, "worlds_per_gpu": B,
-                          "global_batch": ws * B, "shards": [list(s) for s in shards], "gather_ok": ok,
+                          "global_batch": G, "shards": [list(s) for s in shards], "gather_ok": ok,
                           "config": args.config}))
     if world > 1:
         dist.destroy_process_group()

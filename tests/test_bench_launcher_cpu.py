@@ -31,6 +31,27 @@ def test_gpus_2_starts_two_ranks_and_shards():
     assert r["gather_ok"] is True
 
 
+def _dry(argv):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def test_eight_ranks_rehearsal_configs_4_and_5_and_a_ragged_batch():
+    """The driver's N = 8 launch, rehearsed on CPU (gloo, eight processes): BASELINE config 4's 2048 worlds per GPU = 16384,
+    config 5's 8192 per GPU = 65536, and a global batch that is NOT a multiple of eight (ragged last shard); every rank takes
+    its dist.shard_bounds range, state and per-rollout costs come back in world order."""
+    r = _dry(["--gpus", "8", "--dry-run", "--config", "4"])
+    assert r["n_gpus"] == 8 and r["global_batch"] == 16384 and r["gather_ok"] is True
+    assert r["shards"] == [[2048 * k, 2048 * (k + 1)] for k in range(8)]
+    r = _dry(["--gpus", "8", "--dry-run", "--config", "5"])
+    assert r["global_batch"] == 65536 and r["shards"][-1] == [57344, 65536] and r["gather_ok"] is True
+    r = _dry(["--gpus", "8", "--dry-run", "--config", "5", "--global-batch", "65531"])
+    assert r["shards"] == [list(shard_bounds(65531, k, 8)) for k in range(8)] and r["shards"][-1] == [57344, 65531]
+    assert r["gather_ok"] is True
+
+
 def test_single_rank_dry_run_and_mismatch_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], env=_env(),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)

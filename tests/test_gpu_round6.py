@@ -290,3 +290,41 @@ def test_config4_snake64_through_float32_buffers():
     assert np.median(eb) <= np.median(ea) * 1.5 and eb.max() < 1e-4
     bh.close()
     bw.close()
+
+
+# ---------------------------------------------------------------------------
+# the single-process multi-device driver
+# ---------------------------------------------------------------------------
+def test_sharded_worlds_two_shards_on_one_device_equal_the_unsharded_launch_bitwise():
+    """dist.ShardedWorlds, the library-level driver (one host thread, one handle and one stream per shard): with
+    `devices=[0, 0, 0]` the three shards of a ragged batch run on this box's one GPU, each on its own stream, per-shard
+    torque sequences and costs; gathered in world order they are the unsharded launch bit for bit."""
+    from arboris_python_amd import synth
+    from arboris_python_amd.batch import BatchedWorlds
+    from arboris_python_amd.dist import ShardedWorlds
+    m, _, _ = load_model("human36_c4")
+    B, T, dt = 1000, 12, 5e-3
+    q, dq = synth.standing_states(m, B, seed=4, drop=0.02, vel=0.1)
+    rng = np.random.default_rng(4)
+    tau = rng.uniform(-0.05, 0.05, size=(T, B, m.ndof)); tau[:, :, :6] = 0.
+    sw = ShardedWorlds(m, devices=[0, 0, 0])
+    shards = sw.scatter(q, dq, torch.float32, cforce=True)
+    assert [(s["lo"], s["hi"]) for s in shards] == [(0, 334), (334, 668), (668, 1000)]
+    costs, per = [], []
+    for s, sh in zip(sw.steppers, shards):
+        c = dict(out=torch.zeros(sh["hi"] - sh["lo"], dtype=torch.float32, device=s.device),
+                 w_dq=torch.full((m.ndof,), 0.1, dtype=torch.float32, device=s.device))
+        costs.append(c)
+        per.append(dict(cost=c, ext_gforce=torch.as_tensor(tau[:, sh["lo"]:sh["hi"]], dtype=torch.float32, device=s.device).contiguous()))
+    sw.step(shards, dt, T, per_shard=per)
+    out = sw.gather(shards, keys=("q", "dq", "cforce"), extra=[dict(cost=c["out"]) for c in costs])
+    bw = BatchedWorlds(m)
+    tq, tdq = bw.to_device(q, dq, torch.float32)
+    cf = bw.new_cforce(B, torch.float32)
+    cost = dict(out=torch.zeros(B, dtype=torch.float32, device=bw.device), w_dq=torch.full((m.ndof,), 0.1, dtype=torch.float32, device=bw.device))
+    bw.step(tq, tdq, dt, T, cforce=cf, ext_gforce=torch.as_tensor(tau, dtype=torch.float32, device=bw.device).contiguous(), cost=cost)
+    torch.cuda.synchronize()
+    assert torch.equal(out["q"], tq.cpu()) and torch.equal(out["dq"], tdq.cpu()) and torch.equal(out["cforce"], cf.cpu())
+    assert torch.equal(out["cost"], cost["out"].cpu()) and float(out["cost"].min()) > 0.
+    assert len({id(st) for st in sw.streams}) == 3
+    sw.close(); bw.close()
