@@ -46,6 +46,12 @@
 #include "arb_gs_stage.h"
 #include "arb_step_kernel.h"
 #include "arb_aux_kernels.h"
+#if !defined(ARB_PART) && !defined(ARB_QUICK)
+#include "arb_wide_kernel.h"
+#define ARB_WITH_WIDE 1
+#else
+#define ARB_WITH_WIDE 0
+#endif
 #include "arb_launch.h"
 
 #ifndef ARB_PART
@@ -100,6 +106,14 @@ struct arb_model {
     // the forest: k worlds share a wavefront's lanes.  Built by arb_model_create for models of at most 16 dofs.
     arb_model *forest = nullptr;
     int forest_k = 1;
+#if ARB_WITH_WIDE
+    // Worlds past one wavefront (more than 64 dofs / bodies, 16 constraints or 128 augmented columns; up to ARB_WIDE_MAX): the
+    // workgroup-per-world kernel of arb_wide_kernel.h, float64 arithmetic, its own device-resident model
+    bool is_wide = false;
+    WideModel wide;
+    WideModel *wide_dev = nullptr;
+    size_t wide_lds = 0;
+#endif
 };
 
 // ARB_ERR_STALLED when an earlier launch of the handle raised the status word (host memory: no synchronisation).
@@ -381,6 +395,10 @@ static int forest_copies(int nb, int n, int nc) {
 // fk = 1: the described world, plus its forest when it is small; fk > 1: `d` describes a forest of fk copies
 static int model_create(const arb_model_desc *d, int device, arb_model **out, int fk);
 static int probe_rest_growth(arb_model *M, const arb_model_desc *d, float *growth);
+#if ARB_WITH_WIDE
+static int wide_create(const arb_model_desc *d, int device, arb_model **out);
+#endif
+static int device_cus(int device);
 template <typename T>
 static int inspect_t(arb_model *M, const DevModel<T> *dm, const Layout &L, const void *q, const void *dq,
                      const void *cforce, const void *ext, long nw, double dt, unsigned flags,
@@ -404,10 +422,14 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
                    !d->c_radius || !d->c_geom || !d->c_radius0 || !d->c_half || !d->c_plane || !d->c_mu || !d->c_prox || !d->c_eps ||
                    !d->c_min || !d->c_max || !d->c_bpose0 || !d->c_bpose1))
         return ARB_ERR_INVALID;
-    if (n > WAVE || nb > WAVE || nc > WAVE) return ARB_ERR_UNSUPPORTED;   // one world per wavefront
     const int ndol = ARB_MAXDOL * nc;
     const int ncols = n + 1 + ndol;
-    if (ncols > 2 * WAVE || ndol > WAVE) return ARB_ERR_UNSUPPORTED;
+    if (n > WAVE || nb > WAVE || nc > WAVE || ncols > 2 * WAVE || ndol > WAVE) {      // past one world per wavefront
+#if ARB_WITH_WIDE
+        if (with_forest && n <= ARB_WIDE_MAX && nb <= ARB_WIDE_MAX && nc <= 64) return wide_create(d, device, out);
+#endif
+        return ARB_ERR_UNSUPPORTED;
+    }
     // ---- tree bookkeeping (counterpart of World.init, core.py:608-635) ----
     std::vector<int> jnd(nb), depth(nb);
     std::vector<unsigned long long> anc(nb);
@@ -622,6 +644,177 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     return ARB_OK;
 }
 
+#if ARB_WITH_WIDE
+// ---------------------------------------------------------------------------
+// The wide path (arb_wide_kernel.h): worlds past one wavefront.  Its own validation of the description (the masks of the
+// wavefront path are 64 bits wide), its own device-resident model (arrays sized by the model), one launch function.
+// ---------------------------------------------------------------------------
+static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
+    const int nb = d->nb, n = d->ndof, nc = d->nc, ndol = ARB_MAXDOL * nc;
+    std::vector<int> jnd(nb), depth(nb), dof2q(n, -1), dofbody(n, 0), subsize(nb, 1);
+    int maxdepth = 0, ndof_chk = 0, nq_chk = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int p = d->parent[b], jt = d->jtype[b];
+        if (p >= b || p < -1 || jt < 0 || jt > ARB_JT_TXTYTZ) return ARB_ERR_INVALID;
+        jnd[b] = joint_ndof(jt);
+        if (d->dof_off[b] != ndof_chk || d->q_off[b] != nq_chk) return ARB_ERR_INVALID;
+        for (int i = 0; i < jnd[b]; ++i) {
+            if (ndof_chk + i >= n) return ARB_ERR_INVALID;
+            dofbody[ndof_chk + i] = b;
+            if (jt != ARB_JT_FREE) dof2q[ndof_chk + i] = nq_chk + i;
+        }
+        ndof_chk += jnd[b]; nq_chk += joint_nq(jt);
+        depth[b] = (p < 0) ? 0 : depth[p] + 1;
+        maxdepth = std::max(maxdepth, depth[b]);
+    }
+    if (ndof_chk != n || nq_chk != d->nq) return ARB_ERR_INVALID;
+    for (int b = nb - 1; b > 0; --b) if (d->parent[b] >= 0) subsize[d->parent[b]] += subsize[b];
+    for (int b = 0; b < nb; ++b)                              // bodies in DFS preorder: every subtree a contiguous range
+        for (int c2 = b + 1; c2 < b + subsize[b]; ++c2) {
+            int a = c2;
+            while (a > b) a = d->parent[a];
+            if (a != b) return ARB_ERR_UNSUPPORTED;
+        }
+    for (int b = 0; b < nb; ++b) {                            // rigid-body mass matrices (see model_create)
+        const double *Mb = d->mass + 36 * b;
+        double sc = 0.;
+        for (int i = 0; i < 36; ++i) sc = std::max(sc, std::fabs(Mb[i]));
+        const double tol = 1e-9 * std::max(sc, 1e-300);
+        bool ok = true;
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) ok = ok && std::fabs(Mb[6 * i + j] - Mb[6 * j + i]) <= tol;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            ok = ok && std::fabs(Mb[6 * (3 + i) + 3 + j] - (i == j ? Mb[21] : 0.)) <= tol;
+            ok = ok && std::fabs(Mb[6 * i + 3 + j] + Mb[6 * j + 3 + i]) <= tol;
+        }
+        if (!ok) return ARB_ERR_UNSUPPORTED;
+    }
+    bool has_warm = false;
+    for (int c = 0; c < nc; ++c) {
+        const int ct = d->ctype[c];
+        if (ct == ARB_CT_SOFTFINGER) {
+            if (d->c_body[c] >= nb || d->c_body0[c] >= nb) return ARB_ERR_INVALID;
+            if (d->c_geom[c] < ARB_CG_PLANE_SPHERE || d->c_geom[c] > ARB_CG_BOX_SPHERE) return ARB_ERR_INVALID;
+        } else if (ct == ARB_CT_BALLSOCKET) {
+            if (d->c_body[c] >= nb || d->c_body0[c] >= nb) return ARB_ERR_INVALID;
+            has_warm = true;
+        } else if (ct == ARB_CT_JOINTLIMITS) {
+            if (d->c_dof[c] < 0 || d->c_dof[c] >= n || dof2q[d->c_dof[c]] < 0) return ARB_ERR_INVALID;
+        } else return ARB_ERR_INVALID;
+    }
+    arb_model *M = new (std::nothrow) arb_model();
+    if (!M) return ARB_ERR_NOMEM;
+    M->device = device; M->is_wide = true;
+    M->nb = nb; M->n = n; M->nq = d->nq; M->nc = nc; M->ndol = ndol; M->ncols = n + 1 + ndol; M->nsets = 1; M->nmax = n;
+    DeviceGuard guard_(device);
+    if (guard_.err != hipSuccess) { g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err); delete M; return ARB_ERR_HIP; }
+    WideModel &W = M->wide;
+    memset(&W, 0, sizeof(W));
+    W.nb = nb; W.n = n; W.nq = d->nq; W.nc = nc; W.ndol = ndol; W.ncols = n + 1 + ndol; W.ld = (W.ncols + 1) | 1;   // (odd row stride: LDS banks)
+    W.maxdepth = maxdepth; W.has_warm = has_warm; W.has_pd = d->pd_kp != nullptr;
+    for (int i = 0; i < 3; ++i) { W.grav[i] = d->gravity[i]; W.up[i] = d->up[i]; if (d->gravity[i] != 0.) W.has_grav = 1; }
+    for (int i = 0; i < 36 * nb; ++i) if (d->visc[i] != 0.) W.has_visc = 1;
+    int rc = ARB_OK;
+    auto upi = [&](const int *src, size_t cnt, const int **dst) {
+        if (rc != ARB_OK) return;
+        std::vector<int> v(src ? src : nullptr, src ? src + cnt : nullptr);
+        if (!src) v.assign(cnt, 0);
+        rc = upload<int>(M, v, dst);
+    };
+    auto upd = [&](const std::vector<double> &v, const double **dst) { if (rc == ARB_OK) rc = upload<double>(M, v, dst); };
+    auto vec = [](const double *src, size_t cnt) { return src ? std::vector<double>(src, src + cnt) : std::vector<double>(cnt, 0.); };
+    upi(d->parent, nb, &W.parent); upi(d->jtype, nb, &W.jtype); upi(d->dof_off, nb, &W.dof_off); upi(jnd.data(), nb, &W.jnd);
+    upi(d->q_off, nb, &W.q_off); upi(depth.data(), nb, &W.depth); upi(d->weighted, nb, &W.weighted); upi(dof2q.data(), n, &W.dof2q);
+    upi(dofbody.data(), n, &W.dofbody); upi(subsize.data(), nb, &W.subsize);
+    upd(h12(d->H_pr, nb), &W.Hpr); upd(h12(d->H_cn, nb), &W.Hcn);
+    upd(vec(d->mass, 36 * (size_t)nb), &W.mass); upd(vec(d->visc, 36 * (size_t)nb), &W.visc);
+    upd(vec(d->pd_kp, W.has_pd ? (size_t)n * n : 0), &W.pd_kp); upd(vec(d->pd_kd, W.has_pd ? (size_t)n * n : 0), &W.pd_kd);
+    upd(vec(d->pd_tau0, W.has_pd ? (size_t)n : 0), &W.pd_tau0);
+    upi(d->ctype, nc, &W.ctype); upi(d->c_enabled, nc, &W.cen); upi(d->c_body, nc, &W.cbody); upi(d->c_body0, nc, &W.cbody0);
+    upi(d->c_dof, nc, &W.cdof); upi(d->c_geom, nc, &W.cgeom);
+    std::vector<double> rz(9 * (size_t)std::max(nc, 1), 0.0);
+    for (int c = 0; c < nc; ++c)
+        if (d->ctype[c] == ARB_CT_SOFTFINGER && d->c_geom[c] == ARB_CG_PLANE_SPHERE) zaligned_host(d->c_plane + 4 * c, rz.data() + 9 * c);
+    upd(vec(d->c_local, 3 * (size_t)nc), &W.clocal); upd(vec(d->c_radius, nc), &W.cradius); upd(vec(d->c_radius0, nc), &W.cradius0);
+    upd(vec(d->c_half, 3 * (size_t)nc), &W.chalf); upd(vec(d->c_plane, 4 * (size_t)nc), &W.cplane); upd(rz, &W.cRz);
+    upd(nc ? h12(d->c_bpose0, nc) : std::vector<double>(), &W.cb0); upd(nc ? h12(d->c_bpose1, nc) : std::vector<double>(), &W.cb1);
+    upd(vec(d->c_mu, nc), &W.cmu); upd(vec(d->c_eps, 3 * (size_t)nc), &W.ceps); upd(vec(d->c_prox, nc), &W.cprox);
+    upd(vec(d->c_min, nc), &W.cmin); upd(vec(d->c_max, nc), &W.cmax);
+    if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
+    // the augmented system in LDS when it fits beside the pivot row / column (120 KB: one workgroup per CU), else in scratch
+    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48) * sizeof(double);
+    W.z_in_lds = (size_t)n * W.ld * sizeof(double) + small <= 120 * 1024 ? 1 : 0;
+    M->wide_lds = small + (W.z_in_lds ? (size_t)n * W.ld * sizeof(double) : 0);
+    long o = 0;
+    auto take = [&](long cnt) { const long at = o; o += (cnt + 1) & ~1l; return at; };
+    W.o_q = take(d->nq); W.o_dq = take(n); W.o_qd = take(n); W.o_ff = take(std::max(ndol, 1)); W.o_ff0 = take(std::max(ndol, 1));
+    W.o_pose = take(12l * nb); W.o_pc = take(12l * nb); W.o_rcp = take(12l * nb); W.o_tw = take(6l * nb); W.o_ab = take(6l * nb);
+    W.o_om = take(6l * nb); W.o_da = take(18l * nb); W.o_tn = take(6l * nb); W.o_bn = take(6l * nb); W.o_pt = take(12l * nb);
+    W.o_sc = take(12l * n); W.o_ac = take(36l * nb); W.o_mc = take(36l * nb); W.o_wc = take(12l * nb); W.o_xk = take((long)WIDE_XK * n);
+    W.o_rh = take(2l * n); W.o_z = take(W.z_in_lds ? 0 : (long)n * W.ld); W.o_jr = take((long)std::max(ndol, 1) * n);
+    W.o_am = take((long)std::max(ndol * ndol, 1)); W.o_vv = take(std::max(ndol, 1)); W.o_cd = take((long)WIDE_CD * std::max(nc, 1));
+    W.total = o;
+    {
+        void *hp = nullptr, *dp = nullptr;
+        hipError_t e = hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped);
+        if (e == hipSuccess) { M->status_host = static_cast<int *>(hp); M->status_host[0] = M->status_host[1] = 0; e = hipHostGetDevicePointer(&dp, hp, 0); }
+        if (e != hipSuccess) { g_hip_err = std::string("status word: ") + hipGetErrorString(e); arb_model_destroy(M); return ARB_ERR_HIP; }
+        W.status = static_cast<int *>(dp); W.warn = static_cast<int *>(dp) + 1;
+    }
+    void *pw = nullptr;
+    hipError_t e = hipMalloc(&pw, sizeof(WideModel));
+    if (e == hipSuccess) { M->allocs.push_back(pw); e = hipMemcpy(pw, &W, sizeof(WideModel), hipMemcpyHostToDevice); }
+    if (e != hipSuccess) { g_hip_err = std::string("model upload: ") + hipGetErrorString(e); arb_model_destroy(M); return ARB_ERR_HIP; }
+    M->wide_dev = static_cast<WideModel *>(pw);
+    *out = M;
+    return ARB_OK;
+}
+
+// One launch of the wide kernel: grid = min(worlds, two workgroups per CU) workgroups that loop over the worlds, each with its
+// own block of stream-ordered scratch.
+template <typename T>
+static int wide_launch(arb_model *M, const WideIO<T> &io, long nw, double dt, const double *dts, int nsteps, unsigned flags, hipStream_t st) {
+    auto kern = arb_wide_kernel<T>;
+    const size_t lds = M->wide_lds;
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / std::max<size_t>(lds, 1))));
+    const unsigned grid = (unsigned)std::min<long>(nw, per_cu * std::max(1, device_cus(M->device)));
+    void *ws = nullptr;
+    HIP_TRY(arb_scratch_alloc(&ws, (size_t)grid * (size_t)M->wide.total * sizeof(double), st));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WIDE_THREADS), lds, st, M->wide_dev, io, nw, dt, dts, nsteps, flags, (double *)ws);
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(ws, st);
+    if (le != hipSuccess) { g_hip_err = std::string("kernel launch: ") + hipGetErrorString(le); return ARB_ERR_HIP; }
+    return ARB_OK;
+}
+
+template <typename T>
+static int wide_step(arb_model *M, void *q, void *dq, void *cf, const void *ext, const void *zimp, long nw, double dt, const double *dts,
+                     int nsteps, unsigned flags, const arb_rollout_log *log, hipStream_t st, long ext_stride) {
+    WideIO<T> io;
+    memset(&io, 0, sizeof(io));
+    io.q = (T *)q; io.dq = (T *)dq; io.cf = (T *)cf; io.ext = (const T *)ext; io.zimp = (const T *)zimp; io.ext_stride = ext_stride;
+    if (log) { io.log_q = (T *)log->q_log; io.log_dq = (T *)log->dq_log; }
+    return wide_launch<T>(M, io, nw, dt, dts, nsteps, flags, st);
+}
+
+template <typename T>
+static int wide_inspect(arb_model *M, const void *q, const void *dq, const void *cf, const void *ext, const void *zimp, long nw, double dt,
+                        unsigned flags, const arb_inspect_out *o, hipStream_t st) {
+    // what the wide kernel does not form: the body Jacobians and the separate world matrices (the object API of worlds this
+    // large runs through BatchedWorlds), the per-solve diagnostics
+    if (o->jac || o->djac || o->M || o->B || o->N || o->gs_stats || o->gs_trace || o->stamps || o->energy || o->pivot_growth) return ARB_ERR_UNSUPPORTED;
+    WideIO<T> io;
+    memset(&io, 0, sizeof(io));
+    io.q = (T *)q; io.dq = (T *)dq; io.cf = (T *)cf; io.ext = (const T *)ext; io.zimp = (const T *)zimp;
+    io.inspect = 1;
+    io.pose = (T *)o->pose; io.twist = (T *)o->twist; io.Zout = (T *)o->Z; io.gforce0 = (T *)o->gforce0; io.vel_free = (T *)o->vel_free;
+    io.c_sdist = (T *)o->c_sdist; io.c_active = (int *)o->c_active; io.c_jac = (T *)o->c_jac; io.c_force = (T *)o->c_force;
+    io.c_frame = (T *)o->c_frame; io.gforce = (T *)o->gforce; io.q_next = (T *)o->q_next; io.dq_next = (T *)o->dq_next;
+    io.c_adm = (T *)o->c_adm; io.c_vel = (T *)o->c_vel;
+    return wide_launch<T>(M, io, nw, dt, nullptr, 1, flags, st);
+}
+#endif  // ARB_WITH_WIDE
+
 // Pivot growth of the float32 elimination at the model's states of rest (see model_create): two worlds through the
 // float32 inspect kernel, free motion.  Synchronous (part of arb_model_create).
 static int probe_rest_growth(arb_model *M, const arb_model_desc *d, float *growth) {
@@ -764,6 +957,16 @@ extern "C" int arb_hook_set_knob(arb_model *M, const char *name, int value) {
 
 extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
     if (!M || !info) return ARB_ERR_INVALID;
+#if ARB_WITH_WIDE
+    if (M->is_wide) {
+        memset(info, 0, sizeof(*info));
+        info->nb = M->nb; info->ndof = M->n; info->nq = M->nq; info->nc = M->nc;
+        info->nmax = M->n; info->ncols = M->ncols; info->nsets = 1;
+        info->lds_bytes_f32 = info->lds_bytes_f64 = (int32_t)M->wide_lds;
+        info->device = M->device; info->forest_copies = 1; info->wide = 1;
+        return ARB_OK;
+    }
+#endif
     info->nb = M->nb; info->ndof = M->n; info->nq = M->nq; info->nc = M->nc;
     info->nmax = M->nmax; info->ncols = M->ncols; info->nsets = M->nsets;
     info->lds_bytes_f32 = M->lf.total * (int)sizeof(float);
@@ -1088,6 +1291,16 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     if (nworlds > 0x7fffffffLL) return ARB_ERR_INVALID;
     if (int stalled = take_status(M, false)) return stalled;
     ARB_GUARD_DEVICE(M->device);
+#if ARB_WITH_WIDE
+    if (M->is_wide) {
+        // (the wide kernel: float64 arithmetic for either buffer type; see arb_wide_kernel.h for what it takes)
+        if (pd_qdes != nullptr || pd_kp != nullptr || cost != nullptr || (log && log->energy_log) ||
+            (flags & (ARB_STEP_SPLIT_WAVE | ARB_STEP_MFMA_ELIM)) || pd_stride != 0) return ARB_ERR_UNSUPPORTED;
+        hipStream_t sw = reinterpret_cast<hipStream_t>(stream);
+        return dtype == ARB_F32 ? wide_step<float>(M, q, dq, cforce, ext_gforce, ext_imp, (long)nworlds, dt, dt_steps, nsteps, flags, log, sw, ext_stride)
+                                : wide_step<double>(M, q, dq, cforce, ext_gforce, ext_imp, (long)nworlds, dt, dt_steps, nsteps, flags, log, sw, ext_stride);
+    }
+#endif
     // (a dense per-world impedance couples any pair of dofs: the copies of a forest would no longer be independent blocks)
     if (use_forest(M, nworlds, flags, log, cost != nullptr || ext_imp != nullptr)) {
         // small worlds share wavefronts: nworlds / k worlds of the forest on the same buffers, the rest one per wavefront
@@ -1158,6 +1371,15 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
     if (flags & ~ARB_STEP_KNOWN_FLAGS) return ARB_ERR_INVALID;
     ARB_GUARD_DEVICE(M->device);
     if (optional_inputs < 0 || optional_inputs > 7 || (optional_inputs & 3) == 2) return ARB_ERR_INVALID;
+#if ARB_WITH_WIDE
+    if (M->is_wide) {          // one workgroup of four wavefronts per world, workgroups loop over the batch
+        memset(out, 0, sizeof(*out));
+        const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / std::max<size_t>(M->wide_lds, 1))));
+        out->waves_per_simd = 1; out->worlds_per_wavefront = 1; out->feat = 3; out->lds_bytes = (int32_t)M->wide_lds;
+        out->wave_slots = (int32_t)(per_cu * device_cus(M->device)); out->work_queue = 0;
+        return ARB_OK;
+    }
+#endif
     const bool world_logs = (optional_inputs & 4) != 0;      // per-world energies / costs, or state logs of a ragged batch: no forest
     optional_inputs &= 3;
     // (float32 buffers of a model only float64 carries: the launch runs the float64 kernels, see step_promoted)
@@ -1255,6 +1477,14 @@ static int inspect_impl(arb_model *M, int dtype, const void *q, const void *dq, 
     if (int stalled = take_status(M, false)) return stalled;
     ARB_GUARD_DEVICE(M->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#if ARB_WITH_WIDE
+    if (M->is_wide) {
+        if (a != nullptr && (a->pd_qdes || a->pd_kp)) return ARB_ERR_UNSUPPORTED;
+        const void *zi = a ? a->ext_impedance : nullptr;
+        return dtype == ARB_F32 ? wide_inspect<float>(M, q, dq, cforce, ext_gforce, zi, (long)nworlds, dt, flags, out, st)
+                                : wide_inspect<double>(M, q, dq, cforce, ext_gforce, zi, (long)nworlds, dt, flags, out, st);
+    }
+#endif
     if (dtype == ARB_F32)
         return inspect_t<float>(M, M->df_dev, M->lf, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st, a);
     return inspect_t<double>(M, M->dd_dev, M->ld, q, dq, cforce, ext_gforce, (long)nworlds, dt, flags, out, st, a);

@@ -1,0 +1,598 @@
+// arb_wide_kernel.h -- the WIDE step kernel (round 6): worlds of more than 64 dofs or bodies, one WORKGROUP of 256 lanes per
+// world (included by arb_kernels.hip only).
+//
+// The reference allocates any number of dofs (core.py:608-635; robots/snake.py:17-60 takes any n; human36 beside a few
+// free objects is past 64).  The step kernel of arb_step_kernel.h holds a world in ONE wavefront -- column per lane, the
+// augmented system in registers -- which ends at 64 dofs.  This kernel takes over above that: the same phases and the same
+// formulas (world-frame composite assembly of Z, increment form, pivot-free Gauss-Jordan from the last dof to the first,
+// 20 Gauss-Seidel sweeps with the local solves of arb_math.h), written for generality instead of for the last cycle:
+//   * float64 arithmetic whatever the buffers' type (T is only the type of the caller's state buffers);
+//   * a world's intermediate data lives in a per-workgroup block of global scratch (L2-resident: 50 KB .. 1 MB per world),
+//     the augmented system [Z | rhs | J'^T] in LDS when it fits 128 KB, in scratch otherwise; LDS also holds the pivot row
+//     and column of the elimination;
+//   * lane = body / dof / constraint / matrix entry as the phase needs, __syncthreads() between phases;
+//   * workgroups loop over the worlds of the batch (grid = min(worlds, 2 per CU)), steps loop inside.
+// Limits: ndof, nb <= ARB_WIDE_MAX (256), nc <= 64.  Supported inputs: state, constraint forces, user torques (constant or a
+// sequence), the dense impedance of user-defined controllers, per-step dt, state logs; the model's merged PD controllers.
+// Not supported (ARB_ERR_UNSUPPORTED): per-world PD inputs, energy logs, running costs, the split execution.
+#ifndef ARB_WIDE_KERNEL_H
+#define ARB_WIDE_KERNEL_H
+#define WIDE_THREADS 256
+#define WIDE_XK 30          // per dof: X (6) | dX' (6) | P (6) | R (6) | G (6)
+#define WIDE_CD 40          // per constraint: R (9) | p (3) | pos0 (3) | sdist | active | glo | ghi | pad ... | pinv (16) at 24
+
+struct WideModel {
+    int nb, n, nq, nc, ndol, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds;
+    double grav[3], up[3];
+    const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *weighted, *dof2q, *dofbody, *subsize;
+    const double *Hpr, *Hcn, *mass, *visc;                 // [nb][12], [nb][12], [nb][36], [nb][36]
+    const double *pd_kp, *pd_kd, *pd_tau0;                  // [n][n], [n][n], [n]
+    const int *ctype, *cen, *cbody, *cbody0, *cdof, *cgeom;
+    const double *clocal, *cradius, *cradius0, *chalf, *cplane, *cRz, *cb0, *cb1, *cmu, *ceps, *cprox, *cmin, *cmax;
+    // offsets (doubles) of the arrays of ONE world inside a workgroup's scratch block
+    long o_q, o_dq, o_qd, o_ff, o_ff0, o_pose, o_pc, o_rcp, o_tw, o_ab, o_om, o_da, o_tn, o_bn, o_pt, o_sc, o_ac, o_mc, o_wc, o_xk,
+         o_rh, o_z, o_jr, o_am, o_vv, o_cd, total;
+    int *status, *warn;
+};
+
+template <typename T>
+struct WideIO {
+    T *q, *dq, *cf;
+    const T *ext, *zimp;
+    long ext_stride;
+    T *log_q, *log_dq;                                      // [nsteps][nw][nq], [nsteps][nw][n] or null
+    // inspect outputs (any may be null; one step, the state buffers are not written when `inspect` is set)
+    int inspect;
+    T *pose, *twist, *Zout, *gforce0, *vel_free, *c_sdist, *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next, *c_adm, *c_vel;
+    int *c_active;
+};
+
+template <typename T>
+__global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel *__restrict__ mp_in, const WideIO<T> io, long nworlds,
+                                                                double dt_in, const double *__restrict__ dts, int nsteps,
+                                                                unsigned flags, double *__restrict__ scratch_all)
+{
+    const WideModel &M = *mp_in;
+    const int tid = threadIdx.x;
+    const int n = M.n, nb = M.nb, nq = M.nq, nc = M.nc, ndol = M.ndol, ncols = M.ncols, ld = M.ld;
+    double *lds = reinterpret_cast<double *>(arb_lds_raw);
+    double *TROW = lds;                      // [ncols]   the scaled pivot row
+    double *FCOL = TROW + ((ncols + 3) & ~3);   // [n]    the pivot column (multipliers)
+    double *DF = FCOL + ((n + 3) & ~3);      // [8]       force increment of one local solve
+    double *SWORK = DF + 8;                  // [48]      scratch of the sliding solve (eig6 fallback)
+    double *ZL = SWORK + 48;                 // [n][ld]   the augmented system, when it fits
+    double *S = scratch_all + (size_t)blockIdx.x * (size_t)M.total;
+    double *QS = S + M.o_q, *DQS = S + M.o_dq, *QD = S + M.o_qd, *FF = S + M.o_ff, *FF0 = S + M.o_ff0, *POSE = S + M.o_pose,
+           *PC = S + M.o_pc, *RCP = S + M.o_rcp, *TW = S + M.o_tw, *AB = S + M.o_ab, *OM = S + M.o_om, *DA = S + M.o_da,
+           *TN = S + M.o_tn, *BN = S + M.o_bn, *PT = S + M.o_pt, *SC = S + M.o_sc, *AC = S + M.o_ac, *MC = S + M.o_mc,
+           *WC = S + M.o_wc, *XK = S + M.o_xk, *RH = S + M.o_rh, *JR = S + M.o_jr, *AM = S + M.o_am, *VV = S + M.o_vv,
+           *CD = S + M.o_cd;
+    double *Z = M.z_in_lds ? ZL : S + M.o_z;
+    const bool do_con = nc > 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
+    auto ld3 = [](const double *p) { return v3<double>(p[0], p[1], p[2]); };
+    auto ldm = [](const double *p) { M3<double> r; for (int i = 0; i < 9; ++i) r.a[i] = p[i]; return r; };
+    auto st3 = [](double *p, V3<double> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; };
+    auto stm = [](double *p, const M3<double> &m) { for (int i = 0; i < 9; ++i) p[i] = m.a[i]; };
+    // body a is an ancestor of (or is) body b: DFS preorder makes every subtree a contiguous range
+    auto anc_eq = [&](int a, int b) { return a >= 0 && b >= 0 && a <= b && b < a + M.subsize[a]; };
+
+    for (long w = blockIdx.x; w < nworlds; w += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < nq; i += WIDE_THREADS) QS[i] = (double)io.q[w * nq + i];
+    for (int i = tid; i < n; i += WIDE_THREADS) DQS[i] = (double)io.dq[w * n + i];
+    for (int i = tid; i < ndol; i += WIDE_THREADS) FF[i] = io.cf != nullptr ? (double)io.cf[w * ndol + i] : 0.;
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const double dt = dts != nullptr ? dts[step] : dt_in, inv_dt = 1. / dt;
+        if (io.log_q != nullptr) for (int i = tid; i < nq; i += WIDE_THREADS) io.log_q[((long)step * nworlds + w) * nq + i] = (T)QS[i];
+        if (io.log_dq != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) io.log_dq[((long)step * nworlds + w) * n + i] = (T)DQS[i];
+        // ================= phase A: lane = body -- joint-local kinematics (core.py:1294-1315, rigidmotion.py:47-73) ==========
+        for (int b = tid; b < nb; b += WIDE_THREADS) {
+            const int jt = M.jtype[b], doff = M.dof_off[b], k = M.jnd[b];
+            JointLocal<double> jl;
+            joint_local<double>(jt, (const double *)(QS + M.q_off[b]), (const double *)(DQS + doff), jl);
+            const M3<double> R_pr = ldm(M.Hpr + 12 * b), R_cn = ldm(M.Hcn + 12 * b);
+            const V3<double> p_pr = ld3(M.Hpr + 12 * b + 9), p_cn = ld3(M.Hcn + 12 * b + 9);
+            const M3<double> R_rc = mulBT(jl.R, R_cn);                           // H_pc = H_pr H_rn inv(H_cn)   core.py:1298
+            const V3<double> p_rc = mv(jl.R, -mtv(R_cn, p_cn)) + jl.p;
+            const M3<double> R_pc = mul(R_pr, R_rc);
+            const V3<double> p_pc = mv(R_pr, p_rc) + p_pr;
+            stm(PC + 12 * b, R_pc); st3(PC + 12 * b + 9, p_pc);
+            const M3<double> R_cp = transpose(R_pc);                             // Ad_cp = Ad(inv(H_pc))        :1300
+            const V3<double> p_cp = -mtv(R_pc, p_pc);
+            stm(RCP + 12 * b, R_cp); st3(RCP + 12 * b + 9, p_cp);
+            const M3<double> R_nr = transpose(jl.R);
+            const V3<double> p_nr = -mtv(jl.R, jl.p);
+            const V3<double> aw = mv(R_nr, jl.Tw);                               // -T_rn
+            const V3<double> av = cross(p_nr, aw) + mv(R_nr, jl.Tv);
+            const Blk<double> Ad_nr = blk_adjoint(R_nr, p_nr);
+            const Blk<double> dAd_nr = blk_mul(Ad_nr, blk_adjacency(-aw, -av));
+            const Blk<double> Ad_cn = blk_adjoint(R_cn, p_cn);
+            const Blk<double> Ad_rp = blk_adjoint(transpose(R_pr), -mtv(R_pr, p_pr));
+            const Blk<double> dAd_cp = blk_mul(Ad_cn, blk_mul(dAd_nr, Ad_rp));   // core.py:1304
+            stm(DA + 18 * b, dAd_cp.A); stm(DA + 18 * b + 9, dAd_cp.B);
+            // W_c = Ad_cp Ad_pr T_rn: the pseudo twist's own term (see arb_phase_b.h)
+            {
+                const V3<double> uw = mv(R_pr, -aw);
+                const V3<double> uv = cross(p_pr, uw) + mv(R_pr, -av);
+                const V3<double> ww = mv(R_cp, uw);
+                st3(OM + 6 * b, ww); st3(OM + 6 * b + 3, cross(p_cp, ww) + mv(R_cp, uv));
+            }
+            V3<double> bw = v3<double>(0., 0., 0.);
+            if (jt != JT_FREE && jt != JT_TXTYTZ)
+                for (int i = 0; i < 3; ++i) if (i < k) bw = bw + DQS[doff + i] * jl.djw[i];
+            const V3<double> Bnw = mv(R_cn, bw);
+            st3(BN + 6 * b, Bnw); st3(BN + 6 * b + 3, cross(p_cn, Bnw));
+            const V3<double> Tnw = mv(R_cn, jl.Tw);
+            st3(TN + 6 * b, Tnw); st3(TN + 6 * b + 3, cross(p_cn, Tnw) + mv(R_cn, jl.Tv));
+            for (int i = 0; i < k; ++i) {                                        // own columns Ad_cn J_nr, Ad_cn dJ_nr  :1310, 1313
+                V3<double> cw = v3<double>(0., 0., 0.), cv = cw, dw = cw;
+                if (jt == JT_FREE) {
+                    if (i < 3) cw = v3<double>(i == 0 ? 1. : 0., i == 1 ? 1. : 0., i == 2 ? 1. : 0.);
+                    else cv = v3<double>(i == 3 ? 1. : 0., i == 4 ? 1. : 0., i == 5 ? 1. : 0.);
+                } else if (jt == JT_TXTYTZ) {
+                    cv = v3<double>(i == 0 ? 1. : 0., i == 1 ? 1. : 0., i == 2 ? 1. : 0.);
+                } else if (i < 3) {
+                    cw = jl.jw[i]; dw = jl.djw[i];
+                }
+                const V3<double> ow = mv(R_cn, cw), ov = cross(p_cn, ow) + mv(R_cn, cv);
+                const V3<double> dow = mv(R_cn, dw), dov = cross(p_cn, dow);
+                double *sc = SC + 12 * (doff + i);
+                st3(sc, ow); st3(sc + 3, ov); st3(sc + 6, dow); st3(sc + 9, dov);
+            }
+        }
+        for (int i = tid; i < n; i += WIDE_THREADS) { const int qi = M.dof2q[i]; QD[i] = qi >= 0 ? QS[qi] : 0.; }
+        __syncthreads();
+        // pose, twist, bias acceleration and pseudo twist down the tree, one depth level per pass
+        for (int lvl = 0; lvl <= M.maxdepth; ++lvl) {
+            for (int b = tid; b < nb; b += WIDE_THREADS) {
+                if (M.depth[b] != lvl) continue;
+                const int par = M.parent[b];
+                M3<double> Rg = m3_identity<double>();
+                V3<double> pg = v3<double>(0., 0., 0.), tw = pg, tv = pg, aw = pg, av = pg, omw = pg, omv = pg;
+                if (par >= 0) {
+                    Rg = ldm(POSE + 12 * par); pg = ld3(POSE + 12 * par + 9);
+                    tw = ld3(TW + 6 * par); tv = ld3(TW + 6 * par + 3);
+                    aw = ld3(AB + 6 * par); av = ld3(AB + 6 * par + 3);
+                    omw = ld3(OM + 6 * par); omv = ld3(OM + 6 * par + 3);
+                }
+                const M3<double> R_pc = ldm(PC + 12 * b), R_cp = ldm(RCP + 12 * b), dA = ldm(DA + 18 * b), dB = ldm(DA + 18 * b + 9);
+                const V3<double> p_pc = ld3(PC + 12 * b + 9), p_cp = ld3(RCP + 12 * b + 9);
+                stm(POSE + 12 * b, mul(Rg, R_pc)); st3(POSE + 12 * b + 9, mv(Rg, p_pc) + pg);          // core.py:1299
+                const V3<double> rtw = mv(R_cp, tw);
+                st3(TW + 6 * b, rtw + ld3(TN + 6 * b));                                                // core.py:1308
+                st3(TW + 6 * b + 3, cross(p_cp, rtw) + mv(R_cp, tv) + ld3(TN + 6 * b + 3));
+                const V3<double> raw = mv(R_cp, aw);                                                   // core.py:1312-1313 times gvel
+                st3(AB + 6 * b, mv(dA, tw) + raw + ld3(BN + 6 * b));
+                st3(AB + 6 * b + 3, mv(dB, tw) + mv(dA, tv) + cross(p_cp, raw) + mv(R_cp, av) + ld3(BN + 6 * b + 3));
+                if (par >= 0) {
+                    const V3<double> rw = mv(R_cp, omw);
+                    const V3<double> nv = cross(p_cp, rw) + mv(R_cp, omv) + ld3(OM + 6 * b + 3);
+                    st3(OM + 6 * b, rw + ld3(OM + 6 * b)); st3(OM + 6 * b + 3, nv);
+                }
+            }
+            __syncthreads();
+        }
+        // body wrench of the increment form: M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b   (core.py:975-976, 1276-1288)
+        for (int b = tid; b < nb; b += WIDE_THREADS) {
+            const double *Mb = M.mass + 36 * b;
+            double tw[6], ab[6], mt[6], ma[6], mg[6], g6[6] = {0., 0., 0., 0., 0., 0.};
+            for (int i = 0; i < 6; ++i) { tw[i] = TW[6 * b + i]; ab[i] = AB[6 * b + i]; }
+            mat6_vec<double>(Mb, tw, mt);
+            mat6_vec<double>(Mb, ab, ma);
+            if (M.has_grav && M.weighted[b]) {                                                          // controllers.py:56-58
+                const V3<double> gl = mtv(ldm(POSE + 12 * b), v3<double>(M.grav[0], M.grav[1], M.grav[2]));
+                g6[3] = gl.x; g6[4] = gl.y; g6[5] = gl.z;
+            }
+            mat6_vec<double>(Mb, g6, mg);
+            const V3<double> wv = v3<double>(tw[0], tw[1], tw[2]);
+            const M3<double> wx = hat(wv);
+            M3<double> rx = m3_zero<double>();
+            const double mm = Mb[21];
+            if (!(mm <= 1e-10)) {
+                const double im = 1. / mm;
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) rx.a[3 * i + j] = Mb[6 * i + 3 + j] * im;
+            }
+            const M3<double> Cm = sub(mul(rx, wx), mul(wx, rx));
+            const V3<double> mtt = v3<double>(mt[0], mt[1], mt[2]), mtb = v3<double>(mt[3], mt[4], mt[5]);
+            const V3<double> ntop = cross(wv, mtt) + mv(Cm, mtb), nbot = cross(wv, mtb);
+            double pt[6] = {mg[0] - ma[0] - ntop.x, mg[1] - ma[1] - ntop.y, mg[2] - ma[2] - ntop.z,
+                            mg[3] - ma[3] - nbot.x, mg[4] - ma[4] - nbot.y, mg[5] - ma[5] - nbot.z};
+            double pg6[6] = {mg[0], mg[1], mg[2], mg[3], mg[4], mg[5]};
+            if (M.has_visc) {
+                double vt[6];
+                mat6_vec<double>(M.visc + 36 * b, tw, vt);
+                for (int i = 0; i < 6; ++i) pt[i] -= vt[i];
+            }
+            for (int i = 0; i < 6; ++i) { PT[12 * b + i] = pt[i]; PT[12 * b + 6 + i] = pg6[i]; }
+        }
+        // ================= phase A': lane = constraint (constraints.py:277-294, 35-90, collisions.py) =====================
+        if (do_con) for (int c = tid; c < nc; c += WIDE_THREADS) {
+            double *cd = CD + WIDE_CD * c;
+            const int ct = M.ctype[c];
+            bool active = false;
+            double sd = 0.;
+            for (int i = 0; i < 24; ++i) cd[i] = 0.;
+            if (M.cen[c]) {
+                const int b0 = M.cbody0[c], b1 = M.cbody[c];
+                M3<double> Rg0 = m3_identity<double>(), Rg1 = Rg0;
+                V3<double> pg0 = v3<double>(0., 0., 0.), pg1 = pg0, bw0 = pg0, bv0 = pg0, bw1 = pg0, bv1 = pg0;
+                if (ct != ARB_CT_JOINTLIMITS) {
+                    if (b0 >= 0) { Rg0 = ldm(POSE + 12 * b0); pg0 = ld3(POSE + 12 * b0 + 9); bw0 = ld3(TW + 6 * b0); bv0 = ld3(TW + 6 * b0 + 3); }
+                    if (b1 >= 0) { Rg1 = ldm(POSE + 12 * b1); pg1 = ld3(POSE + 12 * b1 + 9); bw1 = ld3(TW + 6 * b1); bv1 = ld3(TW + 6 * b1 + 3); }
+                }
+                if (ct == ARB_CT_SOFTFINGER) {
+                    const M3<double> Rs0 = mul(Rg0, ldm(M.cb0 + 12 * c));
+                    const V3<double> ps0 = mv(Rg0, ld3(M.cb0 + 12 * c + 9)) + pg0;
+                    const V3<double> p_g1 = mv(Rg1, ld3(M.clocal + 3 * c)) + pg1;
+                    V3<double> gc0, gc1;
+                    M3<double> Rc;
+                    sd = narrow_phase(M.cgeom[c], Rs0, ps0, p_g1, M.cradius[c], M.cradius0[c], ld3(M.chalf + 3 * c),
+                                      ld3(M.cplane + 4 * c), M.cplane[4 * c + 3], ldm(M.cRz + 9 * c), gc0, gc1, Rc);
+                    const M3<double> R1 = mulTA(Rc, Rg1), R0 = mulTA(Rc, Rg0);
+                    const V3<double> P1 = mtv(Rc, pg1 - gc0), P0 = mtv(Rc, pg0 - gc0);
+                    const double vz1 = (mv(R1, bv1) + cross(P1, mv(R1, bw1))).z;                        // constraints.py:289-291
+                    const double vz0 = (mv(R0, bv0) + cross(P0, mv(R0, bw0))).z;
+                    active = (sd + (vz1 - vz0) * dt < M.cprox[c]);
+                    stm(cd, transpose(Rc)); st3(cd + 9, -mtv(Rc, gc0));      // world axes about the WORLD origin -> contact frame 0
+                    for (int i = 0; i < 4; ++i) FF[4 * c + i] = 0.;           // constraints.py:294
+                    if (io.inspect && io.c_frame != nullptr && step == 0) {
+                        for (int f = 0; f < 2; ++f) {
+                            T *of = io.c_frame + ((w * nc + c) * 2 + f) * 16;
+                            const V3<double> gf = f ? gc1 : gc0;
+                            for (int i = 0; i < 3; ++i) {
+                                for (int j = 0; j < 3; ++j) of[4 * i + j] = (T)Rc.a[3 * i + j];
+                                of[4 * i + 3] = (T)(i == 0 ? gf.x : i == 1 ? gf.y : gf.z);
+                            }
+                            of[12] = of[13] = of[14] = T(0); of[15] = T(1);
+                        }
+                    }
+                } else if (ct == ARB_CT_JOINTLIMITS) {
+                    const double p0 = QD[M.cdof[c]];
+                    active = (p0 - M.cmin[c] < M.cprox[c]) || (M.cmax[c] - p0 < M.cprox[c]);
+                    cd[12] = p0; cd[17] = (M.cmin[c] - p0) / dt; cd[18] = (M.cmax[c] - p0) / dt;
+                    for (int i = 0; i < 4; ++i) FF[4 * c + i] = 0.;           // constraints.py:58-60
+                    sd = p0;
+                } else {                                                      // BallAndSocket  constraints.py:196-207
+                    const M3<double> RP0 = mul(Rg0, ldm(M.cb0 + 12 * c));
+                    const V3<double> pP0 = mv(Rg0, ld3(M.cb0 + 12 * c + 9)) + pg0, pP1 = mv(Rg1, ld3(M.cb1 + 12 * c + 9)) + pg1;
+                    st3(cd + 12, mtv(RP0, pP1 - pP0));
+                    stm(cd, transpose(RP0)); st3(cd + 9, -mtv(RP0, pP0));
+                    active = true;
+                }
+            }
+            cd[15] = sd; cd[16] = active ? 1. : 0.;
+        }
+        __syncthreads();
+        for (int i = tid; i < ndol; i += WIDE_THREADS) FF0[i] = FF[i];
+        // ================= phase B: composite assembly of Z = M/dt + B + N (core.py:722-734, 813), see arb_phase_b.h =========
+        // ---- lane = body: world-frame matrices about the WORLD origin -------------------------------------------------
+        for (int b = tid; b < nb; b += WIDE_THREADS) {
+            const M3<double> R = ldm(POSE + 12 * b);
+            const V3<double> p = ld3(POSE + 12 * b + 9);
+            const double *Mb = M.mass + 36 * b;
+            auto blk = [](const double *m6, int r0, int c0) {
+                M3<double> o;
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o.a[3 * i + j] = m6[6 * (r0 + i) + c0 + j];
+                return o;
+            };
+            auto rot = [&](const M3<double> &Xm) { return mul(R, mulBT(Xm, R)); };
+            auto rowcross = [](const M3<double> &Xm, V3<double> v) {
+                M3<double> o;
+                for (int i = 0; i < 3; ++i) {
+                    const V3<double> c = cross(v3<double>(Xm.a[3 * i], Xm.a[3 * i + 1], Xm.a[3 * i + 2]), v);
+                    o.a[3 * i] = c.x; o.a[3 * i + 1] = c.y; o.a[3 * i + 2] = c.z;
+                }
+                return o;
+            };
+            double G[36], A[36];
+            {
+                const M3<double> M11 = rot(blk(Mb, 0, 0)), M12 = rot(blk(Mb, 0, 3)), M22 = rot(blk(Mb, 3, 3));
+                const M3<double> G12 = add(M12, hatmul(p, M22));
+                const M3<double> G21 = transpose(G12);
+                const M3<double> G11 = add(sub(M11, rowcross(M12, p)), hatmul(p, G21));
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                    G[6 * i + j] = G11.a[3 * i + j]; G[6 * i + 3 + j] = G12.a[3 * i + j];
+                    G[6 * (3 + i) + j] = G21.a[3 * i + j]; G[6 * (3 + i) + 3 + j] = M22.a[3 * i + j];
+                }
+            }
+            const V3<double> wb = ld3(TW + 6 * b);
+            const double mm = Mb[21];
+            V3<double> cm = v3<double>(0., 0., 0.);
+            if (!(mm <= 1e-10)) cm = (1. / mm) * v3<double>(Mb[6 * 2 + 4], Mb[6 * 0 + 5], Mb[6 * 1 + 3]);
+            const V3<double> Tw = mv(R, wb), Tv = mv(R, cross(cm, wb)) + cross(p, Tw);
+            const V3<double> ow = mv(R, ld3(OM + 6 * b)), ov = mv(R, ld3(OM + 6 * b + 3)) + cross(p, ow);
+            for (int i = 0; i < 36; ++i) A[i] = inv_dt * G[i];
+            for (int j = 0; j < 6; ++j) {                        // -ad(T*)^T Mg
+                const V3<double> gt = v3<double>(G[j], G[6 + j], G[12 + j]), gb = v3<double>(G[18 + j], G[24 + j], G[30 + j]);
+                const V3<double> t = cross(Tw, gt) + cross(Tv, gb), u = cross(Tw, gb);
+                A[j] += t.x; A[6 + j] += t.y; A[12 + j] += t.z; A[18 + j] += u.x; A[24 + j] += u.y; A[30 + j] += u.z;
+            }
+            for (int r = 0; r < 6; ++r) {                        // Mg ad(Om)
+                const V3<double> gl = v3<double>(G[6 * r], G[6 * r + 1], G[6 * r + 2]), gr = v3<double>(G[6 * r + 3], G[6 * r + 4], G[6 * r + 5]);
+                const V3<double> t = cross(gl, ow) + cross(gr, ov), u = cross(gr, ow);
+                A[6 * r] += t.x; A[6 * r + 1] += t.y; A[6 * r + 2] += t.z; A[6 * r + 3] += u.x; A[6 * r + 4] += u.y; A[6 * r + 5] += u.z;
+            }
+            if (M.has_visc) {
+                const double *Vb = M.visc + 36 * b;
+                const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
+                const M3<double> H12 = add(B12, hatmul(p, B22));
+                const M3<double> H21 = sub(B21, rowcross(B22, p));
+                const M3<double> H11 = add(sub(B11, rowcross(B12, p)), hatmul(p, H21));
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                    A[6 * i + j] += H11.a[3 * i + j]; A[6 * i + 3 + j] += H12.a[3 * i + j];
+                    A[6 * (3 + i) + j] += H21.a[3 * i + j]; A[6 * (3 + i) + 3 + j] += B22.a[3 * i + j];
+                }
+            }
+            for (int i = 0; i < 36; ++i) { AC[36 * b + i] = A[i]; MC[36 * b + i] = G[i]; }
+            for (int h = 0; h < 2; ++h) {                        // wrenches to world axes: increment rhs, gravity alone
+                const double *pt = PT + 12 * b + 6 * h;
+                const V3<double> f = mv(R, v3<double>(pt[3], pt[4], pt[5]));
+                const V3<double> tq = mv(R, v3<double>(pt[0], pt[1], pt[2])) + cross(p, f);
+                double *wc = WC + 12 * b + 6 * h;
+                st3(wc, tq); st3(wc + 3, f);
+            }
+        }
+        __syncthreads();
+        // ---- subtree sums: lane = entry, bodies from the leaves to the roots (parent[b] < b) ------------------------
+        for (int e = tid; e < 84; e += WIDE_THREADS) {
+            double *arr = e < 36 ? AC : e < 72 ? MC : WC;
+            const int st = e < 72 ? 36 : 12, off = e < 36 ? e : e < 72 ? e - 36 : e - 72;
+            for (int b = nb - 1; b >= 1; --b) {
+                const int par = M.parent[b];
+                if (par >= 0) arr[st * par + off] += arr[st * b + off];
+            }
+        }
+        __syncthreads();
+        // ---- lane = dof k: own column in world axes, the products with the composites of body(k) -----------------------
+        for (int k = tid; k < n; k += WIDE_THREADS) {
+            const int b = M.dofbody[k];
+            const M3<double> R = ldm(POSE + 12 * b);
+            const V3<double> p = ld3(POSE + 12 * b + 9);
+            const double *sc = SC + 12 * k;
+            const V3<double> sw = ld3(sc), sv = ld3(sc + 3), dsw = ld3(sc + 6), dsv = ld3(sc + 9);
+            const V3<double> okw = ld3(OM + 6 * b), okv = ld3(OM + 6 * b + 3);
+            const V3<double> xw = mv(R, sw), xv = mv(R, sv) + cross(p, xw);
+            const V3<double> aw2 = dsw - cross(okw, sw), av2 = dsv - cross(okv, sw) - cross(okw, sv);
+            const V3<double> dw = mv(R, aw2), dv = mv(R, av2) + cross(p, dw);
+            const double X[6] = {xw.x, xw.y, xw.z, xv.x, xv.y, xv.z}, dX[6] = {dw.x, dw.y, dw.z, dv.x, dv.y, dv.z};
+            const double *Ac = AC + 36 * b, *Mc = MC + 36 * b, *Wc = WC + 12 * b;
+            double *xk = XK + WIDE_XK * k;
+            double rm = 0., rg = 0.;
+            for (int r = 0; r < 6; ++r) {
+                double g = 0., pp = 0., rr = 0.;
+                for (int c2 = 0; c2 < 6; ++c2) {
+                    g += Ac[6 * r + c2] * X[c2] + Mc[6 * r + c2] * dX[c2];
+                    pp += Ac[6 * c2 + r] * X[c2];
+                    rr += Mc[6 * r + c2] * X[c2];
+                }
+                xk[r] = X[r]; xk[6 + r] = dX[r]; xk[12 + r] = pp; xk[18 + r] = rr; xk[24 + r] = g;
+                rm += X[r] * Wc[r]; rg += X[r] * Wc[6 + r];
+            }
+            RH[k] = rm; RH[n + k] = rg;
+        }
+        __syncthreads();
+        // ---- the augmented system [Z | rhs | J'^T]: lane = entry --------------------------------------------------------
+        for (int e = tid; e < n * n; e += WIDE_THREADS) {
+            const int i = e / n, c = e - i * n;
+            double v = 0.;
+            {
+                const int bi = M.dofbody[i], bk = M.dofbody[c];
+                const double *xi = XK + WIDE_XK * i, *xc = XK + WIDE_XK * c;
+                if (anc_eq(bi, bk)) {                            // row i is the column's own or an ancestor's dof: X_i . G_k
+                    for (int r = 0; r < 6; ++r) v += xi[r] * xc[24 + r];
+                } else if (anc_eq(bk, bi)) {                     // a descendant's: P_i . X_k + R_i . dX'_k
+                    for (int r = 0; r < 6; ++r) v += xi[12 + r] * xc[r] + xi[18 + r] * xc[6 + r];
+                }
+                if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];              // controllers.py:141-158
+                if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];      // core.py:815-817
+            }
+            Z[i * ld + c] = v;
+        }
+        // constraint rows s_k [Ad(c0<-g) X_k] (constraints.py:429-433, 203-207, 46-48): rows of J' in JR, columns of J'^T in Z
+        if (do_con) for (int e = tid; e < ndol * n; e += WIDE_THREADS) {
+            const int idx = e / n, k = e - idx * n, c = idx >> 2, r = idx & 3;
+            const double *cd = CD + WIDE_CD * c;
+            const int ct = M.ctype[c];
+            double v = 0.;
+            if (cd[16] != 0.) {
+                if (ct == ARB_CT_JOINTLIMITS) {
+                    v = (r == 0 && k == M.cdof[c]) ? 1. : 0.;
+                } else if (r < (ct == ARB_CT_SOFTFINGER ? 4 : 3)) {
+                    const int bk = M.dofbody[k];
+                    const double s = (anc_eq(bk, M.cbody[c]) ? 1. : 0.) - (anc_eq(bk, M.cbody0[c]) ? 1. : 0.);
+                    if (s != 0.) {
+                        const double *xk = XK + WIDE_XK * k;
+                        const M3<double> Rx = ldm(cd);
+                        const V3<double> cw = mv(Rx, v3<double>(xk[0], xk[1], xk[2]));
+                        const V3<double> cv = mv(Rx, v3<double>(xk[3], xk[4], xk[5])) + cross(ld3(cd + 9), cw);
+                        if (ct == ARB_CT_SOFTFINGER) v = s * (r == 0 ? cw.z : r == 1 ? cv.x : r == 2 ? cv.y : cv.z);
+                        else v = s * (r == 0 ? cv.x : r == 1 ? cv.y : cv.z);
+                    }
+                }
+            }
+            JR[idx * n + k] = v;
+            Z[k * ld + n + 1 + idx] = v;
+        }
+        __syncthreads();
+        // right-hand side of the increment form: gforce - (N + B - Z_a) gvel (+ J'^T f0, core.py:921-924)
+        for (int i = tid; i < n; i += WIDE_THREADS) {
+            double ext = 0.;
+            if (io.ext != nullptr) ext = (double)io.ext[(long)step * io.ext_stride + w * n + i];
+            double rhs = RH[i] + ext, gf0 = RH[n + i] + ext;
+            if (M.has_pd) {
+                double acc = M.pd_tau0[i], accv = 0.;
+                for (int j = 0; j < n; ++j) {
+                    const double kp = M.pd_kp[i * n + j], kd = M.pd_kd[i * n + j];
+                    acc -= kp * QD[j];
+                    accv += (dt * kp + kd) * DQS[j];
+                }
+                rhs += acc - accv; gf0 += acc;
+            }
+            if (io.zimp != nullptr) {
+                double accz = 0.;
+                for (int j = 0; j < n; ++j) accz += (double)io.zimp[((long)w * n + i) * n + j] * DQS[j];
+                rhs += accz;
+            }
+            if (do_con && M.has_warm) for (int idx = 0; idx < ndol; ++idx) rhs += JR[idx * n + i] * FF[idx];
+            if (io.inspect) {
+                if (io.gforce0 != nullptr) io.gforce0[w * n + i] = (T)gf0;
+                if (io.Zout != nullptr) for (int c = 0; c < n; ++c) io.Zout[((long)w * n + i) * n + c] = (T)Z[i * ld + c];
+                RH[n + i] = gf0;
+            }
+            Z[i * ld + n] = rhs;
+        }
+        __syncthreads();
+        // ================= phase C: pivot-free Gauss-Jordan, pivots from the last dof to the first (core.py:818) ==========
+        const int nact = do_con ? ncols : n + 1;
+        for (int j = n - 1; j >= 0; --j) {
+            const double ip = 1. / Z[j * ld + j];
+            // (columns j+1 .. n-1 of row j are zero by now: their pivots are taken)
+            for (int c = tid; c < nact; c += WIDE_THREADS) TROW[c] = (c <= j || c >= n) ? Z[j * ld + c] * ip : 0.;
+            for (int r = tid; r < n; r += WIDE_THREADS) FCOL[r] = (r == j) ? 0. : Z[r * ld + j];
+            __syncthreads();
+            const int ncj = (j + 1) + (nact - n);                    // live columns: 0 .. j and n .. nact - 1
+            for (int e = tid; e < n * ncj; e += WIDE_THREADS) {
+                const int r = e / ncj, cc = e - r * ncj, c = cc <= j ? cc : n + (cc - j - 1);
+                if (r == j) Z[r * ld + c] = TROW[c];
+                else {
+                    const double f = FCOL[r];
+                    if (f != 0.) Z[r * ld + c] -= f * TROW[c];
+                }
+            }
+            __syncthreads();
+        }
+        // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
+        for (int i = tid; i < n; i += WIDE_THREADS) Z[i * ld + n] += DQS[i];
+        __syncthreads();
+        if (io.inspect && io.vel_free != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) io.vel_free[w * n + i] = (T)Z[i * ld + n];
+        // ================= phase D: [v' | Y'] = J' [Y rhs | Y J'^T] (core.py:925-927), block inverses =========================
+        if (do_con) {
+            for (int e = tid; e < ndol * (ndol + 1); e += WIDE_THREADS) {
+                const int idx = e / (ndol + 1), c = e - idx * (ndol + 1);
+                double acc = 0.;
+                if (CD[WIDE_CD * (idx >> 2) + 16] != 0.) {
+                    const double *jr = JR + idx * n;
+                    for (int k = 0; k < n; ++k) acc += jr[k] * Z[k * ld + n + c];
+                }
+                if (c == 0) VV[idx] = acc; else AM[idx * ndol + (c - 1)] = acc;
+            }
+            __syncthreads();
+            if (io.inspect) {
+                if (io.c_adm != nullptr) for (int i = tid; i < ndol * ndol; i += WIDE_THREADS) io.c_adm[(long)w * ndol * ndol + i] = (T)AM[i];
+                if (io.c_vel != nullptr) for (int i = tid; i < ndol; i += WIDE_THREADS) io.c_vel[(long)w * ndol + i] = (T)VV[i];
+                if (io.c_jac != nullptr) for (int i = tid; i < ndol * n; i += WIDE_THREADS) io.c_jac[(long)w * ndol * n + i] = (T)JR[i];
+            }
+            for (int c = tid; c < nc; c += WIDE_THREADS) {
+                double *cd = CD + WIDE_CD * c;
+                if (cd[16] == 0.) continue;
+                const int ct = M.ctype[c], nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
+                double P[16];
+                if (!inv_block<double>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P)) pinv_block<double>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+                for (int i = 0; i < 16; ++i) cd[24 + i] = P[i];
+            }
+            __syncthreads();
+            // ---- 20 Gauss-Seidel sweeps, constraints in registration order (core.py:929-935): lane 0 solves, all lanes update v'
+            for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+                for (int c = 0; c < nc; ++c) {
+                    const double *cd = CD + WIDE_CD * c;
+                    if (cd[16] == 0.) continue;                                  // (wave-uniform: the same value for every lane)
+                    if (tid == 0) {
+                        const int ct = M.ctype[c];
+                        double v[4], Yb[16], f[4], df[4] = {0., 0., 0., 0.};
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = VV[4 * c + i]; f[i] = FF[4 * c + i];
+                            for (int j2 = 0; j2 < 4; ++j2) Yb[4 * i + j2] = AM[(4 * c + i) * ndol + 4 * c + j2];
+                        }
+                        if (ct == ARB_CT_SOFTFINGER) {                           // constraints.py:780-836
+                            const double eps[3] = {M.ceps[3 * c], M.ceps[3 * c + 1], M.ceps[3 * c + 2]};
+                            (void)softfinger_solve<double>(v, Yb, cd + 24, f, df, cd[15], dt, M.cmu[c], eps, SWORK);
+                        } else if (ct == ARB_CT_BALLSOCKET) {                    // constraints.py:235-237
+                            const double *P = cd + 24;
+                            for (int i = 0; i < 3; ++i) {
+                                df[i] = -(P[4 * i] * (v[0] + cd[12] * inv_dt) + P[4 * i + 1] * (v[1] + cd[13] * inv_dt) + P[4 * i + 2] * (v[2] + cd[14] * inv_dt));
+                                f[i] += df[i];
+                            }
+                        } else {                                                 // JointLimits.solve constraints.py:73-90
+                            const double v0 = v[0] - Yb[0] * f[0], p00 = cd[24];
+                            double nf = 0.;
+                            if (v0 <= cd[17]) nf = p00 * (cd[17] - v0);
+                            else if (cd[18] <= v0) nf = p00 * (cd[18] - v0);
+                            df[0] = nf - f[0]; f[0] = nf;
+                        }
+                        for (int i = 0; i < 4; ++i) { FF[4 * c + i] = f[i]; DF[i] = df[i]; }
+                    }
+                    __syncthreads();
+                    for (int r = tid; r < ndol; r += WIDE_THREADS) {              // vel += Y'[:, c] dforce   core.py:935
+                        const double *a = AM + r * ndol + 4 * c;
+                        VV[r] += a[0] * DF[0] + a[1] * DF[1] + a[2] * DF[2] + a[3] * DF[3];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        // ================= phase E: new velocity, integrate (core.py:974-980, joints.py:54-57) ================================
+        if (io.inspect) {
+            if (io.gforce != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) {
+                double g = RH[n + i];
+                if (do_con) for (int idx = 0; idx < ndol; ++idx) g += JR[idx * n + i] * FF[idx];
+                io.gforce[w * n + i] = (T)g;
+            }
+            if (io.c_force != nullptr) for (int i = tid; i < ndol; i += WIDE_THREADS) io.c_force[w * ndol + i] = (T)FF[i];
+            for (int c = tid; c < nc; c += WIDE_THREADS) {
+                if (io.c_sdist != nullptr) io.c_sdist[w * nc + c] = do_con ? (T)CD[WIDE_CD * c + 15] : T(0);
+                if (io.c_active != nullptr) io.c_active[w * nc + c] = (do_con && CD[WIDE_CD * c + 16] != 0.) ? 1 : 0;
+            }
+            if (io.pose != nullptr) for (int b = tid; b < nb; b += WIDE_THREADS) {
+                T *o = io.pose + (w * nb + b) * 16;
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = 0; j < 3; ++j) o[4 * i + j] = (T)POSE[12 * b + 3 * i + j];
+                    o[4 * i + 3] = (T)POSE[12 * b + 9 + i];
+                }
+                o[12] = o[13] = o[14] = T(0); o[15] = T(1);
+            }
+            if (io.twist != nullptr) for (int i = tid; i < 6 * nb; i += WIDE_THREADS) io.twist[w * nb * 6 + i] = (T)TW[i];
+        }
+        for (int i = tid; i < n; i += WIDE_THREADS) {
+            double vnew = Z[i * ld + n];
+            if (do_con) for (int idx = 0; idx < ndol; ++idx) vnew += Z[i * ld + n + 1 + idx] * (FF[idx] - FF0[idx]);
+            RH[i] = vnew;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += WIDE_THREADS) {
+            const double vnew = RH[i];
+            DQS[i] = vnew;
+            const int qi = M.dof2q[i];
+            if (qi >= 0) QS[qi] += dt * vnew;                                   // core.py:238-240
+        }
+        __syncthreads();
+        for (int b = tid; b < nb; b += WIDE_THREADS) {
+            if (M.jtype[b] != JT_FREE) continue;
+            double *qp = QS + M.q_off[b];
+            const double *vp = DQS + M.dof_off[b];
+            M3<double> R, Re; V3<double> p, pe;
+            R.a[0] = qp[0]; R.a[1] = qp[1]; R.a[2] = qp[2]; p.x = qp[3];
+            R.a[3] = qp[4]; R.a[4] = qp[5]; R.a[5] = qp[6]; p.y = qp[7];
+            R.a[6] = qp[8]; R.a[7] = qp[9]; R.a[8] = qp[10]; p.z = qp[11];
+            exp_twist<double>(dt * v3<double>(vp[0], vp[1], vp[2]), dt * v3<double>(vp[3], vp[4], vp[5]), Re, pe);
+            const M3<double> Rn = mul(R, Re);
+            const V3<double> pn = mv(R, pe) + p;
+            qp[0] = Rn.a[0]; qp[1] = Rn.a[1]; qp[2] = Rn.a[2]; qp[3] = pn.x;
+            qp[4] = Rn.a[3]; qp[5] = Rn.a[4]; qp[6] = Rn.a[5]; qp[7] = pn.y;
+            qp[8] = Rn.a[6]; qp[9] = Rn.a[7]; qp[10] = Rn.a[8]; qp[11] = pn.z;
+            qp[12] = 0.; qp[13] = 0.; qp[14] = 0.; qp[15] = 1.;
+        }
+        __syncthreads();
+    }   // steps
+    if (io.inspect) {
+        if (io.q_next != nullptr) for (int i = tid; i < nq; i += WIDE_THREADS) io.q_next[w * nq + i] = (T)QS[i];
+        if (io.dq_next != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) io.dq_next[w * n + i] = (T)DQS[i];
+    } else {
+        for (int i = tid; i < nq; i += WIDE_THREADS) io.q[w * nq + i] = (T)QS[i];
+        for (int i = tid; i < n; i += WIDE_THREADS) io.dq[w * n + i] = (T)DQS[i];
+        if (io.cf != nullptr) for (int i = tid; i < ndol; i += WIDE_THREADS) io.cf[w * ndol + i] = (T)FF[i];
+    }
+    }   // worlds
+}
+#endif  // ARB_WIDE_KERNEL_H

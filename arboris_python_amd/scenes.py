@@ -63,6 +63,33 @@ def human36_world(contacts=0, gravity=True, friction_coeff=0.6, pd=False):
     return w
 
 
+def human36_and_objects_world(nobjects=4, friction_coeff=0.6):
+    """human36 on the floor (its four heel / toe-tip contacts) beside ``nobjects`` free boxes, each carrying a ball that
+    touches the floor: 42 + 6 nobjects dofs -- with four objects 66, PAST the 64 lanes of one wavefront: the smallest
+    everyday scene that needs the wide kernels (csrc/arb_wide_kernel.h; the reference allocates any ndof, core.py:608-635)."""
+    from .core import Body
+    from .joints import FreeJoint
+    from .shapes import Sphere
+    from . import massmatrix, homogeneousmatrix as Hg
+    w = World()
+    add_groundplane(w)
+    add_human36(w)
+    for k in range(nobjects):
+        he = (0.10 + 0.02 * k, 0.08, 0.12)
+        body = Body(name="Box%d" % k, mass=massmatrix.box(he, 2.0 + k))
+        j = FreeJoint(name="BoxRoot%d" % k)
+        j.gpos = Hg.transl(0.6 + 0.5 * k, 0.13 + 0.01 * k, 0.4 - 0.3 * k)
+        w.add_link(w.ground, j, body)
+        w.register(Sphere(body, 0.12, name="Box%d ball" % k))
+    w.register(WeightController())
+    for c in get_all_contacts(w, friction_coeff=friction_coeff):
+        s0, s1 = c._shapes
+        if type(s0).__name__ == "Plane" and (s1.name in FOUR_CONTACTS or str(s1.name).endswith(" ball")):
+            w.register(c)
+    w.init()
+    return w
+
+
 def flat(world):
     """FlatModel of an initialised world."""
     return flatten_world(world)[0]

@@ -18,7 +18,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def random_world(seed):
+def random_world(seed, nbody_range=(3, 11), max_dof=40, max_contacts=6, max_spheres=4):
     from arboris_python_amd.core import World, Body, SubFrame
     from arboris_python_amd import joints as J, massmatrix as mm, homogeneousmatrix as Hg
     from arboris_python_amd.shapes import Sphere, Plane, Point
@@ -28,7 +28,7 @@ def random_world(seed):
     w = World()
     w.register(Plane(w.ground, (0., 1., 0., -0.4), 'floor'))
     kinds = [J.FreeJoint, J.RzRyRxJoint, J.RzRyJoint, J.RzRxJoint, J.RyRxJoint, J.RzJoint, J.RyJoint, J.RxJoint, J.TxTyTzJoint]
-    nbody = int(rng.integers(3, 11))
+    nbody = int(rng.integers(*nbody_range))
     bodies = []
 
     def rand_frame(scale=0.3):
@@ -44,7 +44,7 @@ def random_world(seed):
             b.viscosity = 0.02 * (A @ A.T)
         parent = w.ground if (k == 0 or rng.uniform() < 0.15) else bodies[int(rng.integers(0, len(bodies)))]
         kind = kinds[int(rng.integers(0, len(kinds)))] if k else kinds[int(rng.choice([0, 1, 8, 5]))]
-        if ndof + kind().ndof > 40:
+        if ndof + kind().ndof > max_dof:
             break
         j = kind(name='j%d' % k)
         if isinstance(j, J.FreeJoint):
@@ -61,7 +61,7 @@ def random_world(seed):
             hinges.append(j)
     nsph = 0
     for b in bodies:
-        if rng.uniform() < 0.45 and nsph < 4:
+        if rng.uniform() < 0.45 and nsph < max_spheres:
             fr = SubFrame(b, Hg.transl(*rng.uniform(-0.15, 0.15, 3)), name='s%d' % nsph)
             w.register(Sphere(fr, float(rng.uniform(0.03, 0.12)), name='ball%d' % nsph) if rng.uniform() < 0.7
                        else Point(fr, name='pt%d' % nsph))
@@ -69,7 +69,7 @@ def random_world(seed):
     w.register(WeightController())
     ncon = 0
     for c in get_all_contacts(w, friction_coeff=float(rng.uniform(0.3, 1.2))):
-        if ncon < 6:
+        if ncon < max_contacts:
             w.register(c)
             ncon += 1
     if len(bodies) >= 3 and rng.uniform() < 0.5:

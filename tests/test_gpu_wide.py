@@ -1,0 +1,181 @@
+"""Worlds PAST one wavefront (round 6): more than 64 dofs or bodies run on the wide kernels (csrc/arb_wide_kernel.h: one
+workgroup per world, float64 arithmetic) behind the same C ABI -- `arb_model_create` picks the path, `arb_model_info.wide`
+says so.  The reference allocates any number of dofs (core.py:608-635), `add_snake(w, n)` takes any n
+(robots/snake.py:17-60), human36 beside four free objects has 66.  Against the oracle, float64 (1e-8 where the oracle's own
+explicit inverse allows it), through float32 and float64 buffers, one step and whole launches."""
+import numpy as np
+import pytest
+
+import arb_oracle as O
+from arboris_python_amd import _capi
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.max(np.abs(a - b), axis=-1) / np.maximum(1., np.max(np.abs(b), axis=-1))
+
+
+@pytest.mark.parametrize("seed", range(1, 11))
+def test_wide_random_trees_against_the_oracle(seed):
+    """Random trees of 20-45 bodies and 65-200 dofs: every joint type, rotated frames on both sides of the joints, several
+    roots, viscosity, spheres on a floor and on one another, a ball-and-socket loop closure, joint limits (the generator of
+    tests/test_gpu_random_models.py with larger bounds): one step, float64, 1e-8 per world."""
+    from test_gpu_random_models import random_world
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    from arboris_python_amd import synth
+    w = random_world(1000 + seed, nbody_range=(24, 46), max_dof=200, max_contacts=12, max_spheres=8)
+    m, q0, dq0 = flatten_world(w)
+    if m.ndof <= 64 and m.nb <= 64:
+        pytest.skip("the generator came out small: %d dofs" % m.ndof)
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1 and bw.info["ndof"] == m.ndof
+    B = 6
+    q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1))
+    qr, dqr = synth.random_states(m, B, seed=seed, angle=0.8, vel=1.5, root_box=((-.3, .3), (-.2, .5), (-.3, .3)))
+    q[1:], dq[1:] = qr[1:], dqr[1:]
+    dt = 2e-3
+    cf0 = np.zeros((B, m.nc, 4))
+    oq, odq, ocf = O.step(m, q, dq, dt, cforce=cf0)
+    # (random states start with spheres deep in the floor and loop closures violated by tens of centimetres: |dq+| of
+    # 1e2 .. 4e3 rad/s after one step; the metric is relative to it)
+    ok = np.isfinite(oq).all(axis=1) & np.isfinite(odq).all(axis=1) & (np.abs(odq).max(axis=1) < 1e4)
+    assert ok.sum() >= 1
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    tcf = bw.new_cforce(B, torch.float64)
+    bw.step(tq, tdq, dt, 1, cforce=tcf)
+    torch.cuda.synchronize()
+    eq, edq = _rel(tq.cpu().numpy(), oq), _rel(tdq.cpu().numpy(), odq)
+    print("seed %d: %d bodies, %d dofs, %d constraints (%s): err q %.2e dq %.2e (%d of %d worlds)"
+          % (seed, m.nb, m.ndof, m.nc, sorted(set(m.ctype.tolist())), eq[ok].max(), edq[ok].max(), ok.sum(), B))
+    assert eq[ok].max() < 1e-8 and edq[ok].max() < 1e-7
+    ef = np.abs(tcf.cpu().numpy() - ocf)[ok].max() / max(1., np.abs(ocf[ok]).max())
+    assert ef < 1e-6
+    bw.close()
+
+
+def test_snake_100_against_the_oracle_and_launch_shapes():
+    """add_snake(w, 100): 100 Rz joints, a serial chain (cond(Z) ~ 1e9: the oracle's explicit inverse is itself good to ~1e-5,
+    as for snake-64).  One step against the oracle; T steps in one launch == T one-step launches bit for bit; float32
+    buffers == float64 buffers rounded (the arithmetic is float64 either way)."""
+    from arboris_python_amd import scenes, synth
+    from arboris_python_amd.batch import BatchedWorlds
+    m = scenes.flat(scenes.snake_world(100))
+    assert m.ndof == 100 and m.nb == 100
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1
+    B, dt, T = 40, 1e-3, 5
+    q, dq = synth.random_states(m, B, seed=0, angle=0.5, vel=1.0)
+    oq, odq, _ = O.step(m, q[:8], dq[:8], dt)
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    bw.step(tq, tdq, dt, 1)
+    torch.cuda.synchronize()
+    eq, edq = _rel(tq.cpu().numpy()[:8], oq), _rel(tdq.cpu().numpy()[:8], odq)
+    print("snake-100 one step vs oracle: err q %.2e dq %.2e" % (eq.max(), edq.max()))
+    assert eq.max() < 1e-7 and edq.max() < 5e-5
+    # a better-conditioned check of the same kernel path at 1e-8: residual of the step equation with the oracle's matrices,
+    #   (M/dt + N + B) dq+ = M dq/dt + gforce     (core.py:975-976), whose residual does not go through an inverse
+    dyn = O.update_dynamic(m, q[:8], dq[:8])
+    gforce, Z, Y = O.update_controllers(m, dyn, q[:8], dq[:8], dt)
+    rhs = (dyn["M"] @ (dq[:8] / dt)[..., None])[..., 0] + gforce
+    res = (Z @ tdq.cpu().numpy()[:8][..., None])[..., 0] - rhs
+    res_o = (Z @ odq[..., None])[..., 0] - rhs
+    print("residual |Z dq+ - rhs| / |rhs|: device %.2e, oracle %.2e" % (np.abs(res).max() / np.abs(rhs).max(), np.abs(res_o).max() / np.abs(rhs).max()))
+    assert np.abs(res).max() / np.abs(rhs).max() < 1e-10
+    a_q, a_dq = bw.to_device(q, dq, torch.float64)
+    b_q, b_dq = bw.to_device(q, dq, torch.float64)
+    bw.step(a_q, a_dq, dt, T)
+    for _ in range(T):
+        bw.step(b_q, b_dq, dt, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a_q, b_q) and torch.equal(a_dq, b_dq)
+    f32 = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    c_q, c_dq = bw.to_device(q, dq, torch.float32)
+    d_q, d_dq = bw.to_device(f32(q), f32(dq), torch.float64)
+    bw.step(c_q, c_dq, dt, T)
+    bw.step(d_q, d_dq, dt, T)
+    torch.cuda.synchronize()
+    assert torch.equal(c_q, d_q.float()) and torch.equal(c_dq, d_dq.float())
+    p = bw.plan(4096, 16, dtype=torch.float64)
+    assert p["worlds_per_wavefront"] == 1 and p["wave_slots"] >= 256
+    bw.close()
+
+
+def test_human36_beside_four_free_objects_66_dofs():
+    """human36 on its four floor contacts + four free boxes with a ball each on the floor: 66 dofs, 8 contacts.  A 30-step
+    drop: every step replayed through the oracle from the device's own state (float64, 1e-8 / 1e-7), the contact forces of
+    the last step; the trajectory log of the launch; an inspect of the first step (Z, contact activity)."""
+    from arboris_python_amd import scenes
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    w = scenes.human36_and_objects_world(4)
+    m, q0, dq0 = flatten_world(w)
+    assert m.ndof == 66 and m.nc == 8
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1
+    B, dt, T = 16, 5e-3, 30
+    rng = np.random.default_rng(3)
+    q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1)) + rng.uniform(-0.2, 0.2, (B, m.ndof))
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    cf = bw.new_cforce(B, torch.float64)
+    r = bw.inspect(tq, tdq, dt, ["Z", "c_active", "c_sdist", "gforce0", "q_next", "dq_next", "pose"], cforce=cf)
+    dyn = O.update_dynamic(m, q, dq)
+    gf, Zo, _ = O.update_controllers(m, dyn, q, dq, dt)
+    assert np.abs(r["Z"].cpu().numpy() - Zo).max() / np.abs(Zo).max() < 1e-12
+    assert _rel(r["gforce0"].cpu().numpy(), gf).max() < 1e-10
+    assert np.abs(r["pose"].cpu().numpy() - dyn["pose"]).max() < 1e-12
+    log = bw.rollout(tq, tdq, dt, T, cforce=cf, log_energy=False)
+    torch.cuda.synchronize()
+    lq, ldq = log["q"].cpu().numpy(), log["dq"].cpu().numpy()
+    assert np.array_equal(lq[0], q) and np.array_equal(ldq[0], dq)
+    assert _rel(r["dq_next"].cpu().numpy(), ldq[1]).max() < 1e-12
+    worst = 0.
+    ocf = None
+    for t in range(T - 1):
+        oq, odq, ocf = O.step(m, lq[t], ldq[t], dt)
+        worst = max(worst, _rel(lq[t + 1], oq).max(), 0.1 * _rel(ldq[t + 1], odq).max())
+    print("human36 + 4 objects: %d world-steps replayed, worst err (q, dq / 10) %.2e; max contact force %.0f N" % (B * (T - 1), worst, float(cf.abs().max())))
+    assert worst < 1e-8
+    assert float(cf.abs().max()) > 100.          # feet and balls are on the floor
+    # user torques (a sequence) and a dense impedance on the same model: one launch against oracle steps
+    tau = rng.uniform(-0.3, 0.3, (4, B, m.ndof)); tau[:, :, :6] = 0.
+    za = -(0.2 * rng.uniform(-1, 1, (B, m.ndof, m.ndof)) + 1.5 * np.eye(m.ndof)[None])
+    sq, sdq = bw.to_device(q, dq, torch.float64)
+    scf = bw.new_cforce(B, torch.float64)
+    bw.step(sq, sdq, dt, 4, cforce=scf, ext_gforce=torch.as_tensor(tau, device=bw.device).contiguous(),
+            ext_impedance=torch.as_tensor(za, device=bw.device).contiguous())
+    torch.cuda.synchronize()
+    oq, odq, ocf = q, dq, None
+    for t in range(4):
+        oq, odq, ocf = O.step(m, oq, odq, dt, cforce=ocf, ext_gforce=tau[t], ext_impedance=za)
+    assert _rel(sq.cpu().numpy(), oq).max() < 1e-7 and _rel(sdq.cpu().numpy(), odq).max() < 1e-6
+    # what the wide kernels do not take is refused, not ignored
+    with pytest.raises(_capi.ArbError):
+        bw.step(sq, sdq, dt, 1, cforce=scf, pd_targets=(torch.zeros_like(sdq), torch.zeros_like(sdq)), pd_gains=(torch.ones_like(sdq), torch.ones_like(sdq)))
+    with pytest.raises(_capi.ArbError):
+        bw.inspect(sq, sdq, dt, ["jac"])
+    bw.close()
+
+
+def test_limits_of_the_wide_path():
+    """ndof, nb <= ARB_WIDE_MAX = 256: snake-256 steps; snake-257 is refused with ARB_ERR_UNSUPPORTED (the reference would
+    allocate it)."""
+    import ctypes as C
+    from arboris_python_amd import scenes, synth
+    from arboris_python_amd.batch import BatchedWorlds
+    m = scenes.flat(scenes.snake_world(256))
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1
+    q, dq = synth.random_states(m, 3, seed=1, angle=0.3, vel=0.5)
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    bw.step(tq, tdq, 1e-3, 2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tq).all() and torch.isfinite(tdq).all()
+    bw.close()
+    m2 = scenes.flat(scenes.snake_world(257))
+    desc, keep = _capi.make_desc(m2)
+    h = C.c_void_p()
+    assert _capi.load().arb_model_create(C.byref(desc), 0, C.byref(h)) == 2
