@@ -741,7 +741,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     upd(vec(d->c_min, nc), &W.cmin); upd(vec(d->c_max, nc), &W.cmax);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     // the augmented system in LDS when it fits beside the pivot row / column (120 KB: one workgroup per CU), else in scratch
-    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48) * sizeof(double);
+    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 44 * nc) * sizeof(double);
     W.z_in_lds = (size_t)n * W.ld * sizeof(double) + small <= 120 * 1024 ? 1 : 0;
     M->wide_lds = small + (W.z_in_lds ? (size_t)n * W.ld * sizeof(double) : 0);
     long o = 0;

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     double *FCOL = TROW + ((ncols + 3) & ~3);   // [n]    the pivot column (multipliers)
     double *DF = FCOL + ((n + 3) & ~3);      // [8]       force increment of one local solve
     double *SWORK = DF + 8;                  // [48]      scratch of the sliding solve (eig6 fallback)
-    double *ZL = SWORK + 48;                 // [n][ld]   the augmented system, when it fits
+    double *GVV = SWORK + 48;                // [ndol]    v' during the sweeps
+    double *GFF = GVV + ((M.ndol + 3) & ~3); // [ndol]    constraint forces during the sweeps
+    double *GSC = GFF + ((M.ndol + 3) & ~3); // [nc][44]  per-constraint blocks and constants of the sweeps
+    double *ZL = GSC + 44 * M.nc;            // [n][ld]   the augmented system, when it fits
     double *S = scratch_all + (size_t)blockIdx.x * (size_t)M.total;
     double *QS = S + M.o_q, *DQS = S + M.o_dq, *QD = S + M.o_qd, *FF = S + M.o_ff, *FF0 = S + M.o_ff0, *POSE = S + M.o_pose,
            *PC = S + M.o_pc, *RCP = S + M.o_rcp, *TW = S + M.o_tw, *AB = S + M.o_ab, *OM = S + M.o_om, *DA = S + M.o_da,
@@ -493,44 +496,68 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 for (int i = 0; i < 16; ++i) cd[24 + i] = P[i];
             }
             __syncthreads();
-            // ---- 20 Gauss-Seidel sweeps, constraints in registration order (core.py:929-935): lane 0 solves, all lanes update v'
-            for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
-                for (int c = 0; c < nc; ++c) {
+            // ---- 20 Gauss-Seidel sweeps, constraints in registration order (core.py:929-935).  The sweeps are ONE dependent chain:
+            // the first wavefront runs them alone (lane 0 solves, its 64 lanes update v'), everything it touches per solve in LDS
+            // and hand-overs by wave-level ordering -- no workgroup barrier inside the 20 x nc solves; the other three wavefronts
+            // wait at the barrier below.  Per constraint in LDS (GSC): its admittance block (16) | the block's inverse (16) |
+            // sdist, mu, eps (3), pos0 / dt (3), glo, ghi, type, active.
+            if (tid < WAVE) {
+                for (int c = tid; c < nc; c += WAVE) {
                     const double *cd = CD + WIDE_CD * c;
-                    if (cd[16] == 0.) continue;                                  // (wave-uniform: the same value for every lane)
-                    if (tid == 0) {
-                        const int ct = M.ctype[c];
-                        double v[4], Yb[16], f[4], df[4] = {0., 0., 0., 0.};
-                        for (int i = 0; i < 4; ++i) {
-                            v[i] = VV[4 * c + i]; f[i] = FF[4 * c + i];
-                            for (int j2 = 0; j2 < 4; ++j2) Yb[4 * i + j2] = AM[(4 * c + i) * ndol + 4 * c + j2];
-                        }
-                        if (ct == ARB_CT_SOFTFINGER) {                           // constraints.py:780-836
-                            const double eps[3] = {M.ceps[3 * c], M.ceps[3 * c + 1], M.ceps[3 * c + 2]};
-                            (void)softfinger_solve<double>(v, Yb, cd + 24, f, df, cd[15], dt, M.cmu[c], eps, SWORK);
-                        } else if (ct == ARB_CT_BALLSOCKET) {                    // constraints.py:235-237
-                            const double *P = cd + 24;
-                            for (int i = 0; i < 3; ++i) {
-                                df[i] = -(P[4 * i] * (v[0] + cd[12] * inv_dt) + P[4 * i + 1] * (v[1] + cd[13] * inv_dt) + P[4 * i + 2] * (v[2] + cd[14] * inv_dt));
-                                f[i] += df[i];
-                            }
-                        } else {                                                 // JointLimits.solve constraints.py:73-90
-                            const double v0 = v[0] - Yb[0] * f[0], p00 = cd[24];
-                            double nf = 0.;
-                            if (v0 <= cd[17]) nf = p00 * (cd[17] - v0);
-                            else if (cd[18] <= v0) nf = p00 * (cd[18] - v0);
-                            df[0] = nf - f[0]; f[0] = nf;
-                        }
-                        for (int i = 0; i < 4; ++i) { FF[4 * c + i] = f[i]; DF[i] = df[i]; }
-                    }
-                    __syncthreads();
-                    for (int r = tid; r < ndol; r += WIDE_THREADS) {              // vel += Y'[:, c] dforce   core.py:935
-                        const double *a = AM + r * ndol + 4 * c;
-                        VV[r] += a[0] * DF[0] + a[1] * DF[1] + a[2] * DF[2] + a[3] * DF[3];
-                    }
-                    __syncthreads();
+                    double *g = GSC + 44 * c;
+                    for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2) g[4 * i + j2] = AM[(4 * c + i) * ndol + 4 * c + j2];
+                    for (int i = 0; i < 16; ++i) g[16 + i] = cd[24 + i];
+                    g[32] = cd[15]; g[33] = M.cmu[c]; g[34] = M.ceps[3 * c]; g[35] = M.ceps[3 * c + 1]; g[36] = M.ceps[3 * c + 2];
+                    g[37] = cd[12] * inv_dt; g[38] = cd[13] * inv_dt; g[39] = cd[14] * inv_dt; g[40] = cd[17]; g[41] = cd[18];
+                    g[42] = (double)M.ctype[c]; g[43] = cd[16];
                 }
+                for (int r = tid; r < ndol; r += WAVE) { GVV[r] = VV[r]; GFF[r] = FF[r]; }
+                WAVE_SYNC();
+                for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
+                    if (tid == 0) DF[4] = 0.;                                    // "something changed in this sweep"
+                    for (int c = 0; c < nc; ++c) {
+                        const double *g = GSC + 44 * c;
+                        if (g[43] == 0.) continue;                               // (the same value for every lane)
+                        if (tid == 0) {
+                            const int ct = (int)g[42];
+                            double v[4], f[4], f_old[4], df[4] = {0., 0., 0., 0.};
+                            for (int i = 0; i < 4; ++i) { v[i] = GVV[4 * c + i]; f[i] = f_old[i] = GFF[4 * c + i]; }
+                            if (ct == ARB_CT_SOFTFINGER) {                       // constraints.py:780-836
+                                const double eps[3] = {g[34], g[35], g[36]};
+                                (void)softfinger_solve<double>(v, g, g + 16, f, df, g[32], dt, g[33], eps, SWORK);
+                            } else if (ct == ARB_CT_BALLSOCKET) {                // constraints.py:235-237
+                                const double *P = g + 16;
+                                for (int i = 0; i < 3; ++i) {
+                                    df[i] = -(P[4 * i] * (v[0] + g[37]) + P[4 * i + 1] * (v[1] + g[38]) + P[4 * i + 2] * (v[2] + g[39]));
+                                    f[i] += df[i];
+                                }
+                            } else {                                             // JointLimits.solve constraints.py:73-90
+                                const double v0 = v[0] - g[0] * f[0], p00 = g[16];
+                                double nf = 0.;
+                                if (v0 <= g[40]) nf = p00 * (g[40] - v0);
+                                else if (g[41] <= v0) nf = p00 * (g[41] - v0);
+                                df[0] = nf - f[0]; f[0] = nf;
+                            }
+                            bool ch = false;
+                            for (int i = 0; i < 4; ++i) { GFF[4 * c + i] = f[i]; DF[i] = df[i]; ch = ch || df[i] != 0. || !same_bits(f[i], f_old[i]); }
+                            if (ch) DF[4] = 1.;
+                        }
+                        WAVE_SYNC();
+                        const double d0 = DF[0], d1 = DF[1], d2 = DF[2], d3 = DF[3];
+                        for (int r = tid; r < ndol; r += WAVE) {                  // vel += Y'[:, c] dforce   core.py:935
+                            const double *a = AM + r * ndol + 4 * c;
+                            GVV[r] += a[0] * d0 + a[1] * d1 + a[2] * d2 + a[3] * d3;
+                        }
+                        WAVE_SYNC();
+                    }
+                    // a sweep that changes no force and adds nothing to any velocity is a fixed point of the iteration: the
+                    // remaining sweeps of core.py:929-935 would repeat it bit for bit
+                    if (DF[4] == 0.) break;
+                    WAVE_SYNC();
+                }
+                for (int r = tid; r < ndol; r += WAVE) { VV[r] = GVV[r]; FF[r] = GFF[r]; }
             }
+            __syncthreads();
         }
         // ================= phase E: new velocity, integrate (core.py:974-980, joints.py:54-57) ================================
         if (io.inspect) {
