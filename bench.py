@@ -205,7 +205,7 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
 
 
 def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True, ext=None,
-                 general=False, cost=None, body_columns=False):
+                 general=False, cost=None, body_columns=False, mixed=None, static_worlds=False, waves=None):
     """Run `n_episodes` whole episodes: restore the pristine states, advance `episode` steps (one arb_step
     launch per `spl` steps; default the whole episode in one launch).  Returns wall seconds between the
     two barrier + synchronize brackets, the launch durations in ms (HIP events on the launch stream =
@@ -232,6 +232,12 @@ def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=Non
         kw["body_columns"] = True
     if cost is not None:
         kw["cost"] = cost
+    if mixed is not None:
+        kw["mixed"] = mixed
+    if static_worlds:
+        kw["static_worlds"] = True
+    if waves is not None:
+        kw["waves"] = waves
     seq = ext is not None and ext.dim() == 3         # a torque SEQUENCE (one row per step): chunked launches take their rows
     for _ in range(n_episodes):
         q.copy_(q0); dq.copy_(dq0)
@@ -262,16 +268,30 @@ def build_model(cfg):
     from arboris_python_amd import scenes
     if cfg["model"] == "snake64":
         return scenes.flat(scenes.snake_world(64))
+    if cfg["model"] == "snake100":
+        return scenes.flat(scenes.snake_world(100))
+    if cfg["model"] == "human36_objects":
+        return scenes.flat(scenes.human36_and_objects_world(4))
     return scenes.flat(scenes.human36_world(cfg["contacts"], pd=bool(cfg.get("pd"))))
 
 
 def make_states(cfg, model, lo, hi, seed):
     """Worlds [lo, hi) of the config's seeded global batch (world w has its own stream, seed = (seed, w))."""
     from arboris_python_amd import synth
+    if cfg["model"] == "human36_objects":
+        # the scene as built (the human standing, the boxes beside it a centimetre above the floor), every world with its own
+        # small velocities (world w draws from its own stream)
+        import numpy as np
+        from arboris_python_amd import scenes
+        from arboris_python_amd.flatten import flatten_world
+        _, q0, dq0 = flatten_world(scenes.human36_and_objects_world(4))
+        q = np.tile(q0, (hi - lo, 1))
+        dq = np.stack([dq0 + np.random.default_rng([seed, w]).uniform(-0.1, 0.1, size=len(dq0)) for w in range(lo, hi)])
+        return q, dq
     if cfg["states"] == "standing":
         # config 3/5 distribution: standing pose dropped from U(0, 3 cm), small velocities
         return synth.world_states(model, range(lo, hi), "standing", seed, drop=0.03, vel=0.1)
-    if cfg["model"] == "snake64":
+    if cfg["model"] in ("snake64", "snake100"):
         return synth.world_states(model, range(lo, hi), "random", seed, angle=0.5, vel=1.0)
     # config 2: random poses, hinge angles U(-0.7, 0.7) rad, velocities U(-1, 1).  (More energetic draws -- angle 1,
     # velocities 3, the generator's defaults -- send the reference's own time stepping beyond 100 rad/s within 40 steps
@@ -352,6 +372,35 @@ def dry_run(args, cfg):
         dist.destroy_process_group()
 
 
+def chain_roof(bw, model, cfg, q0, dq0, torch, np, plan, value):
+    """The LATENCY roof of the dominant kernel, measured live (round 6; tools/chain_probe.py is the long form).  One world is
+    one wavefront and a world's step is a chain of dependent instructions: alone on its SIMD (4 worlds per CU, the LDS padded so
+    that no second wavefront fits a SIMD) a wavefront of the headline's build advances one step in T1; with `wave_slots`
+    wavefronts resident the chip cannot pass wave_slots / T1 world-steps/s however well they interleave."""
+    cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
+    waves = plan["waves_per_simd"] if plan["waves_per_simd"] in (2, 3) else None
+    lds0 = bw.plan(4 * cus, cfg["episode"], dtype=q0.dtype, waves=waves, static_worlds=True)["lds_bytes"]
+    pad = max(0, 32 * 1280 - lds0 - 8)            # 32 of a CU's 128 LDS granules per wavefront: four wavefronts per CU
+    n1 = 4 * cus
+    reps = -(-n1 // q0.shape[0])
+    qa, da = q0.repeat(reps, 1)[:n1].contiguous(), dq0.repeat(reps, 1)[:n1].contiguous()
+    bw.set_knob("lds_pad", pad)
+    try:
+        run_episodes(bw, qa, da, cfg["dt"], cfg["episode"], 2, torch, timed=False, static_worlds=True, waves=waves)
+        _, ms, _ = run_episodes(bw, qa, da, cfg["dt"], cfg["episode"], 8, torch, static_worlds=True, waves=waves)
+    finally:
+        bw.set_knob("lds_pad", 0)
+    t1 = float(np.min(ms)) * 1e-3 / cfg["episode"]
+    slots = plan["wave_slots"]
+    return {"lone_wave_us_per_step": t1 * 1e6, "lone_wave_worlds": n1, "wave_slots": slots, "waves_per_simd": plan["waves_per_simd"],
+            "latency_roof": slots / t1, "unit": "world-steps/s", "achieved": value, "frac": value / (slots / t1),
+            "note": "T1 = one step of a wavefront that has its SIMD to itself (%d worlds = 4 per CU, LDS padded by %d B, the "
+                    "headline's kernel build, %d-step episodes); latency_roof = wave_slots / T1: what the chip reaches when "
+                    "its resident wavefronts -- dependent chains -- interleave perfectly.  The per-phase lone-wave cycles "
+                    "and the intermediate occupancies are in profiles/r06_chain.json (tools/chain_probe.py, "
+                    "tools/subphase_probe.py); the pipe roof (instruction mix x pipe rates) is `valu`." % (n1, pad, cfg["episode"])}
+
+
 def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000, general=False, min_launches=10, body_columns=False):
     """One more workload timed like the headline (whole episodes, one launch per episode, states resident in HBM, at least
     `min_seconds` and `min_launches` launches): world-steps/s, the launch durations from HIP events on the launch stream,
@@ -369,7 +418,7 @@ def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000,
         cost = dict(out=torch.zeros(cfg["batch"], dtype=dt2, device=b2.device), w_q=ones, w_dq=0.01 * ones, w_tau=ones.clone())
     elif cfg.get("torques"):
         ex2 = torch.as_tensor(make_torques(mdl, 0, cfg["batch"], seed=2000), dtype=dt2, device=b2.device).contiguous()
-    kw = dict(ext=ex2, general=general, cost=cost, body_columns=body_columns)
+    kw = dict(ext=ex2, general=general, cost=cost, body_columns=body_columns, mixed=cfg.get("mixed"))
     run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
     cal, _, _ = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
     n_ep = max(min_launches, int(np.ceil(min_seconds / max(cal / 2, 1e-6))))
@@ -378,7 +427,9 @@ def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000,
            "value": cfg["batch"] * n_ep * cfg["episode"] / wl, "unit": "world-steps/s",
            "kernel_ms": float(np.mean(me)), "episodes": n_ep, "steps_per_launch": cfg["episode"], "timed_region_s": wl,
            "finite": bool(torch.isfinite(qe).all() and torch.isfinite(dqe).all()),
-           "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")), general_kernels=general, body_columns=body_columns)}
+           "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")), general_kernels=general,
+                                   body_columns=body_columns, cost=cost is not None, mixed=cfg.get("mixed")),
+           "model_info": {k: b2.info[k] for k in ("ndof", "nc", "wide", "mixed_default")}}
     if cost is not None:
         out["cost_finite"] = bool(torch.isfinite(cost["out"]).all())
         out["mean_cost_per_rollout"] = float(cost["out"].double().mean())
@@ -621,6 +672,11 @@ def main():
                                                             "(the matrix-core variant measured slower, DESIGN.md 3)")
         except Exception:
             pass
+    if n_gpus == 1 and launches_per_episode == 1 and not args.split and cfg["dtype"] == "f32":
+        try:
+            res["roofline"]["chain"] = chain_roof(bw, model, cfg, q0, dq0, torch, np, kernel_build, value)
+        except Exception as e:                        # (never lose the line to a diagnostic leg)
+            res["roofline"]["chain"] = {"error": repr(e)}
     if gather_ms is not None:
         res["final_state_allgather_ms"] = gather_ms
     if n_gpus == 1 and not args.no_per_step_leg:
@@ -671,7 +727,22 @@ def main():
                         ("batch65536", dict(cfg, batch=65536, name=cfg["name"] + " -- 65 536 worlds on ONE GPU (the throughput regime)"))):
             cfgs[key] = timed_leg(BatchedWorlds, torch, np, local_rank, dict(c_), 0.5, seed=1000 if key == "batch65536" else 0,
                                   min_launches=5 if key == "batch65536" else 10)
+        # BASELINE config 4's model through float32 buffers (round 6): by default such a launch is promoted to the float64
+        # kernels (config4 above is that path's speed); the mixed build on request -- float32 state and LDS, float64
+        # elimination and right-hand side: 7e-5 against the reference instead of 1e-5 -- has more wave slots
+        c4m = dict(CONFIGS[4], dtype="f32", mixed=True, name=CONFIGS[4]["name"] + " -- float32 buffers, the mixed build (ARB_STEP_MIXED)")
+        cfgs["config4_mixed_f32"] = timed_leg(BatchedWorlds, torch, np, local_rank, c4m, 0.5, seed=0)
+        cfgs["config4_mixed_f32"]["accuracy"] = "dq+ within 7e-5 of the float64 reference (median 8e-6); float64 / promoted: 1e-5 (8e-6 against the oracle's explicit inverse)"
         res["configs"] = cfgs
+        # worlds PAST one wavefront (round 6): the wide kernels, one workgroup per world, float64 arithmetic
+        wide = {}
+        for key, c_ in (("snake100", dict(model="snake100", contacts=0, batch=1024, dtype="f64", dt=1e-3, episode=16, states="random",
+                                          name="snake-100 (100 Rz joints): past the 64 lanes of a wavefront, the wide kernels")),
+                        ("human36_and_4_objects", dict(model="human36_objects", contacts=8, batch=1024, dtype="f32", dt=5e-3, episode=40,
+                                                       states="standing", name="human36 on four floor contacts beside four free boxes "
+                                                                               "with a ball each on the floor: 66 dofs, 8 contacts, the wide kernels"))):
+            wide[key] = timed_leg(BatchedWorlds, torch, np, local_rank, c_, 0.4, seed=0, min_launches=3)
+        res["wide_worlds"] = wide
         # human36 OUTSIDE the model class of the specialised headline kernels (round 4 review: what does a caller get whose
         # model differs slightly?): six floor contacts (three per foot: body-space columns, one column set), and the headline
         # model with a PD controller on its 36 hinge dofs (the general kernels)
