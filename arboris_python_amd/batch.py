@@ -147,7 +147,7 @@ class BatchedWorlds(object):
     def step(self, q, dq, dt, nsteps=1, cforce=None, ext_gforce=None, skip_constraints=False,
              stream=None, fused=False, split=False, pd_targets=None, pd_gains=None, mfma=False, static_worlds=False,
              waves=None, one_world=False, cost=None, general_kernels=False, body_columns=False, ext_impedance=None,
-             mixed=None, _log=None):
+             mixed=None, classic_columns=False, _log=None):
         """Advance every world by ``nsteps`` steps of ``dt`` in place (asynchronous).  ``dt`` is a scalar, or one
         step length per step (``simulate`` takes ``dt = next_time - current_time`` from its timeline,
         core.py:1357): the whole non-uniform timeline then runs inside one launch.
@@ -173,9 +173,9 @@ class BatchedWorlds(object):
         optional): the running cost of the rollout, ``out[w] += sum_t sum_i w_q (q_i - q_ref_i)^2 + w_dq dq_i^2 +
         w_tau tau_t,i^2`` on the state after every step (``arb_step_cost``, include/arbstep.h), summed on chip.
         ``general_kernels=True``: the general kernels also for a model of a specialised class (ARB_STEP_GENERAL_KERNELS).
-        ``body_columns=True``: constraint columns in body space wherever the model qualifies (ARB_STEP_BODY_COLUMNS: the
-        default where it saves the second column set -- human36 with eight contacts --; with four contacts 2 % slower and
-        half as many float32 outliers).
+        ``body_columns=True``: constraint columns in body space wherever the model qualifies (ARB_STEP_BODY_COLUMNS: since
+        round 6 the default for every qualifying model; ``classic_columns=True``, ARB_STEP_CLASSIC_COLUMNS, opts out: the
+        classical columns, 1.7 % faster with four contacts, twice the float32 outliers).
         ``ext_impedance`` (B,ndof,ndof): the summed impedance ``Z_a`` of user-defined controllers, ``Z -= ext_impedance``
         (core.py:815-817), with their generalized force in ``ext_gforce``: the generic Controller plugin path (ABI 8).
         ``mixed``: None = the library's choice (float32 buffers of a model float32 cannot eliminate -- ``self.info
@@ -199,6 +199,8 @@ class BatchedWorlds(object):
             flags |= _capi.ARB_STEP_GENERAL_KERNELS
         if body_columns:
             flags |= _capi.ARB_STEP_BODY_COLUMNS
+        if classic_columns:
+            flags |= _capi.ARB_STEP_CLASSIC_COLUMNS
         if mixed is not None:
             flags |= _capi.ARB_STEP_MIXED if mixed else _capi.ARB_STEP_NO_MIXED
         dts = self._dt_steps(dt, nsteps, st)
@@ -290,7 +292,7 @@ class BatchedWorlds(object):
 
     def plan(self, nworlds, nsteps=1, dtype=None, ext_gforce=False, other_inputs=False, waves=None, split=False,
              static_worlds=False, one_world=False, world_logs=False, general_kernels=False, body_columns=False, cost=False,
-             mixed=None):
+             mixed=None, classic_columns=False):
         """Which kernel build and launch shape ``step`` would use (``arb_step_plan``): a dict with ``waves_per_simd``,
         ``worlds_per_wavefront`` (the copies of a small model's forest), ``feat``, ``lds_bytes``, ``wave_slots``, ``work_queue``.
         ``world_logs``: the launch is a rollout that logs per-world energies (or states of a batch that is not a multiple
@@ -304,6 +306,7 @@ class BatchedWorlds(object):
         flags |= _capi.ARB_STEP_ONE_WORLD if one_world else 0
         flags |= _capi.ARB_STEP_GENERAL_KERNELS if general_kernels else 0
         flags |= _capi.ARB_STEP_BODY_COLUMNS if body_columns else 0
+        flags |= _capi.ARB_STEP_CLASSIC_COLUMNS if classic_columns else 0
         if mixed is not None:
             flags |= _capi.ARB_STEP_MIXED if mixed else _capi.ARB_STEP_NO_MIXED
         p = _capi.StepPlan()
@@ -329,7 +332,7 @@ class BatchedWorlds(object):
         return self._lib.arb_model_status(self._handle) == _capi.ARB_ERR_STALLED
 
     def inspect(self, q, dq, dt, want, cforce=None, ext_gforce=None, skip_constraints=False, general_kernels=False,
-                body_columns=False, ext_impedance=None, pd_targets=None, pd_gains=None):
+                body_columns=False, ext_impedance=None, pd_targets=None, pd_gains=None, classic_columns=False):
         """Evaluate one step without touching ``q``/``dq``; returns a dict of the
         requested intermediate results (names of ``arb_inspect_out``).  ``general_kernels`` / ``body_columns``: the
         arithmetic of ``step`` with the same flag (the inspect kernel forms the constraint-space system the same way).
@@ -360,6 +363,7 @@ class BatchedWorlds(object):
         flags = _capi.ARB_STEP_SKIP_CONSTRAINTS if skip_constraints else 0
         flags |= _capi.ARB_STEP_GENERAL_KERNELS if general_kernels else 0
         flags |= _capi.ARB_STEP_BODY_COLUMNS if body_columns else 0
+        flags |= _capi.ARB_STEP_CLASSIC_COLUMNS if classic_columns else 0
         if ext_impedance is None and pd_targets is None and pd_gains is None:
             _capi.check(self._lib.arb_inspect(
                 self._handle, self._dtype_code(q), q.data_ptr(), dq.data_ptr(),

@@ -205,7 +205,7 @@ def cpu_baseline(model, q, dq, dt, budget_s, episode):
 
 
 def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=None, split=False, timed=True, ext=None,
-                 general=False, cost=None, body_columns=False, mixed=None, static_worlds=False, waves=None):
+                 general=False, cost=None, body_columns=False, mixed=None, static_worlds=False, waves=None, classic=False):
     """Run `n_episodes` whole episodes: restore the pristine states, advance `episode` steps (one arb_step
     launch per `spl` steps; default the whole episode in one launch).  Returns wall seconds between the
     two barrier + synchronize brackets, the launch durations in ms (HIP events on the launch stream =
@@ -230,6 +230,8 @@ def run_episodes(bw, q0, dq0, dt, episode, n_episodes, torch, dist=None, spl=Non
         kw["general_kernels"] = True
     if body_columns:
         kw["body_columns"] = True
+    if classic:
+        kw["classic_columns"] = True
     if cost is not None:
         kw["cost"] = cost
     if mixed is not None:
@@ -401,7 +403,8 @@ def chain_roof(bw, model, cfg, q0, dq0, torch, np, plan, value):
                     "tools/subphase_probe.py); the pipe roof (instruction mix x pipe rates) is `valu`." % (n1, pad, cfg["episode"])}
 
 
-def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000, general=False, min_launches=10, body_columns=False):
+def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000, general=False, min_launches=10, body_columns=False,
+              classic=False):
     """One more workload timed like the headline (whole episodes, one launch per episode, states resident in HBM, at least
     `min_seconds` and `min_launches` launches): world-steps/s, the launch durations from HIP events on the launch stream,
     the build.  cfg["torques"]: True = one torque row per rollout, "sequence" = a torque row per step and rollout
@@ -418,7 +421,7 @@ def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000,
         cost = dict(out=torch.zeros(cfg["batch"], dtype=dt2, device=b2.device), w_q=ones, w_dq=0.01 * ones, w_tau=ones.clone())
     elif cfg.get("torques"):
         ex2 = torch.as_tensor(make_torques(mdl, 0, cfg["batch"], seed=2000), dtype=dt2, device=b2.device).contiguous()
-    kw = dict(ext=ex2, general=general, cost=cost, body_columns=body_columns, mixed=cfg.get("mixed"))
+    kw = dict(ext=ex2, general=general, cost=cost, body_columns=body_columns, mixed=cfg.get("mixed"), classic=classic)
     run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
     cal, _, _ = run_episodes(b2, ta, tb, cfg["dt"], cfg["episode"], 2, torch, timed=False, **kw)
     n_ep = max(min_launches, int(np.ceil(min_seconds / max(cal / 2, 1e-6))))
@@ -428,7 +431,7 @@ def timed_leg(BatchedWorlds, torch, np, local_rank, cfg, min_seconds, seed=1000,
            "kernel_ms": float(np.mean(me)), "episodes": n_ep, "steps_per_launch": cfg["episode"], "timed_region_s": wl,
            "finite": bool(torch.isfinite(qe).all() and torch.isfinite(dqe).all()),
            "kernel_build": b2.plan(cfg["batch"], cfg["episode"], dtype=dt2, ext_gforce=bool(cfg.get("torques")), general_kernels=general,
-                                   body_columns=body_columns, cost=cost is not None, mixed=cfg.get("mixed")),
+                                   body_columns=body_columns, cost=cost is not None, mixed=cfg.get("mixed"), classic_columns=classic),
            "model_info": {k: b2.info[k] for k in ("ndof", "nc", "wide", "mixed_default")}}
     if cost is not None:
         out["cost_finite"] = bool(torch.isfinite(cost["out"]).all())
@@ -712,15 +715,16 @@ def main():
         mp_["algorithmic_bytes_per_world_step"] = (2 * (model.nq + model.ndof) * 4 + 2 * model.nc * 4 * 4 + 4) / 32. + model.ndof * 4
         mp_["algorithmic_bytes_note"] = ("state + contact forces in and out and the cost once per horizon, plus this step's "
                                          "torque row: %d B per world-step" % (model.ndof * 4))
-        # the general kernels on the headline workload (the headline runs the kernels specialised for its model class:
-        # four plane / sphere SoftFingerContacts, no PD controller, no viscosity; a human36 outside the class gets these)
+        # the general kernels on the headline workload (classical constraint columns; a human36 outside the model classes gets these)
         res["general_kernel"] = timed_leg(BatchedWorlds, torch, np, local_rank, cfg, 0.7, general=True)
-        # the more accurate float32 path on request (ARB_STEP_BODY_COLUMNS: the contacts' columns in body space, Y' formed
-        # with float64 sums): the headline workload; one-step errors beyond 1e-5 on 1548 states harvested from an episode
-        # 0.13 % against the default's 0.26 %, largest 2.7e-5 against 3.4e-4 (tools/experiments/step_err.py)
-        res["body_columns_f32"] = timed_leg(BatchedWorlds, torch, np, local_rank, cfg, 0.5, body_columns=True)
-        res["body_columns_f32"]["accuracy"] = ("one-step errors beyond 1e-5 on 1548 harvested states: 0.13 % (default float32 kernels "
-                                               "0.26 %), largest 2.7e-5 (3.4e-4); strict_f64: none")
+        # Round 6: the headline runs BODY-SPACE constraint columns (the default for every model of the class since this round,
+        # decided on 119 808 replayed world-steps per path, profiles/r06_replay_stats.txt).  The classical columns on request
+        # (ARB_STEP_CLASSIC_COLUMNS: the kernels specialised for four contacts, rounds 4-5's headline path) are 1.7 % faster
+        # and have twice the float32 world-steps beyond 1e-5, among them the only ones the device's own arithmetic causes
+        res["classic_columns_f32"] = timed_leg(BatchedWorlds, torch, np, local_rank, cfg, 0.5, classic=True)
+        res["classic_columns_f32"]["accuracy"] = ("world-steps beyond 1e-5 of the float64 reference per 39 936 replayed: 43-57 (criteria d + e, "
+                                                  "caused by the device's float32 system: 4-11); the default (body-space columns): 21-28 (d + e: 0); "
+                                                  "strict_f64: none")
         # the other BASELINE configs and the throughput regime, under the same driver clock (short legs)
         cfgs = {}
         for key, c_ in (("config2", CONFIGS[2]), ("config4", CONFIGS[4]), ("config5", CONFIGS[5]),

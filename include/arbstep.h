@@ -160,14 +160,15 @@ enum {
                                          4 nc rows of the constraint Jacobian are T_c J_p: J_p the six rows of the relative Jacobian of the
                                          contact's pair of bodies, T_c a 4 x 6 frame transform (constraints.py:429-433).  The augmented
                                          system then carries six columns Y J_p^T per PAIR instead of four per contact, and Y' = T (J_p Y
-                                         J_p^T) T^T, v' = T J_p Y rhs are formed afterwards (float64 sums).  The library does this BY DEFAULT
-                                         where it saves the second column set (human36 with the reference's eight contact points: 55
-                                         columns instead of 75, +16 % world-steps/s); the flag asks for it also where one column set
-                                         would do (four contacts: 2 % slower, half as many float32 world-steps beyond 1e-5 of the
-                                         float64 reference -- fewer float32 columns go through the elimination).  Equal to
-                                         the classical columns to rounding, not bit for bit; ignored for models outside the class, with
-                                         ARB_STEP_SPLIT_WAVE, ARB_STEP_MFMA_ELIM and ARB_STEP_GENERAL_KERNELS.  arb_step_plan_info.feat
-                                         reports bit 16. */
+                                         J_p^T) T^T, v' = T J_p Y rhs are formed afterwards (float64 sums).  Since round 6 the library does
+                                         this BY DEFAULT for every model of the class (the flag is kept for callers of ABI 7, where it
+                                         was the default only where it saves the second column set -- human36 with the reference's
+                                         eight contact points: 55 columns instead of 75, +16 % world-steps/s).  With four contacts it
+                                         costs 1.7 % and halves the float32 world-steps beyond 1e-5 of the float64 reference; none of
+                                         those that remain is caused by the device's float32 system (119 808 replayed
+                                         world-steps per path).  Equal to the classical columns to rounding, not bit for bit; not for
+                                         models outside the class, nor with ARB_STEP_SPLIT_WAVE, ARB_STEP_MFMA_ELIM,
+                                         ARB_STEP_GENERAL_KERNELS or ARB_STEP_CLASSIC_COLUMNS.  arb_step_plan_info.feat reports bit 16. */
 #define ARB_STEP_MIXED 2048u            /* float32 state buffers, float64 ELIMINATION: the register tile [Z | rhs | J'^T], the
                                          right-hand side, the pivot-free elimination and the constraint-space products of
                                          phases C / D run in float64 (the assembly of Z is float64 in every kernel); twists,
@@ -191,7 +192,12 @@ enum {
                                          The flag asks for this build for any model (and instead of the promotion).
                                          Ignored for float64 buffers, with ARB_STEP_MFMA_ELIM and ARB_STEP_SPLIT_WAVE. */
 #define ARB_STEP_NO_MIXED 4096u         /* plain float32 kernels whatever the model (ARB_WARN_ILLCOND reports what that costs) */
-#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u | 512u | 1024u | 2048u | 4096u)
+#define ARB_STEP_CLASSIC_COLUMNS 8192u   /* (ABI 8) never body-space constraint columns: the classical columns Y J'^T, four per contact --
+                                         for a model with exactly four contacts the kernels specialised for that class, bit-identical
+                                         to the general kernels (ARB_STEP_GENERAL_KERNELS) and to the split execution.  Since round
+                                         6 body-space columns are the DEFAULT for every model that qualifies (see
+                                         ARB_STEP_BODY_COLUMNS): this flag is the 1.7 % faster, statistically noisier float32 path */
+#define ARB_STEP_KNOWN_FLAGS (1u | 2u | 8u | 16u | 32u | 64u | 128u | 256u | 512u | 1024u | 2048u | 4096u | 8192u)
 
 /*
  * Flattened world (host pointers, copied by arb_model_create).  Bodies are the

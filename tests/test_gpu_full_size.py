@@ -160,7 +160,7 @@ def test_config5_65536_worlds_32_steps(bws, name):
     torch.cuda.synchronize()
     assert torch.isfinite(tq).all() and torch.isfinite(tdq).all() and torch.isfinite(cf).all()
     worlds = np.arange(17, B, 1024)                                 # 64 worlds x 6 steps = 384 world-steps
-    _report("config 5 (%s)" % name, check_replay(bw, m, log, (0, 5, 9, 16, 24, 30), worlds, dt, de_cap=4e-3 if m.nc > 4 else None))
+    _report("config 5 (%s)" % name, check_replay(bw, m, log, (0, 5, 9, 16, 24, 30), worlds, dt))
     # batch-position independence at this size, first step, bitwise
     sub = np.arange(11, B, 997)
     sq, sdq = bw.to_device(q[sub], dq[sub], torch.float32)
@@ -185,7 +185,7 @@ def test_replay_10k_world_steps_every_outlier_adjudicated(bws, name, stride):
     log = bw.rollout(tq, tdq, dt, T, cforce=bw.new_cforce(B, torch.float32), log_energy=False)
     torch.cuda.synchronize()
     worlds = np.arange(3, B, stride)
-    r = check_replay(bw, m, log, range(0, 39), worlds, dt, verbose=False, de_cap=4e-3 if m.nc > 4 else None)
+    r = check_replay(bw, m, log, range(0, 39), worlds, dt, verbose=False)
     _report("%s, %d world-steps" % (name, r["n"]), r)
     assert r["n"] >= 9984
 

@@ -155,7 +155,7 @@ def test_unknown_flags_are_refused():
     q, dq = synth.standing_states(m, 4, seed=2)
     tq, tdq = bw.to_device(q, dq, torch.float32)
     before = tq.clone()
-    for bad in (4, 8192, 1 << 20):                         # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel); 2048, 4096: ABI 8
+    for bad in (4, 16384, 1 << 20):                        # 4 was ARB_STEP_SPLIT (the removed lane-per-world sweep kernel); 2048 .. 8192: ABI 8
         rc = bw._lib.arb_step(bw._handle, _capi.ARB_F32, tq.data_ptr(), tdq.data_ptr(), None, None, 4, 5e-3, 1, bad, None)
         assert rc == 1
     with pytest.raises(ValueError):
@@ -372,9 +372,11 @@ def test_fast_sweeps_hand_over_to_the_complete_variant_bitwise(monkeypatch):
                     if key == "fast" and k >= 30:
                         st = bw.inspect(tq, tdq, 5e-3, ["gs_stats"], cforce=cf.clone())["gs_stats"]
                         handed_over += int((st[:, 3] > 0).sum())
-                    bw.step(tq, tdq, 5e-3, 1, cforce=cf)
+                    bw.step(tq, tdq, 5e-3, 1, cforce=cf, classic_columns=True)
             else:
-                bw.step(tq, tdq, 5e-3, T, cforce=cf, **kw)
+                # (classical columns in both libraries: the test library has no body-space-column kernels, the shipped library's
+                # default for this model since round 6)
+                bw.step(tq, tdq, 5e-3, T, cforce=cf, classic_columns=True, **kw)
             torch.cuda.synchronize()
             bw.status()
             res[key] = (tq, tdq, cf)
@@ -397,8 +399,10 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
     build = lambda p: (p["waves_per_simd"], p["worlds_per_wavefront"])
     p = bw.plan(4 * cus, 40)
-    # (feat 4 / 5: the kernels specialised for four plane / sphere SoftFingerContacts, round 4 -- tests/test_gpu_round4.py)
-    assert build(p) == (2, 1) and p["work_queue"] == 0 and p["feat"] == 4 and p["wave_slots"] == 8 * cus
+    # (feat 20 / 21: body-space constraint columns, this model's default since round 6; feat 4 / 5 with classic_columns: the
+    # kernels specialised for four plane / sphere SoftFingerContacts, round 4 -- tests/test_gpu_round4.py)
+    assert build(p) == (2, 1) and p["work_queue"] == 0 and p["feat"] == 20 and p["wave_slots"] == 8 * cus
+    assert bw.plan(4 * cus, 40, classic_columns=True)["feat"] == 4
     p = bw.plan(16 * cus, 40)
     assert build(p) == (3, 1) and p["work_queue"] == 1 and p["wave_slots"] == 12 * cus
     assert p["lds_bytes"] * 12 <= 160 * 1024
@@ -406,9 +410,11 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     assert build(bw.plan(16 * cus, 40, waves=2)) == (2, 1)
     assert build(bw.plan(4 * cus, 40, waves=3)) == (3, 1)
     p = bw.plan(64 * cus, 40, ext_gforce=True)
-    assert build(p) == (3, 1) and p["feat"] == 5 and p["work_queue"] == 1
+    assert build(p) == (3, 1) and p["feat"] == 21 and p["work_queue"] == 1
+    assert bw.plan(64 * cus, 40, ext_gforce=True, classic_columns=True)["feat"] == 5
     assert p["lds_bytes"] <= 10 * 1280                       # twelve wavefronts per CU at the 1280-byte LDS granule
-    assert build(bw.plan(64 * cus, 40, other_inputs=True)) == (3, 1) and bw.plan(64 * cus, 40, other_inputs=True)["feat"] == 3
+    assert build(bw.plan(64 * cus, 40, other_inputs=True)) == (3, 1) and bw.plan(64 * cus, 40, other_inputs=True)["feat"] == 19
+    assert bw.plan(64 * cus, 40, other_inputs=True, classic_columns=True)["feat"] == 3
     assert build(bw.plan(64 * cus, 40, waves=3)) == (3, 1)
     assert build(bw.plan(64 * cus, 40, dtype=torch.float64)) == (2, 1)
     assert bw.plan(64 * cus, 40, static_worlds=True)["work_queue"] == 0

@@ -21,7 +21,7 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
     assert _capi.load().arb_build_variants() == 0
     # model: class bits in float32 (4: contacts, 8: no constraints, 4 | 16: contacts with body-space columns, 0: the general
     # kernels), in float64
-    want = {"human36_c4": (4, 4),                # four plane / sphere SoftFingerContacts
+    want = {"human36_c4": (20, 20),              # four plane / sphere SoftFingerContacts: body-space columns by default (round 6)
             "human36_c8": (20, 20),              # eight on two feet: body-space constraint columns, ONE column set (round 5)
             "human36_g": (8, 0),                 # no constraints (BASELINE config 2): float32 only
             "human36_visc": (0, 0),              # joint viscosity: outside the classes
@@ -38,6 +38,9 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
             assert bw.plan(B, T, dtype=torch.float64)["feat"] == spec64, (name, B, T)
         if spec32:
             assert bw.plan(8192, 40, general_kernels=True)["feat"] == 0
+        if name == "human36_c4":                 # the classical columns on request: the kernels specialised for four contacts
+            assert bw.plan(8192, 40, classic_columns=True)["feat"] == 4 and bw.plan(8192, 40, dtype=torch.float64, classic_columns=True)["feat"] == 4
+            assert bw.plan(8192, 40, ext_gforce=True, classic_columns=True)["feat"] == 5
         bw.close()
 
 
@@ -65,10 +68,12 @@ def test_specialised_kernels_equal_the_general_ones_bitwise(monkeypatch, model, 
             rng = np.random.default_rng(B)
             ext = torch.as_tensor(rng.normal(0., 0.5, (B, m.ndof)), dtype=dt_, device="cuda")
         cls = 8 if m.nc == 0 else 4
-        assert bw.plan(B, 1 if mode == "per_step" else T, dtype=dt_, ext_gforce=torques, **kw)["feat"] == (cls | (1 if torques else 0))
+        # (classic_columns: the specialised kernels of the four-contact class run the CLASSICAL columns; the model's default since
+        # round 6 are body-space columns, equal to these to rounding only -- tests/test_gpu_round5.py)
+        assert bw.plan(B, 1 if mode == "per_step" else T, dtype=dt_, ext_gforce=torques, classic_columns=True, **kw)["feat"] == (cls | (1 if torques else 0))
         res = {}
         for key in ("spec", "general"):
-            gk = dict(general_kernels=(key == "general"))
+            gk = dict(general_kernels=(key == "general"), classic_columns=True)
             tq, tdq = bw.to_device(q, dq, dt_)
             cf = bw.new_cforce(B, dt_) if m.nc else None
             if mode == "per_step":

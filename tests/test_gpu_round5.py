@@ -347,9 +347,10 @@ def test_body_space_columns_against_the_oracle_and_the_two_set_kernels(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_body_space_columns_on_request_for_the_four_contact_model(dtype):
-    """ARB_STEP_BODY_COLUMNS: a model that fits one column set anyway (human36 with four contacts, the headline workload) steps
-    through the body-space kernels when asked -- against the oracle like the default path, and against the default path."""
+def test_body_space_columns_of_the_four_contact_model(dtype):
+    """Body-space columns on a model that fits one column set anyway (human36 with four contacts, the headline workload): the
+    DEFAULT since round 6 (on request, ARB_STEP_BODY_COLUMNS, in round 5) -- against the oracle like the classical columns
+    (ARB_STEP_CLASSIC_COLUMNS), and against them."""
     from conftest import assert_f32_parity
     from arboris_python_amd.batch import BatchedWorlds
     g = load_golden("g3_contacts.npz")
@@ -358,14 +359,15 @@ def test_body_space_columns_on_request_for_the_four_contact_model(dtype):
     npt = np.float64 if dtype == "float64" else np.float32
     Q = np.concatenate([g["drop4_q"][:39], g["rand4_q"]]); DQ = np.concatenate([g["drop4_dq"][:39], g["rand4_dq"]])
     bw = BatchedWorlds(m)
-    assert bw.plan(8192, 40, dtype=dt_)["feat"] == 4 and bw.plan(8192, 40, dtype=dt_, body_columns=True)["feat"] == 20
+    assert bw.plan(8192, 40, dtype=dt_)["feat"] == 20 and bw.plan(8192, 40, dtype=dt_, body_columns=True)["feat"] == 20
+    assert bw.plan(8192, 40, dtype=dt_, classic_columns=True)["feat"] == 4
     assert bw.plan(8192, 40, dtype=dt_, body_columns=True, general_kernels=True)["feat"] == 0
     oq, odq, ocf = O.step(m, Q.astype(npt).astype(np.float64), DQ.astype(npt).astype(np.float64), 5e-3)
     res = {}
     for bc in (False, True):
         tq, tdq = bw.to_device(Q, DQ, dt_)
         cf = bw.new_cforce(len(Q), dt_)
-        bw.step(tq, tdq, 5e-3, 1, cforce=cf, body_columns=bc)
+        bw.step(tq, tdq, 5e-3, 1, cforce=cf, classic_columns=not bc)
         torch.cuda.synchronize()
         res[bc] = (tq.double().cpu().numpy(), tdq.double().cpu().numpy())
         if dtype == "float64":

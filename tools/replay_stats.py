@@ -57,6 +57,6 @@ print("outliers: %d, by criterion: %s" % (int((e > 1e-5).sum()), dict(sorted(cri
 de = crit.get("d", 0) + crit.get("e", 0)
 print("criteria (d) + (e): %d = %.4f %% of the world-steps (cap %.2f %%); largest system errors among them: Y' %.1e, v' %.1e, solve rows %.1e"
       "; the a-priori float32 bounds they had to stay inside (parity_tools.APRIORI_K): Y' %.1e, v' %.1e of the largest entry"
-      % (de, 100. * de / n, 100 * (4e-3 if m.nc > 4 else P.DE_SHARE_CAP), diag["e_adm"], diag["e_vel"], diag["e_row"], diag["apriori_adm"], diag["apriori_vel"]))
+      % (de, 100. * de / n, 100 * P.DE_SHARE_CAP, diag["e_adm"], diag["e_vel"], diag["e_row"], diag["apriori_adm"], diag["apriori_vel"]))
 print("above the caps (q 1e-3, dq 1e-2): %d %s" % (len(over), over))
 print("unexplained: %d %s" % (len(unexplained), unexplained[:20]))
