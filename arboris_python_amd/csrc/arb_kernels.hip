@@ -367,8 +367,8 @@ static const int kNmaxChoices[] = {16, 32, 44, 48, 64};    // 44: human36 (42 do
 
 static int forest_create(const arb_model_desc *d, int K, int device, arb_model **out);
 
-// How many copies of a small model share a wavefront (1: none).  Measured on an MI355X (tools/experiments/forest_probe.py,
-// tools/experiments/forest_rate.py, M world-steps/s at 65 536 worlds x 64 steps): simplearm (3 dofs) float32 106
+// How many copies of a small model share a wavefront (1: none).  Measured on an MI355X (tools/forest_probe.py,
+// tools/forest_rate.py, M world-steps/s at 65 536 worlds x 64 steps): simplearm (3 dofs) float32 106
 // alone, 274 with 5 copies (still the 16-row tile), 526 with 8, 241 with 21 (64 rows); float64 86 / 345 / ~400 / 104;
 // the 15-dof free snake 62 alone, 95 as a pair; ball and socket (6 dofs, 1 constraint) 83 alone, 198 with 5 copies,
 // 193 with 7 (two column sets).  Hence: as many copies as fit the 32-row tile with ONE set of columns, and the 24-body

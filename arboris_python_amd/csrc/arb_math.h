@@ -1641,7 +1641,7 @@ ARB_HD int softfinger_try(const T v[4], const T Y[16], const T P[16], T f[4], T 
     }
     // sliding, constraints.py:803-836
     alpha[0] = v0[0]; alpha[1] = v0[1]; alpha[2] = v0[2]; alpha[3] = v0[3] + sdist / dt;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ARB_NO_SOFTFINGER_BARRIER)      /* (reproducer: tools/softfinger_barrier_repro.sh) */
     // Compiler workaround (hipcc 7.2, gfx950, -O2 and up): without this barrier the force that comes in, which
     // the finish needs again AFTER the root finder (df = f_new - f), reached softfinger_slide_finish with wrong
     // values in float32 lane-per-world code -- f_new right, df = 1e17 -- for one input in two million solves

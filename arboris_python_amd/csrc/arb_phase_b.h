@@ -141,7 +141,7 @@
             // (the three-wave kernels pass the accumulators through a half-size table in two passes -- less LDS, more
             // registers held across the first pass --, the two-wave kernels through a full table in one)
             // (measured on the 16- and 32-row tiles, whose register peak is the same phase A / B as the 44-row tile's: two passes
-            // in their two-wave kernels cost 65 spilled VGPRs and 3-6 %, tools/experiments/forest_rate.py)
+            // in their two-wave kernels cost 65 spilled VGPRs and 3-6 %, tools/forest_rate.py)
             constexpr bool TWO_PASS = (CM == 2 || CM == 3 || CM == 4 || MODE == 1);
             constexpr int TBS = TWO_PASS ? TB_STRIDE : TB_STRIDE1;
             const bool lscan = LSCAN_OK && mp->lay.lscan;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, 
     // (the float64 64-row kernels, compiled for one wave per SIMD with part of the register tile in AGPRs, faulted on
     // their first launch -- queue or not -- with the item loop around the body, ROCm 7.2: there every workgroup draws
     // ONE item and the grid is the number of items; the hardware dispatcher does the looping)
-    // (reproducer: tools/experiments/f64_64_item_loop_repro.sh builds with -DARB_QUEUE_LOOP_ALL=1, which puts the loop back)
+    // (reproducer: tools/f64_64_item_loop_repro.sh builds with -DARB_QUEUE_LOOP_ALL=1, which puts the loop back)
 #ifndef ARB_QUEUE_LOOP
 #define ARB_QUEUE_LOOP 1
 #endif

@@ -297,7 +297,7 @@ def make_states(cfg, model, lo, hi, seed):
         return synth.world_states(model, range(lo, hi), "random", seed, angle=0.5, vel=1.0)
     # config 2: random poses, hinge angles U(-0.7, 0.7) rad, velocities U(-1, 1).  (More energetic draws -- angle 1,
     # velocities 3, the generator's defaults -- send the reference's own time stepping beyond 100 rad/s within 40 steps
-    # for 80 % of the worlds, in the float64 oracle as on the device, tools/experiments/config2_finite.py: the step's cost does not
+    # for 80 % of the worlds, in the float64 oracle as on the device, tools/config2_finite.py: the step's cost does not
     # depend on the data, but a benchmark should not integrate garbage.)
     return synth.world_states(model, range(lo, hi), "random", seed, angle=0.7, vel=1.0)
 

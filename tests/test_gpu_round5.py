@@ -267,7 +267,7 @@ def test_float32_on_an_ill_conditioned_model_is_right_by_default_and_warns_when_
         assert float(gr.max()) < _capi.ARB_ILLCOND_GROWTH / 4.
         cf = bw.new_cforce(B, torch.float32) if m.nc else None
         # (free motion from random states: 20 steps -- the reference's own time stepping sends a few of 5000 such worlds
-        # beyond 1e5 rad/s by step 35, tools/experiments/growth_probe.py, and a diverging world IS ill-conditioned)
+        # beyond 1e5 rad/s by step 35, tools/growth_probe.py, and a diverging world IS ill-conditioned)
         bw.step(tq, tdq, 5e-3, 40 if m.nc else 20, cforce=cf)
         bw.step(tq, tdq, 5e-3, 1, cforce=cf)
         torch.cuda.synchronize()
