@@ -1066,6 +1066,10 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
             if (bodyc) {                                                                                               \
                 if constexpr (MODE == 1) return ONE(NM, 1, 19);                                                        \
                 else if constexpr (std::is_same<T, float>::value) {                                                    \
+                    if (M->nc == 4 && noopt) {      /* (compiled for four contacts: FEAT bit 32) */                    \
+                        if (w3) return plain ? ONE_(NM, 1, 52, 2) : ONE_(NM, 1, 53, 2);                                \
+                        return plain ? ONE(NM, 1, 52) : ONE(NM, 1, 53);                                                \
+                    }                                                                                                  \
                     if (w3) return plain ? ONE_(NM, 1, 20, 2) : noopt ? ONE_(NM, 1, 21, 2) : ONE_(NM, 1, 19, 2);       \
                     return plain ? ONE(NM, 1, 20) : noopt ? ONE(NM, 1, 21) : ONE(NM, 1, 19);                           \
                 } else return plain ? ONE(NM, 1, 20) : noopt ? ONE(NM, 1, 21) : ONE(NM, 1, 19);                        \
@@ -1078,7 +1082,7 @@ static int launch(arb_model *M, const DevModel<T> *dm, const Layout &L, T *q, T 
 #endif
 // (the instantiation must fit the model: a kernel with the wrong tile, column sets or model class computes on, silently wrong --
 // round 4's first launch table sent an 8-contact model to the one-set specialised kernel; checked at every launch since)
-#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && (((FT) & 16) ? (M->bodycols && (NS) == 1) : (M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS))))) && (!((FT) & 8) || (M->spec0_ok && M->nc == 0))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, ((FT) & 16) ? ((CMV) == 2 ? M->lfb3 : (std::is_same<T, float>::value ? M->lfb : M->ldb)) : (CMV) == 2 ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st, M->kn, ext_stride, pd_stride, cost))
+#define ONE_(NM, NS, FT, CMV) (!(M->nmax == (NM) && (!((FT) & 32) || M->nc == 4) && (((FT) & 16) ? (M->bodycols && (NS) == 1) : (M->nsets == (NS) && (!((FT) & 4) || (M->spec_ok && M->nc == 4 * (NS))))) && (!((FT) & 8) || (M->spec0_ok && M->nc == 0))) ? (g_hip_err = "internal: kernel instantiation does not fit the model", (int)ARB_ERR_HIP) : launch_one<T, NM, NS, MODE, FT, CMV>(dm, ((FT) & 16) ? ((CMV) == 2 ? M->lfb3 : (std::is_same<T, float>::value ? M->lfb : M->ldb)) : (CMV) == 2 ? M->lf3 : L, q, dq, cf, ext, pwd, nw, dt, nsteps, flags, dbg, zmode, logo, sio, dts, st, M->kn, ext_stride, pd_stride, cost))
 #define ONE(NM, NS, FT) ONE_(NM, NS, FT, 0)
 #ifdef ARB_QUICK
     // development build: a single register tile (float, NMAX=44), the production kernels only (-DARB_QUICK=2: also

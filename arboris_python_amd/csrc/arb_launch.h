@@ -193,6 +193,11 @@ template int launch_one<float, ARB_PART_NMAX, 1, 0, 20, 0>(ARB_LAUNCH_ONE_ARGS(f
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 21, 0>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 20, 2>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 21, 2>(ARB_LAUNCH_ONE_ARGS(float));
+#elif ARB_PART_SPEC == 8       /* float32, body-space columns compiled for four contacts (FEAT bit 32): the headline */
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 52, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 53, 0>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 52, 2>(ARB_LAUNCH_ONE_ARGS(float));
+template int launch_one<float, ARB_PART_NMAX, 1, 0, 53, 2>(ARB_LAUNCH_ONE_ARGS(float));
 #elif ARB_PART_SPEC == 6
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 19, 0>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 19, 2>(ARB_LAUNCH_ONE_ARGS(float));
@@ -278,6 +283,10 @@ ARB_EXTERN_TILE_MIXED(16) ARB_EXTERN_TILE_MIXED(32) ARB_EXTERN_TILE_MIXED(44) AR
     extern template int launch_one<float, NM, 1, 0, 21, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
     extern template int launch_one<float, NM, 1, 0, 20, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
     extern template int launch_one<float, NM, 1, 0, 21, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 52, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 53, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 52, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
+    extern template int launch_one<float, NM, 1, 0, 53, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
     extern template int launch_one<float, NM, 1, 0, 19, 0>(ARB_LAUNCH_ONE_ARGS(float)); \
     extern template int launch_one<float, NM, 1, 0, 19, 2>(ARB_LAUNCH_ONE_ARGS(float)); \
     extern template int launch_one<float, NM, 1, 1, 19, 0>(ARB_LAUNCH_ONE_ARGS(float)); \

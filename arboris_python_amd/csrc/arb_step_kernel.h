@@ -58,11 +58,16 @@ __global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, 
 #ifndef ARB_BC_NC
 #define ARB_BC_NC 0           // development: the BODYCOL kernels compiled for this number of contacts (0: a run-time value)
 #endif
-    constexpr bool NC_CONST = ((FEAT & 12) != 0 && !BODYCOL) || (BODYCOL && ARB_BC_NC > 0 && MODE == 0);       // nc, ndol compile-time constants
-    constexpr int SPEC_NC = BODYCOL ? ARB_BC_NC : (FEAT & 8) ? 0 : 4 * NSETS;
+    // FEAT bit 5 (32, round 6): the BODYCOL kernels compiled for exactly FOUR contacts (plain inputs 52, user torques 53): since
+    // round 6 body-space columns are the default of every qualifying model, so the headline model (four contacts) runs them,
+    // and a compile-time nc is worth 1.2 % there (measured in round 5, ARB_BC_NC; not worth the builds while it was opt-in)
+    constexpr int BC_NC = (FEAT & 32) ? 4 : ARB_BC_NC;
+    constexpr bool NC_CONST = ((FEAT & 12) != 0 && !BODYCOL) || (BODYCOL && BC_NC > 0 && MODE == 0);       // nc, ndol compile-time constants
+    constexpr int SPEC_NC = BODYCOL ? BC_NC : (FEAT & 8) ? 0 : 4 * NSETS;
     static_assert(!NC_CONST || (!FEAT_ALL && MODE == 0 && (CM == 0 || CM == 2)), "specialised kernels: plain inputs / user torques");
-    static_assert(!BODYCOL || (NSETS == 1 && (CM == 0 || CM == 2) && (FEAT == 20 || FEAT == 21 || FEAT == 19)),
-                  "body-space columns: one column set; plain inputs (20), user torques (21), every optional input / inspect (19)");
+    static_assert(!BODYCOL || (NSETS == 1 && (CM == 0 || CM == 2) && (FEAT == 20 || FEAT == 21 || FEAT == 19 || FEAT == 52 || FEAT == 53)),
+                  "body-space columns: one column set; plain inputs (20), user torques (21), every optional input / inspect (19); + 32: four contacts");
+    static_assert(!(FEAT & 32) || BODYCOL, "FEAT bit 32 qualifies the body-space-column kernels");
     static_assert((FEAT & 12) != 12 && (!(FEAT & 8) || NSETS == 1), "specialised kernels: one model class at a time");
     const T *__restrict__ gext = FEAT_EXT ? gext_in : nullptr;
     // ABI 7: control inputs that change along the horizon -- step t reads row t of [nsteps][nworlds][ndof] arrays (stride 0:

@@ -399,9 +399,10 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     cus = torch.cuda.get_device_properties(bw.device).multi_processor_count
     build = lambda p: (p["waves_per_simd"], p["worlds_per_wavefront"])
     p = bw.plan(4 * cus, 40)
-    # (feat 20 / 21: body-space constraint columns, this model's default since round 6; feat 4 / 5 with classic_columns: the
-    # kernels specialised for four plane / sphere SoftFingerContacts, round 4 -- tests/test_gpu_round4.py)
-    assert build(p) == (2, 1) and p["work_queue"] == 0 and p["feat"] == 20 and p["wave_slots"] == 8 * cus
+    # (feat 52 / 53 = 16 + 32 + 4 [+ 1]: body-space constraint columns compiled for four contacts, this model's default since
+    # round 6; feat 4 / 5 with classic_columns: the classical columns specialised for four plane / sphere SoftFingerContacts,
+    # round 4 -- tests/test_gpu_round4.py)
+    assert build(p) == (2, 1) and p["work_queue"] == 0 and p["feat"] == 52 and p["wave_slots"] == 8 * cus
     assert bw.plan(4 * cus, 40, classic_columns=True)["feat"] == 4
     p = bw.plan(16 * cus, 40)
     assert build(p) == (3, 1) and p["work_queue"] == 1 and p["wave_slots"] == 12 * cus
@@ -410,7 +411,7 @@ def test_step_plan_reports_the_batch_size_rules(monkeypatch):
     assert build(bw.plan(16 * cus, 40, waves=2)) == (2, 1)
     assert build(bw.plan(4 * cus, 40, waves=3)) == (3, 1)
     p = bw.plan(64 * cus, 40, ext_gforce=True)
-    assert build(p) == (3, 1) and p["feat"] == 21 and p["work_queue"] == 1
+    assert build(p) == (3, 1) and p["feat"] == 53 and p["work_queue"] == 1
     assert bw.plan(64 * cus, 40, ext_gforce=True, classic_columns=True)["feat"] == 5
     assert p["lds_bytes"] <= 10 * 1280                       # twelve wavefronts per CU at the 1280-byte LDS granule
     assert build(bw.plan(64 * cus, 40, other_inputs=True)) == (3, 1) and bw.plan(64 * cus, 40, other_inputs=True)["feat"] == 19

@@ -21,7 +21,8 @@ def test_plan_reports_the_specialised_kernels(monkeypatch):
     assert _capi.load().arb_build_variants() == 0
     # model: class bits in float32 (4: contacts, 8: no constraints, 4 | 16: contacts with body-space columns, 0: the general
     # kernels), in float64
-    want = {"human36_c4": (20, 20),              # four plane / sphere SoftFingerContacts: body-space columns by default (round 6)
+    want = {"human36_c4": (52, 20),              # four plane / sphere SoftFingerContacts: body-space columns by default (round 6;
+                                                 # float32: compiled for four contacts, FEAT bit 32)
             "human36_c8": (20, 20),              # eight on two feet: body-space constraint columns, ONE column set (round 5)
             "human36_g": (8, 0),                 # no constraints (BASELINE config 2): float32 only
             "human36_visc": (0, 0),              # joint viscosity: outside the classes

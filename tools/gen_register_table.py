@@ -19,11 +19,13 @@ BEGIN, END = "<!-- REGISTERS:BEGIN (tools/gen_register_table.py) -->", "<!-- REG
 
 # (precision, column sets, mode, feat, cm) of the float32 / float64 44-row kernels worth a row, with what they are
 ROWS = [
-    ("f", 1, 0, 4, 2, "specialised (four contacts), three waves -- the headline kernel"),
-    ("f", 1, 0, 5, 2, "... with user torques / torque sequences / running cost (the MPC leg at large batches)"),
-    ("f", 1, 0, 4, 0, "specialised, two waves"),
-    ("f", 1, 0, 5, 0, "... with user torques (the 2048-rollout MPC leg)"),
-    ("f", 1, 0, 20, 2, "body-space columns (eight contacts), three waves -- `contacts8`"),
+    ("f", 1, 0, 52, 2, "body-space columns compiled for four contacts, three waves -- the headline kernel (round 6)"),
+    ("f", 1, 0, 53, 2, "... with user torques / torque sequences / running cost (the MPC leg at large batches)"),
+    ("f", 1, 0, 52, 0, "body-space columns, four contacts, two waves"),
+    ("f", 1, 0, 53, 0, "... with user torques (the 2048-rollout MPC leg)"),
+    ("f", 1, 0, 4, 2, "classical columns specialised for four contacts, three waves (`classic_columns_f32`; the headline until round 5)"),
+    ("f", 1, 0, 4, 0, "classical columns, four contacts, two waves"),
+    ("f", 1, 0, 20, 2, "body-space columns, any number of contacts (eight: `contacts8`), three waves"),
     ("f", 1, 0, 20, 0, "body-space columns, two waves"),
     ("f", 1, 0, 19, 2, "body-space columns, every optional input (rollout logs), three waves"),
     ("f", 1, 0, 8, 2, "no constraints (config 2 at large batches), three waves"),
@@ -32,6 +34,7 @@ ROWS = [
     ("f", 1, 0, 1, 2, "general + user torques, three waves"),
     ("f", 1, 0, 3, 2, "general, every optional input, three waves"),
     ("f", 1, 0, 0, 0, "general, two waves"),
+    ("f", 1, 0, 0, 3, "mixed build (float32 state, float64 elimination; ARB_STEP_MIXED)"),
     ("f", 2, 0, 0, 0, "general, two column sets"),
     ("f", 1, 1, 3, 0, "inspect"),
     ("f", 1, 1, 19, 0, "inspect, body-space columns"),
