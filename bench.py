@@ -675,7 +675,9 @@ def main():
                                                             "(the matrix-core variant measured slower, DESIGN.md 3)")
         except Exception:
             pass
-    if n_gpus == 1 and launches_per_episode == 1 and not args.split and cfg["dtype"] == "f32":
+    # (not under the profiling runs of tools/profile_gpu.sh: the lone-wave launches would mix into the per-kernel statistics)
+    if (n_gpus == 1 and launches_per_episode == 1 and not args.split and cfg["dtype"] == "f32" and not args.no_per_step_leg
+            and os.environ.get("ARB_BENCH_LEGS") != "perstep"):
         try:
             res["roofline"]["chain"] = chain_roof(bw, model, cfg, q0, dq0, torch, np, kernel_build, value)
         except Exception as e:                        # (never lose the line to a diagnostic leg)
