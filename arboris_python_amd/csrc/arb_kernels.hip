@@ -805,13 +805,22 @@ static int wide_step(arb_model *M, void *q, void *dq, void *cf, const void *ext,
 template <typename T>
 static int wide_inspect(arb_model *M, const void *q, const void *dq, const void *cf, const void *ext, const void *zimp, long nw, double dt,
                         unsigned flags, const arb_inspect_out *o, hipStream_t st) {
-    // what the wide kernel does not form: the body Jacobians and the separate world matrices (the object API of worlds this
-    // large runs through BatchedWorlds), the per-solve diagnostics
-    if (o->jac || o->djac || o->M || o->B || o->N || o->gs_stats || o->gs_trace || o->stamps || o->energy || o->pivot_growth) return ARB_ERR_UNSUPPORTED;
+    // what the wide kernel does not form: the per-solve diagnostics of the wavefront kernels, the energies
+    if (o->gs_stats || o->gs_trace || o->stamps || o->energy || o->pivot_growth) return ARB_ERR_UNSUPPORTED;
     WideIO<T> io;
     memset(&io, 0, sizeof(io));
     io.q = (T *)q; io.dq = (T *)dq; io.cf = (T *)cf; io.ext = (const T *)ext; io.zimp = (const T *)zimp;
     io.inspect = 1;
+    // the three world matrices: one pass each, like the wavefront kernels (core.py:722-734)
+    struct { void *ptr; int zmode; } passes[3] = {{o->M, 1}, {o->B, 2}, {o->N, 3}};
+    for (auto &ps : passes) {
+        if (!ps.ptr) continue;
+        WideIO<T> i1 = io;
+        i1.zmode = ps.zmode; i1.Zout = (T *)ps.ptr;
+        const int rc = wide_launch<T>(M, i1, nw, dt, nullptr, 1, flags | ARB_STEP_SKIP_CONSTRAINTS, st);
+        if (rc != ARB_OK) return rc;
+    }
+    io.jac = (T *)o->jac; io.djac = (T *)o->djac;
     io.pose = (T *)o->pose; io.twist = (T *)o->twist; io.Zout = (T *)o->Z; io.gforce0 = (T *)o->gforce0; io.vel_free = (T *)o->vel_free;
     io.c_sdist = (T *)o->c_sdist; io.c_active = (int *)o->c_active; io.c_jac = (T *)o->c_jac; io.c_force = (T *)o->c_force;
     io.c_frame = (T *)o->c_frame; io.gforce = (T *)o->gforce; io.q_next = (T *)o->q_next; io.dq_next = (T *)o->dq_next;

@@ -43,6 +43,8 @@ struct WideIO {
     T *log_q, *log_dq;                                      // [nsteps][nw][nq], [nsteps][nw][n] or null
     // inspect outputs (any may be null; one step, the state buffers are not written when `inspect` is set)
     int inspect;
+    int zmode;                                              // inspect: what Zout receives -- 0 Z, 1 M, 2 B, 3 N (core.py:722-734)
+    T *jac, *djac;                                          // [nw][nb][6][n] Body.jacobian / djacobian (core.py:1273-1274)
     T *pose, *twist, *Zout, *gforce0, *vel_free, *c_sdist, *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next, *c_adm, *c_vel;
     int *c_active;
 };
@@ -306,18 +308,20 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             if (!(mm <= 1e-10)) cm = (1. / mm) * v3<double>(Mb[6 * 2 + 4], Mb[6 * 0 + 5], Mb[6 * 1 + 3]);
             const V3<double> Tw = mv(R, wb), Tv = mv(R, cross(cm, wb)) + cross(p, Tw);
             const V3<double> ow = mv(R, ld3(OM + 6 * b)), ov = mv(R, ld3(OM + 6 * b + 3)) + cross(p, ow);
-            for (int i = 0; i < 36; ++i) A[i] = inv_dt * G[i];
-            for (int j = 0; j < 6; ++j) {                        // -ad(T*)^T Mg
+            const bool useM = io.zmode == 0 || io.zmode == 1, useN = io.zmode == 0 || io.zmode == 3, useB = io.zmode == 0 || io.zmode == 2;
+            const double cM = io.zmode == 1 ? 1. : inv_dt;
+            for (int i = 0; i < 36; ++i) A[i] = useM ? cM * G[i] : 0.;
+            if (useN) for (int j = 0; j < 6; ++j) {              // -ad(T*)^T Mg
                 const V3<double> gt = v3<double>(G[j], G[6 + j], G[12 + j]), gb = v3<double>(G[18 + j], G[24 + j], G[30 + j]);
                 const V3<double> t = cross(Tw, gt) + cross(Tv, gb), u = cross(Tw, gb);
                 A[j] += t.x; A[6 + j] += t.y; A[12 + j] += t.z; A[18 + j] += u.x; A[24 + j] += u.y; A[30 + j] += u.z;
             }
-            for (int r = 0; r < 6; ++r) {                        // Mg ad(Om)
+            if (useN) for (int r = 0; r < 6; ++r) {              // Mg ad(Om)
                 const V3<double> gl = v3<double>(G[6 * r], G[6 * r + 1], G[6 * r + 2]), gr = v3<double>(G[6 * r + 3], G[6 * r + 4], G[6 * r + 5]);
                 const V3<double> t = cross(gl, ow) + cross(gr, ov), u = cross(gr, ow);
                 A[6 * r] += t.x; A[6 * r + 1] += t.y; A[6 * r + 2] += t.z; A[6 * r + 3] += u.x; A[6 * r + 4] += u.y; A[6 * r + 5] += u.z;
             }
-            if (M.has_visc) {
+            if (M.has_visc && useB) {
                 const double *Vb = M.visc + 36 * b;
                 const M3<double> B11 = rot(blk(Vb, 0, 0)), B12 = rot(blk(Vb, 0, 3)), B21 = rot(blk(Vb, 3, 0)), B22 = rot(blk(Vb, 3, 3));
                 const M3<double> H12 = add(B12, hatmul(p, B22));
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     A[6 * (3 + i) + j] += H21.a[3 * i + j]; A[6 * (3 + i) + 3 + j] += B22.a[3 * i + j];
                 }
             }
-            for (int i = 0; i < 36; ++i) { AC[36 * b + i] = A[i]; MC[36 * b + i] = G[i]; }
+            for (int i = 0; i < 36; ++i) { AC[36 * b + i] = A[i]; MC[36 * b + i] = useN ? G[i] : 0.; }     // (M dX' is a term of N)
             for (int h = 0; h < 2; ++h) {                        // wrenches to world axes: increment rhs, gravity alone
                 const double *pt = PT + 12 * b + 6 * h;
                 const V3<double> f = mv(R, v3<double>(pt[3], pt[4], pt[5]));
@@ -388,10 +392,40 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 } else if (anc_eq(bk, bi)) {                     // a descendant's: P_i . X_k + R_i . dX'_k
                     for (int r = 0; r < 6; ++r) v += xi[12 + r] * xc[r] + xi[18 + r] * xc[6 + r];
                 }
-                if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];              // controllers.py:141-158
-                if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];      // core.py:815-817
+                if (io.zmode == 0) {
+                    if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];          // controllers.py:141-158
+                    if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];  // core.py:815-817
+                }
             }
             Z[i * ld + c] = v;
+        }
+        if (io.inspect && io.zmode != 0) {           // the world matrices M, B, N one by one (the object API): Zout and on to the next world
+            __syncthreads();
+            if (io.Zout != nullptr) for (int e = tid; e < n * n; e += WIDE_THREADS) io.Zout[(long)w * n * n + e] = (T)Z[(e / n) * ld + (e % n)];
+            break;
+        }
+        // inspect: body Jacobians J_b = Ad(b<-g) X, dJ_b = Ad(b<-g) dX' + ad(Om_b) J_b over the dofs of b's ancestors (see arb_phase_b.h)
+        if (io.inspect && step == 0 && (io.jac != nullptr || io.djac != nullptr)) {
+            for (int e = tid; e < nb * n; e += WIDE_THREADS) {
+                const int b = e / n, k = e - b * n;
+                double j6[6] = {0., 0., 0., 0., 0., 0.}, e6[6] = {0., 0., 0., 0., 0., 0.};
+                if (anc_eq(M.dofbody[k], b)) {
+                    const M3<double> R = ldm(POSE + 12 * b);
+                    const V3<double> p = ld3(POSE + 12 * b + 9), obw = ld3(OM + 6 * b), obv = ld3(OM + 6 * b + 3);
+                    const double *xk = XK + WIDE_XK * k;
+                    const V3<double> xw = v3<double>(xk[0], xk[1], xk[2]), xv = v3<double>(xk[3], xk[4], xk[5]);
+                    const V3<double> dw = v3<double>(xk[6], xk[7], xk[8]), dv = v3<double>(xk[9], xk[10], xk[11]);
+                    const V3<double> jw = mtv(R, xw), jv = mtv(R, xv - cross(p, xw));
+                    const V3<double> ew = mtv(R, dw) + cross(obw, jw);
+                    const V3<double> ev = mtv(R, dv - cross(p, dw)) + cross(obv, jw) + cross(obw, jv);
+                    j6[0] = jw.x; j6[1] = jw.y; j6[2] = jw.z; j6[3] = jv.x; j6[4] = jv.y; j6[5] = jv.z;
+                    e6[0] = ew.x; e6[1] = ew.y; e6[2] = ew.z; e6[3] = ev.x; e6[4] = ev.y; e6[5] = ev.z;
+                }
+                for (int i = 0; i < 6; ++i) {
+                    if (io.jac != nullptr) io.jac[(((long)w * nb + b) * 6 + i) * n + k] = (T)j6[i];
+                    if (io.djac != nullptr) io.djac[(((long)w * nb + b) * 6 + i) * n + k] = (T)e6[i];
+                }
+            }
         }
         // constraint rows s_k [Ad(c0<-g) X_k] (constraints.py:429-433, 203-207, 46-48): rows of J' in JR, columns of J'^T in Z
         if (do_con) for (int e = tid; e < ndol * n; e += WIDE_THREADS) {

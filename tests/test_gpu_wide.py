@@ -156,7 +156,7 @@ def test_human36_beside_four_free_objects_66_dofs():
     with pytest.raises(_capi.ArbError):
         bw.step(sq, sdq, dt, 1, cforce=scf, pd_targets=(torch.zeros_like(sdq), torch.zeros_like(sdq)), pd_gains=(torch.ones_like(sdq), torch.ones_like(sdq)))
     with pytest.raises(_capi.ArbError):
-        bw.inspect(sq, sdq, dt, ["jac"])
+        bw.inspect(sq, sdq, dt, ["gs_stats"])
     bw.close()
 
 
@@ -179,3 +179,30 @@ def test_limits_of_the_wide_path():
     desc, keep = _capi.make_desc(m2)
     h = C.c_void_p()
     assert _capi.load().arb_model_create(C.byref(desc), 0, C.byref(h)) == 2
+
+
+def test_object_api_simulates_a_wide_world():
+    """`simulate`'s loop body on a world of 66 dofs through the object API (World.update_dynamic / update_controllers /
+    update_constraints / integrate on the device, a batch of one): body Jacobians, the world matrices M, B, N, the impedance
+    and every step's state against the oracle (float64)."""
+    from arboris_python_amd import scenes
+    from arboris_python_amd.flatten import flatten_world
+    w = scenes.human36_and_objects_world(4)
+    m, q, dq = flatten_world(w)
+    dt = 5e-3
+    w.update_dynamic()
+    dyn = O.update_dynamic(m, q[None], dq[None])
+    assert np.abs(w.mass - dyn["M"][0]).max() / np.abs(dyn["M"][0]).max() < 1e-12
+    assert np.abs(w.nleffects - dyn["N"][0]).max() <= 1e-12 * max(1., np.abs(dyn["N"][0]).max())
+    assert np.abs(w.viscosity - dyn["Bv"][0]).max() < 1e-12
+    bodies = list(w.ground.iter_descendant_bodies())
+    for b in (0, 5, 16, 17, 20):
+        assert np.abs(bodies[b].jacobian - dyn["jac"][0, b]).max() < 1e-12 and np.abs(bodies[b].djacobian - dyn["djac"][0, b]).max() < 1e-11
+        assert np.abs(bodies[b].twist - dyn["twist"][0, b]).max() < 1e-12
+    oq, odq, ocf = q[None], dq[None], None
+    for k in range(6):
+        w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt); w.integrate(dt)
+        oq, odq, ocf = O.step(m, oq, odq, dt, cforce=ocf)
+        qd = np.concatenate([np.asarray(j.gpos, float).ravel() for j in w.iterjoints()])
+        assert _rel(qd, oq[0]) < 1e-9 and _rel(w.gvel, odq[0]) < 1e-8, k
+    assert w._engine.flatten_count == 1
