@@ -746,9 +746,10 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     upd(vec(d->c_min, nc), &W.cmin); upd(vec(d->c_max, nc), &W.cmax);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     // the augmented system in LDS when it fits beside the pivot row / column (120 KB: one workgroup per CU), else in scratch
-    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 44 * nc) * sizeof(double);
+    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc) * sizeof(double);
     W.z_in_lds = (size_t)n * W.ld * sizeof(double) + small <= 120 * 1024 ? 1 : 0;
     M->wide_lds = small + (W.z_in_lds ? (size_t)n * W.ld * sizeof(double) : 0);
+    W.chain_in_lds = (W.z_in_lds && 84l * nb <= (long)n * W.ld) ? 1 : 0;        // (the pose / twist chain borrows the system's LDS space)
     long o = 0;
     auto take = [&](long cnt) { const long at = o; o += (cnt + 1) & ~1l; return at; };
     W.o_q = take(d->nq); W.o_dq = take(n); W.o_qd = take(n); W.o_ff = take(std::max(ndol, 1)); W.o_ff0 = take(std::max(ndol, 1));

@@ -22,7 +22,7 @@
 #define WIDE_CD 40          // per constraint: R (9) | p (3) | pos0 (3) | sdist | active | glo | ghi | pad ... | pinv (16) at 24
 
 struct WideModel {
-    int nb, n, nq, nc, ndol, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds;
+    int nb, n, nq, nc, ndol, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds, chain_in_lds;
     double grav[3], up[3];
     const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *weighted, *dof2q, *dofbody, *subsize;
     const double *Hpr, *Hcn, *mass, *visc;                 // [nb][12], [nb][12], [nb][36], [nb][36]
@@ -64,12 +64,18 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     double *SWORK = DF + 8;                  // [48]      scratch of the sliding solve (eig6 fallback)
     double *GVV = SWORK + 48;                // [ndol]    v' during the sweeps
     double *GFF = GVV + ((M.ndol + 3) & ~3); // [ndol]    constraint forces during the sweeps
-    double *GSC = GFF + ((M.ndol + 3) & ~3); // [nc][44]  per-constraint blocks and constants of the sweeps
-    double *ZL = GSC + 44 * M.nc;            // [n][ld]   the augmented system, when it fits
+    double *GSC = GFF + ((M.ndol + 3) & ~3); // [nc][52]  per-constraint blocks and constants of the sweeps
+    double *ZL = GSC + 52 * M.nc;            // [n][ld]   the augmented system, when it fits
     double *S = scratch_all + (size_t)blockIdx.x * (size_t)M.total;
-    double *QS = S + M.o_q, *DQS = S + M.o_dq, *QD = S + M.o_qd, *FF = S + M.o_ff, *FF0 = S + M.o_ff0, *POSE = S + M.o_pose,
-           *PC = S + M.o_pc, *RCP = S + M.o_rcp, *TW = S + M.o_tw, *AB = S + M.o_ab, *OM = S + M.o_om, *DA = S + M.o_da,
-           *TN = S + M.o_tn, *BN = S + M.o_bn, *PT = S + M.o_pt, *SC = S + M.o_sc, *AC = S + M.o_ac, *MC = S + M.o_mc,
+    // The per-body arrays of the pose / twist chain (84 doubles per body, contiguous in the scratch block from o_pose on) live in
+    // LDS while the chain runs -- in the space the augmented system takes afterwards (chain_in_lds: they fit it) --: one
+    // depth level of a serial chain is a dependent round trip, 100 of them for snake-100.  Everything that reads them comes
+    // before the assembly of Z.
+    double *CHB = M.chain_in_lds ? ZL : S + M.o_pose;
+    double *QS = S + M.o_q, *DQS = S + M.o_dq, *QD = S + M.o_qd, *FF = S + M.o_ff, *FF0 = S + M.o_ff0, *POSE = CHB,
+           *PC = CHB + (M.o_pc - M.o_pose), *RCP = CHB + (M.o_rcp - M.o_pose), *TW = CHB + (M.o_tw - M.o_pose), *AB = CHB + (M.o_ab - M.o_pose),
+           *OM = CHB + (M.o_om - M.o_pose), *DA = CHB + (M.o_da - M.o_pose), *TN = CHB + (M.o_tn - M.o_pose), *BN = CHB + (M.o_bn - M.o_pose),
+           *PT = S + M.o_pt, *SC = S + M.o_sc, *AC = S + M.o_ac, *MC = S + M.o_mc,
            *WC = S + M.o_wc, *XK = S + M.o_xk, *RH = S + M.o_rh, *JR = S + M.o_jr, *AM = S + M.o_am, *VV = S + M.o_vv,
            *CD = S + M.o_cd;
     double *Z = M.z_in_lds ? ZL : S + M.o_z;
@@ -80,6 +86,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     auto stm = [](double *p, const M3<double> &m) { for (int i = 0; i < 9; ++i) p[i] = m.a[i]; };
     // body a is an ancestor of (or is) body b: DFS preorder makes every subtree a contiguous range
     auto anc_eq = [&](int a, int b) { return a >= 0 && b >= 0 && a <= b && b < a + M.subsize[a]; };
+    // two-dimensional lane mapping of the matrix loops (no integer division per entry): a power-of-two number of column lanes
+    // covering n (at most 256), the other lanes stride over rows
+    int cwn = 1;
+    while (cwn < n && cwn < WIDE_THREADS) cwn <<= 1;
+    const int cl_n = tid & (cwn - 1), r0_n = tid / cwn, rs_n = WIDE_THREADS / cwn;
 
     for (long w = blockIdx.x; w < nworlds; w += gridDim.x) {
     __syncthreads();
@@ -178,6 +189,17 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 }
             }
             __syncthreads();
+        }
+        if (io.inspect && step == 0) {      // (poses and twists leave here: their arrays are gone once Z is assembled)
+            if (io.pose != nullptr) for (int b = tid; b < nb; b += WIDE_THREADS) {
+                T *o = io.pose + (w * nb + b) * 16;
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = 0; j < 3; ++j) o[4 * i + j] = (T)POSE[12 * b + 3 * i + j];
+                    o[4 * i + 3] = (T)POSE[12 * b + 9 + i];
+                }
+                o[12] = o[13] = o[14] = T(0); o[15] = T(1);
+            }
+            if (io.twist != nullptr) for (int i = tid; i < 6 * nb; i += WIDE_THREADS) io.twist[w * nb * 6 + i] = (T)TW[i];
         }
         // body wrench of the increment form: M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b   (core.py:975-976, 1276-1288)
         for (int b = tid; b < nb; b += WIDE_THREADS) {
@@ -380,30 +402,6 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             RH[k] = rm; RH[n + k] = rg;
         }
         __syncthreads();
-        // ---- the augmented system [Z | rhs | J'^T]: lane = entry --------------------------------------------------------
-        for (int e = tid; e < n * n; e += WIDE_THREADS) {
-            const int i = e / n, c = e - i * n;
-            double v = 0.;
-            {
-                const int bi = M.dofbody[i], bk = M.dofbody[c];
-                const double *xi = XK + WIDE_XK * i, *xc = XK + WIDE_XK * c;
-                if (anc_eq(bi, bk)) {                            // row i is the column's own or an ancestor's dof: X_i . G_k
-                    for (int r = 0; r < 6; ++r) v += xi[r] * xc[24 + r];
-                } else if (anc_eq(bk, bi)) {                     // a descendant's: P_i . X_k + R_i . dX'_k
-                    for (int r = 0; r < 6; ++r) v += xi[12 + r] * xc[r] + xi[18 + r] * xc[6 + r];
-                }
-                if (io.zmode == 0) {
-                    if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];          // controllers.py:141-158
-                    if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];  // core.py:815-817
-                }
-            }
-            Z[i * ld + c] = v;
-        }
-        if (io.inspect && io.zmode != 0) {           // the world matrices M, B, N one by one (the object API): Zout and on to the next world
-            __syncthreads();
-            if (io.Zout != nullptr) for (int e = tid; e < n * n; e += WIDE_THREADS) io.Zout[(long)w * n * n + e] = (T)Z[(e / n) * ld + (e % n)];
-            break;
-        }
         // inspect: body Jacobians J_b = Ad(b<-g) X, dJ_b = Ad(b<-g) dX' + ad(Om_b) J_b over the dofs of b's ancestors (see arb_phase_b.h)
         if (io.inspect && step == 0 && (io.jac != nullptr || io.djac != nullptr)) {
             for (int e = tid; e < nb * n; e += WIDE_THREADS) {
@@ -426,6 +424,30 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     if (io.djac != nullptr) io.djac[(((long)w * nb + b) * 6 + i) * n + k] = (T)e6[i];
                 }
             }
+        }
+        __syncthreads();            // (last reads of the chain arrays: Z takes their LDS space now)
+        // ---- the augmented system [Z | rhs | J'^T]: lane = entry --------------------------------------------------------
+        for (int i = r0_n; i < n; i += rs_n) for (int c = cl_n; c < n; c += cwn) {
+            double v = 0.;
+            {
+                const int bi = M.dofbody[i], bk = M.dofbody[c];
+                const double *xi = XK + WIDE_XK * i, *xc = XK + WIDE_XK * c;
+                if (anc_eq(bi, bk)) {                            // row i is the column's own or an ancestor's dof: X_i . G_k
+                    for (int r = 0; r < 6; ++r) v += xi[r] * xc[24 + r];
+                } else if (anc_eq(bk, bi)) {                     // a descendant's: P_i . X_k + R_i . dX'_k
+                    for (int r = 0; r < 6; ++r) v += xi[12 + r] * xc[r] + xi[18 + r] * xc[6 + r];
+                }
+                if (io.zmode == 0) {
+                    if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];          // controllers.py:141-158
+                    if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];  // core.py:815-817
+                }
+            }
+            Z[i * ld + c] = v;
+        }
+        if (io.inspect && io.zmode != 0) {           // the world matrices M, B, N one by one (the object API): Zout and on to the next world
+            __syncthreads();
+            if (io.Zout != nullptr) for (int e = tid; e < n * n; e += WIDE_THREADS) io.Zout[(long)w * n * n + e] = (T)Z[(e / n) * ld + (e % n)];
+            break;
         }
         // constraint rows s_k [Ad(c0<-g) X_k] (constraints.py:429-433, 203-207, 46-48): rows of J' in JR, columns of J'^T in Z
         if (do_con) for (int e = tid; e < ndol * n; e += WIDE_THREADS) {
@@ -489,13 +511,21 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             for (int c = tid; c < nact; c += WIDE_THREADS) TROW[c] = (c <= j || c >= n) ? Z[j * ld + c] * ip : 0.;
             for (int r = tid; r < n; r += WIDE_THREADS) FCOL[r] = (r == j) ? 0. : Z[r * ld + j];
             __syncthreads();
-            const int ncj = (j + 1) + (nact - n);                    // live columns: 0 .. j and n .. nact - 1
-            for (int e = tid; e < n * ncj; e += WIDE_THREADS) {
-                const int r = e / ncj, cc = e - r * ncj, c = cc <= j ? cc : n + (cc - j - 1);
-                if (r == j) Z[r * ld + c] = TROW[c];
-                else {
-                    const double f = FCOL[r];
-                    if (f != 0.) Z[r * ld + c] -= f * TROW[c];
+            // live columns: 0 .. j and n .. nact - 1 (TROW is zero in between), compacted; lane = live column x row stride: the
+            // column lanes are the next power of two of the live count (a shift and a mask per lane and pivot, no division per entry)
+            const int ncj = (j + 1) + (nact - n);
+            int sh = 0;
+            while ((1 << sh) < ncj && sh < 8) ++sh;
+            const int cwj = 1 << sh, clj = tid & (cwj - 1), r0j = tid >> sh, rsj = WIDE_THREADS >> sh;
+            for (int cc = clj; cc < ncj; cc += cwj) {
+                const int c = cc <= j ? cc : n + (cc - j - 1);
+                const double t = TROW[c];
+                for (int r = r0j; r < n; r += rsj) {
+                    if (r == j) Z[r * ld + c] = t;
+                    else {
+                        const double f = FCOL[r];
+                        if (f != 0.) Z[r * ld + c] -= f * t;
+                    }
                 }
             }
             __syncthreads();
@@ -538,19 +568,26 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             if (tid < WAVE) {
                 for (int c = tid; c < nc; c += WAVE) {
                     const double *cd = CD + WIDE_CD * c;
-                    double *g = GSC + 44 * c;
+                    double *g = GSC + 52 * c;
                     for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2) g[4 * i + j2] = AM[(4 * c + i) * ndol + 4 * c + j2];
                     for (int i = 0; i < 16; ++i) g[16 + i] = cd[24 + i];
                     g[32] = cd[15]; g[33] = M.cmu[c]; g[34] = M.ceps[3 * c]; g[35] = M.ceps[3 * c + 1]; g[36] = M.ceps[3 * c + 2];
                     g[37] = cd[12] * inv_dt; g[38] = cd[13] * inv_dt; g[39] = cd[14] * inv_dt; g[40] = cd[17]; g[41] = cd[18];
                     g[42] = (double)M.ctype[c]; g[43] = cd[16];
+                    // per-step constants of the sliding solve (admittance-only part of the sextic) and the warm start of its root
+                    // finder, as the wavefront kernels keep them per contact (arb_gs_stage.h): [44..49] SlidePre, [50] last root
+                    if (cd[16] != 0. && M.ctype[c] == ARB_CT_SOFTFINGER) {
+                        const SlidePre sp = slide_precompute<double>(g);
+                        g[44] = sp.tr; g[45] = sp.m2; g[46] = sp.det; g[47] = sp.sQ; g[48] = sp.sA; g[49] = sp.nq;
+                    }
+                    g[50] = NAN;
                 }
                 for (int r = tid; r < ndol; r += WAVE) { GVV[r] = VV[r]; GFF[r] = FF[r]; }
                 WAVE_SYNC();
                 for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
                     if (tid == 0) DF[4] = 0.;                                    // "something changed in this sweep"
                     for (int c = 0; c < nc; ++c) {
-                        const double *g = GSC + 44 * c;
+                        const double *g = GSC + 52 * c;
                         if (g[43] == 0.) continue;                               // (the same value for every lane)
                         if (tid == 0) {
                             const int ct = (int)g[42];
@@ -558,7 +595,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                             for (int i = 0; i < 4; ++i) { v[i] = GVV[4 * c + i]; f[i] = f_old[i] = GFF[4 * c + i]; }
                             if (ct == ARB_CT_SOFTFINGER) {                       // constraints.py:780-836
                                 const double eps[3] = {g[34], g[35], g[36]};
-                                (void)softfinger_solve<double>(v, g, g + 16, f, df, g[32], dt, g[33], eps, SWORK);
+                                double *gm = GSC + 52 * c;
+                                const SlidePre sp = {gm[44], gm[45], gm[46], gm[47], gm[48], gm[49]};
+                                double alpha[4], shift = 0., warm = gm[50];
+                                int br = softfinger_try<double>(v, g, g + 16, f, df, g[32], dt, g[33], eps, SWORK, alpha, &shift, true, &sp, &warm);
+                                if (br == 3) { shift = slide_shift_from_eig<double>(SWORK); br = 2; warm = NAN; }
+                                if (br == 2) softfinger_slide_finish<double>(g, alpha, eps, shift, f, df);
+                                if (br == 2) gm[50] = warm;          // (the next sweep restarts next to this root)
                             } else if (ct == ARB_CT_BALLSOCKET) {                // constraints.py:235-237
                                 const double *P = g + 16;
                                 for (int i = 0; i < 3; ++i) {
@@ -605,15 +648,6 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 if (io.c_sdist != nullptr) io.c_sdist[w * nc + c] = do_con ? (T)CD[WIDE_CD * c + 15] : T(0);
                 if (io.c_active != nullptr) io.c_active[w * nc + c] = (do_con && CD[WIDE_CD * c + 16] != 0.) ? 1 : 0;
             }
-            if (io.pose != nullptr) for (int b = tid; b < nb; b += WIDE_THREADS) {
-                T *o = io.pose + (w * nb + b) * 16;
-                for (int i = 0; i < 3; ++i) {
-                    for (int j = 0; j < 3; ++j) o[4 * i + j] = (T)POSE[12 * b + 3 * i + j];
-                    o[4 * i + 3] = (T)POSE[12 * b + 9 + i];
-                }
-                o[12] = o[13] = o[14] = T(0); o[15] = T(1);
-            }
-            if (io.twist != nullptr) for (int i = tid; i < 6 * nb; i += WIDE_THREADS) io.twist[w * nb * 6 + i] = (T)TW[i];
         }
         for (int i = tid; i < n; i += WIDE_THREADS) {
             double vnew = Z[i * ld + n];

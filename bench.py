@@ -600,7 +600,7 @@ def main():
                 res["roofline"]["traffic"] = (pm["FETCH_SIZE"]["mean_per_launch"] + pm["WRITE_SIZE"]["mean_per_launch"]) * 1024.
                 # hand-overs of a world's state between wavefronts in the work queue (csrc launch_one: ARB_QUEUE_CHUNK /
                 # ARB_QUEUE_TAIL defaults 4 / 4): chunks of 4 steps, then the last 4 steps one by one
-                chunk_, tail_ = 4, min(4, EP - 1)          # (the library's work-item sizes: csrc Knobs)
+                chunk_, tail_ = 4, min(6, EP - 1)          # (the library's work-item sizes: csrc Knobs)
                 items_ = (-(-(EP - tail_) // chunk_) + tail_) if chunk_ > 0 else 1
                 handover = items_ * bytes_per_world_step * B
                 res["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "

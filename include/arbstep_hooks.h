@@ -53,7 +53,7 @@ int arb_build_variants(void);
  * -DARB_DEVELOPMENT reads ARB_<NAME IN CAPITALS> once at arb_model_create and calls this).  Names and defaults:
  *   "queue_spin_cap" (1 << 24)  polls after which a wavefront gives up waiting for a chunk of the work queue; negative:
  *                               every wait of a later chunk expires at once -- the fault injection of the ARB_ERR_STALLED tests
- *   "queue_chunk" (4), "queue_tail" (4)  steps per work item, single-step items at the end of an episode (0 chunk: no queue)
+ *   "queue_chunk" (4), "queue_tail" (6)  steps per work item, single-step items at the end of an episode (0 chunk: no queue)
  *   "lds_pad" (0)               bytes of dynamic LDS added to every step-kernel workgroup (occupancy experiments)
  *   "force_waves" (0)           2 | 3: pin the float32 build whatever the flags say
  *   "gsw_waves" (3)             the split execution's sweep kernel: 3 | 4 waves per SIMD
