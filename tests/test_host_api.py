@@ -167,9 +167,49 @@ def test_user_plugins_are_rejected_clearly():
     with pytest.raises(UnsupportedModelError):
         flatten_world(w)
     w = core.simplearm()
-    w.register(MyController())
-    with pytest.raises(UnsupportedModelError):
+    ctrl = MyController()
+    w.register(ctrl)
+    with pytest.raises(UnsupportedModelError, match="ext_impedance"):
         flatten_world(w)
+    # (round 6) ... unless the caller takes the user-defined controllers over: the object API polls them on the host every step
+    # and feeds what they return to the device (core.py:814-817; _engine.py)
+    w.init()
+    host = []
+    m, q, dq = flatten_world(w, host_controllers=host)
+    assert host == [ctrl] and m.ndof == 3 and not m.has_pd
+
+
+def test_model_signature_caches_everything_but_the_state():
+    """The object API flattens a world once per change of anything `flatten_world` reads except the state (round 6;
+    `_engine.model_signature`): stepping (new joint positions / velocities, new constraint forces) keeps the signature,
+    a disabled constraint, a new PD target, a changed mass or a moved frame does not."""
+    from arboris_python_amd._engine import model_signature
+    from arboris_python_amd.controllers import ProportionalDerivativeController
+    w = scenes.human36_world(4)
+    js = [j for j in w.getjoints() if j.ndof == 1][:2]
+    pd = ProportionalDerivativeController(js, kp=np.eye(2), kd=np.eye(2))
+    w.register(pd)
+    w.init()
+    s0 = model_signature(w)
+    assert model_signature(w) == s0
+    for j in w.iterjoints():                               # the state moves: same model
+        if np.ndim(j.gpos) == 1:
+            j.gpos[:] = j.gpos + 0.1
+    w._gvel[:] = 0.3
+    list(w.iterconstraints())[0]._force = np.ones(4)
+    assert model_signature(w) == s0
+    c0 = list(w.iterconstraints())[0]
+    c0.disable()
+    s1 = model_signature(w)
+    assert s1 != s0
+    c0.enable()
+    assert model_signature(w) == s0
+    pd.gpos_des[0] = 0.5
+    assert model_signature(w) != s0
+    pd.gpos_des[0] = 0.
+    body = list(w.ground.iter_descendant_bodies())[3]
+    body.mass[3, 3] *= 1.5
+    assert model_signature(w) != s0
 
 
 def test_se3_helpers_known_answers():
