@@ -328,3 +328,56 @@ def test_sharded_worlds_two_shards_on_one_device_equal_the_unsharded_launch_bitw
     assert torch.equal(out["cost"], cost["out"].cpu()) and float(out["cost"].min()) > 0.
     assert len({id(st) for st in sw.streams}) == 3
     sw.close(); bw.close()
+
+
+# ---------------------------------------------------------------------------
+# body-space columns as the default: any number of plane / sphere contacts
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("ncon", [1, 2, 3, 5, 7])
+def test_body_space_columns_by_default_for_any_number_of_contacts(ncon):
+    """Since round 6 every model of the class (enabled plane / sphere SoftFingerContacts only, no PD controller, no viscosity,
+    one small tree) runs body-space constraint columns by default -- not only the 4- and 8-contact models of the benchmark:
+    human36 with the first `ncon` of its eight foot points, float64 against the oracle (1e-8) over a short drop, the default
+    against the classical columns (equal to rounding), float32 through `assert_f32_parity`."""
+    from conftest import assert_f32_parity
+    from arboris_python_amd.core import World
+    from arboris_python_amd.robots.human36 import add_human36
+    from arboris_python_amd.robots.simpleshapes import add_groundplane
+    from arboris_python_amd.controllers import WeightController
+    from arboris_python_amd.constraints import get_all_contacts
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    from arboris_python_amd import synth
+    w = World()
+    add_groundplane(w); add_human36(w); w.register(WeightController())
+    for i, c in enumerate(get_all_contacts(w, friction_coeff=.6)):
+        if i < ncon:
+            w.register(c)
+    w.init()
+    m, _, _ = flatten_world(w)
+    assert m.nc == ncon
+    bw = BatchedWorlds(m)
+    assert bw.plan(512, 8, dtype=torch.float64)["feat"] & 16 and bw.plan(8192, 40)["feat"] & 16
+    assert not (bw.plan(8192, 40, classic_columns=True)["feat"] & 16)
+    B, dt = 96, 5e-3
+    q, dq = synth.standing_states(m, B, seed=60 + ncon, drop=0.01, vel=0.3)
+    q[:, 7] -= 0.004
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    cq, cdq = bw.to_device(q, dq, torch.float64)
+    cf, ccf = bw.new_cforce(B, torch.float64), bw.new_cforce(B, torch.float64)
+    oq, odq, ocf = q, dq, None
+    for k in range(5):
+        bw.step(tq, tdq, dt, 1, cforce=cf)
+        bw.step(cq, cdq, dt, 1, cforce=ccf, classic_columns=True)
+        oq, odq, ocf = O.step(m, oq, odq, dt, cforce=ocf)
+    torch.cuda.synchronize()
+    assert _rel(tq.cpu().numpy(), oq).max() < 1e-8 and _rel(tdq.cpu().numpy(), odq).max() < 1e-7
+    assert _rel(cq.cpu().numpy(), oq).max() < 1e-8 and _rel(cdq.cpu().numpy(), odq).max() < 1e-7
+    assert float(cf.abs().max()) > 10.
+    f32 = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    sq, sdq = bw.to_device(q, dq, torch.float32)
+    bw.step(sq, sdq, dt, 1, cforce=bw.new_cforce(B, torch.float32))
+    torch.cuda.synchronize()
+    rq, rdq, _ = O.step(m, f32(q), f32(dq), dt)
+    assert_f32_parity(m, q, dq, dt, sq.double().cpu().numpy(), sdq.double().cpu().numpy(), rq, rdq)
+    bw.close()
