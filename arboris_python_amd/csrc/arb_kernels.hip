@@ -795,23 +795,28 @@ static int wide_launch(arb_model *M, const WideIO<T> &io, long nw, double dt, co
 
 template <typename T>
 static int wide_step(arb_model *M, void *q, void *dq, void *cf, const void *ext, const void *zimp, long nw, double dt, const double *dts,
-                     int nsteps, unsigned flags, const arb_rollout_log *log, hipStream_t st, long ext_stride) {
+                     int nsteps, unsigned flags, const arb_rollout_log *log, hipStream_t st, long ext_stride,
+                     const void *pd_qdes, const void *pd_dqdes, const void *pd_kp, const void *pd_kd, long pd_stride, const arb_step_cost *cost) {
     WideIO<T> io;
     memset(&io, 0, sizeof(io));
     io.q = (T *)q; io.dq = (T *)dq; io.cf = (T *)cf; io.ext = (const T *)ext; io.zimp = (const T *)zimp; io.ext_stride = ext_stride;
-    if (log) { io.log_q = (T *)log->q_log; io.log_dq = (T *)log->dq_log; }
+    if (log) { io.log_q = (T *)log->q_log; io.log_dq = (T *)log->dq_log; io.log_energy = (T *)log->energy_log; }
+    io.pd_qdes = (const T *)pd_qdes; io.pd_dqdes = (const T *)pd_dqdes; io.pd_kp = (const T *)pd_kp; io.pd_kd = (const T *)pd_kd; io.pd_stride = pd_stride;
+    if (cost) { io.cost_out = (T *)cost->cost_out; io.cost_wq = (const T *)cost->w_q; io.cost_wdq = (const T *)cost->w_dq;
+                io.cost_wtau = (const T *)cost->w_tau; io.cost_qref = (const T *)cost->q_ref; }
     return wide_launch<T>(M, io, nw, dt, dts, nsteps, flags, st);
 }
 
 template <typename T>
 static int wide_inspect(arb_model *M, const void *q, const void *dq, const void *cf, const void *ext, const void *zimp, long nw, double dt,
-                        unsigned flags, const arb_inspect_out *o, hipStream_t st) {
+                        unsigned flags, const arb_inspect_out *o, hipStream_t st, const arb_step_args *a) {
     // what the wide kernel does not form: the per-solve diagnostics of the wavefront kernels, the energies
     if (o->gs_stats || o->gs_trace || o->stamps || o->energy || o->pivot_growth) return ARB_ERR_UNSUPPORTED;
     WideIO<T> io;
     memset(&io, 0, sizeof(io));
     io.q = (T *)q; io.dq = (T *)dq; io.cf = (T *)cf; io.ext = (const T *)ext; io.zimp = (const T *)zimp;
     io.inspect = 1;
+    if (a != nullptr) { io.pd_qdes = (const T *)a->pd_qdes; io.pd_dqdes = (const T *)a->pd_dqdes; io.pd_kp = (const T *)a->pd_kp; io.pd_kd = (const T *)a->pd_kd; }
     // the three world matrices: one pass each, like the wavefront kernels (core.py:722-734)
     struct { void *ptr; int zmode; } passes[3] = {{o->M, 1}, {o->B, 2}, {o->N, 3}};
     for (auto &ps : passes) {
@@ -1303,7 +1308,12 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
     // targets without gains use the model's gain matrices, so the model must hold a PD controller
     if ((pd_qdes == nullptr) != (pd_dqdes == nullptr) || (pd_kp == nullptr) != (pd_kd == nullptr)) return ARB_ERR_INVALID;
     if (pd_kp != nullptr && pd_qdes == nullptr) return ARB_ERR_INVALID;
-    if (pd_qdes != nullptr && pd_kp == nullptr && !M->df.has_pd) return ARB_ERR_INVALID;
+#if ARB_WITH_WIDE
+    const bool model_has_pd = M->is_wide ? (M->wide.has_pd != 0) : (M->df.has_pd != 0);
+#else
+    const bool model_has_pd = M->df.has_pd != 0;
+#endif
+    if (pd_qdes != nullptr && pd_kp == nullptr && !model_has_pd) return ARB_ERR_INVALID;
     if (cost != nullptr && cost->cost_out == nullptr) return ARB_ERR_INVALID;
     if (nworlds == 0 || nsteps == 0) return ARB_OK;     // empty batch: nothing to do (pointers may be null)
     if (!q || !dq) return ARB_ERR_INVALID;
@@ -1313,11 +1323,12 @@ static int step_impl(arb_model *M, int dtype, void *q, void *dq, void *cforce, c
 #if ARB_WITH_WIDE
     if (M->is_wide) {
         // (the wide kernel: float64 arithmetic for either buffer type; see arb_wide_kernel.h for what it takes)
-        if (pd_qdes != nullptr || pd_kp != nullptr || cost != nullptr || (log && log->energy_log) ||
-            (flags & (ARB_STEP_SPLIT_WAVE | ARB_STEP_MFMA_ELIM)) || pd_stride != 0) return ARB_ERR_UNSUPPORTED;
+        if ((flags & (ARB_STEP_SPLIT_WAVE | ARB_STEP_MFMA_ELIM)) && !(flags & ARB_STEP_FUSED)) return ARB_ERR_UNSUPPORTED;
         hipStream_t sw = reinterpret_cast<hipStream_t>(stream);
-        return dtype == ARB_F32 ? wide_step<float>(M, q, dq, cforce, ext_gforce, ext_imp, (long)nworlds, dt, dt_steps, nsteps, flags, log, sw, ext_stride)
-                                : wide_step<double>(M, q, dq, cforce, ext_gforce, ext_imp, (long)nworlds, dt, dt_steps, nsteps, flags, log, sw, ext_stride);
+        return dtype == ARB_F32 ? wide_step<float>(M, q, dq, cforce, ext_gforce, ext_imp, (long)nworlds, dt, dt_steps, nsteps, flags, log, sw, ext_stride,
+                                                   pd_qdes, pd_dqdes, pd_kp, pd_kd, pd_stride, cost)
+                                : wide_step<double>(M, q, dq, cforce, ext_gforce, ext_imp, (long)nworlds, dt, dt_steps, nsteps, flags, log, sw, ext_stride,
+                                                    pd_qdes, pd_dqdes, pd_kp, pd_kd, pd_stride, cost);
     }
 #endif
     // (a dense per-world impedance couples any pair of dofs: the copies of a forest would no longer be independent blocks)
@@ -1498,10 +1509,9 @@ static int inspect_impl(arb_model *M, int dtype, const void *q, const void *dq, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #if ARB_WITH_WIDE
     if (M->is_wide) {
-        if (a != nullptr && (a->pd_qdes || a->pd_kp)) return ARB_ERR_UNSUPPORTED;
         const void *zi = a ? a->ext_impedance : nullptr;
-        return dtype == ARB_F32 ? wide_inspect<float>(M, q, dq, cforce, ext_gforce, zi, (long)nworlds, dt, flags, out, st)
-                                : wide_inspect<double>(M, q, dq, cforce, ext_gforce, zi, (long)nworlds, dt, flags, out, st);
+        return dtype == ARB_F32 ? wide_inspect<float>(M, q, dq, cforce, ext_gforce, zi, (long)nworlds, dt, flags, out, st, a)
+                                : wide_inspect<double>(M, q, dq, cforce, ext_gforce, zi, (long)nworlds, dt, flags, out, st, a);
     }
 #endif
     if (dtype == ARB_F32)
@@ -1522,7 +1532,12 @@ extern "C" int arb_inspect_ex(arb_model *M, int dtype, const arb_step_args *a, c
     if (a->ext_gforce_steps || a->pd_qdes_steps || a->pd_dqdes_steps || a->cost || a->log || a->dt_steps) return ARB_ERR_INVALID;
     if ((a->pd_qdes == nullptr) != (a->pd_dqdes == nullptr) || (a->pd_kp == nullptr) != (a->pd_kd == nullptr)) return ARB_ERR_INVALID;
     if (a->pd_kp != nullptr && a->pd_qdes == nullptr) return ARB_ERR_INVALID;
-    if (a->pd_qdes != nullptr && a->pd_kp == nullptr && !M->df.has_pd) return ARB_ERR_INVALID;
+#if ARB_WITH_WIDE
+    const bool model_has_pd = M->is_wide ? (M->wide.has_pd != 0) : (M->df.has_pd != 0);
+#else
+    const bool model_has_pd = M->df.has_pd != 0;
+#endif
+    if (a->pd_qdes != nullptr && a->pd_kp == nullptr && !model_has_pd) return ARB_ERR_INVALID;
     return inspect_impl(M, dtype, a->q, a->dq, a->cforce, a->ext_gforce, a->nworlds, a->dt, a->flags, out, stream, a);
 }
 

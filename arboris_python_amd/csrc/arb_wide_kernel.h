@@ -12,9 +12,10 @@
 //     and column of the elimination;
 //   * lane = body / dof / constraint / matrix entry as the phase needs, __syncthreads() between phases;
 //   * workgroups loop over the worlds of the batch (grid = min(worlds, 2 per CU)), steps loop inside.
-// Limits: ndof, nb <= ARB_WIDE_MAX (256), nc <= 64.  Supported inputs: state, constraint forces, user torques (constant or a
-// sequence), the dense impedance of user-defined controllers, per-step dt, state logs; the model's merged PD controllers.
-// Not supported (ARB_ERR_UNSUPPORTED): per-world PD inputs, energy logs, running costs, the split execution.
+// Limits: ndof, nb <= ARB_WIDE_MAX (256), nc <= 64.  Inputs: everything arb_step_ex takes -- state, constraint forces, user
+// torques (constant or a sequence), the dense impedance of user-defined controllers, per-world PD targets / gains (and target
+// sequences), per-step dt, state and energy logs, the running cost; the model's merged PD controllers.
+// Not supported (ARB_ERR_UNSUPPORTED): the execution variants of the wavefront kernels (split sweeps, matrix-core elimination).
 #ifndef ARB_WIDE_KERNEL_H
 #define ARB_WIDE_KERNEL_H
 #define WIDE_THREADS 256
@@ -41,6 +42,14 @@ struct WideIO {
     const T *ext, *zimp;
     long ext_stride;
     T *log_q, *log_dq;                                      // [nsteps][nw][nq], [nsteps][nw][n] or null
+    T *log_energy;                                          // [nsteps][nw][2] kinetic, potential (observers.py:40-51) or null
+    // one ProportionalDerivativeController per world (controllers.py:63-158): targets [nw][n] (pd_stride: a sequence, one row
+    // per step) with the model's gain matrices, or with per-world DIAGONAL gains kp / kd [nw][n] that replace them
+    const T *pd_qdes, *pd_dqdes, *pd_kp, *pd_kd;
+    long pd_stride;
+    // running cost of the rollout (arb_step_cost): out[w] += sum_i wq (qj - qref)^2 + wdq dq^2 + wtau tau^2 after every step
+    T *cost_out;
+    const T *cost_wq, *cost_wdq, *cost_wtau, *cost_qref;
     // inspect outputs (any may be null; one step, the state buffers are not written when `inspect` is set)
     int inspect;
     int zmode;                                              // inspect: what Zout receives -- 0 Z, 1 M, 2 B, 3 N (core.py:722-734)
@@ -200,6 +209,32 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 o[12] = o[13] = o[14] = T(0); o[15] = T(1);
             }
             if (io.twist != nullptr) for (int i = tid; i < 6 * nb; i += WIDE_THREADS) io.twist[w * nb * 6 + i] = (T)TW[i];
+        }
+        // energies as an observer sees them at the beginning of the step (EnergyMonitor.update, observers.py:40-51)
+        if (io.log_energy != nullptr) {
+            double ke = 0., pe = 0.;
+            for (int b = tid; b < nb; b += WIDE_THREADS) {
+                const double *Mb = M.mass + 36 * b;
+                double tw[6], mt[6];
+                for (int i = 0; i < 6; ++i) tw[i] = TW[6 * b + i];
+                mat6_vec<double>(Mb, tw, mt);
+                for (int i = 0; i < 6; ++i) ke += 0.5 * tw[i] * mt[i];
+                const double mass_b = Mb[35];
+                if (mass_b > 0.) {
+                    const V3<double> cm = v3<double>(Mb[6 * 2 + 4] / mass_b, Mb[6 * 0 + 5] / mass_b, Mb[6 * 1 + 3] / mass_b);
+                    const V3<double> cg = mv(ldm(POSE + 12 * b), cm) + ld3(POSE + 12 * b + 9);
+                    pe += 9.81 * Mb[21] * (M.up[0] * cg.x + M.up[1] * cg.y + M.up[2] * cg.z);
+                }
+            }
+            for (int off = 32; off >= 1; off >>= 1) { ke += __shfl_xor(ke, off); pe += __shfl_xor(pe, off); }
+            __syncthreads();
+            if ((tid & 63) == 0) { TROW[2 * (tid >> 6)] = ke; TROW[2 * (tid >> 6) + 1] = pe; }
+            __syncthreads();
+            if (tid == 0) {
+                T *o = io.log_energy + ((long)step * nworlds + w) * 2;
+                o[0] = (T)(TROW[0] + TROW[2] + TROW[4] + TROW[6]); o[1] = (T)(TROW[1] + TROW[3] + TROW[5] + TROW[7]);
+            }
+            __syncthreads();
         }
         // body wrench of the increment form: M_b g_b - M_b (dJ_b gvel) - N_b T_b - B_b T_b   (core.py:975-976, 1276-1288)
         for (int b = tid; b < nb; b += WIDE_THREADS) {
@@ -438,7 +473,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     for (int r = 0; r < 6; ++r) v += xi[12 + r] * xc[r] + xi[18 + r] * xc[6 + r];
                 }
                 if (io.zmode == 0) {
-                    if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];          // controllers.py:141-158
+                    if (io.pd_kp != nullptr) { if (i == c) v += dt * (double)io.pd_kp[w * n + i] + (double)io.pd_kd[w * n + i]; }
+                    else if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];     // controllers.py:141-158
                     if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];  // core.py:815-817
                 }
             }
@@ -480,11 +516,18 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             double ext = 0.;
             if (io.ext != nullptr) ext = (double)io.ext[(long)step * io.ext_stride + w * n + i];
             double rhs = RH[i] + ext, gf0 = RH[n + i] + ext;
-            if (M.has_pd) {
-                double acc = M.pd_tau0[i], accv = 0.;
+            const long pdo = (long)step * io.pd_stride + w * n;       // (this step's PD targets)
+            if (io.pd_kp != nullptr) {             // per-world diagonal gains and targets: tau0 = kp (qdes - q) + kd dqdes, Z += dt kp + kd
+                const double kp = (double)io.pd_kp[w * n + i], kd = (double)io.pd_kd[w * n + i];
+                const double acc = kp * ((double)io.pd_qdes[pdo + i] - QD[i]) + kd * (double)io.pd_dqdes[pdo + i];
+                rhs += acc - (dt * kp + kd) * DQS[i]; gf0 += acc;
+            } else if (M.has_pd) {
+                double acc = io.pd_qdes != nullptr ? 0. : M.pd_tau0[i], accv = 0.;
                 for (int j = 0; j < n; ++j) {
                     const double kp = M.pd_kp[i * n + j], kd = M.pd_kd[i * n + j];
-                    acc -= kp * QD[j];
+                    if (io.pd_qdes != nullptr) {
+                        if (kp != 0. || kd != 0.) acc += kp * ((double)io.pd_qdes[pdo + j] - QD[j]) + kd * (double)io.pd_dqdes[pdo + j];
+                    } else acc -= kp * QD[j];
                     accv += (dt * kp + kd) * DQS[j];
                 }
                 rhs += acc - accv; gf0 += acc;
@@ -662,6 +705,22 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             if (qi >= 0) QS[qi] += dt * vnew;                                   // core.py:238-240
         }
         __syncthreads();
+        if (io.cost_out != nullptr) {              // running cost on the state after this step, this step's torques
+            double c = 0.;
+            for (int i = tid; i < n; i += WIDE_THREADS) {
+                const int qi = M.dof2q[i];
+                const double dd = (qi >= 0 ? QS[qi] : 0.) - (io.cost_qref != nullptr ? (double)io.cost_qref[i] : 0.);
+                const double vv = DQS[i];
+                const double tau = io.ext != nullptr ? (double)io.ext[(long)step * io.ext_stride + w * n + i] : 0.;
+                c += (io.cost_wq != nullptr ? (double)io.cost_wq[i] : 0.) * dd * dd + (io.cost_wdq != nullptr ? (double)io.cost_wdq[i] : 0.) * vv * vv
+                   + (io.cost_wtau != nullptr ? (double)io.cost_wtau[i] : 0.) * tau * tau;
+            }
+            for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+            if ((tid & 63) == 0) FCOL[tid >> 6] = c;
+            __syncthreads();
+            if (tid == 0) io.cost_out[w] = (T)((double)io.cost_out[w] + ((FCOL[0] + FCOL[1]) + (FCOL[2] + FCOL[3])));
+            __syncthreads();
+        }
         for (int b = tid; b < nb; b += WIDE_THREADS) {
             if (M.jtype[b] != JT_FREE) continue;
             double *qp = QS + M.q_off[b];

@@ -261,7 +261,10 @@ typedef struct arb_model_info {
     int32_t mixed_default;    /* (ABI 8) what float32 launches of this model run by default: 0 the float32 kernels, 1 the mixed
                                  build, 2 promotion to the float64 kernels (see ARB_STEP_MIXED) */
     int32_t wide;             /* (ABI 8) 1: more than 64 dofs / bodies / 16 constraints: one WORKGROUP per world (the wide kernels,
-                                 float64 arithmetic whatever the buffers' type); nmax, nsets and the LDS sizes then describe them */
+                                 float64 arithmetic whatever the buffers' type); nmax, nsets and the LDS sizes then describe them.
+                                 They take every input of arb_step_ex and arb_inspect; ARB_STEP_SPLIT_WAVE / ARB_STEP_MFMA_ELIM and
+                                 the per-solve diagnostics of arb_inspect (gs_stats, gs_trace, stamps, pivot_growth, energy) are
+                                 ARB_ERR_UNSUPPORTED there */
     float rest_pivot_growth;  /* (ABI 8) pivot growth of the float32 elimination at the model's rest state (see ARB_WARN_ILLCOND) */
 } arb_model_info;
 

@@ -152,9 +152,9 @@ def test_human36_beside_four_free_objects_66_dofs():
     for t in range(4):
         oq, odq, ocf = O.step(m, oq, odq, dt, cforce=ocf, ext_gforce=tau[t], ext_impedance=za)
     assert _rel(sq.cpu().numpy(), oq).max() < 1e-7 and _rel(sdq.cpu().numpy(), odq).max() < 1e-6
-    # what the wide kernels do not take is refused, not ignored
+    # what the wide kernels do not take is refused, not ignored: the execution variants of the wavefront kernels, their diagnostics
     with pytest.raises(_capi.ArbError):
-        bw.step(sq, sdq, dt, 1, cforce=scf, pd_targets=(torch.zeros_like(sdq), torch.zeros_like(sdq)), pd_gains=(torch.ones_like(sdq), torch.ones_like(sdq)))
+        bw.step(sq, sdq, dt, 1, cforce=scf, split="wave")
     with pytest.raises(_capi.ArbError):
         bw.inspect(sq, sdq, dt, ["gs_stats"])
     bw.close()
@@ -206,3 +206,50 @@ def test_object_api_simulates_a_wide_world():
         qd = np.concatenate([np.asarray(j.gpos, float).ravel() for j in w.iterjoints()])
         assert _rel(qd, oq[0]) < 1e-9 and _rel(w.gvel, odq[0]) < 1e-8, k
     assert w._engine.flatten_count == 1
+
+
+def test_wide_worlds_take_every_input_of_arb_step_ex():
+    """Per-world PD targets and diagonal gains (a target SEQUENCE), the running cost with a torque sequence, energy logs: the wide
+    kernels against the oracle (float64) on human36 + 4 objects."""
+    from arboris_python_amd import scenes
+    from arboris_python_amd.flatten import flatten_world, JT_FREE
+    from arboris_python_amd.batch import BatchedWorlds
+    w = scenes.human36_and_objects_world(4)
+    m, q0, dq0 = flatten_world(w)
+    bw = BatchedWorlds(m)
+    B, T, dt = 12, 5, 5e-3
+    rng = np.random.default_rng(8)
+    q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1)) + rng.uniform(-0.2, 0.2, (B, m.ndof))
+    free = np.zeros(m.ndof, bool)
+    for b in range(m.nb):
+        if m.jtype[b] == JT_FREE:
+            free[int(m.dof_off[b]):int(m.dof_off[b]) + 6] = True
+    kp = np.where(free, 0., rng.uniform(5., 30., (B, m.ndof))); kd = np.where(free, 0., rng.uniform(0.5, 2., (B, m.ndof)))
+    qdes = rng.uniform(-0.2, 0.2, (T, B, m.ndof)); dqdes = rng.uniform(-0.1, 0.1, (T, B, m.ndof))
+    tau = rng.uniform(-0.3, 0.3, (T, B, m.ndof)) * ~free
+    host = dict(w_q=rng.uniform(0., 2., m.ndof), w_dq=rng.uniform(0., 0.1, m.ndof), w_tau=rng.uniform(0., 5., m.ndof), q_ref=rng.uniform(-0.2, 0.2, m.ndof))
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=bw.device)
+    cost = {k: dev(v) for k, v in host.items()}
+    cost["out"] = torch.zeros(B, dtype=torch.float64, device=bw.device)
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    cf = bw.new_cforce(B, torch.float64)
+    log = bw.rollout(tq, tdq, dt, T, cforce=cf, ext_gforce=dev(tau), pd_targets=(dev(qdes), dev(dqdes)), pd_gains=(dev(kp), dev(kd)), cost=cost)
+    torch.cuda.synchronize()
+    oq, odq, ocf, ocost = q, dq, None, np.zeros(B)
+    for t in range(T):
+        dyn = O.update_dynamic(m, oq, odq)
+        ke = 0.5 * np.einsum('bi,bij,bj->b', odq, dyn["M"], odq)
+        pe = np.zeros(B)
+        for b in range(m.nb):
+            mb = m.mass[b][5, 5]
+            if mb > 0:
+                c = np.array([m.mass[b][2, 4], m.mass[b][0, 5], m.mass[b][1, 3]]) / mb
+                cg = np.einsum('bij,j->bi', dyn["pose"][:, b, 0:3, 0:3], c) + dyn["pose"][:, b, 0:3, 3]
+                pe += 9.81 * m.mass[b][3, 3] * (cg @ m.up)
+        e = log["energy"][t].cpu().numpy()
+        assert np.abs(e[:, 0] - ke).max() <= 1e-10 * max(1., np.abs(ke).max()) and np.abs(e[:, 1] - pe).max() <= 1e-10 * np.abs(pe).max(), t
+        oq, odq, ocf = O.step(m, oq, odq, dt, cforce=ocf, ext_gforce=tau[t], pd=dict(qdes=qdes[t], dqdes=dqdes[t], kp=kp, kd=kd))
+        ocost += O.stage_cost(m, oq, odq, tau[t], **host)
+    assert _rel(tq.cpu().numpy(), oq).max() < 1e-8 and _rel(tdq.cpu().numpy(), odq).max() < 1e-7
+    assert np.abs(cost["out"].cpu().numpy() - ocost).max() <= 1e-10 * np.abs(ocost).max()
+    bw.close()
