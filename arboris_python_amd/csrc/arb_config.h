@@ -63,6 +63,25 @@
 #ifndef ARB_ROWS_SPLIT
 #define ARB_ROWS_SPLIT 1
 #endif
+// s_setprio level of a wave per phase (round 6).  The sweeps have run at 2 since round 3 (ARB_GS_PRIO: +5 %): a wave whose next
+// instructions are one dependent chain should issue ahead of a wave with independent work to fill the gaps.  Phase C -- 42 pivots
+// in sequence -- at 1: +0.4 % alone, +0.9 % together with 22-row groups (same-process A/B, bit-identical).
+#ifndef ARB_C_PRIO
+#define ARB_C_PRIO 1
+#endif
+#ifndef ARB_A_PRIO
+#define ARB_A_PRIO 0
+#endif
+#ifndef ARB_B_PRIO
+#define ARB_B_PRIO 0
+#endif
+#ifndef ARB_D_PRIO
+#define ARB_D_PRIO 1            // (phase D, the constraint-space products and the T Y_b T^T passes: +0.25 % on top; A or B at 1: -0.2 %)
+#endif
+#define ARB_ANY_PRIO (ARB_A_PRIO | ARB_B_PRIO | ARB_C_PRIO | ARB_D_PRIO)
+#ifndef ARB_ELIM_GB_BIG
+#define ARB_ELIM_GB_BIG 22      // rows per skippable group of the unrolled elimination on the 44- and 48-row tiles (8 until round 5:
+#endif                          // with 22 a pivot tests two or three groups instead of six; the small tiles -- forests -- keep 8)
 #ifndef ARB_GS_PRIO
 #define ARB_GS_PRIO 2           // s_setprio level of a wave during its Gauss-Seidel sweeps (0: unchanged; 2 measured +5 %, 3 the same)
 #endif

@@ -3,6 +3,9 @@
         // ================= phase A: lane = body ===========================
         ARB_OPAQUE_LANE();
         ARB_STAMP(0);
+#if ARB_ANY_PRIO
+        __builtin_amdgcn_s_setprio(ARB_A_PRIO);
+#endif
         if (FEAT_ALL && dts != nullptr) { dt = (T)dts[step]; inv_dt = T(1) / dt; }
         // (forests are built on the 16- and 32-row tiles only: the larger kernels carry none of this)
         const int fk = (NMAX > 32) ? 1 : ARB_UNI(mp->fk);

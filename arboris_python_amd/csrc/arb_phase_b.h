@@ -3,6 +3,9 @@
         // ================= phase B: lane = dof column =======================
         ARB_OPAQUE_LANE();
         ARB_STAMP(2);
+#if ARB_ANY_PRIO
+        __builtin_amdgcn_s_setprio(ARB_B_PRIO);
+#endif
         // (ZT: the arithmetic type of the register tile -- T, or float64 for float32 worlds in the ARB_ELIM_F64 experiment)
         // (CM 3: the mixed build of round 6 -- the same mechanism as a production kernel for every tile)
         constexpr bool ELIM64 = CM == 3 || ((ARB_ELIM_F64 != 0) && std::is_same<T, float>::value && NMAX <= 48 && CM != 1);

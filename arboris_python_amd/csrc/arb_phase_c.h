@@ -59,6 +59,9 @@
                 }
             }
         }
+#if ARB_ANY_PRIO
+        __builtin_amdgcn_s_setprio(ARB_C_PRIO);
+#endif
         // Pivots are taken from the last dof to the first (extremities before the
         // root): on these graded, nearly-SPD matrices that order halves the float32
         // error of pivot-free elimination (measured).
@@ -166,7 +169,7 @@
                     if (NSETS == 2) t2 = Z2[j] * ip;
                     const unsigned long long rel = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)rel_hi, j) << 32)
                                                  | (unsigned)__builtin_amdgcn_readlane((int)rel_lo, j);
-                    constexpr int GB = ARB_ELIM_GB;
+                    constexpr int GB = NMAX >= 44 ? ARB_ELIM_GB_BIG : ARB_ELIM_GB;
 #pragma unroll
                     for (int g = 0; g < (NMAX + GB - 1) / GB; ++g) {
                         if (((rel >> (GB * g)) & ((1ull << GB) - 1ull)) == 0ull) continue;
@@ -260,6 +263,9 @@
         }
         }
         ARB_CSTAMP(5);
+#if ARB_ANY_PRIO
+        __builtin_amdgcn_s_setprio(ARB_D_PRIO);
+#endif
         if constexpr (TRACK_GROWTH) {
             if (sizeof(T) == 4 && MODE == 0) warn_illcond = warn_illcond || (growth_bits > (11 << 23));      // ARB_ILLCOND_GROWTH = 2^11
             if (MODE == 1 && dbg.pivot_growth != nullptr && lane == 0)
