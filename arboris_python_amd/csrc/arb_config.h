@@ -78,7 +78,13 @@
 #ifndef ARB_D_PRIO
 #define ARB_D_PRIO 1            // (phase D, the constraint-space products and the T Y_b T^T passes: +0.25 % on top; A or B at 1: -0.2 %)
 #endif
-#define ARB_ANY_PRIO (ARB_A_PRIO | ARB_B_PRIO | ARB_C_PRIO | ARB_D_PRIO)
+#ifndef ARB_ALVL_PRIO
+#define ARB_ALVL_PRIO 0         // (the level loop of phase A alone)
+#endif
+#ifndef ARB_E_PRIO
+#define ARB_E_PRIO 0
+#endif
+#define ARB_ANY_PRIO (ARB_A_PRIO | ARB_B_PRIO | ARB_C_PRIO | ARB_D_PRIO | ARB_ALVL_PRIO | ARB_E_PRIO)
 #ifndef ARB_ELIM_GB_BIG
 #define ARB_ELIM_GB_BIG 22      // rows per skippable group of the unrolled elimination on the 44- and 48-row tiles (8 until round 5:
 #endif                          // with 22 a pivot tests two or three groups instead of six; the small tiles -- forests -- keep 8)

@@ -259,6 +259,9 @@
                 }
             }
             // pose and twist down the tree, one depth level at a time
+#if ARB_ALVL_PRIO
+            __builtin_amdgcn_s_setprio(ARB_ALVL_PRIO);
+#endif
             if (!jumped)
             for (int lvl = 0; lvl <= mp->maxdepth; ++lvl) {
                 // (lane-dense, see ARB_DENSE: every lane goes through the level's arithmetic -- a lane of another level on
@@ -296,6 +299,9 @@
                 WAVE_SYNC();
             }
             ARB_ASTAMP(4);
+#if ARB_ALVL_PRIO
+            __builtin_amdgcn_s_setprio(ARB_A_PRIO);
+#endif
             if (on) {
                 T *bd = BD + b * BDS;
                 const T *Mb = mp->mass + 36 * b;

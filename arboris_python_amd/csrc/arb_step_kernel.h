@@ -388,6 +388,9 @@ __global__ __launch_bounds__(WAVE, ARB_KERNEL_WAVES(T, NMAX, NSETS, MODE, FEAT, 
         // ================= phase E: new velocity, integrate ==================
         ARB_OPAQUE_LANE();
         ARB_STAMP(6);
+#if ARB_ANY_PRIO
+        __builtin_amdgcn_s_setprio(ARB_E_PRIO);
+#endif
         if (MODE == 1) {
             if (dbg.gforce != nullptr && lane < n) {
                 // World._gforce after update_constraints: controllers + sum J_c^T f_c  (core.py:936-937);
