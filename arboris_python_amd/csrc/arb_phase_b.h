@@ -486,12 +486,21 @@
 #pragma unroll
                 for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(Gk[i]), "+v"(Xk[i]), "+v"(dXk[i]));
 #endif
+#ifndef ARB_ROWS_PAIR
+#define ARB_ROWS_PAIR 1          // rows of Z per scheduling fence (round 6, measured on the three-wave build: 2 rows -2.3 % -- 54 more
+                                 // spilled registers --, 4 rows +-0 %; 1 = row by row stays)
+#endif
+                constexpr int RP = (sizeof(T) == 4) ? ARB_ROWS_PAIR : 1;
 #pragma unroll
-                for (int i = 0; i < NMAX; ++i) {
+                for (int i0 = 0; i0 < NMAX; i0 += RP) {
                     // (the wave-uniform branch per row also keeps the rows apart for the scheduler: as one
                     // branch-free block the compiler hoists the LDS reads of all NMAX rows and spills ~1500 VGPRs)
-                    if (i < n) {
-                        asm volatile("");          // not speculatable: a real scalar branch per row, no if-conversion into lane masks
+                    if (i0 < n) {
+                        asm volatile("");          // not speculatable: a real scalar branch per row (pair), no if-conversion into lane masks
+#pragma unroll
+                      for (int i = i0; i < i0 + RP; ++i) {
+                        if (i >= NMAX) continue;
+                        if (i > i0 && !(i < n)) { Z[i] = ZT(0); continue; }
                         const D2 *xi = reinterpret_cast<const D2 *>(STG + XPR_STRIDE * i);   // wave-uniform: broadcast reads
                         double tu = 0., td = 0.;
                         // all nine reads of the row are issued before the first multiply-add (the asm defines the nine values
@@ -527,8 +536,10 @@
                         }
                         const ZT val = (ZT)((i <= e_k) ? tu : td);
                         Z[i] = (((i < 32 ? rel_lo : rel_hi) >> (i & 31)) & 1u) ? val : ZT(0);
+                      }
                     } else {
-                        Z[i] = ZT(0);
+#pragma unroll
+                        for (int i = i0; i < i0 + RP; ++i) if (i < NMAX) Z[i] = ZT(0);
                     }
                 }
             }
