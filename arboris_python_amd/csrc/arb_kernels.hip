@@ -811,7 +811,7 @@ template <typename T>
 static int wide_inspect(arb_model *M, const void *q, const void *dq, const void *cf, const void *ext, const void *zimp, long nw, double dt,
                         unsigned flags, const arb_inspect_out *o, hipStream_t st, const arb_step_args *a) {
     // what the wide kernel does not form: the per-solve diagnostics of the wavefront kernels, the energies
-    if (o->gs_stats || o->gs_trace || o->stamps || o->energy || o->pivot_growth) return ARB_ERR_UNSUPPORTED;
+    if (o->gs_stats || o->gs_trace || o->energy || o->pivot_growth) return ARB_ERR_UNSUPPORTED;
     WideIO<T> io;
     memset(&io, 0, sizeof(io));
     io.q = (T *)q; io.dq = (T *)dq; io.cf = (T *)cf; io.ext = (const T *)ext; io.zimp = (const T *)zimp;
@@ -826,7 +826,7 @@ static int wide_inspect(arb_model *M, const void *q, const void *dq, const void 
         const int rc = wide_launch<T>(M, i1, nw, dt, nullptr, 1, flags | ARB_STEP_SKIP_CONSTRAINTS, st);
         if (rc != ARB_OK) return rc;
     }
-    io.jac = (T *)o->jac; io.djac = (T *)o->djac;
+    io.jac = (T *)o->jac; io.djac = (T *)o->djac; io.stamps = (long long *)o->stamps;
     io.pose = (T *)o->pose; io.twist = (T *)o->twist; io.Zout = (T *)o->Z; io.gforce0 = (T *)o->gforce0; io.vel_free = (T *)o->vel_free;
     io.c_sdist = (T *)o->c_sdist; io.c_active = (int *)o->c_active; io.c_jac = (T *)o->c_jac; io.c_force = (T *)o->c_force;
     io.c_frame = (T *)o->c_frame; io.gforce = (T *)o->gforce; io.q_next = (T *)o->q_next; io.dq_next = (T *)o->dq_next;

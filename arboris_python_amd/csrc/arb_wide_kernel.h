@@ -56,6 +56,7 @@ struct WideIO {
     T *jac, *djac;                                          // [nw][nb][6][n] Body.jacobian / djacobian (core.py:1273-1274)
     T *pose, *twist, *Zout, *gforce0, *vel_free, *c_sdist, *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next, *c_adm, *c_vel;
     int *c_active;
+    long long *stamps;                                      // [nw][8] shader clock at the phase boundaries (diagnostic, inspect)
 };
 
 template <typename T>
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         const double dt = dts != nullptr ? dts[step] : dt_in, inv_dt = 1. / dt;
         if (io.log_q != nullptr) for (int i = tid; i < nq; i += WIDE_THREADS) io.log_q[((long)step * nworlds + w) * nq + i] = (T)QS[i];
         if (io.log_dq != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) io.log_dq[((long)step * nworlds + w) * n + i] = (T)DQS[i];
+        if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 0] = (long long)clock64();
         // ================= phase A: lane = body -- joint-local kinematics (core.py:1294-1315, rigidmotion.py:47-73) ==========
         for (int b = tid; b < nb; b += WIDE_THREADS) {
             const int jt = M.jtype[b], doff = M.dof_off[b], k = M.jnd[b];
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             }
             for (int i = 0; i < 6; ++i) { PT[12 * b + i] = pt[i]; PT[12 * b + 6 + i] = pg6[i]; }
         }
+        if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 1] = (long long)clock64();
         // ================= phase A': lane = constraint (constraints.py:277-294, 35-90, collisions.py) =====================
         if (do_con) for (int c = tid; c < nc; c += WIDE_THREADS) {
             double *cd = CD + WIDE_CD * c;
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         }
         __syncthreads();
         for (int i = tid; i < ndol; i += WIDE_THREADS) FF0[i] = FF[i];
+        if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 2] = (long long)clock64();
         // ================= phase B: composite assembly of Z = M/dt + B + N (core.py:722-734, 813), see arb_phase_b.h =========
         // ---- lane = body: world-frame matrices about the WORLD origin -------------------------------------------------
         for (int b = tid; b < nb; b += WIDE_THREADS) {
@@ -461,6 +465,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             }
         }
         __syncthreads();            // (last reads of the chain arrays: Z takes their LDS space now)
+        if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 3] = (long long)clock64();
         // ---- the augmented system [Z | rhs | J'^T]: lane = entry --------------------------------------------------------
         for (int i = r0_n; i < n; i += rs_n) for (int c = cl_n; c < n; c += cwn) {
             double v = 0.;
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             Z[i * ld + n] = rhs;
         }
         __syncthreads();
+        if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 4] = (long long)clock64();
         // ================= phase C: pivot-free Gauss-Jordan, pivots from the last dof to the first (core.py:818) ==========
         const int nact = do_con ? ncols : n + 1;
         for (int j = n - 1; j >= 0; --j) {
@@ -560,15 +566,25 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             int sh = 0;
             while ((1 << sh) < ncj && sh < 8) ++sh;
             const int cwj = 1 << sh, clj = tid & (cwj - 1), r0j = tid >> sh, rsj = WIDE_THREADS >> sh;
+            // (rows four at a time: the four multipliers and the four entries are loaded before the first is stored -- the loop is
+            // a chain of LDS round trips otherwise, one per entry: 10.9 k cycles per pivot of snake-100, 64 % of its step)
             for (int cc = clj; cc < ncj; cc += cwj) {
                 const int c = cc <= j ? cc : n + (cc - j - 1);
                 const double t = TROW[c];
-                for (int r = r0j; r < n; r += rsj) {
-                    if (r == j) Z[r * ld + c] = t;
-                    else {
-                        const double f = FCOL[r];
-                        if (f != 0.) Z[r * ld + c] -= f * t;
-                    }
+                double *zc = Z + c;
+                int r = r0j;
+                for (; r + 3 * rsj < n; r += 4 * rsj) {
+                    const int r1 = r + rsj, r2 = r + 2 * rsj, r3 = r + 3 * rsj;
+                    const double f0 = FCOL[r], f1 = FCOL[r1], f2 = FCOL[r2], f3 = FCOL[r3];      // (FCOL[j] is 0)
+                    const double z0 = zc[r * ld], z1 = zc[r1 * ld], z2 = zc[r2 * ld], z3 = zc[r3 * ld];
+                    zc[r * ld] = (r == j) ? t : (f0 != 0. ? z0 - f0 * t : z0);
+                    zc[r1 * ld] = (r1 == j) ? t : (f1 != 0. ? z1 - f1 * t : z1);
+                    zc[r2 * ld] = (r2 == j) ? t : (f2 != 0. ? z2 - f2 * t : z2);
+                    zc[r3 * ld] = (r3 == j) ? t : (f3 != 0. ? z3 - f3 * t : z3);
+                }
+                for (; r < n; r += rsj) {
+                    const double f = FCOL[r], z = zc[r * ld];
+                    zc[r * ld] = (r == j) ? t : (f != 0. ? z - f * t : z);
                 }
             }
             __syncthreads();
@@ -577,6 +593,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         for (int i = tid; i < n; i += WIDE_THREADS) Z[i * ld + n] += DQS[i];
         __syncthreads();
         if (io.inspect && io.vel_free != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) io.vel_free[w * n + i] = (T)Z[i * ld + n];
+        if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 5] = (long long)clock64();
         // ================= phase D: [v' | Y'] = J' [Y rhs | Y J'^T] (core.py:925-927), block inverses =========================
         if (do_con) {
             for (int e = tid; e < ndol * (ndol + 1); e += WIDE_THREADS) {
@@ -603,6 +620,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 for (int i = 0; i < 16; ++i) cd[24 + i] = P[i];
             }
             __syncthreads();
+            if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 6] = (long long)clock64();
             // ---- 20 Gauss-Seidel sweeps, constraints in registration order (core.py:929-935).  The sweeps are ONE dependent chain:
             // the first wavefront runs them alone (lane 0 solves, its 64 lanes update v'), everything it touches per solve in LDS
             // and hand-overs by wave-level ordering -- no workgroup barrier inside the 20 x nc solves; the other three wavefronts
@@ -679,6 +697,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             }
             __syncthreads();
         }
+        if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 7] = (long long)clock64();
         // ================= phase E: new velocity, integrate (core.py:974-980, joints.py:54-57) ================================
         if (io.inspect) {
             if (io.gforce != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) {
