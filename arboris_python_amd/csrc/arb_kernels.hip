@@ -46,7 +46,7 @@
 #include "arb_gs_stage.h"
 #include "arb_step_kernel.h"
 #include "arb_aux_kernels.h"
-#if !defined(ARB_PART) && !defined(ARB_QUICK)
+#if (!defined(ARB_PART) || defined(ARB_PART_WIDE)) && !defined(ARB_QUICK)
 #include "arb_wide_kernel.h"
 #define ARB_WITH_WIDE 1
 #else
@@ -113,6 +113,9 @@ struct arb_model {
     WideModel wide;
     WideModel *wide_dev = nullptr;
     size_t wide_lds = 0;
+    WideModel wide_c;                  // the compact layout of the same world (system in registers), where the model qualifies
+    WideModel *wide_c_dev = nullptr;
+    size_t wide_c_lds = 0;
 #endif
 };
 
@@ -625,7 +628,7 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
 #ifdef ARB_DEVELOPMENT
     {   // development builds: the knobs from the environment, once -- AFTER the forest exists (arb_hook_set_knob copies the
         // knobs into the forest's handle: before round 6 the forest kept the defaults)
-        const char *names[] = {"lds_pad", "queue_chunk", "queue_tail", "queue_spin_cap", "force_waves", "gsw_waves", "ablate"};
+        const char *names[] = {"lds_pad", "queue_chunk", "queue_tail", "queue_spin_cap", "force_waves", "gsw_waves", "ablate", "wide_compact"};
         for (const char *nm : names) {
             std::string e = std::string("ARB_") + nm;
             for (auto &ch : e) ch = (char)toupper((unsigned char)ch);
@@ -730,6 +733,19 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     upi(d->parent, nb, &W.parent); upi(d->jtype, nb, &W.jtype); upi(d->dof_off, nb, &W.dof_off); upi(jnd.data(), nb, &W.jnd);
     upi(d->q_off, nb, &W.q_off); upi(depth.data(), nb, &W.depth); upi(d->weighted, nb, &W.weighted); upi(dof2q.data(), n, &W.dof2q);
     upi(dofbody.data(), n, &W.dofbody); upi(subsize.data(), nb, &W.subsize);
+    if (maxdepth >= ARB_JUMP_DEPTH) {                         // a deep tree: the ancestor 2^r levels up, for the log-depth chains
+        int rounds = 0;
+        while ((1 << rounds) < maxdepth + 1) ++rounds;
+        std::vector<int> janc((size_t)rounds * nb, -1);
+        for (int b = 0; b < nb; ++b) janc[b] = d->parent[b];
+        for (int r = 1; r < rounds; ++r)
+            for (int b = 0; b < nb; ++b) {
+                const int a = janc[(size_t)(r - 1) * nb + b];
+                janc[(size_t)r * nb + b] = a >= 0 ? janc[(size_t)(r - 1) * nb + a] : -1;
+            }
+        W.jrounds = rounds;
+        upi(janc.data(), janc.size(), &W.janc);
+    }
     upd(h12(d->H_pr, nb), &W.Hpr); upd(h12(d->H_cn, nb), &W.Hcn);
     upd(vec(d->mass, 36 * (size_t)nb), &W.mass); upd(vec(d->visc, 36 * (size_t)nb), &W.visc);
     upd(vec(d->pd_kp, W.has_pd ? (size_t)n * n : 0), &W.pd_kp); upd(vec(d->pd_kd, W.has_pd ? (size_t)n * n : 0), &W.pd_kd);
@@ -745,20 +761,6 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     upd(vec(d->c_mu, nc), &W.cmu); upd(vec(d->c_eps, 3 * (size_t)nc), &W.ceps); upd(vec(d->c_prox, nc), &W.cprox);
     upd(vec(d->c_min, nc), &W.cmin); upd(vec(d->c_max, nc), &W.cmax);
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
-    // the augmented system in LDS when it fits beside the pivot row / column (120 KB: one workgroup per CU), else in scratch
-    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc) * sizeof(double);
-    W.z_in_lds = (size_t)n * W.ld * sizeof(double) + small <= 120 * 1024 ? 1 : 0;
-    M->wide_lds = small + (W.z_in_lds ? (size_t)n * W.ld * sizeof(double) : 0);
-    W.chain_in_lds = (W.z_in_lds && 84l * nb <= (long)n * W.ld) ? 1 : 0;        // (the pose / twist chain borrows the system's LDS space)
-    long o = 0;
-    auto take = [&](long cnt) { const long at = o; o += (cnt + 1) & ~1l; return at; };
-    W.o_q = take(d->nq); W.o_dq = take(n); W.o_qd = take(n); W.o_ff = take(std::max(ndol, 1)); W.o_ff0 = take(std::max(ndol, 1));
-    W.o_pose = take(12l * nb); W.o_pc = take(12l * nb); W.o_rcp = take(12l * nb); W.o_tw = take(6l * nb); W.o_ab = take(6l * nb);
-    W.o_om = take(6l * nb); W.o_da = take(18l * nb); W.o_tn = take(6l * nb); W.o_bn = take(6l * nb); W.o_pt = take(12l * nb);
-    W.o_sc = take(12l * n); W.o_ac = take(36l * nb); W.o_mc = take(36l * nb); W.o_wc = take(12l * nb); W.o_xk = take((long)WIDE_XK * n);
-    W.o_rh = take(2l * n); W.o_z = take(W.z_in_lds ? 0 : (long)n * W.ld); W.o_jr = take((long)std::max(ndol, 1) * n);
-    W.o_am = take((long)std::max(ndol * ndol, 1)); W.o_vv = take(std::max(ndol, 1)); W.o_cd = take((long)WIDE_CD * std::max(nc, 1));
-    W.total = o;
     {
         void *hp = nullptr, *dp = nullptr;
         hipError_t e = hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped);
@@ -766,11 +768,57 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         if (e != hipSuccess) { g_hip_err = std::string("status word: ") + hipGetErrorString(e); arb_model_destroy(M); return ARB_ERR_HIP; }
         W.status = static_cast<int *>(dp); W.warn = static_cast<int *>(dp) + 1;
     }
-    void *pw = nullptr;
-    hipError_t e = hipMalloc(&pw, sizeof(WideModel));
-    if (e == hipSuccess) { M->allocs.push_back(pw); e = hipMemcpy(pw, &W, sizeof(WideModel), hipMemcpyHostToDevice); }
-    if (e != hipSuccess) { g_hip_err = std::string("model upload: ") + hipGetErrorString(e); arb_model_destroy(M); return ARB_ERR_HIP; }
-    M->wide_dev = static_cast<WideModel *>(pw);
+    // Two layouts of one world's data, the same tables behind both.  The COMPACT build (arb_wide_kernel.h; at most 128 dofs and
+    // 128 columns): the system in registers, LDS for the rest -- pivot hand-over buffers, the admittance of the sweeps, then one
+    // region for chain arrays (24 nb doubles live to the end of phase B + 60 nb dead by then, under the 84 nb of phase B's
+    // composites) and per-dof vectors, which the solution columns take over.  Otherwise: the system in LDS when it fits beside
+    // the pivot row / column (120 KB: one workgroup per CU), else in scratch.  ("wide_compact" 0, arb_hook_set_knob, selects
+    // the second where the first is the default: the tests hold the two bit-identical.)
+    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc) * sizeof(double);
+    W.sld = (1 + ndol) | 1;
+    auto layout = [&](WideModel &L, bool compact, size_t *lds_out) {
+        L.kmax = 0; L.ac_in_lds = L.am_in_lds = 0; L.l_am = L.l_ac = L.l_xk = 0;
+        if (compact) {
+            const int kmax = n <= 80 ? 20 : n <= 112 ? 28 : 32;            // rows per wavefront (four wavefronts)
+            const long region = std::max(108l * nb + (long)WIDE_XK * n, (long)n * L.sld);
+            const long head = 2l * WIDE_CW;                                 // (the pivot rows, double-buffered)
+            L.kmax = kmax; L.l_am = head; L.l_ac = 24l * nb; L.l_xk = 108l * nb;
+            L.ac_in_lds = 1; L.am_in_lds = 1; L.chain_in_lds = 1; L.z_in_lds = 0;
+            *lds_out = small + (size_t)(head + ((ndol * ndol + 1) & ~1) + region) * sizeof(double);
+        } else {
+            L.z_in_lds = (size_t)n * L.ld * sizeof(double) + small <= 120 * 1024 ? 1 : 0;
+            *lds_out = small + (L.z_in_lds ? (size_t)n * L.ld * sizeof(double) : 0);
+            L.chain_in_lds = (L.z_in_lds && 84l * nb <= (long)n * L.ld) ? 1 : 0;    // (the pose / twist chain borrows the system's LDS space)
+            L.ac_in_lds = (L.chain_in_lds && 108l * nb <= (long)n * L.ld) ? 1 : 0;  // (phase B's composites behind the live chain arrays)
+            L.l_ac = 24l * nb;
+        }
+        long o = 0;
+        auto take = [&](long cnt) { const long at = o; o += (cnt + 1) & ~1l; return at; };
+        L.o_q = take(d->nq); L.o_dq = take(n); L.o_qd = take(n); L.o_ff = take(std::max(ndol, 1)); L.o_ff0 = take(std::max(ndol, 1));
+        // (the chain arrays, contiguous from o_pose on: pose, twist and pseudo twist -- read until the per-dof vectors are formed -- first)
+        L.o_pose = take(12l * nb); L.o_tw = take(6l * nb); L.o_om = take(6l * nb); L.o_pc = take(12l * nb); L.o_rcp = take(12l * nb);
+        L.o_ab = take(6l * nb); L.o_da = take(18l * nb); L.o_tn = take(6l * nb); L.o_bn = take(6l * nb); L.o_pt = take(12l * nb);
+        L.o_sc = take(12l * n); L.o_ac = take(36l * nb); L.o_mc = take(36l * nb); L.o_wc = take(12l * nb); L.o_xk = take((long)WIDE_XK * n);
+        L.o_rh = take(2l * n); L.o_z = take(L.z_in_lds ? 0 : (long)n * L.ld); L.o_jr = take((long)std::max(ndol, 1) * n);
+        L.o_am = take((long)std::max(ndol * ndol, 1)); L.o_vv = take(std::max(ndol, 1)); L.o_cd = take((long)WIDE_CD * std::max(nc, 1));
+        L.total = o;
+    };
+    auto to_device = [&](const WideModel &L, WideModel **dst) {
+        void *pw = nullptr;
+        hipError_t e = hipMalloc(&pw, sizeof(WideModel));
+        if (e == hipSuccess) { M->allocs.push_back(pw); e = hipMemcpy(pw, &L, sizeof(WideModel), hipMemcpyHostToDevice); }
+        if (e != hipSuccess) { g_hip_err = std::string("model upload: ") + hipGetErrorString(e); return ARB_ERR_HIP; }
+        *dst = static_cast<WideModel *>(pw);
+        return ARB_OK;
+    };
+    layout(W, false, &M->wide_lds);
+    rc = to_device(W, &M->wide_dev);
+    if (rc == ARB_OK && n <= 128 && W.ncols <= WIDE_CW) {
+        M->wide_c = W;
+        layout(M->wide_c, true, &M->wide_c_lds);
+        if (M->wide_c_lds <= 150 * 1024) rc = to_device(M->wide_c, &M->wide_c_dev);
+    }
+    if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     *out = M;
     return ARB_OK;
 }
@@ -779,15 +827,18 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
 // own block of stream-ordered scratch.
 template <typename T>
 static int wide_launch(arb_model *M, const WideIO<T> &io, long nw, double dt, const double *dts, int nsteps, unsigned flags, hipStream_t st) {
-    auto kern = arb_wide_kernel<T>;
-    const size_t lds = M->wide_lds;
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool compact = M->wide_c_dev != nullptr && M->kn.wide_compact != 0;
+    const WideModel &L = compact ? M->wide_c : M->wide;
+    const size_t lds = compact ? M->wide_c_lds : M->wide_lds;
     const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / std::max<size_t>(lds, 1))));
     const unsigned grid = (unsigned)std::min<long>(nw, per_cu * std::max(1, device_cus(M->device)));
     void *ws = nullptr;
-    HIP_TRY(arb_scratch_alloc(&ws, (size_t)grid * (size_t)M->wide.total * sizeof(double), st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WIDE_THREADS), lds, st, M->wide_dev, io, nw, dt, dts, nsteps, flags, (double *)ws);
-    const hipError_t le = hipGetLastError();
+    HIP_TRY(arb_scratch_alloc(&ws, (size_t)grid * (size_t)L.total * sizeof(double), st));
+    const WideModel *dev = compact ? M->wide_c_dev : M->wide_dev;
+    const hipError_t le = L.kmax == 20 ? wide_launch_one<T, 20>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
+                        : L.kmax == 28 ? wide_launch_one<T, 28>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
+                        : L.kmax == 32 ? wide_launch_one<T, 32>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
+                                       : wide_launch_one<T, 0>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st);
     (void)hipFreeAsync(ws, st);
     if (le != hipSuccess) { g_hip_err = std::string("kernel launch: ") + hipGetErrorString(le); return ARB_ERR_HIP; }
     return ARB_OK;
@@ -965,7 +1016,7 @@ extern "C" int arb_hook_set_knob(arb_model *M, const char *name, int value) {
     struct { const char *n; int Knobs::*f; } tab[] = {
         {"lds_pad", &Knobs::lds_pad}, {"queue_chunk", &Knobs::queue_chunk}, {"queue_tail", &Knobs::queue_tail},
         {"queue_spin_cap", &Knobs::queue_spin_cap}, {"force_waves", &Knobs::force_waves}, {"gsw_waves", &Knobs::gsw_waves},
-        {"ablate", &Knobs::ablate}};
+        {"ablate", &Knobs::ablate}, {"wide_compact", &Knobs::wide_compact}};
     for (auto &t : tab)
         if (strcmp(t.n, name) == 0) {
             M->kn.*(t.f) = value;
@@ -982,7 +1033,7 @@ extern "C" int arb_model_get_info(const arb_model *M, arb_model_info *info) {
         memset(info, 0, sizeof(*info));
         info->nb = M->nb; info->ndof = M->n; info->nq = M->nq; info->nc = M->nc;
         info->nmax = M->n; info->ncols = M->ncols; info->nsets = 1;
-        info->lds_bytes_f32 = info->lds_bytes_f64 = (int32_t)M->wide_lds;
+        info->lds_bytes_f32 = info->lds_bytes_f64 = (int32_t)((M->wide_c_dev && M->kn.wide_compact) ? M->wide_c_lds : M->wide_lds);
         info->device = M->device; info->forest_copies = 1; info->wide = 1;
         return ARB_OK;
     }
@@ -1404,8 +1455,9 @@ extern "C" int arb_step_plan(arb_model *M, int dtype, int64_t nworlds, int32_t n
 #if ARB_WITH_WIDE
     if (M->is_wide) {          // one workgroup of four wavefronts per world, workgroups loop over the batch
         memset(out, 0, sizeof(*out));
-        const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / std::max<size_t>(M->wide_lds, 1))));
-        out->waves_per_simd = 1; out->worlds_per_wavefront = 1; out->feat = 3; out->lds_bytes = (int32_t)M->wide_lds;
+        const size_t wlds = (M->wide_c_dev && M->kn.wide_compact) ? M->wide_c_lds : M->wide_lds;
+        const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / std::max<size_t>(wlds, 1))));
+        out->waves_per_simd = 1; out->worlds_per_wavefront = 1; out->feat = 3; out->lds_bytes = (int32_t)wlds;
         out->wave_slots = (int32_t)(per_cu * device_cus(M->device)); out->work_queue = 0;
         return ARB_OK;
     }

@@ -80,7 +80,7 @@ struct Knobs {
     // (queue_tail 6 since round 6: swept on the body-space-column kernels, tools/queue_sweep.py -- 4096 worlds +1.4 %, eight
     // contacts +1 %, 8192 / 65 536 worlds unchanged against 4; the schedule does not change a bit of the results)
     int lds_pad = 0, queue_chunk = 4, queue_tail = 6, queue_spin_cap = 1 << 24;
-    int force_waves = 0, gsw_waves = 3, ablate = 0;
+    int force_waves = 0, gsw_waves = 3, ablate = 0, wide_compact = 1;
 };
 
 // Wave slots of a device for one-wavefront workgroups of a kernel that runs `waves_per_simd` wavefronts per SIMD by its
@@ -184,7 +184,8 @@ int launch_one(const DevModel<T> *dm, const Layout &L, T *q, T *dq, T *cf, const
     const DevModel<T> *, const Layout &, T *, T *, T *, const T *, const PerWorldPD<T> &, long, double, int, unsigned,   \
     const DebugOut<T> &, int, const LogOut<T> &, const SplitIO<T> &, const double *, hipStream_t, const Knobs &, long, long, \
     const CostIO<T> &
-#if defined(ARB_PART) && defined(ARB_PART_SPEC)      /* (translation units of their own: the specialised kernels, tiles 44 / 48) */
+#if defined(ARB_PART) && defined(ARB_PART_WIDE)      /* (the workgroup-per-world kernels: instantiated in arb_wide_kernel.h) */
+#elif defined(ARB_PART) && defined(ARB_PART_SPEC)    /* (translation units of their own: the specialised kernels, tiles 44 / 48) */
 #if ARB_PART_SPEC == 1         /* float32, one column set: two and three waves */
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 4, 0>(ARB_LAUNCH_ONE_ARGS(float));
 template int launch_one<float, ARB_PART_NMAX, 1, 0, 5, 0>(ARB_LAUNCH_ONE_ARGS(float));

@@ -16,14 +16,146 @@
 // torques (constant or a sequence), the dense impedance of user-defined controllers, per-world PD targets / gains (and target
 // sequences), per-step dt, state and energy logs, the running cost; the model's merged PD controllers.
 // Not supported (ARB_ERR_UNSUPPORTED): the execution variants of the wavefront kernels (split sweeps, matrix-core elimination).
+//
+// The COMPACT build (KMAX > 0; worlds of at most 128 dofs and 128 columns: snake-100, human36 beside a few objects) keeps the
+// augmented system in REGISTERS: lane (c, g) = column c of 128, rows g, g + 2, g + 4 ... (KMAX of them) of that column.  A
+// pivot is then one hand-over through LDS (the pivot row from the lanes that hold it, the pivot column from the lanes of that
+// column; double-buffered, one barrier) and KMAX fused multiply-adds per lane on registers -- against a round trip through LDS
+// per entry of the LDS-resident elimination (690 k of snake-100's 970 k cycles per step before).  LDS then has room for
+// everything else a step touches: the chain arrays, the composites of phase B, the per-dof vectors X_k .. G_k, the solution
+// columns, the admittance of the sweeps.
 #ifndef ARB_WIDE_KERNEL_H
 #define ARB_WIDE_KERNEL_H
 #define WIDE_THREADS 256
-#define WIDE_XK 30          // per dof: X (6) | dX' (6) | P (6) | R (6) | G (6)
+#define WIDE_CW 128         // compact build: column lanes (two row groups of 128 lanes)
+
+typedef double wide_d4 __attribute__((ext_vector_type(4)));
+
+// Element k of a lane's column, kept as NCH vectors of four doubles (k is the same for every lane of the wavefront: a branch
+// over the vectors, then an indexed register move -- s_set_gpr_idx -- inside one; not a chain of selects.  The unit is
+// compiled with -simplifycfg-sink-common=false, csrc/Makefile: sinking the leaves' accesses into one access through a
+// computed address would turn the registers into scratch memory)
+template <int LO, int HI, int NCH>
+__device__ __forceinline__ double wide_reg_get(const wide_d4 (&z)[NCH], int ch, int e) {
+    if constexpr (HI - LO == 1) {
+        return z[LO][e];
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (ch < MID) return wide_reg_get<LO, MID, NCH>(z, ch, e);
+        return wide_reg_get<MID, HI, NCH>(z, ch, e);
+    }
+}
+template <int LO, int HI, int NCH>
+__device__ __forceinline__ void wide_reg_set(wide_d4 (&z)[NCH], int ch, int e, double t) {
+    if constexpr (HI - LO == 1) {
+        z[LO][e] = t;
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (ch < MID) wide_reg_set<LO, MID, NCH>(z, ch, e, t);
+        else wide_reg_set<MID, HI, NCH>(z, ch, e, t);
+    }
+}
+
+#ifndef WIDE_STAMP
+#define WIDE_STAMP(i)       // (tools/wide_elim_probe.py: shader-clock stamps between the parts of one pivot)
+#endif
+// The elimination of the compact build.  Wavefront g of the four holds rows g, g + 4, g + 8 ... (KQ of them) of ALL 128 columns:
+// lane l the columns l and l + 64.  Pivot j: wavefront j & 3 hands the pivot row over (element j >> 2 of its lanes), lane
+// j & 63 of every wavefront its KQ entries of the pivot column (the multipliers of that wavefront's rows); double-buffered --
+// pivot j - 2 writes a buffer again only behind the barrier of pivot j - 1, which every lane passes after its reads of pivot
+// j --: one barrier per pivot, then 2 KQ fused multiply-adds per lane on registers.  Columns j + 1 .. n - 1 are dead (what the
+// elimination left of them stays in the registers, nothing reads it).  Per pivot and wavefront LDS returns KQ multipliers to
+// 64 lanes: this layout halves that traffic against two row groups of 128 lanes -- it is what bounds the loop.
+// A function of its own, not inlined: the kernel around it is one function of ~30 000 instructions whose register
+// allocation left this loop's registers -- the system -- in scratch memory; a call boundary gives the loop an allocation of
+// its own.  Arguments of a device function arrive in vector registers: readfirstlane makes the pivot counter a scalar again
+// (the branches over it scalar branches); LDS goes by offsets, not pointers (a pointer argument is a generic one, every access
+// through it a flat instruction).
+template <int KQ>
+__device__ __attribute__((noinline)) void wide_eliminate(const double *__restrict__ Z, int ld_, int n_, int nact_, int rb_off_,
+                                                         int zl_off_, int sld_, const double *__restrict__ DQS)
+{
+    constexpr int NCH = KQ / 4;
+    const int tid = threadIdx.x;
+    const int ld = __builtin_amdgcn_readfirstlane(ld_), n = __builtin_amdgcn_readfirstlane(n_), nact = __builtin_amdgcn_readfirstlane(nact_),
+              rb_off = __builtin_amdgcn_readfirstlane(rb_off_),
+              zl_off = __builtin_amdgcn_readfirstlane(zl_off_), sld = __builtin_amdgcn_readfirstlane(sld_);
+    typedef __attribute__((address_space(3))) double lds_double;
+    lds_double *const lds0 = (lds_double *)arb_lds_raw;
+    lds_double *const RB = lds0 + rb_off, *const ZL = lds0 + zl_off;
+    const int l = tid & 63, zg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // out of the scratch block into the registers (coalesced; the only pass over the system that leaves the CU)
+    wide_d4 za[NCH], zb[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * (4 * ch + e) + zg;
+            za[ch][e] = (r < n && l < nact) ? Z[r * ld + l] : 0.;
+            zb[ch][e] = (r < n && l + 64 < nact) ? Z[r * ld + l + 64] : 0.;
+        }
+    for (int j = n - 1; j >= 0; --j) {
+        lds_double *rb = RB + (j & 1) * WIDE_CW;
+        const int gj = j & 3, cj = j >> 4;
+        int ej = (j >> 2) & 3;
+        // (vector cj, element ej; the element index opaque: seen next to cj the compiler folds the two back into ONE index into
+        // the whole array -- an address, and the registers become scratch memory)
+        asm volatile("" : "+s"(ej));
+        WIDE_STAMP(0);
+        if (zg == gj) { rb[l] = wide_reg_get<0, NCH, NCH>(za, cj, ej); rb[l + 64] = wide_reg_get<0, NCH, NCH>(zb, cj, ej); }
+        WIDE_STAMP(1);
+        // the multipliers of this wavefront's rows are the registers of ITS lane j & 63 (column j): broadcast through scalar
+        // registers (v_readlane), not through LDS -- nothing of the pivot column leaves the wavefront, and the fused multiply-adds
+        // take them as scalar operands.  (Before the barrier: independent of it.)
+        const int lj = j & 63;
+        wide_d4 f[NCH];
+        if (j < 64) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(za[ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(za[ch][e]), lj));
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zb[ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(zb[ch][e]), lj));
+        }
+        WIDE_STAMP(2);
+        __syncthreads();
+        WIDE_STAMP(3);
+        const double ip = arb_rcp(rb[j]);
+        const double ta = rb[l] * ip, tb = rb[l + 64] * ip;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) { za[ch] = za[ch] - f[ch] * ta; zb[ch] = zb[ch] - f[ch] * tb; }
+        WIDE_STAMP(4);
+        if (zg == gj) { wide_reg_set<0, NCH, NCH>(za, cj, ej, ta); wide_reg_set<0, NCH, NCH>(zb, cj, ej, tb); }
+        WIDE_STAMP(5);
+    }
+    __syncthreads();                // (the chain arrays and the per-dof vectors are dead: the solution columns take their LDS)
+    // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * (4 * ch + e) + zg;
+            if (r >= n) continue;
+            if (l >= n && l < nact) ZL[r * sld + (l - n)] = l == n ? za[ch][e] + DQS[r] : za[ch][e];
+            if (l + 64 >= n && l + 64 < nact) ZL[r * sld + (l + 64 - n)] = l + 64 == n ? zb[ch][e] + DQS[r] : zb[ch][e];
+        }
+    __syncthreads();
+}
+
+#define WIDE_XK 32          // per dof: X (6) | dX' (6) | P (6) | R (6) | G (6) | the dof's body and the end of that body's subtree (2)
 #define WIDE_CD 40          // per constraint: R (9) | p (3) | pos0 (3) | sdist | active | glo | ghi | pad ... | pinv (16) at 24
 
 struct WideModel {
     int nb, n, nq, nc, ndol, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds, chain_in_lds;
+    int kmax, ac_in_lds, am_in_lds, sld;                    // compact build: rows per lane (0: the LDS / scratch build); what else is in LDS
+    long l_ac, l_xk, l_am;                                  // (offsets, doubles, inside the LDS region behind the sweeps' blocks)
+    int jrounds;                                            // > 0: a deep tree -- the chain runs in this many pointer-jumping rounds
+    const int *janc;                                        // [jrounds][nb] the ancestor 2^r levels up (-1: none)
     double grav[3], up[3];
     const int *parent, *jtype, *dof_off, *jnd, *q_off, *depth, *weighted, *dof2q, *dofbody, *subsize;
     const double *Hpr, *Hcn, *mass, *visc;                 // [nb][12], [nb][12], [nb][36], [nb][36]
@@ -59,7 +191,7 @@ struct WideIO {
     long long *stamps;                                      // [nw][8] shader clock at the phase boundaries (diagnostic, inspect)
 };
 
-template <typename T>
+template <typename T, int KMAX>
 __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel *__restrict__ mp_in, const WideIO<T> io, long nworlds,
                                                                 double dt_in, const double *__restrict__ dts, int nsteps,
                                                                 unsigned flags, double *__restrict__ scratch_all)
@@ -75,7 +207,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     double *GVV = SWORK + 48;                // [ndol]    v' during the sweeps
     double *GFF = GVV + ((M.ndol + 3) & ~3); // [ndol]    constraint forces during the sweeps
     double *GSC = GFF + ((M.ndol + 3) & ~3); // [nc][52]  per-constraint blocks and constants of the sweeps
-    double *ZL = GSC + 52 * M.nc;            // [n][ld]   the augmented system, when it fits
+    double *ZL = GSC + 52 * M.nc;            // [n][ld]   the augmented system, when it fits (compact build: the region below)
+    constexpr bool REGZ = KMAX > 0;
+    // compact build: [2][128] pivot rows | the admittance of the sweeps | chain arrays, composites,
+    // per-dof vectors (the solution columns take their place after the elimination)
+    double *GAM = ZL + M.l_am;
+    if constexpr (REGZ) ZL += M.l_am + ((M.ndol * M.ndol + 1) & ~1);
     double *S = scratch_all + (size_t)blockIdx.x * (size_t)M.total;
     // The per-body arrays of the pose / twist chain (84 doubles per body, contiguous in the scratch block from o_pose on) live in
     // LDS while the chain runs -- in the space the augmented system takes afterwards (chain_in_lds: they fit it) --: one
@@ -85,10 +222,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     double *QS = S + M.o_q, *DQS = S + M.o_dq, *QD = S + M.o_qd, *FF = S + M.o_ff, *FF0 = S + M.o_ff0, *POSE = CHB,
            *PC = CHB + (M.o_pc - M.o_pose), *RCP = CHB + (M.o_rcp - M.o_pose), *TW = CHB + (M.o_tw - M.o_pose), *AB = CHB + (M.o_ab - M.o_pose),
            *OM = CHB + (M.o_om - M.o_pose), *DA = CHB + (M.o_da - M.o_pose), *TN = CHB + (M.o_tn - M.o_pose), *BN = CHB + (M.o_bn - M.o_pose),
-           *PT = S + M.o_pt, *SC = S + M.o_sc, *AC = S + M.o_ac, *MC = S + M.o_mc,
-           *WC = S + M.o_wc, *XK = S + M.o_xk, *RH = S + M.o_rh, *JR = S + M.o_jr, *AM = S + M.o_am, *VV = S + M.o_vv,
-           *CD = S + M.o_cd;
+           *PT = S + M.o_pt, *SC = S + M.o_sc, *AC = M.ac_in_lds ? ZL + M.l_ac : S + M.o_ac, *MC = M.ac_in_lds ? AC + 36 * nb : S + M.o_mc,
+           *WC = M.ac_in_lds ? AC + 72 * nb : S + M.o_wc, *XK = REGZ ? ZL + M.l_xk : S + M.o_xk, *RH = S + M.o_rh, *JR = S + M.o_jr,
+           *AM = M.am_in_lds ? GAM : S + M.o_am, *VV = S + M.o_vv, *CD = S + M.o_cd;
     double *Z = M.z_in_lds ? ZL : S + M.o_z;
+    // the solution columns [Y rhs | Y J'^T] after the elimination: inside Z, or (compact build) written out of the registers
+    const double *SL = REGZ ? ZL : Z + n;
+    const int sld = REGZ ? M.sld : ld;
     const bool do_con = nc > 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
     auto ld3 = [](const double *p) { return v3<double>(p[0], p[1], p[2]); };
     auto ldm = [](const double *p) { M3<double> r; for (int i = 0; i < 9; ++i) r.a[i] = p[i]; return r; };
@@ -171,6 +311,69 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         }
         for (int i = tid; i < n; i += WIDE_THREADS) { const int qi = M.dof2q[i]; QD[i] = qi >= 0 ? QS[qi] : 0.; }
         __syncthreads();
+        // Deep trees (snake-100: 101 levels of one working lane, 286 k of the step's 1.2 M cycles): log-depth chains, as in the
+        // float64 wavefront kernels (arb_phase_a.h).  Poses by pointer jumping -- every body composes its pose with that of its
+        // ancestor 2^r levels up, round after round --; twists, bias accelerations and pseudo twists are sums over the
+        // ancestors once they are written in WORLD axes about the world origin: Ad(H_gc) T_c = Ad(H_gp) T_p + Ad(H_gc) Tn_c.
+        // The ancestor tables are the model's (janc); lane = body (nb <= 256).
+        if (M.jrounds > 0) {
+            const int b = tid;
+            const bool on = b < nb;
+            const int par = on ? M.parent[b] : -1;
+            if (on) for (int i = 0; i < 12; ++i) POSE[12 * b + i] = PC[12 * b + i];
+            __syncthreads();
+            for (int r = 0; r < M.jrounds; ++r) {
+                const int a = on ? M.janc[r * nb + b] : -1;
+                M3<double> Ra = m3_identity<double>(); V3<double> pa = v3<double>(0., 0., 0.);
+                if (a >= 0) { Ra = ldm(POSE + 12 * a); pa = ld3(POSE + 12 * a + 9); }
+                __syncthreads();
+                if (a >= 0) {
+                    const M3<double> Rb = ldm(POSE + 12 * b);
+                    const V3<double> pb = ld3(POSE + 12 * b + 9);
+                    stm(POSE + 12 * b, mul(Ra, Rb)); st3(POSE + 12 * b + 9, mv(Ra, pb) + pa);
+                }
+                __syncthreads();
+            }
+            auto jump_sum = [&](double *arr) {          // inclusive sum over the ancestors of the 6-vectors of `arr`
+                __syncthreads();
+                for (int r = 0; r < M.jrounds; ++r) {
+                    const int a = on ? M.janc[r * nb + b] : -1;
+                    double add6[6] = {0., 0., 0., 0., 0., 0.};
+                    if (a >= 0) for (int i = 0; i < 6; ++i) add6[i] = arr[6 * a + i];
+                    __syncthreads();
+                    if (a >= 0) for (int i = 0; i < 6; ++i) arr[6 * b + i] += add6[i];
+                    __syncthreads();
+                }
+            };
+            M3<double> Rgb = m3_identity<double>(); V3<double> pgb = v3<double>(0., 0., 0.);
+            auto to_world = [&](double *arr, V3<double> lw, V3<double> lv) {
+                const V3<double> ww = mv(Rgb, lw);
+                st3(arr + 6 * b, ww); st3(arr + 6 * b + 3, cross(pgb, ww) + mv(Rgb, lv));
+            };
+            auto to_body = [&](double *arr) {
+                const V3<double> ww = ld3(arr + 6 * b), wv = ld3(arr + 6 * b + 3);
+                st3(arr + 6 * b, mtv(Rgb, ww)); st3(arr + 6 * b + 3, mtv(Rgb, wv - cross(pgb, ww)));
+            };
+            if (on) {
+                Rgb = ldm(POSE + 12 * b); pgb = ld3(POSE + 12 * b + 9);
+                to_world(TW, ld3(TN + 6 * b), ld3(TN + 6 * b + 3));                                        // core.py:1308
+                to_world(OM, ld3(OM + 6 * b), ld3(OM + 6 * b + 3));
+            }
+            jump_sum(TW);
+            if (on) to_body(TW);
+            __syncthreads();
+            if (on) {                                   // dAd_cp T_p + Bn_c in body axes (core.py:1312-1313 times gvel), to world axes
+                V3<double> tw = v3<double>(0., 0., 0.), tv = tw;
+                if (par >= 0) { tw = ld3(TW + 6 * par); tv = ld3(TW + 6 * par + 3); }
+                const M3<double> dA = ldm(DA + 18 * b), dB = ldm(DA + 18 * b + 9);
+                to_world(AB, mv(dA, tw) + ld3(BN + 6 * b), mv(dB, tw) + mv(dA, tv) + ld3(BN + 6 * b + 3));
+            }
+            jump_sum(AB);
+            if (on) to_body(AB);
+            jump_sum(OM);
+            if (on) to_body(OM);
+            __syncthreads();
+        } else
         // pose, twist, bias acceleration and pseudo twist down the tree, one depth level per pass
         for (int lvl = 0; lvl <= M.maxdepth; ++lvl) {
             for (int b = tid; b < nb; b += WIDE_THREADS) {
@@ -438,6 +641,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 xk[r] = X[r]; xk[6 + r] = dX[r]; xk[12 + r] = pp; xk[18 + r] = rr; xk[24 + r] = g;
                 rm += X[r] * Wc[r]; rg += X[r] * Wc[6 + r];
             }
+            xk[30] = (double)b; xk[31] = (double)(b + M.subsize[b]);
             RH[k] = rm; RH[n + k] = rg;
         }
         __syncthreads();
@@ -466,15 +670,16 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         }
         __syncthreads();            // (last reads of the chain arrays: Z takes their LDS space now)
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 3] = (long long)clock64();
-        // ---- the augmented system [Z | rhs | J'^T]: lane = entry --------------------------------------------------------
+        // ---- the augmented system [Z | rhs | J'^T]: lane = entry (compact build: assembled in scratch, then into the registers) ----
+        {
         for (int i = r0_n; i < n; i += rs_n) for (int c = cl_n; c < n; c += cwn) {
             double v = 0.;
             {
-                const int bi = M.dofbody[i], bk = M.dofbody[c];
                 const double *xi = XK + WIDE_XK * i, *xc = XK + WIDE_XK * c;
-                if (anc_eq(bi, bk)) {                            // row i is the column's own or an ancestor's dof: X_i . G_k
+                const double bi = xi[30], bie = xi[31], bk = xc[30], bke = xc[31];     // (bodies of the two dofs, ends of their subtrees)
+                if (bi <= bk && bk < bie) {                      // row i is the column's own or an ancestor's dof: X_i . G_k
                     for (int r = 0; r < 6; ++r) v += xi[r] * xc[24 + r];
-                } else if (anc_eq(bk, bi)) {                     // a descendant's: P_i . X_k + R_i . dX'_k
+                } else if (bk <= bi && bi < bke) {               // a descendant's: P_i . X_k + R_i . dX'_k
                     for (int r = 0; r < 6; ++r) v += xi[12 + r] * xc[r] + xi[18 + r] * xc[6 + r];
                 }
                 if (io.zmode == 0) {
@@ -515,6 +720,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             JR[idx * n + k] = v;
             Z[k * ld + n + 1 + idx] = v;
         }
+        }
         __syncthreads();
         // right-hand side of the increment form: gforce - (N + B - Z_a) gvel (+ J'^T f0, core.py:921-924)
         for (int i = tid; i < n; i += WIDE_THREADS) {
@@ -554,8 +760,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 4] = (long long)clock64();
         // ================= phase C: pivot-free Gauss-Jordan, pivots from the last dof to the first (core.py:818) ==========
         const int nact = do_con ? ncols : n + 1;
+        if constexpr (REGZ) {
+            // (LDS offsets as integers: the difference of two generic pointers into LDS is an expression the back end mishandles)
+            const int zl0 = ((ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc;
+            wide_eliminate<KMAX>(Z, ld, n, nact, zl0, zl0 + (int)M.l_am + ((ndol * ndol + 1) & ~1), sld, DQS);
+        } else {
         for (int j = n - 1; j >= 0; --j) {
-            const double ip = 1. / Z[j * ld + j];
+            const double ip = arb_rcp(Z[j * ld + j]);
             // (columns j+1 .. n-1 of row j are zero by now: their pivots are taken)
             for (int c = tid; c < nact; c += WIDE_THREADS) TROW[c] = (c <= j || c >= n) ? Z[j * ld + c] * ip : 0.;
             for (int r = tid; r < n; r += WIDE_THREADS) FCOL[r] = (r == j) ? 0. : Z[r * ld + j];
@@ -577,14 +788,14 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     const int r1 = r + rsj, r2 = r + 2 * rsj, r3 = r + 3 * rsj;
                     const double f0 = FCOL[r], f1 = FCOL[r1], f2 = FCOL[r2], f3 = FCOL[r3];      // (FCOL[j] is 0)
                     const double z0 = zc[r * ld], z1 = zc[r1 * ld], z2 = zc[r2 * ld], z3 = zc[r3 * ld];
-                    zc[r * ld] = (r == j) ? t : (f0 != 0. ? z0 - f0 * t : z0);
-                    zc[r1 * ld] = (r1 == j) ? t : (f1 != 0. ? z1 - f1 * t : z1);
-                    zc[r2 * ld] = (r2 == j) ? t : (f2 != 0. ? z2 - f2 * t : z2);
-                    zc[r3 * ld] = (r3 == j) ? t : (f3 != 0. ? z3 - f3 * t : z3);
+                    zc[r * ld] = (r == j) ? t : z0 - f0 * t;
+                    zc[r1 * ld] = (r1 == j) ? t : z1 - f1 * t;
+                    zc[r2 * ld] = (r2 == j) ? t : z2 - f2 * t;
+                    zc[r3 * ld] = (r3 == j) ? t : z3 - f3 * t;
                 }
                 for (; r < n; r += rsj) {
                     const double f = FCOL[r], z = zc[r * ld];
-                    zc[r * ld] = (r == j) ? t : (f != 0. ? z - f * t : z);
+                    zc[r * ld] = (r == j) ? t : z - f * t;
                 }
             }
             __syncthreads();
@@ -592,7 +803,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
         for (int i = tid; i < n; i += WIDE_THREADS) Z[i * ld + n] += DQS[i];
         __syncthreads();
-        if (io.inspect && io.vel_free != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) io.vel_free[w * n + i] = (T)Z[i * ld + n];
+        }
+        if (io.inspect && io.vel_free != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) io.vel_free[w * n + i] = (T)SL[i * sld];
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 5] = (long long)clock64();
         // ================= phase D: [v' | Y'] = J' [Y rhs | Y J'^T] (core.py:925-927), block inverses =========================
         if (do_con) {
@@ -601,7 +813,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 double acc = 0.;
                 if (CD[WIDE_CD * (idx >> 2) + 16] != 0.) {
                     const double *jr = JR + idx * n;
-                    for (int k = 0; k < n; ++k) acc += jr[k] * Z[k * ld + n + c];
+                    for (int k = 0; k < n; ++k) acc += jr[k] * SL[k * sld + c];
                 }
                 if (c == 0) VV[idx] = acc; else AM[idx * ndol + (c - 1)] = acc;
             }
@@ -712,8 +924,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             }
         }
         for (int i = tid; i < n; i += WIDE_THREADS) {
-            double vnew = Z[i * ld + n];
-            if (do_con) for (int idx = 0; idx < ndol; ++idx) vnew += Z[i * ld + n + 1 + idx] * (FF[idx] - FF0[idx]);
+            double vnew = SL[i * sld];
+            if (do_con) for (int idx = 0; idx < ndol; ++idx) vnew += SL[i * sld + 1 + idx] * (FF[idx] - FF0[idx]);
             RH[i] = vnew;
         }
         __syncthreads();
@@ -768,4 +980,29 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     }
     }   // worlds
 }
+
+// One launch of one instantiation.  In the split build (csrc/Makefile) every KMAX is a translation unit of its own
+// (-DARB_PART -DARB_PART_WIDE=KMAX), the host unit sees `extern template` declarations.
+template <typename T, int KMAX>
+hipError_t wide_launch_one(const WideModel *dev, const WideIO<T> &io, long nw, double dt, const double *dts, int nsteps, unsigned flags,
+                           double *ws, unsigned grid, size_t lds, hipStream_t st) {
+    auto kern = arb_wide_kernel<T, KMAX>;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WIDE_THREADS), lds, st, dev, io, nw, dt, dts, nsteps, flags, ws);
+    return hipGetLastError();
+}
+#define ARB_WIDE_ONE_ARGS(T) const WideModel *, const WideIO<T> &, long, double, const double *, int, unsigned, double *, unsigned, size_t, hipStream_t
+#if defined(ARB_PART_WIDE)
+template hipError_t wide_launch_one<float, ARB_PART_WIDE>(ARB_WIDE_ONE_ARGS(float));
+template hipError_t wide_launch_one<double, ARB_PART_WIDE>(ARB_WIDE_ONE_ARGS(double));
+#elif defined(ARB_SPLIT_BUILD)
+#define ARB_EXTERN_WIDE(K) \
+    extern template hipError_t wide_launch_one<float, K>(ARB_WIDE_ONE_ARGS(float)); \
+    extern template hipError_t wide_launch_one<double, K>(ARB_WIDE_ONE_ARGS(double));
+ARB_EXTERN_WIDE(0) ARB_EXTERN_WIDE(20) ARB_EXTERN_WIDE(28) ARB_EXTERN_WIDE(32)
+#undef ARB_EXTERN_WIDE
+#endif
 #endif  // ARB_WIDE_KERNEL_H

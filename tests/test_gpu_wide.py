@@ -253,3 +253,54 @@ def test_wide_worlds_take_every_input_of_arb_step_ex():
     assert _rel(tq.cpu().numpy(), oq).max() < 1e-8 and _rel(tdq.cpu().numpy(), odq).max() < 1e-7
     assert np.abs(cost["out"].cpu().numpy() - ocost).max() <= 1e-10 * np.abs(ocost).max()
     bw.close()
+
+
+@pytest.mark.parametrize("scene", ["snake100", "human36+4", "random"])
+def test_compact_build_equals_the_lds_build_bit_for_bit(scene):
+    """Worlds of at most 128 dofs and 128 columns run the COMPACT build by default (arb_wide_kernel.h: the augmented system in
+    registers, one LDS hand-over per pivot, log-depth chains shared with the other build); the knob "wide_compact" 0 selects the
+    build that keeps the system in LDS / scratch.  Same assembly, same pivots, same multipliers, same sweeps: states, forces and
+    every inspect output identical to the last bit, float32 and float64 buffers."""
+    from arboris_python_amd import scenes, synth
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    if scene == "snake100":
+        m = scenes.flat(scenes.snake_world(100))
+        q, dq = synth.random_states(m, 12, seed=3, angle=0.5, vel=1.0)
+        dt, steps = 1e-3, 6
+    elif scene == "human36+4":
+        m, q0, dq0 = flatten_world(scenes.human36_and_objects_world(4))
+        q, dq = np.tile(q0, (12, 1)), np.tile(dq0, (12, 1))
+        dq = dq + 0.05 * np.random.RandomState(2).standard_normal(dq.shape)
+        dt, steps = 5e-3, 25
+    else:
+        from test_gpu_random_models import random_world
+        w = random_world(1004, nbody_range=(24, 30), max_dof=100, max_contacts=6, max_spheres=4)
+        m, q0, dq0 = flatten_world(w)
+        assert 64 < m.ndof <= 128 and m.ndof + 1 + 4 * m.nc <= 128, (m.ndof, m.nc)
+        q, dq = np.tile(q0, (12, 1)), np.tile(dq0, (12, 1))
+        dt, steps = 2e-3, 8
+    B = len(q)
+    names = ["Z", "gforce0", "vel_free", "c_adm", "c_vel", "c_force", "gforce", "q_next", "dq_next", "pose", "twist"]
+    for dtype in (torch.float64, torch.float32):
+        out = {}
+        for compact in (1, 0):
+            bw = BatchedWorlds(m)
+            assert bw.info["wide"] == 1
+            bw.set_knob("wide_compact", compact)
+            lds = bw.plan(B, steps, dtype=dtype)["lds_bytes"]
+            tq, tdq = bw.to_device(q, dq, dtype)
+            cf = bw.new_cforce(B, dtype) if m.nc else None
+            r = bw.inspect(tq, tdq, dt, [n for n in names if m.nc or not n.startswith("c_")], cforce=cf)
+            bw.step(tq, tdq, dt, steps, cforce=cf)
+            torch.cuda.synchronize()
+            out[compact] = (tq.cpu(), tdq.cpu(), None if cf is None else cf.cpu(), {k: v.cpu() for k, v in r.items()}, lds)
+            bw.close()
+        a, b = out[1], out[0]
+        assert a[4] != b[4], "the two builds ask for different amounts of LDS: the knob did not switch"
+        assert torch.isfinite(a[1]).all()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        if a[2] is not None:
+            assert torch.equal(a[2], b[2])
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), k
