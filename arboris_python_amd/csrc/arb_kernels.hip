@@ -769,22 +769,35 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         W.status = static_cast<int *>(dp); W.warn = static_cast<int *>(dp) + 1;
     }
     // Two layouts of one world's data, the same tables behind both.  The COMPACT build (arb_wide_kernel.h; at most 128 dofs and
-    // 128 columns): the system in registers, LDS for the rest -- pivot hand-over buffers, the admittance of the sweeps, then one
+    // 256 columns): the system in registers, LDS for the rest -- pivot hand-over buffers, the admittance of the sweeps, then one
     // region for chain arrays (24 nb doubles live to the end of phase B + 60 nb dead by then, under the 84 nb of phase B's
     // composites) and per-dof vectors, which the solution columns take over.  Otherwise: the system in LDS when it fits beside
     // the pivot row / column (120 KB: one workgroup per CU), else in scratch.  ("wide_compact" 0, arb_hook_set_knob, selects
     // the second where the first is the default: the tests hold the two bit-identical.)
     const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc) * sizeof(double);
     W.sld = (1 + ndol) | 1;
-    auto layout = [&](WideModel &L, bool compact, size_t *lds_out) {
-        L.kmax = 0; L.ac_in_lds = L.am_in_lds = 0; L.l_am = L.l_ac = L.l_xk = 0;
+    // (compact: 1 = everything below in LDS, 2 = without the rows of J', 3 = without the admittance of the sweeps as well --
+    //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB)
+    auto layout = [&](WideModel &L, int compact, size_t *lds_out) {
+        L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = 0;
         if (compact) {
             const int kmax = n <= 80 ? 20 : n <= 112 ? 28 : 32;            // rows per wavefront (four wavefronts)
-            const long region = std::max(108l * nb + (long)WIDE_XK * n, (long)n * L.sld);
-            const long head = 2l * WIDE_CW;                                 // (the pivot rows, double-buffered)
+            L.cp = L.ncols <= 128 ? 2 : 4;                                 // columns per lane
+            // (the rows of J' under the composites, dead by the time they are written, when they fit; the solution columns
+            //  behind them -- the per-dof vectors, read while J' is written, lie past 108 nb)
+            const long jrsz = ((long)ndol * n + 1) & ~1l;
+            const bool under = ndol > 0 && jrsz <= 84l * nb;
+            L.jr_in_lds = (ndol > 0 && compact == 1) ? 1 : 0;
+            L.am_in_lds = compact <= 2 ? 1 : 0;
+            L.l_sol = (L.jr_in_lds && under) ? 24l * nb + jrsz : 0;
+            long region = std::max(108l * nb + (long)WIDE_XK * n, L.l_sol + (long)n * L.sld);
+            L.l_jr = under ? 24l * nb : region;                  // (... or a place of their own)
+            if (L.jr_in_lds && !under) region += jrsz;
+            const long head = 2l * 64 * L.cp;                               // (the pivot rows, double-buffered)
             L.kmax = kmax; L.l_am = head; L.l_ac = 24l * nb; L.l_xk = 108l * nb;
-            L.ac_in_lds = 1; L.am_in_lds = 1; L.chain_in_lds = 1; L.z_in_lds = 0;
-            *lds_out = small + (size_t)(head + ((ndol * ndol + 1) & ~1) + region) * sizeof(double);
+            L.l_reg = head + (L.am_in_lds ? ((ndol * ndol + 1) & ~1) : 0);
+            L.ac_in_lds = 1; L.chain_in_lds = 1; L.z_in_lds = 0;
+            *lds_out = small + (size_t)(L.l_reg + region) * sizeof(double);
         } else {
             L.z_in_lds = (size_t)n * L.ld * sizeof(double) + small <= 120 * 1024 ? 1 : 0;
             *lds_out = small + (L.z_in_lds ? (size_t)n * L.ld * sizeof(double) : 0);
@@ -811,12 +824,14 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         *dst = static_cast<WideModel *>(pw);
         return ARB_OK;
     };
-    layout(W, false, &M->wide_lds);
+    layout(W, 0, &M->wide_lds);
     rc = to_device(W, &M->wide_dev);
-    if (rc == ARB_OK && n <= 128 && W.ncols <= WIDE_CW) {
+    if (rc == ARB_OK && n <= 128 && W.ncols <= 256) {
         M->wide_c = W;
-        layout(M->wide_c, true, &M->wide_c_lds);
-        if (M->wide_c_lds <= 150 * 1024) rc = to_device(M->wide_c, &M->wide_c_dev);
+        for (int level = 1; level <= 3; ++level) {
+            layout(M->wide_c, level, &M->wide_c_lds);
+            if (M->wide_c_lds <= 150 * 1024) { rc = to_device(M->wide_c, &M->wide_c_dev); break; }
+        }
     }
     if (rc != ARB_OK) { arb_model_destroy(M); return rc; }
     *out = M;
@@ -835,10 +850,11 @@ static int wide_launch(arb_model *M, const WideIO<T> &io, long nw, double dt, co
     void *ws = nullptr;
     HIP_TRY(arb_scratch_alloc(&ws, (size_t)grid * (size_t)L.total * sizeof(double), st));
     const WideModel *dev = compact ? M->wide_c_dev : M->wide_dev;
-    const hipError_t le = L.kmax == 20 ? wide_launch_one<T, 20>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
-                        : L.kmax == 28 ? wide_launch_one<T, 28>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
-                        : L.kmax == 32 ? wide_launch_one<T, 32>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
-                                       : wide_launch_one<T, 0>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st);
+#define ARB_WIDE_GO(K, P) wide_launch_one<T, K, P>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
+    const hipError_t le = L.kmax == 0 ? ARB_WIDE_GO(0, 2)
+                        : L.cp == 2 ? (L.kmax == 20 ? ARB_WIDE_GO(20, 2) : L.kmax == 28 ? ARB_WIDE_GO(28, 2) : ARB_WIDE_GO(32, 2))
+                                    : (L.kmax == 20 ? ARB_WIDE_GO(20, 4) : L.kmax == 28 ? ARB_WIDE_GO(28, 4) : ARB_WIDE_GO(32, 4));
+#undef ARB_WIDE_GO
     (void)hipFreeAsync(ws, st);
     if (le != hipSuccess) { g_hip_err = std::string("kernel launch: ") + hipGetErrorString(le); return ARB_ERR_HIP; }
     return ARB_OK;

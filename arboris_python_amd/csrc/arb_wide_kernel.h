@@ -27,7 +27,6 @@
 #ifndef ARB_WIDE_KERNEL_H
 #define ARB_WIDE_KERNEL_H
 #define WIDE_THREADS 256
-#define WIDE_CW 128         // compact build: column lanes (two row groups of 128 lanes)
 
 typedef double wide_d4 __attribute__((ext_vector_type(4)));
 
@@ -59,8 +58,8 @@ __device__ __forceinline__ void wide_reg_set(wide_d4 (&z)[NCH], int ch, int e, d
 #ifndef WIDE_STAMP
 #define WIDE_STAMP(i)       // (tools/wide_elim_probe.py: shader-clock stamps between the parts of one pivot)
 #endif
-// The elimination of the compact build.  Wavefront g of the four holds rows g, g + 4, g + 8 ... (KQ of them) of ALL 128 columns:
-// lane l the columns l and l + 64.  Pivot j: wavefront j & 3 hands the pivot row over (element j >> 2 of its lanes), lane
+// The elimination of the compact build.  Wavefront g of the four holds rows g, g + 4, g + 8 ... (KQ of them) of ALL 64 CP columns
+// (CP 2: 128, CP 4: 256): lane l the columns l, l + 64, ...  Pivot j: wavefront j & 3 hands the pivot row over (element j >> 2 of its lanes), lane
 // j & 63 of every wavefront its KQ entries of the pivot column (the multipliers of that wavefront's rows); double-buffered --
 // pivot j - 2 writes a buffer again only behind the barrier of pivot j - 1, which every lane passes after its reads of pivot
 // j --: one barrier per pivot, then 2 KQ fused multiply-adds per lane on registers.  Columns j + 1 .. n - 1 are dead (what the
@@ -71,7 +70,7 @@ __device__ __forceinline__ void wide_reg_set(wide_d4 (&z)[NCH], int ch, int e, d
 // its own.  Arguments of a device function arrive in vector registers: readfirstlane makes the pivot counter a scalar again
 // (the branches over it scalar branches); LDS goes by offsets, not pointers (a pointer argument is a generic one, every access
 // through it a flat instruction).
-template <int KQ>
+template <int KQ, int CP>
 __device__ __attribute__((noinline)) void wide_eliminate(const double *__restrict__ Z, int ld_, int n_, int nact_, int rb_off_,
                                                          int zl_off_, int sld_, const double *__restrict__ DQS)
 {
@@ -85,24 +84,28 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
     lds_double *const RB = lds0 + rb_off, *const ZL = lds0 + zl_off;
     const int l = tid & 63, zg = __builtin_amdgcn_readfirstlane(tid >> 6);
     // out of the scratch block into the registers (coalesced; the only pass over the system that leaves the CU)
-    wide_d4 za[NCH], zb[NCH];
+    wide_d4 z[CP][NCH];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
+    for (int p = 0; p < CP; ++p)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * (4 * ch + e) + zg;
-            za[ch][e] = (r < n && l < nact) ? Z[r * ld + l] : 0.;
-            zb[ch][e] = (r < n && l + 64 < nact) ? Z[r * ld + l + 64] : 0.;
-        }
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * (4 * ch + e) + zg;
+                z[p][ch][e] = (r < n && l + 64 * p < nact) ? Z[r * ld + l + 64 * p] : 0.;
+            }
     for (int j = n - 1; j >= 0; --j) {
-        lds_double *rb = RB + (j & 1) * WIDE_CW;
+        lds_double *rb = RB + (j & 1) * (64 * CP);
         const int gj = j & 3, cj = j >> 4;
         int ej = (j >> 2) & 3;
         // (vector cj, element ej; the element index opaque: seen next to cj the compiler folds the two back into ONE index into
         // the whole array -- an address, and the registers become scratch memory)
         asm volatile("" : "+s"(ej));
         WIDE_STAMP(0);
-        if (zg == gj) { rb[l] = wide_reg_get<0, NCH, NCH>(za, cj, ej); rb[l + 64] = wide_reg_get<0, NCH, NCH>(zb, cj, ej); }
+        if (zg == gj) {
+#pragma unroll
+            for (int p = 0; p < CP; ++p) rb[l + 64 * p] = wide_reg_get<0, NCH, NCH>(z[p], cj, ej);
+        }
         WIDE_STAMP(1);
         // the multipliers of this wavefront's rows are the registers of ITS lane j & 63 (column j): broadcast through scalar
         // registers (v_readlane), not through LDS -- nothing of the pivot column leaves the wavefront, and the fused multiply-adds
@@ -114,36 +117,44 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
             for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(za[ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(za[ch][e]), lj));
+                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z[0][ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(z[0][ch][e]), lj));
         } else {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zb[ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(zb[ch][e]), lj));
+                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z[1][ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(z[1][ch][e]), lj));
         }
         WIDE_STAMP(2);
         __syncthreads();
         WIDE_STAMP(3);
         const double ip = arb_rcp(rb[j]);
-        const double ta = rb[l] * ip, tb = rb[l + 64] * ip;
+        double t[CP];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) { za[ch] = za[ch] - f[ch] * ta; zb[ch] = zb[ch] - f[ch] * tb; }
+        for (int p = 0; p < CP; ++p) t[p] = rb[l + 64 * p] * ip;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int p = 0; p < CP; ++p) z[p][ch] = z[p][ch] - f[ch] * t[p];
         WIDE_STAMP(4);
-        if (zg == gj) { wide_reg_set<0, NCH, NCH>(za, cj, ej, ta); wide_reg_set<0, NCH, NCH>(zb, cj, ej, tb); }
+        // (a branch per vector around the selects, inside the loop above, measured slower: 868 against 674 cycles)
+        if (zg == gj) {
+#pragma unroll
+            for (int p = 0; p < CP; ++p) wide_reg_set<0, NCH, NCH>(z[p], cj, ej, t[p]);
+        }
         WIDE_STAMP(5);
     }
     __syncthreads();                // (the chain arrays and the per-dof vectors are dead: the solution columns take their LDS)
     // the rhs column holds gvel+ - gvel: add gvel back so that it is Y (M gvel/dt + gforce)
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
+    for (int p = 0; p < CP; ++p)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * (4 * ch + e) + zg;
-            if (r >= n) continue;
-            if (l >= n && l < nact) ZL[r * sld + (l - n)] = l == n ? za[ch][e] + DQS[r] : za[ch][e];
-            if (l + 64 >= n && l + 64 < nact) ZL[r * sld + (l + 64 - n)] = l + 64 == n ? zb[ch][e] + DQS[r] : zb[ch][e];
-        }
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * (4 * ch + e) + zg, c = l + 64 * p;
+                if (r < n && c >= n && c < nact) ZL[r * sld + (c - n)] = c == n ? z[p][ch][e] + DQS[r] : z[p][ch][e];
+            }
     __syncthreads();
 }
 
@@ -152,8 +163,10 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
 
 struct WideModel {
     int nb, n, nq, nc, ndol, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds, chain_in_lds;
-    int kmax, ac_in_lds, am_in_lds, sld;                    // compact build: rows per lane (0: the LDS / scratch build); what else is in LDS
-    long l_ac, l_xk, l_am;                                  // (offsets, doubles, inside the LDS region behind the sweeps' blocks)
+    int kmax, cp, ac_in_lds, am_in_lds, sld;                  // compact build: rows per lane (0: the LDS / scratch build); what else is in LDS
+    long l_ac, l_xk, l_am, l_reg;                                // (offsets, doubles, inside the LDS region behind the sweeps' blocks)
+    int jr_in_lds;                                          // compact build: the rows of J' in LDS (under the dead composites)
+    long l_jr, l_sol;                                       // ... and where; where the solution columns go after the elimination
     int jrounds;                                            // > 0: a deep tree -- the chain runs in this many pointer-jumping rounds
     const int *janc;                                        // [jrounds][nb] the ancestor 2^r levels up (-1: none)
     double grav[3], up[3];
@@ -191,7 +204,7 @@ struct WideIO {
     long long *stamps;                                      // [nw][8] shader clock at the phase boundaries (diagnostic, inspect)
 };
 
-template <typename T, int KMAX>
+template <typename T, int KMAX, int CP>
 __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel *__restrict__ mp_in, const WideIO<T> io, long nworlds,
                                                                 double dt_in, const double *__restrict__ dts, int nsteps,
                                                                 unsigned flags, double *__restrict__ scratch_all)
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     // compact build: [2][128] pivot rows | the admittance of the sweeps | chain arrays, composites,
     // per-dof vectors (the solution columns take their place after the elimination)
     double *GAM = ZL + M.l_am;
-    if constexpr (REGZ) ZL += M.l_am + ((M.ndol * M.ndol + 1) & ~1);
+    if constexpr (REGZ) ZL += M.l_reg;
     double *S = scratch_all + (size_t)blockIdx.x * (size_t)M.total;
     // The per-body arrays of the pose / twist chain (84 doubles per body, contiguous in the scratch block from o_pose on) live in
     // LDS while the chain runs -- in the space the augmented system takes afterwards (chain_in_lds: they fit it) --: one
@@ -223,11 +236,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
            *PC = CHB + (M.o_pc - M.o_pose), *RCP = CHB + (M.o_rcp - M.o_pose), *TW = CHB + (M.o_tw - M.o_pose), *AB = CHB + (M.o_ab - M.o_pose),
            *OM = CHB + (M.o_om - M.o_pose), *DA = CHB + (M.o_da - M.o_pose), *TN = CHB + (M.o_tn - M.o_pose), *BN = CHB + (M.o_bn - M.o_pose),
            *PT = S + M.o_pt, *SC = S + M.o_sc, *AC = M.ac_in_lds ? ZL + M.l_ac : S + M.o_ac, *MC = M.ac_in_lds ? AC + 36 * nb : S + M.o_mc,
-           *WC = M.ac_in_lds ? AC + 72 * nb : S + M.o_wc, *XK = REGZ ? ZL + M.l_xk : S + M.o_xk, *RH = S + M.o_rh, *JR = S + M.o_jr,
+           *WC = M.ac_in_lds ? AC + 72 * nb : S + M.o_wc, *XK = REGZ ? ZL + M.l_xk : S + M.o_xk, *RH = S + M.o_rh, *JR = M.jr_in_lds ? ZL + M.l_jr : S + M.o_jr,
            *AM = M.am_in_lds ? GAM : S + M.o_am, *VV = S + M.o_vv, *CD = S + M.o_cd;
     double *Z = M.z_in_lds ? ZL : S + M.o_z;
     // the solution columns [Y rhs | Y J'^T] after the elimination: inside Z, or (compact build) written out of the registers
-    const double *SL = REGZ ? ZL : Z + n;
+    const double *SL = REGZ ? ZL + M.l_sol : Z + n;
     const int sld = REGZ ? M.sld : ld;
     const bool do_con = nc > 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
     auto ld3 = [](const double *p) { return v3<double>(p[0], p[1], p[2]); };
@@ -672,23 +685,30 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 3] = (long long)clock64();
         // ---- the augmented system [Z | rhs | J'^T]: lane = entry (compact build: assembled in scratch, then into the registers) ----
         {
-        for (int i = r0_n; i < n; i += rs_n) for (int c = cl_n; c < n; c += cwn) {
-            double v = 0.;
-            {
-                const double *xi = XK + WIDE_XK * i, *xc = XK + WIDE_XK * c;
-                const double bi = xi[30], bie = xi[31], bk = xc[30], bke = xc[31];     // (bodies of the two dofs, ends of their subtrees)
-                if (bi <= bk && bk < bie) {                      // row i is the column's own or an ancestor's dof: X_i . G_k
-                    for (int r = 0; r < 6; ++r) v += xi[r] * xc[24 + r];
-                } else if (bk <= bi && bi < bke) {               // a descendant's: P_i . X_k + R_i . dX'_k
-                    for (int r = 0; r < 6; ++r) v += xi[12 + r] * xc[r] + xi[18 + r] * xc[6 + r];
-                }
+        // lane = column (its per-dof vectors in registers), rows strided; both products of a row are formed, whichever applies
+        // is kept: the row's vectors are loaded in one batch (the same for every lane of a wavefront: LDS broadcasts)
+        for (int c = cl_n; c < n; c += cwn) {
+            const double *xc = XK + WIDE_XK * c;
+            double x0[12], xg[6];
+            for (int r = 0; r < 12; ++r) x0[r] = xc[r];
+            for (int r = 0; r < 6; ++r) xg[r] = xc[24 + r];
+            const double bk = xc[30], bke = xc[31];              // (the body of the column's dof, the end of its subtree)
+            for (int i = r0_n; i < n; i += rs_n) {
+                const double *xi = XK + WIDE_XK * i;
+                double a[6], pp[6], rr[6];
+                for (int r = 0; r < 6; ++r) { a[r] = xi[r]; pp[r] = xi[12 + r]; rr[r] = xi[18 + r]; }
+                const double bi = xi[30], bie = xi[31];
+                double v1 = 0., v2 = 0.;
+                for (int r = 0; r < 6; ++r) v1 += a[r] * xg[r];                              // own or an ancestor's dof: X_i . G_k
+                for (int r = 0; r < 6; ++r) v2 += pp[r] * x0[r] + rr[r] * x0[6 + r];         // a descendant's: P_i . X_k + R_i . dX'_k
+                double v = (bi <= bk && bk < bie) ? v1 : (bk <= bi && bi < bke) ? v2 : 0.;
                 if (io.zmode == 0) {
                     if (io.pd_kp != nullptr) { if (i == c) v += dt * (double)io.pd_kp[w * n + i] + (double)io.pd_kd[w * n + i]; }
                     else if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];     // controllers.py:141-158
                     if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];  // core.py:815-817
                 }
+                Z[i * ld + c] = v;
             }
-            Z[i * ld + c] = v;
         }
         if (io.inspect && io.zmode != 0) {           // the world matrices M, B, N one by one (the object API): Zout and on to the next world
             __syncthreads();
@@ -763,7 +783,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         if constexpr (REGZ) {
             // (LDS offsets as integers: the difference of two generic pointers into LDS is an expression the back end mishandles)
             const int zl0 = ((ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc;
-            wide_eliminate<KMAX>(Z, ld, n, nact, zl0, zl0 + (int)M.l_am + ((ndol * ndol + 1) & ~1), sld, DQS);
+            wide_eliminate<KMAX, CP>(Z, ld, n, nact, zl0, zl0 + (int)M.l_reg + (int)M.l_sol, sld, DQS);
         } else {
         for (int j = n - 1; j >= 0; --j) {
             const double ip = arb_rcp(Z[j * ld + j]);
@@ -983,10 +1003,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
 
 // One launch of one instantiation.  In the split build (csrc/Makefile) every KMAX is a translation unit of its own
 // (-DARB_PART -DARB_PART_WIDE=KMAX), the host unit sees `extern template` declarations.
-template <typename T, int KMAX>
+template <typename T, int KMAX, int CP>
 hipError_t wide_launch_one(const WideModel *dev, const WideIO<T> &io, long nw, double dt, const double *dts, int nsteps, unsigned flags,
                            double *ws, unsigned grid, size_t lds, hipStream_t st) {
-    auto kern = arb_wide_kernel<T, KMAX>;
+    auto kern = arb_wide_kernel<T, KMAX, CP>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -996,13 +1016,13 @@ hipError_t wide_launch_one(const WideModel *dev, const WideIO<T> &io, long nw, d
 }
 #define ARB_WIDE_ONE_ARGS(T) const WideModel *, const WideIO<T> &, long, double, const double *, int, unsigned, double *, unsigned, size_t, hipStream_t
 #if defined(ARB_PART_WIDE)
-template hipError_t wide_launch_one<float, ARB_PART_WIDE>(ARB_WIDE_ONE_ARGS(float));
-template hipError_t wide_launch_one<double, ARB_PART_WIDE>(ARB_WIDE_ONE_ARGS(double));
+template hipError_t wide_launch_one<float, ARB_PART_WIDE, ARB_PART_WIDE_CP>(ARB_WIDE_ONE_ARGS(float));
+template hipError_t wide_launch_one<double, ARB_PART_WIDE, ARB_PART_WIDE_CP>(ARB_WIDE_ONE_ARGS(double));
 #elif defined(ARB_SPLIT_BUILD)
-#define ARB_EXTERN_WIDE(K) \
-    extern template hipError_t wide_launch_one<float, K>(ARB_WIDE_ONE_ARGS(float)); \
-    extern template hipError_t wide_launch_one<double, K>(ARB_WIDE_ONE_ARGS(double));
-ARB_EXTERN_WIDE(0) ARB_EXTERN_WIDE(20) ARB_EXTERN_WIDE(28) ARB_EXTERN_WIDE(32)
+#define ARB_EXTERN_WIDE(K, P) \
+    extern template hipError_t wide_launch_one<float, K, P>(ARB_WIDE_ONE_ARGS(float)); \
+    extern template hipError_t wide_launch_one<double, K, P>(ARB_WIDE_ONE_ARGS(double));
+ARB_EXTERN_WIDE(0, 2) ARB_EXTERN_WIDE(20, 2) ARB_EXTERN_WIDE(28, 2) ARB_EXTERN_WIDE(32, 2) ARB_EXTERN_WIDE(20, 4) ARB_EXTERN_WIDE(28, 4) ARB_EXTERN_WIDE(32, 4)
 #undef ARB_EXTERN_WIDE
 #endif
 #endif  // ARB_WIDE_KERNEL_H

@@ -255,7 +255,7 @@ def test_wide_worlds_take_every_input_of_arb_step_ex():
     bw.close()
 
 
-@pytest.mark.parametrize("scene", ["snake100", "human36+4", "random"])
+@pytest.mark.parametrize("scene", ["snake100", "snake128", "human36+4", "human36+12", "random"])
 def test_compact_build_equals_the_lds_build_bit_for_bit(scene):
     """Worlds of at most 128 dofs and 128 columns run the COMPACT build by default (arb_wide_kernel.h: the augmented system in
     registers, one LDS hand-over per pivot, log-depth chains shared with the other build); the knob "wide_compact" 0 selects the
@@ -264,10 +264,16 @@ def test_compact_build_equals_the_lds_build_bit_for_bit(scene):
     from arboris_python_amd import scenes, synth
     from arboris_python_amd.flatten import flatten_world
     from arboris_python_amd.batch import BatchedWorlds
-    if scene == "snake100":
-        m = scenes.flat(scenes.snake_world(100))
+    if scene in ("snake100", "snake128"):            # (snake-128: 129 columns -- four columns per lane instead of two)
+        m = scenes.flat(scenes.snake_world(int(scene[5:])))
         q, dq = synth.random_states(m, 12, seed=3, angle=0.5, vel=1.0)
         dt, steps = 1e-3, 6
+    elif scene == "human36+12":                      # (114 dofs, 16 contacts: 179 columns)
+        m, q0, dq0 = flatten_world(scenes.human36_and_objects_world(12))
+        assert m.ndof == 114 and m.ndof + 1 + 4 * m.nc > 128
+        q, dq = np.tile(q0, (12, 1)), np.tile(dq0, (12, 1))
+        dq = dq + 0.05 * np.random.RandomState(2).standard_normal(dq.shape)
+        dt, steps = 5e-3, 12
     elif scene == "human36+4":
         m, q0, dq0 = flatten_world(scenes.human36_and_objects_world(4))
         q, dq = np.tile(q0, (12, 1)), np.tile(dq0, (12, 1))

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 kmax = int(sys.argv[2]) if len(sys.argv) > 2 else (20 if n <= 80 else 28 if n <= 112 else 32)
 src = open(os.path.join(ROOT, "arboris_python_amd", "csrc", "arb_wide_kernel.h")).read()
-body = src[src.index("#define WIDE_CW 128"):src.index("struct WideModel {")]
+body = src[src.index("typedef double wide_d4"):src.index("#define WIDE_XK")]
 prog = r'''
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,7 +23,7 @@ __device__ long long g_acc[8];
 ''' + body.replace("    const int tid = threadIdx.x;\n", "    const int tid = threadIdx.x;\n    WIDE_STAMP_DECL\n", 1) \
           .replace("    __syncthreads();                // (the chain arrays", "    WIDE_STAMP_END\n    __syncthreads();                // (the chain arrays", 1) + r'''
 __global__ __launch_bounds__(256) void k(const double *Z, int ld, int n, int nact, double *out, int sld, const double *DQS) {
-    wide_eliminate<KMAXV>(Z + (size_t)blockIdx.x * n * ld, ld, n, nact, 0, 1024, sld, DQS);
+    wide_eliminate<KMAXV, 2>(Z + (size_t)blockIdx.x * n * ld, ld, n, nact, 0, 1024, sld, DQS);
     if (threadIdx.x < n) out[blockIdx.x * n + threadIdx.x] = reinterpret_cast<double *>(arb_lds_raw)[1024 + threadIdx.x * sld];
 }
 int main() {
