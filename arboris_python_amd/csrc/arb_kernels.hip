@@ -628,7 +628,7 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
 #ifdef ARB_DEVELOPMENT
     {   // development builds: the knobs from the environment, once -- AFTER the forest exists (arb_hook_set_knob copies the
         // knobs into the forest's handle: before round 6 the forest kept the defaults)
-        const char *names[] = {"lds_pad", "queue_chunk", "queue_tail", "queue_spin_cap", "force_waves", "gsw_waves", "ablate", "wide_compact"};
+        const char *names[] = {"lds_pad", "queue_chunk", "queue_tail", "queue_spin_cap", "force_waves", "gsw_waves", "ablate", "wide_compact", "wide_gs_groups"};
         for (const char *nm : names) {
             std::string e = std::string("ARB_") + nm;
             for (auto &ch : e) ch = (char)toupper((unsigned char)ch);
@@ -774,7 +774,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     // composites) and per-dof vectors, which the solution columns take over.  Otherwise: the system in LDS when it fits beside
     // the pivot row / column (120 KB: one workgroup per CU), else in scratch.  ("wide_compact" 0, arb_hook_set_knob, selects
     // the second where the first is the default: the tests hold the two bit-identical.)
-    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc) * sizeof(double);
+    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 59 * nc) * sizeof(double);
     W.sld = (1 + ndol) | 1;
     // (compact: 1 = everything below in LDS, 2 = without the rows of J', 3 = without the admittance of the sweeps as well --
     //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB)
@@ -841,9 +841,11 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
 // One launch of the wide kernel: grid = min(worlds, two workgroups per CU) workgroups that loop over the worlds, each with its
 // own block of stream-ordered scratch.
 template <typename T>
-static int wide_launch(arb_model *M, const WideIO<T> &io, long nw, double dt, const double *dts, int nsteps, unsigned flags, hipStream_t st) {
+static int wide_launch(arb_model *M, const WideIO<T> &io_in, long nw, double dt, const double *dts, int nsteps, unsigned flags, hipStream_t st) {
     const bool compact = M->wide_c_dev != nullptr && M->kn.wide_compact != 0;
     const WideModel &L = compact ? M->wide_c : M->wide;
+    WideIO<T> io = io_in;
+    io.gs_serial = M->kn.wide_gs_groups == 0;
     const size_t lds = compact ? M->wide_c_lds : M->wide_lds;
     const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / std::max<size_t>(lds, 1))));
     const unsigned grid = (unsigned)std::min<long>(nw, per_cu * std::max(1, device_cus(M->device)));
@@ -1032,7 +1034,7 @@ extern "C" int arb_hook_set_knob(arb_model *M, const char *name, int value) {
     struct { const char *n; int Knobs::*f; } tab[] = {
         {"lds_pad", &Knobs::lds_pad}, {"queue_chunk", &Knobs::queue_chunk}, {"queue_tail", &Knobs::queue_tail},
         {"queue_spin_cap", &Knobs::queue_spin_cap}, {"force_waves", &Knobs::force_waves}, {"gsw_waves", &Knobs::gsw_waves},
-        {"ablate", &Knobs::ablate}, {"wide_compact", &Knobs::wide_compact}};
+        {"ablate", &Knobs::ablate}, {"wide_compact", &Knobs::wide_compact}, {"wide_gs_groups", &Knobs::wide_gs_groups}};
     for (auto &t : tab)
         if (strcmp(t.n, name) == 0) {
             M->kn.*(t.f) = value;

@@ -80,7 +80,7 @@ struct Knobs {
     // (queue_tail 6 since round 6: swept on the body-space-column kernels, tools/queue_sweep.py -- 4096 worlds +1.4 %, eight
     // contacts +1 %, 8192 / 65 536 worlds unchanged against 4; the schedule does not change a bit of the results)
     int lds_pad = 0, queue_chunk = 4, queue_tail = 6, queue_spin_cap = 1 << 24;
-    int force_waves = 0, gsw_waves = 3, ablate = 0, wide_compact = 1;
+    int force_waves = 0, gsw_waves = 3, ablate = 0, wide_compact = 1, wide_gs_groups = 1;
 };
 
 // Wave slots of a device for one-wavefront workgroups of a kernel that runs `waves_per_simd` wavefronts per SIMD by its

@@ -201,6 +201,7 @@ struct WideIO {
     T *jac, *djac;                                          // [nw][nb][6][n] Body.jacobian / djacobian (core.py:1273-1274)
     T *pose, *twist, *Zout, *gforce0, *vel_free, *c_sdist, *c_jac, *c_force, *c_frame, *gforce, *q_next, *dq_next, *c_adm, *c_vel;
     int *c_active;
+    int gs_serial;                                          // the sweeps over ALL constraints in one sequence (no independent groups)
     long long *stamps;                                      // [nw][8] shader clock at the phase boundaries (diagnostic, inspect)
 };
 
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     double *GVV = SWORK + 48;                // [ndol]    v' during the sweeps
     double *GFF = GVV + ((M.ndol + 3) & ~3); // [ndol]    constraint forces during the sweeps
     double *GSC = GFF + ((M.ndol + 3) & ~3); // [nc][52]  per-constraint blocks and constants of the sweeps
-    double *ZL = GSC + 52 * M.nc;            // [n][ld]   the augmented system, when it fits (compact build: the region below)
+    unsigned long long *GGM = reinterpret_cast<unsigned long long *>(GSC + 52 * M.nc);   // [nc]  the group of a constraint, a bit per member
+    double *GDF = GSC + 53 * M.nc;           // [nc][6]   per group: the force increment of this round's solve (4), its constraint
+    double *ZL = GSC + 59 * M.nc;            // [n][ld]   the augmented system, when it fits (compact build: the region below)
     constexpr bool REGZ = KMAX > 0;
     // compact build: [2][128] pivot rows | the admittance of the sweeps | chain arrays, composites,
     // per-dof vectors (the solution columns take their place after the elimination)
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         const int nact = do_con ? ncols : n + 1;
         if constexpr (REGZ) {
             // (LDS offsets as integers: the difference of two generic pointers into LDS is an expression the back end mishandles)
-            const int zl0 = ((ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 52 * nc;
+            const int zl0 = ((ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 59 * nc;
             wide_eliminate<KMAX, CP>(Z, ld, n, nact, zl0, zl0 + (int)M.l_reg + (int)M.l_sol, sld, DQS);
         } else {
         for (int j = n - 1; j >= 0; --j) {
@@ -853,11 +856,22 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             }
             __syncthreads();
             if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 6] = (long long)clock64();
-            // ---- 20 Gauss-Seidel sweeps, constraints in registration order (core.py:929-935).  The sweeps are ONE dependent chain:
-            // the first wavefront runs them alone (lane 0 solves, its 64 lanes update v'), everything it touches per solve in LDS
-            // and hand-overs by wave-level ordering -- no workgroup barrier inside the 20 x nc solves; the other three wavefronts
-            // wait at the barrier below.  Per constraint in LDS (GSC): its admittance block (16) | the block's inverse (16) |
-            // sdist, mu, eps (3), pos0 / dt (3), glo, ghi, type, active.
+            // ---- 20 Gauss-Seidel sweeps, constraints in registration order (core.py:929-935).  The sweeps are a dependent chain:
+            // the first wavefront runs them alone, everything it touches per solve in LDS and hand-overs by wave-level ordering --
+            // no workgroup barrier inside the 20 x nc solves; the other three wavefronts wait at the barrier below.  Per
+            // constraint in LDS (GSC): its admittance block (16) | the block's inverse (16) | sdist, mu, eps (3), pos0 / dt (3),
+            // glo, ghi, type, active | constants of the sliding solve (6), its last root.
+            //
+            // INDEPENDENT GROUPS of constraints are swept side by side.  Two constraints interact through the 4 x 4 blocks of the
+            // admittance Y' that couple them; where both blocks are exactly zero -- constraints on different kinematic trees that
+            // touch nothing but the ground: the feet of a robot and the objects lying around it -- neither solve reads anything
+            // the other writes (the update vel += Y'[:, c] dforce adds exact zeros to the other's rows), so the order between them
+            // is immaterial.  The groups are the connected components of "some coupling block is non-zero", found per step; lane
+            // g (the lowest constraint of its group) sweeps the group's constraints in registration order, all groups in lockstep:
+            // a round = one solve per group, then every row takes the update of its own group's constraint.  A row receives the
+            // same additions in the same order as in the serial sweep minus the exact zeros: the same bits (io.gs_serial, the
+            // knob "wide_gs_groups" 0: the serial sweep, which the tests compare with).  human36 beside four objects: rounds of
+            // four solves instead of eight.
             if (tid < WAVE) {
                 for (int c = tid; c < nc; c += WAVE) {
                     const double *cd = CD + WIDE_CD * c;
@@ -874,49 +888,91 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                         g[44] = sp.tr; g[45] = sp.m2; g[46] = sp.det; g[47] = sp.sQ; g[48] = sp.sA; g[49] = sp.nq;
                     }
                     g[50] = NAN;
+                    // the constraints this one is coupled with (itself included), a bit each
+                    unsigned long long m = 0ull;
+                    if (cd[16] != 0.) {
+                        m = 1ull << c;
+                        if (!io.gs_serial) {
+                            for (int c2 = 0; c2 < nc; ++c2) {
+                                if (c2 == c || CD[WIDE_CD * c2 + 16] == 0.) continue;
+                                bool nz = false;
+                                for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2)
+                                    nz = nz || AM[(4 * c + i) * ndol + 4 * c2 + j2] != 0. || AM[(4 * c2 + i) * ndol + 4 * c + j2] != 0.;
+                                if (nz) m |= 1ull << c2;
+                            }
+                        } else {
+                            for (int c2 = 0; c2 < nc; ++c2) if (CD[WIDE_CD * c2 + 16] != 0.) m |= 1ull << c2;       // (one group)
+                        }
+                    }
+                    GGM[c] = m;
                 }
                 for (int r = tid; r < ndol; r += WAVE) { GVV[r] = VV[r]; GFF[r] = FF[r]; }
                 WAVE_SYNC();
+                // connected components: every mask takes over the masks of its members, six times (2^6 >= 64 constraints)
+                for (int it = 0; it < 6; ++it) {
+                    unsigned long long m = tid < nc ? GGM[tid] : 0ull, m2 = m;
+                    for (unsigned long long rest = m; rest; rest &= rest - 1) m2 |= GGM[__builtin_ctzll(rest)];
+                    WAVE_SYNC();
+                    if (tid < nc) GGM[tid] = m2;
+                    WAVE_SYNC();
+                }
+                // (lane c < nc: leads its group when it is the group's lowest constraint)
+                const unsigned long long grp = tid < nc ? GGM[tid] : 0ull;
+                const unsigned long long mine = (grp != 0ull && __builtin_ctzll(grp) == tid) ? grp : 0ull;
                 for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
                     if (tid == 0) DF[4] = 0.;                                    // "something changed in this sweep"
-                    for (int c = 0; c < nc; ++c) {
-                        const double *g = GSC + 52 * c;
-                        if (g[43] == 0.) continue;                               // (the same value for every lane)
-                        if (tid == 0) {
-                            const int ct = (int)g[42];
+                    WAVE_SYNC();
+                    unsigned long long rem = mine;
+                    while (__any(rem != 0ull)) {
+                        if (tid < nc) GDF[6 * tid + 4] = -1.;                    // (no update from this group in this round)
+                        if (rem != 0ull) {
+                            const int c = __builtin_ctzll(rem);
+                            rem &= rem - 1;
+                            const double *g = GSC + 52 * c;
+                            // (the constraint's block out of LDS in ONE batch: read where the solve uses them, every value is a
+                            // round trip of its own -- one wavefront, nothing to hide it behind)
+                            double gl[52];
+                            for (int i = 0; i < 52; ++i) gl[i] = g[i];
+                            const int ct = (int)gl[42];
                             double v[4], f[4], f_old[4], df[4] = {0., 0., 0., 0.};
                             for (int i = 0; i < 4; ++i) { v[i] = GVV[4 * c + i]; f[i] = f_old[i] = GFF[4 * c + i]; }
+                            __builtin_amdgcn_sched_barrier(0);
                             if (ct == ARB_CT_SOFTFINGER) {                       // constraints.py:780-836
-                                const double eps[3] = {g[34], g[35], g[36]};
+                                const double eps[3] = {gl[34], gl[35], gl[36]};
                                 double *gm = GSC + 52 * c;
-                                const SlidePre sp = {gm[44], gm[45], gm[46], gm[47], gm[48], gm[49]};
-                                double alpha[4], shift = 0., warm = gm[50];
-                                int br = softfinger_try<double>(v, g, g + 16, f, df, g[32], dt, g[33], eps, SWORK, alpha, &shift, true, &sp, &warm);
-                                if (br == 3) { shift = slide_shift_from_eig<double>(SWORK); br = 2; warm = NAN; }
-                                if (br == 2) softfinger_slide_finish<double>(g, alpha, eps, shift, f, df);
+                                const SlidePre sp = {gl[44], gl[45], gl[46], gl[47], gl[48], gl[49]};
+                                double alpha[4], shift = 0., warm = gl[50], swork[48];
+                                int br = softfinger_try<double>(v, gl, gl + 16, f, df, gl[32], dt, gl[33], eps, swork, alpha, &shift, true, &sp, &warm);
+                                if (br == 3) { shift = slide_shift_from_eig<double>(swork); br = 2; warm = NAN; }
+                                if (br == 2) softfinger_slide_finish<double>(gl, alpha, eps, shift, f, df);
                                 if (br == 2) gm[50] = warm;          // (the next sweep restarts next to this root)
                             } else if (ct == ARB_CT_BALLSOCKET) {                // constraints.py:235-237
-                                const double *P = g + 16;
+                                const double *P = gl + 16;
                                 for (int i = 0; i < 3; ++i) {
-                                    df[i] = -(P[4 * i] * (v[0] + g[37]) + P[4 * i + 1] * (v[1] + g[38]) + P[4 * i + 2] * (v[2] + g[39]));
+                                    df[i] = -(P[4 * i] * (v[0] + gl[37]) + P[4 * i + 1] * (v[1] + gl[38]) + P[4 * i + 2] * (v[2] + gl[39]));
                                     f[i] += df[i];
                                 }
                             } else {                                             // JointLimits.solve constraints.py:73-90
-                                const double v0 = v[0] - g[0] * f[0], p00 = g[16];
+                                const double v0 = v[0] - gl[0] * f[0], p00 = gl[16];
                                 double nf = 0.;
-                                if (v0 <= g[40]) nf = p00 * (g[40] - v0);
-                                else if (g[41] <= v0) nf = p00 * (g[41] - v0);
+                                if (v0 <= gl[40]) nf = p00 * (gl[40] - v0);
+                                else if (gl[41] <= v0) nf = p00 * (gl[41] - v0);
                                 df[0] = nf - f[0]; f[0] = nf;
                             }
                             bool ch = false;
-                            for (int i = 0; i < 4; ++i) { GFF[4 * c + i] = f[i]; DF[i] = df[i]; ch = ch || df[i] != 0. || !same_bits(f[i], f_old[i]); }
+                            for (int i = 0; i < 4; ++i) { GFF[4 * c + i] = f[i]; GDF[6 * tid + i] = df[i]; ch = ch || df[i] != 0. || !same_bits(f[i], f_old[i]); }
+                            GDF[6 * tid + 4] = (double)c;
                             if (ch) DF[4] = 1.;
                         }
                         WAVE_SYNC();
-                        const double d0 = DF[0], d1 = DF[1], d2 = DF[2], d3 = DF[3];
                         for (int r = tid; r < ndol; r += WAVE) {                  // vel += Y'[:, c] dforce   core.py:935
+                            const unsigned long long gr = GGM[r >> 2];
+                            if (gr == 0ull) continue;                            // (an inactive constraint's rows: never read)
+                            const double *gd = GDF + 6 * __builtin_ctzll(gr);
+                            const int c = (int)gd[4];
+                            if (c < 0) continue;
                             const double *a = AM + r * ndol + 4 * c;
-                            GVV[r] += a[0] * d0 + a[1] * d1 + a[2] * d2 + a[3] * d3;
+                            GVV[r] += a[0] * gd[0] + a[1] * gd[1] + a[2] * gd[2] + a[3] * gd[3];
                         }
                         WAVE_SYNC();
                     }

@@ -310,3 +310,38 @@ def test_compact_build_equals_the_lds_build_bit_for_bit(scene):
             assert torch.equal(a[2], b[2])
         for k in a[3]:
             assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize("scene", ["human36+4", "human36+12", "random"])
+def test_independent_groups_of_constraints_sweep_side_by_side_same_bits(scene):
+    """The Gauss-Seidel sweeps of the wide kernels run the connected components of the constraint coupling (the non-zero 4 x 4
+    blocks of the admittance) side by side -- the feet of human36 in one group, every object's contact in a group of its own:
+    rounds of four solves instead of eight (sixteen with twelve objects).  The knob "wide_gs_groups" 0 runs the one serial
+    sequence of core.py:929-935; states and forces are the same to the last bit over whole rollouts."""
+    from arboris_python_amd import scenes
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    if scene.startswith("human36+"):
+        m, q0, dq0 = flatten_world(scenes.human36_and_objects_world(int(scene[8:])))
+        steps, dt = 40, 5e-3
+    else:
+        from test_gpu_random_models import random_world
+        m, q0, dq0 = flatten_world(random_world(1004, nbody_range=(24, 30), max_dof=100, max_contacts=6, max_spheres=4))
+        steps, dt = 3, 2e-3          # (the generator's worlds start with loop closures far open: violent, a few steps stay finite)
+    B = 16
+    q, dq = np.tile(q0, (B, 1)), np.tile(dq0, (B, 1))
+    if scene != "random":
+        dq = dq + 0.1 * np.random.RandomState(5).standard_normal(dq.shape)
+    out = {}
+    for groups in (1, 0):
+        bw = BatchedWorlds(m)
+        bw.set_knob("wide_gs_groups", groups)
+        tq, tdq = bw.to_device(q, dq, torch.float64)
+        cf = bw.new_cforce(B, torch.float64)
+        bw.step(tq, tdq, dt, steps, cforce=cf)
+        torch.cuda.synchronize()
+        out[groups] = (tq.cpu(), tdq.cpu(), cf.cpu())
+        bw.close()
+    assert torch.isfinite(out[1][1]).all() and out[1][2].abs().max() > 0
+    for a, b in zip(out[1], out[0]):
+        assert torch.equal(a, b)
