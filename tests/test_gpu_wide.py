@@ -345,3 +345,60 @@ def test_independent_groups_of_constraints_sweep_side_by_side_same_bits(scene):
     assert torch.isfinite(out[1][1]).all() and out[1][2].abs().max() > 0
     for a, b in zip(out[1], out[0]):
         assert torch.equal(a, b)
+
+
+def test_wide_kernels_against_the_reference_itself_g15():
+    """tests/golden/g15_wide.npz holds what the REFERENCE computes on worlds past 64 dofs (tools/gen_golden.py: add_snake(w, 100)
+    under gravity; human36 beside four free objects, 30 steps with contacts).  The wide kernels against it, float64: snake-100
+    to the accuracy of the reference's own explicit inverse (cond(Z) ~ 1e9), the 66-dof scene step by step -- states, active
+    sets through the constraint forces -- and as one 30-step launch."""
+    from conftest import load_golden, load_model
+    from arboris_python_amd.batch import BatchedWorlds
+    g = load_golden("g15_wide.npz")
+    m, _, _ = load_model("snake100_g")
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1
+    dt = float(g["snake_dt"])
+    tq, tdq = bw.to_device(g["snake_q"], g["snake_dq"], torch.float64)
+    r = bw.inspect(tq, tdq, dt, ["Z"])
+    Z0 = g["snake_Z0"]
+    assert np.abs(r["Z"][0].cpu().numpy() - Z0).max() / np.abs(Z0).max() < 1e-12
+    bw.step(tq, tdq, dt, 1)
+    # cond(Z) ~ 1e10: the reference's dq+ = inv(Z) (M dq / dt + gforce) carries the error of numpy's explicit inverse (the oracle,
+    # the same numpy calls, reproduces it to the bit).  The kernel's elimination is the more accurate of the two: both within
+    # cond * eps of one another, and the kernel's dq+ satisfies the step equation with the smaller residual
+    dyn = O.update_dynamic(m, g["snake_q"], g["snake_dq"])
+    gf, Z, _ = O.update_controllers(m, dyn, g["snake_q"], g["snake_dq"], dt)
+    rhs = (dyn["M"] @ g["snake_dq"][..., None])[..., 0] / dt + gf
+    res = lambda x: (np.abs((Z @ x[..., None])[..., 0] - rhs).max(axis=1) / np.abs(rhs).max(axis=1))
+    r_dev, r_ref = res(tdq.cpu().numpy()), res(g["snake_dq_next"])
+    print("snake-100 step equation residual: kernel %.1e, reference %.1e; |kernel - reference| %.1e"
+          % (r_dev.max(), r_ref.max(), _rel(tdq.cpu().numpy(), g["snake_dq_next"]).max()))
+    assert r_dev.max() < 1e-12 and (r_dev < r_ref).all()
+    assert _rel(tq.cpu().numpy(), g["snake_q_next"]).max() < 5e-7 and _rel(tdq.cpu().numpy(), g["snake_dq_next"]).max() < 5e-4
+    tq, tdq = bw.to_device(g["snake_q"][:2], g["snake_dq"][:2], torch.float64)
+    bw.step(tq, tdq, dt, 5)
+    assert _rel(tq.cpu().numpy(), g["snake_roll5_q"]).max() < 3e-6 and _rel(tdq.cpu().numpy(), g["snake_roll5_dq"]).max() < 2e-3
+    bw.close()
+    m, _, _ = load_model("human36_obj4")
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1 and bw.info["ndof"] == 66
+    dt = float(g["human_dt"])
+    T = len(g["human_active"])
+    tq, tdq = bw.to_device(g["human_q"][:1], g["human_dq"][:1], torch.float64)
+    cf = bw.new_cforce(1, torch.float64)
+    worst = 0.
+    for k in range(T):
+        bw.step(tq, tdq, dt, 1, cforce=cf)
+        f = cf.cpu().numpy()[0]
+        assert ((np.abs(f).max(axis=1) > 0) <= g["human_active"][k]).all(), k          # (a force only where the reference's contact is active)
+        assert np.abs(f - g["human_force"][k]).max() <= 1e-7 * max(1., np.abs(g["human_force"][k]).max()), k
+        e = max(_rel(tq.cpu().numpy(), g["human_q"][k + 1:k + 2]).max(), _rel(tdq.cpu().numpy(), g["human_dq"][k + 1:k + 2]).max())
+        worst = max(worst, e)
+    print("human36 + 4 objects, %d steps against the reference: worst state error %.2e" % (T, worst))
+    assert worst < 1e-8
+    tq2, tdq2 = bw.to_device(g["human_q"][:1], g["human_dq"][:1], torch.float64)
+    cf2 = bw.new_cforce(1, torch.float64)
+    bw.step(tq2, tdq2, dt, T, cforce=cf2)
+    assert torch.equal(tq2, tq) and torch.equal(tdq2, tdq) and torch.equal(cf2, cf)
+    bw.close()

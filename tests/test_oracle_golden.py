@@ -195,6 +195,34 @@ def test_snake64():
     close(q, g["roll10_q"], 1e-8); close(dq, g["roll10_dq"], 1e-6)
 
 
+def test_wide_worlds_from_the_reference_g15():
+    """g15 (round 6): the reference itself on worlds past 64 dofs -- add_snake(w, 100) under gravity (one step from four
+    states, the impedance, 5-step rollouts) and human36 beside four free objects (66 dofs, 8 contacts, 30 steps of the loop
+    body with the active sets and constraint forces).  The oracle is size-generic; this pins it -- and through it the wide
+    kernels (tests/test_gpu_wide.py reads the same file) -- at these sizes."""
+    g = load_golden("g15_wide.npz")
+    m, _, _ = load_model("snake100_g")
+    assert m.ndof == 100
+    dt = float(g["snake_dt"])
+    qn, dqn, _, d = O.step(m, g["snake_q"], g["snake_dq"], dt, debug=True)
+    # (cond(Z) ~ 1e9: the reference's explicit inverse and the oracle's agree to ~1e-6 of |dq+|)
+    close(qn, g["snake_q_next"], 1e-8); close(dqn, g["snake_dq_next"], 3e-6)
+    close(d["Z"][0], g["snake_Z0"], 1e-10)
+    q, dq, _ = O.rollout(m, g["snake_q"][:2], g["snake_dq"][:2], [dt] * 5)
+    close(q, g["snake_roll5_q"], 1e-7); close(dq, g["snake_roll5_dq"], 1e-5)
+    m, _, _ = load_model("human36_obj4")
+    assert m.ndof == 66 and m.nc == 8
+    dt = float(g["human_dt"])
+    q, dq = g["human_q"][:1].copy(), g["human_dq"][:1].copy()
+    cf = np.zeros((1, m.nc, 4))
+    for k in range(len(g["human_active"])):
+        q, dq, cf, d = O.step(m, q, dq, dt, cforce=cf, debug=True)
+        assert (d["active"][0] == g["human_active"][k]).all(), k
+        close(cf[0], g["human_force"][k], 1e-7)
+        close(q[0], g["human_q"][k + 1], 1e-9); close(dq[0], g["human_dq"][k + 1], 1e-8)
+    assert g["human_active"].any(axis=0).all()            # (every contact -- the four feet, the four balls -- is active at some step)
+
+
 def test_snake64_needs_float64_assembly():
     """Why snake-64 runs with the float64 kernels only: cond(Z) = 3e8, so an
     impedance matrix that is merely ROUNDED to float32 entry by entry -- the best a float32 assembly of Z could deliver --

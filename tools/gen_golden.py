@@ -906,10 +906,86 @@ def gen_user_controller():
     save("g14_user_controller.npz", **d)
 
 
+def gen_wide():
+    """g15 (round 6): worlds PAST 64 dofs run by the reference itself -- the pin of the wide kernels (csrc/arb_wide_kernel.h)
+    and of the oracle at these sizes.  (a) add_snake(w, 100) under gravity: four random states, one step each, the world's
+    impedance at the first, a 5-step rollout from two of them.  (b) human36 on the floor beside four free boxes carrying a
+    ball each (66 dofs, 8 plane / sphere contacts: arboris_python_amd.scenes.human36_and_objects_world built from the
+    reference's classes): 30 steps of the loop body from the scene's initial state with a small random velocity; per
+    step the state, the active set, the constraint forces."""
+    from arboris.shapes import Sphere
+    from arboris.joints import FreeJoint
+    import arboris.massmatrix as MM
+    w = World()
+    add_snake(w, 100)
+    w.register(WeightController())
+    w.init()
+    m = save_model("snake100_g", w)
+    out = {}
+    B = 4
+    q, dq = synth.random_states(m, B, seed=15, angle=0.5, vel=1.0)
+    dt = 1e-3
+    qn, dqn = [], []
+    for i in range(B):
+        set_state(w, m, q[i], dq[i])
+        ref_step(w, dt)
+        a, b = get_state(w, m)
+        qn.append(a); dqn.append(b)
+    out.update(snake_q=q, snake_dq=dq, snake_dt=np.array(dt), snake_q_next=np.array(qn), snake_dq_next=np.array(dqn))
+    set_state(w, m, q[0], dq[0])
+    w.update_dynamic(); w.update_controllers(dt)
+    out["snake_Z0"] = w._impedance.copy()
+    out["snake_gforce0"] = w._gforce.copy()
+    rq, rdq = [], []
+    for i in range(2):
+        set_state(w, m, q[i], dq[i])
+        for _ in range(5):
+            ref_step(w, dt)
+        a, b = get_state(w, m)
+        rq.append(a); rdq.append(b)
+    out["snake_roll5_q"], out["snake_roll5_dq"] = np.array(rq), np.array(rdq)
+
+    w = World()
+    add_groundplane(w)
+    add_human36(w)
+    for k in range(4):
+        he = (0.10 + 0.02 * k, 0.08, 0.12)
+        body = Body(name="Box%d" % k, mass=MM.box(he, 2.0 + k))
+        j = FreeJoint(name="BoxRoot%d" % k)
+        j.gpos = Hg.transl(0.6 + 0.5 * k, 0.13 + 0.01 * k, 0.4 - 0.3 * k)
+        w.add_link(w.ground, j, body)
+        w.register(Sphere(body, 0.12, name="Box%d ball" % k))
+    w.register(WeightController())
+    for c in get_all_contacts(w, friction_coeff=.6):
+        s0, s1 = c._shapes
+        if type(s0).__name__ == "Plane" and (s1.name in FOUR or str(s1.name).endswith(" ball")):
+            w.register(c)
+    w.init()
+    m = save_model("human36_obj4", w)
+    assert m.ndof == 66 and m.nc == 8, (m.ndof, m.nc)
+    q0, dq0 = get_state(w, m)
+    dq0 = dq0 + 0.05 * np.random.default_rng(151).standard_normal(m.ndof)
+    set_state(w, m, q0, dq0)
+    dt, nsteps = 5e-3, 30
+    cons = list(w._constraints)
+    qs, dqs, act, frc = [], [], [], []
+    for k in range(nsteps):
+        a, b = get_state(w, m)
+        qs.append(a); dqs.append(b)
+        w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+        act.append([bool(c.is_active()) for c in cons])
+        frc.append([c._force.copy() for c in cons])
+        w.integrate(dt)
+    a, b = get_state(w, m)
+    qs.append(a); dqs.append(b)
+    out.update(human_q=np.array(qs), human_dq=np.array(dqs), human_active=np.array(act), human_force=np.array(frc), human_dt=np.array(dt))
+    save("g15_wide.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     table = dict(g0=gen_primitives, g1=gen_simplearm, g2=gen_human36, g3=gen_contacts,
-                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz, g12=gen_singular_blocks, g13=gen_energy_monitor, g14=gen_user_controller)
+                 g4=gen_snake, g5=gen_energy, g6=gen_constraints, g7=gen_shapes, g8=gen_pd_per_world, g9=gen_parse_order, g10=gen_viscosity, g11=gen_txtytz, g12=gen_singular_blocks, g13=gen_energy_monitor, g14=gen_user_controller, g15=gen_wide)
     for k in which:
         table[k]()

@@ -28,9 +28,11 @@ for nl in (64, 100, 128, 256):
     for B in (256, 2048):
         q, dq = synth.random_states(m, B, seed=0, angle=0.5, vel=1.0)
         leg("snake-%d" % nl, m, q, dq, 1e-3, 16, torch.float64, False)
-w = scenes.human36_and_objects_world(4)
-m, q0, dq0 = flatten_world(w)
-for B in (512, 4096):
-    rng = np.random.default_rng(0)
-    q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1)) + rng.uniform(-0.1, 0.1, (B, m.ndof))
-    leg("human36 + 4 objects", m, q, dq, 5e-3, 40, torch.float32, True)
+for nobj in (4, 12):                     # (66 dofs / 8 contacts: 99 columns; 114 dofs / 16 contacts: 179 columns)
+    w = scenes.human36_and_objects_world(nobj)
+    m, q0, dq0 = flatten_world(w)
+    for B in (512, 4096):
+        rng = np.random.default_rng(0)
+        q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1)) + rng.uniform(-0.1, 0.1, (B, m.ndof))
+        for dtype in (torch.float32, torch.float64):
+            leg("human36 + %d objects" % nobj, m, q, dq, 5e-3, 40, dtype, True)
