@@ -733,7 +733,9 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     upi(d->parent, nb, &W.parent); upi(d->jtype, nb, &W.jtype); upi(d->dof_off, nb, &W.dof_off); upi(jnd.data(), nb, &W.jnd);
     upi(d->q_off, nb, &W.q_off); upi(depth.data(), nb, &W.depth); upi(d->weighted, nb, &W.weighted); upi(dof2q.data(), n, &W.dof2q);
     upi(dofbody.data(), n, &W.dofbody); upi(subsize.data(), nb, &W.subsize);
-    if (maxdepth >= ARB_JUMP_DEPTH) {                         // a deep tree: the ancestor 2^r levels up, for the log-depth chains
+    // (the wide kernels' own threshold: a level of the serial loop costs a workgroup ~2.8 k cycles, a round of the four jumping
+    //  passes ~2 k -- human36's nine levels: 25 k against 10 k)
+    if (maxdepth >= 4) {                                      // the ancestor 2^r levels up, for the log-depth chains
         int rounds = 0;
         while ((1 << rounds) < maxdepth + 1) ++rounds;
         std::vector<int> janc((size_t)rounds * nb, -1);
@@ -779,7 +781,16 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     // (compact: 1 = everything below in LDS, 2 = without the rows of J', 3 = without the admittance of the sweeps as well --
     //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB)
     auto layout = [&](WideModel &L, int compact, size_t *lds_out) {
-        L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = 0;
+        L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = L.vec_in_lds = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = L.l_vec = 0;
+        // the scratch block: state and small vectors first, then per-body wrenches and joint columns (the compact build may keep
+        // these two groups in LDS), then everything else
+        long o = 0;
+        auto take = [&](long cnt) { const long at = o; o += (cnt + 1) & ~1l; return at; };
+        L.o_q = take(d->nq); L.o_dq = take(n); L.o_qd = take(n); L.o_ff = take(std::max(ndol, 1)); L.o_ff0 = take(std::max(ndol, 1));
+        L.o_rh = take(2l * n); L.o_vv = take(std::max(ndol, 1)); L.o_cd = take((long)WIDE_CD * std::max(nc, 1));
+        const long tier1 = o;
+        L.o_pt = take(12l * nb); L.o_sc = take(12l * n);
+        const long tier2 = o;
         if (compact) {
             const int kmax = n <= 80 ? 20 : n <= 112 ? 28 : 32;            // rows per wavefront (four wavefronts)
             L.cp = L.ncols <= 128 ? 2 : 4;                                 // columns per lane
@@ -797,7 +808,14 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             L.kmax = kmax; L.l_am = head; L.l_ac = 24l * nb; L.l_xk = 108l * nb;
             L.l_reg = head + (L.am_in_lds ? ((ndol * ndol + 1) & ~1) : 0);
             L.ac_in_lds = 1; L.chain_in_lds = 1; L.z_in_lds = 0;
-            *lds_out = small + (size_t)(L.l_reg + region) * sizeof(double);
+            L.l_vec = region;
+            size_t lds = small + (size_t)(L.l_reg + region) * sizeof(double);
+            // (the vectors in LDS only where they cost no workgroup per CU: 160 KB / the request, at most four)
+            const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / lds)));
+            const size_t cap = std::min<size_t>(150 * 1024, 160 * 1024 / per_cu);
+            if (lds + tier2 * sizeof(double) <= cap) { L.vec_in_lds = 2; lds += tier2 * sizeof(double); }
+            else if (lds + tier1 * sizeof(double) <= cap) { L.vec_in_lds = 1; lds += tier1 * sizeof(double); }
+            *lds_out = lds;
         } else {
             L.z_in_lds = (size_t)n * L.ld * sizeof(double) + small <= 120 * 1024 ? 1 : 0;
             *lds_out = small + (L.z_in_lds ? (size_t)n * L.ld * sizeof(double) : 0);
@@ -805,15 +823,12 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             L.ac_in_lds = (L.chain_in_lds && 108l * nb <= (long)n * L.ld) ? 1 : 0;  // (phase B's composites behind the live chain arrays)
             L.l_ac = 24l * nb;
         }
-        long o = 0;
-        auto take = [&](long cnt) { const long at = o; o += (cnt + 1) & ~1l; return at; };
-        L.o_q = take(d->nq); L.o_dq = take(n); L.o_qd = take(n); L.o_ff = take(std::max(ndol, 1)); L.o_ff0 = take(std::max(ndol, 1));
         // (the chain arrays, contiguous from o_pose on: pose, twist and pseudo twist -- read until the per-dof vectors are formed -- first)
         L.o_pose = take(12l * nb); L.o_tw = take(6l * nb); L.o_om = take(6l * nb); L.o_pc = take(12l * nb); L.o_rcp = take(12l * nb);
-        L.o_ab = take(6l * nb); L.o_da = take(18l * nb); L.o_tn = take(6l * nb); L.o_bn = take(6l * nb); L.o_pt = take(12l * nb);
-        L.o_sc = take(12l * n); L.o_ac = take(36l * nb); L.o_mc = take(36l * nb); L.o_wc = take(12l * nb); L.o_xk = take((long)WIDE_XK * n);
-        L.o_rh = take(2l * n); L.o_z = take(L.z_in_lds ? 0 : (long)n * L.ld); L.o_jr = take((long)std::max(ndol, 1) * n);
-        L.o_am = take((long)std::max(ndol * ndol, 1)); L.o_vv = take(std::max(ndol, 1)); L.o_cd = take((long)WIDE_CD * std::max(nc, 1));
+        L.o_ab = take(6l * nb); L.o_da = take(18l * nb); L.o_tn = take(6l * nb); L.o_bn = take(6l * nb);
+        L.o_ac = take(36l * nb); L.o_mc = take(36l * nb); L.o_wc = take(12l * nb); L.o_xk = take((long)WIDE_XK * n);
+        L.o_z = take(L.z_in_lds ? 0 : (long)n * L.ld); L.o_jr = take((long)std::max(ndol, 1) * n);
+        L.o_am = take((long)std::max(ndol * ndol, 1));
         L.total = o;
     };
     auto to_device = [&](const WideModel &L, WideModel **dst) {

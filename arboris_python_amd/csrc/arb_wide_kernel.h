@@ -165,6 +165,8 @@ struct WideModel {
     int nb, n, nq, nc, ndol, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds, chain_in_lds;
     int kmax, cp, ac_in_lds, am_in_lds, sld;                  // compact build: rows per lane (0: the LDS / scratch build); what else is in LDS
     long l_ac, l_xk, l_am, l_reg;                                // (offsets, doubles, inside the LDS region behind the sweeps' blocks)
+    int vec_in_lds;                                         // compact build: 1 = the state and the small per-world vectors in LDS, 2 = per-body wrenches and joint columns too
+    long l_vec;
     int jr_in_lds;                                          // compact build: the rows of J' in LDS (under the dead composites)
     long l_jr, l_sol;                                       // ... and where; where the solution columns go after the elimination
     int jrounds;                                            // > 0: a deep tree -- the chain runs in this many pointer-jumping rounds
@@ -235,12 +237,15 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     // depth level of a serial chain is a dependent round trip, 100 of them for snake-100.  Everything that reads them comes
     // before the assembly of Z.
     double *CHB = M.chain_in_lds ? ZL : S + M.o_pose;
-    double *QS = S + M.o_q, *DQS = S + M.o_dq, *QD = S + M.o_qd, *FF = S + M.o_ff, *FF0 = S + M.o_ff0, *POSE = CHB,
+    // (the scratch block begins with the state and the small vectors, then the per-body wrenches and the joints' columns: the
+    //  compact build keeps them in LDS where that costs no workgroup per CU -- every one of them is an L2 round trip otherwise)
+    double *V1 = M.vec_in_lds >= 1 ? ZL + M.l_vec : S, *V2 = M.vec_in_lds >= 2 ? ZL + M.l_vec : S;
+    double *QS = V1 + M.o_q, *DQS = V1 + M.o_dq, *QD = V1 + M.o_qd, *FF = V1 + M.o_ff, *FF0 = V1 + M.o_ff0, *POSE = CHB,
            *PC = CHB + (M.o_pc - M.o_pose), *RCP = CHB + (M.o_rcp - M.o_pose), *TW = CHB + (M.o_tw - M.o_pose), *AB = CHB + (M.o_ab - M.o_pose),
            *OM = CHB + (M.o_om - M.o_pose), *DA = CHB + (M.o_da - M.o_pose), *TN = CHB + (M.o_tn - M.o_pose), *BN = CHB + (M.o_bn - M.o_pose),
-           *PT = S + M.o_pt, *SC = S + M.o_sc, *AC = M.ac_in_lds ? ZL + M.l_ac : S + M.o_ac, *MC = M.ac_in_lds ? AC + 36 * nb : S + M.o_mc,
-           *WC = M.ac_in_lds ? AC + 72 * nb : S + M.o_wc, *XK = REGZ ? ZL + M.l_xk : S + M.o_xk, *RH = S + M.o_rh, *JR = M.jr_in_lds ? ZL + M.l_jr : S + M.o_jr,
-           *AM = M.am_in_lds ? GAM : S + M.o_am, *VV = S + M.o_vv, *CD = S + M.o_cd;
+           *PT = V2 + M.o_pt, *SC = V2 + M.o_sc, *AC = M.ac_in_lds ? ZL + M.l_ac : S + M.o_ac, *MC = M.ac_in_lds ? AC + 36 * nb : S + M.o_mc,
+           *WC = M.ac_in_lds ? AC + 72 * nb : S + M.o_wc, *XK = REGZ ? ZL + M.l_xk : S + M.o_xk, *RH = V1 + M.o_rh, *JR = M.jr_in_lds ? ZL + M.l_jr : S + M.o_jr,
+           *AM = M.am_in_lds ? GAM : S + M.o_am, *VV = V1 + M.o_vv, *CD = V1 + M.o_cd;
     double *Z = M.z_in_lds ? ZL : S + M.o_z;
     // the solution columns [Y rhs | Y J'^T] after the elimination: inside Z, or (compact build) written out of the registers
     const double *SL = REGZ ? ZL + M.l_sol : Z + n;

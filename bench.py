@@ -270,10 +270,10 @@ def build_model(cfg):
     from arboris_python_amd import scenes
     if cfg["model"] == "snake64":
         return scenes.flat(scenes.snake_world(64))
-    if cfg["model"] == "snake100":
-        return scenes.flat(scenes.snake_world(100))
+    if cfg["model"] in ("snake100", "snake128"):
+        return scenes.flat(scenes.snake_world(int(cfg["model"][5:])))
     if cfg["model"] == "human36_objects":
-        return scenes.flat(scenes.human36_and_objects_world(4))
+        return scenes.flat(scenes.human36_and_objects_world(cfg.get("objects", 4)))
     return scenes.flat(scenes.human36_world(cfg["contacts"], pd=bool(cfg.get("pd"))))
 
 
@@ -286,14 +286,14 @@ def make_states(cfg, model, lo, hi, seed):
         import numpy as np
         from arboris_python_amd import scenes
         from arboris_python_amd.flatten import flatten_world
-        _, q0, dq0 = flatten_world(scenes.human36_and_objects_world(4))
+        _, q0, dq0 = flatten_world(scenes.human36_and_objects_world(cfg.get("objects", 4)))
         q = np.tile(q0, (hi - lo, 1))
         dq = np.stack([dq0 + np.random.default_rng([seed, w]).uniform(-0.1, 0.1, size=len(dq0)) for w in range(lo, hi)])
         return q, dq
     if cfg["states"] == "standing":
         # config 3/5 distribution: standing pose dropped from U(0, 3 cm), small velocities
         return synth.world_states(model, range(lo, hi), "standing", seed, drop=0.03, vel=0.1)
-    if cfg["model"] in ("snake64", "snake100"):
+    if cfg["model"] in ("snake64", "snake100", "snake128"):
         return synth.world_states(model, range(lo, hi), "random", seed, angle=0.5, vel=1.0)
     # config 2: random poses, hinge angles U(-0.7, 0.7) rad, velocities U(-1, 1).  (More energetic draws -- angle 1,
     # velocities 3, the generator's defaults -- send the reference's own time stepping beyond 100 rad/s within 40 steps
@@ -744,9 +744,14 @@ def main():
         wide = {}
         for key, c_ in (("snake100", dict(model="snake100", contacts=0, batch=1024, dtype="f64", dt=1e-3, episode=16, states="random",
                                           name="snake-100 (100 Rz joints): past the 64 lanes of a wavefront, the wide kernels")),
+                        ("snake128", dict(model="snake128", contacts=0, batch=1024, dtype="f64", dt=1e-3, episode=16, states="random",
+                                          name="snake-128: 129 columns, the compact wide build with four columns per lane")),
                         ("human36_and_4_objects", dict(model="human36_objects", contacts=8, batch=1024, dtype="f32", dt=5e-3, episode=40,
                                                        states="standing", name="human36 on four floor contacts beside four free boxes "
-                                                                               "with a ball each on the floor: 66 dofs, 8 contacts, the wide kernels"))):
+                                                                               "with a ball each on the floor: 66 dofs, 8 contacts, the wide kernels")),
+                        ("human36_and_12_objects", dict(model="human36_objects", objects=12, contacts=16, batch=1024, dtype="f32", dt=5e-3,
+                                                        episode=40, states="standing", name="human36 beside twelve free boxes: 114 dofs, "
+                                                                                            "16 contacts (179 columns), the wide kernels"))):
             wide[key] = timed_leg(BatchedWorlds, torch, np, local_rank, c_, 0.4, seed=0, min_launches=3)
         res["wide_worlds"] = wide
         # human36 OUTSIDE the model class of the specialised headline kernels (round 4 review: what does a caller get whose
