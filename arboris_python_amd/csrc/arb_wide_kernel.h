@@ -102,9 +102,16 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
         // the whole array -- an address, and the registers become scratch memory)
         asm volatile("" : "+s"(ej));
         WIDE_STAMP(0);
+        // (the owner scales the row: its reciprocal chain hides under the readlanes below, the other wavefronts read t itself)
+        double t[CP];
         if (zg == gj) {
 #pragma unroll
-            for (int p = 0; p < CP; ++p) rb[l + 64 * p] = wide_reg_get<0, NCH, NCH>(z[p], cj, ej);
+            for (int p = 0; p < CP; ++p) t[p] = wide_reg_get<0, NCH, NCH>(z[p], cj, ej);
+            const double own = j < 64 ? t[0] : t[1];                 // (pivots are columns j < n <= 128)
+            const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(own), j & 63), __builtin_amdgcn_readlane(__double2loint(own), j & 63));
+            const double ip = arb_rcp(piv);
+#pragma unroll
+            for (int p = 0; p < CP; ++p) { t[p] = t[p] * ip; rb[l + 64 * p] = t[p]; }
         }
         WIDE_STAMP(1);
         // the multipliers of this wavefront's rows are the registers of ITS lane j & 63 (column j): broadcast through scalar
@@ -128,10 +135,10 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
         WIDE_STAMP(2);
         __syncthreads();
         WIDE_STAMP(3);
-        const double ip = arb_rcp(rb[j]);
-        double t[CP];
+        if (zg != gj) {
 #pragma unroll
-        for (int p = 0; p < CP; ++p) t[p] = rb[l + 64 * p] * ip;
+            for (int p = 0; p < CP; ++p) t[p] = rb[l + 64 * p];
+        }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
