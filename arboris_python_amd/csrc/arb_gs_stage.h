@@ -18,9 +18,24 @@ template <typename T, int MODE, typename G = T, bool ALLOW_FAST = true, bool SPE
 // the 32 banks: eight-way conflicts, 28 extra LDS cycles per solve, 80 solves per step -- 370 M of the 438 M conflict cycles per
 // launch that SQ_LDS_BANK_CONFLICT had counted since round 3 (28 % of the LDS-active cycles).  With rows of 4 nc + 4 floats
 // read as ONE 16-byte vector the 16 / 32 rows lie in distinct 16-byte slots of the 256-byte bank row: conflict-free.
+#ifndef ARB_GS_NOINLINE
+#define ARB_GS_NOINLINE 0       // 1 (development): the stage as a function of its own -- measured round 6, same bits: classical columns +2.8 %, the headline (body-space columns) -1.1 %, the 64-row mixed build loses a wave per SIMD to the callee's registers: not adopted
+#endif
+#if ARB_GS_NOINLINE
+__device__ __attribute__((noinline)) void gs_stage(const DevModel<T> *mp, const int lane, const int nc_, const int ndol_, const int lda_, const T dt_t,
+                                         const T inv_dt_t, const T *AM_, T *CD_, T *VV_, T *FF_, T *WORK_,
+                                         const DebugOut<T> &dbg, const long w) {
+    // (arguments arrive in vector registers; LDS pointers as generic pointers: back to scalars and to LDS offsets)
+    const int nc = __builtin_amdgcn_readfirstlane(nc_), ndol = __builtin_amdgcn_readfirstlane(ndol_), lda = __builtin_amdgcn_readfirstlane(lda_);
+    T *const lds0_ = reinterpret_cast<T *>(arb_lds_raw);
+    const T *AM = lds0_ + __builtin_amdgcn_readfirstlane((int)(AM_ - lds0_));
+    T *CD = lds0_ + __builtin_amdgcn_readfirstlane((int)(CD_ - lds0_)), *VV = lds0_ + __builtin_amdgcn_readfirstlane((int)(VV_ - lds0_)),
+      *FF = lds0_ + __builtin_amdgcn_readfirstlane((int)(FF_ - lds0_)), *WORK = lds0_ + __builtin_amdgcn_readfirstlane((int)(WORK_ - lds0_));
+#else
 __device__ __forceinline__ void gs_stage(const DevModel<T> *mp, const int lane, const int nc, const int ndol, const int lda, const T dt_t,
                                          const T inv_dt_t, const T *AM, T *CD, T *VV, T *FF, T *WORK,
                                          const DebugOut<T> &dbg, const long w) {
+#endif
     constexpr bool SAME = std::is_same<T, G>::value;
     const G dt = (G)dt_t, inv_dt = SAME ? (G)inv_dt_t : G(1) / (G)dt_t;
     // (pseudo-)inverse of every active constraint's own admittance block (once per step): pinv(Y_cc) of
