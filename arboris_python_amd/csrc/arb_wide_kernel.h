@@ -270,6 +270,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     while (cwn < n && cwn < WIDE_THREADS) cwn <<= 1;
     const int cl_n = tid & (cwn - 1), r0_n = tid / cwn, rs_n = WIDE_THREADS / cwn;
 
+    // (deep trees: this lane's ancestors 2^r levels up, once per launch -- read per round they are an L2 round trip each, 28 per step)
+    int janc_r[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (int r = 0; r < 8; ++r) if (r < M.jrounds && tid < nb) janc_r[r] = M.janc[r * nb + tid];
+
     for (long w = blockIdx.x; w < nworlds; w += gridDim.x) {
     __syncthreads();
     for (int i = tid; i < nq; i += WIDE_THREADS) QS[i] = (double)io.q[w * nq + i];
@@ -350,8 +354,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             const int par = on ? M.parent[b] : -1;
             if (on) for (int i = 0; i < 12; ++i) POSE[12 * b + i] = PC[12 * b + i];
             __syncthreads();
-            for (int r = 0; r < M.jrounds; ++r) {
-                const int a = on ? M.janc[r * nb + b] : -1;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r >= M.jrounds) break;
+                const int a = janc_r[r];
                 M3<double> Ra = m3_identity<double>(); V3<double> pa = v3<double>(0., 0., 0.);
                 if (a >= 0) { Ra = ldm(POSE + 12 * a); pa = ld3(POSE + 12 * a + 9); }
                 __syncthreads();
@@ -364,8 +370,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             }
             auto jump_sum = [&](double *arr) {          // inclusive sum over the ancestors of the 6-vectors of `arr`
                 __syncthreads();
-                for (int r = 0; r < M.jrounds; ++r) {
-                    const int a = on ? M.janc[r * nb + b] : -1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r >= M.jrounds) break;
+                    const int a = janc_r[r];
                     double add6[6] = {0., 0., 0., 0., 0., 0.};
                     if (a >= 0) for (int i = 0; i < 6; ++i) add6[i] = arr[6 * a + i];
                     __syncthreads();
@@ -635,12 +643,28 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         }
         __syncthreads();
         // ---- subtree sums: lane = entry, bodies from the leaves to the roots (parent[b] < b) ------------------------
-        for (int e = tid; e < 84; e += WIDE_THREADS) {
-            double *arr = e < 36 ? AC : e < 72 ? MC : WC;
-            const int st = e < 72 ? 36 : 12, off = e < 36 ? e : e < 72 ? e - 36 : e - 72;
-            for (int b = nb - 1; b >= 1; --b) {
-                const int par = M.parent[b];
-                if (par >= 0) arr[st * par + off] += arr[st * b + off];
+        // (the parents from LDS -- the pivot-row buffer is free here --, the next body's entry and parent read before this body's sum
+        // is stored, and a body whose parent is the body before it -- every link of a chain, the first child of any body -- hands
+        // its sum over in a register: the same additions in the same order, without a dependent LDS write -> read per body)
+        {
+            int *PARL = reinterpret_cast<int *>(TROW);
+            for (int b = tid; b < nb; b += WIDE_THREADS) PARL[b] = M.parent[b];
+            __syncthreads();
+            for (int e = tid; e < 84; e += WIDE_THREADS) {
+                double *arr = e < 36 ? AC : e < 72 ? MC : WC;
+                const int st = e < 72 ? 36 : 12, off = e < 36 ? e : e < 72 ? e - 36 : e - 72;
+                double carry = 0., cur = arr[st * (nb - 1) + off];
+                int carry_to = -1, par = PARL[nb - 1];
+                for (int b = nb - 1; b >= 1; --b) {
+                    const double nxt = arr[st * (b - 1) + off];          // (nothing below writes entry b - 1 in this iteration)
+                    const int par_nxt = PARL[b - 1];
+                    const double v = carry_to == b ? cur + carry : cur;
+                    if (carry_to == b) arr[st * b + off] = v;
+                    if (par == b - 1) { carry = v; carry_to = par; }
+                    else { if (par >= 0) arr[st * par + off] += v; carry_to = -1; }
+                    cur = nxt; par = par_nxt;
+                }
+                if (carry_to == 0) arr[off] = cur + carry;
             }
         }
         __syncthreads();
@@ -708,7 +732,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             for (int r = 0; r < 12; ++r) x0[r] = xc[r];
             for (int r = 0; r < 6; ++r) xg[r] = xc[24 + r];
             const double bk = xc[30], bke = xc[31];              // (the body of the column's dof, the end of its subtree)
-            for (int i = r0_n; i < n; i += rs_n) {
+            const auto entry = [&](const int i) {
                 const double *xi = XK + WIDE_XK * i;
                 double a[6], pp[6], rr[6];
                 for (int r = 0; r < 6; ++r) { a[r] = xi[r]; pp[r] = xi[12 + r]; rr[r] = xi[18 + r]; }
@@ -722,8 +746,15 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     else if (M.has_pd) v += dt * M.pd_kp[i * n + c] + M.pd_kd[i * n + c];     // controllers.py:141-158
                     if (io.zimp != nullptr) v -= (double)io.zimp[((long)w * n + i) * n + c];  // core.py:815-817
                 }
-                Z[i * ld + c] = v;
+                return v;
+            };
+            // (four rows side by side: a row's sums are dependent chains of float64 operations, ~900 cycles a row one at a time)
+            int i = r0_n;
+            for (; i + 3 * rs_n < n; i += 4 * rs_n) {
+                const double v0 = entry(i), v1 = entry(i + rs_n), v2 = entry(i + 2 * rs_n), v3 = entry(i + 3 * rs_n);
+                Z[i * ld + c] = v0; Z[(i + rs_n) * ld + c] = v1; Z[(i + 2 * rs_n) * ld + c] = v2; Z[(i + 3 * rs_n) * ld + c] = v3;
             }
+            for (; i < n; i += rs_n) Z[i * ld + c] = entry(i);
         }
         if (io.inspect && io.zmode != 0) {           // the world matrices M, B, N one by one (the object API): Zout and on to the next world
             __syncthreads();
