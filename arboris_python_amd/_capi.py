@@ -32,7 +32,7 @@ ARB_STEP_BODY_COLUMNS = 1024
 ARB_STEP_MIXED = 2048
 ARB_STEP_NO_MIXED = 4096
 ARB_STEP_CLASSIC_COLUMNS = 8192
-ARB_WIDE_MAX = 256
+ARB_WIDE_MAX = 1024
 ARB_WARN_ILLCOND = 1
 ARB_ILLCOND_GROWTH = 2048.0
 

@@ -735,7 +735,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     upi(dofbody.data(), n, &W.dofbody); upi(subsize.data(), nb, &W.subsize);
     // (the wide kernels' own threshold: a level of the serial loop costs a workgroup ~2.8 k cycles, a round of the four jumping
     //  passes ~2 k -- human36's nine levels: 25 k against 10 k)
-    if (maxdepth >= 4) {                                      // the ancestor 2^r levels up, for the log-depth chains
+    if (maxdepth >= 4 && maxdepth < 256 && nb <= 256) {       // the ancestor 2^r levels up, for the log-depth chains (lane = body, <= 8 rounds)
         int rounds = 0;
         while ((1 << rounds) < maxdepth + 1) ++rounds;
         std::vector<int> janc((size_t)rounds * nb, -1);
@@ -863,7 +863,9 @@ static int wide_launch(arb_model *M, const WideIO<T> &io_in, long nw, double dt,
     io.gs_serial = M->kn.wide_gs_groups == 0;
     const size_t lds = compact ? M->wide_c_lds : M->wide_lds;
     const long per_cu = std::max(1l, std::min(4l, (long)(160 * 1024 / std::max<size_t>(lds, 1))));
-    const unsigned grid = (unsigned)std::min<long>(nw, per_cu * std::max(1, device_cus(M->device)));
+    // (at most 2 GB of scratch per launch: a 1024-dof world's block is 8.5 MB)
+    const long by_scratch = std::max(1l, (long)((2048l << 20) / ((size_t)L.total * sizeof(double))));
+    const unsigned grid = (unsigned)std::min<long>(std::min<long>(nw, by_scratch), per_cu * std::max(1, device_cus(M->device)));
     void *ws = nullptr;
     HIP_TRY(arb_scratch_alloc(&ws, (size_t)grid * (size_t)L.total * sizeof(double), st));
     const WideModel *dev = compact ? M->wide_c_dev : M->wide_dev;

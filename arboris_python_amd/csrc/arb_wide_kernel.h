@@ -12,7 +12,7 @@
 //     and column of the elimination;
 //   * lane = body / dof / constraint / matrix entry as the phase needs, __syncthreads() between phases;
 //   * workgroups loop over the worlds of the batch (grid = min(worlds, 2 per CU)), steps loop inside.
-// Limits: ndof, nb <= ARB_WIDE_MAX (256), nc <= 64.  Inputs: everything arb_step_ex takes -- state, constraint forces, user
+// Limits: ndof, nb <= ARB_WIDE_MAX (1024), nc <= 64.  Inputs: everything arb_step_ex takes -- state, constraint forces, user
 // torques (constant or a sequence), the dense impedance of user-defined controllers, per-world PD targets / gains (and target
 // sequences), per-step dt, state and energy logs, the running cost; the model's merged PD controllers.
 // Not supported (ARB_ERR_UNSUPPORTED): the execution variants of the wavefront kernels (split sweeps, matrix-core elimination).

@@ -223,9 +223,16 @@ def flatten_world(world, positions=True, host_controllers=None):
     ndof = 0
     nq = 0
 
-    def visit(body, body_index):
-        nonlocal ndof, nq
-        for j in body.childrenjoints:
+    # (depth-first without recursion: a chain of a thousand links is deeper than the interpreter's recursion limit)
+    index_of[id(world.ground)] = -1
+    stack = [(-1, iter(world.ground.childrenjoints))]
+    while stack:
+        body_index, joints = stack[-1]
+        j = next(joints, None)
+        if j is None:
+            stack.pop()
+            continue
+        if True:
             f0, f1 = j._frame0, j._frame1
             child = f1.body
             (tid, k, kq) = _joint_type(j)
@@ -248,10 +255,7 @@ def flatten_world(world, positions=True, host_controllers=None):
             m.joint_names.append(j.name)
             q0.append(np.array(j.gpos, dtype=np.float64).ravel())
             dq0.append(np.array(j.gvel, dtype=np.float64).ravel())
-            visit(child, idx)
-
-    index_of[id(world.ground)] = -1
-    visit(world.ground, -1)
+            stack.append((idx, iter(child.childrenjoints)))
 
     m.nb, m.ndof, m.nq = len(bodies), ndof, nq
     m.up = np.array(world.up, dtype=float)

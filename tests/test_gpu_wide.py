@@ -161,21 +161,35 @@ def test_human36_beside_four_free_objects_66_dofs():
 
 
 def test_limits_of_the_wide_path():
-    """ndof, nb <= ARB_WIDE_MAX = 256: snake-256 steps; snake-257 is refused with ARB_ERR_UNSUPPORTED (the reference would
+    """ndof, nb <= ARB_WIDE_MAX = 1024 (past 128 dofs the augmented system lives in scratch: a capability): snake-256 steps,
+    snake-300 steps and satisfies the step equation, snake-1025 is refused with ARB_ERR_UNSUPPORTED (the reference would
     allocate it)."""
     import ctypes as C
     from arboris_python_amd import scenes, synth
     from arboris_python_amd.batch import BatchedWorlds
-    m = scenes.flat(scenes.snake_world(256))
-    bw = BatchedWorlds(m)
-    assert bw.info["wide"] == 1
-    q, dq = synth.random_states(m, 3, seed=1, angle=0.3, vel=0.5)
-    tq, tdq = bw.to_device(q, dq, torch.float64)
-    bw.step(tq, tdq, 1e-3, 2)
-    torch.cuda.synchronize()
-    assert torch.isfinite(tq).all() and torch.isfinite(tdq).all()
-    bw.close()
-    m2 = scenes.flat(scenes.snake_world(257))
+    assert _capi.ARB_WIDE_MAX == 1024
+    for nl in (256, 300):
+        m = scenes.flat(scenes.snake_world(nl))
+        bw = BatchedWorlds(m)
+        assert bw.info["wide"] == 1
+        q, dq = synth.random_states(m, 3, seed=1, angle=0.3, vel=0.5)
+        tq, tdq = bw.to_device(q, dq, torch.float64)
+        dt = 1e-3
+        bw.step(tq, tdq, dt, 1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(tq).all() and torch.isfinite(tdq).all()
+        # the step equation Z dq+ = M dq / dt + gforce (core.py:818-824) with the oracle's Z and right-hand side
+        dyn = O.update_dynamic(m, q, dq)
+        gf, Z, _ = O.update_controllers(m, dyn, q, dq, dt)
+        rhs = (dyn["M"] @ dq[..., None])[..., 0] / dt + gf
+        res = np.abs((Z @ tdq.cpu().numpy()[..., None])[..., 0] - rhs).max(axis=1) / np.abs(rhs).max(axis=1)
+        print("snake-%d: residual of the step equation %.1e" % (nl, res.max()))
+        assert res.max() < 1e-11
+        bw.step(tq, tdq, dt, 2)
+        torch.cuda.synchronize()
+        assert torch.isfinite(tdq).all()
+        bw.close()
+    m2 = scenes.flat(scenes.snake_world(1025))
     desc, keep = _capi.make_desc(m2)
     h = C.c_void_p()
     assert _capi.load().arb_model_create(C.byref(desc), 0, C.byref(h)) == 2
