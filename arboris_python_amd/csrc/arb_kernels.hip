@@ -770,7 +770,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         if (e != hipSuccess) { g_hip_err = std::string("status word: ") + hipGetErrorString(e); arb_model_destroy(M); return ARB_ERR_HIP; }
         W.status = static_cast<int *>(dp); W.warn = static_cast<int *>(dp) + 1;
     }
-    // Two layouts of one world's data, the same tables behind both.  The COMPACT build (arb_wide_kernel.h; at most 128 dofs and
+    // Two layouts of one world's data, the same tables behind both.  The COMPACT build (arb_wide_kernel.h; at most 192 dofs and
     // 256 columns): the system in registers, LDS for the rest -- pivot hand-over buffers, the admittance of the sweeps, then one
     // region for chain arrays (24 nb doubles live to the end of phase B + 60 nb dead by then, under the 84 nb of phase B's
     // composites) and per-dof vectors, which the solution columns take over.  Otherwise: the system in LDS when it fits beside
@@ -779,7 +779,8 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 59 * nc) * sizeof(double);
     W.sld = (1 + ndol) | 1;
     // (compact: 1 = everything below in LDS, 2 = without the rows of J', 3 = without the admittance of the sweeps as well --
-    //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB)
+    //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB --, 4 .. 6 = the same with the chain arrays and
+    //  phase B's composites in scratch: what many BODIES ask for, 108 doubles each)
     auto layout = [&](WideModel &L, int compact, size_t *lds_out) {
         L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = L.vec_in_lds = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = L.l_vec = 0;
         // the scratch block: state and small vectors first, then per-body wrenches and joint columns (the compact build may keep
@@ -792,22 +793,24 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         L.o_pt = take(12l * nb); L.o_sc = take(12l * n);
         const long tier2 = o;
         if (compact) {
-            const int kmax = n <= 80 ? 20 : n <= 112 ? 28 : 32;            // rows per wavefront (four wavefronts)
+            const int kmax = n <= 80 ? 20 : n <= 112 ? 28 : n <= 128 ? 32 : n <= 160 ? 40 : 48;     // rows per wavefront (four wavefronts)
             L.cp = L.ncols <= 128 ? 2 : 4;                                 // columns per lane
             // (the rows of J' under the composites, dead by the time they are written, when they fit; the solution columns
             //  behind them -- the per-dof vectors, read while J' is written, lie past 108 nb)
             const long jrsz = ((long)ndol * n + 1) & ~1l;
-            const bool under = ndol > 0 && jrsz <= 84l * nb;
-            L.jr_in_lds = (ndol > 0 && compact == 1) ? 1 : 0;
-            L.am_in_lds = compact <= 2 ? 1 : 0;
+            const bool bodies = compact <= 3;                    // (chain arrays and composites in LDS)
+            const int sub = bodies ? compact : compact - 3;
+            const bool under = bodies && ndol > 0 && jrsz <= 84l * nb;
+            L.jr_in_lds = (ndol > 0 && sub == 1) ? 1 : 0;
+            L.am_in_lds = sub <= 2 ? 1 : 0;
             L.l_sol = (L.jr_in_lds && under) ? 24l * nb + jrsz : 0;
-            long region = std::max(108l * nb + (long)WIDE_XK * n, L.l_sol + (long)n * L.sld);
+            long region = std::max((bodies ? 108l * nb : 0l) + (long)WIDE_XK * n, L.l_sol + (long)n * L.sld);
             L.l_jr = under ? 24l * nb : region;                  // (... or a place of their own)
             if (L.jr_in_lds && !under) region += jrsz;
             const long head = 2l * 64 * L.cp;                               // (the pivot rows, double-buffered)
-            L.kmax = kmax; L.l_am = head; L.l_ac = 24l * nb; L.l_xk = 108l * nb;
+            L.kmax = kmax; L.l_am = head; L.l_ac = 24l * nb; L.l_xk = bodies ? 108l * nb : 0;
             L.l_reg = head + (L.am_in_lds ? ((ndol * ndol + 1) & ~1) : 0);
-            L.ac_in_lds = 1; L.chain_in_lds = 1; L.z_in_lds = 0;
+            L.ac_in_lds = bodies ? 1 : 0; L.chain_in_lds = bodies ? 1 : 0; L.z_in_lds = 0;
             L.l_vec = region;
             size_t lds = small + (size_t)(L.l_reg + region) * sizeof(double);
             // (the vectors in LDS only where they cost no workgroup per CU: 160 KB / the request, at most four)
@@ -841,9 +844,9 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     };
     layout(W, 0, &M->wide_lds);
     rc = to_device(W, &M->wide_dev);
-    if (rc == ARB_OK && n <= 128 && W.ncols <= 256) {
+    if (rc == ARB_OK && n <= 192 && W.ncols <= 256) {
         M->wide_c = W;
-        for (int level = 1; level <= 3; ++level) {
+        for (int level = 1; level <= 6; ++level) {
             layout(M->wide_c, level, &M->wide_c_lds);
             if (M->wide_c_lds <= 150 * 1024) { rc = to_device(M->wide_c, &M->wide_c_dev); break; }
         }
@@ -872,7 +875,8 @@ static int wide_launch(arb_model *M, const WideIO<T> &io_in, long nw, double dt,
 #define ARB_WIDE_GO(K, P) wide_launch_one<T, K, P>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
     const hipError_t le = L.kmax == 0 ? ARB_WIDE_GO(0, 2)
                         : L.cp == 2 ? (L.kmax == 20 ? ARB_WIDE_GO(20, 2) : L.kmax == 28 ? ARB_WIDE_GO(28, 2) : ARB_WIDE_GO(32, 2))
-                                    : (L.kmax == 20 ? ARB_WIDE_GO(20, 4) : L.kmax == 28 ? ARB_WIDE_GO(28, 4) : ARB_WIDE_GO(32, 4));
+                                    : (L.kmax == 20 ? ARB_WIDE_GO(20, 4) : L.kmax == 28 ? ARB_WIDE_GO(28, 4) : L.kmax == 32 ? ARB_WIDE_GO(32, 4)
+                                       : L.kmax == 40 ? ARB_WIDE_GO(40, 4) : ARB_WIDE_GO(48, 4));
 #undef ARB_WIDE_GO
     (void)hipFreeAsync(ws, st);
     if (le != hipSuccess) { g_hip_err = std::string("kernel launch: ") + hipGetErrorString(le); return ARB_ERR_HIP; }

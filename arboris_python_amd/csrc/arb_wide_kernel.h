@@ -17,13 +17,14 @@
 // sequences), per-step dt, state and energy logs, the running cost; the model's merged PD controllers.
 // Not supported (ARB_ERR_UNSUPPORTED): the execution variants of the wavefront kernels (split sweeps, matrix-core elimination).
 //
-// The COMPACT build (KMAX > 0; worlds of at most 128 dofs and 128 columns: snake-100, human36 beside a few objects) keeps the
-// augmented system in REGISTERS: lane (c, g) = column c of 128, rows g, g + 2, g + 4 ... (KMAX of them) of that column.  A
-// pivot is then one hand-over through LDS (the pivot row from the lanes that hold it, the pivot column from the lanes of that
-// column; double-buffered, one barrier) and KMAX fused multiply-adds per lane on registers -- against a round trip through LDS
-// per entry of the LDS-resident elimination (690 k of snake-100's 970 k cycles per step before).  LDS then has room for
-// everything else a step touches: the chain arrays, the composites of phase B, the per-dof vectors X_k .. G_k, the solution
-// columns, the admittance of the sweeps.
+// The COMPACT build (KMAX > 0; worlds of at most 192 dofs and 256 columns: snake-100, human36 beside a few objects) keeps the
+// augmented system in REGISTERS: wavefront g of the four holds rows g, g + 4, ... (KMAX of them), lane l the columns l, l + 64, ...
+// (CP of them), see wide_eliminate below.  A pivot is then one hand-over of the pivot row through LDS (double-buffered, one
+// barrier), the multipliers by v_readlane from the wavefront's own lane, and KMAX x CP fused multiply-adds per lane on registers --
+// against a round trip through LDS per entry of the LDS-resident elimination (690 k of snake-100's 970 k cycles per step
+// before).  LDS then has room for everything else a step touches: the chain arrays, the composites of phase B, the per-dof
+// vectors X_k .. G_k, the rows of J', the solution columns, the admittance of the sweeps, the state (each group falls back to the
+// scratch block when a world's size asks for it: the layout levels of wide_create, arb_kernels.hip).
 #ifndef ARB_WIDE_KERNEL_H
 #define ARB_WIDE_KERNEL_H
 #define WIDE_THREADS 256
@@ -107,7 +108,8 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
         if (zg == gj) {
 #pragma unroll
             for (int p = 0; p < CP; ++p) t[p] = wide_reg_get<0, NCH, NCH>(z[p], cj, ej);
-            const double own = j < 64 ? t[0] : t[1];                 // (pivots are columns j < n <= 128)
+            double own = j < 64 ? t[0] : t[1];                       // (pivots are columns j < n <= 192: the lane's first three)
+            if constexpr (CP > 2) own = j < 128 ? own : t[2];
             const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(own), j & 63), __builtin_amdgcn_readlane(__double2loint(own), j & 63));
             const double ip = arb_rcp(piv);
 #pragma unroll
@@ -119,19 +121,13 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
         // take them as scalar operands.  (Before the barrier: independent of it.)
         const int lj = j & 63;
         wide_d4 f[NCH];
-        if (j < 64) {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z[0][ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(z[0][ch][e]), lj));
-        } else {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z[1][ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(z[1][ch][e]), lj));
-        }
+#define WIDE_MULT(P)                                                                                                                 \
+        _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch) _Pragma("unroll") for (int e = 0; e < 4; ++e)                               \
+            f[ch][e] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(z[P][ch][e]), lj), __builtin_amdgcn_readlane(__double2loint(z[P][ch][e]), lj));
+        if (j < 64) { WIDE_MULT(0) }
+        else if (CP == 2 || j < 128) { WIDE_MULT(1) }
+        else { WIDE_MULT(CP > 2 ? 2 : 1) }
+#undef WIDE_MULT
         WIDE_STAMP(2);
         __syncthreads();
         WIDE_STAMP(3);
@@ -1122,6 +1118,7 @@ template hipError_t wide_launch_one<double, ARB_PART_WIDE, ARB_PART_WIDE_CP>(ARB
     extern template hipError_t wide_launch_one<float, K, P>(ARB_WIDE_ONE_ARGS(float)); \
     extern template hipError_t wide_launch_one<double, K, P>(ARB_WIDE_ONE_ARGS(double));
 ARB_EXTERN_WIDE(0, 2) ARB_EXTERN_WIDE(20, 2) ARB_EXTERN_WIDE(28, 2) ARB_EXTERN_WIDE(32, 2) ARB_EXTERN_WIDE(20, 4) ARB_EXTERN_WIDE(28, 4) ARB_EXTERN_WIDE(32, 4)
+ARB_EXTERN_WIDE(40, 4) ARB_EXTERN_WIDE(48, 4)
 #undef ARB_EXTERN_WIDE
 #endif
 #endif  // ARB_WIDE_KERNEL_H

@@ -495,7 +495,7 @@ int arb_inspect(arb_model *m, int dtype, const void *q, const void *dq,
  * modified; nsteps is ignored: one step).  Control sequences, dt_steps, log and cost are refused (ARB_ERR_INVALID). */
 int arb_inspect_ex(arb_model *m, int dtype, const arb_step_args *args, const arb_inspect_out *out, void *stream);
 
-#define ARB_WIDE_MAX 1024  /* (ABI 8) largest ndof / nb of a world (the wide kernels: one workgroup of 256 lanes per world; past 128 dofs the
+#define ARB_WIDE_MAX 1024  /* (ABI 8) largest ndof / nb of a world (the wide kernels: one workgroup of 256 lanes per world; past 192 dofs the
                               * augmented system lives in scratch memory: a capability, ~n^3 slower) */
 
 #ifdef __cplusplus

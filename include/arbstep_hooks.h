@@ -59,7 +59,7 @@ int arb_build_variants(void);
  *   "gsw_waves" (3)             the split execution's sweep kernel: 3 | 4 waves per SIMD
  *   "ablate" (0)                inspect kernels: bit 3 = run all 20 Gauss-Seidel sweeps (no fixed-point exit)
  *   "wide_compact" (1)          wide kernels (worlds past 64 dofs): 0 = the build that keeps the augmented system in LDS / scratch
- *                               where the compact build (system in registers; <= 128 dofs, <= 256 columns) is the default
+ *                               where the compact build (system in registers; <= 192 dofs, <= 256 columns) is the default
  *   "wide_gs_groups" (1)        wide kernels: 0 = one serial sequence of Gauss-Seidel solves over all constraints instead of the
  *                               independent groups side by side (both knobs: bit-identical results, tests/test_gpu_wide.py)
  * Returns ARB_OK, or ARB_ERR_INVALID for an unknown name.  Applies to the handle's forest as well. */

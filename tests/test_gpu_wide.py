@@ -269,23 +269,24 @@ def test_wide_worlds_take_every_input_of_arb_step_ex():
     bw.close()
 
 
-@pytest.mark.parametrize("scene", ["snake100", "snake128", "human36+4", "human36+12", "random", "random:1003:100", "random:1005:100",
+@pytest.mark.parametrize("scene", ["snake100", "snake128", "snake140", "snake192", "human36+4", "human36+12", "human36+16", "random",
+                                   "random:1003:100", "random:1005:100",
                                    "random:1010:100", "random:1003:200", "random:1016:200", "random:1018:200"])
 def test_compact_build_equals_the_lds_build_bit_for_bit(scene):
-    """Worlds of at most 128 dofs and 128 columns run the COMPACT build by default (arb_wide_kernel.h: the augmented system in
+    """Worlds of at most 192 dofs and 256 columns run the COMPACT build by default (arb_wide_kernel.h: the augmented system in
     registers, one LDS hand-over per pivot, log-depth chains shared with the other build); the knob "wide_compact" 0 selects the
     build that keeps the system in LDS / scratch.  Same assembly, same pivots, same multipliers, same sweeps: states, forces and
     every inspect output identical to the last bit, float32 and float64 buffers."""
     from arboris_python_amd import scenes, synth
     from arboris_python_amd.flatten import flatten_world
     from arboris_python_amd.batch import BatchedWorlds
-    if scene in ("snake100", "snake128"):            # (snake-128: 129 columns -- four columns per lane instead of two)
-        m = scenes.flat(scenes.snake_world(int(scene[5:])))
+    if scene.startswith("snake"):                    # (snake-128: 129 columns -- four columns per lane instead of two; snake-140 / 192:
+        m = scenes.flat(scenes.snake_world(int(scene[5:])))      #  40 / 48 rows per wavefront, the chain arrays of so many bodies in scratch)
         q, dq = synth.random_states(m, 12, seed=3, angle=0.5, vel=1.0)
         dt, steps = 1e-3, 6
-    elif scene == "human36+12":                      # (114 dofs, 16 contacts: 179 columns)
-        m, q0, dq0 = flatten_world(scenes.human36_and_objects_world(12))
-        assert m.ndof == 114 and m.ndof + 1 + 4 * m.nc > 128
+    elif scene in ("human36+12", "human36+16"):      # (114 dofs, 16 contacts: 179 columns; 138 dofs, 20 contacts: 219 columns)
+        m, q0, dq0 = flatten_world(scenes.human36_and_objects_world(int(scene[8:])))
+        assert m.ndof == 42 + 6 * int(scene[8:]) and m.ndof + 1 + 4 * m.nc > 128
         q, dq = np.tile(q0, (12, 1)), np.tile(dq0, (12, 1))
         dq = dq + 0.05 * np.random.RandomState(2).standard_normal(dq.shape)
         dt, steps = 5e-3, 12
