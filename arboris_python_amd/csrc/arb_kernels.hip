@@ -782,7 +782,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB --, 4 .. 6 = the same with the chain arrays and
     //  phase B's composites in scratch: what many BODIES ask for, 108 doubles each)
     auto layout = [&](WideModel &L, int compact, size_t *lds_out) {
-        L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = L.vec_in_lds = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = L.l_vec = 0;
+        L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = L.vec_in_lds = L.sol_in_lds = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = L.l_vec = 0;
         // the scratch block: state and small vectors first, then per-body wrenches and joint columns (the compact build may keep
         // these two groups in LDS), then everything else
         long o = 0;
@@ -794,7 +794,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         const long tier2 = o;
         if (compact) {
             const int kmax = n <= 80 ? 20 : n <= 112 ? 28 : n <= 128 ? 32 : n <= 160 ? 40 : 48;     // rows per wavefront (four wavefronts)
-            L.cp = L.ncols <= 128 ? 2 : 4;                                 // columns per lane
+            L.cp = L.ncols <= 128 ? 2 : L.ncols <= 256 ? 4 : 6;            // columns per lane
             // (the rows of J' under the composites, dead by the time they are written, when they fit; the solution columns
             //  behind them -- the per-dof vectors, read while J' is written, lie past 108 nb)
             const long jrsz = ((long)ndol * n + 1) & ~1l;
@@ -804,7 +804,8 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             L.jr_in_lds = (ndol > 0 && sub == 1) ? 1 : 0;
             L.am_in_lds = sub <= 2 ? 1 : 0;
             L.l_sol = (L.jr_in_lds && under) ? 24l * nb + jrsz : 0;
-            long region = std::max((bodies ? 108l * nb : 0l) + (long)WIDE_XK * n, L.l_sol + (long)n * L.sld);
+            L.sol_in_lds = (size_t)n * L.sld * sizeof(double) <= 64 * 1024 ? 1 : 0;      // (many constraints: 83 dofs x 249 columns are 165 KB)
+            long region = std::max((bodies ? 108l * nb : 0l) + (long)WIDE_XK * n, L.l_sol + (L.sol_in_lds ? (long)n * L.sld : 0l));
             L.l_jr = under ? 24l * nb : region;                  // (... or a place of their own)
             if (L.jr_in_lds && !under) region += jrsz;
             const long head = 2l * 64 * L.cp;                               // (the pivot rows, double-buffered)
@@ -831,7 +832,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         L.o_ab = take(6l * nb); L.o_da = take(18l * nb); L.o_tn = take(6l * nb); L.o_bn = take(6l * nb);
         L.o_ac = take(36l * nb); L.o_mc = take(36l * nb); L.o_wc = take(12l * nb); L.o_xk = take((long)WIDE_XK * n);
         L.o_z = take(L.z_in_lds ? 0 : (long)n * L.ld); L.o_jr = take((long)std::max(ndol, 1) * n);
-        L.o_am = take((long)std::max(ndol * ndol, 1));
+        L.o_am = take((long)std::max(ndol * ndol, 1)); L.o_sol = take((L.kmax && !L.sol_in_lds) ? (long)n * L.sld : 0);
         L.total = o;
     };
     auto to_device = [&](const WideModel &L, WideModel **dst) {
@@ -844,7 +845,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     };
     layout(W, 0, &M->wide_lds);
     rc = to_device(W, &M->wide_dev);
-    if (rc == ARB_OK && n <= 192 && W.ncols <= 256) {
+    if (rc == ARB_OK && ((n <= 192 && W.ncols <= 256) || (n <= 128 && W.ncols <= 384))) {      // (rows per wavefront x columns per lane: registers)
         M->wide_c = W;
         for (int level = 1; level <= 6; ++level) {
             layout(M->wide_c, level, &M->wide_c_lds);
@@ -875,6 +876,7 @@ static int wide_launch(arb_model *M, const WideIO<T> &io_in, long nw, double dt,
 #define ARB_WIDE_GO(K, P) wide_launch_one<T, K, P>(dev, io, nw, dt, dts, nsteps, flags, (double *)ws, grid, lds, st)
     const hipError_t le = L.kmax == 0 ? ARB_WIDE_GO(0, 2)
                         : L.cp == 2 ? (L.kmax == 20 ? ARB_WIDE_GO(20, 2) : L.kmax == 28 ? ARB_WIDE_GO(28, 2) : ARB_WIDE_GO(32, 2))
+                        : L.cp == 6 ? (L.kmax == 20 ? ARB_WIDE_GO(20, 6) : L.kmax == 28 ? ARB_WIDE_GO(28, 6) : ARB_WIDE_GO(32, 6))
                                     : (L.kmax == 20 ? ARB_WIDE_GO(20, 4) : L.kmax == 28 ? ARB_WIDE_GO(28, 4) : L.kmax == 32 ? ARB_WIDE_GO(32, 4)
                                        : L.kmax == 40 ? ARB_WIDE_GO(40, 4) : ARB_WIDE_GO(48, 4));
 #undef ARB_WIDE_GO

@@ -60,7 +60,7 @@ __device__ __forceinline__ void wide_reg_set(wide_d4 (&z)[NCH], int ch, int e, d
 #define WIDE_STAMP(i)       // (tools/wide_elim_probe.py: shader-clock stamps between the parts of one pivot)
 #endif
 // The elimination of the compact build.  Wavefront g of the four holds rows g, g + 4, g + 8 ... (KQ of them) of ALL 64 CP columns
-// (CP 2: 128, CP 4: 256): lane l the columns l, l + 64, ...  Pivot j: wavefront j & 3 hands the pivot row over (element j >> 2 of its lanes), lane
+// (CP 2: 128, CP 4: 256, CP 6: 384 -- every world of at most 128 dofs and 64 constraints): lane l the columns l, l + 64, ...  Pivot j: wavefront j & 3 hands the pivot row over (element j >> 2 of its lanes), lane
 // j & 63 of every wavefront its KQ entries of the pivot column (the multipliers of that wavefront's rows); double-buffered --
 // pivot j - 2 writes a buffer again only behind the barrier of pivot j - 1, which every lane passes after its reads of pivot
 // j --: one barrier per pivot, then 2 KQ fused multiply-adds per lane on registers.  Columns j + 1 .. n - 1 are dead (what the
@@ -73,7 +73,7 @@ __device__ __forceinline__ void wide_reg_set(wide_d4 (&z)[NCH], int ch, int e, d
 // through it a flat instruction).
 template <int KQ, int CP>
 __device__ __attribute__((noinline)) void wide_eliminate(const double *__restrict__ Z, int ld_, int n_, int nact_, int rb_off_,
-                                                         int zl_off_, int sld_, const double *__restrict__ DQS)
+                                                         int zl_off_, int sld_, const double *__restrict__ DQS, double *__restrict__ solg)
 {
     constexpr int NCH = KQ / 4;
     const int tid = threadIdx.x;
@@ -156,7 +156,11 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * (4 * ch + e) + zg, c = l + 64 * p;
-                if (r < n && c >= n && c < nact) ZL[r * sld + (c - n)] = c == n ? z[p][ch][e] + DQS[r] : z[p][ch][e];
+                if (r < n && c >= n && c < nact) {
+                    const double v = c == n ? z[p][ch][e] + DQS[r] : z[p][ch][e];
+                    if (solg != nullptr) solg[r * sld + (c - n)] = v;          // (many constraints: the solution columns in scratch)
+                    else ZL[r * sld + (c - n)] = v;
+                }
             }
     __syncthreads();
 }
@@ -171,6 +175,7 @@ struct WideModel {
     int vec_in_lds;                                         // compact build: 1 = the state and the small per-world vectors in LDS, 2 = per-body wrenches and joint columns too
     long l_vec;
     int jr_in_lds;                                          // compact build: the rows of J' in LDS (under the dead composites)
+    int sol_in_lds; long o_sol;                             // compact build: the solution columns in LDS (else in the scratch block at o_sol)
     long l_jr, l_sol;                                       // ... and where; where the solution columns go after the elimination
     int jrounds;                                            // > 0: a deep tree -- the chain runs in this many pointer-jumping rounds
     const int *janc;                                        // [jrounds][nb] the ancestor 2^r levels up (-1: none)
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
            *AM = M.am_in_lds ? GAM : S + M.o_am, *VV = V1 + M.o_vv, *CD = V1 + M.o_cd;
     double *Z = M.z_in_lds ? ZL : S + M.o_z;
     // the solution columns [Y rhs | Y J'^T] after the elimination: inside Z, or (compact build) written out of the registers
-    const double *SL = REGZ ? ZL + M.l_sol : Z + n;
+    const double *SL = REGZ ? (M.sol_in_lds ? ZL + M.l_sol : S + M.o_sol) : Z + n;
     const int sld = REGZ ? M.sld : ld;
     const bool do_con = nc > 0 && !(flags & ARB_STEP_SKIP_CONSTRAINTS);
     auto ld3 = [](const double *p) { return v3<double>(p[0], p[1], p[2]); };
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         if constexpr (REGZ) {
             // (LDS offsets as integers: the difference of two generic pointers into LDS is an expression the back end mishandles)
             const int zl0 = ((ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 59 * nc;
-            wide_eliminate<KMAX, CP>(Z, ld, n, nact, zl0, zl0 + (int)M.l_reg + (int)M.l_sol, sld, DQS);
+            wide_eliminate<KMAX, CP>(Z, ld, n, nact, zl0, zl0 + (int)M.l_reg + (int)M.l_sol, sld, DQS, M.sol_in_lds ? nullptr : S + M.o_sol);
         } else {
         for (int j = n - 1; j >= 0; --j) {
             const double ip = arb_rcp(Z[j * ld + j]);
@@ -1118,7 +1123,7 @@ template hipError_t wide_launch_one<double, ARB_PART_WIDE, ARB_PART_WIDE_CP>(ARB
     extern template hipError_t wide_launch_one<float, K, P>(ARB_WIDE_ONE_ARGS(float)); \
     extern template hipError_t wide_launch_one<double, K, P>(ARB_WIDE_ONE_ARGS(double));
 ARB_EXTERN_WIDE(0, 2) ARB_EXTERN_WIDE(20, 2) ARB_EXTERN_WIDE(28, 2) ARB_EXTERN_WIDE(32, 2) ARB_EXTERN_WIDE(20, 4) ARB_EXTERN_WIDE(28, 4) ARB_EXTERN_WIDE(32, 4)
-ARB_EXTERN_WIDE(40, 4) ARB_EXTERN_WIDE(48, 4)
+ARB_EXTERN_WIDE(40, 4) ARB_EXTERN_WIDE(48, 4) ARB_EXTERN_WIDE(20, 6) ARB_EXTERN_WIDE(28, 6) ARB_EXTERN_WIDE(32, 6)
 #undef ARB_EXTERN_WIDE
 #endif
 #endif  // ARB_WIDE_KERNEL_H

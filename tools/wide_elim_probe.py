@@ -23,7 +23,7 @@ __device__ long long g_acc[8];
 ''' + body.replace("    const int tid = threadIdx.x;\n", "    const int tid = threadIdx.x;\n    WIDE_STAMP_DECL\n", 1) \
           .replace("    __syncthreads();                // (the chain arrays", "    WIDE_STAMP_END\n    __syncthreads();                // (the chain arrays", 1) + r'''
 __global__ __launch_bounds__(256) void k(const double *Z, int ld, int n, int nact, double *out, int sld, const double *DQS) {
-    wide_eliminate<KMAXV, 2>(Z + (size_t)blockIdx.x * n * ld, ld, n, nact, 0, 1024, sld, DQS);
+    wide_eliminate<KMAXV, 2>(Z + (size_t)blockIdx.x * n * ld, ld, n, nact, 0, 1024, sld, DQS, nullptr);
     if (threadIdx.x < n) out[blockIdx.x * n + threadIdx.x] = reinterpret_cast<double *>(arb_lds_raw)[1024 + threadIdx.x * sld];
 }
 int main() {
