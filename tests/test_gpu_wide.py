@@ -411,25 +411,26 @@ def test_wide_kernels_against_the_reference_itself_g15():
     bw.step(tq, tdq, dt, 5)
     assert _rel(tq.cpu().numpy(), g["snake_roll5_q"]).max() < 3e-6 and _rel(tdq.cpu().numpy(), g["snake_roll5_dq"]).max() < 2e-3
     bw.close()
-    m, _, _ = load_model("human36_obj4")
-    bw = BatchedWorlds(m)
-    assert bw.info["wide"] == 1 and bw.info["ndof"] == 66
-    dt = float(g["human_dt"])
-    T = len(g["human_active"])
-    tq, tdq = bw.to_device(g["human_q"][:1], g["human_dq"][:1], torch.float64)
-    cf = bw.new_cforce(1, torch.float64)
-    worst = 0.
-    for k in range(T):
-        bw.step(tq, tdq, dt, 1, cforce=cf)
-        f = cf.cpu().numpy()[0]
-        assert ((np.abs(f).max(axis=1) > 0) <= g["human_active"][k]).all(), k          # (a force only where the reference's contact is active)
-        assert np.abs(f - g["human_force"][k]).max() <= 1e-7 * max(1., np.abs(g["human_force"][k]).max()), k
-        e = max(_rel(tq.cpu().numpy(), g["human_q"][k + 1:k + 2]).max(), _rel(tdq.cpu().numpy(), g["human_dq"][k + 1:k + 2]).max())
-        worst = max(worst, e)
-    print("human36 + 4 objects, %d steps against the reference: worst state error %.2e" % (T, worst))
-    assert worst < 1e-8
-    tq2, tdq2 = bw.to_device(g["human_q"][:1], g["human_dq"][:1], torch.float64)
-    cf2 = bw.new_cforce(1, torch.float64)
-    bw.step(tq2, tdq2, dt, T, cforce=cf2)
-    assert torch.equal(tq2, tq) and torch.equal(tdq2, tdq) and torch.equal(cf2, cf)
-    bw.close()
+    for key, nobj in (("human", 4), ("human12", 12)):     # (66 dofs / 8 contacts: two columns per lane; 114 dofs / 16 contacts: four)
+        m, _, _ = load_model("human36_obj%d" % nobj)
+        bw = BatchedWorlds(m)
+        assert bw.info["wide"] == 1 and bw.info["ndof"] == 42 + 6 * nobj
+        dt = float(g[key + "_dt"])
+        T = len(g[key + "_active"])
+        tq, tdq = bw.to_device(g[key + "_q"][:1], g[key + "_dq"][:1], torch.float64)
+        cf = bw.new_cforce(1, torch.float64)
+        worst = 0.
+        for k in range(T):
+            bw.step(tq, tdq, dt, 1, cforce=cf)
+            f = cf.cpu().numpy()[0]
+            assert ((np.abs(f).max(axis=1) > 0) <= g[key + "_active"][k]).all(), k       # (a force only where the reference's contact is active)
+            assert np.abs(f - g[key + "_force"][k]).max() <= 1e-7 * max(1., np.abs(g[key + "_force"][k]).max()), k
+            e = max(_rel(tq.cpu().numpy(), g[key + "_q"][k + 1:k + 2]).max(), _rel(tdq.cpu().numpy(), g[key + "_dq"][k + 1:k + 2]).max())
+            worst = max(worst, e)
+        print("human36 + %d objects, %d steps against the reference: worst state error %.2e" % (nobj, T, worst))
+        assert worst < 1e-8
+        tq2, tdq2 = bw.to_device(g[key + "_q"][:1], g[key + "_dq"][:1], torch.float64)
+        cf2 = bw.new_cforce(1, torch.float64)
+        bw.step(tq2, tdq2, dt, T, cforce=cf2)
+        assert torch.equal(tq2, tq) and torch.equal(tdq2, tdq) and torch.equal(cf2, cf)
+        bw.close()

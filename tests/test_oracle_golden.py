@@ -210,17 +210,19 @@ def test_wide_worlds_from_the_reference_g15():
     close(d["Z"][0], g["snake_Z0"], 1e-10)
     q, dq, _ = O.rollout(m, g["snake_q"][:2], g["snake_dq"][:2], [dt] * 5)
     close(q, g["snake_roll5_q"], 1e-7); close(dq, g["snake_roll5_dq"], 1e-5)
-    m, _, _ = load_model("human36_obj4")
-    assert m.ndof == 66 and m.nc == 8
-    dt = float(g["human_dt"])
-    q, dq = g["human_q"][:1].copy(), g["human_dq"][:1].copy()
-    cf = np.zeros((1, m.nc, 4))
-    for k in range(len(g["human_active"])):
-        q, dq, cf, d = O.step(m, q, dq, dt, cforce=cf, debug=True)
-        assert (d["active"][0] == g["human_active"][k]).all(), k
-        close(cf[0], g["human_force"][k], 1e-7)
-        close(q[0], g["human_q"][k + 1], 1e-9); close(dq[0], g["human_dq"][k + 1], 1e-8)
-    assert g["human_active"].any(axis=0).all()            # (every contact -- the four feet, the four balls -- is active at some step)
+    for key, nobj in (("human", 4), ("human12", 12)):     # (66 dofs / 8 contacts; 114 dofs / 16 contacts)
+        m, _, _ = load_model("human36_obj%d" % nobj)
+        assert m.ndof == 42 + 6 * nobj and m.nc == 4 + nobj
+        dt = float(g[key + "_dt"])
+        q, dq = g[key + "_q"][:1].copy(), g[key + "_dq"][:1].copy()
+        cf = np.zeros((1, m.nc, 4))
+        for k in range(len(g[key + "_active"])):
+            q, dq, cf, d = O.step(m, q, dq, dt, cforce=cf, debug=True)
+            assert (d["active"][0] == g[key + "_active"][k]).all(), k
+            close(cf[0], g[key + "_force"][k], 1e-7)
+            close(q[0], g[key + "_q"][k + 1], 1e-9); close(dq[0], g[key + "_dq"][k + 1], 1e-8)
+        # (the four feet and the lower balls touch the floor within the steps; the twelve boxes start one centimetre higher each)
+        assert g[key + "_active"].any(axis=0).sum() >= 8
 
 
 def test_snake64_needs_float64_assembly():

@@ -945,40 +945,41 @@ def gen_wide():
         rq.append(a); rdq.append(b)
     out["snake_roll5_q"], out["snake_roll5_dq"] = np.array(rq), np.array(rdq)
 
-    w = World()
-    add_groundplane(w)
-    add_human36(w)
-    for k in range(4):
-        he = (0.10 + 0.02 * k, 0.08, 0.12)
-        body = Body(name="Box%d" % k, mass=MM.box(he, 2.0 + k))
-        j = FreeJoint(name="BoxRoot%d" % k)
-        j.gpos = Hg.transl(0.6 + 0.5 * k, 0.13 + 0.01 * k, 0.4 - 0.3 * k)
-        w.add_link(w.ground, j, body)
-        w.register(Sphere(body, 0.12, name="Box%d ball" % k))
-    w.register(WeightController())
-    for c in get_all_contacts(w, friction_coeff=.6):
-        s0, s1 = c._shapes
-        if type(s0).__name__ == "Plane" and (s1.name in FOUR or str(s1.name).endswith(" ball")):
-            w.register(c)
-    w.init()
-    m = save_model("human36_obj4", w)
-    assert m.ndof == 66 and m.nc == 8, (m.ndof, m.nc)
-    q0, dq0 = get_state(w, m)
-    dq0 = dq0 + 0.05 * np.random.default_rng(151).standard_normal(m.ndof)
-    set_state(w, m, q0, dq0)
-    dt, nsteps = 5e-3, 30
-    cons = list(w._constraints)
-    qs, dqs, act, frc = [], [], [], []
-    for k in range(nsteps):
+    for nobj, key, nsteps in ((4, "human", 30), (12, "human12", 16)):
+        w = World()
+        add_groundplane(w)
+        add_human36(w)
+        for k in range(nobj):
+            he = (0.10 + 0.02 * k, 0.08, 0.12)
+            body = Body(name="Box%d" % k, mass=MM.box(he, 2.0 + k))
+            j = FreeJoint(name="BoxRoot%d" % k)
+            j.gpos = Hg.transl(0.6 + 0.5 * k, 0.13 + 0.01 * k, 0.4 - 0.3 * k)
+            w.add_link(w.ground, j, body)
+            w.register(Sphere(body, 0.12, name="Box%d ball" % k))
+        w.register(WeightController())
+        for c in get_all_contacts(w, friction_coeff=.6):
+            s0, s1 = c._shapes
+            if type(s0).__name__ == "Plane" and (s1.name in FOUR or str(s1.name).endswith(" ball")):
+                w.register(c)
+        w.init()
+        m = save_model("human36_obj%d" % nobj, w)
+        assert m.ndof == 42 + 6 * nobj and m.nc == 4 + nobj, (m.ndof, m.nc)
+        q0, dq0 = get_state(w, m)
+        dq0 = dq0 + 0.05 * np.random.default_rng(151).standard_normal(m.ndof)
+        set_state(w, m, q0, dq0)
+        dt = 5e-3
+        cons = list(w._constraints)
+        qs, dqs, act, frc = [], [], [], []
+        for k in range(nsteps):
+            a, b = get_state(w, m)
+            qs.append(a); dqs.append(b)
+            w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
+            act.append([bool(c.is_active()) for c in cons])
+            frc.append([c._force.copy() for c in cons])
+            w.integrate(dt)
         a, b = get_state(w, m)
         qs.append(a); dqs.append(b)
-        w.update_dynamic(); w.update_controllers(dt); w.update_constraints(dt)
-        act.append([bool(c.is_active()) for c in cons])
-        frc.append([c._force.copy() for c in cons])
-        w.integrate(dt)
-    a, b = get_state(w, m)
-    qs.append(a); dqs.append(b)
-    out.update(human_q=np.array(qs), human_dq=np.array(dqs), human_active=np.array(act), human_force=np.array(frc), human_dt=np.array(dt))
+        out.update({key + "_q": np.array(qs), key + "_dq": np.array(dqs), key + "_active": np.array(act), key + "_force": np.array(frc), key + "_dt": np.array(dt)})
     save("g15_wide.npz", **out)
 
 
