@@ -434,3 +434,53 @@ def test_wide_kernels_against_the_reference_itself_g15():
         bw.step(tq2, tdq2, dt, T, cforce=cf2)
         assert torch.equal(tq2, tq) and torch.equal(tdq2, tdq) and torch.equal(cf2, cf)
         bw.close()
+
+
+def test_every_pair_of_get_all_contacts_on_a_60_dof_world_runs_wide():
+    """`get_all_contacts` (constraints.py:840-875) pairs every two shapes of a world: human36 (eight foot points) beside three free
+    balls on a ground plane has 38 SoftFingerContacts -- plane / point, plane / ball, ball / point, ball / ball -- on 60 dofs:
+    213 columns, past the wavefront kernels' 128 although the world has fewer than 64 dofs.  `arb_model_create` routes it to the
+    wide kernels (compact build, four columns per lane); 25 steps against the oracle, step by step, float64."""
+    from arboris_python_amd.core import World, Body
+    from arboris_python_amd.joints import FreeJoint
+    from arboris_python_amd.shapes import Sphere
+    from arboris_python_amd import massmatrix, homogeneousmatrix as Hg
+    from arboris_python_amd.robots.human36 import add_human36
+    from arboris_python_amd.robots.simpleshapes import add_groundplane
+    from arboris_python_amd.controllers import WeightController
+    from arboris_python_amd.constraints import get_all_contacts
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    w = World()
+    add_groundplane(w)
+    add_human36(w)
+    for k in range(3):
+        body = Body(name="Ball%d" % k, mass=massmatrix.sphere(0.1, 1.0 + k))
+        j = FreeJoint(name="BallRoot%d" % k)
+        j.gpos = Hg.transl(0.12 + 0.19 * k, 0.105, 0.05 * k)          # (a row of balls in front of the feet, touching one another)
+        w.add_link(w.ground, j, body)
+        w.register(Sphere(body, 0.1, name="Ball%d" % k))
+    w.register(WeightController())
+    for c in get_all_contacts(w, friction_coeff=0.6):
+        w.register(c)
+    w.init()
+    m, q0, dq0 = flatten_world(w)
+    assert m.ndof == 60 and m.nc == 38
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1
+    B, dt, T = 4, 5e-3, 25
+    q = np.tile(q0, (B, 1))
+    dq = np.tile(dq0, (B, 1)) + 0.1 * np.random.RandomState(7).standard_normal((B, m.ndof))
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    cf = bw.new_cforce(B, torch.float64)
+    oq, odq, ocf = q.copy(), dq.copy(), np.zeros((B, m.nc, 4))
+    worst, seen = 0., np.zeros(m.nc, bool)
+    for k in range(T):
+        oq, odq, ocf = O.step(m, oq, odq, dt, cforce=ocf)
+        bw.step(tq, tdq, dt, 1, cforce=cf)
+        worst = max(worst, _rel(tq.cpu().numpy(), oq).max(), _rel(tdq.cpu().numpy(), odq).max())
+        seen |= (np.abs(ocf).max(axis=(0, 2)) > 0)
+    print("human36 + 3 balls, every pair (38 contacts): %d steps, worst state error %.2e, %d contacts carried a force" % (T, worst, seen.sum()))
+    assert worst < 1e-8 and seen.sum() >= 8
+    assert np.abs(cf.cpu().numpy() - ocf).max() <= 1e-6 * max(1., np.abs(ocf).max())
+    bw.close()
