@@ -227,7 +227,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     double *TROW = lds;                      // [ncols]   the scaled pivot row
     double *FCOL = TROW + ((ncols + 3) & ~3);   // [n]    the pivot column (multipliers)
     double *DF = FCOL + ((n + 3) & ~3);      // [8]       force increment of one local solve
-    double *SWORK = DF + 8;                  // [48]      scratch of the sliding solve (eig6 fallback)
+    double *SWORK = DF + 8;                  // [48]      (spare: the sliding solve's eig6 fallback keeps its scratch per lane since the group sweeps)
     double *GVV = SWORK + 48;                // [ndol]    v' during the sweeps
     double *GFF = GVV + ((M.ndol + 3) & ~3); // [ndol]    constraint forces during the sweeps
     double *GSC = GFF + ((M.ndol + 3) & ~3); // [nc][52]  per-constraint blocks and constants of the sweeps

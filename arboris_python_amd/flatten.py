@@ -232,30 +232,29 @@ def flatten_world(world, positions=True, host_controllers=None):
         if j is None:
             stack.pop()
             continue
-        if True:
-            f0, f1 = j._frame0, j._frame1
-            child = f1.body
-            (tid, k, kq) = _joint_type(j)
-            idx = len(bodies)
-            bodies.append(child)
-            index_of[id(child)] = idx
-            parent.append(body_index)
-            jtype.append(tid)
-            dof_off.append(ndof)
-            jnd.append(k)
-            q_off.append(nq)
-            jnq.append(kq)
-            ndof += k
-            nq += kq
-            H_pr.append(_bpose(f0))
-            H_cn.append(_bpose(f1))
-            mass.append(np.array(child.mass, dtype=np.float64).reshape(6, 6))
-            visc.append(np.array(child.viscosity, dtype=np.float64).reshape(6, 6))
-            m.body_names.append(child.name)
-            m.joint_names.append(j.name)
-            q0.append(np.array(j.gpos, dtype=np.float64).ravel())
-            dq0.append(np.array(j.gvel, dtype=np.float64).ravel())
-            stack.append((idx, iter(child.childrenjoints)))
+        f0, f1 = j._frame0, j._frame1
+        child = f1.body
+        (tid, k, kq) = _joint_type(j)
+        idx = len(bodies)
+        bodies.append(child)
+        index_of[id(child)] = idx
+        parent.append(body_index)
+        jtype.append(tid)
+        dof_off.append(ndof)
+        jnd.append(k)
+        q_off.append(nq)
+        jnq.append(kq)
+        ndof += k
+        nq += kq
+        H_pr.append(_bpose(f0))
+        H_cn.append(_bpose(f1))
+        mass.append(np.array(child.mass, dtype=np.float64).reshape(6, 6))
+        visc.append(np.array(child.viscosity, dtype=np.float64).reshape(6, 6))
+        m.body_names.append(child.name)
+        m.joint_names.append(j.name)
+        q0.append(np.array(j.gpos, dtype=np.float64).ravel())
+        dq0.append(np.array(j.gvel, dtype=np.float64).ravel())
+        stack.append((idx, iter(child.childrenjoints)))
 
     m.nb, m.ndof, m.nq = len(bodies), ndof, nq
     m.up = np.array(world.up, dtype=float)
