@@ -37,7 +37,18 @@ class BatchedWorlds(object):
         self._lib = lib if lib is not None else _capi.load()      # (lib: another build of the library, tests)
         desc, keep = _capi.make_desc(model)
         handle = C.c_void_p()
-        _capi.check(self._lib.arb_model_create(C.byref(desc), self.device_index, C.byref(handle)))
+        status = self._lib.arb_model_create(C.byref(desc), self.device_index, C.byref(handle))
+        if status == 2:                      # ARB_ERR_UNSUPPORTED: say which limit (include/arbstep.h)
+            why = []
+            if model.ndof > _capi.ARB_WIDE_MAX or model.nb > _capi.ARB_WIDE_MAX:
+                why.append("%d dofs / %d bodies (at most %d)" % (model.ndof, model.nb, _capi.ARB_WIDE_MAX))
+            if model.nc > 64:
+                why.append("%d constraints (at most 64: register the pairs that can touch, not every pair of "
+                           "get_all_contacts)" % model.nc)
+            raise _capi.ArbError("libarbstep: model not supported by the device step (status 2)%s"
+                                 % (": " + "; ".join(why) if why else ": bodies not in depth-first order, or mass matrices that are "
+                                    "not rigid-body inertias"))
+        _capi.check(status)
         self._handle = handle
         del keep
         info = _capi.ModelInfo()

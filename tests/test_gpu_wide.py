@@ -195,6 +195,8 @@ def test_limits_of_the_wide_path():
     desc, keep = _capi.make_desc(m2)
     h = C.c_void_p()
     assert _capi.load().arb_model_create(C.byref(desc), 0, C.byref(h)) == 2
+    with pytest.raises(_capi.ArbError, match="1025 dofs"):       # (the Python layer says which limit)
+        BatchedWorlds(m2)
 
 
 def test_object_api_simulates_a_wide_world():
