@@ -34,6 +34,8 @@ ARB_STEP_NO_MIXED = 4096
 ARB_STEP_CLASSIC_COLUMNS = 8192
 ARB_WIDE_MAX = 1024
 ARB_WARN_ILLCOND = 1
+ARB_WARN_ACTIVE_CONSTRAINTS = 2
+ARB_WIDE_MAX_CONSTRAINTS = 256
 ARB_ILLCOND_GROWTH = 2048.0
 
 _PD = C.POINTER(C.c_double)

@@ -42,9 +42,8 @@ class BatchedWorlds(object):
             why = []
             if model.ndof > _capi.ARB_WIDE_MAX or model.nb > _capi.ARB_WIDE_MAX:
                 why.append("%d dofs / %d bodies (at most %d)" % (model.ndof, model.nb, _capi.ARB_WIDE_MAX))
-            if model.nc > 64:
-                why.append("%d constraints (at most 64: register the pairs that can touch, not every pair of "
-                           "get_all_contacts)" % model.nc)
+            if model.nc > _capi.ARB_WIDE_MAX_CONSTRAINTS:
+                why.append("%d constraints (at most %d registered, 64 active in a step)" % (model.nc, _capi.ARB_WIDE_MAX_CONSTRAINTS))
             raise _capi.ArbError("libarbstep: model not supported by the device step (status 2)%s"
                                  % (": " + "; ".join(why) if why else ": bodies not in depth-first order, or mass matrices that are "
                                     "not rigid-body inertias"))

@@ -429,7 +429,7 @@ static int model_create(const arb_model_desc *d, int device, arb_model **out, in
     const int ncols = n + 1 + ndol;
     if (n > WAVE || nb > WAVE || nc > WAVE || ncols > 2 * WAVE || ndol > WAVE) {      // past one world per wavefront
 #if ARB_WITH_WIDE
-        if (with_forest && n <= ARB_WIDE_MAX && nb <= ARB_WIDE_MAX && nc <= 64) return wide_create(d, device, out);
+        if (with_forest && n <= ARB_WIDE_MAX && nb <= ARB_WIDE_MAX && nc <= ARB_WIDE_MAX_CONSTRAINTS) return wide_create(d, device, out);
 #endif
         return ARB_ERR_UNSUPPORTED;
     }
@@ -712,12 +712,14 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     arb_model *M = new (std::nothrow) arb_model();
     if (!M) return ARB_ERR_NOMEM;
     M->device = device; M->is_wide = true;
-    M->nb = nb; M->n = n; M->nq = d->nq; M->nc = nc; M->ndol = ndol; M->ncols = n + 1 + ndol; M->nsets = 1; M->nmax = n;
+    // (at most 64 of a world's constraints ACTIVE in one step: the solve works on slots, see arb_wide_kernel.h)
+    const int ncap = std::min(nc, 64), nds = 4 * ncap;
+    M->nb = nb; M->n = n; M->nq = d->nq; M->nc = nc; M->ndol = ndol; M->ncols = n + 1 + nds; M->nsets = 1; M->nmax = n;
     DeviceGuard guard_(device);
     if (guard_.err != hipSuccess) { g_hip_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err); delete M; return ARB_ERR_HIP; }
     WideModel &W = M->wide;
     memset(&W, 0, sizeof(W));
-    W.nb = nb; W.n = n; W.nq = d->nq; W.nc = nc; W.ndol = ndol; W.ncols = n + 1 + ndol; W.ld = (W.ncols + 1) | 1;   // (odd row stride: LDS banks)
+    W.nb = nb; W.n = n; W.nq = d->nq; W.nc = nc; W.ndol = ndol; W.ncap = ncap; W.nds = nds; W.ncols = n + 1 + nds; W.ld = (W.ncols + 1) | 1;   // (odd row stride: LDS banks)
     W.maxdepth = maxdepth; W.has_warm = has_warm; W.has_pd = d->pd_kp != nullptr;
     for (int i = 0; i < 3; ++i) { W.grav[i] = d->gravity[i]; W.up[i] = d->up[i]; if (d->gravity[i] != 0.) W.has_grav = 1; }
     for (int i = 0; i < 36 * nb; ++i) if (d->visc[i] != 0.) W.has_visc = 1;
@@ -776,8 +778,8 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     // composites) and per-dof vectors, which the solution columns take over.  Otherwise: the system in LDS when it fits beside
     // the pivot row / column (120 KB: one workgroup per CU), else in scratch.  ("wide_compact" 0, arb_hook_set_knob, selects
     // the second where the first is the default: the tests hold the two bit-identical.)
-    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 59 * nc) * sizeof(double);
-    W.sld = (1 + ndol) | 1;
+    const size_t small = (size_t)(((W.ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((nds + 3) & ~3) + 59 * ncap + (ncap & 1) + 2 * ((ncap + 5) >> 2)) * sizeof(double);
+    W.sld = (1 + nds) | 1;
     // (compact: 1 = everything below in LDS, 2 = without the rows of J', 3 = without the admittance of the sweeps as well --
     //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB --, 4 .. 6 = the same with the chain arrays and
     //  phase B's composites in scratch: what many BODIES ask for, 108 doubles each)
@@ -788,7 +790,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         long o = 0;
         auto take = [&](long cnt) { const long at = o; o += (cnt + 1) & ~1l; return at; };
         L.o_q = take(d->nq); L.o_dq = take(n); L.o_qd = take(n); L.o_ff = take(std::max(ndol, 1)); L.o_ff0 = take(std::max(ndol, 1));
-        L.o_rh = take(2l * n); L.o_vv = take(std::max(ndol, 1)); L.o_cd = take((long)WIDE_CD * std::max(nc, 1));
+        L.o_rh = take(2l * n); L.o_vv = take(std::max(nds, 1)); L.o_cd = take((long)WIDE_CD * std::max(nc, 1));
         const long tier1 = o;
         L.o_pt = take(12l * nb); L.o_sc = take(12l * n);
         const long tier2 = o;
@@ -797,7 +799,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             L.cp = L.ncols <= 128 ? 2 : L.ncols <= 256 ? 4 : 6;            // columns per lane
             // (the rows of J' under the composites, dead by the time they are written, when they fit; the solution columns
             //  behind them -- the per-dof vectors, read while J' is written, lie past 108 nb)
-            const long jrsz = ((long)ndol * n + 1) & ~1l;
+            const long jrsz = ((long)nds * n + 1) & ~1l;
             const bool bodies = compact <= 3;                    // (chain arrays and composites in LDS)
             const int sub = bodies ? compact : compact - 3;
             const bool under = bodies && ndol > 0 && jrsz <= 84l * nb;
@@ -810,7 +812,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             if (L.jr_in_lds && !under) region += jrsz;
             const long head = 2l * 64 * L.cp;                               // (the pivot rows, double-buffered)
             L.kmax = kmax; L.l_am = head; L.l_ac = 24l * nb; L.l_xk = bodies ? 108l * nb : 0;
-            L.l_reg = head + (L.am_in_lds ? ((ndol * ndol + 1) & ~1) : 0);
+            L.l_reg = head + (L.am_in_lds ? ((nds * nds + 1) & ~1) : 0);
             L.ac_in_lds = bodies ? 1 : 0; L.chain_in_lds = bodies ? 1 : 0; L.z_in_lds = 0;
             L.l_vec = region;
             size_t lds = small + (size_t)(L.l_reg + region) * sizeof(double);
@@ -831,8 +833,8 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
         L.o_pose = take(12l * nb); L.o_tw = take(6l * nb); L.o_om = take(6l * nb); L.o_pc = take(12l * nb); L.o_rcp = take(12l * nb);
         L.o_ab = take(6l * nb); L.o_da = take(18l * nb); L.o_tn = take(6l * nb); L.o_bn = take(6l * nb);
         L.o_ac = take(36l * nb); L.o_mc = take(36l * nb); L.o_wc = take(12l * nb); L.o_xk = take((long)WIDE_XK * n);
-        L.o_z = take(L.z_in_lds ? 0 : (long)n * L.ld); L.o_jr = take((long)std::max(ndol, 1) * n);
-        L.o_am = take((long)std::max(ndol * ndol, 1)); L.o_sol = take((L.kmax && !L.sol_in_lds) ? (long)n * L.sld : 0);
+        L.o_z = take(L.z_in_lds ? 0 : (long)n * L.ld); L.o_jr = take((long)std::max(nds, 1) * n);
+        L.o_am = take((long)std::max(nds * nds, 1)); L.o_sol = take((L.kmax && !L.sol_in_lds) ? (long)n * L.sld : 0);
         L.total = o;
     };
     auto to_device = [&](const WideModel &L, WideModel **dst) {

@@ -12,7 +12,7 @@
 //     and column of the elimination;
 //   * lane = body / dof / constraint / matrix entry as the phase needs, __syncthreads() between phases;
 //   * workgroups loop over the worlds of the batch (grid = min(worlds, 2 per CU)), steps loop inside.
-// Limits: ndof, nb <= ARB_WIDE_MAX (1024), nc <= 64.  Inputs: everything arb_step_ex takes -- state, constraint forces, user
+// Limits: ndof, nb <= ARB_WIDE_MAX (1024), nc <= ARB_WIDE_MAX_CONSTRAINTS (256) of which at most 64 ACTIVE in one step.  Inputs: everything arb_step_ex takes -- state, constraint forces, user
 // torques (constant or a sequence), the dense impedance of user-defined controllers, per-world PD targets / gains (and target
 // sequences), per-step dt, state and energy logs, the running cost; the model's merged PD controllers.
 // Not supported (ARB_ERR_UNSUPPORTED): the execution variants of the wavefront kernels (split sweeps, matrix-core elimination).
@@ -169,7 +169,7 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
 #define WIDE_CD 40          // per constraint: R (9) | p (3) | pos0 (3) | sdist | active | glo | ghi | pad ... | pinv (16) at 24
 
 struct WideModel {
-    int nb, n, nq, nc, ndol, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds, chain_in_lds;
+    int nb, n, nq, nc, ndol, ncap, nds, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds, chain_in_lds;
     int kmax, cp, ac_in_lds, am_in_lds, sld;                  // compact build: rows per lane (0: the LDS / scratch build); what else is in LDS
     long l_ac, l_xk, l_am, l_reg;                                // (offsets, doubles, inside the LDS region behind the sweeps' blocks)
     int vec_in_lds;                                         // compact build: 1 = the state and the small per-world vectors in LDS, 2 = per-body wrenches and joint columns too
@@ -222,18 +222,22 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
 {
     const WideModel &M = *mp_in;
     const int tid = threadIdx.x;
-    const int n = M.n, nb = M.nb, nq = M.nq, nc = M.nc, ndol = M.ndol, ncols = M.ncols, ld = M.ld;
+    // nc / ndol: the world's constraints and their 4 nc force components; ncap / nds: at most so many of them ACTIVE in one step (and
+    // four times that): the slots of everything the solve touches; ncols = n + 1 + nds columns at most
+    const int n = M.n, nb = M.nb, nq = M.nq, nc = M.nc, ndol = M.ndol, ncap = M.ncap, nds = M.nds, ncols = M.ncols, ld = M.ld;
     double *lds = reinterpret_cast<double *>(arb_lds_raw);
     double *TROW = lds;                      // [ncols]   the scaled pivot row
     double *FCOL = TROW + ((ncols + 3) & ~3);   // [n]    the pivot column (multipliers)
     double *DF = FCOL + ((n + 3) & ~3);      // [8]       force increment of one local solve
     double *SWORK = DF + 8;                  // [48]      (spare: the sliding solve's eig6 fallback keeps its scratch per lane since the group sweeps)
-    double *GVV = SWORK + 48;                // [ndol]    v' during the sweeps
-    double *GFF = GVV + ((M.ndol + 3) & ~3); // [ndol]    constraint forces during the sweeps
-    double *GSC = GFF + ((M.ndol + 3) & ~3); // [nc][52]  per-constraint blocks and constants of the sweeps
-    unsigned long long *GGM = reinterpret_cast<unsigned long long *>(GSC + 52 * M.nc);   // [nc]  the group of a constraint, a bit per member
-    double *GDF = GSC + 53 * M.nc;           // [nc][6]   per group: the force increment of this round's solve (4), its constraint
-    double *ZL = GSC + 59 * M.nc;            // [n][ld]   the augmented system, when it fits (compact build: the region below)
+    double *GVV = SWORK + 48;                // [nds]     v' during the sweeps
+    double *GFF = GVV + ((M.nds + 3) & ~3);  // [nds]     constraint forces during the sweeps
+    double *GSC = GFF + ((M.nds + 3) & ~3);  // [ncap][52] per-slot blocks and constants of the sweeps
+    unsigned long long *GGM = reinterpret_cast<unsigned long long *>(GSC + 52 * M.ncap);   // [ncap]  the group of a slot, a bit per member
+    double *GDF = GSC + 53 * M.ncap;         // [ncap][6] per group: the force increment of this round's solve (4), its slot
+    int *ORDL = reinterpret_cast<int *>(GSC + 59 * M.ncap);      // [ncap + 2]  slot -> constraint (this step's active ones, in order), their number
+    double *ZL = GSC + 59 * M.ncap + (M.ncap & 1) + 2 * ((M.ncap + 5) >> 2);     // (16-byte steps: what follows is read two doubles at a time)
+    // ZL: [n][ld]   the augmented system, when it fits (compact build: the region below)
     constexpr bool REGZ = KMAX > 0;
     // compact build: [2][128] pivot rows | the admittance of the sweeps | chain arrays, composites,
     // per-dof vectors (the solution columns take their place after the elimination)
@@ -270,10 +274,6 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
     int cwn = 1;
     while (cwn < n && cwn < WIDE_THREADS) cwn <<= 1;
     const int cl_n = tid & (cwn - 1), r0_n = tid / cwn, rs_n = WIDE_THREADS / cwn;
-
-    // (deep trees: this lane's ancestors 2^r levels up, once per launch -- read per round they are an L2 round trip each, 28 per step)
-    int janc_r[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    for (int r = 0; r < 8; ++r) if (r < M.jrounds && tid < nb) janc_r[r] = M.janc[r * nb + tid];
 
     for (long w = blockIdx.x; w < nworlds; w += gridDim.x) {
     __syncthreads();
@@ -355,10 +355,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             const int par = on ? M.parent[b] : -1;
             if (on) for (int i = 0; i < 12; ++i) POSE[12 * b + i] = PC[12 * b + i];
             __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (r >= M.jrounds) break;
-                const int a = janc_r[r];
+            for (int r = 0; r < M.jrounds; ++r) {
+                const int a = on ? M.janc[r * nb + b] : -1;
                 M3<double> Ra = m3_identity<double>(); V3<double> pa = v3<double>(0., 0., 0.);
                 if (a >= 0) { Ra = ldm(POSE + 12 * a); pa = ld3(POSE + 12 * a + 9); }
                 __syncthreads();
@@ -371,10 +369,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             }
             auto jump_sum = [&](double *arr) {          // inclusive sum over the ancestors of the 6-vectors of `arr`
                 __syncthreads();
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (r >= M.jrounds) break;
-                    const int a = janc_r[r];
+                for (int r = 0; r < M.jrounds; ++r) {
+                    const int a = on ? M.janc[r * nb + b] : -1;
                     double add6[6] = {0., 0., 0., 0., 0., 0.};
                     if (a >= 0) for (int i = 0; i < 6; ++i) add6[i] = arr[6 * a + i];
                     __syncthreads();
@@ -571,6 +567,27 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         }
         __syncthreads();
         for (int i = tid; i < ndol; i += WIDE_THREADS) FF0[i] = FF[i];
+        // ---- this step's ACTIVE constraints, in registration order: slot s holds constraint ORDL[s].  Everything the solve touches --
+        // rows of J', columns of the system, admittance, sweeps -- is indexed by slot: a world may REGISTER many more constraints
+        // (every pair of get_all_contacts) than are active at a time; at most ncap = min(nc, 64) active ones are kept (more: the
+        // later ones are left out of the step and ARB_WARN_ACTIVE_CONSTRAINTS is raised)
+        if (tid < WAVE) {
+            int base = 0;
+            for (int c0 = 0; c0 < nc; c0 += WAVE) {
+                const int c = c0 + tid;
+                const bool act = do_con && c < nc && CD[WIDE_CD * c + 16] != 0.;
+                const unsigned long long bal = __ballot(act);
+                const int s = base + __popcll(bal & ((1ull << tid) - 1ull));
+                if (act) { if (s < ncap) ORDL[s] = c; else CD[WIDE_CD * c + 16] = 0.; }
+                base += __popcll(bal);
+            }
+            if (tid == 0) {
+                ORDL[ncap] = base < ncap ? base : ncap;
+                if (base > ncap) (void)__hip_atomic_fetch_or(M.warn, (int)ARB_WARN_ACTIVE_CONSTRAINTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+        const int nca = ORDL[ncap], nda = 4 * nca;
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 2] = (long long)clock64();
         // ================= phase B: composite assembly of Z = M/dt + B + N (core.py:722-734, 813), see arb_phase_b.h =========
         // ---- lane = body: world-frame matrices about the WORLD origin -------------------------------------------------
@@ -763,12 +780,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             break;
         }
         // constraint rows s_k [Ad(c0<-g) X_k] (constraints.py:429-433, 203-207, 46-48): rows of J' in JR, columns of J'^T in Z
-        if (do_con) for (int e = tid; e < ndol * n; e += WIDE_THREADS) {
-            const int idx = e / n, k = e - idx * n, c = idx >> 2, r = idx & 3;
+        if (do_con) for (int e = tid; e < nda * n; e += WIDE_THREADS) {
+            const int idx = e / n, k = e - idx * n, c = ORDL[idx >> 2], r = idx & 3;
             const double *cd = CD + WIDE_CD * c;
             const int ct = M.ctype[c];
             double v = 0.;
-            if (cd[16] != 0.) {
+            {
                 if (ct == ARB_CT_JOINTLIMITS) {
                     v = (r == 0 && k == M.cdof[c]) ? 1. : 0.;
                 } else if (r < (ct == ARB_CT_SOFTFINGER ? 4 : 3)) {
@@ -815,7 +832,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 for (int j = 0; j < n; ++j) accz += (double)io.zimp[((long)w * n + i) * n + j] * DQS[j];
                 rhs += accz;
             }
-            if (do_con && M.has_warm) for (int idx = 0; idx < ndol; ++idx) rhs += JR[idx * n + i] * FF[idx];
+            if (do_con && M.has_warm) for (int idx = 0; idx < nda; ++idx) rhs += JR[idx * n + i] * FF[4 * ORDL[idx >> 2] + (idx & 3)];
             if (io.inspect) {
                 if (io.gforce0 != nullptr) io.gforce0[w * n + i] = (T)gf0;
                 if (io.Zout != nullptr) for (int c = 0; c < n; ++c) io.Zout[((long)w * n + i) * n + c] = (T)Z[i * ld + c];
@@ -826,10 +843,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         __syncthreads();
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 4] = (long long)clock64();
         // ================= phase C: pivot-free Gauss-Jordan, pivots from the last dof to the first (core.py:818) ==========
-        const int nact = do_con ? ncols : n + 1;
+        const int nact = n + 1 + nda;                 // (the live columns: dofs, right-hand side, the active constraints' four each)
         if constexpr (REGZ) {
             // (LDS offsets as integers: the difference of two generic pointers into LDS is an expression the back end mishandles)
-            const int zl0 = ((ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((ndol + 3) & ~3) + 59 * nc;
+            const int zl0 = ((ncols + 3) & ~3) + ((n + 3) & ~3) + 8 + 48 + 2 * ((nds + 3) & ~3) + 59 * ncap + (ncap & 1) + 2 * ((ncap + 5) >> 2);
             wide_eliminate<KMAX, CP>(Z, ld, n, nact, zl0, zl0 + (int)M.l_reg + (int)M.l_sol, sld, DQS, M.sol_in_lds ? nullptr : S + M.o_sol);
         } else {
         for (int j = n - 1; j >= 0; --j) {
@@ -875,27 +892,46 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 5] = (long long)clock64();
         // ================= phase D: [v' | Y'] = J' [Y rhs | Y J'^T] (core.py:925-927), block inverses =========================
         if (do_con) {
-            for (int e = tid; e < ndol * (ndol + 1); e += WIDE_THREADS) {
-                const int idx = e / (ndol + 1), c = e - idx * (ndol + 1);
+            for (int e = tid; e < nda * (nda + 1); e += WIDE_THREADS) {
+                const int idx = e / (nda + 1), c = e - idx * (nda + 1);
                 double acc = 0.;
-                if (CD[WIDE_CD * (idx >> 2) + 16] != 0.) {
+                {
                     const double *jr = JR + idx * n;
                     for (int k = 0; k < n; ++k) acc += jr[k] * SL[k * sld + c];
                 }
-                if (c == 0) VV[idx] = acc; else AM[idx * ndol + (c - 1)] = acc;
+                if (c == 0) VV[idx] = acc; else AM[idx * nds + (c - 1)] = acc;
             }
             __syncthreads();
             if (io.inspect) {
-                if (io.c_adm != nullptr) for (int i = tid; i < ndol * ndol; i += WIDE_THREADS) io.c_adm[(long)w * ndol * ndol + i] = (T)AM[i];
-                if (io.c_vel != nullptr) for (int i = tid; i < ndol; i += WIDE_THREADS) io.c_vel[(long)w * ndol + i] = (T)VV[i];
-                if (io.c_jac != nullptr) for (int i = tid; i < ndol * n; i += WIDE_THREADS) io.c_jac[(long)w * ndol * n + i] = (T)JR[i];
+                // (by constraint, as the caller registered them: zero where a constraint is not active)
+                if (io.c_adm != nullptr) {
+                    for (int i = tid; i < ndol * ndol; i += WIDE_THREADS) io.c_adm[(long)w * ndol * ndol + i] = T(0);
+                    __syncthreads();
+                    for (int e = tid; e < nda * nda; e += WIDE_THREADS) {
+                        const int i = e / nda, j2 = e - i * nda;
+                        io.c_adm[(long)w * ndol * ndol + (long)(4 * ORDL[i >> 2] + (i & 3)) * ndol + 4 * ORDL[j2 >> 2] + (j2 & 3)] = (T)AM[i * nds + j2];
+                    }
+                }
+                if (io.c_vel != nullptr) {
+                    for (int i = tid; i < ndol; i += WIDE_THREADS) io.c_vel[(long)w * ndol + i] = T(0);
+                    __syncthreads();
+                    for (int i = tid; i < nda; i += WIDE_THREADS) io.c_vel[(long)w * ndol + 4 * ORDL[i >> 2] + (i & 3)] = (T)VV[i];
+                }
+                if (io.c_jac != nullptr) {
+                    for (int i = tid; i < ndol * n; i += WIDE_THREADS) io.c_jac[(long)w * ndol * n + i] = T(0);
+                    __syncthreads();
+                    for (int e = tid; e < nda * n; e += WIDE_THREADS) {
+                        const int i = e / n, k = e - i * n;
+                        io.c_jac[(long)w * ndol * n + (long)(4 * ORDL[i >> 2] + (i & 3)) * n + k] = (T)JR[e];
+                    }
+                }
             }
-            for (int c = tid; c < nc; c += WIDE_THREADS) {
+            for (int sl = tid; sl < nca; sl += WIDE_THREADS) {
+                const int c = ORDL[sl];
                 double *cd = CD + WIDE_CD * c;
-                if (cd[16] == 0.) continue;
                 const int ct = M.ctype[c], nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 double P[16];
-                if (!inv_block<double>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P)) pinv_block<double>(AM + (4 * c) * ndol + 4 * c, ndol, nd, P);
+                if (!inv_block<double>(AM + (4 * sl) * nds + 4 * sl, nds, nd, P)) pinv_block<double>(AM + (4 * sl) * nds + 4 * sl, nds, nd, P);
                 for (int i = 0; i < 16; ++i) cd[24 + i] = P[i];
             }
             __syncthreads();
@@ -917,58 +953,57 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
             // knob "wide_gs_groups" 0: the serial sweep, which the tests compare with).  human36 beside four objects: rounds of
             // four solves instead of eight.
             if (tid < WAVE) {
-                for (int c = tid; c < nc; c += WAVE) {
-                    const double *cd = CD + WIDE_CD * c;
+                // (from here on c, c2 are SLOTS: the step's active constraints in registration order)
+                for (int c = tid; c < nca; c += WAVE) {
+                    const int cc = ORDL[c];                                      // (the constraint in this slot)
+                    const double *cd = CD + WIDE_CD * cc;
                     double *g = GSC + 52 * c;
-                    for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2) g[4 * i + j2] = AM[(4 * c + i) * ndol + 4 * c + j2];
+                    for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2) g[4 * i + j2] = AM[(4 * c + i) * nds + 4 * c + j2];
                     for (int i = 0; i < 16; ++i) g[16 + i] = cd[24 + i];
-                    g[32] = cd[15]; g[33] = M.cmu[c]; g[34] = M.ceps[3 * c]; g[35] = M.ceps[3 * c + 1]; g[36] = M.ceps[3 * c + 2];
+                    g[32] = cd[15]; g[33] = M.cmu[cc]; g[34] = M.ceps[3 * cc]; g[35] = M.ceps[3 * cc + 1]; g[36] = M.ceps[3 * cc + 2];
                     g[37] = cd[12] * inv_dt; g[38] = cd[13] * inv_dt; g[39] = cd[14] * inv_dt; g[40] = cd[17]; g[41] = cd[18];
-                    g[42] = (double)M.ctype[c]; g[43] = cd[16];
+                    g[42] = (double)M.ctype[cc]; g[43] = cd[16];
                     // per-step constants of the sliding solve (admittance-only part of the sextic) and the warm start of its root
                     // finder, as the wavefront kernels keep them per contact (arb_gs_stage.h): [44..49] SlidePre, [50] last root
-                    if (cd[16] != 0. && M.ctype[c] == ARB_CT_SOFTFINGER) {
+                    if (M.ctype[cc] == ARB_CT_SOFTFINGER) {
                         const SlidePre sp = slide_precompute<double>(g);
                         g[44] = sp.tr; g[45] = sp.m2; g[46] = sp.det; g[47] = sp.sQ; g[48] = sp.sA; g[49] = sp.nq;
                     }
                     g[50] = NAN;
                     // the constraints this one is coupled with (itself included), a bit each
-                    unsigned long long m = 0ull;
-                    if (cd[16] != 0.) {
-                        m = 1ull << c;
-                        if (!io.gs_serial) {
-                            for (int c2 = 0; c2 < nc; ++c2) {
-                                if (c2 == c || CD[WIDE_CD * c2 + 16] == 0.) continue;
-                                bool nz = false;
-                                for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2)
-                                    nz = nz || AM[(4 * c + i) * ndol + 4 * c2 + j2] != 0. || AM[(4 * c2 + i) * ndol + 4 * c + j2] != 0.;
-                                if (nz) m |= 1ull << c2;
-                            }
-                        } else {
-                            for (int c2 = 0; c2 < nc; ++c2) if (CD[WIDE_CD * c2 + 16] != 0.) m |= 1ull << c2;       // (one group)
+                    unsigned long long m = 1ull << c;
+                    if (!io.gs_serial) {
+                        for (int c2 = 0; c2 < nca; ++c2) {
+                            if (c2 == c) continue;
+                            bool nz = false;
+                            for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2)
+                                nz = nz || AM[(4 * c + i) * nds + 4 * c2 + j2] != 0. || AM[(4 * c2 + i) * nds + 4 * c + j2] != 0.;
+                            if (nz) m |= 1ull << c2;
                         }
+                    } else {
+                        m = nca >= 64 ? ~0ull : (1ull << nca) - 1ull;            // (one group)
                     }
                     GGM[c] = m;
                 }
-                for (int r = tid; r < ndol; r += WAVE) { GVV[r] = VV[r]; GFF[r] = FF[r]; }
+                for (int r = tid; r < nda; r += WAVE) { GVV[r] = VV[r]; GFF[r] = FF[4 * ORDL[r >> 2] + (r & 3)]; }
                 WAVE_SYNC();
-                // connected components: every mask takes over the masks of its members, six times (2^6 >= 64 constraints)
+                // connected components: every mask takes over the masks of its members, six times (2^6 >= 64 slots)
                 for (int it = 0; it < 6; ++it) {
-                    unsigned long long m = tid < nc ? GGM[tid] : 0ull, m2 = m;
+                    unsigned long long m = tid < nca ? GGM[tid] : 0ull, m2 = m;
                     for (unsigned long long rest = m; rest; rest &= rest - 1) m2 |= GGM[__builtin_ctzll(rest)];
                     WAVE_SYNC();
-                    if (tid < nc) GGM[tid] = m2;
+                    if (tid < nca) GGM[tid] = m2;
                     WAVE_SYNC();
                 }
                 // (lane c < nc: leads its group when it is the group's lowest constraint)
-                const unsigned long long grp = tid < nc ? GGM[tid] : 0ull;
+                const unsigned long long grp = tid < nca ? GGM[tid] : 0ull;
                 const unsigned long long mine = (grp != 0ull && __builtin_ctzll(grp) == tid) ? grp : 0ull;
                 for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
                     if (tid == 0) DF[4] = 0.;                                    // "something changed in this sweep"
                     WAVE_SYNC();
                     unsigned long long rem = mine;
                     while (__any(rem != 0ull)) {
-                        if (tid < nc) GDF[6 * tid + 4] = -1.;                    // (no update from this group in this round)
+                        if (tid < nca) GDF[6 * tid + 4] = -1.;                   // (no update from this group in this round)
                         if (rem != 0ull) {
                             const int c = __builtin_ctzll(rem);
                             rem &= rem - 1;
@@ -1009,13 +1044,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                             if (ch) DF[4] = 1.;
                         }
                         WAVE_SYNC();
-                        for (int r = tid; r < ndol; r += WAVE) {                  // vel += Y'[:, c] dforce   core.py:935
-                            const unsigned long long gr = GGM[r >> 2];
-                            if (gr == 0ull) continue;                            // (an inactive constraint's rows: never read)
-                            const double *gd = GDF + 6 * __builtin_ctzll(gr);
+                        for (int r = tid; r < nda; r += WAVE) {                   // vel += Y'[:, c] dforce   core.py:935
+                            const double *gd = GDF + 6 * __builtin_ctzll(GGM[r >> 2]);
                             const int c = (int)gd[4];
                             if (c < 0) continue;
-                            const double *a = AM + r * ndol + 4 * c;
+                            const double *a = AM + r * nds + 4 * c;
                             GVV[r] += a[0] * gd[0] + a[1] * gd[1] + a[2] * gd[2] + a[3] * gd[3];
                         }
                         WAVE_SYNC();
@@ -1025,7 +1058,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     if (DF[4] == 0.) break;
                     WAVE_SYNC();
                 }
-                for (int r = tid; r < ndol; r += WAVE) { VV[r] = GVV[r]; FF[r] = GFF[r]; }
+                for (int r = tid; r < nda; r += WAVE) { VV[r] = GVV[r]; FF[4 * ORDL[r >> 2] + (r & 3)] = GFF[r]; }
             }
             __syncthreads();
         }
@@ -1034,7 +1067,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         if (io.inspect) {
             if (io.gforce != nullptr) for (int i = tid; i < n; i += WIDE_THREADS) {
                 double g = RH[n + i];
-                if (do_con) for (int idx = 0; idx < ndol; ++idx) g += JR[idx * n + i] * FF[idx];
+                if (do_con) for (int idx = 0; idx < nda; ++idx) g += JR[idx * n + i] * FF[4 * ORDL[idx >> 2] + (idx & 3)];
                 io.gforce[w * n + i] = (T)g;
             }
             if (io.c_force != nullptr) for (int i = tid; i < ndol; i += WIDE_THREADS) io.c_force[w * ndol + i] = (T)FF[i];
@@ -1045,7 +1078,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         }
         for (int i = tid; i < n; i += WIDE_THREADS) {
             double vnew = SL[i * sld];
-            if (do_con) for (int idx = 0; idx < ndol; ++idx) vnew += SL[i * sld + 1 + idx] * (FF[idx] - FF0[idx]);
+            if (do_con) for (int idx = 0; idx < nda; ++idx) { const int fi = 4 * ORDL[idx >> 2] + (idx & 3); vnew += SL[i * sld + 1 + idx] * (FF[fi] - FF0[fi]); }
             RH[i] = vnew;
         }
         __syncthreads();

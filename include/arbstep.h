@@ -379,8 +379,14 @@ int arb_model_status(arb_model *m);
  *                      model with ARB_F64.  The results are still written; the warning does not stop anything.
  *                      (Since ABI 8 only launches pinned with ARB_STEP_NO_MIXED can raise it for such a model: by default its
  *                      float32 launches are promoted to the float64 kernels, see ARB_STEP_MIXED.)
+ *   ARB_WARN_ACTIVE_CONSTRAINTS   (ABI 8, worlds on the wide kernels: arb_model_info.wide) more than 64 of a world's constraints
+ *                      were ACTIVE in one step.  Such a world may register up to ARB_WIDE_MAX_CONSTRAINTS -- every pair of
+ *                      get_all_contacts, constraints.py:840-875 -- and its steps solve on the active ones; beyond 64 the later
+ *                      ones in registration order are left out of that step's solve (the reference would stack them all,
+ *                      core.py:898-935).
  */
 #define ARB_WARN_ILLCOND 1u
+#define ARB_WARN_ACTIVE_CONSTRAINTS 2u
 #define ARB_ILLCOND_GROWTH 2048.0   /* 2^11: the float32 kernels compare exponents */
 int arb_model_warnings(arb_model *m, uint32_t *warnings);
 
@@ -495,6 +501,7 @@ int arb_inspect(arb_model *m, int dtype, const void *q, const void *dq,
  * modified; nsteps is ignored: one step).  Control sequences, dt_steps, log and cost are refused (ARB_ERR_INVALID). */
 int arb_inspect_ex(arb_model *m, int dtype, const arb_step_args *args, const arb_inspect_out *out, void *stream);
 
+#define ARB_WIDE_MAX_CONSTRAINTS 256   /* (ABI 8) constraints a wide world may REGISTER (every pair of get_all_contacts); at most 64 active per step */
 #define ARB_WIDE_MAX 1024  /* (ABI 8) largest ndof / nb of a world (the wide kernels: one workgroup of 256 lanes per world; past 192 dofs the
                               * augmented system lives in scratch memory: a capability, ~n^3 slower) */
 

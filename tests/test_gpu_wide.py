@@ -438,11 +438,13 @@ def test_wide_kernels_against_the_reference_itself_g15():
         bw.close()
 
 
-def test_every_pair_of_get_all_contacts_on_a_60_dof_world_runs_wide():
-    """`get_all_contacts` (constraints.py:840-875) pairs every two shapes of a world: human36 (eight foot points) beside three free
-    balls on a ground plane has 38 SoftFingerContacts -- plane / point, plane / ball, ball / point, ball / ball -- on 60 dofs:
-    213 columns, past the wavefront kernels' 128 although the world has fewer than 64 dofs.  `arb_model_create` routes it to the
-    wide kernels (compact build, four columns per lane); 25 steps against the oracle, step by step, float64."""
+@pytest.mark.parametrize("nballs", [3, 8])
+def test_every_pair_of_get_all_contacts_runs_wide(nballs):
+    """`get_all_contacts` (constraints.py:840-875) pairs every two shapes of a world: human36 (eight foot points) beside free balls
+    on a ground plane.  Three balls: 38 SoftFingerContacts -- plane / point, plane / ball, ball / point, ball / ball -- on 60 dofs,
+    213 columns: past the wavefront kernels' 128 although the world has fewer than 64 dofs.  Eight balls: 108 contacts on 90 dofs
+    -- more than the 64 a step may have ACTIVE, which is all that counts: the wide kernels solve on the step's active constraints
+    (slots; `ARB_WIDE_MAX_CONSTRAINTS` = 256 may be registered).  25 steps against the oracle, step by step, float64; no warning."""
     from arboris_python_amd.core import World, Body
     from arboris_python_amd.joints import FreeJoint
     from arboris_python_amd.shapes import Sphere
@@ -456,10 +458,11 @@ def test_every_pair_of_get_all_contacts_on_a_60_dof_world_runs_wide():
     w = World()
     add_groundplane(w)
     add_human36(w)
-    for k in range(3):
+    for k in range(nballs):
         body = Body(name="Ball%d" % k, mass=massmatrix.sphere(0.1, 1.0 + k))
         j = FreeJoint(name="BallRoot%d" % k)
-        j.gpos = Hg.transl(0.12 + 0.19 * k, 0.105, 0.05 * k)          # (a row of balls in front of the feet, touching one another)
+        # (rows of balls in front of the feet, touching one another)
+        j.gpos = Hg.transl(0.12 + 0.19 * (k % 4), 0.105, 0.05 * (k % 4) + 0.21 * (k // 4))
         w.add_link(w.ground, j, body)
         w.register(Sphere(body, 0.1, name="Ball%d" % k))
     w.register(WeightController())
@@ -467,7 +470,7 @@ def test_every_pair_of_get_all_contacts_on_a_60_dof_world_runs_wide():
         w.register(c)
     w.init()
     m, q0, dq0 = flatten_world(w)
-    assert m.ndof == 60 and m.nc == 38
+    assert m.ndof == 42 + 6 * nballs and m.nc == 8 + nballs + nballs * (nballs - 1) // 2 + 8 * nballs
     bw = BatchedWorlds(m)
     assert bw.info["wide"] == 1
     B, dt, T = 4, 5e-3, 25
@@ -482,7 +485,57 @@ def test_every_pair_of_get_all_contacts_on_a_60_dof_world_runs_wide():
         bw.step(tq, tdq, dt, 1, cforce=cf)
         worst = max(worst, _rel(tq.cpu().numpy(), oq).max(), _rel(tdq.cpu().numpy(), odq).max())
         seen |= (np.abs(ocf).max(axis=(0, 2)) > 0)
-    print("human36 + 3 balls, every pair (38 contacts): %d steps, worst state error %.2e, %d contacts carried a force" % (T, worst, seen.sum()))
+    print("human36 + %d balls, every pair (%d contacts): %d steps, worst state error %.2e, %d contacts carried a force"
+          % (nballs, m.nc, T, worst, seen.sum()))
     assert worst < 1e-8 and seen.sum() >= 8
     assert np.abs(cf.cpu().numpy() - ocf).max() <= 1e-6 * max(1., np.abs(ocf).max())
+    assert bw.warnings() == 0
+    # the inspect outputs come back by CONSTRAINT, zero where one is not active
+    r = bw.inspect(tq, tdq, dt, ["c_active", "c_adm", "c_force"], cforce=cf)
+    act = r["c_active"][0].cpu().numpy().astype(bool)
+    adm = r["c_adm"][0].cpu().numpy().reshape(m.nc, 4, m.nc, 4)
+    assert 0 < act.sum() <= 64 and (np.abs(adm[~act]).max() == 0 if (~act).any() else True)
+    assert (np.abs(adm[act][:, :, act]).max(axis=(1, 3)).diagonal() > 0).all()
     bw.close()
+
+
+def test_more_than_64_active_constraints_raise_a_warning():
+    """Seventy free balls resting on the floor: 70 plane / ball contacts active at once (420 dofs: the scratch build).  A step keeps
+    the first 64 in registration order, leaves the others out of its solve -- their balls fall through -- and raises
+    ARB_WARN_ACTIVE_CONSTRAINTS on the handle (include/arbstep.h); with 64 balls nothing is raised."""
+    from arboris_python_amd.core import World, Body
+    from arboris_python_amd.joints import FreeJoint
+    from arboris_python_amd.shapes import Sphere
+    from arboris_python_amd import massmatrix, homogeneousmatrix as Hg
+    from arboris_python_amd.robots.simpleshapes import add_groundplane
+    from arboris_python_amd.controllers import WeightController
+    from arboris_python_amd.constraints import get_all_contacts
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    for nballs, expect in ((64, 0), (70, _capi.ARB_WARN_ACTIVE_CONSTRAINTS)):
+        w = World()
+        add_groundplane(w)
+        for k in range(nballs):
+            body = Body(name="Ball%d" % k, mass=massmatrix.sphere(0.1, 1.0))
+            j = FreeJoint(name="BallRoot%d" % k)
+            j.gpos = Hg.transl(0.3 * (k % 10), 0.1, 0.3 * (k // 10))
+            w.add_link(w.ground, j, body)
+            w.register(Sphere(body, 0.1, name="Ball%d" % k))
+        w.register(WeightController())
+        for c in get_all_contacts(w, friction_coeff=0.6):
+            if type(c._shapes[0]).__name__ == "Plane":
+                w.register(c)
+        w.init()
+        m, q0, dq0 = flatten_world(w)
+        assert m.nc == nballs and m.ndof == 6 * nballs
+        bw = BatchedWorlds(m)
+        tq, tdq = bw.to_device(q0[None], dq0[None], torch.float64)
+        cf = bw.new_cforce(1, torch.float64)
+        bw.step(tq, tdq, 5e-3, 2, cforce=cf)
+        torch.cuda.synchronize()
+        assert bw.warnings() == expect
+        f = cf.cpu().numpy()[0]
+        assert (np.abs(f[:64]).max(axis=1) > 0).all() and (np.abs(f[64:]) == 0).all()
+        vy = tdq.cpu().numpy()[0].reshape(nballs, 6)[:, 4]          # (free joint twist: angular 0..2, linear 3..5; y is up)
+        assert (np.abs(vy[:64]) < 1e-6).all() and (vy[64:] < -0.05).all()
+        bw.close()
