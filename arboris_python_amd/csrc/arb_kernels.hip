@@ -807,7 +807,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             L.am_in_lds = sub <= 2 ? 1 : 0;
             L.l_sol = (L.jr_in_lds && under) ? 24l * nb + jrsz : 0;
             L.sol_in_lds = (size_t)n * L.sld * sizeof(double) <= 64 * 1024 ? 1 : 0;      // (many constraints: 83 dofs x 249 columns are 165 KB)
-            long region = std::max((bodies ? 108l * nb : 0l) + (long)WIDE_XK * n, L.l_sol + (L.sol_in_lds ? (long)n * L.sld : 0l));
+            long region = (std::max((bodies ? 108l * nb : 0l) + (long)WIDE_XK * n, L.l_sol + (L.sol_in_lds ? (long)n * L.sld : 0l)) + 1) & ~1l;   // (16-byte steps)
             L.l_jr = under ? 24l * nb : region;                  // (... or a place of their own)
             if (L.jr_in_lds && !under) region += jrsz;
             const long head = 2l * 64 * L.cp;                               // (the pivot rows, double-buffered)
