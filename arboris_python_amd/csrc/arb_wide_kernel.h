@@ -95,6 +95,8 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
                 const int r = 4 * (4 * ch + e) + zg;
                 z[p][ch][e] = (r < n && l + 64 * p < nact) ? Z[r * ld + l + 64 * p] : 0.;
             }
+    // (column groups past the live columns -- a world that registers many constraints and has few of them active -- are skipped)
+    const int pl = (nact + 63) >> 6;
     for (int j = n - 1; j >= 0; --j) {
         lds_double *rb = RB + (j & 1) * (64 * CP);
         const int gj = j & 3, cj = j >> 4;
@@ -107,13 +109,13 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
         double t[CP];
         if (zg == gj) {
 #pragma unroll
-            for (int p = 0; p < CP; ++p) t[p] = wide_reg_get<0, NCH, NCH>(z[p], cj, ej);
+            for (int p = 0; p < CP; ++p) t[p] = (p < 2 || p < pl) ? wide_reg_get<0, NCH, NCH>(z[p], cj, ej) : 0.;
             double own = j < 64 ? t[0] : t[1];                       // (pivots are columns j < n <= 192: the lane's first three)
             if constexpr (CP > 2) own = j < 128 ? own : t[2];
             const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(own), j & 63), __builtin_amdgcn_readlane(__double2loint(own), j & 63));
             const double ip = arb_rcp(piv);
 #pragma unroll
-            for (int p = 0; p < CP; ++p) { t[p] = t[p] * ip; rb[l + 64 * p] = t[p]; }
+            for (int p = 0; p < CP; ++p) if (p < 2 || p < pl) { t[p] = t[p] * ip; rb[l + 64 * p] = t[p]; }
         }
         WIDE_STAMP(1);
         // the multipliers of this wavefront's rows are the registers of ITS lane j & 63 (column j): broadcast through scalar
@@ -133,17 +135,19 @@ __device__ __attribute__((noinline)) void wide_eliminate(const double *__restric
         WIDE_STAMP(3);
         if (zg != gj) {
 #pragma unroll
-            for (int p = 0; p < CP; ++p) t[p] = rb[l + 64 * p];
+            for (int p = 0; p < CP; ++p) t[p] = (p < 2 || p < pl) ? rb[l + 64 * p] : 0.;
         }
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
+        for (int p = 0; p < CP; ++p) {
+            if (p >= 2 && p >= pl) continue;
 #pragma unroll
-            for (int p = 0; p < CP; ++p) z[p][ch] = z[p][ch] - f[ch] * t[p];
+            for (int ch = 0; ch < NCH; ++ch) z[p][ch] = z[p][ch] - f[ch] * t[p];
+        }
         WIDE_STAMP(4);
         // (a branch per vector around the selects, inside the loop above, measured slower: 868 against 674 cycles)
         if (zg == gj) {
 #pragma unroll
-            for (int p = 0; p < CP; ++p) wide_reg_set<0, NCH, NCH>(z[p], cj, ej, t[p]);
+            for (int p = 0; p < CP; ++p) if (p < 2 || p < pl) wide_reg_set<0, NCH, NCH>(z[p], cj, ej, t[p]);
         }
         WIDE_STAMP(5);
     }
