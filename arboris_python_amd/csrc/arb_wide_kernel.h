@@ -900,8 +900,16 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 const int idx = e / (nda + 1), c = e - idx * (nda + 1);
                 double acc = 0.;
                 {
-                    const double *jr = JR + idx * n;
-                    for (int k = 0; k < n; ++k) acc += jr[k] * SL[k * sld + c];
+                    // (eight terms' operands in flight at a time -- the rows of J' and the solution columns of a world with many
+                    // constraints live in scratch, a dependent load per term was 400 cycles a term --, added in the same order)
+                    const double *jr = JR + idx * n, *sl = SL + c;
+                    int k = 0;
+                    for (; k + 8 <= n; k += 8) {
+                        double a[8], b[8];
+                        for (int u = 0; u < 8; ++u) { a[u] = jr[k + u]; b[u] = sl[(k + u) * sld]; }
+                        for (int u = 0; u < 8; ++u) acc += a[u] * b[u];
+                    }
+                    for (; k < n; ++k) acc += jr[k] * sl[k * sld];
                 }
                 if (c == 0) VV[idx] = acc; else AM[idx * nds + (c - 1)] = acc;
             }
