@@ -784,7 +784,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     //  what many constraints ask for: 124 rows of J' for 128 dofs are 127 KB --, 4 .. 6 = the same with the chain arrays and
     //  phase B's composites in scratch: what many BODIES ask for, 108 doubles each)
     auto layout = [&](WideModel &L, int compact, size_t *lds_out) {
-        L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = L.vec_in_lds = L.sol_in_lds = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = L.l_vec = 0;
+        L.kmax = 0; L.cp = 2; L.ac_in_lds = L.am_in_lds = L.jr_in_lds = L.vec_in_lds = L.sol_in_lds = L.am_cap = 0; L.l_am = L.l_ac = L.l_xk = L.l_jr = L.l_sol = L.l_reg = L.l_vec = 0;
         // the scratch block: state and small vectors first, then per-body wrenches and joint columns (the compact build may keep
         // these two groups in LDS), then everything else
         long o = 0;
@@ -800,8 +800,10 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             // (the rows of J' under the composites, dead by the time they are written, when they fit; the solution columns
             //  behind them -- the per-dof vectors, read while J' is written, lie past 108 nb)
             const long jrsz = ((long)nds * n + 1) & ~1l;
-            const bool bodies = compact <= 3;                    // (chain arrays and composites in LDS)
-            const int sub = bodies ? compact : compact - 3;
+            const bool capoff = compact > 6;                     // (7 .. 12: levels 1 .. 6 without the 32 KB kept for a packed admittance)
+            const int lvl = capoff ? compact - 6 : compact;
+            const bool bodies = lvl <= 3;                        // (chain arrays and composites in LDS)
+            const int sub = bodies ? lvl : lvl - 3;
             const bool under = bodies && ndol > 0 && jrsz <= 84l * nb;
             L.jr_in_lds = (ndol > 0 && sub == 1) ? 1 : 0;
             L.am_in_lds = sub <= 2 ? 1 : 0;
@@ -812,7 +814,9 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
             if (L.jr_in_lds && !under) region += jrsz;
             const long head = 2l * 64 * L.cp;                               // (the pivot rows, double-buffered)
             L.kmax = kmax; L.l_am = head; L.l_ac = 24l * nb; L.l_xk = bodies ? 108l * nb : 0;
-            L.l_reg = head + (L.am_in_lds ? ((nds * nds + 1) & ~1) : 0);
+            // (the admittance of the sweeps: all of it, or room for what <= 16 active constraints need -- the kernel packs the step's)
+            L.am_cap = L.am_in_lds ? nds * nds : ((nds > 0 && !capoff) ? std::min(nds * nds, 64 * 64) : 0);
+            L.l_reg = head + ((L.am_cap + 1) & ~1);
             L.ac_in_lds = bodies ? 1 : 0; L.chain_in_lds = bodies ? 1 : 0; L.z_in_lds = 0;
             L.l_vec = region;
             size_t lds = small + (size_t)(L.l_reg + region) * sizeof(double);
@@ -849,7 +853,7 @@ static int wide_create(const arb_model_desc *d, int device, arb_model **out) {
     rc = to_device(W, &M->wide_dev);
     if (rc == ARB_OK && ((n <= 192 && W.ncols <= 256) || (n <= 128 && W.ncols <= 384))) {      // (rows per wavefront x columns per lane: registers)
         M->wide_c = W;
-        for (int level = 1; level <= 6; ++level) {
+        for (int level = 1; level <= 12; ++level) {
             layout(M->wide_c, level, &M->wide_c_lds);
             if (M->wide_c_lds <= 150 * 1024) { rc = to_device(M->wide_c, &M->wide_c_dev); break; }
         }

@@ -176,6 +176,7 @@ struct WideModel {
     int nb, n, nq, nc, ndol, ncap, nds, ncols, ld, maxdepth, has_visc, has_pd, has_warm, has_grav, z_in_lds, chain_in_lds;
     int kmax, cp, ac_in_lds, am_in_lds, sld;                  // compact build: rows per lane (0: the LDS / scratch build); what else is in LDS
     long l_ac, l_xk, l_am, l_reg;                                // (offsets, doubles, inside the LDS region behind the sweeps' blocks)
+    int am_cap;                                             // compact build: doubles of LDS kept for the admittance of the sweeps (0: none)
     int vec_in_lds;                                         // compact build: 1 = the state and the small per-world vectors in LDS, 2 = per-body wrenches and joint columns too
     long l_vec;
     int jr_in_lds;                                          // compact build: the rows of J' in LDS (under the dead composites)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
            *OM = CHB + (M.o_om - M.o_pose), *DA = CHB + (M.o_da - M.o_pose), *TN = CHB + (M.o_tn - M.o_pose), *BN = CHB + (M.o_bn - M.o_pose),
            *PT = V2 + M.o_pt, *SC = V2 + M.o_sc, *AC = M.ac_in_lds ? ZL + M.l_ac : S + M.o_ac, *MC = M.ac_in_lds ? AC + 36 * nb : S + M.o_mc,
            *WC = M.ac_in_lds ? AC + 72 * nb : S + M.o_wc, *XK = REGZ ? ZL + M.l_xk : S + M.o_xk, *RH = V1 + M.o_rh, *JR = M.jr_in_lds ? ZL + M.l_jr : S + M.o_jr,
-           *AM = M.am_in_lds ? GAM : S + M.o_am, *VV = V1 + M.o_vv, *CD = V1 + M.o_cd;
+           *AMG = S + M.o_am, *VV = V1 + M.o_vv, *CD = V1 + M.o_cd;
     double *Z = M.z_in_lds ? ZL : S + M.o_z;
     // the solution columns [Y rhs | Y J'^T] after the elimination: inside Z, or (compact build) written out of the registers
     const double *SL = REGZ ? (M.sol_in_lds ? ZL + M.l_sol : S + M.o_sol) : Z + n;
@@ -592,6 +593,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
         }
         __syncthreads();
         const int nca = ORDL[ncap], nda = 4 * nca;
+        // the admittance Y' of the step's active constraints, packed (row stride = their 4 nca rows): in LDS when it fits what the
+        // layout keeps for it -- a world that registers 108 constraints and has 15 active reads 28 KB, not 0.5 MB of scratch
+        const bool am_l = nda * nda <= M.am_cap;
+        double *const AM = am_l ? GAM : AMG;
+        const int ams = am_l ? nda : nds;
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 2] = (long long)clock64();
         // ================= phase B: composite assembly of Z = M/dt + B + N (core.py:722-734, 813), see arb_phase_b.h =========
         // ---- lane = body: world-frame matrices about the WORLD origin -------------------------------------------------
@@ -911,7 +917,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     }
                     for (; k < n; ++k) acc += jr[k] * sl[k * sld];
                 }
-                if (c == 0) VV[idx] = acc; else AM[idx * nds + (c - 1)] = acc;
+                if (c == 0) VV[idx] = acc; else AM[idx * ams + (c - 1)] = acc;
             }
             __syncthreads();
             if (io.inspect) {
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     __syncthreads();
                     for (int e = tid; e < nda * nda; e += WIDE_THREADS) {
                         const int i = e / nda, j2 = e - i * nda;
-                        io.c_adm[(long)w * ndol * ndol + (long)(4 * ORDL[i >> 2] + (i & 3)) * ndol + 4 * ORDL[j2 >> 2] + (j2 & 3)] = (T)AM[i * nds + j2];
+                        io.c_adm[(long)w * ndol * ndol + (long)(4 * ORDL[i >> 2] + (i & 3)) * ndol + 4 * ORDL[j2 >> 2] + (j2 & 3)] = (T)AM[i * ams + j2];
                     }
                 }
                 if (io.c_vel != nullptr) {
@@ -943,7 +949,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                 double *cd = CD + WIDE_CD * c;
                 const int ct = M.ctype[c], nd = (ct == ARB_CT_SOFTFINGER) ? 4 : (ct == ARB_CT_BALLSOCKET ? 3 : 1);
                 double P[16];
-                if (!inv_block<double>(AM + (4 * sl) * nds + 4 * sl, nds, nd, P)) pinv_block<double>(AM + (4 * sl) * nds + 4 * sl, nds, nd, P);
+                if (!inv_block<double>(AM + (4 * sl) * ams + 4 * sl, ams, nd, P)) pinv_block<double>(AM + (4 * sl) * ams + 4 * sl, ams, nd, P);
                 for (int i = 0; i < 16; ++i) cd[24 + i] = P[i];
             }
             __syncthreads();
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     const int cc = ORDL[c];                                      // (the constraint in this slot)
                     const double *cd = CD + WIDE_CD * cc;
                     double *g = GSC + 52 * c;
-                    for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2) g[4 * i + j2] = AM[(4 * c + i) * nds + 4 * c + j2];
+                    for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2) g[4 * i + j2] = AM[(4 * c + i) * ams + 4 * c + j2];
                     for (int i = 0; i < 16; ++i) g[16 + i] = cd[24 + i];
                     g[32] = cd[15]; g[33] = M.cmu[cc]; g[34] = M.ceps[3 * cc]; g[35] = M.ceps[3 * cc + 1]; g[36] = M.ceps[3 * cc + 2];
                     g[37] = cd[12] * inv_dt; g[38] = cd[13] * inv_dt; g[39] = cd[14] * inv_dt; g[40] = cd[17]; g[41] = cd[18];
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                             if (c2 == c) continue;
                             bool nz = false;
                             for (int i = 0; i < 4; ++i) for (int j2 = 0; j2 < 4; ++j2)
-                                nz = nz || AM[(4 * c + i) * nds + 4 * c2 + j2] != 0. || AM[(4 * c2 + i) * nds + 4 * c + j2] != 0.;
+                                nz = nz || AM[(4 * c + i) * ams + 4 * c2 + j2] != 0. || AM[(4 * c2 + i) * ams + 4 * c + j2] != 0.;
                             if (nz) m |= 1ull << c2;
                         }
                     } else {
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                             const double *gd = GDF + 6 * __builtin_ctzll(GGM[r >> 2]);
                             const int c = (int)gd[4];
                             if (c < 0) continue;
-                            const double *a = AM + r * nds + 4 * c;
+                            const double *a = AM + r * ams + 4 * c;
                             GVV[r] += a[0] * gd[0] + a[1] * gd[1] + a[2] * gd[2] + a[3] * gd[3];
                         }
                         WAVE_SYNC();
