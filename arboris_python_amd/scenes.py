@@ -90,6 +90,32 @@ def human36_and_objects_world(nobjects=4, friction_coeff=0.6):
     return w
 
 
+def human36_and_balls_world(nballs=3, friction_coeff=0.6):
+    """human36 beside ``nballs`` free balls on the ground plane with EVERY pair of shapes ``get_all_contacts`` finds
+    (constraints.py:840-875) registered: plane / point (the eight foot points), plane / ball, ball / point, ball / ball --
+    8 + n + 8 n + n (n - 1) / 2 SoftFingerContacts (three balls: 38 on 60 dofs; eight: 108 on 90 dofs), of which a step has
+    ten to thirty active: the reference's idiom for a scene, and what the wide kernels' slots are for."""
+    from .core import Body
+    from .joints import FreeJoint
+    from .shapes import Sphere
+    from . import massmatrix, homogeneousmatrix as Hg
+    w = World()
+    add_groundplane(w)
+    add_human36(w)
+    for k in range(nballs):
+        body = Body(name="Ball%d" % k, mass=massmatrix.sphere(0.1, 1.0 + k))
+        j = FreeJoint(name="BallRoot%d" % k)
+        # (rows of balls in front of the feet, touching one another)
+        j.gpos = Hg.transl(0.12 + 0.19 * (k % 4), 0.105, 0.05 * (k % 4) + 0.21 * (k // 4))
+        w.add_link(w.ground, j, body)
+        w.register(Sphere(body, 0.1, name="Ball%d" % k))
+    w.register(WeightController())
+    for c in get_all_contacts(w, friction_coeff=friction_coeff):
+        w.register(c)
+    w.init()
+    return w
+
+
 def flat(world):
     """FlatModel of an initialised world."""
     return flatten_world(world)[0]

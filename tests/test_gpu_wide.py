@@ -445,30 +445,10 @@ def test_every_pair_of_get_all_contacts_runs_wide(nballs):
     213 columns: past the wavefront kernels' 128 although the world has fewer than 64 dofs.  Eight balls: 108 contacts on 90 dofs
     -- more than the 64 a step may have ACTIVE, which is all that counts: the wide kernels solve on the step's active constraints
     (slots; `ARB_WIDE_MAX_CONSTRAINTS` = 256 may be registered).  25 steps against the oracle, step by step, float64; no warning."""
-    from arboris_python_amd.core import World, Body
-    from arboris_python_amd.joints import FreeJoint
-    from arboris_python_amd.shapes import Sphere
-    from arboris_python_amd import massmatrix, homogeneousmatrix as Hg
-    from arboris_python_amd.robots.human36 import add_human36
-    from arboris_python_amd.robots.simpleshapes import add_groundplane
-    from arboris_python_amd.controllers import WeightController
-    from arboris_python_amd.constraints import get_all_contacts
+    from arboris_python_amd import scenes
     from arboris_python_amd.flatten import flatten_world
     from arboris_python_amd.batch import BatchedWorlds
-    w = World()
-    add_groundplane(w)
-    add_human36(w)
-    for k in range(nballs):
-        body = Body(name="Ball%d" % k, mass=massmatrix.sphere(0.1, 1.0 + k))
-        j = FreeJoint(name="BallRoot%d" % k)
-        # (rows of balls in front of the feet, touching one another)
-        j.gpos = Hg.transl(0.12 + 0.19 * (k % 4), 0.105, 0.05 * (k % 4) + 0.21 * (k // 4))
-        w.add_link(w.ground, j, body)
-        w.register(Sphere(body, 0.1, name="Ball%d" % k))
-    w.register(WeightController())
-    for c in get_all_contacts(w, friction_coeff=0.6):
-        w.register(c)
-    w.init()
+    w = scenes.human36_and_balls_world(nballs)
     m, q0, dq0 = flatten_world(w)
     assert m.ndof == 42 + 6 * nballs and m.nc == 8 + nballs + nballs * (nballs - 1) // 2 + 8 * nballs
     bw = BatchedWorlds(m)

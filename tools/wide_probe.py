@@ -36,3 +36,8 @@ for nobj in (4, 12):                     # (66 dofs / 8 contacts: 99 columns; 11
         q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1)) + rng.uniform(-0.1, 0.1, (B, m.ndof))
         for dtype in (torch.float32, torch.float64):
             leg("human36 + %d objects" % nobj, m, q, dq, 5e-3, 40, dtype, True)
+for nballs in (3, 8):                    # (every pair of get_all_contacts: 38 contacts on 60 dofs, 108 on 90; 10-30 active)
+    m, q0, dq0 = flatten_world(scenes.human36_and_balls_world(nballs))
+    B = 512
+    q = np.tile(q0, (B, 1)); dq = np.tile(dq0, (B, 1)) + np.random.default_rng(0).uniform(-0.05, 0.05, (B, m.ndof))
+    leg("human36 + %d balls, all pairs" % nballs, m, q, dq, 5e-3, 40, torch.float64, True)
