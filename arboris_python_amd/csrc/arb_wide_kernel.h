@@ -5,16 +5,19 @@
 // free objects is past 64).  The step kernel of arb_step_kernel.h holds a world in ONE wavefront -- column per lane, the
 // augmented system in registers -- which ends at 64 dofs.  This kernel takes over above that: the same phases and the same
 // formulas (world-frame composite assembly of Z, increment form, pivot-free Gauss-Jordan from the last dof to the first,
-// 20 Gauss-Seidel sweeps with the local solves of arb_math.h), written for generality instead of for the last cycle:
+// 20 Gauss-Seidel sweeps with the local solves of arb_math.h):
 //   * float64 arithmetic whatever the buffers' type (T is only the type of the caller's state buffers);
-//   * a world's intermediate data lives in a per-workgroup block of global scratch (L2-resident: 50 KB .. 1 MB per world),
-//     the augmented system [Z | rhs | J'^T] in LDS when it fits 128 KB, in scratch otherwise; LDS also holds the pivot row
-//     and column of the elimination;
-//   * lane = body / dof / constraint / matrix entry as the phase needs, __syncthreads() between phases;
-//   * workgroups loop over the worlds of the batch (grid = min(worlds, 2 per CU)), steps loop inside.
-// Limits: ndof, nb <= ARB_WIDE_MAX (1024), nc <= ARB_WIDE_MAX_CONSTRAINTS (256) of which at most 64 ACTIVE in one step.  Inputs: everything arb_step_ex takes -- state, constraint forces, user
-// torques (constant or a sequence), the dense impedance of user-defined controllers, per-world PD targets / gains (and target
-// sequences), per-step dt, state and energy logs, the running cost; the model's merged PD controllers.
+//   * lane = body / dof / constraint / column as the phase needs, __syncthreads() between phases; workgroups loop over the worlds
+//     of the batch, steps loop inside;
+//   * two builds of the same source, bit-identical by test: the COMPACT build below (augmented system [Z | rhs | J'^T] in registers,
+//     everything else in LDS as far as it fits) and the LDS / scratch build (the system in LDS when it fits 120 KB, else in a
+//     per-workgroup block of global scratch, L2-resident; pivot row and column of the elimination in LDS);
+//   * the solve works on the step's ACTIVE constraints ("slots", at most 64): a world may register every pair of get_all_contacts;
+//   * independent groups of constraints are swept side by side (same bits as the serial sweep).
+// Limits: ndof, nb <= ARB_WIDE_MAX (1024), nc <= ARB_WIDE_MAX_CONSTRAINTS (256) of which at most 64 ACTIVE in one step.  Inputs:
+// everything arb_step_ex takes -- state, constraint forces, user torques (constant or a sequence), the dense impedance of
+// user-defined controllers, per-world PD targets / gains (and target sequences), per-step dt, state and energy logs, the running
+// cost; the model's merged PD controllers.
 // Not supported (ARB_ERR_UNSUPPORTED): the execution variants of the wavefront kernels (split sweeps, matrix-core elimination).
 //
 // The COMPACT build (KMAX > 0; worlds of at most 192 dofs and 256 columns: snake-100, human36 beside a few objects) keeps the
