@@ -274,19 +274,22 @@ def build_model(cfg):
         return scenes.flat(scenes.snake_world(int(cfg["model"][5:])))
     if cfg["model"] == "human36_objects":
         return scenes.flat(scenes.human36_and_objects_world(cfg.get("objects", 4)))
+    if cfg["model"] == "human36_balls":
+        return scenes.flat(scenes.human36_and_balls_world(cfg.get("objects", 3)))
     return scenes.flat(scenes.human36_world(cfg["contacts"], pd=bool(cfg.get("pd"))))
 
 
 def make_states(cfg, model, lo, hi, seed):
     """Worlds [lo, hi) of the config's seeded global batch (world w has its own stream, seed = (seed, w))."""
     from arboris_python_amd import synth
-    if cfg["model"] == "human36_objects":
+    if cfg["model"] in ("human36_objects", "human36_balls"):
         # the scene as built (the human standing, the boxes beside it a centimetre above the floor), every world with its own
         # small velocities (world w draws from its own stream)
         import numpy as np
         from arboris_python_amd import scenes
         from arboris_python_amd.flatten import flatten_world
-        _, q0, dq0 = flatten_world(scenes.human36_and_objects_world(cfg.get("objects", 4)))
+        _, q0, dq0 = flatten_world(scenes.human36_and_balls_world(cfg.get("objects", 3)) if cfg["model"] == "human36_balls"
+                                   else scenes.human36_and_objects_world(cfg.get("objects", 4)))
         q = np.tile(q0, (hi - lo, 1))
         dq = np.stack([dq0 + np.random.default_rng([seed, w]).uniform(-0.1, 0.1, size=len(dq0)) for w in range(lo, hi)])
         return q, dq
@@ -751,7 +754,11 @@ def main():
                                                                                "with a ball each on the floor: 66 dofs, 8 contacts, the wide kernels")),
                         ("human36_and_12_objects", dict(model="human36_objects", objects=12, contacts=16, batch=1024, dtype="f32", dt=5e-3,
                                                         episode=40, states="standing", name="human36 beside twelve free boxes: 114 dofs, "
-                                                                                            "16 contacts (179 columns), the wide kernels"))):
+                                                                                            "16 contacts (179 columns), the wide kernels")),
+                        ("human36_and_3_balls_all_pairs", dict(model="human36_balls", objects=3, contacts=38, batch=512, dtype="f64", dt=5e-3,
+                                                               episode=40, states="standing", name="human36 beside three free balls with EVERY "
+                                                               "pair of get_all_contacts registered: 60 dofs, 38 contacts (10-15 active per step), "
+                                                               "the wide kernels' active-constraint slots"))):
             wide[key] = timed_leg(BatchedWorlds, torch, np, local_rank, c_, 0.4, seed=0, min_launches=3)
         res["wide_worlds"] = wide
         # human36 OUTSIDE the model class of the specialised headline kernels (round 4 review: what does a caller get whose
