@@ -199,13 +199,15 @@ def test_limits_of_the_wide_path():
         BatchedWorlds(m2)
 
 
-def test_object_api_simulates_a_wide_world():
-    """`simulate`'s loop body on a world of 66 dofs through the object API (World.update_dynamic / update_controllers /
-    update_constraints / integrate on the device, a batch of one): body Jacobians, the world matrices M, B, N, the impedance
-    and every step's state against the oracle (float64)."""
+@pytest.mark.parametrize("scene", ["objects4", "balls8"])
+def test_object_api_simulates_a_wide_world(scene):
+    """`simulate`'s loop body on a world of 66 dofs -- and on one of 90 dofs with the 108 contacts of every pair of
+    `get_all_contacts` -- through the object API (World.update_dynamic / update_controllers / update_constraints / integrate on
+    the device, a batch of one): body Jacobians, the world matrices M, B, N, the impedance and every step's state against the
+    oracle (float64)."""
     from arboris_python_amd import scenes
     from arboris_python_amd.flatten import flatten_world
-    w = scenes.human36_and_objects_world(4)
+    w = scenes.human36_and_objects_world(4) if scene == "objects4" else scenes.human36_and_balls_world(8)
     m, q, dq = flatten_world(w)
     dt = 5e-3
     w.update_dynamic()
