@@ -453,3 +453,17 @@ def test_design_register_table_is_generated_from_the_shipped_library():
         pytest.skip("llvm tools not installed")
     r = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_python_constants_mirror_the_header():
+    """Every `#define ARB_<NAME> <integer>` of include/arbstep.h that `_capi` repeats has the same value there (flags, status codes,
+    warning bits, limits): the ctypes layer cannot see the C preprocessor."""
+    import os
+    import re
+    from arboris_python_amd import _capi
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "arbstep.h")).read()
+    defs = {k: int(v.rstrip("uU"), 0) for k, v in re.findall(r"#define\s+(ARB_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+u?|\d+u?)\b", header)}
+    shared = [k for k in defs if hasattr(_capi, k)]
+    assert len(shared) >= 12 and {"ARB_WIDE_MAX", "ARB_WIDE_MAX_CONSTRAINTS", "ARB_WARN_ACTIVE_CONSTRAINTS", "ARB_ABI_VERSION"} <= set(shared)
+    for k in shared:
+        assert getattr(_capi, k) == defs[k], (k, getattr(_capi, k), defs[k])
