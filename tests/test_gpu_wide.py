@@ -521,3 +521,30 @@ def test_more_than_64_active_constraints_raise_a_warning():
         vy = tdq.cpu().numpy()[0].reshape(nballs, 6)[:, 4]          # (free joint twist: angular 0..2, linear 3..5; y is up)
         assert (np.abs(vy[:64]) < 1e-6).all() and (vy[64:] < -0.05).all()
         bw.close()
+
+
+def test_scratch_build_with_contacts_past_the_compact_range():
+    """human36 beside 26 free objects: 198 dofs, 30 contacts -- past the 192 dofs of the compact build: the system lives in the
+    scratch block, the constraint slots, sweeps and products are the shared code.  Eight steps against the oracle, float64."""
+    from arboris_python_amd import scenes
+    from arboris_python_amd.flatten import flatten_world
+    from arboris_python_amd.batch import BatchedWorlds
+    m, q0, dq0 = flatten_world(scenes.human36_and_objects_world(26))
+    assert m.ndof == 198 and m.nc == 30
+    bw = BatchedWorlds(m)
+    assert bw.info["wide"] == 1 and bw.plan(2, 1, dtype=torch.float64)["lds_bytes"] < 64 * 1024      # (no system in LDS or registers)
+    B, dt, T = 2, 5e-3, 8
+    q = np.tile(q0, (B, 1))
+    dq = np.tile(dq0, (B, 1)) + 0.05 * np.random.RandomState(3).standard_normal((B, m.ndof))
+    tq, tdq = bw.to_device(q, dq, torch.float64)
+    cf = bw.new_cforce(B, torch.float64)
+    oq, odq, ocf = q.copy(), dq.copy(), np.zeros((B, m.nc, 4))
+    worst = 0.
+    for k in range(T):
+        oq, odq, ocf = O.step(m, oq, odq, dt, cforce=ocf)
+        bw.step(tq, tdq, dt, 1, cforce=cf)
+        worst = max(worst, _rel(tq.cpu().numpy(), oq).max(), _rel(tdq.cpu().numpy(), odq).max())
+    print("human36 + 26 objects (198 dofs, 30 contacts), scratch build: %d steps, worst state error %.2e" % (T, worst))
+    assert worst < 1e-8 and np.abs(ocf).max() > 0
+    assert np.abs(cf.cpu().numpy() - ocf).max() <= 1e-6 * max(1., np.abs(ocf).max())
+    bw.close()
