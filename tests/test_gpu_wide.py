@@ -18,7 +18,7 @@ def _rel(a, b):
     return np.max(np.abs(a - b), axis=-1) / np.maximum(1., np.max(np.abs(b), axis=-1))
 
 
-@pytest.mark.parametrize("seed", list(range(1, 11)) + [1002, 1005, 1010])
+@pytest.mark.parametrize("seed", list(range(1, 25)) + [1002, 1003, 1005, 1006, 1009, 1010])
 def test_wide_random_trees_against_the_oracle(seed):
     """Random trees of 20-45 bodies and 65-200 dofs: every joint type, rotated frames on both sides of the joints, several
     roots, viscosity, spheres on a floor and on one another, a ball-and-socket loop closure, joint limits (the generator of
