@@ -1016,15 +1016,25 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     if (tid < nca) GGM[tid] = m2;
                     WAVE_SYNC();
                 }
-                // (lane c < nc: leads its group when it is the group's lowest constraint)
-                const unsigned long long grp = tid < nca ? GGM[tid] : 0ull;
-                const unsigned long long mine = (grp != 0ull && __builtin_ctzll(grp) == tid) ? grp : 0ull;
+            }
+            __syncthreads();
+            // Independent groups share nothing -- not the rows of v', not the forces, not the fixed-point test (a group whose sweep
+            // changed nothing would repeat itself bit for bit whatever the others do): the FOUR wavefronts take the groups in turn
+            // (group k of the step on wavefront k mod 4) and sweep them without a word to one another; one workgroup barrier at the
+            // end.  human36 beside four objects: the feet on one wavefront, the objects' contacts on the others.
+            {
+                const int wv = tid >> 6, ln = tid & (WAVE - 1);
+                // (lane c < nca: leads its group when it is the group's lowest slot; the groups are numbered by their leaders)
+                const unsigned long long grp = ln < nca ? GGM[ln] : 0ull;
+                const bool lead = grp != 0ull && __builtin_ctzll(grp) == ln;
+                const unsigned long long leaders = __ballot(lead);
+                const unsigned long long mine = (lead && (__popcll(leaders & ((1ull << ln) - 1ull)) & 3) == wv) ? grp : 0ull;
                 for (int sweep = 0; sweep < GS_SWEEPS; ++sweep) {
-                    if (tid == 0) DF[4] = 0.;                                    // "something changed in this sweep"
+                    if (ln == 0) DF[wv] = 0.;                                    // "something changed in this sweep (of this wavefront's groups)"
                     WAVE_SYNC();
                     unsigned long long rem = mine;
                     while (__any(rem != 0ull)) {
-                        if (tid < nca) GDF[6 * tid + 4] = -1.;                   // (no update from this group in this round)
+                        if (mine != 0ull) GDF[6 * ln + 4] = -1.;                 // (no update from this group in this round)
                         if (rem != 0ull) {
                             const int c = __builtin_ctzll(rem);
                             rem &= rem - 1;
@@ -1060,13 +1070,15 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                                 df[0] = nf - f[0]; f[0] = nf;
                             }
                             bool ch = false;
-                            for (int i = 0; i < 4; ++i) { GFF[4 * c + i] = f[i]; GDF[6 * tid + i] = df[i]; ch = ch || df[i] != 0. || !same_bits(f[i], f_old[i]); }
-                            GDF[6 * tid + 4] = (double)c;
-                            if (ch) DF[4] = 1.;
+                            for (int i = 0; i < 4; ++i) { GFF[4 * c + i] = f[i]; GDF[6 * ln + i] = df[i]; ch = ch || df[i] != 0. || !same_bits(f[i], f_old[i]); }
+                            GDF[6 * ln + 4] = (double)c;
+                            if (ch) DF[wv] = 1.;
                         }
                         WAVE_SYNC();
-                        for (int r = tid; r < nda; r += WAVE) {                   // vel += Y'[:, c] dforce   core.py:935
-                            const double *gd = GDF + 6 * __builtin_ctzll(GGM[r >> 2]);
+                        for (int r = ln; r < nda; r += WAVE) {                    // vel += Y'[:, c] dforce   core.py:935
+                            const int ld_ = __builtin_ctzll(GGM[r >> 2]);        // (the row's group; this wavefront's?)
+                            if ((__popcll(leaders & ((1ull << ld_) - 1ull)) & 3) != wv) continue;
+                            const double *gd = GDF + 6 * ld_;
                             const int c = (int)gd[4];
                             if (c < 0) continue;
                             const double *a = AM + r * ams + 4 * c;
@@ -1076,11 +1088,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void arb_wide_kernel(const WideModel 
                     }
                     // a sweep that changes no force and adds nothing to any velocity is a fixed point of the iteration: the
                     // remaining sweeps of core.py:929-935 would repeat it bit for bit
-                    if (DF[4] == 0.) break;
+                    if (DF[wv] == 0.) break;
                     WAVE_SYNC();
                 }
-                for (int r = tid; r < nda; r += WAVE) { VV[r] = GVV[r]; FF[4 * ORDL[r >> 2] + (r & 3)] = GFF[r]; }
             }
+            __syncthreads();
+            for (int r = tid; r < nda; r += WIDE_THREADS) { VV[r] = GVV[r]; FF[4 * ORDL[r >> 2] + (r & 3)] = GFF[r]; }
             __syncthreads();
         }
         if (io.inspect && io.stamps != nullptr && tid == 0) io.stamps[w * 8 + 7] = (long long)clock64();
